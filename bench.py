@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py - frames/sec of the 4-layer 2160p composite hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One step = one output frame of the headline pipeline (BASELINE.json / SURVEY.md 8d):
+4 x 2160p v210 layers -> unpack -> YCbCr->RGB (BT.709 matrix, gamma LUT, 709->2020 gamut) ->
+combine_4 -> RGB->YCbCr (BT.2020) -> v210 pack, executed by ONE fused HIP kernel through the
+C ABI (ph_fused_v210_combine).  Inputs are resident in HBM before the timed region; a ring of
+distinct frame sets (> 256 MiB in total) defeats the Infinity Cache.  Channels are independent
+(SURVEY.md 8e): with N GPUs every rank runs its own channel, no collective on the data path,
+scaling = weak, value = total frames/sec over all ranks.
+
+Prints ONE JSON line (rank 0).  The CPU baseline leg (rank 0, N = 1) times the oracle's
+restatement of the same pipeline on the host cores - a reported baseline, never the product.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WIDTH, HEIGHT, LAYERS = 3840, 2160, 4
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--ring", type=int, default=8, help="distinct frame sets cycled through (cache defeat)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--layers", type=int, default=LAYERS)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    return ap.parse_args()
+
+
+def synth_v210(torch, width, height, seed, device):
+    """Legal-range random v210 frame generated on the GPU (Y 64..940, C 64..960)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    groups = height * (width // 6)
+    y = torch.randint(64, 941, (groups, 6), generator=g, device=device, dtype=torch.int32)
+    cb = torch.randint(64, 961, (groups, 3), generator=g, device=device, dtype=torch.int32)
+    cr = torch.randint(64, 961, (groups, 3), generator=g, device=device, dtype=torch.int32)
+    w = torch.empty((groups, 4), dtype=torch.int32, device=device)
+    w[:, 0] = (cr[:, 0] << 20) | (y[:, 0] << 10) | cb[:, 0]
+    w[:, 1] = (y[:, 2] << 20) | (cb[:, 1] << 10) | y[:, 1]
+    w[:, 2] = (cb[:, 2] << 20) | (y[:, 3] << 10) | cr[:, 1]
+    w[:, 3] = (y[:, 5] << 20) | (cr[:, 2] << 10) | y[:, 4]
+    return w.reshape(-1).contiguous()
+
+
+def cpu_baseline(args, budget_s):
+    """The oracle's restatement of the same pipeline (read x4 -> combine_4 -> write) on the
+    host cores, on a bounded sample: whole 2160p frames until the budget is used."""
+    import numpy as np
+    import frames
+    from oracle import orc
+    w, h, n = args.width, args.height, args.layers
+    layers = [frames.v210_random(w, h, frames.layer_seed(0, i)) for i in range(n)]
+    rd = (orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
+    wr = (orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    scratch = np.empty((n + 1) * w * h * 4, np.float32)
+    orc.set_num_threads(0)
+    cores = orc.num_threads()
+    orc.pipeline_v210_combine(layers, w, h, *rd, *wr, scratch=scratch)  # warm-up (page faults)
+    t0 = time.perf_counter()
+    frames_done = 0
+    while True:
+        orc.pipeline_v210_combine(layers, w, h, *rd, *wr, scratch=scratch)
+        frames_done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or frames_done >= 200:
+            break
+    return {"value": round(frames_done / el, 3), "unit": "frames/sec", "cores": cores, "kind": "port",
+            "sample": "%d whole %dx%d %d-layer frames through oracle/ (OpenMP over lines, %d threads) in %.1f s"
+                      % (frames_done, w, h, n, cores, el)}
+
+
+def recorded_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("fused_v210_combine_4_2160p_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse()
+    import torch
+    from phaneron_amd import capi
+    import numpy as np
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libphaneron_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    w, h, n = args.width, args.height, args.layers
+    ctx = capi.Context(local_rank)
+    frame_words = capi.v210_pitch_bytes(w) * h // 4
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+    rd = [dev(capi.ycbcr2rgb_matrix("709")), dev(capi.gamma2linear_lut("709")),
+          dev(np.concatenate([capi.rgb2rgb_matrix("709", "2020"), np.zeros(3, np.float32)]))]
+    wr = [dev(capi.rgb2ycbcr_matrix("2020")), dev(capi.linear2gamma_lut("2020"))]
+    ring = []
+    for r in range(args.ring):
+        ins = [synth_v210(torch, w, h, 0x5EED0000 + 16 * (rank * 64 + r) + l, device) for l in range(n)]
+        ring.append((ins, torch.empty(frame_words, dtype=torch.int32, device=device)))
+    torch.cuda.synchronize()
+
+    stream = ctx.torch_stream(capi.QUEUE_PROCESS)
+
+    def step(i):
+        ins, out = ring[i % args.ring]
+        ctx.fused_v210_combine(ins, out, w, h, *rd, *wr)
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.wait()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    ev1.record(stream)
+    ctx.wait()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # average launch duration on the kernel's stream
+
+    if rank == 0:
+        fps = world * args.steps / elapsed
+        algo_bytes = (n + 1) * frame_words * 4  # each input byte once + each output byte once
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "frames/sec, 4-layer 2160p50 composite pipeline (v210 unpack->CSC->combine->CSC->v210 pack)",
+            "value": round(fps, 2), "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u10->f32->u10",
+            "data": "synthetic",
+            "config": {"workload": "headline: 1 channel per GPU, %d x %dx%d v210 layers -> fused unpack/CSC(709->2020)/"
+                                   "combine_%d/CSC/pack -> 1 v210 frame" % (n, w, h, n),
+                       "ring_frame_sets": args.ring, "channels": world, "realtime_target_fps": 50},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(),
+                         "kernel": "fused_v210_combine_kernel<%d>" % n, "algorithmic_bytes_per_launch": algo_bytes,
+                         "avg_launch_ms": round(kernel_ms, 5)},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+/* phaneron_hip.h - C ABI of libphaneron_hip.so: the MI355X (gfx950) replacement for the
+ * `nodencl` binding underneath phaneron's src/process operators and src/clJobQueue.ts.
+ *
+ * The reference reaches its OpenCL kernels only through the nodencl JS API (npm nodencl@1.4.2,
+ * not vendored).  Each entry point below replaces one piece of that surface and cites the
+ * reference call sites (paths relative to the reference checkout) that define its meaning.
+ * INTEGRATION.md shows the N-API stub that binds these for node (node/ph_napi.c is that stub).
+ *
+ * Conventions
+ *   - extern "C", opaque handles, plain pointers and sizes; no C++/torch types.
+ *   - every call returns 0 on success, a negative PH_E_* code otherwise; ph_last_error() gives
+ *     the message (the reference surfaces failures as rejected promises / thrown Error).
+ *   - one caller thread per context (the reference calls from the single node main thread);
+ *     work completes asynchronously on the context's three in-order HIP streams.
+ *   - device buffers are reference counted like nodencl's OpenCLBuffer (addRef/release).
+ *   - there is NO CPU fallback: without a HIP device ph_ctx_create fails.
+ */
+#ifndef PHANERON_HIP_H
+#define PHANERON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PH_ABI_VERSION 1
+
+enum {
+  PH_OK = 0,
+  PH_E_INVALID = -1,     /* bad argument / unknown kernel argument name */
+  PH_E_NO_DEVICE = -2,   /* no HIP device (there is no CPU path) */
+  PH_E_HIP = -3,         /* a HIP runtime call failed; see ph_last_error */
+  PH_E_UNKNOWN_KERNEL = -4,
+  PH_E_RANGE = -5        /* buffer too small for the geometry requested */
+};
+
+typedef struct ph_ctx ph_ctx;
+typedef struct ph_buf ph_buf;
+typedef struct ph_program ph_program;
+
+/* nodencl `clContext.queue.{load,process,unload}` (src/index.ts:94-108, io.ts:79-98,
+ * clJobQueue.ts:126,131): three in-order queues. */
+enum { PH_QUEUE_LOAD = 0, PH_QUEUE_PROCESS = 1, PH_QUEUE_UNLOAD = 2 };
+
+/* ---- context: `new clContext({platformIndex, deviceIndex, overlapping})` + `initialise()`
+ *      (src/index.ts:94-107) ------------------------------------------------------------------ */
+int ph_ctx_create(int device_index, ph_ctx **out);
+int ph_ctx_destroy(ph_ctx *ctx);
+/* `getPlatformInfo()` (src/index.ts:103-106): vendor / device name strings. */
+int ph_ctx_info(ph_ctx *ctx, char *vendor, size_t vendor_len, char *device, size_t device_len);
+/* message of the last failure on this thread (ctx may be NULL for ph_ctx_create failures). */
+const char *ph_last_error(ph_ctx *ctx);
+/* the hipStream_t behind a queue, for interop (tests wrap it as a torch external stream). */
+void *ph_ctx_stream(ph_ctx *ctx, int queue);
+/* `waitFinish(queue)` (clJobQueue.ts:131, io.ts callers): returns when the stream is idle. */
+int ph_wait_finish(ph_ctx *ctx, int queue);
+
+/* ---- buffers: `createBuffer(bytes, access, svmType, imageDims?, owner?)` (19 call sites, e.g.
+ *      io.ts:61-77,144-150, mixer.ts:196-205, combiner.ts:230-239, yadif.ts:76-86) -------------- */
+enum { PH_ACCESS_READONLY = 0, PH_ACCESS_WRITEONLY = 1, PH_ACCESS_READWRITE = 2 };
+enum { PH_SVM_NONE = 0, PH_SVM_COARSE = 1, PH_SVM_FINE = 2 };
+/* width/height > 0 mark the buffer as an RGBA f32 image (nodencl `ImageDims`): row-major,
+ * unpadded, 16 bytes per pixel.  Storage comes from a per-context pool (no hipMalloc per frame). */
+int ph_buf_create(ph_ctx *ctx, size_t bytes, int access, int svm_type, int width, int height,
+                  const char *owner, ph_buf **out);
+/* adopt device memory owned by the caller (e.g. a torch tensor); never freed by the library. */
+int ph_buf_wrap(ph_ctx *ctx, void *device_ptr, size_t bytes, int width, int height, ph_buf **out);
+int ph_buf_addref(ph_buf *buf);  /* OpenCLBuffer.addRef()  (loadSave.ts:102-106 ...) */
+int ph_buf_release(ph_buf *buf); /* OpenCLBuffer.release(): last release recycles the storage */
+int ph_buf_refcount(const ph_buf *buf);
+size_t ph_buf_bytes(const ph_buf *buf);
+void *ph_buf_device_ptr(ph_buf *buf);
+int ph_buf_dims(const ph_buf *buf, int *width, int *height);
+/* `buf.hostAccess(dir, queue, src?)` (io.ts:89-94,172; loadSave.ts:76-99; transform.ts:84-89):
+ *   WRITEONLY + src : copy `bytes` of host memory to the device on `queue` (async, pinned staging)
+ *   WRITEONLY, no src: expose the host mirror for the caller to fill (ph_buf_host_ptr)
+ *   NONE            : hand the (filled) host mirror back to the device
+ *   READONLY        : make the device contents visible in the host mirror (sync on return) */
+enum { PH_HOST_READONLY = 0, PH_HOST_WRITEONLY = 1, PH_HOST_NONE = 2 };
+int ph_buf_host_access(ph_buf *buf, int dir, int queue, const void *src, size_t bytes);
+void *ph_buf_host_ptr(ph_buf *buf); /* pinned host mirror (allocated on first use) */
+/* the `logBuffers()` debug hook (src/index.ts:184): live buffers / pooled bytes */
+int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes);
+
+/* ---- programs: `createProgram(kernelSrc, {name, globalWorkItems, workItemsPerGroup})`
+ *      (imageProcess.ts:69-72, packer.ts:97-103).  The OpenCL C text is NOT compiled: it (or a
+ *      "phaneron:<op>" tag) only selects a precompiled gfx950 kernel by kernel name + argument
+ *      list.  Names: read/write (v210), yadif, transform, resize, combine_N, transition_dissolve,
+ *      transition_wipe, mixer, wipe. ------------------------------------------------------------ */
+int ph_program_create(ph_ctx *ctx, const char *kernel_src, const char *name,
+                      const uint32_t *global_work_items, int n_dims,
+                      uint32_t work_items_per_group, ph_program **out);
+int ph_program_destroy(ph_program *prog);
+const char *ph_program_kernel(const ph_program *prog); /* resolved kernel id, e.g. "v210_read" */
+
+/* ---- `runProgram(program, params, queue)` (clJobQueue.ts:126): params keyed by the OpenCL
+ *      kernel ARGUMENT NAME (input, output, width, colMatrix, gammaLut, gamutMatrix, interlace,
+ *      prev, cur, next, parity, tff, skipSpatial, transformMatrix, scale, offsetX, offsetY, flip,
+ *      l<i>In, input0, input1, mix, wipe, maskIn) ------------------------------------------------- */
+enum { PH_ARG_BUF = 0, PH_ARG_U32 = 1, PH_ARG_I32 = 2, PH_ARG_F32 = 3 };
+typedef struct ph_arg {
+  const char *name;
+  int kind;
+  union {
+    ph_buf *buf;
+    uint32_t u32;
+    int32_t i32;
+    float f32;
+  } v;
+} ph_arg;
+/* nodencl `RunTimings` in microseconds (clJobQueue.ts:159-215 prints them) */
+typedef struct ph_run_timings {
+  uint32_t data_to_kernel;
+  uint32_t kernel_exec;
+  uint32_t total_time;
+} ph_run_timings;
+/* timings may be NULL (no events recorded, fully asynchronous).  With timings the call
+ * returns after the kernel has finished (hipEvent pair on the queue's stream). */
+int ph_run_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args, int queue,
+                   ph_run_timings *timings);
+
+/* ---- typed entry points: the same kernels on raw device pointers, launched on `queue`.
+ *      Images are row-major float RGBA (16 B/pixel); v210 is LE 32-bit words with line pitch
+ *      ph_v210_pitch_bytes(width).  Matrices / LUTs are DEVICE pointers (the reference passes
+ *      them as OpenCLBuffers, loadSave.ts:114-127). --------------------------------------------- */
+uint32_t ph_v210_pitch_bytes(uint32_t width); /* v210.ts:198-204 */
+/* v210.ts:25-111 */
+int ph_v210_read(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t width, uint32_t height,
+                 const void *col_matrix12, const void *gamma_lut, const void *gamut_matrix9);
+/* v210.ts:113-195; interlace 0 / 1 (top, even lines) / 3 (bottom, odd lines) (packer.ts:24-28) */
+int ph_v210_write(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t width,
+                  uint32_t height, uint32_t interlace, const void *col_matrix12,
+                  const void *gamma_lut);
+/* yadifCl.ts:105-167 */
+int ph_yadif(ph_ctx *ctx, int queue, const void *prev, const void *cur, const void *next, int width,
+             int height, int parity, int tff, int skip_spatial, void *out);
+/* transform.ts:36-59 (matrix9: device pointer to the 3x3 row-major matrix) */
+int ph_transform(ph_ctx *ctx, int queue, const void *in, int in_w, int in_h, const void *matrix9,
+                 void *out, int out_w, int out_h);
+/* resize.ts:35-59 (flip4: device pointer) */
+int ph_resize(ph_ctx *ctx, int queue, const void *in, int in_w, int in_h, float scale,
+              float offset_x, float offset_y, const void *flip4, void *out, int out_w, int out_h);
+/* combine.ts:24-68, 2 <= n <= 8 */
+int ph_combine(ph_ctx *ctx, int queue, int n, const void *const *layers, int width, int height,
+               void *out);
+/* transition.ts:60-65 / :66-74, mix.ts:30-45, wipe.ts:30-47 */
+int ph_transition_dissolve(ph_ctx *ctx, int queue, const void *in0, const void *in1, float mix,
+                           int width, int height, void *out);
+int ph_transition_wipe(ph_ctx *ctx, int queue, const void *in0, const void *in1, const void *mask,
+                       int width, int height, void *out);
+int ph_mixer(ph_ctx *ctx, int queue, const void *in0, const void *in1, float mix, int width,
+             int height, void *out);
+int ph_wipe(ph_ctx *ctx, int queue, const void *in0, const void *in1, float wipe, int width,
+            int height, void *out);
+
+/* ---- fused channel pipeline (no reference equivalent: it is the reference's job batch
+ *      [v210 read] x n -> combine_n -> v210 write executed as ONE kernel with the
+ *      f32 RGBA intermediates kept in registers).  Bit-identical to running the separate
+ *      kernels above.  1 <= n <= 8 (n == 1: combiner passthrough, combiner.ts:222-228).
+ *      All layers share one reader colourspec (matrices/LUT are device pointers). ------------- */
+int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *layers, void *out,
+                          uint32_t width, uint32_t height, const void *rd_col_matrix12,
+                          const void *rd_gamma_lut, const void *rd_gamut_matrix9,
+                          const void *wr_col_matrix12, const void *wr_gamma_lut);
+
+/* ---- host colour maths (src/process/colourMaths.ts, run by Loader/Saver constructors
+ *      loadSave.ts:50-63,139-149): outputs are HOST arrays the caller uploads. ------------------ */
+int ph_colour_gamma2linear_lut(const char *colspec, float *lut65536);     /* :130-149 */
+int ph_colour_linear2gamma_lut(const char *colspec, float *lut65536);     /* :151-169 */
+int ph_colour_ycbcr2rgb_matrix(const char *colspec, int num_bits, int luma_black, int luma_white,
+                               int chroma_range, float *m12);             /* :276-332 */
+int ph_colour_rgb2ycbcr_matrix(const char *colspec, int num_bits, int luma_black, int luma_white,
+                               int chroma_range, float *m12);             /* :334-390 */
+int ph_colour_rgb2rgb_matrix(const char *src_colspec, const char *dst_colspec, float *m9); /* :392 */
+/* transform.ts:119-171 */
+int ph_transform_matrix(int width, int height, int flip_h, int flip_v, double anchor_x,
+                        double anchor_y, double scale_x, double scale_y, double offset_x,
+                        double offset_y, double rotate, float *m9);
+
+int ph_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,60 @@
+"""Build libphaneron_hip.so (hand-written gfx950 kernels + the C ABI) in-tree with hipcc.
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the
+resulting .so travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libphaneron_hip.so")
+ARCH = "gfx950"
+
+SOURCES = ["ph_kernels.hip", "ph_api.cpp", "ph_colour.cpp"]
+HEADERS = ["ph_device.h", "ph_kernels.h", os.path.join("..", "..", "include", "phaneron_hip.h")]
+# -ffp-contract=off: every fused multiply-add in the kernels is explicit (parity with the
+# reference's OpenCL arithmetic); no fast-math anywhere.
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libphaneron_hip.so cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP source for gfx950 and link libphaneron_hip.so.  Returns its path."""
+    if not force and not _stale():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cc = hipcc()
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        cmd = [cc, "--offload-arch=" + ARCH, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + COMMON + list(extra_flags)
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,242 @@
+"""ctypes binding of libphaneron_hip.so (include/phaneron_hip.h).
+
+Device memory, streams and process groups are torch's job (plumbing); every pixel is
+computed by the library's HIP kernels.  Nothing here falls back to the CPU: a missing
+library or a failing call raises PhaneronError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libphaneron_hip.so")
+
+QUEUE_LOAD, QUEUE_PROCESS, QUEUE_UNLOAD = 0, 1, 2
+HOST_READONLY, HOST_WRITEONLY, HOST_NONE = 0, 1, 2
+ARG_BUF, ARG_U32, ARG_I32, ARG_F32 = 0, 1, 2, 3
+
+EXPORTS = [
+    "ph_abi_version", "ph_last_error", "ph_ctx_create", "ph_ctx_destroy", "ph_ctx_info", "ph_ctx_stream",
+    "ph_wait_finish", "ph_buf_create", "ph_buf_wrap", "ph_buf_addref", "ph_buf_release", "ph_buf_refcount",
+    "ph_buf_bytes", "ph_buf_device_ptr", "ph_buf_dims", "ph_buf_host_access", "ph_buf_host_ptr",
+    "ph_ctx_buffer_stats", "ph_program_create", "ph_program_destroy", "ph_program_kernel", "ph_run_program",
+    "ph_v210_pitch_bytes", "ph_v210_read", "ph_v210_write", "ph_yadif", "ph_transform", "ph_resize", "ph_combine",
+    "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
+    "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
+    "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
+]
+
+
+class PhaneronError(RuntimeError):
+    pass
+
+
+class _ArgVal(C.Union):
+    _fields_ = [("buf", C.c_void_p), ("u32", C.c_uint32), ("i32", C.c_int32), ("f32", C.c_float)]
+
+
+class PhArg(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("kind", C.c_int), ("v", _ArgVal)]
+
+
+class RunTimings(C.Structure):
+    _fields_ = [("data_to_kernel", C.c_uint32), ("kernel_exec", C.c_uint32), ("total_time", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built (python -m phaneron_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PhaneronError("%s is missing: build it with `python -m phaneron_amd.build` "
+                            "(there is no CPU fallback)" % LIB_PATH)
+    l = C.CDLL(LIB_PATH)
+    vp, ci, cu, cf, cd, cs = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_double, C.c_size_t
+    f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+    sig = {
+        "ph_abi_version": (ci, []),
+        "ph_last_error": (C.c_char_p, [vp]),
+        "ph_ctx_create": (ci, [ci, C.POINTER(vp)]),
+        "ph_ctx_destroy": (ci, [vp]),
+        "ph_ctx_info": (ci, [vp, C.c_char_p, cs, C.c_char_p, cs]),
+        "ph_ctx_stream": (vp, [vp, ci]),
+        "ph_wait_finish": (ci, [vp, ci]),
+        "ph_buf_create": (ci, [vp, cs, ci, ci, ci, ci, C.c_char_p, C.POINTER(vp)]),
+        "ph_buf_wrap": (ci, [vp, vp, cs, ci, ci, C.POINTER(vp)]),
+        "ph_buf_addref": (ci, [vp]),
+        "ph_buf_release": (ci, [vp]),
+        "ph_buf_refcount": (ci, [vp]),
+        "ph_buf_bytes": (cs, [vp]),
+        "ph_buf_device_ptr": (vp, [vp]),
+        "ph_buf_dims": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
+        "ph_buf_host_access": (ci, [vp, ci, ci, vp, cs]),
+        "ph_buf_host_ptr": (vp, [vp]),
+        "ph_ctx_buffer_stats": (ci, [vp, C.POINTER(cs), C.POINTER(cs), C.POINTER(cs)]),
+        "ph_program_create": (ci, [vp, C.c_char_p, C.c_char_p, C.POINTER(cu), ci, cu, C.POINTER(vp)]),
+        "ph_program_destroy": (ci, [vp]),
+        "ph_program_kernel": (C.c_char_p, [vp]),
+        "ph_run_program": (ci, [vp, vp, C.POINTER(PhArg), ci, ci, C.POINTER(RunTimings)]),
+        "ph_v210_pitch_bytes": (cu, [cu]),
+        "ph_v210_read": (ci, [vp, ci, vp, vp, cu, cu, vp, vp, vp]),
+        "ph_v210_write": (ci, [vp, ci, vp, vp, cu, cu, cu, vp, vp]),
+        "ph_yadif": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+        "ph_transform": (ci, [vp, ci, vp, ci, ci, vp, vp, ci, ci]),
+        "ph_resize": (ci, [vp, ci, vp, ci, ci, cf, cf, cf, vp, vp, ci, ci]),
+        "ph_combine": (ci, [vp, ci, ci, C.POINTER(vp), ci, ci, vp]),
+        "ph_transition_dissolve": (ci, [vp, ci, vp, vp, cf, ci, ci, vp]),
+        "ph_transition_wipe": (ci, [vp, ci, vp, vp, vp, ci, ci, vp]),
+        "ph_mixer": (ci, [vp, ci, vp, vp, cf, ci, ci, vp]),
+        "ph_wipe": (ci, [vp, ci, vp, vp, cf, ci, ci, vp]),
+        "ph_fused_v210_combine": (ci, [vp, ci, ci, C.POINTER(vp), vp, cu, cu, vp, vp, vp, vp, vp]),
+        "ph_colour_gamma2linear_lut": (ci, [C.c_char_p, f32p]),
+        "ph_colour_linear2gamma_lut": (ci, [C.c_char_p, f32p]),
+        "ph_colour_ycbcr2rgb_matrix": (ci, [C.c_char_p, ci, ci, ci, ci, f32p]),
+        "ph_colour_rgb2ycbcr_matrix": (ci, [C.c_char_p, ci, ci, ci, ci, f32p]),
+        "ph_colour_rgb2rgb_matrix": (ci, [C.c_char_p, C.c_char_p, f32p]),
+        "ph_transform_matrix": (ci, [ci, ci, ci, ci, cd, cd, cd, cd, cd, cd, cd, f32p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(l, name)  # AttributeError here = the header and the library disagree
+        fn.restype, fn.argtypes = res, args
+    _lib = l
+    return l
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = lib().ph_last_error(ctx)
+        raise PhaneronError("libphaneron_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+# ---- host colour maths (pure host code in the library; no device needed) ---------------------
+def gamma2linear_lut(colspec):
+    out = np.empty(65536, np.float32)
+    check(lib().ph_colour_gamma2linear_lut(colspec.encode(), out))
+    return out
+
+
+def linear2gamma_lut(colspec):
+    out = np.empty(65536, np.float32)
+    check(lib().ph_colour_linear2gamma_lut(colspec.encode(), out))
+    return out
+
+
+def ycbcr2rgb_matrix(colspec, num_bits=10, luma_black=64, luma_white=940, chroma_range=896):
+    out = np.empty(12, np.float32)
+    check(lib().ph_colour_ycbcr2rgb_matrix(colspec.encode(), num_bits, luma_black, luma_white, chroma_range, out))
+    return out
+
+
+def rgb2ycbcr_matrix(colspec, num_bits=10, luma_black=64, luma_white=940, chroma_range=896):
+    out = np.empty(12, np.float32)
+    check(lib().ph_colour_rgb2ycbcr_matrix(colspec.encode(), num_bits, luma_black, luma_white, chroma_range, out))
+    return out
+
+
+def rgb2rgb_matrix(src, dst):
+    out = np.empty(9, np.float32)
+    check(lib().ph_colour_rgb2rgb_matrix(src.encode(), dst.encode(), out))
+    return out
+
+
+def transform_matrix(width, height, flip_h=False, flip_v=False, anchor_x=0.0, anchor_y=0.0, scale_x=1.0,
+                     scale_y=1.0, offset_x=0.0, offset_y=0.0, rotate=0.0):
+    out = np.empty(9, np.float32)
+    check(lib().ph_transform_matrix(width, height, int(flip_h), int(flip_v), anchor_x, anchor_y, scale_x, scale_y,
+                                    offset_x, offset_y, rotate, out))
+    return out
+
+
+def v210_pitch_bytes(width):
+    return int(lib().ph_v210_pitch_bytes(width))
+
+
+# ---- device side ---------------------------------------------------------------------------------
+def _ptr(t):
+    """Device pointer of a torch CUDA tensor (or a raw int)."""
+    return C.c_void_p(t if isinstance(t, int) else t.data_ptr())
+
+
+class Context:
+    """One GPU: three in-order HIP streams (load / process / unload) and a buffer pool -
+    the nodencl `clContext` of the reference (src/index.ts:94-108)."""
+
+    def __init__(self, device_index=0):
+        h = C.c_void_p()
+        check(lib().ph_ctx_create(device_index, C.byref(h)))
+        self.h = h
+        self.device_index = device_index
+
+    def close(self):
+        if self.h:
+            lib().ph_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def info(self):
+        v, d = C.create_string_buffer(128), C.create_string_buffer(256)
+        check(lib().ph_ctx_info(self.h, v, 128, d, 256), self.h)
+        return v.value.decode(), d.value.decode()
+
+    def stream_ptr(self, queue=QUEUE_PROCESS):
+        return lib().ph_ctx_stream(self.h, queue)
+
+    def torch_stream(self, queue=QUEUE_PROCESS):
+        import torch
+        return torch.cuda.ExternalStream(self.stream_ptr(queue), device=torch.device("cuda", self.device_index))
+
+    def wait(self, queue=QUEUE_PROCESS):
+        check(lib().ph_wait_finish(self.h, queue), self.h)
+
+    # typed kernels on torch tensors / raw pointers ------------------------------------------------
+    def v210_read(self, src, dst, width, height, col_matrix, lut, gamut, queue=QUEUE_PROCESS):
+        check(lib().ph_v210_read(self.h, queue, _ptr(src), _ptr(dst), width, height, _ptr(col_matrix), _ptr(lut),
+                                 _ptr(gamut)), self.h)
+
+    def v210_write(self, src, dst, width, height, interlace, col_matrix, lut, queue=QUEUE_PROCESS):
+        check(lib().ph_v210_write(self.h, queue, _ptr(src), _ptr(dst), width, height, interlace, _ptr(col_matrix),
+                                  _ptr(lut)), self.h)
+
+    def yadif(self, prev, cur, nxt, dst, width, height, parity, tff, skip_spatial=False, queue=QUEUE_PROCESS):
+        check(lib().ph_yadif(self.h, queue, _ptr(prev), _ptr(cur), _ptr(nxt), width, height, int(parity), int(tff),
+                             int(skip_spatial), _ptr(dst)), self.h)
+
+    def transform(self, src, in_w, in_h, matrix, dst, out_w, out_h, queue=QUEUE_PROCESS):
+        check(lib().ph_transform(self.h, queue, _ptr(src), in_w, in_h, _ptr(matrix), _ptr(dst), out_w, out_h), self.h)
+
+    def resize(self, src, in_w, in_h, scale, offset_x, offset_y, flip, dst, out_w, out_h, queue=QUEUE_PROCESS):
+        check(lib().ph_resize(self.h, queue, _ptr(src), in_w, in_h, scale, offset_x, offset_y, _ptr(flip), _ptr(dst),
+                              out_w, out_h), self.h)
+
+    def combine(self, layers, dst, width, height, queue=QUEUE_PROCESS):
+        arr = (C.c_void_p * len(layers))(*[_ptr(l).value for l in layers])
+        check(lib().ph_combine(self.h, queue, len(layers), arr, width, height, _ptr(dst)), self.h)
+
+    def transition_dissolve(self, in0, in1, mix, dst, width, height, queue=QUEUE_PROCESS):
+        check(lib().ph_transition_dissolve(self.h, queue, _ptr(in0), _ptr(in1), mix, width, height, _ptr(dst)), self.h)
+
+    def transition_wipe(self, in0, in1, mask, dst, width, height, queue=QUEUE_PROCESS):
+        check(lib().ph_transition_wipe(self.h, queue, _ptr(in0), _ptr(in1), _ptr(mask), width, height, _ptr(dst)),
+              self.h)
+
+    def mixer(self, in0, in1, mix, dst, width, height, queue=QUEUE_PROCESS):
+        check(lib().ph_mixer(self.h, queue, _ptr(in0), _ptr(in1), mix, width, height, _ptr(dst)), self.h)
+
+    def wipe(self, in0, in1, wipe, dst, width, height, queue=QUEUE_PROCESS):
+        check(lib().ph_wipe(self.h, queue, _ptr(in0), _ptr(in1), wipe, width, height, _ptr(dst)), self.h)
+
+    def fused_v210_combine(self, layers, dst, width, height, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut,
+                           queue=QUEUE_PROCESS):
+        arr = (C.c_void_p * len(layers))(*[_ptr(l).value for l in layers])
+        check(lib().ph_fused_v210_combine(self.h, queue, len(layers), arr, _ptr(dst), width, height, _ptr(rd_cm),
+                                          _ptr(rd_lut), _ptr(rd_gm), _ptr(wr_cm), _ptr(wr_lut)), self.h)

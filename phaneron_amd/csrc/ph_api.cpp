@@ -1,0 +1,600 @@
+// ph_api.cpp - the C ABI of libphaneron_hip.so (include/phaneron_hip.h): context, ref-counted
+// pooled device buffers, program lookup by kernel name, named-argument dispatch (the nodencl
+// `runProgram` contract the reference's clJobQueue drives) and the typed entry points.
+//
+// No CPU path exists here: every entry point that does work needs a HIP device.
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/phaneron_hip.h"
+#include "ph_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define PH_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) return fail(PH_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+}  // namespace
+
+struct ph_ctx {
+  int device = 0;
+  hipStream_t streams[3] = {nullptr, nullptr, nullptr};
+  hipDeviceProp_t props;
+  std::multimap<size_t, void *> pool;  // free device blocks by exact size
+  size_t pooled_bytes = 0, live_buffers = 0, live_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct ph_buf {
+  ph_ctx *ctx;
+  void *dptr;
+  void *hptr;  // pinned host mirror, lazily allocated
+  size_t bytes;
+  int width, height;
+  int refs;
+  bool owned;
+  bool host_dirty;
+  std::string owner;
+};
+
+enum KernelId {
+  K_V210_READ,
+  K_V210_WRITE,
+  K_YADIF,
+  K_TRANSFORM,
+  K_RESIZE,
+  K_COMBINE,
+  K_DISSOLVE,
+  K_TWIPE,
+  K_MIXER,
+  K_WIPE
+};
+
+struct ph_program {
+  ph_ctx *ctx;
+  KernelId id;
+  int n_layers;  // combine_N
+  std::string kernel;
+  uint32_t global[2];
+  uint32_t local;
+};
+
+namespace {
+
+int set_device(ph_ctx *ctx) {
+  PH_HIP(hipSetDevice(ctx->device));
+  return PH_OK;
+}
+
+hipStream_t stream_of(ph_ctx *ctx, int queue) { return ctx->streams[(queue >= 0 && queue < 3) ? queue : PH_QUEUE_PROCESS]; }
+
+int pool_alloc(ph_ctx *ctx, size_t bytes, void **out) {
+  auto it = ctx->pool.find(bytes);
+  if (it != ctx->pool.end()) {
+    *out = it->second;
+    ctx->pool.erase(it);
+    ctx->pooled_bytes -= bytes;
+    return PH_OK;
+  }
+  PH_HIP(hipMalloc(out, bytes ? bytes : 1));
+  return PH_OK;
+}
+
+void pool_free(ph_ctx *ctx, size_t bytes, void *p) {
+  // Recycling is stream-safe because all kernels touching a buffer were enqueued (in order)
+  // before its last release, and the next user enqueues after it on the same in-order queues;
+  // cross-queue users call ph_wait_finish first, exactly as the reference does (io.ts, clJobQueue.ts:131).
+  ctx->pool.emplace(bytes, p);
+  ctx->pooled_bytes += bytes;
+}
+
+// Does the OpenCL C text define `__kernel void <name>(` with an argument called `arg`?
+bool src_kernel_has_arg(const char *src, const char *name, const char *arg) {
+  if (!src) return false;
+  std::string pat = std::string("void ") + name + "(";
+  const char *k = strstr(src, pat.c_str());
+  if (!k) return false;
+  const char *end = strchr(k, ')');
+  if (!end) return false;
+  std::string sig(k, end);
+  return sig.find(arg) != std::string::npos;
+}
+
+const ph_arg *find_arg(const ph_arg *args, int n, const char *name) {
+  for (int i = 0; i < n; ++i)
+    if (args[i].name && 0 == strcmp(args[i].name, name)) return &args[i];
+  return nullptr;
+}
+
+int need_buf(const ph_arg *args, int n, const char *name, size_t min_bytes, ph_buf **out) {
+  const ph_arg *a = find_arg(args, n, name);
+  if (!a || a->kind != PH_ARG_BUF || !a->v.buf) return fail(PH_E_INVALID, "kernel argument '%s' (buffer) missing", name);
+  if (a->v.buf->bytes < min_bytes)
+    return fail(PH_E_RANGE, "kernel argument '%s': buffer of %zu bytes, %zu needed", name, a->v.buf->bytes, min_bytes);
+  *out = a->v.buf;
+  return PH_OK;
+}
+
+int need_num(const ph_arg *args, int n, const char *name, double *out) {
+  const ph_arg *a = find_arg(args, n, name);
+  if (!a || a->kind == PH_ARG_BUF) return fail(PH_E_INVALID, "kernel argument '%s' (number) missing", name);
+  *out = a->kind == PH_ARG_F32 ? (double)a->v.f32 : a->kind == PH_ARG_I32 ? (double)a->v.i32 : (double)a->v.u32;
+  return PH_OK;
+}
+
+int need_image(ph_buf *b, const char *name, int *w, int *h) {
+  if (b->width <= 0 || b->height <= 0) return fail(PH_E_INVALID, "kernel argument '%s' is not an image buffer", name);
+  if (b->bytes < (size_t)b->width * b->height * 16) return fail(PH_E_RANGE, "image '%s' smaller than its dims", name);
+  *w = b->width;
+  *h = b->height;
+  return PH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ph_abi_version(void) { return PH_ABI_VERSION; }
+
+const char *ph_last_error(ph_ctx *) { return g_err.c_str(); }
+
+int ph_ctx_create(int device_index, ph_ctx **out) {
+  if (!out) return fail(PH_E_INVALID, "ph_ctx_create: out is NULL");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(PH_E_NO_DEVICE, "no HIP device available (%s); libphaneron_hip has no CPU path",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device_index < 0 || device_index >= count) return fail(PH_E_INVALID, "device index %d out of range (%d devices)", device_index, count);
+  ph_ctx *ctx = new ph_ctx();
+  ctx->device = device_index;
+  PH_HIP(hipSetDevice(device_index));
+  PH_HIP(hipGetDeviceProperties(&ctx->props, device_index));
+  for (int i = 0; i < 3; ++i) PH_HIP(hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking));
+  PH_HIP(hipEventCreate(&ctx->ev0));
+  PH_HIP(hipEventCreate(&ctx->ev1));
+  *out = ctx;
+  return PH_OK;
+}
+
+int ph_ctx_destroy(ph_ctx *ctx) {
+  if (!ctx) return PH_OK;
+  hipSetDevice(ctx->device);
+  for (int i = 0; i < 3; ++i)
+    if (ctx->streams[i]) {
+      hipStreamSynchronize(ctx->streams[i]);
+      hipStreamDestroy(ctx->streams[i]);
+    }
+  for (auto &kv : ctx->pool) hipFree(kv.second);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  delete ctx;
+  return PH_OK;
+}
+
+int ph_ctx_info(ph_ctx *ctx, char *vendor, size_t vlen, char *device, size_t dlen) {
+  if (!ctx) return fail(PH_E_INVALID, "ph_ctx_info: ctx is NULL");
+  if (vendor && vlen) snprintf(vendor, vlen, "Advanced Micro Devices, Inc.");
+  if (device && dlen) snprintf(device, dlen, "%s (%s)", ctx->props.name, ctx->props.gcnArchName);
+  return PH_OK;
+}
+
+void *ph_ctx_stream(ph_ctx *ctx, int queue) { return ctx ? (void *)stream_of(ctx, queue) : nullptr; }
+
+int ph_wait_finish(ph_ctx *ctx, int queue) {
+  if (!ctx) return fail(PH_E_INVALID, "ph_wait_finish: ctx is NULL");
+  PH_HIP(hipStreamSynchronize(stream_of(ctx, queue)));
+  return PH_OK;
+}
+
+// ---- buffers -------------------------------------------------------------------------------
+int ph_buf_create(ph_ctx *ctx, size_t bytes, int access, int svm_type, int width, int height, const char *owner,
+                  ph_buf **out) {
+  (void)access;
+  (void)svm_type;  // OpenCL SVM hints have no HIP counterpart: device memory + pinned mirror
+  if (!ctx || !out) return fail(PH_E_INVALID, "ph_buf_create: NULL argument");
+  if (width > 0 && height > 0 && bytes < (size_t)width * height * 16)
+    return fail(PH_E_RANGE, "ph_buf_create: %zu bytes cannot hold a %dx%d RGBA f32 image", bytes, width, height);
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  void *d = nullptr;
+  rc = pool_alloc(ctx, bytes, &d);
+  if (rc) return rc;
+  ph_buf *b = new ph_buf{ctx, d, nullptr, bytes, width > 0 ? width : 0, height > 0 ? height : 0, 1, true, false,
+                         owner ? owner : ""};
+  ctx->live_buffers++;
+  ctx->live_bytes += bytes;
+  *out = b;
+  return PH_OK;
+}
+
+int ph_buf_wrap(ph_ctx *ctx, void *device_ptr, size_t bytes, int width, int height, ph_buf **out) {
+  if (!ctx || !out || !device_ptr) return fail(PH_E_INVALID, "ph_buf_wrap: NULL argument");
+  *out = new ph_buf{ctx, device_ptr, nullptr, bytes, width > 0 ? width : 0, height > 0 ? height : 0, 1, false, false,
+                    "wrapped"};
+  ctx->live_buffers++;
+  return PH_OK;
+}
+
+int ph_buf_addref(ph_buf *b) {
+  if (!b) return fail(PH_E_INVALID, "ph_buf_addref: NULL buffer");
+  return ++b->refs, PH_OK;
+}
+
+int ph_buf_release(ph_buf *b) {
+  if (!b) return fail(PH_E_INVALID, "ph_buf_release: NULL buffer");
+  if (--b->refs > 0) return PH_OK;
+  ph_ctx *ctx = b->ctx;
+  hipSetDevice(ctx->device);
+  if (b->owned) {
+    pool_free(ctx, b->bytes, b->dptr);
+    ctx->live_bytes -= b->bytes;
+  }
+  if (b->hptr) hipHostFree(b->hptr);
+  ctx->live_buffers--;
+  delete b;
+  return PH_OK;
+}
+
+int ph_buf_refcount(const ph_buf *b) { return b ? b->refs : 0; }
+size_t ph_buf_bytes(const ph_buf *b) { return b ? b->bytes : 0; }
+void *ph_buf_device_ptr(ph_buf *b) { return b ? b->dptr : nullptr; }
+int ph_buf_dims(const ph_buf *b, int *w, int *h) {
+  if (!b) return fail(PH_E_INVALID, "ph_buf_dims: NULL buffer");
+  if (w) *w = b->width;
+  if (h) *h = b->height;
+  return PH_OK;
+}
+
+void *ph_buf_host_ptr(ph_buf *b) {
+  if (!b) return nullptr;
+  if (!b->hptr) {
+    hipSetDevice(b->ctx->device);
+    if (hipHostMalloc(&b->hptr, b->bytes ? b->bytes : 1, hipHostMallocDefault) != hipSuccess) {
+      fail(PH_E_HIP, "hipHostMalloc(%zu) failed", b->bytes);
+      b->hptr = nullptr;
+    }
+  }
+  return b->hptr;
+}
+
+int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t bytes) {
+  if (!b) return fail(PH_E_INVALID, "ph_buf_host_access: NULL buffer");
+  int rc = set_device(b->ctx);
+  if (rc) return rc;
+  hipStream_t s = stream_of(b->ctx, queue);
+  if (!ph_buf_host_ptr(b)) return PH_E_HIP;
+  switch (dir) {
+    case PH_HOST_WRITEONLY:
+      if (src) {
+        if (bytes > b->bytes) return fail(PH_E_RANGE, "hostAccess: %zu source bytes into a %zu byte buffer", bytes, b->bytes);
+        // previous async upload from the mirror must have drained before it is overwritten
+        PH_HIP(hipStreamSynchronize(s));
+        memcpy(b->hptr, src, bytes);
+        PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, bytes, hipMemcpyHostToDevice, s));
+        b->host_dirty = false;
+      } else {
+        b->host_dirty = true;  // caller fills the mirror, then calls hostAccess('none')
+      }
+      return PH_OK;
+    case PH_HOST_NONE:
+      if (b->host_dirty) {
+        PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, b->bytes, hipMemcpyHostToDevice, s));
+        b->host_dirty = false;
+      }
+      return PH_OK;
+    case PH_HOST_READONLY:
+      PH_HIP(hipMemcpyAsync(b->hptr, b->dptr, b->bytes, hipMemcpyDeviceToHost, s));
+      PH_HIP(hipStreamSynchronize(s));
+      return PH_OK;
+    default:
+      return fail(PH_E_INVALID, "hostAccess: unknown direction %d", dir);
+  }
+}
+
+int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes) {
+  if (!ctx) return fail(PH_E_INVALID, "ph_ctx_buffer_stats: ctx is NULL");
+  if (live_buffers) *live_buffers = ctx->live_buffers;
+  if (live_bytes) *live_bytes = ctx->live_bytes;
+  if (pooled_bytes) *pooled_bytes = ctx->pooled_bytes;
+  return PH_OK;
+}
+
+// ---- programs ---------------------------------------------------------------------------------
+int ph_program_create(ph_ctx *ctx, const char *src, const char *name, const uint32_t *gwi, int n_dims, uint32_t wipg,
+                      ph_program **out) {
+  if (!ctx || !name || !out) return fail(PH_E_INVALID, "ph_program_create: NULL argument");
+  ph_program p{ctx, K_V210_READ, 0, "", {0, 0}, wipg};
+  for (int i = 0; i < n_dims && i < 2; ++i) p.global[i] = gwi ? gwi[i] : 0;
+  const bool tagged = src && 0 == strncmp(src, "phaneron:", 9);
+  const char *tag = tagged ? src + 9 : "";
+  if (0 == strcmp(name, "read") || 0 == strcmp(name, "write")) {
+    // several pack formats name their kernels read/write; the argument list tells them apart
+    const bool is_read = name[0] == 'r';
+    const bool v210 = tagged ? 0 == strcmp(tag, "v210")
+                             : (src_kernel_has_arg(src, name, "uint4") && src_kernel_has_arg(src, name, "colMatrix") &&
+                                !src_kernel_has_arg(src, name, "inputY") && !src_kernel_has_arg(src, name, "outputY"));
+    if (!v210) return fail(PH_E_UNKNOWN_KERNEL, "no gfx950 kernel for pack format of '%s' (only v210 is built)", name);
+    p.id = is_read ? K_V210_READ : K_V210_WRITE;
+    p.kernel = is_read ? "v210_read" : "v210_write";
+  } else if (0 == strcmp(name, "yadif")) {
+    p.id = K_YADIF, p.kernel = "yadif";
+  } else if (0 == strcmp(name, "transform")) {
+    p.id = K_TRANSFORM, p.kernel = "transform";
+  } else if (0 == strcmp(name, "resize")) {
+    p.id = K_RESIZE, p.kernel = "resize";
+  } else if (0 == strncmp(name, "combine_", 8)) {
+    const int n = atoi(name + 8);
+    if (n < 2 || n > ph::kMaxLayers) return fail(PH_E_UNKNOWN_KERNEL, "combine_%d: 2..%d layers are built", n, ph::kMaxLayers);
+    p.id = K_COMBINE, p.n_layers = n, p.kernel = name;
+  } else if (0 == strcmp(name, "transition_dissolve")) {
+    p.id = K_DISSOLVE, p.kernel = name;
+  } else if (0 == strcmp(name, "transition_wipe")) {
+    p.id = K_TWIPE, p.kernel = name;
+  } else if (0 == strcmp(name, "mixer")) {
+    p.id = K_MIXER, p.kernel = name;
+  } else if (0 == strcmp(name, "wipe")) {
+    p.id = K_WIPE, p.kernel = name;
+  } else {
+    return fail(PH_E_UNKNOWN_KERNEL, "unknown kernel '%s'", name);
+  }
+  *out = new ph_program(p);
+  return PH_OK;
+}
+
+int ph_program_destroy(ph_program *p) {
+  delete p;
+  return PH_OK;
+}
+
+const char *ph_program_kernel(const ph_program *p) { return p ? p->kernel.c_str() : ""; }
+
+static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue) {
+  ph_buf *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr, *o = nullptr;
+  double num = 0;
+  int rc, w, h;
+#define TRY(x) \
+  if ((rc = (x)) != PH_OK) return rc
+  switch (prog->id) {
+    case K_V210_READ: {
+      TRY(need_num(args, n, "width", &num));
+      const uint32_t width = (uint32_t)num;
+      if (!prog->local || !width) return fail(PH_E_INVALID, "v210 read: width / workItemsPerGroup not set");
+      const uint32_t height = prog->global[0] / prog->local;  // Reader: global = wipg * height (v210.ts:293-294)
+      TRY(need_buf(args, n, "input", (size_t)ph_v210_pitch_bytes(width) * height, &a));
+      TRY(need_buf(args, n, "output", (size_t)width * height * 16, &o));
+      TRY(need_buf(args, n, "colMatrix", 48, &b));
+      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
+      TRY(need_buf(args, n, "gamutMatrix", 36, &d));
+      return ph_v210_read(ctx, queue, a->dptr, o->dptr, width, height, b->dptr, c->dptr, d->dptr);
+    }
+    case K_V210_WRITE: {
+      double il = 0;
+      TRY(need_num(args, n, "width", &num));
+      TRY(need_num(args, n, "interlace", &il));
+      const uint32_t width = (uint32_t)num, interlace = (uint32_t)il;
+      if (!prog->local || !width) return fail(PH_E_INVALID, "v210 write: width / workItemsPerGroup not set");
+      // Writer: global = wipg * height / (interlaced ? 2 : 1) (v210.ts:322-323)
+      const uint32_t height = prog->global[0] / prog->local * (interlace ? 2 : 1);
+      TRY(need_buf(args, n, "input", (size_t)width * height * 16, &a));
+      TRY(need_buf(args, n, "output", (size_t)ph_v210_pitch_bytes(width) * height, &o));
+      TRY(need_buf(args, n, "colMatrix", 48, &b));
+      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
+      return ph_v210_write(ctx, queue, a->dptr, o->dptr, width, height, interlace, b->dptr, c->dptr);
+    }
+    case K_YADIF: {
+      double parity, tff, skip;
+      TRY(need_buf(args, n, "output", 0, &o));
+      TRY(need_image(o, "output", &w, &h));
+      const size_t img = (size_t)w * h * 16;
+      TRY(need_buf(args, n, "prev", img, &a));
+      TRY(need_buf(args, n, "cur", img, &b));
+      TRY(need_buf(args, n, "next", img, &c));
+      TRY(need_num(args, n, "parity", &parity));
+      TRY(need_num(args, n, "tff", &tff));
+      TRY(need_num(args, n, "skipSpatial", &skip));
+      return ph_yadif(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, (int)parity, (int)tff, (int)skip, o->dptr);
+    }
+    case K_TRANSFORM: {
+      int iw, ih;
+      TRY(need_buf(args, n, "input", 0, &a));
+      TRY(need_image(a, "input", &iw, &ih));
+      TRY(need_buf(args, n, "output", 0, &o));
+      TRY(need_image(o, "output", &w, &h));
+      TRY(need_buf(args, n, "transformMatrix", 32, &b));
+      return ph_transform(ctx, queue, a->dptr, iw, ih, b->dptr, o->dptr, w, h);
+    }
+    case K_RESIZE: {
+      int iw, ih;
+      double scale, ox, oy;
+      TRY(need_buf(args, n, "input", 0, &a));
+      TRY(need_image(a, "input", &iw, &ih));
+      TRY(need_buf(args, n, "output", 0, &o));
+      TRY(need_image(o, "output", &w, &h));
+      TRY(need_buf(args, n, "flip", 16, &b));
+      TRY(need_num(args, n, "scale", &scale));
+      TRY(need_num(args, n, "offsetX", &ox));
+      TRY(need_num(args, n, "offsetY", &oy));
+      return ph_resize(ctx, queue, a->dptr, iw, ih, (float)scale, (float)ox, (float)oy, b->dptr, o->dptr, w, h);
+    }
+    case K_COMBINE: {
+      const void *layers[ph::kMaxLayers];
+      TRY(need_buf(args, n, "output", 0, &o));
+      TRY(need_image(o, "output", &w, &h));
+      for (int i = 0; i < prog->n_layers; ++i) {
+        char nm[16];
+        snprintf(nm, sizeof nm, "l%dIn", i);
+        TRY(need_buf(args, n, nm, (size_t)w * h * 16, &a));
+        layers[i] = a->dptr;
+      }
+      return ph_combine(ctx, queue, prog->n_layers, layers, w, h, o->dptr);
+    }
+    case K_DISSOLVE:
+    case K_MIXER:
+    case K_WIPE: {
+      TRY(need_buf(args, n, "output", 0, &o));
+      TRY(need_image(o, "output", &w, &h));
+      TRY(need_buf(args, n, "input0", (size_t)w * h * 16, &a));
+      TRY(need_buf(args, n, "input1", (size_t)w * h * 16, &b));
+      TRY(need_num(args, n, prog->id == K_WIPE ? "wipe" : "mix", &num));
+      if (prog->id == K_WIPE) return ph_wipe(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
+      if (prog->id == K_MIXER) return ph_mixer(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
+      return ph_transition_dissolve(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
+    }
+    case K_TWIPE: {
+      TRY(need_buf(args, n, "output", 0, &o));
+      TRY(need_image(o, "output", &w, &h));
+      TRY(need_buf(args, n, "input0", (size_t)w * h * 16, &a));
+      TRY(need_buf(args, n, "input1", (size_t)w * h * 16, &b));
+      TRY(need_buf(args, n, "maskIn", (size_t)w * h * 16, &c));
+      return ph_transition_wipe(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, o->dptr);
+    }
+  }
+#undef TRY
+  return fail(PH_E_UNKNOWN_KERNEL, "unhandled kernel id");
+}
+
+int ph_run_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args, int queue, ph_run_timings *t) {
+  if (!ctx || !prog || (n_args > 0 && !args)) return fail(PH_E_INVALID, "ph_run_program: NULL argument");
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  if (!t) return dispatch(ctx, prog, args, n_args, queue);
+  hipStream_t s = stream_of(ctx, queue);
+  const auto t0 = std::chrono::steady_clock::now();
+  PH_HIP(hipEventRecord(ctx->ev0, s));
+  rc = dispatch(ctx, prog, args, n_args, queue);
+  if (rc) return rc;
+  PH_HIP(hipEventRecord(ctx->ev1, s));
+  PH_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  PH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  const auto t1 = std::chrono::steady_clock::now();
+  t->data_to_kernel = 0;  // arguments are device-resident: nothing moves at launch
+  t->kernel_exec = (uint32_t)(ms * 1000.0f + 0.5f);
+  t->total_time = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+  return PH_OK;
+}
+
+// ---- typed entry points ------------------------------------------------------------------------
+uint32_t ph_v210_pitch_bytes(uint32_t width) { return width ? ph::v210_pitch_bytes(width) : 0; }
+
+#define PH_LAUNCH(expr)                                                                         \
+  do {                                                                                          \
+    if (!ctx) return fail(PH_E_INVALID, "%s: ctx is NULL", __func__);                           \
+    int rc_ = set_device(ctx);                                                                  \
+    if (rc_) return rc_;                                                                        \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(PH_E_HIP, "%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+    return PH_OK;                                                                               \
+  } while (0)
+
+int ph_v210_read(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t width, uint32_t height, const void *cm,
+                 const void *lut, const void *gm) {
+  if (!in || !out || !cm || !lut || !gm || !width) return fail(PH_E_INVALID, "ph_v210_read: NULL/zero argument");
+  if (!height) return PH_OK;
+  PH_LAUNCH(ph::launch_v210_read(stream_of(ctx, queue), in, out, width, height, cm, lut, gm));
+}
+
+int ph_v210_write(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t width, uint32_t height,
+                  uint32_t interlace, const void *cm, const void *lut) {
+  if (!in || !out || !cm || !lut || !width) return fail(PH_E_INVALID, "ph_v210_write: NULL/zero argument");
+  if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_v210_write: interlace must be 0, 1 or 3");
+  if (!height) return PH_OK;
+  PH_LAUNCH(ph::launch_v210_write(stream_of(ctx, queue), in, out, width, height, interlace, cm, lut));
+}
+
+int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *layers, void *out, uint32_t width,
+                          uint32_t height, const void *rd_cm, const void *rd_lut, const void *rd_gm,
+                          const void *wr_cm, const void *wr_lut) {
+  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_fused_v210_combine: 1..%d layers", ph::kMaxLayers);
+  if (!layers || !out || !rd_cm || !rd_lut || !rd_gm || !wr_cm || !wr_lut || !width)
+    return fail(PH_E_INVALID, "ph_fused_v210_combine: NULL/zero argument");
+  if (width % 48) return fail(PH_E_INVALID, "ph_fused_v210_combine: width %u is not a multiple of 48; run the separate kernels", width);
+  if (!height) return PH_OK;
+  ph::FusedArgs a{};
+  for (int i = 0; i < n; ++i) {
+    if (!layers[i]) return fail(PH_E_INVALID, "ph_fused_v210_combine: layer %d is NULL", i);
+    a.layers[i] = layers[i];
+  }
+  a.out = out;
+  a.quads_per_line_used = width / 6;
+  a.quads_per_line_pitch = ph::v210_pitch_bytes(width) / 16;
+  a.total_quads = a.quads_per_line_used * height;
+  a.rd_cm = (const float *)rd_cm, a.rd_lut = (const float *)rd_lut, a.rd_gm = (const float *)rd_gm;
+  a.wr_cm = (const float *)wr_cm, a.wr_lut = (const float *)wr_lut;
+  PH_LAUNCH(ph::launch_fused_v210_combine(stream_of(ctx, queue), n, a));
+}
+
+int ph_yadif(ph_ctx *ctx, int queue, const void *prev, const void *cur, const void *next, int w, int h, int parity,
+             int tff, int skip, void *out) {
+  if (!prev || !cur || !next || !out || w <= 0 || h <= 0) return fail(PH_E_INVALID, "ph_yadif: NULL/zero argument");
+  PH_LAUNCH(ph::launch_yadif(stream_of(ctx, queue), prev, cur, next, w, h, parity, tff ? 1 : 0, skip ? 1 : 0, out));
+}
+
+int ph_transform(ph_ctx *ctx, int queue, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh) {
+  if (!in || !m9 || !out || iw <= 0 || ih <= 0 || ow <= 0 || oh <= 0) return fail(PH_E_INVALID, "ph_transform: NULL/zero argument");
+  PH_LAUNCH(ph::launch_transform(stream_of(ctx, queue), in, iw, ih, m9, out, ow, oh));
+}
+
+int ph_resize(ph_ctx *ctx, int queue, const void *in, int iw, int ih, float scale, float ox, float oy,
+              const void *flip4, void *out, int ow, int oh) {
+  if (!in || !flip4 || !out || iw <= 0 || ih <= 0 || ow <= 0 || oh <= 0) return fail(PH_E_INVALID, "ph_resize: NULL/zero argument");
+  PH_LAUNCH(ph::launch_resize(stream_of(ctx, queue), in, iw, ih, scale, ox, oy, flip4, out, ow, oh));
+}
+
+int ph_combine(ph_ctx *ctx, int queue, int n, const void *const *layers, int w, int h, void *out) {
+  // the reference's Combine throws below 2 inputs (combine.ts:92-93)
+  if (n < 2 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "Combine requires between 2 and %d input buffers, got %d", ph::kMaxLayers, n);
+  if (!layers || !out || w <= 0 || h <= 0) return fail(PH_E_INVALID, "ph_combine: NULL/zero argument");
+  ph::CombineArgs a{};
+  for (int i = 0; i < n; ++i) {
+    if (!layers[i]) return fail(PH_E_INVALID, "ph_combine: layer %d is NULL", i);
+    a.layers[i] = layers[i];
+  }
+  a.out = out;
+  a.npx = (size_t)w * h;
+  PH_LAUNCH(ph::launch_combine(stream_of(ctx, queue), n, a));
+}
+
+int ph_transition_dissolve(ph_ctx *ctx, int queue, const void *in0, const void *in1, float mix, int w, int h, void *out) {
+  if (!in0 || !in1 || !out || w <= 0 || h <= 0) return fail(PH_E_INVALID, "ph_transition_dissolve: NULL/zero argument");
+  PH_LAUNCH(ph::launch_dissolve(stream_of(ctx, queue), in0, in1, mix, w, h, out));
+}
+
+int ph_mixer(ph_ctx *ctx, int queue, const void *in0, const void *in1, float mix, int w, int h, void *out) {
+  if (!in0 || !in1 || !out || w <= 0 || h <= 0) return fail(PH_E_INVALID, "ph_mixer: NULL/zero argument");
+  PH_LAUNCH(ph::launch_dissolve(stream_of(ctx, queue), in0, in1, mix, w, h, out));  // same arithmetic (mix.ts:41-42)
+}
+
+int ph_transition_wipe(ph_ctx *ctx, int queue, const void *in0, const void *in1, const void *mask, int w, int h,
+                       void *out) {
+  if (!in0 || !in1 || !mask || !out || w <= 0 || h <= 0) return fail(PH_E_INVALID, "ph_transition_wipe: NULL/zero argument");
+  PH_LAUNCH(ph::launch_twipe(stream_of(ctx, queue), in0, in1, mask, w, h, out));
+}
+
+int ph_wipe(ph_ctx *ctx, int queue, const void *in0, const void *in1, float wipe, int w, int h, void *out) {
+  if (!in0 || !in1 || !out || w <= 0 || h <= 0) return fail(PH_E_INVALID, "ph_wipe: NULL/zero argument");
+  PH_LAUNCH(ph::launch_wipe(stream_of(ctx, queue), in0, in1, wipe, w, h, out));
+}
+
+}  // extern "C"

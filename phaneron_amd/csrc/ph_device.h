@@ -1,0 +1,133 @@
+// ph_device.h - device-side arithmetic shared by every kernel (gfx950 only).
+//
+// Parity rules (SURVEY.md 7 "hard parts"): the reference's OpenCL C runs on AMD's device
+// library, where dot(float4) = fma(a3,b3, fma(a2,b2, fma(a1,b1, a0*b0))), dot(float3) the
+// 3-term analogue, and convert_ushort_sat_rte = rint -> max 0 -> min 65535 -> fptoui.  A
+// one-bit difference before a LUT index picks a different LUT entry, so these chains are
+// spelled out with explicit fused ops and contraction is off for everything else.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace ph {
+
+__device__ __forceinline__ float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+__device__ __forceinline__ float dot4(float a0, float a1, float a2, float a3, const float4 m) {
+  return fma_rn(a3, m.w, fma_rn(a2, m.z, fma_rn(a1, m.y, a0 * m.x)));
+}
+__device__ __forceinline__ float dot3(float a0, float a1, float a2, float m0, float m1, float m2) {
+  return fma_rn(a2, m2, fma_rn(a1, m1, a0 * m0));
+}
+
+// convert_ushort_sat_rte: v_rndne_f32, v_max (NaN -> 0), v_min, v_cvt_u32_f32
+__device__ __forceinline__ uint32_t sat_u16_rte(float x) {
+  x = __builtin_rintf(x);
+  x = __builtin_fmaxf(x, 0.0f);
+  x = __builtin_fminf(x, 65535.0f);
+  return (uint32_t)x;
+}
+// convert_ushort_sat / _rtz: truncating
+__device__ __forceinline__ uint32_t sat_u16_trunc(float x) {
+  x = __builtin_fmaxf(x, 0.0f);
+  x = __builtin_fminf(x, 65535.0f);
+  return (uint32_t)x;
+}
+
+// Reader-side constants (v210.ts:42-52): 3x4 YCbCr->RGB matrix, 3x3 gamut matrix.
+struct ReadK {
+  float4 r, g, b;
+  float gm[9];
+};
+__device__ __forceinline__ ReadK load_read_k(const float *__restrict__ cm, const float *__restrict__ gm) {
+  ReadK k;
+  k.r = make_float4(cm[0], cm[1], cm[2], cm[3]);
+  k.g = make_float4(cm[4], cm[5], cm[6], cm[7]);
+  k.b = make_float4(cm[8], cm[9], cm[10], cm[11]);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k.gm[i] = gm[i];
+  return k;
+}
+// Writer-side constants (v210.ts:138-140): 3x4 RGB->YCbCr matrix.
+struct WriteK {
+  float4 y, u, v;
+};
+__device__ __forceinline__ WriteK load_write_k(const float *__restrict__ cm) {
+  WriteK k;
+  k.y = make_float4(cm[0], cm[1], cm[2], cm[3]);
+  k.u = make_float4(cm[4], cm[5], cm[6], cm[7]);
+  k.v = make_float4(cm[8], cm[9], cm[10], cm[11]);
+  return k;
+}
+
+// One pixel of the v210 read kernel (v210.ts:65-78; tail :96-109 passes last = 0).
+__device__ __forceinline__ float4 read_px(float y, float cb, float cr, float last, const ReadK &k,
+                                          const float *__restrict__ lut) {
+  const float r = lut[sat_u16_rte(dot4(y, cb, cr, last, k.r) * 65535.0f)];
+  const float g = lut[sat_u16_rte(dot4(y, cb, cr, last, k.g) * 65535.0f)];
+  const float b = lut[sat_u16_rte(dot4(y, cb, cr, last, k.b) * 65535.0f)];
+  return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
+                     dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
+}
+
+// The six (Y,Cb,Cr) triples of a v210 word quad (v210.ts:58-63).
+struct Yuv6 {
+  float y[6], cb[3], cr[3];
+};
+__device__ __forceinline__ Yuv6 unpack_quad(const uint4 w) {
+  Yuv6 q;
+  q.cb[0] = (float)(w.x & 0x3ff), q.y[0] = (float)((w.x >> 10) & 0x3ff), q.cr[0] = (float)((w.x >> 20) & 0x3ff);
+  q.y[1] = (float)(w.y & 0x3ff), q.cb[1] = (float)((w.y >> 10) & 0x3ff), q.y[2] = (float)((w.y >> 20) & 0x3ff);
+  q.cr[1] = (float)(w.z & 0x3ff), q.y[3] = (float)((w.z >> 10) & 0x3ff), q.cb[2] = (float)((w.z >> 20) & 0x3ff);
+  q.y[4] = (float)(w.w & 0x3ff), q.cr[2] = (float)((w.w >> 10) & 0x3ff), q.y[5] = (float)((w.w >> 20) & 0x3ff);
+  return q;
+}
+
+// One pixel of the v210 write kernel (v210.ts:145-156): linear RGB -> gamma LUT -> code values.
+struct Yuv1 {
+  uint32_t y, u, v;
+};
+__device__ __forceinline__ Yuv1 write_px(float r, float g, float b, const WriteK &k,
+                                         const float *__restrict__ lut) {
+  const float gr = lut[sat_u16_rte(r * 65535.0f)];
+  const float gg = lut[sat_u16_rte(g * 65535.0f)];
+  const float gb = lut[sat_u16_rte(b * 65535.0f)];
+  Yuv1 o;
+  o.y = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
+  o.u = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.u));
+  o.v = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.v));
+  return o;
+}
+// luma only: odd pixels contribute no chroma to the packed words (v210.ts:159-162)
+__device__ __forceinline__ uint32_t write_px_luma(float r, float g, float b, const WriteK &k,
+                                                  const float *__restrict__ lut) {
+  const float gr = lut[sat_u16_rte(r * 65535.0f)];
+  const float gg = lut[sat_u16_rte(g * 65535.0f)];
+  const float gb = lut[sat_u16_rte(b * 65535.0f)];
+  return sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
+}
+// tail variant (v210.ts:173-184): truncating LUT index, round-half-away outputs
+__device__ __forceinline__ Yuv1 write_px_tail(float r, float g, float b, const WriteK &k,
+                                              const float *__restrict__ lut) {
+  const float gr = lut[sat_u16_trunc(r * 65535.0f)];
+  const float gg = lut[sat_u16_trunc(g * 65535.0f)];
+  const float gb = lut[sat_u16_trunc(b * 65535.0f)];
+  Yuv1 o;
+  o.y = sat_u16_trunc(__builtin_roundf(dot4(gr, gg, gb, 1.0f, k.y)));
+  o.u = sat_u16_trunc(__builtin_roundf(dot4(gr, gg, gb, 1.0f, k.u)));
+  o.v = sat_u16_trunc(__builtin_roundf(dot4(gr, gg, gb, 1.0f, k.v)));
+  return o;
+}
+
+__device__ __forceinline__ uint4 pack_quad(const uint32_t y[6], const uint32_t u[3], const uint32_t v[3]) {
+  uint4 w;  // v210.ts:159-162 (16-bit fields shifted in 32-bit registers, as the reference)
+  w.x = v[0] << 20 | y[0] << 10 | u[0];
+  w.y = y[2] << 20 | u[1] << 10 | y[1];
+  w.z = u[2] << 20 | y[3] << 10 | v[1];
+  w.w = y[5] << 20 | v[2] << 10 | y[4];
+  return w;
+}
+
+}  // namespace ph

@@ -1,0 +1,43 @@
+// ph_kernels.h - host-visible launchers of the gfx950 kernels (ph_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ph {
+
+constexpr int kMaxLayers = 8;
+
+struct FusedArgs {
+  const void *layers[kMaxLayers];
+  void *out;
+  uint32_t quads_per_line_used;   // width / 6
+  uint32_t quads_per_line_pitch;  // pitch bytes / 16
+  uint32_t total_quads;           // quads_per_line_used * height
+  const float *rd_cm, *rd_lut, *rd_gm, *wr_cm, *wr_lut;
+};
+
+struct CombineArgs {
+  const void *layers[kMaxLayers];
+  void *out;
+  size_t npx;
+};
+
+uint32_t v210_pitch_bytes(uint32_t width);
+
+hipError_t launch_v210_read(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
+                            const void *cm, const void *lut, const void *gm);
+hipError_t launch_v210_write(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
+                             uint32_t interlace, const void *cm, const void *lut);
+hipError_t launch_fused_v210_combine(hipStream_t s, int n, const FusedArgs &a);
+hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int parity,
+                        int tff, int skip, void *out);
+hipError_t launch_transform(hipStream_t s, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh);
+hipError_t launch_resize(hipStream_t s, const void *in, int iw, int ih, float scale, float ox, float oy,
+                         const void *flip4, void *out, int ow, int oh);
+hipError_t launch_combine(hipStream_t s, int n, const CombineArgs &a);
+hipError_t launch_dissolve(hipStream_t s, const void *in0, const void *in1, float mix, int w, int h, void *out);
+hipError_t launch_twipe(hipStream_t s, const void *in0, const void *in1, const void *mask, int w, int h, void *out);
+hipError_t launch_wipe(hipStream_t s, const void *in0, const void *in1, float wipe, int w, int h, void *out);
+
+}  // namespace ph

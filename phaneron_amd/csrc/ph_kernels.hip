@@ -1,0 +1,516 @@
+// ph_kernels.hip - hand-written gfx950 kernels for the phaneron per-pixel hot path.
+//
+// Layouts: v210 = little-endian 32-bit words, 4 words (16 B) per 6 pixels, line pitch
+// ceil(width/48)*128 B; images = row-major float4 RGBA, unpadded.  One lane owns one v210
+// word quad (16-byte coalesced load/store); the 6 float4 pixels that go with it are moved
+// between "quad order" and "pixel order" through LDS so the f32 side is also accessed as
+// contiguous 1 KiB wave transactions.
+#include "ph_device.h"
+#include "ph_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace ph {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------------------
+// v210 read (reference v210.ts:25-111)
+// ------------------------------------------------------------------------------------------
+// Fast path, width % 6 == 0: quads are numbered flat over the frame (f = line*qpl_used + g),
+// the float4 output of quad f starts at pixel 6f, so a wave's 64 quads produce 384 contiguous
+// pixels = six 1 KiB stores after the LDS transpose.
+__global__ __launch_bounds__(kBlock) void v210_read_kernel(const uint4 *__restrict__ in,
+                                                           float4 *__restrict__ out, uint32_t quads_per_line_used,
+                                                           uint32_t quads_per_line_pitch, uint32_t total_quads,
+                                                           const float *__restrict__ cm, const float *__restrict__ lut,
+                                                           const float *__restrict__ gm) {
+  __shared__ float4 tile[kBlock / kWave][kWave * 6];
+  const ReadK k = load_read_k(cm, gm);
+  const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const uint32_t f = blockIdx.x * kBlock + threadIdx.x;
+  if (f < total_quads) {
+    const uint32_t line = f / quads_per_line_used, g = f - line * quads_per_line_used;
+    const Yuv6 q = unpack_quad(in[(size_t)line * quads_per_line_pitch + g]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) tile[wave][6 * lane + j] = read_px(q.y[j], q.cb[j >> 1], q.cr[j >> 1], 1.0f, k, lut);
+  }
+  __syncthreads();
+  const uint32_t wave_f0 = blockIdx.x * kBlock + wave * kWave;  // first quad of this wave
+  const size_t px0 = (size_t)wave_f0 * 6, px_end = (size_t)total_quads * 6;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const size_t p = px0 + s * kWave + lane;
+    if (p < px_end) out[p] = tile[wave][s * kWave + lane];
+  }
+}
+
+// General path (any width): one lane per quad slot of the line, including the reference's
+// tail quirk for width % 6 != 0 (4th vector component 0, v210.ts:84-110).
+__global__ __launch_bounds__(kBlock) void v210_read_tail_kernel(const uint4 *__restrict__ in,
+                                                                float4 *__restrict__ out, uint32_t width,
+                                                                uint32_t height, uint32_t quads_per_line_pitch,
+                                                                const float *__restrict__ cm,
+                                                                const float *__restrict__ lut,
+                                                                const float *__restrict__ gm) {
+  const ReadK k = load_read_k(cm, gm);
+  const uint32_t full = width / 6, remain = width % 6, slots = full + (remain ? 1 : 0);
+  const uint32_t f = blockIdx.x * kBlock + threadIdx.x;
+  if (f >= slots * height) return;
+  const uint32_t line = f / slots, g = f - line * slots;
+  const Yuv6 q = unpack_quad(in[(size_t)line * quads_per_line_pitch + g]);
+  float4 *o = out + (size_t)line * width + 6 * g;
+  if (g < full) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) o[j] = read_px(q.y[j], q.cb[j >> 1], q.cr[j >> 1], 1.0f, k, lut);
+  } else {
+    for (uint32_t j = 0; j < remain && j < 4; ++j) o[j] = read_px(q.y[j], q.cb[j >> 1], q.cr[j >> 1], 0.0f, k, lut);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// v210 write (reference v210.ts:113-195)
+// ------------------------------------------------------------------------------------------
+// width % 6 == 0.  `lines` output lines are produced: line = first + idx*step (interlace).
+// Within a line the six float4 loads per wave are contiguous 1 KiB reads; LDS turns them
+// into quad order.  Lines are addressed by pitch (see DESIGN.md "deviations").
+__global__ __launch_bounds__(kBlock) void v210_write_kernel(const float4 *__restrict__ in, uint4 *__restrict__ out,
+                                                            uint32_t width, uint32_t quads_per_line_used,
+                                                            uint32_t quads_per_line_pitch, uint32_t first_line,
+                                                            uint32_t line_step, uint32_t blocks_per_line,
+                                                            const float *__restrict__ cm,
+                                                            const float *__restrict__ lut) {
+  __shared__ float4 tile[kBlock / kWave][kWave * 6];
+  const WriteK k = load_write_k(cm);
+  const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const uint32_t line_idx = blockIdx.x / blocks_per_line, blk = blockIdx.x - line_idx * blocks_per_line;
+  const uint32_t line = first_line + line_idx * line_step;
+  const uint32_t g0 = blk * kBlock + wave * kWave;  // first quad of this wave in the line
+  const float4 *src = in + (size_t)line * width;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const uint32_t p = g0 * 6 + s * kWave + lane;
+    if (p < width) tile[wave][s * kWave + lane] = src[p];
+  }
+  __syncthreads();
+  const uint32_t g = g0 + lane;
+  if (g >= quads_per_line_used) return;
+  uint32_t y[6], u[3], v[3];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float4 px = tile[wave][6 * lane + j];
+    if ((j & 1) == 0) {
+      const Yuv1 c = write_px(px.x, px.y, px.z, k, lut);
+      y[j] = c.y, u[j >> 1] = c.u, v[j >> 1] = c.v;
+    } else {
+      y[j] = write_px_luma(px.x, px.y, px.z, k, lut);
+    }
+  }
+  out[(size_t)line * quads_per_line_pitch + g] = pack_quad(y, u, v);
+}
+
+// Any width: one lane per quad slot; implements the tail (remain = width % 6 pixels with the
+// reference's truncating / round-half-away arithmetic) and zero-fills the rest of the last
+// 128-byte block of the line (v210.ts:131-136).
+__global__ __launch_bounds__(kBlock) void v210_write_tail_kernel(const float4 *__restrict__ in,
+                                                                 uint4 *__restrict__ out, uint32_t width,
+                                                                 uint32_t lines, uint32_t quads_per_line_pitch,
+                                                                 uint32_t first_line, uint32_t line_step,
+                                                                 const float *__restrict__ cm,
+                                                                 const float *__restrict__ lut) {
+  const WriteK k = load_write_k(cm);
+  const uint32_t f = blockIdx.x * kBlock + threadIdx.x;
+  if (f >= quads_per_line_pitch * lines) return;
+  const uint32_t line_idx = f / quads_per_line_pitch, g = f - line_idx * quads_per_line_pitch;
+  const uint32_t line = first_line + line_idx * line_step;
+  const uint32_t full = width / 6, remain = width % 6;
+  const float4 *px = in + (size_t)line * width + 6 * g;
+  uint4 w = make_uint4(0, 0, 0, 0);
+  if (g < full) {
+    uint32_t y[6], u[3], v[3];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float4 p = px[j];
+      const Yuv1 c = write_px(p.x, p.y, p.z, k, lut);
+      y[j] = c.y;
+      if ((j & 1) == 0) u[j >> 1] = c.u, v[j >> 1] = c.v;
+    }
+    w = pack_quad(y, u, v);
+  } else if (g == full && remain) {
+    Yuv1 c[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (uint32_t j = 0; j < remain && j < 4; ++j) c[j] = write_px_tail(px[j].x, px[j].y, px[j].z, k, lut);
+    w.x = c[0].v << 20 | c[0].y << 10 | c[0].u;
+    if (2 == remain) {
+      w.y = c[1].y;
+    } else if (4 == remain) {
+      w.y = c[2].y << 20 | c[2].u << 10 | c[1].y;
+      w.z = c[3].y << 10 | c[2].v;
+    }
+  } else if (width % 48 == 0) {
+    return;  // no padding quads exist
+  }
+  // quads past the tail inside the last 48-pixel block are cleared, like the reference
+  out[(size_t)line * quads_per_line_pitch + g] = w;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused channel pipeline: [v210 read] x N -> combine_N -> v210 write, one quad per lane.
+// The f32 RGBA intermediates of the reference's job batch live in registers only.
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(kBlock) void fused_v210_combine_kernel(FusedArgs a) {
+  const ReadK rk = load_read_k(a.rd_cm, a.rd_gm);
+  const WriteK wk = load_write_k(a.wr_cm);
+  const uint32_t f = blockIdx.x * kBlock + threadIdx.x;
+  if (f >= a.total_quads) return;
+  const uint32_t line = f / a.quads_per_line_used, g = f - line * a.quads_per_line_used;
+  const size_t off = (size_t)line * a.quads_per_line_pitch + g;
+
+  uint4 w[N];
+#pragma unroll
+  for (int l = 0; l < N; ++l) w[l] = reinterpret_cast<const uint4 *>(a.layers[l])[off];
+
+  float4 acc[6];
+  {
+    const Yuv6 q = unpack_quad(w[0]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] = read_px(q.y[j], q.cb[j >> 1], q.cr[j >> 1], 1.0f, rk, a.rd_lut);
+  }
+#pragma unroll
+  for (int l = 1; l < N; ++l) {  // combine.ts:45-65: premultiplied "over", alpha = top layer's
+    const Yuv6 q = unpack_quad(w[l]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float4 t = read_px(q.y[j], q.cb[j >> 1], q.cr[j >> 1], 1.0f, rk, a.rd_lut);
+      const float kk = 1.0f - t.w;
+      acc[j].x = fma_rn(acc[j].x, kk, t.x);
+      acc[j].y = fma_rn(acc[j].y, kk, t.y);
+      acc[j].z = fma_rn(acc[j].z, kk, t.z);
+      acc[j].w = fma_rn(acc[j].w, 0.0f, t.w);
+    }
+  }
+  uint32_t y[6], u[3], v[3];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    if ((j & 1) == 0) {
+      const Yuv1 c = write_px(acc[j].x, acc[j].y, acc[j].z, wk, a.wr_lut);
+      y[j] = c.y, u[j >> 1] = c.u, v[j >> 1] = c.v;
+    } else {
+      y[j] = write_px_luma(acc[j].x, acc[j].y, acc[j].z, wk, a.wr_lut);
+    }
+  }
+  reinterpret_cast<uint4 *>(a.out)[off] = pack_quad(y, u, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// yadif (reference yadifCl.ts:28-167).  grid = (ceil(w/256), h); interpolated rows stage the
+// two neighbouring `cur` rows (x0-3 .. x0+258) in LDS for the 14-tap spatial predictor.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float yadif_spatial(float a, float b, float c, float d, float e, float f, float g,
+                                               float h, float i, float j, float k, float l, float m, float n) {
+  float pred = (d + k) / 2.0f;
+  float best = __builtin_fabsf(c - j) + __builtin_fabsf(d - k) + __builtin_fabsf(e - l);
+  float score = __builtin_fabsf(b - k) + __builtin_fabsf(c - l) + __builtin_fabsf(d - m);
+  bool cmp = score < best;
+  pred = cmp ? (c + l) / 2.0f : pred;
+  best = cmp ? score : best;
+  score = cmp ? __builtin_fabsf(a - l) + __builtin_fabsf(b - m) + __builtin_fabsf(c - n) : score;
+  cmp = cmp && (score < best);
+  pred = cmp ? (b + m) / 2.0f : pred;
+  best = cmp ? score : best;
+
+  score = __builtin_fabsf(d - i) + __builtin_fabsf(e - j) + __builtin_fabsf(f - k);
+  cmp = score < best;
+  pred = cmp ? (e + j) / 2.0f : pred;
+  best = cmp ? score : best;
+  score = cmp ? __builtin_fabsf(e - h) + __builtin_fabsf(f - i) + __builtin_fabsf(g - j) : score;
+  cmp = cmp && (score < best);
+  pred = cmp ? (f + i) / 2.0f : pred;
+  return pred;
+}
+
+__device__ __forceinline__ float yadif_temporal(float A, float B, float C, float D, float E, float F, float G,
+                                                float H, float I, float J, float K, float L, float pred,
+                                                int skip) {
+  const float p0 = (C + H) / 2.0f, p1 = F, p2 = (D + I) / 2.0f, p3 = G, p4 = (E + J) / 2.0f;
+  const float t0 = __builtin_fabsf(D - I);
+  const float t1 = (__builtin_fabsf(A - F) + __builtin_fabsf(B - G)) / 2.0f;
+  const float t2 = (__builtin_fabsf(K - F) + __builtin_fabsf(G - L)) / 2.0f;
+  float diff = __builtin_fmaxf(__builtin_fmaxf(t0, t1), t2);
+  if (!skip) {
+    const float p2mp3 = p2 - p3, p2mp1 = p2 - p1, p0mp1 = p0 - p1, p4mp3 = p4 - p3;
+    const float maxi = __builtin_fmaxf(__builtin_fmaxf(p2mp3, p2mp1), __builtin_fminf(p0mp1, p4mp3));
+    const float mini = __builtin_fminf(__builtin_fminf(p2mp3, p2mp1), __builtin_fmaxf(p0mp1, p4mp3));
+    diff = __builtin_fmaxf(__builtin_fmaxf(diff, mini), -maxi);
+  }
+  pred = (pred > (p2 + diff)) ? p2 + diff : pred;
+  pred = (pred < (p2 - diff)) ? p2 - diff : pred;
+  return pred;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+#define PH_C4(v, c) ((c) == 0 ? (v).x : (c) == 1 ? (v).y : (c) == 2 ? (v).z : (v).w)
+
+__global__ __launch_bounds__(kBlock) void yadif_kernel(const float4 *__restrict__ prev, const float4 *__restrict__ cur,
+                                                       const float4 *__restrict__ next, int w, int h, int parity,
+                                                       int tff, int skip, float4 *__restrict__ out) {
+  __shared__ float4 rows[2][kBlock + 6];
+  const int y = blockIdx.y, x0 = blockIdx.x * kBlock, x = x0 + (int)threadIdx.x;
+  if ((y & 1) == parity) {  // keep the primary field (yadifCl.ts:117-121)
+    if (x < w) out[(size_t)y * w + x] = cur[(size_t)y * w + x];
+    return;
+  }
+  const int ym1 = clampi(y - 1, 0, h - 1), yp1 = clampi(y + 1, 0, h - 1);
+  for (int t = threadIdx.x; t < kBlock + 6; t += kBlock) {
+    const int xs = clampi(x0 - 3 + t, 0, w - 1);  // CLAMP_TO_EDGE
+    rows[0][t] = cur[(size_t)ym1 * w + xs];
+    rows[1][t] = cur[(size_t)yp1 * w + xs];
+  }
+  __syncthreads();
+  if (x >= w) return;
+  const int second = !(parity ^ tff);  // yadifCl.ts:143
+  const float4 *s0 = second ? cur : prev, *s1 = second ? next : cur;
+  const int ym2 = clampi(y - 2, 0, h - 1), yp2 = clampi(y + 2, 0, h - 1);
+  const float4 A = prev[(size_t)ym1 * w + x], B = prev[(size_t)yp1 * w + x];
+  const float4 C = s0[(size_t)ym2 * w + x], D = s0[(size_t)y * w + x], E = s0[(size_t)yp2 * w + x];
+  const float4 H = s1[(size_t)ym2 * w + x], I = s1[(size_t)y * w + x], J = s1[(size_t)yp2 * w + x];
+  const float4 K = next[(size_t)ym1 * w + x], L = next[(size_t)yp1 * w + x];
+  const float alpha = cur[(size_t)y * w + x].w;
+  float4 ra[7], rb[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) ra[t] = rows[0][threadIdx.x + t], rb[t] = rows[1][threadIdx.x + t];
+  const float4 F = ra[3], G = rb[3];
+  float res[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float sp = yadif_spatial(PH_C4(ra[0], c), PH_C4(ra[1], c), PH_C4(ra[2], c), PH_C4(ra[3], c),
+                                   PH_C4(ra[4], c), PH_C4(ra[5], c), PH_C4(ra[6], c), PH_C4(rb[0], c),
+                                   PH_C4(rb[1], c), PH_C4(rb[2], c), PH_C4(rb[3], c), PH_C4(rb[4], c),
+                                   PH_C4(rb[5], c), PH_C4(rb[6], c));
+    res[c] = yadif_temporal(PH_C4(A, c), PH_C4(B, c), PH_C4(C, c), PH_C4(D, c), PH_C4(E, c), PH_C4(F, c),
+                            PH_C4(G, c), PH_C4(H, c), PH_C4(I, c), PH_C4(J, c), PH_C4(K, c), PH_C4(L, c), sp, skip);
+  }
+  out[(size_t)y * w + x] = make_float4(res[0], res[1], res[2], alpha);  // :164 alpha from cur
+}
+
+// ------------------------------------------------------------------------------------------
+// bilinear sampler (OpenCL 1.2 s8.2: NORMALIZED | CLAMP (border 0) | LINEAR).  The f32
+// evaluation order is fixed: weights first, then ((w00*t00 + w10*t10) + w01*t01) + w11*t11,
+// plain mul/add, no fma (DESIGN.md "sampler").
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 texel_border(const float4 *__restrict__ img, int w, int h, int x, int y) {
+  if (x < 0 || y < 0 || x >= w || y >= h) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return img[(size_t)y * w + x];
+}
+__device__ __forceinline__ float4 sample_linear(const float4 *__restrict__ img, int w, int h, float s, float t) {
+  const float u = s * (float)w, v = t * (float)h;
+  const float fu = u - 0.5f, fv = v - 0.5f;
+  const float flu = __builtin_floorf(fu), flv = __builtin_floorf(fv);
+  const int i0 = (int)flu, j0 = (int)flv;
+  const float a = fu - flu, b = fv - flv;
+  const float oma = 1.0f - a, omb = 1.0f - b;
+  const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
+  const float4 t00 = texel_border(img, w, h, i0, j0), t10 = texel_border(img, w, h, i0 + 1, j0);
+  const float4 t01 = texel_border(img, w, h, i0, j0 + 1), t11 = texel_border(img, w, h, i0 + 1, j0 + 1);
+  float4 r;
+  r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+  r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+  r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+  r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+  return r;
+}
+
+// transform.ts:36-59.  2-D grid; 64x4 blocks keep a wave on one output row.
+__global__ __launch_bounds__(kBlock) void transform_kernel(const float4 *__restrict__ in, int iw, int ih,
+                                                           const float *__restrict__ m, float4 *__restrict__ out,
+                                                           int ow, int oh) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= ow || y >= oh) return;
+  const float px = (float)x / (float)ow - 0.5f, py = (float)y / (float)oh - 0.5f;
+  const float s = dot3(m[0], m[1], m[2], px, py, 1.0f) + 0.5f;
+  const float t = dot3(m[3], m[4], m[5], px, py, 1.0f) + 0.5f;
+  out[(size_t)y * ow + x] = sample_linear(in, iw, ih, s, t);
+}
+
+// resize.ts:35-59
+__global__ __launch_bounds__(kBlock) void resize_kernel(const float4 *__restrict__ in, int iw, int ih, float scale,
+                                                        float off_x, float off_y, const float *__restrict__ flip,
+                                                        float4 *__restrict__ out, int ow, int oh) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= ow || y >= oh) return;
+  const float cx = (-0.5f - off_x) / scale + 0.5f, cy = (-0.5f - off_y) / scale + 0.5f;
+  const float ox = fma_rn(cx, flip[1], flip[0]), oy = fma_rn(cy, flip[3], flip[2]);
+  const float mx = flip[1] / scale, my = flip[3] / scale;
+  const float s = fma_rn((float)x / (float)ow, mx, ox), t = fma_rn((float)y / (float)oh, my, oy);
+  out[(size_t)y * ow + x] = sample_linear(in, iw, ih, s, t);
+}
+
+// ------------------------------------------------------------------------------------------
+// combine_N / transitions / mixer / wipe: one float4 per lane, grid-stride
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(kBlock) void combine_kernel(CombineArgs a) {
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < a.npx; p += (size_t)gridDim.x * kBlock) {
+    float4 acc = reinterpret_cast<const float4 *>(a.layers[0])[p];
+#pragma unroll
+    for (int l = 1; l < N; ++l) {
+      const float4 t = reinterpret_cast<const float4 *>(a.layers[l])[p];
+      const float k = 1.0f - t.w;
+      acc.x = fma_rn(acc.x, k, t.x);
+      acc.y = fma_rn(acc.y, k, t.y);
+      acc.z = fma_rn(acc.z, k, t.z);
+      acc.w = fma_rn(acc.w, 0.0f, t.w);
+    }
+    reinterpret_cast<float4 *>(a.out)[p] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void dissolve_kernel(const float4 *__restrict__ in0, const float4 *__restrict__ in1,
+                                                          float mix, size_t npx, float4 *__restrict__ out) {
+  const float rmix = 1.0f - mix;
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock) {
+    const float4 a = in0[p], b = in1[p];
+    out[p] = make_float4(fma_rn(a.x, mix, b.x * rmix), fma_rn(a.y, mix, b.y * rmix), fma_rn(a.z, mix, b.z * rmix),
+                         fma_rn(a.w, mix, b.w * rmix));
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void twipe_kernel(const float4 *__restrict__ in0, const float4 *__restrict__ in1,
+                                                       const float4 *__restrict__ mask, size_t npx,
+                                                       float4 *__restrict__ out) {
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock) {
+    const float4 a = in0[p], b = in1[p];
+    const float m = mask[p].x, rm = 1.0f - m;
+    out[p] = make_float4(fma_rn(b.x, m, a.x * rm), fma_rn(b.y, m, a.y * rm), fma_rn(b.z, m, a.z * rm),
+                         fma_rn(b.w, m, a.w * rm));
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void wipe_kernel(const float4 *__restrict__ in0, const float4 *__restrict__ in1,
+                                                      float wipe, int w, int h, float4 *__restrict__ out) {
+  const float edge = (float)w * wipe;  // wipe.ts:44
+  const size_t npx = (size_t)w * h;
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock) {
+    const int x = (int)(p % (size_t)w);
+    out[p] = ((float)x > edge) ? in1[p] : in0[p];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+static inline uint32_t stream_grid(size_t n) {  // memory-bound element-wise: <= 8 blocks per CU
+  const uint64_t want = (n + kBlock - 1) / kBlock;
+  return (uint32_t)(want < 2048 ? (want ? want : 1) : 2048);
+}
+
+uint32_t v210_pitch_bytes(uint32_t width) { return (width + 47 - ((width - 1) % 48)) * 8 / 3; }
+
+hipError_t launch_v210_read(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
+                            const void *cm, const void *lut, const void *gm) {
+  const uint32_t qpl = v210_pitch_bytes(width) / 16;
+  if (width % 6 == 0) {
+    const uint32_t used = width / 6, total = used * height;
+    v210_read_kernel<<<div_up(total, kBlock), kBlock, 0, s>>>((const uint4 *)in, (float4 *)out, used, qpl, total,
+                                                             (const float *)cm, (const float *)lut, (const float *)gm);
+  } else {
+    const uint32_t slots = width / 6 + 1;
+    v210_read_tail_kernel<<<div_up((uint64_t)slots * height, kBlock), kBlock, 0, s>>>(
+        (const uint4 *)in, (float4 *)out, width, height, qpl, (const float *)cm, (const float *)lut, (const float *)gm);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_v210_write(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
+                             uint32_t interlace, const void *cm, const void *lut) {
+  const uint32_t qpl = v210_pitch_bytes(width) / 16;
+  const uint32_t step = interlace ? 2 : 1, first = (interlace == 3) ? 1 : 0;
+  const uint32_t lines = interlace ? height / 2 : height;  // v210.ts:323
+  if (lines == 0) return hipSuccess;
+  if (width % 48 == 0) {
+    const uint32_t used = width / 6, bpl = div_up(used, kBlock);
+    v210_write_kernel<<<bpl * lines, kBlock, 0, s>>>((const float4 *)in, (uint4 *)out, width, used, qpl, first, step,
+                                                     bpl, (const float *)cm, (const float *)lut);
+  } else {
+    v210_write_tail_kernel<<<div_up((uint64_t)qpl * lines, kBlock), kBlock, 0, s>>>(
+        (const float4 *)in, (uint4 *)out, width, lines, qpl, first, step, (const float *)cm, (const float *)lut);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_fused_v210_combine(hipStream_t s, int n, const FusedArgs &a) {
+  const uint32_t grid = div_up(a.total_quads, kBlock);
+  switch (n) {
+    case 1: fused_v210_combine_kernel<1><<<grid, kBlock, 0, s>>>(a); break;
+    case 2: fused_v210_combine_kernel<2><<<grid, kBlock, 0, s>>>(a); break;
+    case 3: fused_v210_combine_kernel<3><<<grid, kBlock, 0, s>>>(a); break;
+    case 4: fused_v210_combine_kernel<4><<<grid, kBlock, 0, s>>>(a); break;
+    case 5: fused_v210_combine_kernel<5><<<grid, kBlock, 0, s>>>(a); break;
+    case 6: fused_v210_combine_kernel<6><<<grid, kBlock, 0, s>>>(a); break;
+    case 7: fused_v210_combine_kernel<7><<<grid, kBlock, 0, s>>>(a); break;
+    case 8: fused_v210_combine_kernel<8><<<grid, kBlock, 0, s>>>(a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int parity,
+                        int tff, int skip, void *out) {
+  dim3 grid(div_up(w, kBlock), h);
+  yadif_kernel<<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, parity,
+                                       tff, skip, (float4 *)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_transform(hipStream_t s, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh) {
+  dim3 grid(div_up(ow, 64), div_up(oh, 4));
+  transform_kernel<<<grid, kBlock, 0, s>>>((const float4 *)in, iw, ih, (const float *)m9, (float4 *)out, ow, oh);
+  return hipGetLastError();
+}
+
+hipError_t launch_resize(hipStream_t s, const void *in, int iw, int ih, float scale, float ox, float oy,
+                         const void *flip4, void *out, int ow, int oh) {
+  dim3 grid(div_up(ow, 64), div_up(oh, 4));
+  resize_kernel<<<grid, kBlock, 0, s>>>((const float4 *)in, iw, ih, scale, ox, oy, (const float *)flip4, (float4 *)out,
+                                        ow, oh);
+  return hipGetLastError();
+}
+
+hipError_t launch_combine(hipStream_t s, int n, const CombineArgs &a) {
+  const uint32_t grid = stream_grid(a.npx);
+  switch (n) {
+    case 2: combine_kernel<2><<<grid, kBlock, 0, s>>>(a); break;
+    case 3: combine_kernel<3><<<grid, kBlock, 0, s>>>(a); break;
+    case 4: combine_kernel<4><<<grid, kBlock, 0, s>>>(a); break;
+    case 5: combine_kernel<5><<<grid, kBlock, 0, s>>>(a); break;
+    case 6: combine_kernel<6><<<grid, kBlock, 0, s>>>(a); break;
+    case 7: combine_kernel<7><<<grid, kBlock, 0, s>>>(a); break;
+    case 8: combine_kernel<8><<<grid, kBlock, 0, s>>>(a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_dissolve(hipStream_t s, const void *in0, const void *in1, float mix, int w, int h, void *out) {
+  const size_t npx = (size_t)w * h;
+  dissolve_kernel<<<stream_grid(npx), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, mix, npx, (float4 *)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_twipe(hipStream_t s, const void *in0, const void *in1, const void *mask, int w, int h, void *out) {
+  const size_t npx = (size_t)w * h;
+  twipe_kernel<<<stream_grid(npx), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, (const float4 *)mask, npx,
+                                                   (float4 *)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_wipe(hipStream_t s, const void *in0, const void *in1, float wipe, int w, int h, void *out) {
+  wipe_kernel<<<stream_grid((size_t)w * h), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, wipe, w, h,
+                                                           (float4 *)out);
+  return hipGetLastError();
+}
+
+}  // namespace ph

@@ -1,0 +1,115 @@
+"""Helpers for the -m gpu tests: run cases through the C ABI on cuda:0 with torch as the
+device-memory plumbing.  Colour parameters come from the product's own host maths
+(ph_colour_*), never from the oracle."""
+import numpy as np
+import torch
+
+from phaneron_amd import capi
+
+_ctx = None
+
+
+def ctx():
+    global _ctx
+    if _ctx is None:
+        _ctx = capi.Context(0)
+    return _ctx
+
+
+def dev(a):
+    """numpy -> cuda tensor (bit-preserving: uint32 travels as int32)."""
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        a = a.view(np.int32)
+    t = torch.from_numpy(a).cuda()
+    torch.cuda.synchronize()
+    return t
+
+
+def host(t, dtype=None):
+    ctx().wait()
+    torch.cuda.synchronize()
+    a = t.cpu().numpy()
+    return a.view(dtype) if dtype is not None else a
+
+
+class ColourParams:
+    """Device-resident matrices / LUTs for a (read spec -> working spec -> write spec) set."""
+    _cache = {}
+
+    @classmethod
+    def reader(cls, spec, out_spec):
+        key = ("r", spec, out_spec)
+        if key not in cls._cache:
+            cls._cache[key] = (dev(capi.ycbcr2rgb_matrix(spec)), dev(capi.gamma2linear_lut(spec)),
+                               dev(np.concatenate([capi.rgb2rgb_matrix(spec, out_spec), np.zeros(3, np.float32)])))
+        return cls._cache[key]
+
+    @classmethod
+    def writer(cls, spec):
+        key = ("w", spec)
+        if key not in cls._cache:
+            cls._cache[key] = (dev(capi.rgb2ycbcr_matrix(spec)), dev(capi.linear2gamma_lut(spec)))
+        return cls._cache[key]
+
+
+def run_case(c, inp, hm=None):
+    """Run one tests/golden/cases.py case on the GPU; returns a numpy array shaped like the golden."""
+    k = ctx()
+    op = c["op"]
+    if op == "v210_read":
+        cm, lut, gm = ColourParams.reader(c["spec"], c["out_spec"])
+        out = torch.zeros(c["h"] * c["w"] * 4, dtype=torch.float32, device="cuda")
+        src = dev(inp["words"])
+        k.v210_read(src, out, c["w"], c["h"], cm, lut, gm)
+        return host(out)
+    if op == "v210_write":
+        cm, lut = ColourParams.writer(c["spec"])
+        out = dev(inp["dst"])
+        src = dev(inp["rgba"])
+        k.v210_write(src, out, c["w"], c["h"], c["interlace"], cm, lut)
+        return host(out, np.uint32)
+    if op == "yadif":
+        out = torch.zeros(c["h"] * c["w"] * 4, dtype=torch.float32, device="cuda")
+        p, cu, n = dev(inp["prev"]), dev(inp["cur"]), dev(inp["next"])
+        k.yadif(p, cu, n, out, c["w"], c["h"], c["parity"], c["tff"], c["skip"])
+        return host(out)
+    if op == "transform":
+        t = hm["transform"][c["tp"]]
+        p = t["params"]
+        m = capi.transform_matrix(c["mw"], c["mh"], p.get("flipH", False), p.get("flipV", False),
+                                  p.get("anchorX", 0.0), p.get("anchorY", 0.0), p.get("scaleX", 1.0),
+                                  p.get("scaleY", 1.0), p.get("offsetX", 0.0), p.get("offsetY", 0.0),
+                                  p.get("rotate", 0.0))
+        out = torch.zeros(c["oh"] * c["ow"] * 4, dtype=torch.float32, device="cuda")
+        src, md = dev(inp["img"]), dev(m)
+        k.transform(src, c["iw"], c["ih"], md, out, c["ow"], c["oh"])
+        return host(out)
+    if op == "resize":
+        flip = np.array([1.0 if c["fh"] else 0.0, -1.0 if c["fh"] else 1.0, 1.0 if c["fv"] else 0.0,
+                         -1.0 if c["fv"] else 1.0], np.float32)
+        out = torch.zeros(c["oh"] * c["ow"] * 4, dtype=torch.float32, device="cuda")
+        src, fd = dev(inp["img"]), dev(flip)
+        k.resize(src, c["iw"], c["ih"], c["scale"], c["ox"], c["oy"], fd, out, c["ow"], c["oh"])
+        return host(out)
+    if op == "combine":
+        ls = [dev(l) for l in inp["layers"]]
+        out = torch.zeros(c["h"] * c["w"] * 4, dtype=torch.float32, device="cuda")
+        k.combine(ls, out, c["w"], c["h"])
+        return host(out)
+    if op in ("dissolve", "mixer", "wipe"):
+        a, b = dev(inp["in0"]), dev(inp["in1"])
+        out = torch.zeros(c["h"] * c["w"] * 4, dtype=torch.float32, device="cuda")
+        if op == "dissolve":
+            k.transition_dissolve(a, b, c["mix"], out, c["w"], c["h"])
+        elif op == "mixer":
+            k.mixer(a, b, c["mix"], out, c["w"], c["h"])
+        else:
+            k.wipe(a, b, c["wipe"], out, c["w"], c["h"])
+        return host(out)
+    if op == "twipe":
+        a, b, m = dev(inp["in0"]), dev(inp["in1"]), dev(inp["mask"])
+        out = torch.zeros(c["h"] * c["w"] * 4, dtype=torch.float32, device="cuda")
+        k.transition_wipe(a, b, m, out, c["w"], c["h"])
+        return host(out)
+    raise KeyError(op)

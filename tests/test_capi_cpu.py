@@ -1,0 +1,83 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/*.h declares,
+its host colour maths equals the reference goldens, and it refuses to run without a GPU."""
+import ctypes
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from phaneron_amd import build, capi
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+HM = json.load(open(os.path.join(ROOT, "tests", "golden", "host_maths.json")))
+
+
+def hexes(a):
+    return ["%08x" % v for v in np.ascontiguousarray(a, np.float32).view(np.uint32)]
+
+
+def declared_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names.update(re.findall(r"\b(ph_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = build.build()
+    lib = ctypes.CDLL(path)
+    syms = declared_symbols()
+    assert len(syms) >= 40
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTS) == syms  # the ctypes binding covers the whole header
+
+
+def test_abi_version():
+    assert capi.lib().ph_abi_version() == 1
+
+
+@pytest.mark.parametrize("spec", ["601-625", "601_525", "709", "2020", "sRGB", "bogus"])
+def test_product_colour_maths_matches_reference(spec):
+    import hashlib
+    assert hashlib.sha256(capi.gamma2linear_lut(spec).tobytes()).hexdigest() == HM["lut"][spec]["g2l_sha256"]
+    assert hashlib.sha256(capi.linear2gamma_lut(spec).tobytes()).hexdigest() == HM["lut"][spec]["l2g_sha256"]
+    for rng, a in (("10", (10, 64, 940, 896)), ("8", (8, 16, 235, 224))):
+        assert hexes(capi.ycbcr2rgb_matrix(spec, *a)) == HM["ycbcr2rgb"]["%s/%s" % (spec, rng)]
+        assert hexes(capi.rgb2ycbcr_matrix(spec, *a)) == HM["rgb2ycbcr"]["%s/%s" % (spec, rng)]
+    for dst in ["601-625", "601_525", "709", "2020", "sRGB", "bogus"]:
+        assert hexes(capi.rgb2rgb_matrix(spec, dst)) == HM["rgb2rgb"]["%s->%s" % (spec, dst)]
+
+
+@pytest.mark.parametrize("i", range(len(HM["transform"])))
+def test_product_transform_matrix_matches_reference(i):
+    t = HM["transform"][i]
+    p = t["params"]
+    m = capi.transform_matrix(t["width"], t["height"], p.get("flipH", False), p.get("flipV", False),
+                              p.get("anchorX", 0.0), p.get("anchorY", 0.0), p.get("scaleX", 1.0), p.get("scaleY", 1.0),
+                              p.get("offsetX", 0.0), p.get("offsetY", 0.0), p.get("rotate", 0.0))
+    assert hexes(m) == t["matrix"]
+
+
+def test_pitch():
+    for w, want in ((1920, 5120), (3840, 10240), (1280, 3456), (720, 1920), (100, 384)):
+        assert capi.v210_pitch_bytes(w) == want
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.PhaneronError, match="no HIP device"):
+        capi.Context(0)
+
+
+def test_product_never_imports_oracle():
+    for path in glob.glob(os.path.join(ROOT, "phaneron_amd", "**", "*"), recursive=True) + \
+            glob.glob(os.path.join(ROOT, "node", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".cpp", ".hip", ".h", ".js", ".c")):
+            assert "oracle" not in open(path).read().replace("no oracle", ""), path
