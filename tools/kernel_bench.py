@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Per-kernel timings at UHD size through the C ABI (HIP events on the library's stream):
+GB/s of compulsory traffic for every kernel of the path.  Writes one JSON line per kernel."""
+import json
+import os
+import sys
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from phaneron_amd import capi
+
+
+def main():
+    w, h = 3840, 2160
+    ctx = capi.Context(0)
+    stream = ctx.torch_stream()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rd = [dev(capi.ycbcr2rgb_matrix("709")), dev(capi.gamma2linear_lut("709")),
+          dev(np.concatenate([capi.rgb2rgb_matrix("709", "2020"), np.zeros(3, np.float32)]))]
+    wr = [dev(capi.rgb2ycbcr_matrix("2020")), dev(capi.linear2gamma_lut("2020"))]
+    words = capi.v210_pitch_bytes(w) * h // 4
+    R = 6  # ring to defeat the 256 MiB Infinity Cache
+    v = [torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device="cuda") & 0x3FFFFFFF for _ in range(R)]
+    img = [torch.rand(w * h * 4, dtype=torch.float32, device="cuda") for _ in range(R)]
+    out_img = [torch.empty(w * h * 4, dtype=torch.float32, device="cuda") for _ in range(2)]
+    out_v = [torch.empty(words, dtype=torch.int32, device="cuda") for _ in range(2)]
+    src1080 = [torch.rand(1920 * 1080 * 4, dtype=torch.float32, device="cuda") for _ in range(R)]
+    m = dev(capi.transform_matrix(w, h))
+    flip = dev(np.array([0, 1, 0, 1], np.float32))
+    torch.cuda.synchronize()
+    vb, ib = words * 4, w * h * 16
+
+    def timeit(name, fn, bytes_, reps=30):
+        for i in range(3):
+            fn(i)
+        ctx.wait()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for i in range(reps):
+            fn(i)
+        e1.record(stream)
+        ctx.wait()
+        ms = e0.elapsed_time(e1) / reps
+        print(json.dumps({"kernel": name, "ms": round(ms, 4), "algorithmic_MB": round(bytes_ / 1e6, 1),
+                          "GBps": round(bytes_ / ms / 1e6, 1)}), flush=True)
+
+    timeit("v210_read 2160p", lambda i: ctx.v210_read(v[i % R], out_img[i % 2], w, h, *rd), vb + ib)
+    timeit("v210_write 2160p", lambda i: ctx.v210_write(img[i % R], out_v[i % 2], w, h, 0, *wr), vb + ib)
+    timeit("combine_4 2160p", lambda i: ctx.combine([img[(i + j) % R] for j in range(4)], out_img[i % 2], w, h), 5 * ib)
+    timeit("combine_2 2160p", lambda i: ctx.combine([img[(i + j) % R] for j in range(2)], out_img[i % 2], w, h), 3 * ib)
+    timeit("transition_dissolve 2160p", lambda i: ctx.transition_dissolve(img[i % R], img[(i + 1) % R], 0.3, out_img[i % 2], w, h), 3 * ib)
+    timeit("transition_wipe 2160p", lambda i: ctx.transition_wipe(img[i % R], img[(i + 1) % R], img[(i + 2) % R], out_img[i % 2], w, h), 4 * ib)
+    timeit("wipe 2160p", lambda i: ctx.wipe(img[i % R], img[(i + 1) % R], 0.4, out_img[i % 2], w, h), 3 * ib)
+    timeit("yadif 2160p", lambda i: ctx.yadif(img[i % R], img[(i + 1) % R], img[(i + 2) % R], out_img[i % 2], w, h, 0, 1), 4 * ib)
+    timeit("transform identity 2160p", lambda i: ctx.transform(img[i % R], w, h, m, out_img[i % 2], w, h), 2 * ib)
+    timeit("transform 1080->2160", lambda i: ctx.transform(src1080[i % R], 1920, 1080, m, out_img[i % 2], w, h), ib + ib // 4)
+    timeit("resize 1080->2160", lambda i: ctx.resize(src1080[i % R], 1920, 1080, 1.0, 0.0, 0.0, flip, out_img[i % 2], w, h), ib + ib // 4)
+    for n in (1, 2, 4, 8):
+        if n <= R:
+            timeit("fused_v210_combine_%d 2160p" % n,
+                   lambda i, n=n: ctx.fused_v210_combine([v[(i + j) % R] for j in range(n)], out_v[i % 2], w, h, *rd, *wr),
+                   (n + 1) * vb)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -86,6 +86,58 @@ __global__ void valu_fma(float* __restrict__ out, float a, float b) {
   out[tid] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
 }
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int PER>
+__global__ void valu_pk_fma(float* __restrict__ out, float a, float b) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  float2v x0 = {(float)tid, tid + 1.f}, x1 = {tid + 2.f, tid + 3.f}, x2 = {tid + 4.f, tid + 5.f}, x3 = {tid + 6.f, tid + 7.f};
+  float2v x4 = x0 + 8.f, x5 = x1 + 8.f, x6 = x2 + 8.f, x7 = x3 + 8.f;
+  const float2v av = {a, a}, bv = {b, b};
+  for (int i = 0; i < PER; ++i) {
+    x0 = __builtin_elementwise_fma(x0, av, bv); x1 = __builtin_elementwise_fma(x1, av, bv);
+    x2 = __builtin_elementwise_fma(x2, av, bv); x3 = __builtin_elementwise_fma(x3, av, bv);
+    x4 = __builtin_elementwise_fma(x4, av, bv); x5 = __builtin_elementwise_fma(x5, av, bv);
+    x6 = __builtin_elementwise_fma(x6, av, bv); x7 = __builtin_elementwise_fma(x7, av, bv);
+  }
+  float2v s = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+  out[tid] = s.x + s.y;
+}
+// the index chain of one LUT lookup: mul, rndne, max, min, cvt (5 dependent-free streams)
+template <int PER>
+__global__ void valu_index_chain(uint32_t* __restrict__ out, float a) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  float x0 = tid * 1e-3f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+  uint32_t acc = 0;
+  for (int i = 0; i < PER; ++i) {
+    x0 += a; x1 += a; x2 += a; x3 += a;
+    acc += (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(x0 * 65535.0f), 0.f), 65535.f);
+    acc += (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(x1 * 65535.0f), 0.f), 65535.f);
+    acc += (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(x2 * 65535.0f), 0.f), 65535.f);
+    acc += (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(x3 * 65535.0f), 0.f), 65535.f);
+  }
+  out[tid] = acc;
+}
+template <int PER>
+__global__ void valu_transc(float* __restrict__ out, float a) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  float x0 = 0.2f + tid * 1e-9f, x1 = x0 + 0.1f, x2 = x0 + 0.2f, x3 = x0 + 0.3f;
+  for (int i = 0; i < PER; ++i) {
+    x0 = __builtin_amdgcn_exp2f(a * __builtin_amdgcn_logf(x0)); x1 = __builtin_amdgcn_exp2f(a * __builtin_amdgcn_logf(x1));
+    x2 = __builtin_amdgcn_exp2f(a * __builtin_amdgcn_logf(x2)); x3 = __builtin_amdgcn_exp2f(a * __builtin_amdgcn_logf(x3));
+  }
+  out[tid] = x0 + x1 + x2 + x3;
+}
+template <int PER>
+__global__ void bpermute_rate(uint32_t* __restrict__ out, uint32_t seed) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t s = mix32(tid ^ seed), v = tid, acc = 0;
+  for (int i = 0; i < PER; ++i) {
+    s = s * 1664525u + 1013904223u;
+    acc += __builtin_amdgcn_ds_bpermute((s >> 24) & 0xfc, v + i);
+  }
+  out[tid] = acc;
+}
+
 template <typename F> static float time_ms(F f, int reps = 10) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   f(); CK(hipDeviceSynchronize());
@@ -132,5 +184,13 @@ int main() {
   }
   ms = time_ms([&] { valu_fma<512><<<blocks, thr>>>(out, 1.0001f, 0.5f); });
   printf("{\"probe\":\"valu_fma\",\"Gops_per_s\":%.1f}\n", lanes * 512 * 8 / ms / 1e6);
+  ms = time_ms([&] { valu_pk_fma<512><<<blocks, thr>>>(out, 1.0001f, 0.5f); });
+  printf("{\"probe\":\"valu_pk_fma (2 fma per instr)\",\"Gfma_per_s\":%.1f}\n", lanes * 512 * 16 / ms / 1e6);
+  ms = time_ms([&] { valu_index_chain<256><<<blocks, thr>>>((uint32_t*)out, 1e-4f); });
+  printf("{\"probe\":\"valu_index_chain (add,mul,rndne,max,min,cvt,iadd = 7 ops)\",\"Gchains_per_s\":%.1f}\n", lanes * 256 * 4 / ms / 1e6);
+  ms = time_ms([&] { valu_transc<256><<<blocks, thr>>>(out, 0.45f); });
+  printf("{\"probe\":\"valu_pow (log2,mul,exp2)\",\"Gpow_per_s\":%.1f}\n", lanes * 256 * 4 / ms / 1e6);
+  ms = time_ms([&] { bpermute_rate<256><<<blocks, thr>>>((uint32_t*)out, 3); });
+  printf("{\"probe\":\"ds_bpermute\",\"Gops_per_s\":%.1f}\n", lanes * 256 / ms / 1e6);
   return 0;
 }
