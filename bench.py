@@ -124,6 +124,11 @@ def main():
     rd = [dev(capi.ycbcr2rgb_matrix("709")), dev(capi.gamma2linear_lut("709")),
           dev(np.concatenate([capi.rgb2rgb_matrix("709", "2020"), np.zeros(3, np.float32)]))]
     wr = [dev(capi.rgb2ycbcr_matrix("2020")), dev(capi.linear2gamma_lut("2020"))]
+    torch.cuda.synchronize()
+    ctx.register_lut(rd[1], capi.gamma2linear_lut("709"))   # exact LDS form of the tables
+    ctx.register_lut(wr[1], capi.linear2gamma_lut("2020"))
+    if os.environ.get("PH_BENCH_GLOBAL_LUT"):
+        ctx.set_option("lds_lut", 0)
     ring = []
     for r in range(args.ring):
         ins = [synth_v210(torch, w, h, 0x5EED0000 + 16 * (rank * 64 + r) + l, device) for l in range(n)]

@@ -165,6 +165,22 @@ int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *laye
                           const void *rd_gamma_lut, const void *rd_gamut_matrix9,
                           const void *wr_col_matrix12, const void *wr_gamma_lut);
 
+/* ---- gamma LUT placement.  The reference hands its kernels a 65536-entry f32 `gammaLut` buffer
+ *      (loadSave.ts:65-73,152-160) and gathers from it 3x per pixel.  Registering the table's
+ *      host contents lets the library keep an exact compressed copy for the CU's LDS
+ *      (DESIGN.md "LUT placement"); kernels given a registered device pointer then use the LDS
+ *      kernels, any other pointer uses the global-gather kernels.  Results are bit-identical.
+ *      Buffers filled through ph_buf_host_access with 262144 bytes are registered automatically
+ *      when first used as `gammaLut`.  Returns 1 if the table is LDS-capable, 0 if it is kept
+ *      plain (not exactly compressible into 160 KiB), negative on error. ----------------------- */
+int ph_lut_register(ph_ctx *ctx, const void *device_lut_f32, const float *host_lut65536);
+int ph_lut_unregister(ph_ctx *ctx, const void *device_lut_f32);
+/* lds_bytes = 0 when the pointer is unknown or plain */
+int ph_lut_query(ph_ctx *ctx, const void *device_lut_f32, uint32_t *lds_bytes, uint32_t *toe,
+                 uint32_t *block_shift);
+/* options: "lds_lut" (default 1): 0 forces the global-gather kernels (A/B tests, profiles) */
+int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value);
+
 /* ---- host colour maths (src/process/colourMaths.ts, run by Loader/Saver constructors
  *      loadSave.ts:50-63,139-149): outputs are HOST arrays the caller uploads. ------------------ */
 int ph_colour_gamma2linear_lut(const char *colspec, float *lut65536);     /* :130-149 */

@@ -25,6 +25,7 @@ EXPORTS = [
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
+    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option",
 ]
 
 
@@ -99,6 +100,10 @@ def lib():
         "ph_colour_rgb2ycbcr_matrix": (ci, [C.c_char_p, ci, ci, ci, ci, f32p]),
         "ph_colour_rgb2rgb_matrix": (ci, [C.c_char_p, C.c_char_p, f32p]),
         "ph_transform_matrix": (ci, [ci, ci, ci, ci, cd, cd, cd, cd, cd, cd, cd, f32p]),
+        "ph_lut_register": (ci, [vp, vp, f32p]),
+        "ph_lut_unregister": (ci, [vp, vp]),
+        "ph_lut_query": (ci, [vp, vp, C.POINTER(cu), C.POINTER(cu), C.POINTER(cu)]),
+        "ph_ctx_set_option": (ci, [vp, C.c_char_p, ci]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(l, name)  # AttributeError here = the header and the library disagree
@@ -197,6 +202,25 @@ class Context:
 
     def wait(self, queue=QUEUE_PROCESS):
         check(lib().ph_wait_finish(self.h, queue), self.h)
+
+    def register_lut(self, device_lut, host_lut):
+        """Tell the library the host contents of a device gamma LUT so its kernels can keep an exact
+        compressed copy in LDS.  Returns True if the table is LDS-capable."""
+        rc = lib().ph_lut_register(self.h, _ptr(device_lut), np.ascontiguousarray(host_lut, np.float32))
+        if rc < 0:
+            check(rc, self.h)
+        return rc == 1
+
+    def unregister_lut(self, device_lut):
+        check(lib().ph_lut_unregister(self.h, _ptr(device_lut)), self.h)
+
+    def lut_info(self, device_lut):
+        b, t, s = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().ph_lut_query(self.h, _ptr(device_lut), C.byref(b), C.byref(t), C.byref(s)), self.h)
+        return dict(lds_bytes=b.value, toe=t.value, block_shift=s.value)
+
+    def set_option(self, name, value):
+        check(lib().ph_ctx_set_option(self.h, name.encode(), int(value)), self.h)
 
     # typed kernels on torch tensors / raw pointers ------------------------------------------------
     def v210_read(self, src, dst, width, height, col_matrix, lut, gamut, queue=QUEUE_PROCESS):

@@ -13,6 +13,7 @@
 
 #include "../../include/phaneron_hip.h"
 #include "ph_kernels.h"
+#include "ph_lut_host.h"
 
 namespace {
 
@@ -36,8 +37,15 @@ int fail(int code, const char *fmt, ...) {
 
 }  // namespace
 
+struct LutEntry {
+  ph::LutView view{nullptr, 0, 0, 0, 0};
+  void *blob_dev = nullptr;
+};
+
 struct ph_ctx {
   int device = 0;
+  std::map<const void *, LutEntry> luts;  // device f32 table -> compressed LDS form
+  bool use_lds_lut = true;
   hipStream_t streams[3] = {nullptr, nullptr, nullptr};
   hipDeviceProp_t props;
   std::multimap<size_t, void *> pool;  // free device blocks by exact size
@@ -54,6 +62,7 @@ struct ph_buf {
   int refs;
   bool owned;
   bool host_dirty;
+  bool lut_dirty;  // 256 KiB of host data went in since the table was last compressed
   std::string owner;
 };
 
@@ -186,6 +195,8 @@ int ph_ctx_destroy(ph_ctx *ctx) {
       hipStreamDestroy(ctx->streams[i]);
     }
   for (auto &kv : ctx->pool) hipFree(kv.second);
+  for (auto &kv : ctx->luts)
+    if (kv.second.blob_dev) hipFree(kv.second.blob_dev);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   delete ctx;
@@ -221,7 +232,7 @@ int ph_buf_create(ph_ctx *ctx, size_t bytes, int access, int svm_type, int width
   rc = pool_alloc(ctx, bytes, &d);
   if (rc) return rc;
   ph_buf *b = new ph_buf{ctx, d, nullptr, bytes, width > 0 ? width : 0, height > 0 ? height : 0, 1, true, false,
-                         owner ? owner : ""};
+                         false, owner ? owner : ""};
   ctx->live_buffers++;
   ctx->live_bytes += bytes;
   *out = b;
@@ -231,7 +242,7 @@ int ph_buf_create(ph_ctx *ctx, size_t bytes, int access, int svm_type, int width
 int ph_buf_wrap(ph_ctx *ctx, void *device_ptr, size_t bytes, int width, int height, ph_buf **out) {
   if (!ctx || !out || !device_ptr) return fail(PH_E_INVALID, "ph_buf_wrap: NULL argument");
   *out = new ph_buf{ctx, device_ptr, nullptr, bytes, width > 0 ? width : 0, height > 0 ? height : 0, 1, false, false,
-                    "wrapped"};
+                    false, "wrapped"};
   ctx->live_buffers++;
   return PH_OK;
 }
@@ -246,6 +257,7 @@ int ph_buf_release(ph_buf *b) {
   if (--b->refs > 0) return PH_OK;
   ph_ctx *ctx = b->ctx;
   hipSetDevice(ctx->device);
+  ph_lut_unregister(ctx, b->dptr);  // the storage goes back to the pool: forget any LUT form of it
   if (b->owned) {
     pool_free(ctx, b->bytes, b->dptr);
     ctx->live_bytes -= b->bytes;
@@ -293,6 +305,7 @@ int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t by
         memcpy(b->hptr, src, bytes);
         PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, bytes, hipMemcpyHostToDevice, s));
         b->host_dirty = false;
+        b->lut_dirty = (bytes == 65536 * 4);
       } else {
         b->host_dirty = true;  // caller fills the mirror, then calls hostAccess('none')
       }
@@ -301,6 +314,7 @@ int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t by
       if (b->host_dirty) {
         PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, b->bytes, hipMemcpyHostToDevice, s));
         b->host_dirty = false;
+        b->lut_dirty = (b->bytes == 65536 * 4);
       }
       return PH_OK;
     case PH_HOST_READONLY:
@@ -318,6 +332,69 @@ int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, s
   if (live_bytes) *live_bytes = ctx->live_bytes;
   if (pooled_bytes) *pooled_bytes = ctx->pooled_bytes;
   return PH_OK;
+}
+
+// ---- gamma LUT registry ------------------------------------------------------------------------
+int ph_lut_unregister(ph_ctx *ctx, const void *dev) {
+  if (!ctx) return fail(PH_E_INVALID, "ph_lut_unregister: ctx is NULL");
+  auto it = ctx->luts.find(dev);
+  if (it == ctx->luts.end()) return PH_OK;
+  if (it->second.blob_dev) {
+    // kernels already enqueued may still read the blob: drain before freeing
+    for (int q = 0; q < 3; ++q) hipStreamSynchronize(ctx->streams[q]);
+    hipFree(it->second.blob_dev);
+  }
+  ctx->luts.erase(it);
+  return PH_OK;
+}
+
+int ph_lut_register(ph_ctx *ctx, const void *dev, const float *host) {
+  if (!ctx || !dev || !host) return fail(PH_E_INVALID, "ph_lut_register: NULL argument");
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  ph_lut_unregister(ctx, dev);
+  std::vector<uint32_t> blob;
+  ph::LutHostInfo info;
+  LutEntry e;
+  if (ph::lut_compress(host, ph::kLutMaxLdsBytes, blob, info)) {
+    PH_HIP(hipMalloc(&e.blob_dev, info.bytes));
+    PH_HIP(hipMemcpy(e.blob_dev, blob.data(), info.bytes, hipMemcpyHostToDevice));
+    e.view = ph::LutView{(const uint32_t *)e.blob_dev, info.bytes, info.toe, info.shift, info.lo_off};
+  }
+  ctx->luts[dev] = e;
+  return e.view.bytes ? 1 : 0;
+}
+
+int ph_lut_query(ph_ctx *ctx, const void *dev, uint32_t *lds_bytes, uint32_t *toe, uint32_t *shift) {
+  if (!ctx) return fail(PH_E_INVALID, "ph_lut_query: ctx is NULL");
+  auto it = ctx->luts.find(dev);
+  const bool have = it != ctx->luts.end();
+  if (lds_bytes) *lds_bytes = have ? it->second.view.bytes : 0;
+  if (toe) *toe = have ? it->second.view.toe : 0;
+  if (shift) *shift = have ? it->second.view.shift : 0;
+  return PH_OK;
+}
+
+int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
+  if (!ctx || !name) return fail(PH_E_INVALID, "ph_ctx_set_option: NULL argument");
+  if (0 == strcmp(name, "lds_lut")) return ctx->use_lds_lut = (value != 0), PH_OK;
+  return fail(PH_E_INVALID, "unknown option '%s'", name);
+}
+
+// the compressed form of a device LUT pointer, or NULL (unknown / plain / LDS path switched off)
+static const ph::LutView *lds_view(ph_ctx *ctx, const void *dev) {
+  if (!ctx->use_lds_lut) return nullptr;
+  auto it = ctx->luts.find(dev);
+  return (it != ctx->luts.end() && it->second.view.bytes) ? &it->second.view : nullptr;
+}
+
+// a ph_buf used as `gammaLut`: (re)compress from its host mirror if new data went in
+static void refresh_buf_lut(ph_ctx *ctx, ph_buf *b) {
+  if (b->lut_dirty && b->hptr && b->bytes >= 65536 * 4) {
+    hipStreamSynchronize(stream_of(ctx, PH_QUEUE_LOAD));  // the mirror must be stable
+    ph_lut_register(ctx, b->dptr, (const float *)b->hptr);
+    b->lut_dirty = false;
+  }
 }
 
 // ---- programs ---------------------------------------------------------------------------------
@@ -386,6 +463,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "colMatrix", 48, &b));
       TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
       TRY(need_buf(args, n, "gamutMatrix", 36, &d));
+      refresh_buf_lut(ctx, c);
       return ph_v210_read(ctx, queue, a->dptr, o->dptr, width, height, b->dptr, c->dptr, d->dptr);
     }
     case K_V210_WRITE: {
@@ -400,6 +478,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "output", (size_t)ph_v210_pitch_bytes(width) * height, &o));
       TRY(need_buf(args, n, "colMatrix", 48, &b));
       TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
+      refresh_buf_lut(ctx, c);
       return ph_v210_write(ctx, queue, a->dptr, o->dptr, width, height, interlace, b->dptr, c->dptr);
     }
     case K_YADIF: {
@@ -512,6 +591,10 @@ int ph_v210_read(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t wid
                  const void *lut, const void *gm) {
   if (!in || !out || !cm || !lut || !gm || !width) return fail(PH_E_INVALID, "ph_v210_read: NULL/zero argument");
   if (!height) return PH_OK;
+  if (ctx && width % 6 == 0)
+    if (const ph::LutView *v = lds_view(ctx, lut))
+      PH_LAUNCH(ph::launch_v210_read_lds(stream_of(ctx, queue), in, out, width, height, cm, gm, *v,
+                                         (uint32_t)ctx->props.multiProcessorCount));
   PH_LAUNCH(ph::launch_v210_read(stream_of(ctx, queue), in, out, width, height, cm, lut, gm));
 }
 
@@ -520,6 +603,10 @@ int ph_v210_write(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t wi
   if (!in || !out || !cm || !lut || !width) return fail(PH_E_INVALID, "ph_v210_write: NULL/zero argument");
   if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_v210_write: interlace must be 0, 1 or 3");
   if (!height) return PH_OK;
+  if (ctx && width % 48 == 0)
+    if (const ph::LutView *v = lds_view(ctx, lut))
+      PH_LAUNCH(ph::launch_v210_write_lds(stream_of(ctx, queue), in, out, width, height, interlace, cm, *v,
+                                          (uint32_t)ctx->props.multiProcessorCount));
   PH_LAUNCH(ph::launch_v210_write(stream_of(ctx, queue), in, out, width, height, interlace, cm, lut));
 }
 
@@ -542,6 +629,13 @@ int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *laye
   a.total_quads = a.quads_per_line_used * height;
   a.rd_cm = (const float *)rd_cm, a.rd_lut = (const float *)rd_lut, a.rd_gm = (const float *)rd_gm;
   a.wr_cm = (const float *)wr_cm, a.wr_lut = (const float *)wr_lut;
+  if (ctx) {
+    const ph::LutView *rv = lds_view(ctx, rd_lut), *wv = lds_view(ctx, wr_lut);
+    if (rv && wv) {
+      ph::FusedLdsArgs la{a, *rv, *wv};
+      PH_LAUNCH(ph::launch_fused_v210_combine_lds(stream_of(ctx, queue), n, la, (uint32_t)ctx->props.multiProcessorCount));
+    }
+  }
   PH_LAUNCH(ph::launch_fused_v210_combine(stream_of(ctx, queue), n, a));
 }
 

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "ph_lut.h"
+
 namespace ph {
 
 constexpr int kMaxLayers = 8;
@@ -15,6 +17,11 @@ struct FusedArgs {
   uint32_t quads_per_line_pitch;  // pitch bytes / 16
   uint32_t total_quads;           // quads_per_line_used * height
   const float *rd_cm, *rd_lut, *rd_gm, *wr_cm, *wr_lut;
+};
+
+struct FusedLdsArgs {
+  FusedArgs f;
+  LutView rd, wr;  // compressed reader / writer tables (ph_lut.h)
 };
 
 struct CombineArgs {
@@ -30,6 +37,12 @@ hipError_t launch_v210_read(hipStream_t s, const void *in, void *out, uint32_t w
 hipError_t launch_v210_write(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
                              uint32_t interlace, const void *cm, const void *lut);
 hipError_t launch_fused_v210_combine(hipStream_t s, int n, const FusedArgs &a);
+// LDS-LUT variants (ph_kernels_lds.hip): one 1024-lane workgroup per CU
+hipError_t launch_fused_v210_combine_lds(hipStream_t s, int n, const FusedLdsArgs &a, uint32_t num_cus);
+hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
+                                const void *cm, const void *gm, const LutView &lut, uint32_t num_cus);
+hipError_t launch_v210_write_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
+                                 uint32_t interlace, const void *cm, const LutView &lut, uint32_t num_cus);
 hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int parity,
                         int tff, int skip, void *out);
 hipError_t launch_transform(hipStream_t s, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh);

@@ -1,0 +1,259 @@
+// ph_kernels_lds.hip - the LDS-LUT kernels: same arithmetic as ph_kernels.hip, but the 3
+// gamma-LUT lookups per pixel are served from an exact compressed copy of the table held in
+// the CU's LDS (ph_lut.h) instead of 256 KiB of global memory.
+//
+// One workgroup of 1024 lanes per CU (the table takes ~153 KiB of the 160 KiB LDS), grid =
+// number of CUs, persistent loop over the frame.
+//
+// The fused channel pipeline needs TWO tables (reader gamma->linear, writer linear->gamma)
+// and only one fits, so it runs in two phases per tile: phase 1 holds the reader table,
+// unpacks/converts/combines P quads per lane into registers (linear RGB); phase 2 swaps
+// the writer table into LDS and converts/packs those registers.  Table swaps come from L2.
+#include "ph_device.h"
+#include "ph_kernels.h"
+#include "ph_lut.h"
+
+#include <cstdlib>
+
+#pragma clang fp contract(off)
+
+namespace ph {
+
+constexpr int kLdsBlock = 1024;
+
+extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
+
+// all lanes of the workgroup copy the table blob global -> LDS (16 bytes per lane per step)
+__device__ __forceinline__ void lds_lut_load(const LutView &v) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(v.blob);
+  uint4 *dst = reinterpret_cast<uint4 *>(g_lds);
+  const uint32_t n = v.bytes / 16;
+  for (uint32_t i = threadIdx.x; i < n; i += kLdsBlock) dst[i] = src[i];
+}
+
+// exact table value for index idx (0..65535): two LDS reads, see ph_lut.h
+__device__ __forceinline__ float lds_lut_get(const LutView &v, uint32_t idx) {
+  const uint32_t blk = v.toe + ((idx - v.toe) >> v.shift);  // wraps huge for idx < toe
+  const uint32_t b = idx < blk ? idx : blk;
+  const uint32_t a = *reinterpret_cast<const uint32_t *>(g_lds + 4 * b);
+  const uint32_t lo = *reinterpret_cast<const uint16_t *>(g_lds + v.lo_off + 2 * idx);
+  return __uint_as_float(a + ((lo - a) & 0xffffu));
+}
+
+__device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const ReadK &k, const LutView &lut) {
+  const float r = lds_lut_get(lut, sat_u16_rte(dot4(y, cb, cr, 1.0f, k.r) * 65535.0f));
+  const float g = lds_lut_get(lut, sat_u16_rte(dot4(y, cb, cr, 1.0f, k.g) * 65535.0f));
+  const float b = lds_lut_get(lut, sat_u16_rte(dot4(y, cb, cr, 1.0f, k.b) * 65535.0f));
+  return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
+                     dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
+}
+
+__device__ __forceinline__ Yuv1 write_px_lds(float r, float g, float b, const WriteK &k, const LutView &lut) {
+  const float gr = lds_lut_get(lut, sat_u16_rte(r * 65535.0f));
+  const float gg = lds_lut_get(lut, sat_u16_rte(g * 65535.0f));
+  const float gb = lds_lut_get(lut, sat_u16_rte(b * 65535.0f));
+  Yuv1 o;
+  o.y = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
+  o.u = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.u));
+  o.v = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.v));
+  return o;
+}
+__device__ __forceinline__ uint32_t write_px_luma_lds(float r, float g, float b, const WriteK &k, const LutView &lut) {
+  const float gr = lds_lut_get(lut, sat_u16_rte(r * 65535.0f));
+  const float gg = lds_lut_get(lut, sat_u16_rte(g * 65535.0f));
+  const float gb = lds_lut_get(lut, sat_u16_rte(b * 65535.0f));
+  return sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
+}
+
+__device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const WriteK &wk, const LutView &lut) {
+  uint32_t y[6], u[3], v[3];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    if ((j & 1) == 0) {
+      const Yuv1 c = write_px_lds(rgb[3 * j], rgb[3 * j + 1], rgb[3 * j + 2], wk, lut);
+      y[j] = c.y, u[j >> 1] = c.u, v[j >> 1] = c.v;
+    } else {
+      y[j] = write_px_luma_lds(rgb[3 * j], rgb[3 * j + 1], rgb[3 * j + 2], wk, lut);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  return pack_quad(y, u, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// fused [v210 read] x N -> combine_N -> v210 write, two LDS phases per tile of 1024*P quads
+// ------------------------------------------------------------------------------------------
+template <int N, int P>
+__global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(FusedLdsArgs a) {
+  const ReadK rk = load_read_k(a.f.rd_cm, a.f.rd_gm);
+  const WriteK wk = load_write_k(a.f.wr_cm);
+  const uint32_t tile_quads = kLdsBlock * P;
+  const uint32_t tiles = (a.f.total_quads + tile_quads - 1) / tile_quads;
+  for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    float acc[P][18];
+    lds_lut_load(a.rd);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      uint32_t f = tile * tile_quads + p * kLdsBlock + threadIdx.x;  // width % 48 == 0: flat == offset
+      f = f < a.f.total_quads ? f : a.f.total_quads - 1;                // tail lanes recompute the last quad
+      {
+        // layers are streamed one at a time with a one-deep prefetch: 8 VGPRs of input in
+        // flight instead of 4*N, which is what keeps P quads of accumulators in registers
+        uint4 w = reinterpret_cast<const uint4 *>(a.f.layers[0])[f];
+#pragma unroll
+        for (int l = 0; l < N; ++l) {
+          uint4 nxt = w;
+          if (l + 1 < N) nxt = reinterpret_cast<const uint4 *>(a.f.layers[l + 1])[f];
+          const Yuv6 q = unpack_quad(w);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const float4 t = read_px_lds(q.y[j], q.cb[j >> 1], q.cr[j >> 1], rk, a.rd);
+            if (l == 0) {
+              acc[p][3 * j] = t.x, acc[p][3 * j + 1] = t.y, acc[p][3 * j + 2] = t.z;
+            } else {  // combine.ts:45-65
+              const float kk = 1.0f - t.w;
+              acc[p][3 * j] = fma_rn(acc[p][3 * j], kk, t.x);
+              acc[p][3 * j + 1] = fma_rn(acc[p][3 * j + 1], kk, t.y);
+              acc[p][3 * j + 2] = fma_rn(acc[p][3 * j + 2], kk, t.z);
+            }
+            // Pin the accumulators here.  Without this LLVM sinks the whole decode/gamut/combine
+            // arithmetic to its first use in phase 2 (past the barrier and the table swap) and
+            // keeps the 2 raw LDS words of every lookup alive instead: hundreds of spilled VGPRs.
+            asm volatile("" : "+v"(acc[p][3 * j]), "+v"(acc[p][3 * j + 1]), "+v"(acc[p][3 * j + 2]));
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);  // schedule pixel pairs, not whole quads
+          }
+          w = nxt;
+          __builtin_amdgcn_sched_barrier(0);  // keep the compiler from hoisting every layer's load
+        }
+      }
+    }
+    __syncthreads();
+    lds_lut_load(a.wr);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const uint32_t f = tile * tile_quads + p * kLdsBlock + threadIdx.x;
+      const uint4 packed = write_quad_lds(acc[p], wk, a.wr);
+      if (f < a.f.total_quads) reinterpret_cast<uint4 *>(a.f.out)[f] = packed;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// v210 read / write with the table in LDS (single phase).  width % 6 == 0; the f32 side is
+// accessed directly (each lane owns 96 contiguous bytes; the six accesses of a wave hit the
+// same cache lines, so HBM sees each line once).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLdsBlock) void v210_read_lds_kernel(const uint4 *__restrict__ in, float4 *__restrict__ out,
+                                                                   uint32_t quads_per_line_used,
+                                                                   uint32_t quads_per_line_pitch, uint32_t total_quads,
+                                                                   const float *__restrict__ cm,
+                                                                   const float *__restrict__ gm, LutView lut) {
+  const ReadK k = load_read_k(cm, gm);
+  lds_lut_load(lut);
+  __syncthreads();
+  for (uint32_t f = blockIdx.x * kLdsBlock + threadIdx.x; f < total_quads; f += gridDim.x * kLdsBlock) {
+    const uint32_t line = f / quads_per_line_used, g = f - line * quads_per_line_used;
+    const Yuv6 q = unpack_quad(in[(size_t)line * quads_per_line_pitch + g]);
+    float4 *o = out + (size_t)f * 6;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) o[j] = read_px_lds(q.y[j], q.cb[j >> 1], q.cr[j >> 1], k, lut);
+  }
+}
+
+__global__ __launch_bounds__(kLdsBlock) void v210_write_lds_kernel(const float4 *__restrict__ in, uint4 *__restrict__ out,
+                                                                    uint32_t width, uint32_t quads_per_line,
+                                                                    uint32_t lines, uint32_t first_line,
+                                                                    uint32_t line_step, const float *__restrict__ cm,
+                                                                    LutView lut) {
+  const WriteK k = load_write_k(cm);
+  lds_lut_load(lut);
+  __syncthreads();
+  const uint32_t total = quads_per_line * lines;  // width % 48 == 0: used == pitch
+  for (uint32_t f = blockIdx.x * kLdsBlock + threadIdx.x; f < total; f += gridDim.x * kLdsBlock) {
+    const uint32_t li = f / quads_per_line, g = f - li * quads_per_line;
+    const uint32_t line = first_line + li * line_step;
+    const float4 *px = in + (size_t)line * width + 6 * g;
+    float rgb[18];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float4 p = px[j];
+      rgb[3 * j] = p.x, rgb[3 * j + 1] = p.y, rgb[3 * j + 2] = p.z;
+    }
+    out[(size_t)line * quads_per_line + g] = write_quad_lds(rgb, k, lut);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+template <typename K>
+static hipError_t allow_lds(K kernel, uint32_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes);
+}
+
+template <int N, int P>
+static hipError_t launch_fused_np(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
+  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P>, lds);
+  if (e != hipSuccess) return e;
+  const uint32_t tiles = (a.f.total_quads + kLdsBlock * P - 1) / (kLdsBlock * P);
+  fused_v210_combine_lds_kernel<N, P><<<tiles < grid ? tiles : grid, kLdsBlock, lds, s>>>(a);
+  return hipGetLastError();
+}
+
+// P = quads per lane per tile.  5 is the most that stays in 128 VGPRs (4 waves/SIMD, i.e. the one
+// 1024-lane workgroup a CU can hold); PH_FUSED_P=4 selects the smaller tile for A/B runs.
+template <int N>
+static hipError_t launch_fused_n(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
+  static const int p = [] {
+    const char *e = getenv("PH_FUSED_P");
+    return (e && atoi(e) == 4) ? 4 : 5;
+  }();
+  return p == 4 ? launch_fused_np<N, 4>(s, a, grid, lds) : launch_fused_np<N, 5>(s, a, grid, lds);
+}
+
+hipError_t launch_fused_v210_combine_lds(hipStream_t s, int n, const FusedLdsArgs &a, uint32_t num_cus) {
+  const uint32_t lds = a.rd.bytes > a.wr.bytes ? a.rd.bytes : a.wr.bytes;
+  switch (n) {
+    case 1: return launch_fused_n<1>(s, a, num_cus, lds);
+    case 2: return launch_fused_n<2>(s, a, num_cus, lds);
+    case 3: return launch_fused_n<3>(s, a, num_cus, lds);
+    case 4: return launch_fused_n<4>(s, a, num_cus, lds);
+    case 5: return launch_fused_n<5>(s, a, num_cus, lds);
+    case 6: return launch_fused_n<6>(s, a, num_cus, lds);
+    case 7: return launch_fused_n<7>(s, a, num_cus, lds);
+    case 8: return launch_fused_n<8>(s, a, num_cus, lds);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
+                                const void *cm, const void *gm, const LutView &lut, uint32_t num_cus) {
+  hipError_t e = allow_lds(v210_read_lds_kernel, lut.bytes);
+  if (e != hipSuccess) return e;
+  const uint32_t used = width / 6, total = used * height;
+  const uint32_t want = (total + kLdsBlock - 1) / kLdsBlock;
+  v210_read_lds_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, lut.bytes, s>>>(
+      (const uint4 *)in, (float4 *)out, used, v210_pitch_bytes(width) / 16, total, (const float *)cm, (const float *)gm,
+      lut);
+  return hipGetLastError();
+}
+
+hipError_t launch_v210_write_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
+                                 uint32_t interlace, const void *cm, const LutView &lut, uint32_t num_cus) {
+  hipError_t e = allow_lds(v210_write_lds_kernel, lut.bytes);
+  if (e != hipSuccess) return e;
+  const uint32_t step = interlace ? 2 : 1, first = (interlace == 3) ? 1 : 0;
+  const uint32_t lines = interlace ? height / 2 : height, qpl = width / 6;
+  if (!lines) return hipSuccess;
+  const uint32_t want = (qpl * lines + kLdsBlock - 1) / kLdsBlock;
+  v210_write_lds_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, lut.bytes, s>>>(
+      (const float4 *)in, (uint4 *)out, width, qpl, lines, first, step, (const float *)cm, lut);
+  return hipGetLastError();
+}
+
+}  // namespace ph

@@ -1,0 +1,20 @@
+// ph_lut_host.h - host API of the LUT compressor (ph_lut.cpp)
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+#include "ph_lut.h"
+
+namespace ph {
+
+struct LutHostInfo {
+  uint32_t bytes = 0, toe = 0, shift = 0, lo_off = 0;
+};
+
+// max LDS a single workgroup can hold on gfx950 is 160 KiB; tables must leave room for nothing else
+constexpr uint32_t kLutMaxLdsBytes = 160 * 1024;
+
+// Returns false when the table cannot be represented exactly within max_bytes.
+bool lut_compress(const float *lut65536, uint32_t max_bytes, std::vector<uint32_t> &blob, LutHostInfo &info);
+
+}  // namespace ph

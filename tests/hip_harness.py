@@ -41,7 +41,10 @@ class ColourParams:
     def reader(cls, spec, out_spec):
         key = ("r", spec, out_spec)
         if key not in cls._cache:
-            cls._cache[key] = (dev(capi.ycbcr2rgb_matrix(spec)), dev(capi.gamma2linear_lut(spec)),
+            lut = capi.gamma2linear_lut(spec)
+            dlut = dev(lut)
+            ctx().register_lut(dlut, lut)  # lets the library keep the exact LDS form of the table
+            cls._cache[key] = (dev(capi.ycbcr2rgb_matrix(spec)), dlut,
                                dev(np.concatenate([capi.rgb2rgb_matrix(spec, out_spec), np.zeros(3, np.float32)])))
         return cls._cache[key]
 
@@ -49,7 +52,10 @@ class ColourParams:
     def writer(cls, spec):
         key = ("w", spec)
         if key not in cls._cache:
-            cls._cache[key] = (dev(capi.rgb2ycbcr_matrix(spec)), dev(capi.linear2gamma_lut(spec)))
+            lut = capi.linear2gamma_lut(spec)
+            dlut = dev(lut)
+            ctx().register_lut(dlut, lut)
+            cls._cache[key] = (dev(capi.rgb2ycbcr_matrix(spec)), dlut)
         return cls._cache[key]
 
 

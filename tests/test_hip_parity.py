@@ -23,6 +23,16 @@ KAT = json.load(open(os.path.join(GOLD, "kat.json")))
 NPZ = np.load(os.path.join(GOLD, "kernels.npz"))
 
 
+@pytest.fixture(params=["lds_lut", "global_lut"], autouse=True)
+def lut_path(request):
+    """Every test runs twice: with the gamma LUTs served from LDS (default) and with the
+    global-gather kernels; both must be bit-identical to the reference."""
+    import hip_harness as hh
+    hh.ctx().set_option("lds_lut", request.param == "lds_lut")
+    yield request.param
+    hh.ctx().set_option("lds_lut", True)
+
+
 def assert_bits(got, want, what=""):
     g = np.ascontiguousarray(got).reshape(-1).view(np.uint32)
     w = np.ascontiguousarray(want).reshape(-1).view(np.uint32)
@@ -144,6 +154,19 @@ def test_combine_vs_oracle_1080p(n):
     out = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
     hh.ctx().combine([hh.dev(l) for l in layers], out, w, h)
     assert_bits(hh.host(out), orc.combine(layers), "combine_%d" % n)
+
+
+def test_lut_registry_reports_lds_form():
+    import hip_harness as hh
+    for spec in ("709", "2020", "601-625"):
+        _, lut, _ = hh.ColourParams.reader(spec, spec)
+        info = hh.ctx().lut_info(lut)
+        assert 0 < info["lds_bytes"] <= 160 * 1024, info
+        _, wlut = hh.ColourParams.writer(spec)
+        assert 0 < hh.ctx().lut_info(wlut)["lds_bytes"] <= 160 * 1024
+    # the sRGB gamma->linear table does not compress into 160 KiB: it must stay plain and still work
+    _, lut, _ = hh.ColourParams.reader("sRGB", "709")
+    assert hh.ctx().lut_info(lut)["lds_bytes"] == 0
 
 
 def test_combine_rejects_single_layer():

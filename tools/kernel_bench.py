@@ -21,6 +21,11 @@ def main():
     rd = [dev(capi.ycbcr2rgb_matrix("709")), dev(capi.gamma2linear_lut("709")),
           dev(np.concatenate([capi.rgb2rgb_matrix("709", "2020"), np.zeros(3, np.float32)]))]
     wr = [dev(capi.rgb2ycbcr_matrix("2020")), dev(capi.linear2gamma_lut("2020"))]
+    torch.cuda.synchronize()
+    ctx.register_lut(rd[1], capi.gamma2linear_lut("709"))
+    ctx.register_lut(wr[1], capi.linear2gamma_lut("2020"))
+    if os.environ.get("PH_BENCH_GLOBAL_LUT"):
+        ctx.set_option("lds_lut", 0)
     words = capi.v210_pitch_bytes(w) * h // 4
     R = 6  # ring to defeat the 256 MiB Infinity Cache
     v = [torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device="cuda") & 0x3FFFFFFF for _ in range(R)]
