@@ -68,8 +68,8 @@ def cpu_baseline(args, budget_s):
     rd = (orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
     wr = (orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
     scratch = np.empty((n + 1) * w * h * 4, np.float32)
-    orc.set_num_threads(0)
-    cores = orc.num_threads()
+    cores = orc.effective_cpus()  # cgroup quota, not the 256 logical CPUs the box reports
+    orc.set_num_threads(cores)
     orc.pipeline_v210_combine(layers, w, h, *rd, *wr, scratch=scratch)  # warm-up (page faults)
     t0 = time.perf_counter()
     frames_done = 0

@@ -240,6 +240,25 @@ def pipeline_v210_combine(layers, width, height, rd_cm, rd_lut, rd_gm, wr_cm, wr
     return out
 
 
+def effective_cpus():
+    """CPUs this process may really use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // period))
+        except Exception:
+            pass
+    return n
+
+
 def num_threads():
     return int(lib().orc_num_threads())
 

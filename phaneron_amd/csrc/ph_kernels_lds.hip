@@ -87,16 +87,21 @@ template <int N, int P>
 __global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(FusedLdsArgs a) {
   const ReadK rk = load_read_k(a.f.rd_cm, a.f.rd_gm);
   const WriteK wk = load_write_k(a.f.wr_cm);
+  // Every workgroup owns one contiguous, equally sized range of quads (all CUs finish together)
+  // and walks it in tiles of 1024*P quads; only the last tile of a range is partially filled.
+  const uint32_t per_wg = (a.f.total_quads + gridDim.x - 1) / gridDim.x;
+  const uint32_t wg_begin = blockIdx.x * per_wg;
+  const uint32_t wg_end = wg_begin + per_wg < a.f.total_quads ? wg_begin + per_wg : a.f.total_quads;
   const uint32_t tile_quads = kLdsBlock * P;
-  const uint32_t tiles = (a.f.total_quads + tile_quads - 1) / tile_quads;
-  for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  for (uint32_t tile_begin = wg_begin; tile_begin < wg_end; tile_begin += tile_quads) {
     float acc[P][18];
     lds_lut_load(a.rd);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      uint32_t f = tile * tile_quads + p * kLdsBlock + threadIdx.x;  // width % 48 == 0: flat == offset
-      f = f < a.f.total_quads ? f : a.f.total_quads - 1;                // tail lanes recompute the last quad
+      uint32_t f = tile_begin + p * kLdsBlock + threadIdx.x;  // width % 48 == 0: flat index == offset
+      if (p * kLdsBlock >= wg_end - tile_begin) break;         // uniform: this slice of the tile is empty
+      f = f < wg_end ? f : wg_end - 1;                         // tail lanes recompute the last quad
       {
         // layers are streamed one at a time with a one-deep prefetch: 8 VGPRs of input in
         // flight instead of 4*N, which is what keeps P quads of accumulators in registers
@@ -133,9 +138,10 @@ __global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(Fused
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const uint32_t f = tile * tile_quads + p * kLdsBlock + threadIdx.x;
+      const uint32_t f = tile_begin + p * kLdsBlock + threadIdx.x;
+      if (p * kLdsBlock >= wg_end - tile_begin) break;
       const uint4 packed = write_quad_lds(acc[p], wk, a.wr);
-      if (f < a.f.total_quads) reinterpret_cast<uint4 *>(a.f.out)[f] = packed;
+      if (f < wg_end) reinterpret_cast<uint4 *>(a.f.out)[f] = packed;
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -200,18 +206,19 @@ template <int N, int P>
 static hipError_t launch_fused_np(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
   hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P>, lds);
   if (e != hipSuccess) return e;
-  const uint32_t tiles = (a.f.total_quads + kLdsBlock * P - 1) / (kLdsBlock * P);
-  fused_v210_combine_lds_kernel<N, P><<<tiles < grid ? tiles : grid, kLdsBlock, lds, s>>>(a);
+  const uint32_t slices = (a.f.total_quads + kLdsBlock - 1) / kLdsBlock;  // never more workgroups than 1024-quad slices
+  fused_v210_combine_lds_kernel<N, P><<<slices < grid ? slices : grid, kLdsBlock, lds, s>>>(a);
   return hipGetLastError();
 }
 
 // P = quads per lane per tile.  5 is the most that stays in 128 VGPRs (4 waves/SIMD, i.e. the one
-// 1024-lane workgroup a CU can hold); PH_FUSED_P=4 selects the smaller tile for A/B runs.
+// 1024-lane workgroup a CU can hold); 4 measured faster (99 vs 118 us at 2160p x4).  PH_FUSED_P=5
+// selects the larger tile for A/B runs.
 template <int N>
 static hipError_t launch_fused_n(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
   static const int p = [] {
     const char *e = getenv("PH_FUSED_P");
-    return (e && atoi(e) == 4) ? 4 : 5;
+    return (e && atoi(e) == 5) ? 5 : 4;
   }();
   return p == 4 ? launch_fused_np<N, 4>(s, a, grid, lds) : launch_fused_np<N, 5>(s, a, grid, lds);
 }
