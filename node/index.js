@@ -1,0 +1,126 @@
+'use strict'
+// node/index.js - the nodencl-shaped JS surface over the N-API addon (node/ph_napi.c), i.e.
+// what phaneron's src/index.ts:94-108 gets from `new nodenCLContext(...)`: clContext with
+// initialise / getPlatformInfo / createBuffer / createProgram / runProgram / waitFinish /
+// queue / logBuffers, and OpenCLBuffer objects that ARE node Buffers with hostAccess /
+// addRef / release and free-form timestamp fields.  Call sites: SURVEY.md 8(b).
+const path = require('path')
+
+let addon = null
+function loadAddon() {
+	if (!addon) {
+		try {
+			addon = require(path.join(__dirname, 'phaneron_napi.node'))
+		} catch (e) {
+			throw new Error(`phaneron HIP addon not available (${e.message}); build it with python node/build.py - there is no OpenCL or CPU fallback`)
+		}
+	}
+	return addon
+}
+
+const ACCESS = { readonly: 0, writeonly: 1, readwrite: 2 }
+const SVM = { none: 0, coarse: 1, fine: 2 }
+const HOSTDIR = { readonly: 0, writeonly: 1, none: 2 }
+
+// Decorate the node Buffer the addon returned (pinned host mirror of the device buffer) with
+// the OpenCLBuffer members the reference uses.
+function makeOpenCLBuffer(native, created, numBytes, imageDims, owner) {
+	const buf = created.buffer
+	const handle = created.handle
+	Object.defineProperty(buf, '_handle', { value: handle, enumerable: false })
+	buf.numBytes = numBytes
+	buf.owner = owner || ''
+	buf.imageDims = imageDims
+	buf.timestamp = 0
+	buf.loadstamp = 0
+	buf.creationTime = process.hrtime()
+	buf.hostAccess = (dir, queue, src) => {
+		if (!(dir in HOSTDIR)) return Promise.reject(new Error(`hostAccess: unknown direction '${dir}'`))
+		if (Buffer.isBuffer(queue)) { src = queue; queue = 0 } // hostAccess(dir, src)
+		return native.hostAccess(handle, HOSTDIR[dir], queue || 0, src)
+	}
+	buf.addRef = () => { native.bufAddRef(handle) }
+	buf.release = () => { native.bufRelease(handle) }
+	buf.refCount = () => native.bufRefCount(handle)
+	return buf
+}
+
+class clContext {
+	constructor(params) {
+		params = params || {}
+		this.platformIndex = params.platformIndex || 0
+		this.deviceIndex = params.deviceIndex || 0
+		this.overlapping = params.overlapping !== false
+		this.profile = !!params.profile // true: runProgram records hipEvents and returns real RunTimings
+		this.queue = this.overlapping ? { load: 0, process: 1, unload: 2 } : { load: 1, process: 1, unload: 1 }
+		this._ctx = null
+		this._native = null
+	}
+
+	async initialise() {
+		this._native = loadAddon()
+		this._ctx = this._native.createContext(this.deviceIndex)
+	}
+
+	_need() {
+		if (!this._ctx) throw new Error('clContext has not been initialised')
+		return this._native
+	}
+
+	getPlatformInfo() {
+		const info = this._need().contextInfo(this._ctx)
+		const devices = []
+		devices[this.deviceIndex] = { type: 'CL_DEVICE_TYPE_GPU', name: info.device, vendor: info.vendor }
+		return { vendor: info.vendor, name: 'AMD HIP (gfx950)', devices }
+	}
+
+	async createBuffer(numBytes, bufDir, bufType, imageDims, owner) {
+		const native = this._need()
+		if (!(bufDir in ACCESS)) throw new Error(`createBuffer: unknown direction '${bufDir}'`)
+		if (!(bufType in SVM)) throw new Error(`createBuffer: unknown svm type '${bufType}'`)
+		const w = imageDims ? imageDims.width : 0
+		const h = imageDims ? imageDims.height : 0
+		const created = native.createBuffer(this._ctx, numBytes, ACCESS[bufDir], SVM[bufType], w, h, owner || '')
+		return makeOpenCLBuffer(native, created, numBytes, imageDims, owner)
+	}
+
+	async createProgram(kernel, options) {
+		const native = this._need()
+		if (!options || !options.name) throw new Error('createProgram requires a kernel name')
+		const gwi = options.globalWorkItems === undefined ? [] :
+			typeof options.globalWorkItems === 'number' ? [options.globalWorkItems] : Array.from(options.globalWorkItems)
+		const handle = native.createProgram(this._ctx, String(kernel), options.name, gwi, options.workItemsPerGroup || 0)
+		return { name: options.name, globalWorkItems: gwi, workItemsPerGroup: options.workItemsPerGroup || 0, _handle: handle }
+	}
+
+	async runProgram(program, params, queue) {
+		const native = this._need()
+		const names = []
+		const values = []
+		for (const name of Object.keys(params)) {
+			const v = params[name]
+			if (v === undefined || v === null) continue
+			names.push(name)
+			if (Buffer.isBuffer(v)) {
+				if (!v._handle) throw new Error(`runProgram: parameter '${name}' is a plain Buffer, not an OpenCLBuffer`)
+				values.push(v._handle)
+			} else {
+				values.push(typeof v === 'boolean' ? (v ? 1 : 0) : v)
+			}
+		}
+		const q = queue === undefined ? this.queue.process : queue
+		return native.runProgram(this._ctx, program._handle, names, values, q, this.profile)
+	}
+
+	async waitFinish(queue) {
+		return this._need().waitFinish(this._ctx, queue === undefined ? this.queue.process : queue)
+	}
+
+	logBuffers() {
+		const s = this._need().bufferStats(this._ctx)
+		console.log(`phaneron HIP buffers: ${s.liveBuffers} live (${s.liveBytes} bytes), ${s.pooledBytes} bytes pooled`)
+		return s
+	}
+}
+
+module.exports = { clContext }

@@ -1,0 +1,455 @@
+/* ph_napi.c - raw N-API glue between node and libphaneron_hip.so (include/phaneron_hip.h).
+ *
+ * This is the thin addon the reference would load INSTEAD of `nodencl`: node/index.js wraps
+ * these functions into the nodencl-shaped `clContext` / `OpenCLBuffer` objects that
+ * src/process and src/clJobQueue.ts call.  Plain C, no node-addon-api; nothing here computes
+ * pixels - every entry forwards to the C ABI.
+ *
+ * Blocking calls (waitFinish, hostAccess, timed runProgram) run on the libuv thread pool via
+ * napi_async_work and settle a promise, so the JS thread is never blocked - the reference
+ * awaits these (clJobQueue.ts:126-131, io.ts:79-98).
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/phaneron_hip.h"
+
+#define NAPI_OK(call)                                                         \
+  do {                                                                        \
+    if ((call) != napi_ok) {                                                  \
+      napi_throw_error(env, NULL, "N-API call failed: " #call);               \
+      return NULL;                                                            \
+    }                                                                         \
+  } while (0)
+
+typedef struct {
+  ph_ctx *ctx;
+} ctx_box;
+
+typedef struct {
+  ph_buf *buf; /* NULL once the last reference has been released */
+} buf_box;
+
+typedef struct {
+  ph_program *prog;
+} prog_box;
+
+static napi_value throw_ph(napi_env env, const char *what) {
+  char msg[640];
+  snprintf(msg, sizeof msg, "%s: %s", what, ph_last_error(NULL));
+  napi_throw_error(env, NULL, msg);
+  return NULL;
+}
+
+static void ctx_finalize(napi_env env, void *data, void *hint) {
+  (void)env, (void)hint;
+  ctx_box *b = (ctx_box *)data;
+  if (b->ctx) ph_ctx_destroy(b->ctx);
+  free(b);
+}
+static void buf_finalize(napi_env env, void *data, void *hint) {
+  (void)env, (void)hint;
+  buf_box *b = (buf_box *)data;
+  while (b->buf && ph_buf_refcount(b->buf) > 1) ph_buf_release(b->buf); /* leaked refs die with the JS object */
+  if (b->buf) ph_buf_release(b->buf);
+  free(b);
+}
+static void prog_finalize(napi_env env, void *data, void *hint) {
+  (void)env, (void)hint;
+  prog_box *b = (prog_box *)data;
+  if (b->prog) ph_program_destroy(b->prog);
+  free(b);
+}
+static void noop_finalize(napi_env env, void *data, void *hint) { (void)env, (void)data, (void)hint; }
+
+static int get_box(napi_env env, napi_value v, void **out) { return napi_get_value_external(env, v, out) == napi_ok && *out; }
+
+static int get_i32(napi_env env, napi_value v, int32_t *out) { return napi_get_value_int32(env, v, out) == napi_ok; }
+
+/* createContext(deviceIndex) -> external */
+static napi_value CreateContext(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], out;
+  int32_t dev = 0;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc >= 1) get_i32(env, argv[0], &dev);
+  ctx_box *box = (ctx_box *)calloc(1, sizeof *box);
+  if (ph_ctx_create(dev, &box->ctx) != PH_OK) {
+    free(box);
+    return throw_ph(env, "createContext");
+  }
+  NAPI_OK(napi_create_external(env, box, ctx_finalize, NULL, &out));
+  return out;
+}
+
+/* contextInfo(ctx) -> { vendor, device } */
+static napi_value ContextInfo(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], out, s;
+  ctx_box *c;
+  char vendor[128], device[256];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&c)) return throw_ph(env, "contextInfo: bad context");
+  if (ph_ctx_info(c->ctx, vendor, sizeof vendor, device, sizeof device) != PH_OK) return throw_ph(env, "contextInfo");
+  NAPI_OK(napi_create_object(env, &out));
+  NAPI_OK(napi_create_string_utf8(env, vendor, NAPI_AUTO_LENGTH, &s));
+  NAPI_OK(napi_set_named_property(env, out, "vendor", s));
+  NAPI_OK(napi_create_string_utf8(env, device, NAPI_AUTO_LENGTH, &s));
+  NAPI_OK(napi_set_named_property(env, out, "device", s));
+  return out;
+}
+
+/* createBuffer(ctx, bytes, access, svm, width, height, owner) -> { handle, buffer }
+ * `buffer` is a node Buffer over the pinned host mirror: the reference treats OpenCLBuffer as a
+ * Buffer (Buffer.copy / readFloatLE / concat, displayFrame). */
+static napi_value CreateBuffer(napi_env env, napi_callback_info info) {
+  size_t argc = 7;
+  napi_value argv[7], out, handle, nodebuf;
+  ctx_box *c;
+  double bytes = 0;
+  int32_t access = 0, svm = 0, w = 0, h = 0;
+  char owner[256] = "";
+  size_t len = 0;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 2 || !get_box(env, argv[0], (void **)&c)) return throw_ph(env, "createBuffer: bad context");
+  if (napi_get_value_double(env, argv[1], &bytes) != napi_ok || bytes < 0) return throw_ph(env, "createBuffer: bad size");
+  if (argc > 2) get_i32(env, argv[2], &access);
+  if (argc > 3) get_i32(env, argv[3], &svm);
+  if (argc > 4) get_i32(env, argv[4], &w);
+  if (argc > 5) get_i32(env, argv[5], &h);
+  if (argc > 6) napi_get_value_string_utf8(env, argv[6], owner, sizeof owner, &len);
+  buf_box *box = (buf_box *)calloc(1, sizeof *box);
+  if (ph_buf_create(c->ctx, (size_t)bytes, access, svm, w, h, owner, &box->buf) != PH_OK) {
+    free(box);
+    return throw_ph(env, "createBuffer");
+  }
+  void *host = ph_buf_host_ptr(box->buf);
+  if (!host) {
+    ph_buf_release(box->buf);
+    free(box);
+    return throw_ph(env, "createBuffer (host mirror)");
+  }
+  NAPI_OK(napi_create_external(env, box, buf_finalize, NULL, &handle));
+  NAPI_OK(napi_create_external_buffer(env, (size_t)bytes, host, noop_finalize, NULL, &nodebuf));
+  NAPI_OK(napi_create_object(env, &out));
+  NAPI_OK(napi_set_named_property(env, out, "handle", handle));
+  NAPI_OK(napi_set_named_property(env, out, "buffer", nodebuf));
+  return out;
+}
+
+static napi_value BufAddRef(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], out;
+  buf_box *b;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&b) || !b->buf) {
+    napi_throw_error(env, NULL, "addRef on a released buffer");
+    return NULL;
+  }
+  ph_buf_addref(b->buf);
+  NAPI_OK(napi_create_int32(env, ph_buf_refcount(b->buf), &out));
+  return out;
+}
+
+static napi_value BufRelease(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], out;
+  buf_box *b;
+  int left;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&b) || !b->buf) {
+    napi_throw_error(env, NULL, "release on a released buffer");
+    return NULL;
+  }
+  left = ph_buf_refcount(b->buf) - 1;
+  ph_buf_release(b->buf);
+  if (left <= 0) b->buf = NULL;
+  NAPI_OK(napi_create_int32(env, left, &out));
+  return out;
+}
+
+static napi_value BufRefCount(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], out;
+  buf_box *b;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&b)) return throw_ph(env, "refCount: bad buffer");
+  NAPI_OK(napi_create_int32(env, b->buf ? ph_buf_refcount(b->buf) : 0, &out));
+  return out;
+}
+
+/* ---- async plumbing ----------------------------------------------------------------------- */
+typedef enum { JOB_WAIT, JOB_HOST_ACCESS, JOB_RUN_TIMED } job_kind;
+
+typedef struct {
+  job_kind kind;
+  napi_async_work work;
+  napi_deferred deferred;
+  ph_ctx *ctx;
+  int queue;
+  /* host access */
+  ph_buf *buf;
+  int dir;
+  const void *src;
+  size_t src_bytes;
+  napi_ref src_ref; /* keeps the source Buffer alive while the copy runs */
+  /* timed run */
+  ph_program *prog;
+  ph_arg *args;
+  char *names; /* storage for argument names */
+  int n_args;
+  ph_run_timings timings;
+  /* result */
+  int rc;
+  char err[512];
+} job;
+
+static void job_execute(napi_env env, void *data) {
+  (void)env;
+  job *j = (job *)data;
+  switch (j->kind) {
+    case JOB_WAIT: j->rc = ph_wait_finish(j->ctx, j->queue); break;
+    case JOB_HOST_ACCESS: j->rc = ph_buf_host_access(j->buf, j->dir, j->queue, j->src, j->src_bytes); break;
+    case JOB_RUN_TIMED: j->rc = ph_run_program(j->ctx, j->prog, j->args, j->n_args, j->queue, &j->timings); break;
+  }
+  if (j->rc != PH_OK) snprintf(j->err, sizeof j->err, "%s", ph_last_error(NULL)); /* thread-local: copy here */
+}
+
+static napi_value timings_object(napi_env env, const ph_run_timings *t) {
+  napi_value o, v;
+  napi_create_object(env, &o);
+  napi_create_uint32(env, t->data_to_kernel, &v);
+  napi_set_named_property(env, o, "dataToKernel", v);
+  napi_create_uint32(env, t->kernel_exec, &v);
+  napi_set_named_property(env, o, "kernelExec", v);
+  napi_create_uint32(env, t->total_time, &v);
+  napi_set_named_property(env, o, "totalTime", v);
+  return o;
+}
+
+static void job_complete(napi_env env, napi_status status, void *data) {
+  job *j = (job *)data;
+  napi_value v;
+  (void)status;
+  if (j->rc == PH_OK) {
+    if (j->kind == JOB_RUN_TIMED)
+      v = timings_object(env, &j->timings);
+    else
+      napi_get_undefined(env, &v);
+    napi_resolve_deferred(env, j->deferred, v);
+  } else {
+    napi_value msg;
+    napi_create_string_utf8(env, j->err, NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &v);
+    napi_reject_deferred(env, j->deferred, v);
+  }
+  if (j->src_ref) napi_delete_reference(env, j->src_ref);
+  napi_delete_async_work(env, j->work);
+  free(j->args);
+  free(j->names);
+  free(j);
+}
+
+static napi_value start_job(napi_env env, job *j, const char *name) {
+  napi_value promise, resname;
+  if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+      napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &resname) != napi_ok ||
+      napi_create_async_work(env, NULL, resname, job_execute, job_complete, j, &j->work) != napi_ok ||
+      napi_queue_async_work(env, j->work) != napi_ok) {
+    free(j->args);
+    free(j->names);
+    free(j);
+    napi_throw_error(env, NULL, "could not start async work");
+    return NULL;
+  }
+  return promise;
+}
+
+/* waitFinish(ctx, queue) -> Promise<void> */
+static napi_value WaitFinish(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  ctx_box *c;
+  int32_t q = PH_QUEUE_PROCESS;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&c)) return throw_ph(env, "waitFinish: bad context");
+  if (argc > 1) get_i32(env, argv[1], &q);
+  job *j = (job *)calloc(1, sizeof *j);
+  j->kind = JOB_WAIT, j->ctx = c->ctx, j->queue = q;
+  return start_job(env, j, "phaneron.waitFinish");
+}
+
+/* hostAccess(buf, dir, queue, srcBuffer?) -> Promise<void> */
+static napi_value HostAccess(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  buf_box *b;
+  int32_t dir = PH_HOST_NONE, q = 0;
+  bool is_buf = false;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 2 || !get_box(env, argv[0], (void **)&b) || !b->buf) {
+    napi_throw_error(env, NULL, "hostAccess on a released buffer");
+    return NULL;
+  }
+  get_i32(env, argv[1], &dir);
+  if (argc > 2) get_i32(env, argv[2], &q);
+  job *j = (job *)calloc(1, sizeof *j);
+  j->kind = JOB_HOST_ACCESS, j->buf = b->buf, j->dir = dir, j->queue = q;
+  if (argc > 3 && napi_is_buffer(env, argv[3], &is_buf) == napi_ok && is_buf) {
+    void *p;
+    napi_get_buffer_info(env, argv[3], &p, &j->src_bytes);
+    j->src = p;
+    napi_create_reference(env, argv[3], 1, &j->src_ref);
+  }
+  return start_job(env, j, "phaneron.hostAccess");
+}
+
+/* createProgram(ctx, kernelSrc, name, globalWorkItems[], workItemsPerGroup) -> external */
+static napi_value CreateProgram(napi_env env, napi_callback_info info) {
+  size_t argc = 5, len = 0, srclen = 0;
+  napi_value argv[5], out;
+  ctx_box *c;
+  char name[128] = "";
+  char *src = NULL;
+  uint32_t gwi[2] = {0, 0}, n_dims = 0, wipg = 0;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 3 || !get_box(env, argv[0], (void **)&c)) return throw_ph(env, "createProgram: bad context");
+  if (napi_get_value_string_utf8(env, argv[1], NULL, 0, &srclen) == napi_ok) {
+    src = (char *)malloc(srclen + 1);
+    napi_get_value_string_utf8(env, argv[1], src, srclen + 1, &srclen);
+  }
+  napi_get_value_string_utf8(env, argv[2], name, sizeof name, &len);
+  if (argc > 3) {
+    bool is_arr = false;
+    napi_is_array(env, argv[3], &is_arr);
+    if (is_arr) {
+      napi_get_array_length(env, argv[3], &n_dims);
+      for (uint32_t i = 0; i < n_dims && i < 2; ++i) {
+        napi_value e;
+        napi_get_element(env, argv[3], i, &e);
+        napi_get_value_uint32(env, e, &gwi[i]);
+      }
+      if (n_dims > 2) n_dims = 2;
+    } else if (napi_get_value_uint32(env, argv[3], &gwi[0]) == napi_ok) {
+      n_dims = 1;
+    }
+  }
+  if (argc > 4) napi_get_value_uint32(env, argv[4], &wipg);
+  prog_box *box = (prog_box *)calloc(1, sizeof *box);
+  int rc = ph_program_create(c->ctx, src, name, gwi, (int)n_dims, wipg, &box->prog);
+  free(src);
+  if (rc != PH_OK) {
+    free(box);
+    return throw_ph(env, "createProgram");
+  }
+  NAPI_OK(napi_create_external(env, box, prog_finalize, NULL, &out));
+  return out;
+}
+
+/* runProgram(ctx, prog, names[], values[], queue, timed) -> RunTimings | Promise<RunTimings>
+ * values[i] is a buffer handle (external) or a number; float-valued kernel arguments are the
+ * ones named in FLOAT_ARGS, everything else numeric is passed as a 32-bit integer. */
+static const char *FLOAT_ARGS[] = {"scale", "offsetX", "offsetY", "mix", "wipe", NULL};
+
+static napi_value RunProgram(napi_env env, napi_callback_info info) {
+  size_t argc = 6;
+  napi_value argv[6];
+  ctx_box *c;
+  prog_box *p;
+  uint32_t n = 0;
+  int32_t q = PH_QUEUE_PROCESS;
+  bool timed = false;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 4 || !get_box(env, argv[0], (void **)&c) || !get_box(env, argv[1], (void **)&p))
+    return throw_ph(env, "runProgram: bad context/program");
+  napi_get_array_length(env, argv[2], &n);
+  if (argc > 4) get_i32(env, argv[4], &q);
+  if (argc > 5) napi_get_value_bool(env, argv[5], &timed);
+  ph_arg *args = (ph_arg *)calloc(n ? n : 1, sizeof *args);
+  char *names = (char *)calloc(n ? n : 1, 64);
+  for (uint32_t i = 0; i < n; ++i) {
+    napi_value nm, val;
+    napi_valuetype t;
+    size_t len;
+    napi_get_element(env, argv[2], i, &nm);
+    napi_get_element(env, argv[3], i, &val);
+    napi_get_value_string_utf8(env, nm, names + 64 * i, 64, &len);
+    args[i].name = names + 64 * i;
+    napi_typeof(env, val, &t);
+    if (t == napi_external) {
+      buf_box *b;
+      napi_get_value_external(env, val, (void **)&b);
+      if (!b || !b->buf) {
+        free(args), free(names);
+        napi_throw_error(env, NULL, "runProgram: a buffer argument has already been released");
+        return NULL;
+      }
+      args[i].kind = PH_ARG_BUF, args[i].v.buf = b->buf;
+    } else {
+      double d = 0;
+      napi_coerce_to_number(env, val, &val);
+      napi_get_value_double(env, val, &d);
+      int is_float = 0;
+      for (const char **f = FLOAT_ARGS; *f; ++f) is_float |= (0 == strcmp(*f, args[i].name));
+      if (is_float)
+        args[i].kind = PH_ARG_F32, args[i].v.f32 = (float)d;
+      else
+        args[i].kind = PH_ARG_I32, args[i].v.i32 = (int32_t)d;
+    }
+  }
+  if (timed) {
+    job *j = (job *)calloc(1, sizeof *j);
+    j->kind = JOB_RUN_TIMED, j->ctx = c->ctx, j->prog = p->prog, j->args = args, j->names = names;
+    j->n_args = (int)n, j->queue = q;
+    return start_job(env, j, "phaneron.runProgram");
+  }
+  int rc = ph_run_program(c->ctx, p->prog, args, (int)n, q, NULL);
+  free(args), free(names);
+  if (rc != PH_OK) return throw_ph(env, "runProgram");
+  ph_run_timings zero = {0, 0, 0};
+  return timings_object(env, &zero);
+}
+
+/* bufferStats(ctx) -> { liveBuffers, liveBytes, pooledBytes } (nodencl logBuffers) */
+static napi_value BufferStats(napi_env env, napi_callback_info info) {
+  size_t argc = 1, a = 0, b = 0, p = 0;
+  napi_value argv[1], out, v;
+  ctx_box *c;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&c)) return throw_ph(env, "bufferStats: bad context");
+  ph_ctx_buffer_stats(c->ctx, &a, &b, &p);
+  NAPI_OK(napi_create_object(env, &out));
+  napi_create_double(env, (double)a, &v), napi_set_named_property(env, out, "liveBuffers", v);
+  napi_create_double(env, (double)b, &v), napi_set_named_property(env, out, "liveBytes", v);
+  napi_create_double(env, (double)p, &v), napi_set_named_property(env, out, "pooledBytes", v);
+  return out;
+}
+
+static napi_value AbiVersion(napi_env env, napi_callback_info info) {
+  napi_value v;
+  (void)info;
+  napi_create_int32(env, ph_abi_version(), &v);
+  return v;
+}
+
+NAPI_MODULE_INIT() {
+  static const struct {
+    const char *name;
+    napi_callback fn;
+  } fns[] = {
+      {"abiVersion", AbiVersion},   {"createContext", CreateContext}, {"contextInfo", ContextInfo},
+      {"createBuffer", CreateBuffer}, {"bufAddRef", BufAddRef},       {"bufRelease", BufRelease},
+      {"bufRefCount", BufRefCount}, {"hostAccess", HostAccess},       {"waitFinish", WaitFinish},
+      {"createProgram", CreateProgram}, {"runProgram", RunProgram},   {"bufferStats", BufferStats},
+  };
+  for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
+    napi_value f;
+    if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok ||
+        napi_set_named_property(env, exports, fns[i].name, f) != napi_ok)
+      return NULL;
+  }
+  return exports;
+}

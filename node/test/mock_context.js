@@ -1,0 +1,75 @@
+'use strict'
+// A recording stand-in for a nodencl-shaped clContext: no device, every call is appended to a
+// trace.  The same scenario (scenario.js) is run against the REFERENCE's operator code
+// (type-stripped, build container only -> tests/golden/host_trace.json) and against node/ -
+// the traces must be identical: same buffers, programs, kernel parameters, refcounts, order.
+const crypto = require('crypto')
+
+function makeMock() {
+	const trace = []
+	let nextBuf = 0
+	let nextProg = 0
+	const live = new Map()
+	const hash = (b) => crypto.createHash('sha256').update(b).digest('hex').slice(0, 16)
+
+	const describe = (v) => {
+		if (Buffer.isBuffer(v) && v._mockId !== undefined) return { buf: v._mockId, refs: v._refs, ts: v.timestamp }
+		if (typeof v === 'number') return Number.isInteger(v) ? v : Math.fround(v)
+		if (typeof v === 'boolean') return v
+		return String(v)
+	}
+
+	const ctx = {
+		queue: { load: 0, process: 1, unload: 2 },
+		trace,
+		live,
+		async initialise() {},
+		getPlatformInfo() { return { vendor: 'mock', devices: [{ type: 'mock' }] } },
+		async createBuffer(numBytes, dir, type, dims, owner) {
+			const buf = Buffer.alloc(numBytes)
+			buf._mockId = nextBuf++
+			buf._refs = 1
+			buf.timestamp = 0
+			buf.loadstamp = 0
+			buf.numBytes = numBytes
+			buf.hostAccess = async (d, q, src) => {
+				trace.push({ op: 'hostAccess', buf: buf._mockId, dir: d, queue: q === undefined ? null : q, src: src ? { bytes: src.length, sha: hash(src) } : null })
+				if (src) src.copy(buf)
+			}
+			buf.addRef = () => { buf._refs++; trace.push({ op: 'addRef', buf: buf._mockId, refs: buf._refs }) }
+			buf.release = () => {
+				buf._refs--
+				trace.push({ op: 'release', buf: buf._mockId, refs: buf._refs })
+				if (buf._refs === 0) live.delete(buf._mockId)
+			}
+			live.set(buf._mockId, buf)
+			trace.push({ op: 'createBuffer', buf: buf._mockId, numBytes, dir, type, dims: dims ? { width: dims.width, height: dims.height } : null, owner: owner || null })
+			return buf
+		},
+		async createProgram(kernel, options) {
+			const prog = { id: nextProg++, name: options.name }
+			trace.push({
+				op: 'createProgram', prog: prog.id, name: options.name,
+				globalWorkItems: options.globalWorkItems === undefined ? null : (typeof options.globalWorkItems === 'number' ? options.globalWorkItems : Array.from(options.globalWorkItems)),
+				workItemsPerGroup: options.workItemsPerGroup === undefined ? null : options.workItemsPerGroup
+			})
+			return prog
+		},
+		async runProgram(program, params, queue) {
+			const p = {}
+			const data = {}
+			for (const k of Object.keys(params)) {
+				p[k] = describe(params[k])
+				// small read-only operands (matrices, LUTs, flip vectors): pin their contents too
+				if (Buffer.isBuffer(params[k]) && params[k].length <= 262144 && !/^(output|input|prev|cur|next|l\dIn|input\d|maskIn)$/.test(k)) data[k] = hash(params[k])
+			}
+			trace.push({ op: 'runProgram', prog: program.id, name: program.name, queue, params: p, data })
+			return { dataToKernel: 0, kernelExec: 0, totalTime: 0 }
+		},
+		async waitFinish(queue) { trace.push({ op: 'waitFinish', queue: queue === undefined ? null : queue }) },
+		logBuffers() {}
+	}
+	return ctx
+}
+
+module.exports = { makeMock }

@@ -78,7 +78,7 @@ def strip(src, local_modules):
     # optional chaining (node 12)
     src = src.replace("?.", ".")
     # V8 7.8 rejects a class field literally named `in`
-    src = re.sub(r"^(\s*)in = ", r"\1['in'] = ", src, flags=re.M)
+    src = re.sub(r"^(\s*)in = ", r"\1;['in'] = ", src, flags=re.M)
 
     # exports
     names = []

@@ -446,6 +446,21 @@ int ph_program_destroy(ph_program *p) {
 
 const char *ph_program_kernel(const ph_program *p) { return p ? p->kernel.c_str() : ""; }
 
+// nodencl lets a caller map a buffer for writing (hostAccess('writeonly')), fill it and launch
+// without an explicit unmap (loadSave.ts:76-99): flush such mirrors on the launch queue first.
+static int flush_dirty_args(ph_ctx *ctx, const ph_arg *args, int n, int queue) {
+  for (int i = 0; i < n; ++i) {
+    if (args[i].kind != PH_ARG_BUF || !args[i].v.buf) continue;
+    ph_buf *b = args[i].v.buf;
+    if (b->host_dirty && b->hptr) {
+      PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, b->bytes, hipMemcpyHostToDevice, stream_of(ctx, queue)));
+      b->host_dirty = false;
+      b->lut_dirty = (b->bytes == 65536 * 4);
+    }
+  }
+  return PH_OK;
+}
+
 static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue) {
   ph_buf *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr, *o = nullptr;
   double num = 0;
@@ -556,6 +571,8 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
 int ph_run_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args, int queue, ph_run_timings *t) {
   if (!ctx || !prog || (n_args > 0 && !args)) return fail(PH_E_INVALID, "ph_run_program: NULL argument");
   int rc = set_device(ctx);
+  if (rc) return rc;
+  rc = flush_dirty_args(ctx, args, n_args, queue);
   if (rc) return rc;
   if (!t) return dispatch(ctx, prog, args, n_args, queue);
   hipStream_t s = stream_of(ctx, queue);

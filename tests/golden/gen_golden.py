@@ -113,6 +113,12 @@ def main():
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)
         f.write("\n")
+    # host-logic trace: the reference's own operator + dispatcher code against the recording mock
+    tr = subprocess.run(["node", os.path.join(ROOT, "node", "test", "scenario.js"),
+                         os.path.join(ROOT, "oracle", "_ref", "js")], check=True, capture_output=True, text=True).stdout
+    with open(os.path.join(HERE, "host_trace.json"), "w") as f:
+        json.dump(json.loads(tr), f, indent=0, sort_keys=True)
+        f.write("\n")
     np.savez_compressed(os.path.join(HERE, "kernels.npz"), **out)
     print("wrote %d kernel cases, host_maths.json, kat.json" % len(out))
 

@@ -1,0 +1,108 @@
+"""The drop-in boundary in the reference's own host language (node/):
+  CPU: the JS operator layer + dispatcher produce the SAME trace against a recording mock as the
+       reference's own (type-stripped) operator code did when the goldens were generated;
+       the N-API addon builds and loads and exposes the nodencl-shaped entry points.
+  GPU: the JS layer on the real addon reproduces the oracle bit for bit."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+NODE = shutil.which("node")
+needs_node = pytest.mark.skipif(NODE is None, reason="node is not installed")
+
+
+@needs_node
+def test_js_operator_layer_matches_reference_trace():
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "scenario.js"), os.path.join(ROOT, "node")],
+                         check=True, capture_output=True, text=True).stdout
+    got = json.loads(out)
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "host_trace.json")))
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, "trace event %d differs:\n got  %s\n want %s" % (i, json.dumps(g)[:400], json.dumps(w)[:400])
+
+
+@needs_node
+def test_reference_trace_still_reproducible_here():
+    """Where the reference checkout exists the golden trace must regenerate identically."""
+    ref_js = os.path.join(ROOT, "oracle", "_ref", "js", "clJobQueue.js")
+    if not os.path.exists(ref_js):
+        pytest.skip("oracle/_ref/js not built (reference checkout absent)")
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "scenario.js"), os.path.dirname(ref_js)],
+                         check=True, capture_output=True, text=True).stdout
+    assert json.loads(out) == json.load(open(os.path.join(ROOT, "tests", "golden", "host_trace.json")))
+
+
+@needs_node
+def test_napi_addon_builds_loads_and_refuses_without_gpu():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "node"))
+    from phaneron_amd import build as hipbuild
+    hipbuild.build()
+    subprocess.run([sys.executable, os.path.join(ROOT, "node", "build.py")], check=True)
+    js = ("const a=require('%s');"
+          "const want=['abiVersion','createContext','contextInfo','createBuffer','bufAddRef','bufRelease','bufRefCount',"
+          "'hostAccess','waitFinish','createProgram','runProgram','bufferStats'];"
+          "for (const k of want) if (typeof a[k] !== 'function') { console.log('missing', k); process.exit(2) }"
+          "console.log(a.abiVersion())") % os.path.join(ROOT, "node", "phaneron_napi.node")
+    r = subprocess.run([NODE, "-e", js], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip() == "1"
+    import torch
+    if not torch.cuda.is_available():
+        js = ("const {clContext}=require('%s'); const c=new clContext({deviceIndex:0});"
+              "c.initialise().then(()=>{console.log('unexpected');process.exit(3)},e=>{console.log(e.message);})") % \
+            os.path.join(ROOT, "node", "index.js")
+        r = subprocess.run([NODE, "-e", js], capture_output=True, text=True)
+        assert "no HIP device" in r.stdout, r.stdout + r.stderr
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_layer_end_to_end_on_gpu(tmp_path):
+    import frames
+    from oracle import orc
+    w, h, n = 1920, 96, 4
+    layers = [frames.v210_random(w, h, frames.layer_seed(3, i)) for i in range(n)]
+    for i, l in enumerate(layers):
+        l.tofile(tmp_path / ("layer%d.bin" % i))
+    pip = dict(flipH=False, flipV=False, anchorX=0.0, anchorY=0.0, scaleX=0.5, scaleY=0.5, rotate=-0.0,
+               offsetX=-0.25, offsetY=0.25)
+    yw, yh = 320, 48
+    fields = [frames.rgba_random(yw, yh, 700 + i) for i in range(4)]
+    for i, f in enumerate(fields):
+        f.tofile(tmp_path / ("field%d.bin" % i))
+    job = dict(channel=dict(width=w, height=h, layers=["layer%d.bin" % i for i in range(n)], readSpec="709",
+                            writeSpec="2020", pip=pip),
+               yadif=dict(width=yw, height=yh, frames=["field%d.bin" % i for i in range(4)], tff=True))
+    (tmp_path / "job.json").write_text(json.dumps(job))
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "gpu_run.js"), str(tmp_path)], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads((tmp_path / "result.json").read_text())
+    assert res["rampCompare"] == 0  # the reference scripts' "Compare returned 0"
+    assert "gfx950" in res["platform"]["devices"][0]["name"]
+
+    rd = (orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
+    rgba = [orc.v210_read(l, w, h, *rd) for l in layers]
+    m = orc.transform_matrix(w, h, False, False, 0.0, 0.0, 0.5, 0.5, -0.25, 0.25, -0.0)
+    rgba[1] = orc.transform(rgba[1], m, w, h)
+    want = orc.v210_write(orc.combine(rgba), w, h, 0, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    got = np.fromfile(tmp_path / "channel_out.bin", np.uint32)
+    assert np.array_equal(got, want)
+
+    # yadif send_field, tff: outputs for cur = field1 and field2, two each (yadif.ts:125-145)
+    assert res["yadifTimestamps"] == [2, 3, 4, 5]
+    k = 0
+    for cur in (1, 2):
+        for second in (False, True):
+            parity = 1 ^ (0 if second else 1)
+            want = orc.yadif(fields[cur - 1], fields[cur], fields[cur + 1], parity, True, False)
+            got = np.fromfile(tmp_path / ("yadif_out%d.bin" % k), np.float32)
+            assert np.array_equal(got.view(np.uint32), want.reshape(-1).view(np.uint32)), k
+            k += 1
