@@ -79,5 +79,7 @@ def test_no_cpu_fallback():
 def test_product_never_imports_oracle():
     for path in glob.glob(os.path.join(ROOT, "phaneron_amd", "**", "*"), recursive=True) + \
             glob.glob(os.path.join(ROOT, "node", "**", "*"), recursive=True):
+        if os.sep + "test" + os.sep in path:
+            continue  # node/test/ is test infrastructure (it drives the checker on purpose)
         if os.path.isfile(path) and path.endswith((".py", ".cpp", ".hip", ".h", ".js", ".c")):
             assert "oracle" not in open(path).read().replace("no oracle", ""), path
