@@ -141,30 +141,27 @@ def main():
         ins, out = ring[i % args.ring]
         ctx.fused_v210_combine(ins, out, w, h, *rd, *wr)
 
-    for i in range(args.warmup):
-        step(i)
-    ctx.wait()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    from phaneron_amd import multigpu
+
+    def sync():
+        ctx.wait()
         torch.cuda.synchronize()
+
+    # HIP events on the library's own stream bracket the same K launches the wall clock times
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(args.steps):
+
+    def timed_step(i):
+        if i == args.warmup:
+            ev0.record(stream)
         step(i)
-    ev1.record(stream)
-    ctx.wait()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        dist.barrier()
-        torch.cuda.synchronize()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if i == args.warmup + args.steps - 1:
+            ev1.record(stream)
+
+    elapsed = multigpu.timed_steps(timed_step, args.steps, args.warmup, sync, dist, device)
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # average launch duration on the kernel's stream
 
+    lds = ctx.lut_info(rd[1])["lds_bytes"] and ctx.lut_info(wr[1])["lds_bytes"] and not os.environ.get("PH_BENCH_GLOBAL_LUT")
+    kernel_name = ("fused_v210_combine_lds_kernel<%d,4>" if lds else "fused_v210_combine_kernel<%d>") % n
     if rank == 0:
         fps = world * args.steps / elapsed
         algo_bytes = (n + 1) * frame_words * 4  # each input byte once + each output byte once
@@ -173,14 +170,14 @@ def main():
             "metric": "frames/sec, 4-layer 2160p50 composite pipeline (v210 unpack->CSC->combine->CSC->v210 pack)",
             "value": round(fps, 2), "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u10->f32->u10",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "headline: 1 channel per GPU, %d x %dx%d v210 layers -> fused unpack/CSC(709->2020)/"
                                    "combine_%d/CSC/pack -> 1 v210 frame" % (n, w, h, n),
                        "ring_frame_sets": args.ring, "channels": world, "realtime_target_fps": 50},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(),
-                         "kernel": "fused_v210_combine_kernel<%d>" % n, "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": round(kernel_ms, 5)},
         }
         if world == 1 and args.cpu_seconds > 0:

@@ -1,0 +1,58 @@
+// Types of the nodencl-shaped surface implemented by index.js (what phaneron imports from 'nodencl').
+/// <reference types="node" />
+
+export interface ImageDims {
+	width: number
+	height: number
+}
+
+export interface RunTimings {
+	dataToKernel: number
+	kernelExec: number
+	totalTime: number
+}
+
+export type BufDir = 'readonly' | 'writeonly' | 'readwrite'
+export type BufSVMType = 'none' | 'coarse' | 'fine'
+export type HostAccessDir = 'readonly' | 'writeonly' | 'none'
+
+export interface OpenCLBuffer extends Buffer {
+	readonly numBytes: number
+	readonly owner: string
+	readonly imageDims?: ImageDims
+	readonly creationTime: [number, number]
+	timestamp: number
+	loadstamp: number
+	hostAccess(dir: HostAccessDir, queue?: number, src?: Buffer): Promise<void>
+	addRef(): void
+	release(): void
+	refCount(): number
+}
+
+export interface OpenCLProgram {
+	readonly name: string
+	readonly globalWorkItems: number[]
+	readonly workItemsPerGroup: number
+}
+
+export interface KernelParams {
+	[key: string]: unknown
+}
+
+export interface PlatformInfo {
+	vendor: string
+	name: string
+	devices: Array<{ type: string; name: string; vendor: string }>
+}
+
+export class clContext {
+	constructor(params?: { platformIndex?: number; deviceIndex?: number; overlapping?: boolean; profile?: boolean })
+	readonly queue: { load: number; process: number; unload: number }
+	initialise(): Promise<void>
+	getPlatformInfo(): PlatformInfo
+	createBuffer(numBytes: number, bufDir: BufDir, bufType: BufSVMType, imageDims?: ImageDims, owner?: string): Promise<OpenCLBuffer>
+	createProgram(kernel: string, options: { name: string; globalWorkItems?: number | Uint32Array | number[]; workItemsPerGroup?: number }): Promise<OpenCLProgram>
+	runProgram(program: OpenCLProgram, params: KernelParams, queue?: number): Promise<RunTimings>
+	waitFinish(queue?: number): Promise<void>
+	logBuffers(): { liveBuffers: number; liveBytes: number; pooledBytes: number }
+}

@@ -1,0 +1,128 @@
+"""The N > 1 path on CPU: channel partitioning, the ROUTE hand-off (torch.distributed P2P,
+gloo here / RCCL on GPUs) and the bench timing contract, at world_size 2."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from phaneron_amd import multigpu as mg
+
+
+def test_channel_partition_round_robin_and_blocks():
+    assert [mg.channel_rank(c, 8) for c in range(8)] == list(range(8))
+    assert mg.channels_of_rank(1, 8, 2) == [1, 3, 5, 7]
+    # config 5: 16 channels, 2 per GPU: channel k and k+8 never share a GPU
+    for k in range(16):
+        assert mg.channel_rank(k, 8, 2) != mg.channel_rank((k + 8) % 16, 8, 2)
+    assert mg.channels_of_rank(3, 16, 8, 2) == [6, 7]
+
+
+def test_route_plan_is_consistent_between_ranks():
+    routes = [mg.Route(src=(k + 8) % 16, dst=k) for k in range(16)]
+    sends, recvs = {}, {}
+    for r in range(8):
+        p = mg.plan_routes(routes, r, 8, 2)
+        assert not p.local
+        for rt, peer in p.sends:
+            sends.setdefault((r, peer), []).append(rt)
+        for rt, peer in p.recvs:
+            recvs.setdefault((peer, r), []).append(rt)
+    assert sends == recvs  # same routes, same order, on both ends of every rank pair
+    assert sum(len(v) for v in sends.values()) == 16
+    # everything on one GPU: the reference's zero-copy case
+    p = mg.plan_routes(routes, 0, 1, 0)
+    assert len(p.local) == 16 and not p.sends and not p.recvs
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_ch, numel = 4, 4096
+        routes = [mg.Route(src=(k + 2) % 4, dst=k) for k in range(4)] + [mg.Route(src=0, dst=2)]
+        mine = mg.channels_of_rank(rank, n_ch, world)
+        ex = mg.RouteExchange(routes, rank, world, numel, torch.float32, "cpu")
+        results = []
+        for frame in range(3):
+            frames = {c: torch.full((numel,), float(100 * frame + c)) for c in mine}
+            got = ex.exchange(frames)
+            for rt in routes:
+                if mg.channel_rank(rt.dst, world) == rank:
+                    # several routes can end at one channel in this test: the later one wins the dict
+                    results.append((frame, rt.dst, float(got[rt.dst][0]), float(got[rt.dst][-1])))
+        # timing contract: max over ranks, barrier on both sides
+        import time
+        el = mg.timed_steps(lambda i: time.sleep(0.01 * (rank + 1)), steps=3, warmup=1, sync=lambda: None, dist=dist,
+                            device="cpu")
+        q.put((rank, results, el, ex.traffic_bytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_route_exchange_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    by_rank = {r: (res, el, tb) for r, res, el, tb in out}
+    # channel c lives on rank c % 2; route (src=(k+2)%4 -> k) stays on one rank (local alias),
+    # route (0 -> 2) is also local; so add a crossing check below with explicit values
+    for rank, (res, el, tb) in by_rank.items():
+        for frame, dst, first, last in res:
+            assert first == last
+            assert first in (100 * frame + (dst + 2) % 4, 100 * frame + 0)
+    # both ranks report the same (max) elapsed time: rank 1 sleeps 2x longer
+    assert abs(by_rank[0][1] - by_rank[1][1]) < 1e-9
+    assert by_rank[0][1] >= 3 * 0.02 * 0.9
+
+
+def _worker_cross(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # 4 channels in blocks of 2 per rank: channel k shows channel (k + 2) % 4 -> every route crosses ranks
+        routes = [mg.Route(src=(k + 2) % 4, dst=k) for k in range(4)]
+        mine = mg.channels_of_rank(rank, 4, world, 2)
+        ex = mg.RouteExchange(routes, rank, world, 1024, torch.float32, "cpu", channels_per_rank=2)
+        frames = {c: torch.arange(1024, dtype=torch.float32) + 1000 * c for c in mine}
+        got = ex.exchange(frames)
+        q.put((rank, mine, {d: float(t[0]) for d, t in got.items()}, len(ex.plan.sends), len(ex.plan.recvs)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_route_exchange_every_route_crosses_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_cross, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, mine, got, ns, nr in out:
+        assert mine == ([0, 1] if rank == 0 else [2, 3])
+        assert ns == 2 and nr == 2
+        for dst, first in got.items():
+            assert dst in mine and first == 1000.0 * ((dst + 2) % 4)
