@@ -40,10 +40,45 @@ __device__ __forceinline__ float lds_lut_get(const LutView &v, uint32_t idx) {
   return __uint_as_float(a + ((lo - a) & 0xffffu));
 }
 
+// Same value with ONE LDS read: the anchor is replaced by the fitted arithmetic predictor
+// (ph_lut.h LutPredictor; identical IEEE operation order to ph_lut.cpp pred_eval).  `r` is the
+// rounded, clamped index still in float form.
+__device__ __forceinline__ float lds_lut_get_pred(const LutView &v, float r, uint32_t idx) {
+  const LutPredictor &p = v.pred;
+  const float u = fma_rn(r, p.a, p.b);
+  float q = fma_rn(u, p.q[4], p.q[3]);
+  q = fma_rn(u, q, p.q[2]);
+  q = fma_rn(u, q, p.q[1]);
+  q = fma_rn(u, q, p.q[0]);
+  const float pw = (u * u) * q;
+  const float toe = r * p.toe_slope;
+  const uint32_t pb = __float_as_uint(r < p.knee ? toe : pw);
+  const uint32_t lo = *reinterpret_cast<const uint16_t *>(g_lds + v.lo_off + 2 * idx);
+  const int32_t d = (int32_t)((lo - pb) << 16) >> 16;  // sign-extended 16-bit difference
+  return __uint_as_float(pb + (uint32_t)d);
+}
+
+// index of a gamma-domain value, as float (rounded, clamped) and as integer: v210.ts:68
+__device__ __forceinline__ float lut_index_f(float t) {
+  float x = __builtin_rintf(t * 65535.0f);
+  x = __builtin_fmaxf(x, 0.0f);
+  return __builtin_fminf(x, 65535.0f);
+}
+
+// KP = how many of the three channel lookups use the predictor (0: anchors only).  Splitting the
+// lookups between the two forms balances LDS reads against VALU work.
+template <int KP>
+__device__ __forceinline__ float lut_get_ch(const LutView &lut, float t, int ch) {
+  const float rf = lut_index_f(t);
+  const uint32_t idx = (uint32_t)rf;
+  return ch < KP ? lds_lut_get_pred(lut, rf, idx) : lds_lut_get(lut, idx);
+}
+
+template <int KP>
 __device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const ReadK &k, const LutView &lut) {
-  const float r = lds_lut_get(lut, sat_u16_rte(dot4(y, cb, cr, 1.0f, k.r) * 65535.0f));
-  const float g = lds_lut_get(lut, sat_u16_rte(dot4(y, cb, cr, 1.0f, k.g) * 65535.0f));
-  const float b = lds_lut_get(lut, sat_u16_rte(dot4(y, cb, cr, 1.0f, k.b) * 65535.0f));
+  const float r = lut_get_ch<KP>(lut, dot4(y, cb, cr, 1.0f, k.r), 0);
+  const float b = lut_get_ch<KP>(lut, dot4(y, cb, cr, 1.0f, k.b), 1);
+  const float g = lut_get_ch<KP>(lut, dot4(y, cb, cr, 1.0f, k.g), 2);
   return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
                      dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
 }
@@ -83,7 +118,7 @@ __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const Wr
 // ------------------------------------------------------------------------------------------
 // fused [v210 read] x N -> combine_N -> v210 write, two LDS phases per tile of 1024*P quads
 // ------------------------------------------------------------------------------------------
-template <int N, int P>
+template <int N, int P, int KP>
 __global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(FusedLdsArgs a) {
   const ReadK rk = load_read_k(a.f.rd_cm, a.f.rd_gm);
   const WriteK wk = load_write_k(a.f.wr_cm);
@@ -113,7 +148,7 @@ __global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(Fused
           const Yuv6 q = unpack_quad(w);
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
-            const float4 t = read_px_lds(q.y[j], q.cb[j >> 1], q.cr[j >> 1], rk, a.rd);
+            const float4 t = read_px_lds<KP>(q.y[j], q.cb[j >> 1], q.cr[j >> 1], rk, a.rd);
             if (l == 0) {
               acc[p][3 * j] = t.x, acc[p][3 * j + 1] = t.y, acc[p][3 * j + 2] = t.z;
             } else {  // combine.ts:45-65
@@ -166,7 +201,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_kernel(const uint4 *_
     const Yuv6 q = unpack_quad(in[(size_t)line * quads_per_line_pitch + g]);
     float4 *o = out + (size_t)f * 6;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) o[j] = read_px_lds(q.y[j], q.cb[j >> 1], q.cr[j >> 1], k, lut);
+    for (int j = 0; j < 6; ++j) o[j] = read_px_lds<0>(q.y[j], q.cb[j >> 1], q.cr[j >> 1], k, lut);
   }
 }
 
@@ -202,13 +237,27 @@ static hipError_t allow_lds(K kernel, uint32_t bytes) {
                              (int)bytes);
 }
 
-template <int N, int P>
-static hipError_t launch_fused_np(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
-  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P>, lds);
+template <int N, int P, int KP>
+static hipError_t launch_fused_npk(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
+  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P, KP>, lds);
   if (e != hipSuccess) return e;
   const uint32_t slices = (a.f.total_quads + kLdsBlock - 1) / kLdsBlock;  // never more workgroups than 1024-quad slices
-  fused_v210_combine_lds_kernel<N, P><<<slices < grid ? slices : grid, kLdsBlock, lds, s>>>(a);
+  fused_v210_combine_lds_kernel<N, P, KP><<<slices < grid ? slices : grid, kLdsBlock, lds, s>>>(a);
   return hipGetLastError();
+}
+
+// KP (predictor lookups per pixel): 2 when the reader table has a verified predictor, else 0.
+// PH_FUSED_KP=0|2|3 overrides for A/B runs.
+template <int N, int P>
+static hipError_t launch_fused_np(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
+  static const int kp_env = [] {
+    const char *e = getenv("PH_FUSED_KP");
+    return e ? atoi(e) : -1;
+  }();
+  int kp = a.rd.pred.ok ? (kp_env >= 0 ? kp_env : 2) : 0;
+  if (kp == 3) return launch_fused_npk<N, P, 3>(s, a, grid, lds);
+  if (kp == 2) return launch_fused_npk<N, P, 2>(s, a, grid, lds);
+  return launch_fused_npk<N, P, 0>(s, a, grid, lds);
 }
 
 // P = quads per lane per tile.  5 is the most that stays in 128 VGPRs (4 waves/SIMD, i.e. the one

@@ -16,12 +16,23 @@
 
 namespace ph {
 
+// Optional arithmetic predictor for the anchor (saves one of the two LDS reads): for index i
+// with r = (float)i,
+//     pred(r) = r < knee ? r * toe_slope : (u*u) * q(u),  u = fma(r, a, b),  q = degree-4 Horner
+// fitted so that |bits(table[i]) - bits(pred(r))| < 32768 for ALL 65536 entries (checked with
+// the same IEEE operations on the host); then table[i] = bits(pred) + sext16(lo16[i] - bits(pred)).
+struct LutPredictor {
+  float a, b, q[5], toe_slope, knee;
+  uint32_t ok;
+};
+
 struct LutView {        // passed by value to kernels
   const uint32_t *blob; // device: [anchors u32 x n_anchors][lo16 x 65536], 16-byte aligned size
   uint32_t bytes;       // multiple of 16; 0 = not compressible
   uint32_t toe;         // T
   uint32_t shift;       // S
   uint32_t lo_off;      // byte offset of lo16[] inside the blob (= 4 * n_anchors, 16-aligned)
+  LutPredictor pred;    // pred.ok == 0: anchors only
 };
 
 }  // namespace ph
