@@ -35,25 +35,28 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source for gfx950 and link libphaneron_hip.so.  Returns its path."""
-    if not force and not _stale():
+def build(force=False, verbose=False, extra_flags=(), variant=None):
+    """Compile every HIP source for gfx950 and link libphaneron_hip.so.  Returns its path.
+    variant: build lib/libphaneron_hip_<variant>.so with extra_flags (A/B experiments)."""
+    global LIB
+    lib = LIB if variant is None else os.path.join(LIB_DIR, "libphaneron_hip_%s.so" % variant)
+    if variant is None and not force and not _stale():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     cc = hipcc()
     objs = []
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ("" if variant is None else "_" + variant) + ".o")
         cmd = [cc, "--offload-arch=" + ARCH, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + COMMON + list(extra_flags)
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libphaneron_hip.so")
+# PHANERON_HIP_LIB selects an alternative build of the same library (A/B kernel experiments)
+LIB_PATH = os.environ.get("PHANERON_HIP_LIB") or os.path.join(_HERE, "lib", "libphaneron_hip.so")
 
 QUEUE_LOAD, QUEUE_PROCESS, QUEUE_UNLOAD = 0, 1, 2
 HOST_READONLY, HOST_WRITEONLY, HOST_NONE = 0, 1, 2

@@ -21,86 +21,101 @@ namespace ph {
 
 constexpr int kLdsBlock = 1024;
 
+// A/B knobs (profiles/): PH_SCHED_LEVEL 0 = no scheduling fences, 1 = one per layer / quad,
+// 2 = one per pixel pair.  PH_TABLE_DMA 1 = table swaps by global_load_lds (LDS-DMA, no VGPRs).
+#ifndef PH_SCHED_LEVEL
+#define PH_SCHED_LEVEL 0
+#endif
+#ifndef PH_TABLE_DMA
+#define PH_TABLE_DMA 1
+#endif
+#define PH_FENCE(level)                                         \
+  do {                                                          \
+    if (PH_SCHED_LEVEL >= (level)) __builtin_amdgcn_sched_barrier(0); \
+  } while (0)
+
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
 // all lanes of the workgroup copy the table blob global -> LDS (16 bytes per lane per step)
 __device__ __forceinline__ void lds_lut_load(const LutView &v) {
+  const uint32_t n = v.bytes / 16;
+#if PH_TABLE_DMA
+  // LDS-DMA: each wave instruction moves 1 KiB global -> LDS (wave-uniform LDS base + lane*16)
+  // without touching VGPRs; all of a wave's pieces are in flight before the single wait.
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint4 *src = reinterpret_cast<const uint4 *>(v.blob);
+  for (uint32_t base = wave * 64; base < n; base += kLdsBlock) {
+    const uint32_t i = base + lane;
+    if (i < n)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i),
+                                       (__attribute__((address_space(3))) void *)(g_lds + 16 * base), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
   const uint4 *src = reinterpret_cast<const uint4 *>(v.blob);
   uint4 *dst = reinterpret_cast<uint4 *>(g_lds);
-  const uint32_t n = v.bytes / 16;
   for (uint32_t i = threadIdx.x; i < n; i += kLdsBlock) dst[i] = src[i];
+#endif
 }
 
-// exact table value for index idx (0..65535): two LDS reads, see ph_lut.h
-__device__ __forceinline__ float lds_lut_get(const LutView &v, uint32_t idx) {
-  const uint32_t blk = v.toe + ((idx - v.toe) >> v.shift);  // wraps huge for idx < toe
-  const uint32_t b = idx < blk ? idx : blk;
-  const uint32_t a = *reinterpret_cast<const uint32_t *>(g_lds + 4 * b);
-  const uint32_t lo = *reinterpret_cast<const uint16_t *>(g_lds + v.lo_off + 2 * idx);
-  return __uint_as_float(a + ((lo - a) & 0xffffu));
+// Per-kernel constants of the lookup arithmetic.  The rounded, clamped index is never
+// converted to an integer: adding 2^23 to the clamped float rounds it to nearest-even (what
+// convert_ushort_sat_rte does) and leaves M + idx in the float's bit pattern (M = 0x4B000000);
+// all following integer steps work on that biased value with the bias folded into constants.
+struct LutK {
+  uint32_t shift;
+  uint32_t blk_bias;    // + (bits >> S)      -> M + T + ((idx - T) >> S)   (for idx >= T)
+  uint32_t anchor_off;  // + ((M + b) << 2)   -> byte address of anchor[b]      (mod 2^32)
+  uint32_t delta_off;   // + ((M + idx) << 1) -> byte address of delta[idx]     (mod 2^32)
+};
+__device__ __forceinline__ LutK make_lut_k(const LutView &v) {
+  constexpr uint32_t M = 0x4B000000u;  // bits of 8388608.0f
+  LutK k;
+  k.shift = v.shift;
+  k.blk_bias = v.toe - (v.toe >> v.shift) + M - (M >> v.shift);
+  k.anchor_off = 0u - (M << 2);
+  k.delta_off = v.delta_off - (M << 1);
+  return k;
 }
 
-// Same value with ONE LDS read: the anchor is replaced by the fitted arithmetic predictor
-// (ph_lut.h LutPredictor; identical IEEE operation order to ph_lut.cpp pred_eval).  `r` is the
-// rounded, clamped index still in float form.
-__device__ __forceinline__ float lds_lut_get_pred(const LutView &v, float r, uint32_t idx) {
-  const LutPredictor &p = v.pred;
-  const float u = fma_rn(r, p.a, p.b);
-  float q = fma_rn(u, p.q[4], p.q[3]);
-  q = fma_rn(u, q, p.q[2]);
-  q = fma_rn(u, q, p.q[1]);
-  q = fma_rn(u, q, p.q[0]);
-  const float pw = (u * u) * q;
-  const float toe = r * p.toe_slope;
-  const uint32_t pb = __float_as_uint(r < p.knee ? toe : pw);
-  const uint32_t lo = *reinterpret_cast<const uint16_t *>(g_lds + v.lo_off + 2 * idx);
-  const int32_t d = (int32_t)((lo - pb) << 16) >> 16;  // sign-extended 16-bit difference
-  return __uint_as_float(pb + (uint32_t)d);
+// table[clamp(rint(x), 0, 65535)] for x = (gamma- or linear-domain value) * 65535:
+// 3 float ops, 5 integer ops, 2 LDS reads (anchor + delta, ph_lut.h)
+__device__ __forceinline__ float lds_lut_at(const LutK &k, float x) {
+  x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 65535.0f);  // v_med3_f32; NaN -> 0 like the reference
+  const uint32_t bits = __float_as_uint(x + 8388608.0f);     // M + idx, rounded to nearest even
+  const uint32_t blk = (bits >> k.shift) + k.blk_bias;
+  const uint32_t bm = bits < blk ? bits : blk;                // M + min(idx, T + ((idx - T) >> S))
+  const uint32_t a = *reinterpret_cast<const uint32_t *>(g_lds + ((bm << 2) + k.anchor_off));
+  const uint32_t d = *reinterpret_cast<const uint16_t *>(g_lds + ((bits << 1) + k.delta_off));
+  return __uint_as_float(a + d);
 }
 
-// index of a gamma-domain value, as float (rounded, clamped) and as integer: v210.ts:68
-__device__ __forceinline__ float lut_index_f(float t) {
-  float x = __builtin_rintf(t * 65535.0f);
-  x = __builtin_fmaxf(x, 0.0f);
-  return __builtin_fminf(x, 65535.0f);
-}
-
-// KP = how many of the three channel lookups use the predictor (0: anchors only).  Splitting the
-// lookups between the two forms balances LDS reads against VALU work.
-template <int KP>
-__device__ __forceinline__ float lut_get_ch(const LutView &lut, float t, int ch) {
-  const float rf = lut_index_f(t);
-  const uint32_t idx = (uint32_t)rf;
-  return ch < KP ? lds_lut_get_pred(lut, rf, idx) : lds_lut_get(lut, idx);
-}
-
-template <int KP>
-__device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const ReadK &k, const LutView &lut) {
-  const float r = lut_get_ch<KP>(lut, dot4(y, cb, cr, 1.0f, k.r), 0);
-  const float b = lut_get_ch<KP>(lut, dot4(y, cb, cr, 1.0f, k.b), 1);
-  const float g = lut_get_ch<KP>(lut, dot4(y, cb, cr, 1.0f, k.g), 2);
+__device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const ReadK &k, const LutK &lut) {
+  const float r = lds_lut_at(lut, dot4(y, cb, cr, 1.0f, k.r) * 65535.0f);
+  const float g = lds_lut_at(lut, dot4(y, cb, cr, 1.0f, k.g) * 65535.0f);
+  const float b = lds_lut_at(lut, dot4(y, cb, cr, 1.0f, k.b) * 65535.0f);
   return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
                      dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
 }
 
-__device__ __forceinline__ Yuv1 write_px_lds(float r, float g, float b, const WriteK &k, const LutView &lut) {
-  const float gr = lds_lut_get(lut, sat_u16_rte(r * 65535.0f));
-  const float gg = lds_lut_get(lut, sat_u16_rte(g * 65535.0f));
-  const float gb = lds_lut_get(lut, sat_u16_rte(b * 65535.0f));
+__device__ __forceinline__ Yuv1 write_px_lds(float r, float g, float b, const WriteK &k, const LutK &lut) {
+  const float gr = lds_lut_at(lut, r * 65535.0f);
+  const float gg = lds_lut_at(lut, g * 65535.0f);
+  const float gb = lds_lut_at(lut, b * 65535.0f);
   Yuv1 o;
   o.y = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
   o.u = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.u));
   o.v = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.v));
   return o;
 }
-__device__ __forceinline__ uint32_t write_px_luma_lds(float r, float g, float b, const WriteK &k, const LutView &lut) {
-  const float gr = lds_lut_get(lut, sat_u16_rte(r * 65535.0f));
-  const float gg = lds_lut_get(lut, sat_u16_rte(g * 65535.0f));
-  const float gb = lds_lut_get(lut, sat_u16_rte(b * 65535.0f));
+__device__ __forceinline__ uint32_t write_px_luma_lds(float r, float g, float b, const WriteK &k, const LutK &lut) {
+  const float gr = lds_lut_at(lut, r * 65535.0f);
+  const float gg = lds_lut_at(lut, g * 65535.0f);
+  const float gb = lds_lut_at(lut, b * 65535.0f);
   return sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
 }
 
-__device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const WriteK &wk, const LutView &lut) {
+__device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const WriteK &wk, const LutK &lut) {
   uint32_t y[6], u[3], v[3];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -109,7 +124,7 @@ __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const Wr
       y[j] = c.y, u[j >> 1] = c.u, v[j >> 1] = c.v;
     } else {
       y[j] = write_px_luma_lds(rgb[3 * j], rgb[3 * j + 1], rgb[3 * j + 2], wk, lut);
-      __builtin_amdgcn_sched_barrier(0);
+      PH_FENCE(2);
     }
   }
   return pack_quad(y, u, v);
@@ -118,10 +133,11 @@ __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const Wr
 // ------------------------------------------------------------------------------------------
 // fused [v210 read] x N -> combine_N -> v210 write, two LDS phases per tile of 1024*P quads
 // ------------------------------------------------------------------------------------------
-template <int N, int P, int KP>
+template <int N, int P>
 __global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(FusedLdsArgs a) {
   const ReadK rk = load_read_k(a.f.rd_cm, a.f.rd_gm);
   const WriteK wk = load_write_k(a.f.wr_cm);
+  const LutK rlut = make_lut_k(a.rd), wlut = make_lut_k(a.wr);
   // Every workgroup owns one contiguous, equally sized range of quads (all CUs finish together)
   // and walks it in tiles of 1024*P quads; only the last tile of a range is partially filled.
   const uint32_t per_wg = (a.f.total_quads + gridDim.x - 1) / gridDim.x;
@@ -135,36 +151,35 @@ __global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(Fused
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       uint32_t f = tile_begin + p * kLdsBlock + threadIdx.x;  // width % 48 == 0: flat index == offset
-      if (p * kLdsBlock >= wg_end - tile_begin) break;         // uniform: this slice of the tile is empty
       f = f < wg_end ? f : wg_end - 1;                         // tail lanes recompute the last quad
-      {
+      if (p * kLdsBlock < wg_end - tile_begin) {               // uniform: skip empty slices of the last tile
         // layers are streamed one at a time with a one-deep prefetch: 8 VGPRs of input in
         // flight instead of 4*N, which is what keeps P quads of accumulators in registers
         uint4 w = reinterpret_cast<const uint4 *>(a.f.layers[0])[f];
 #pragma unroll
+        for (int i = 0; i < 18; ++i) acc[p][i] = 0.0f;
+#pragma unroll 1  // rolled: one copy of the per-layer code whatever N is (I-cache, compile time)
         for (int l = 0; l < N; ++l) {
           uint4 nxt = w;
           if (l + 1 < N) nxt = reinterpret_cast<const uint4 *>(a.f.layers[l + 1])[f];
           const Yuv6 q = unpack_quad(w);
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
-            const float4 t = read_px_lds<KP>(q.y[j], q.cb[j >> 1], q.cr[j >> 1], rk, a.rd);
-            if (l == 0) {
-              acc[p][3 * j] = t.x, acc[p][3 * j + 1] = t.y, acc[p][3 * j + 2] = t.z;
-            } else {  // combine.ts:45-65
-              const float kk = 1.0f - t.w;
-              acc[p][3 * j] = fma_rn(acc[p][3 * j], kk, t.x);
-              acc[p][3 * j + 1] = fma_rn(acc[p][3 * j + 1], kk, t.y);
-              acc[p][3 * j + 2] = fma_rn(acc[p][3 * j + 2], kk, t.z);
-            }
+            const float4 t = read_px_lds(q.y[j], q.cb[j >> 1], q.cr[j >> 1], rk, rlut);
+            // acc starts at 0, so layer 0 goes through the same fma: fma(0, k, t) == t, and the
+            // sign of a zero can never reach the packed output (combine.ts:45-65 for l >= 1)
+            const float kk = 1.0f - t.w;
+            acc[p][3 * j] = fma_rn(acc[p][3 * j], kk, t.x);
+            acc[p][3 * j + 1] = fma_rn(acc[p][3 * j + 1], kk, t.y);
+            acc[p][3 * j + 2] = fma_rn(acc[p][3 * j + 2], kk, t.z);
             // Pin the accumulators here.  Without this LLVM sinks the whole decode/gamut/combine
             // arithmetic to its first use in phase 2 (past the barrier and the table swap) and
             // keeps the 2 raw LDS words of every lookup alive instead: hundreds of spilled VGPRs.
             asm volatile("" : "+v"(acc[p][3 * j]), "+v"(acc[p][3 * j + 1]), "+v"(acc[p][3 * j + 2]));
-            if (j & 1) __builtin_amdgcn_sched_barrier(0);  // schedule pixel pairs, not whole quads
+            if (j & 1) PH_FENCE(2);
           }
           w = nxt;
-          __builtin_amdgcn_sched_barrier(0);  // keep the compiler from hoisting every layer's load
+          PH_FENCE(1);
         }
       }
     }
@@ -174,10 +189,11 @@ __global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(Fused
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const uint32_t f = tile_begin + p * kLdsBlock + threadIdx.x;
-      if (p * kLdsBlock >= wg_end - tile_begin) break;
-      const uint4 packed = write_quad_lds(acc[p], wk, a.wr);
-      if (f < wg_end) reinterpret_cast<uint4 *>(a.f.out)[f] = packed;
-      __builtin_amdgcn_sched_barrier(0);
+      if (p * kLdsBlock < wg_end - tile_begin) {
+        const uint4 packed = write_quad_lds(acc[p], wk, wlut);
+        if (f < wg_end) reinterpret_cast<uint4 *>(a.f.out)[f] = packed;
+      }
+      PH_FENCE(1);
     }
     __syncthreads();
   }
@@ -194,6 +210,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_kernel(const uint4 *_
                                                                    const float *__restrict__ cm,
                                                                    const float *__restrict__ gm, LutView lut) {
   const ReadK k = load_read_k(cm, gm);
+  const LutK lk = make_lut_k(lut);
   lds_lut_load(lut);
   __syncthreads();
   for (uint32_t f = blockIdx.x * kLdsBlock + threadIdx.x; f < total_quads; f += gridDim.x * kLdsBlock) {
@@ -201,7 +218,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_kernel(const uint4 *_
     const Yuv6 q = unpack_quad(in[(size_t)line * quads_per_line_pitch + g]);
     float4 *o = out + (size_t)f * 6;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) o[j] = read_px_lds<0>(q.y[j], q.cb[j >> 1], q.cr[j >> 1], k, lut);
+    for (int j = 0; j < 6; ++j) o[j] = read_px_lds(q.y[j], q.cb[j >> 1], q.cr[j >> 1], k, lk);
   }
 }
 
@@ -211,6 +228,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_write_lds_kernel(const float4 
                                                                     uint32_t line_step, const float *__restrict__ cm,
                                                                     LutView lut) {
   const WriteK k = load_write_k(cm);
+  const LutK lk = make_lut_k(lut);
   lds_lut_load(lut);
   __syncthreads();
   const uint32_t total = quads_per_line * lines;  // width % 48 == 0: used == pitch
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_write_lds_kernel(const float4 
       const float4 p = px[j];
       rgb[3 * j] = p.x, rgb[3 * j + 1] = p.y, rgb[3 * j + 2] = p.z;
     }
-    out[(size_t)line * quads_per_line + g] = write_quad_lds(rgb, k, lut);
+    out[(size_t)line * quads_per_line + g] = write_quad_lds(rgb, k, lk);
   }
 }
 
@@ -237,27 +255,13 @@ static hipError_t allow_lds(K kernel, uint32_t bytes) {
                              (int)bytes);
 }
 
-template <int N, int P, int KP>
-static hipError_t launch_fused_npk(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
-  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P, KP>, lds);
-  if (e != hipSuccess) return e;
-  const uint32_t slices = (a.f.total_quads + kLdsBlock - 1) / kLdsBlock;  // never more workgroups than 1024-quad slices
-  fused_v210_combine_lds_kernel<N, P, KP><<<slices < grid ? slices : grid, kLdsBlock, lds, s>>>(a);
-  return hipGetLastError();
-}
-
-// KP (predictor lookups per pixel): 2 when the reader table has a verified predictor, else 0.
-// PH_FUSED_KP=0|2|3 overrides for A/B runs.
 template <int N, int P>
 static hipError_t launch_fused_np(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
-  static const int kp_env = [] {
-    const char *e = getenv("PH_FUSED_KP");
-    return e ? atoi(e) : -1;
-  }();
-  int kp = a.rd.pred.ok ? (kp_env >= 0 ? kp_env : 2) : 0;
-  if (kp == 3) return launch_fused_npk<N, P, 3>(s, a, grid, lds);
-  if (kp == 2) return launch_fused_npk<N, P, 2>(s, a, grid, lds);
-  return launch_fused_npk<N, P, 0>(s, a, grid, lds);
+  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P>, lds);
+  if (e != hipSuccess) return e;
+  const uint32_t slices = (a.f.total_quads + kLdsBlock - 1) / kLdsBlock;  // never more workgroups than 1024-quad slices
+  fused_v210_combine_lds_kernel<N, P><<<slices < grid ? slices : grid, kLdsBlock, lds, s>>>(a);
+  return hipGetLastError();
 }
 
 // P = quads per lane per tile.  5 is the most that stays in 128 VGPRs (4 waves/SIMD, i.e. the one

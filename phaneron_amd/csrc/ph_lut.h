@@ -5,34 +5,23 @@
 // table (v210.ts:68-70,148-150).  From global memory that is ~300 G lookups/s on MI355X
 // (one cache line per lane); from LDS it is ~4800 G/s.  The table does not fit in LDS as f32,
 // but its bit patterns p[i] are locally smooth, so it is stored as
-//     anchor[b]  (u32)  b = i            for i <  T   (the steep toe: exact value)
-//                       b = T + (i-T)>>S for i >= T   (minimum bit pattern of a 2^S block)
-//     lo16[i]    (u16)  p[i] & 0xffff
-// and p[i] = anchor[b] + ((lo16[i] - anchor[b]) & 0xffff), exact whenever every block's
-// max-min < 65536 (verified when the table is built; otherwise the LUT stays "plain" and the
-// kernels that need LDS tables refuse it and the gather kernels are used).
+//     anchor[b]  (u32)  b = i              for i <  T  (the steep toe: exact value)
+//                       b = T + (i-T)>>S   for i >= T  (minimum bit pattern of a 2^S block)
+//     delta[i]   (u16)  p[i] - anchor[b]
+// and p[i] = anchor[b] + delta[i]: exact whenever every block's max-min < 65536 (verified
+// exhaustively when the table is built; otherwise the LUT stays "plain", the LDS kernels
+// refuse it and the global-gather kernels are used).
 #pragma once
 #include <stdint.h>
 
 namespace ph {
 
-// Optional arithmetic predictor for the anchor (saves one of the two LDS reads): for index i
-// with r = (float)i,
-//     pred(r) = r < knee ? r * toe_slope : (u*u) * q(u),  u = fma(r, a, b),  q = degree-4 Horner
-// fitted so that |bits(table[i]) - bits(pred(r))| < 32768 for ALL 65536 entries (checked with
-// the same IEEE operations on the host); then table[i] = bits(pred) + sext16(lo16[i] - bits(pred)).
-struct LutPredictor {
-  float a, b, q[5], toe_slope, knee;
-  uint32_t ok;
-};
-
-struct LutView {        // passed by value to kernels
-  const uint32_t *blob; // device: [anchors u32 x n_anchors][lo16 x 65536], 16-byte aligned size
-  uint32_t bytes;       // multiple of 16; 0 = not compressible
-  uint32_t toe;         // T
-  uint32_t shift;       // S
-  uint32_t lo_off;      // byte offset of lo16[] inside the blob (= 4 * n_anchors, 16-aligned)
-  LutPredictor pred;    // pred.ok == 0: anchors only
+struct LutView {         // passed by value to kernels
+  const uint32_t *blob;  // device: [anchors u32 x n_anchors][delta u16 x 65536], size % 16 == 0
+  uint32_t bytes;        // 0 = not compressible
+  uint32_t toe;          // T (a multiple of 2^S)
+  uint32_t shift;        // S
+  uint32_t delta_off;    // byte offset of delta[] inside the blob (= 4 * n_anchors, 16-aligned)
 };
 
 }  // namespace ph

@@ -8,15 +8,11 @@
 namespace ph {
 
 struct LutHostInfo {
-  uint32_t bytes = 0, toe = 0, shift = 0, lo_off = 0;
+  uint32_t bytes = 0, toe = 0, shift = 0, delta_off = 0;
 };
 
 // max LDS a single workgroup can hold on gfx950 is 160 KiB; tables must leave room for nothing else
 constexpr uint32_t kLutMaxLdsBytes = 160 * 1024;
-
-// Fit the anchor predictor (ph_lut.h) to a gamma->linear style table; pred.ok = 1 only if the
-// exhaustive check passes.  Returns pred.ok.
-bool lut_fit_predictor(const float *lut65536, LutPredictor &pred);
 
 // Returns false when the table cannot be represented exactly within max_bytes.
 bool lut_compress(const float *lut65536, uint32_t max_bytes, std::vector<uint32_t> &blob, LutHostInfo &info);
