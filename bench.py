@@ -161,7 +161,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # average launch duration on the kernel's stream
 
     lds = ctx.lut_info(rd[1])["lds_bytes"] and ctx.lut_info(wr[1])["lds_bytes"] and not os.environ.get("PH_BENCH_GLOBAL_LUT")
-    kernel_name = ("fused_v210_combine_lds_kernel<%d,4>" if lds else "fused_v210_combine_kernel<%d>") % n
+    kernel_name = ("fused_v210_combine_lds_kernel<%d,...>" if lds else "fused_v210_combine_kernel<%d>") % n
     if rank == 0:
         fps = world * args.steps / elapsed
         algo_bytes = (n + 1) * frame_words * 4  # each input byte once + each output byte once

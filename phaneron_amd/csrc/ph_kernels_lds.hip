@@ -37,6 +37,7 @@ constexpr int kLdsBlock = 1024;
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
 // all lanes of the workgroup copy the table blob global -> LDS (16 bytes per lane per step)
+template <int BS = kLdsBlock>
 __device__ __forceinline__ void lds_lut_load(const LutView &v) {
   const uint32_t n = v.bytes / 16;
 #if PH_TABLE_DMA
@@ -44,7 +45,7 @@ __device__ __forceinline__ void lds_lut_load(const LutView &v) {
   // without touching VGPRs; all of a wave's pieces are in flight before the single wait.
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint4 *src = reinterpret_cast<const uint4 *>(v.blob);
-  for (uint32_t base = wave * 64; base < n; base += kLdsBlock) {
+  for (uint32_t base = wave * 64; base < n; base += BS) {
     const uint32_t i = base + lane;
     if (i < n)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i),
@@ -54,7 +55,7 @@ __device__ __forceinline__ void lds_lut_load(const LutView &v) {
 #else
   const uint4 *src = reinterpret_cast<const uint4 *>(v.blob);
   uint4 *dst = reinterpret_cast<uint4 *>(g_lds);
-  for (uint32_t i = threadIdx.x; i < n; i += kLdsBlock) dst[i] = src[i];
+  for (uint32_t i = threadIdx.x; i < n; i += BS) dst[i] = src[i];
 #endif
 }
 
@@ -133,8 +134,8 @@ __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const Wr
 // ------------------------------------------------------------------------------------------
 // fused [v210 read] x N -> combine_N -> v210 write, two LDS phases per tile of 1024*P quads
 // ------------------------------------------------------------------------------------------
-template <int N, int P>
-__global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(FusedLdsArgs a) {
+template <int N, int P, int BS>
+__global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs a) {
   const ReadK rk = load_read_k(a.f.rd_cm, a.f.rd_gm);
   const WriteK wk = load_write_k(a.f.wr_cm);
   const LutK rlut = make_lut_k(a.rd), wlut = make_lut_k(a.wr);
@@ -143,16 +144,16 @@ __global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(Fused
   const uint32_t per_wg = (a.f.total_quads + gridDim.x - 1) / gridDim.x;
   const uint32_t wg_begin = blockIdx.x * per_wg;
   const uint32_t wg_end = wg_begin + per_wg < a.f.total_quads ? wg_begin + per_wg : a.f.total_quads;
-  const uint32_t tile_quads = kLdsBlock * P;
+  const uint32_t tile_quads = BS * P;
   for (uint32_t tile_begin = wg_begin; tile_begin < wg_end; tile_begin += tile_quads) {
     float acc[P][18];
-    lds_lut_load(a.rd);
+    lds_lut_load<BS>(a.rd);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      uint32_t f = tile_begin + p * kLdsBlock + threadIdx.x;  // width % 48 == 0: flat index == offset
+      uint32_t f = tile_begin + p * BS + threadIdx.x;  // width % 48 == 0: flat index == offset
       f = f < wg_end ? f : wg_end - 1;                         // tail lanes recompute the last quad
-      if (p * kLdsBlock < wg_end - tile_begin) {               // uniform: skip empty slices of the last tile
+      if (p * BS < wg_end - tile_begin) {               // uniform: skip empty slices of the last tile
         // layers are streamed one at a time with a one-deep prefetch: 8 VGPRs of input in
         // flight instead of 4*N, which is what keeps P quads of accumulators in registers
         uint4 w = reinterpret_cast<const uint4 *>(a.f.layers[0])[f];
@@ -184,12 +185,12 @@ __global__ __launch_bounds__(kLdsBlock) void fused_v210_combine_lds_kernel(Fused
       }
     }
     __syncthreads();
-    lds_lut_load(a.wr);
+    lds_lut_load<BS>(a.wr);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const uint32_t f = tile_begin + p * kLdsBlock + threadIdx.x;
-      if (p * kLdsBlock < wg_end - tile_begin) {
+      const uint32_t f = tile_begin + p * BS + threadIdx.x;
+      if (p * BS < wg_end - tile_begin) {
         const uint4 packed = write_quad_lds(acc[p], wk, wlut);
         if (f < wg_end) reinterpret_cast<uint4 *>(a.f.out)[f] = packed;
       }
@@ -255,25 +256,30 @@ static hipError_t allow_lds(K kernel, uint32_t bytes) {
                              (int)bytes);
 }
 
-template <int N, int P>
-static hipError_t launch_fused_np(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
-  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P>, lds);
+template <int N, int P, int BS>
+static hipError_t launch_fused_npb(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
+  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P, BS>, lds);
   if (e != hipSuccess) return e;
-  const uint32_t slices = (a.f.total_quads + kLdsBlock - 1) / kLdsBlock;  // never more workgroups than 1024-quad slices
-  fused_v210_combine_lds_kernel<N, P><<<slices < grid ? slices : grid, kLdsBlock, lds, s>>>(a);
+  const uint32_t slices = (a.f.total_quads + BS - 1) / BS;  // never more workgroups than slices
+  fused_v210_combine_lds_kernel<N, P, BS><<<slices < grid ? slices : grid, BS, lds, s>>>(a);
   return hipGetLastError();
 }
 
-// P = quads per lane per tile.  5 is the most that stays in 128 VGPRs (4 waves/SIMD, i.e. the one
-// 1024-lane workgroup a CU can hold); 4 measured faster (99 vs 118 us at 2160p x4).  PH_FUSED_P=5
-// selects the larger tile for A/B runs.
+// Geometry: one workgroup per CU either way (the table fills the LDS).
+//   1024 lanes x P=4 quads : 128 VGPRs per lane, 4 waves per SIMD, tiles of 4096 quads
+//    512 lanes x P=11 quads: 256 VGPRs per lane, 2 waves per SIMD, tiles of 5632 quads - a whole
+//                            2160p share (5400 quads per CU) in ONE tile: 2 table loads, not 4
+// PH_FUSED_GEOM=1024|512 overrides for A/B runs.
 template <int N>
 static hipError_t launch_fused_n(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
-  static const int p = [] {
-    const char *e = getenv("PH_FUSED_P");
-    return (e && atoi(e) == 5) ? 5 : 4;
+  static const int geom_env = [] {
+    const char *e = getenv("PH_FUSED_GEOM");
+    return e ? atoi(e) : 0;
   }();
-  return p == 4 ? launch_fused_np<N, 4>(s, a, grid, lds) : launch_fused_np<N, 5>(s, a, grid, lds);
+  const uint32_t per_wg = (a.f.total_quads + grid - 1) / grid;
+  int geom = geom_env ? geom_env : (per_wg > 4096 ? 512 : 1024);
+  if (geom == 512) return launch_fused_npb<N, 11, 512>(s, a, grid, lds);
+  return launch_fused_npb<N, 4, 1024>(s, a, grid, lds);
 }
 
 hipError_t launch_fused_v210_combine_lds(hipStream_t s, int n, const FusedLdsArgs &a, uint32_t num_cus) {
