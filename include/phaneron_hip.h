@@ -165,6 +165,22 @@ int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *laye
                           const void *rd_gamma_lut, const void *rd_gamut_matrix9,
                           const void *wr_col_matrix12, const void *wr_gamma_lut);
 
+/* ---- fused layer compositor (no single reference equivalent): the reference's job batches
+ *      [transform] per layer (producer/mixer.ts:189-228) -> combine_N (combiner.ts:219-254) ->
+ *      v210 write (io.ts:152-164) as ONE kernel, so the N + 1 consumer-size f32 RGBA frames between
+ *      them never reach HBM.  Bit-identical to ph_transform x N + ph_combine + ph_v210_write.
+ *      A layer with matrix9 == NULL is used 1:1 and must have the output size.  n == 1: passthrough
+ *      of the single (transformed) layer as the combiner does.  out_width % 48 == 0; the writer
+ *      LUT must be registered (LDS form).  interlace as ph_v210_write. ------------------------- */
+typedef struct ph_layer {
+  const void *rgba;     /* device, float RGBA, width x height */
+  int width, height;
+  const void *matrix9;  /* device 3x3 transform matrix (ph_transform_matrix), or NULL */
+} ph_layer;
+int ph_compose_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers, void *out,
+                          uint32_t out_width, uint32_t out_height, uint32_t interlace,
+                          const void *wr_col_matrix12, const void *wr_gamma_lut);
+
 /* ---- gamma LUT placement.  The reference hands its kernels a 65536-entry f32 `gammaLut` buffer
  *      (loadSave.ts:65-73,152-160) and gathers from it 3x per pixel.  Registering the table's
  *      host contents lets the library keep an exact compressed copy for the CU's LDS

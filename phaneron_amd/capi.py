@@ -26,7 +26,7 @@ EXPORTS = [
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
-    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option",
+    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option", "ph_compose_write_v210",
 ]
 
 
@@ -40,6 +40,10 @@ class _ArgVal(C.Union):
 
 class PhArg(C.Structure):
     _fields_ = [("name", C.c_char_p), ("kind", C.c_int), ("v", _ArgVal)]
+
+
+class PhLayer(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("matrix9", C.c_void_p)]
 
 
 class RunTimings(C.Structure):
@@ -105,6 +109,7 @@ def lib():
         "ph_lut_unregister": (ci, [vp, vp]),
         "ph_lut_query": (ci, [vp, vp, C.POINTER(cu), C.POINTER(cu), C.POINTER(cu)]),
         "ph_ctx_set_option": (ci, [vp, C.c_char_p, ci]),
+        "ph_compose_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), vp, cu, cu, cu, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(l, name)  # AttributeError here = the header and the library disagree
@@ -259,6 +264,15 @@ class Context:
 
     def wipe(self, in0, in1, wipe, dst, width, height, queue=QUEUE_PROCESS):
         check(lib().ph_wipe(self.h, queue, _ptr(in0), _ptr(in1), wipe, width, height, _ptr(dst)), self.h)
+
+    def compose_write_v210(self, layers, dst, out_w, out_h, interlace, wr_cm, wr_lut, queue=QUEUE_PROCESS):
+        """layers: list of (rgba tensor, width, height, matrix tensor or None)"""
+        arr = (PhLayer * len(layers))()
+        for i, (t, w, h, m) in enumerate(layers):
+            arr[i].rgba, arr[i].width, arr[i].height = _ptr(t).value, w, h
+            arr[i].matrix9 = _ptr(m).value if m is not None else None
+        check(lib().ph_compose_write_v210(self.h, queue, len(layers), arr, _ptr(dst), out_w, out_h, interlace,
+                                          _ptr(wr_cm), _ptr(wr_lut)), self.h)
 
     def fused_v210_combine(self, layers, dst, width, height, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut,
                            queue=QUEUE_PROCESS):

@@ -656,6 +656,33 @@ int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *laye
   PH_LAUNCH(ph::launch_fused_v210_combine(stream_of(ctx, queue), n, a));
 }
 
+int ph_compose_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers, void *out, uint32_t out_w,
+                          uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut) {
+  if (!ctx || !layers || !out || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_compose_write_v210: NULL argument");
+  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_compose_write_v210: 1..%d layers", ph::kMaxLayers);
+  if (!out_w || out_w % 48) return fail(PH_E_INVALID, "ph_compose_write_v210: width %u is not a multiple of 48; run the separate kernels", out_w);
+  if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_compose_write_v210: interlace must be 0, 1 or 3");
+  const ph::LutView *wv = lds_view(ctx, wr_lut);
+  if (!wv) return fail(PH_E_INVALID, "ph_compose_write_v210: the writer gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)");
+  ph::ComposeArgs a{};
+  a.n = n;
+  for (int i = 0; i < n; ++i) {
+    if (!layers[i].rgba || layers[i].width <= 0 || layers[i].height <= 0)
+      return fail(PH_E_INVALID, "ph_compose_write_v210: layer %d is empty", i);
+    if (!layers[i].matrix9 && ((uint32_t)layers[i].width != out_w || (uint32_t)layers[i].height != out_h))
+      return fail(PH_E_INVALID, "ph_compose_write_v210: layer %d has no transform but is %dx%d, not the output size", i,
+                  layers[i].width, layers[i].height);
+    a.layers[i] = layers[i].rgba, a.matrix[i] = (const float *)layers[i].matrix9;
+    a.lw[i] = layers[i].width, a.lh[i] = layers[i].height;
+  }
+  a.out = out, a.out_w = out_w, a.out_h = out_h;
+  a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0;
+  a.lines = interlace ? out_h / 2 : out_h;
+  a.wr_cm = (const float *)wr_cm, a.wr = *wv;
+  if (!a.lines) return PH_OK;
+  PH_LAUNCH(ph::launch_compose_write_v210(stream_of(ctx, queue), a, (uint32_t)ctx->props.multiProcessorCount));
+}
+
 int ph_yadif(ph_ctx *ctx, int queue, const void *prev, const void *cur, const void *next, int w, int h, int parity,
              int tff, int skip, void *out) {
   if (!prev || !cur || !next || !out || w <= 0 || h <= 0) return fail(PH_E_INVALID, "ph_yadif: NULL/zero argument");

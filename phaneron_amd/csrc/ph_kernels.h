@@ -24,6 +24,17 @@ struct FusedLdsArgs {
   LutView rd, wr;  // compressed reader / writer tables (ph_lut.h)
 };
 
+struct ComposeArgs {
+  const void *layers[kMaxLayers];
+  const float *matrix[kMaxLayers];  // device 3x3 (transform) or NULL = the layer is used 1:1
+  int lw[kMaxLayers], lh[kMaxLayers];
+  int n;
+  void *out;
+  uint32_t out_w, out_h, lines, first_line, line_step;
+  const float *wr_cm;
+  LutView wr;
+};
+
 struct CombineArgs {
   const void *layers[kMaxLayers];
   void *out;
@@ -43,6 +54,7 @@ hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32
                                 const void *cm, const void *gm, const LutView &lut, uint32_t num_cus);
 hipError_t launch_v210_write_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
                                  uint32_t interlace, const void *cm, const LutView &lut, uint32_t num_cus);
+hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32_t num_cus);
 hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int parity,
                         int tff, int skip, void *out);
 hipError_t launch_transform(hipStream_t s, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh);

@@ -260,6 +260,85 @@ __global__ __launch_bounds__(kLdsBlock) void v210_write_lds_kernel(const float4 
 }
 
 // ------------------------------------------------------------------------------------------
+// compose + write: N float RGBA layers, each either taken 1:1 or through the `transform`
+// sampler (3x3 matrix, bilinear, border 0: transform.ts:36-59), combined with combine_N
+// (combine.ts:45-65) and packed to v210 (v210.ts:113-195) in ONE kernel.  This is the
+// reference's batch [transform] x N -> combine_N -> write without the N + 1 full-size f32
+// frames in between; bit-identical to running those kernels one after the other.
+// Single phase: only the writer table is needed.  One output quad per lane.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 texel_border0(const float4 *__restrict__ img, int w, int h, int x, int y) {
+  if (x < 0 || y < 0 || x >= w || y >= h) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return img[(size_t)y * w + x];
+}
+__device__ __forceinline__ float4 sample_linear0(const float4 *__restrict__ img, int w, int h, float s, float t) {
+  const float u = s * (float)w, v = t * (float)h;
+  const float fu = u - 0.5f, fv = v - 0.5f;
+  const float flu = __builtin_floorf(fu), flv = __builtin_floorf(fv);
+  const int i0 = (int)flu, j0 = (int)flv;
+  const float a = fu - flu, b = fv - flv;
+  const float oma = 1.0f - a, omb = 1.0f - b;
+  const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
+  const float4 t00 = texel_border0(img, w, h, i0, j0), t10 = texel_border0(img, w, h, i0 + 1, j0);
+  const float4 t01 = texel_border0(img, w, h, i0, j0 + 1), t11 = texel_border0(img, w, h, i0 + 1, j0 + 1);
+  float4 r;
+  r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+  r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+  r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+  r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+  return r;
+}
+
+__global__ __launch_bounds__(kLdsBlock) void compose_write_v210_kernel(ComposeArgs a) {
+  const WriteK wk = load_write_k(a.wr_cm);
+  const LutK lk = make_lut_k(a.wr);
+  lds_lut_load(a.wr);
+  __syncthreads();
+  const uint32_t qpl = a.out_w / 6;  // out_w % 48 == 0
+  const uint32_t total = qpl * a.lines;
+  for (uint32_t f = blockIdx.x * kLdsBlock + threadIdx.x; f < total; f += gridDim.x * kLdsBlock) {
+    const uint32_t li = f / qpl, g = f - li * qpl;
+    const uint32_t line = a.first_line + li * a.line_step;
+    float acc[24];
+#pragma unroll 1
+    for (int l = 0; l < a.n; ++l) {
+      const float4 *img = reinterpret_cast<const float4 *>(a.layers[l]);
+      const int lw = a.lw[l], lh = a.lh[l];
+      const float *m = a.matrix[l];
+      float m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+      if (m) m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5];
+      const float py = (float)(int)line / (float)(int)a.out_h - 0.5f;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int x = 6 * g + j;
+        float4 t;
+        if (m) {  // transform.ts:53-57
+          const float px = (float)x / (float)(int)a.out_w - 0.5f;
+          const float s = dot3(m0, m1, m2, px, py, 1.0f) + 0.5f;
+          const float tt = dot3(m3, m4, m5, px, py, 1.0f) + 0.5f;
+          t = sample_linear0(img, lw, lh, s, tt);
+        } else {
+          t = img[(size_t)line * a.out_w + x];
+        }
+        if (l == 0) {
+          acc[4 * j] = t.x, acc[4 * j + 1] = t.y, acc[4 * j + 2] = t.z, acc[4 * j + 3] = t.w;
+        } else {  // combine.ts:45-65
+          const float kk = 1.0f - t.w;
+          acc[4 * j] = fma_rn(acc[4 * j], kk, t.x);
+          acc[4 * j + 1] = fma_rn(acc[4 * j + 1], kk, t.y);
+          acc[4 * j + 2] = fma_rn(acc[4 * j + 2], kk, t.z);
+          acc[4 * j + 3] = fma_rn(acc[4 * j + 3], 0.0f, t.w);
+        }
+      }
+    }
+    float rgb[18];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) rgb[3 * j] = acc[4 * j], rgb[3 * j + 1] = acc[4 * j + 1], rgb[3 * j + 2] = acc[4 * j + 2];
+    reinterpret_cast<uint4 *>(a.out)[(size_t)line * qpl + g] = write_quad_lds(rgb, wk, lk);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 template <typename K>
@@ -308,6 +387,16 @@ hipError_t launch_fused_v210_combine_lds(hipStream_t s, int n, const FusedLdsArg
     case 8: return launch_fused_n<8>(s, a, num_cus, lds);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32_t num_cus) {
+  hipError_t e = allow_lds(compose_write_v210_kernel, a.wr.bytes);
+  if (e != hipSuccess) return e;
+  const uint32_t total = a.out_w / 6 * a.lines;
+  if (!total) return hipSuccess;
+  const uint32_t want = (total + kLdsBlock - 1) / kLdsBlock;
+  compose_write_v210_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, a.wr.bytes, s>>>(a);
+  return hipGetLastError();
 }
 
 hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,

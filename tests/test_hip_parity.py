@@ -195,6 +195,52 @@ def test_fused_pipeline_vs_oracle_chain(n, w, h, rspec, wspec):
     assert_bits(hh.host(out, np.uint32), want, "fused n=%d" % n)
 
 
+@pytest.mark.parametrize("case", ["pip_1080", "upscale2x", "single_layer", "interlaced"])
+def test_compose_write_vs_oracle_chain(case, lut_path):
+    """ph_compose_write_v210 == transform x N -> combine_N -> v210 write of the oracle."""
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    if lut_path != "lds_lut":
+        pytest.skip("the fused compositor exists only in the LDS-LUT form")
+    k = hh.ctx()
+    if case == "pip_1080":
+        ow, oh, il = 960, 270, 0
+        specs = [(960, 270, None), (960, 270, dict(scale_x=0.5, scale_y=0.5, offset_x=-0.25, offset_y=-0.25)),
+                 (480, 135, dict(scale_x=0.5, scale_y=0.5, offset_x=0.25, offset_y=0.25, rotate=0.05)), (960, 270, {})]
+    elif case == "upscale2x":
+        ow, oh, il = 960, 540, 0
+        specs = [(480, 270, {}) for _ in range(4)]
+    elif case == "single_layer":
+        ow, oh, il = 192, 40, 0
+        specs = [(96, 20, dict(flip_h=True))]
+    else:
+        ow, oh, il = 480, 64, 3
+        specs = [(480, 64, None), (240, 32, dict(scale_x=0.75, scale_y=0.75))]
+    imgs = [frames.rgba_random(w, h, 9000 + i) for i, (w, h, _) in enumerate(specs)]
+    mats = [None if kw is None else capi.transform_matrix(ow, oh, **kw) for (_, _, kw) in specs]
+    wcm, wlut = hh.ColourParams.writer("2020")
+    dst0 = np.full(frames.v210_pitch_bytes(ow) * oh // 4, cases.POISON, np.uint32)
+    out = hh.dev(dst0)
+    layers = [(hh.dev(im), w, h, None if m is None else hh.dev(m)) for im, (w, h, _), m in zip(imgs, specs, mats)]
+    k.compose_write_v210(layers, out, ow, oh, il, wcm, wlut)
+    xf = [im if m is None else orc.transform(im, m, ow, oh) for im, m in zip(imgs, mats)]
+    comb = xf[0] if len(xf) == 1 else orc.combine(xf)
+    want = orc.v210_write(comb, ow, oh, il, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"), out=dst0.copy())
+    assert_bits(hh.host(out, np.uint32), want, "compose_write " + case)
+
+
+def test_compose_write_refuses_unregistered_lut():
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    t = torch.zeros(96 * 4 * 4, dtype=torch.float32, device="cuda")
+    raw = hh.dev(capi.linear2gamma_lut("709"))  # not registered: no LDS form
+    with pytest.raises(capi.PhaneronError, match="LDS form"):
+        hh.ctx().compose_write_v210([(t, 96, 4, None), (t, 96, 4, None)], torch.zeros(96 * 4, dtype=torch.int32, device="cuda"),
+                                    96, 4, 0, hh.ColourParams.writer("709")[0], raw)
+
+
 def test_fused_equals_unfused_kernels_2160p():
     """Full BASELINE size: the fused kernel against the separate HIP kernels (already pinned to
     the oracle above), plus the size-independent property that with alpha == 1 everywhere the
