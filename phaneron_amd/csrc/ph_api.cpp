@@ -38,7 +38,7 @@ int fail(int code, const char *fmt, ...) {
 }  // namespace
 
 struct LutEntry {
-  ph::LutView view{nullptr, 0, 0, 0, 0};
+  ph::LutView view{nullptr, 0, 0, 0, 0, 0};
   void *blob_dev = nullptr;
 };
 
@@ -359,7 +359,8 @@ int ph_lut_register(ph_ctx *ctx, const void *dev, const float *host) {
   if (ph::lut_compress(host, ph::kLutMaxLdsBytes, blob, info)) {
     PH_HIP(hipMalloc(&e.blob_dev, info.bytes));
     PH_HIP(hipMemcpy(e.blob_dev, blob.data(), info.bytes, hipMemcpyHostToDevice));
-    e.view = ph::LutView{(const uint32_t *)e.blob_dev, info.bytes, info.toe, info.shift, info.delta_off};
+    e.view = ph::LutView{(const uint32_t *)e.blob_dev, info.bytes, info.toe, info.shift, info.delta_off,
+                         0u - (0x4B000000u << 2)};
   }
   ctx->luts[dev] = e;
   return e.view.bytes ? 1 : 0;

@@ -74,7 +74,7 @@ __device__ __forceinline__ LutK make_lut_k(const LutView &v) {
   LutK k;
   k.shift = v.shift;
   k.blk_bias = v.toe - (v.toe >> v.shift) + M - (M >> v.shift);
-  k.anchor_off = 0u - (M << 2);
+  k.anchor_off = v.anchor_bias;  // == 0u - (M << 2), kept opaque to the compiler (ph_lut.h)
   k.delta_off = v.delta_off - (M << 1);
   return k;
 }

@@ -22,6 +22,8 @@ struct LutView {         // passed by value to kernels
   uint32_t toe;          // T (a multiple of 2^S)
   uint32_t shift;        // S
   uint32_t delta_off;    // byte offset of delta[] inside the blob (= 4 * n_anchors, 16-aligned)
+  uint32_t anchor_bias;  // 0 - (0x4B000000 << 2): passed at run time so it lives in an SGPR and folds
+                         // into v_lshl_add_u32 (as a literal it costs every lookup an extra v_add_u32)
 };
 
 }  // namespace ph

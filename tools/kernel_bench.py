@@ -63,6 +63,14 @@ def main():
     timeit("transform identity 2160p", lambda i: ctx.transform(img[i % R], w, h, m, out_img[i % 2], w, h), 2 * ib)
     timeit("transform 1080->2160", lambda i: ctx.transform(src1080[i % R], 1920, 1080, m, out_img[i % 2], w, h), ib + ib // 4)
     timeit("resize 1080->2160", lambda i: ctx.resize(src1080[i % R], 1920, 1080, 1.0, 0.0, 0.0, flip, out_img[i % 2], w, h), ib + ib // 4)
+    src540 = [torch.rand(1920 * 1080 * 4, dtype=torch.float32, device="cuda") for _ in range(4)]
+    timeit("yadif 1080p", lambda i: ctx.yadif(src1080[i % R], src1080[(i + 1) % R], src1080[(i + 2) % R], out_img[0], 1920, 1080, 0, 1), 4 * ib // 4)
+    timeit("compose_write 4 x (1080p -> 2160p bilinear) -> v210",
+           lambda i: ctx.compose_write_v210([(src1080[(i + j) % R], 1920, 1080, m) for j in range(4)], out_v[i % 2], w, h, 0, *wr),
+           ib + vb)
+    timeit("compose_write 4 x 2160p direct -> v210",
+           lambda i: ctx.compose_write_v210([(img[(i + j) % R], w, h, None) for j in range(4)], out_v[i % 2], w, h, 0, *wr),
+           4 * ib + vb)
     for n in (1, 2, 4, 8):
         if n <= R:
             timeit("fused_v210_combine_%d 2160p" % n,
