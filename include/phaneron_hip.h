@@ -191,9 +191,10 @@ int ph_compose_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers,
  *      plain (not exactly compressible into 160 KiB), negative on error. ----------------------- */
 int ph_lut_register(ph_ctx *ctx, const void *device_lut_f32, const float *host_lut65536);
 int ph_lut_unregister(ph_ctx *ctx, const void *device_lut_f32);
-/* lds_bytes = 0 when the pointer is unknown or plain */
-int ph_lut_query(ph_ctx *ctx, const void *device_lut_f32, uint32_t *lds_bytes, uint32_t *toe,
-                 uint32_t *block_shift);
+/* lds_bytes = 0 when the pointer is unknown or plain; index_bias and blocks_per_octave_log2
+ * describe the logarithmic block layout chosen for the table (ph_lut.h) */
+int ph_lut_query(ph_ctx *ctx, const void *device_lut_f32, uint32_t *lds_bytes, uint32_t *index_bias,
+                 uint32_t *blocks_per_octave_log2);
 /* options: "lds_lut" (default 1): 0 forces the global-gather kernels (A/B tests, profiles) */
 int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value);
 

@@ -223,7 +223,7 @@ class Context:
     def lut_info(self, device_lut):
         b, t, s = C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib().ph_lut_query(self.h, _ptr(device_lut), C.byref(b), C.byref(t), C.byref(s)), self.h)
-        return dict(lds_bytes=b.value, toe=t.value, block_shift=s.value)
+        return dict(lds_bytes=b.value, index_bias=t.value, blocks_per_octave_log2=s.value)
 
     def set_option(self, name, value):
         check(lib().ph_ctx_set_option(self.h, name.encode(), int(value)), self.h)

@@ -38,7 +38,7 @@ int fail(int code, const char *fmt, ...) {
 }  // namespace
 
 struct LutEntry {
-  ph::LutView view{nullptr, 0, 0, 0, 0, 0};
+  ph::LutView view{nullptr, 0, 0.f, 0, 0, 0.f, 0.f};
   void *blob_dev = nullptr;
 };
 
@@ -359,8 +359,7 @@ int ph_lut_register(ph_ctx *ctx, const void *dev, const float *host) {
   if (ph::lut_compress(host, ph::kLutMaxLdsBytes, blob, info)) {
     PH_HIP(hipMalloc(&e.blob_dev, info.bytes));
     PH_HIP(hipMemcpy(e.blob_dev, blob.data(), info.bytes, hipMemcpyHostToDevice));
-    e.view = ph::LutView{(const uint32_t *)e.blob_dev, info.bytes, info.toe, info.shift, info.delta_off,
-                         0u - (0x4B000000u << 2)};
+    e.view = ph::lut_view(info, e.blob_dev);
   }
   ctx->luts[dev] = e;
   return e.view.bytes ? 1 : 0;
@@ -371,8 +370,8 @@ int ph_lut_query(ph_ctx *ctx, const void *dev, uint32_t *lds_bytes, uint32_t *to
   auto it = ctx->luts.find(dev);
   const bool have = it != ctx->luts.end();
   if (lds_bytes) *lds_bytes = have ? it->second.view.bytes : 0;
-  if (toe) *toe = have ? it->second.view.toe : 0;
-  if (shift) *shift = have ? it->second.view.shift : 0;
+  if (toe) *toe = have ? (uint32_t)it->second.view.bias : 0;
+  if (shift) *shift = have ? 23 - it->second.view.shift : 0;
   return PH_OK;
 }
 

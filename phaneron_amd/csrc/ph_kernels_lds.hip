@@ -59,35 +59,28 @@ __device__ __forceinline__ void lds_lut_load(const LutView &v) {
 #endif
 }
 
-// Per-kernel constants of the lookup arithmetic.  The rounded, clamped index is never
-// converted to an integer: adding 2^23 to the clamped float rounds it to nearest-even (what
-// convert_ushort_sat_rte does) and leaves M + idx in the float's bit pattern (M = 0x4B000000);
-// all following integer steps work on that biased value with the bias folded into constants.
+// table[clamp(rint(x), 0, 65535)] for x = (gamma- or linear-domain value) * 65535, see ph_lut.h:
+// 4 float ops, 3 integer ops, 2 LDS reads.
+//   * x + bias then v_rndne: the same round-to-nearest-even as convert_ushort_sat_rte (bias is an
+//     even integer, so ties fall the same way);
+//   * the float's own exponent/mantissa bits are the logarithmic block number: one shift;
+//   * the delta address is produced by an fma whose result is a DENORMAL: (2*(i+bias) + base)
+//     * 2^-149 has exactly that integer as its bit pattern, so no int multiply/add is needed
+//     (f32 denormals are enabled in HIP kernels and cost nothing extra on gfx950).
 struct LutK {
-  uint32_t shift;
-  uint32_t blk_bias;    // + (bits >> S)      -> M + T + ((idx - T) >> S)   (for idx >= T)
-  uint32_t anchor_off;  // + ((M + b) << 2)   -> byte address of anchor[b]      (mod 2^32)
-  uint32_t delta_off;   // + ((M + idx) << 1) -> byte address of delta[idx]     (mod 2^32)
+  float bias, delta_scale, delta_base;
+  uint32_t shift, anchor_off;
 };
 __device__ __forceinline__ LutK make_lut_k(const LutView &v) {
-  constexpr uint32_t M = 0x4B000000u;  // bits of 8388608.0f
-  LutK k;
-  k.shift = v.shift;
-  k.blk_bias = v.toe - (v.toe >> v.shift) + M - (M >> v.shift);
-  k.anchor_off = v.anchor_bias;  // == 0u - (M << 2), kept opaque to the compiler (ph_lut.h)
-  k.delta_off = v.delta_off - (M << 1);
-  return k;
+  return LutK{v.bias, v.delta_scale, v.delta_base, v.shift, v.anchor_off};
 }
-
-// table[clamp(rint(x), 0, 65535)] for x = (gamma- or linear-domain value) * 65535:
-// 3 float ops, 5 integer ops, 2 LDS reads (anchor + delta, ph_lut.h)
 __device__ __forceinline__ float lds_lut_at(const LutK &k, float x) {
   x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 65535.0f);  // v_med3_f32; NaN -> 0 like the reference
-  const uint32_t bits = __float_as_uint(x + 8388608.0f);     // M + idx, rounded to nearest even
-  const uint32_t blk = (bits >> k.shift) + k.blk_bias;
-  const uint32_t bm = bits < blk ? bits : blk;                // M + min(idx, T + ((idx - T) >> S))
-  const uint32_t a = *reinterpret_cast<const uint32_t *>(g_lds + ((bm << 2) + k.anchor_off));
-  const uint32_t d = *reinterpret_cast<const uint16_t *>(g_lds + ((bits << 1) + k.delta_off));
+  const float fb = __builtin_rintf(x + k.bias);               // (float)(idx + bias)
+  const uint32_t a_addr = ((__float_as_uint(fb) >> k.shift) << 2) + k.anchor_off;
+  const uint32_t d_addr = __float_as_uint(fma_rn(fb, k.delta_scale, k.delta_base));
+  const uint32_t a = *reinterpret_cast<const uint32_t *>(g_lds + a_addr);
+  const uint32_t d = *reinterpret_cast<const uint16_t *>(g_lds + d_addr);
   return __uint_as_float(a + d);
 }
 

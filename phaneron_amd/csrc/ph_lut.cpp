@@ -2,46 +2,83 @@
 #include "ph_lut_host.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace ph {
 
+namespace {
+inline uint32_t f2u(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+inline float u2f(uint32_t u) {
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+}  // namespace
+
+LutView lut_view(const LutHostInfo &info, const void *blob_dev) {
+  LutView v;
+  v.blob = static_cast<const uint32_t *>(blob_dev);
+  v.bytes = info.bytes;
+  v.bias = info.bias;
+  v.shift = info.shift;
+  v.anchor_off = 0u - 4u * info.first;
+  v.delta_scale = u2f(2u);  // 2 * 2^-149
+  // (delta_off - 2*bias) * 2^-149: a denormal whose bit pattern is that integer
+  v.delta_base = u2f(info.delta_off - 2u * (uint32_t)info.bias);
+  return v;
+}
+
 bool lut_compress(const float *lut, uint32_t max_bytes, std::vector<uint32_t> &blob, LutHostInfo &info) {
-  uint32_t p[65536];
+  static uint32_t p[65536], blk[65536];
   std::memcpy(p, lut, sizeof p);
   bool found = false;
-  for (uint32_t shift = 4; shift <= 6; ++shift) {
-    const uint32_t B = 1u << shift;
-    // T = first index (multiple of B) from which every block spans < 65536 bit patterns
-    uint32_t toe = 0;
-    for (uint32_t blk = 0; blk < 65536 / B; ++blk) {
-      uint32_t lo = p[blk * B], hi = lo;
-      for (uint32_t i = 1; i < B; ++i) lo = std::min(lo, p[blk * B + i]), hi = std::max(hi, p[blk * B + i]);
-      if (hi - lo >= 65536u) toe = (blk + 1) * B;
-    }
-    uint32_t n_anchors = toe + (65536 - toe) / B;
-    n_anchors = (n_anchors + 3) & ~3u;  // keep delta[] 16-byte aligned
-    const uint32_t bytes = n_anchors * 4 + 65536 * 2;
-    if (bytes > max_bytes) continue;
-    if (found && bytes >= info.bytes) continue;
-    found = true;
-    info.bytes = bytes, info.toe = toe, info.shift = shift, info.delta_off = n_anchors * 4;
-    blob.assign(bytes / 4, 0);
-    uint16_t *delta = reinterpret_cast<uint16_t *>(blob.data() + n_anchors);
-    for (uint32_t i = 0; i < toe; ++i) blob[i] = p[i], delta[i] = 0;
-    for (uint32_t blk = toe / B; blk < 65536 / B; ++blk) {
-      uint32_t lo = p[blk * B];
-      for (uint32_t i = 1; i < B; ++i) lo = std::min(lo, p[blk * B + i]);
-      blob[toe + (blk - toe / B)] = lo;
-      for (uint32_t i = 0; i < B; ++i) delta[blk * B + i] = (uint16_t)(p[blk * B + i] - lo);
+  for (float bias : {16.0f, 32.0f, 64.0f, 128.0f}) {
+    for (uint32_t m = 7; m <= 10; ++m) {
+      const uint32_t shift = 23 - m;
+      const uint32_t first = f2u(bias) >> shift;
+      const uint32_t n_blocks = (f2u(65535.0f + bias) >> shift) - first + 1;
+      const uint32_t n_anchors = (n_blocks + 3) & ~3u;  // keep delta[] 16-byte aligned
+      const uint32_t bytes = n_anchors * 4 + 65536 * 2;
+      if (bytes > max_bytes || (found && bytes >= info.bytes)) continue;
+      std::vector<uint32_t> lo(n_blocks, 0xffffffffu), hi(n_blocks, 0);
+      for (uint32_t i = 0; i < 65536; ++i) {
+        blk[i] = (f2u((float)i + bias) >> shift) - first;
+        lo[blk[i]] = std::min(lo[blk[i]], p[i]);
+        hi[blk[i]] = std::max(hi[blk[i]], p[i]);
+      }
+      bool ok = true;
+      for (uint32_t b = 0; b < n_blocks && ok; ++b)
+        if (lo[b] != 0xffffffffu && hi[b] - lo[b] >= 65536u) ok = false;
+      if (!ok) continue;
+      found = true;
+      info.bytes = bytes, info.shift = shift, info.first = first, info.n_anchors = n_anchors;
+      info.delta_off = n_anchors * 4, info.bias = bias;
+      blob.assign(bytes / 4, 0);
+      for (uint32_t b = 0; b < n_blocks; ++b) blob[b] = lo[b] == 0xffffffffu ? 0 : lo[b];
+      uint16_t *delta = reinterpret_cast<uint16_t *>(blob.data() + n_anchors);
+      for (uint32_t i = 0; i < 65536; ++i) delta[i] = (uint16_t)(p[i] - lo[blk[i]]);
     }
   }
   if (!found) return false;
-  // exhaustive self-check of the decode formula the kernels use
-  const uint16_t *delta = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(blob.data()) + info.delta_off);
+  // Exhaustive self-check with the very operations the kernels use (ph_kernels_lds.hip
+  // lds_lut_at): float add, shift, and the denormal fma that yields the delta byte address.
+  const LutView v = lut_view(info, nullptr);
+  const uint8_t *bytes = reinterpret_cast<const uint8_t *>(blob.data());
   for (uint32_t i = 0; i < 65536; ++i) {
-    const uint32_t b = std::min(i, info.toe + ((i - info.toe) >> info.shift));
-    if (blob[b] + delta[i] != p[i]) return false;
+    const float fb = (float)i + v.bias;
+    const uint32_t a_addr = ((f2u(fb) >> v.shift) << 2) + v.anchor_off;
+    const uint32_t d_addr = f2u(std::fmaf(fb, v.delta_scale, v.delta_base));
+    if (a_addr + 4 > info.delta_off || d_addr != info.delta_off + 2 * i) return false;
+    uint32_t a;
+    uint16_t d;
+    std::memcpy(&a, bytes + a_addr, 4);
+    std::memcpy(&d, bytes + d_addr, 2);
+    if (a + d != p[i]) return false;
   }
   return true;
 }

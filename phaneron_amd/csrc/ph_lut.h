@@ -5,25 +5,29 @@
 // table (v210.ts:68-70,148-150).  From global memory that is ~300 G lookups/s on MI355X
 // (one cache line per lane); from LDS it is ~4800 G/s.  The table does not fit in LDS as f32,
 // but its bit patterns p[i] are locally smooth, so it is stored as
-//     anchor[b]  (u32)  b = i              for i <  T  (the steep toe: exact value)
-//                       b = T + (i-T)>>S   for i >= T  (minimum bit pattern of a 2^S block)
-//     delta[i]   (u16)  p[i] - anchor[b]
-// and p[i] = anchor[b] + delta[i]: exact whenever every block's max-min < 65536 (verified
-// exhaustively when the table is built; otherwise the LUT stays "plain", the LDS kernels
-// refuse it and the global-gather kernels are used).
+//     anchor[b]  (u32)  minimum bit pattern of block b
+//     delta[i]   (u16)  p[i] - anchor[block(i)]
+// with p[i] = anchor[block(i)] + delta[i].  Blocks are LOGARITHMIC in the index:
+//     block(i) = (bits((float)(i + bias)) >> (23 - m)) - first
+// i.e. 2^m blocks per octave of (i + bias): single entries in the steep toe near 0, ~128
+// entries per block at the top.  One float add and one shift give the block, which is what
+// makes the lookup cheap (the LUT curves are power laws, so equal *relative* block widths
+// bound the deltas).  Exact whenever every block's max-min < 65536; that and the decode
+// formula are verified exhaustively when the table is built, otherwise the LUT stays
+// "plain": the LDS kernels refuse it and the global-gather kernels are used.
 #pragma once
 #include <stdint.h>
 
 namespace ph {
 
-struct LutView {         // passed by value to kernels
-  const uint32_t *blob;  // device: [anchors u32 x n_anchors][delta u16 x 65536], size % 16 == 0
-  uint32_t bytes;        // 0 = not compressible
-  uint32_t toe;          // T (a multiple of 2^S)
-  uint32_t shift;        // S
-  uint32_t delta_off;    // byte offset of delta[] inside the blob (= 4 * n_anchors, 16-aligned)
-  uint32_t anchor_bias;  // 0 - (0x4B000000 << 2): passed at run time so it lives in an SGPR and folds
-                         // into v_lshl_add_u32 (as a literal it costs every lookup an extra v_add_u32)
+struct LutView {          // passed by value to kernels
+  const uint32_t *blob;   // device: [anchors u32 x n_anchors][delta u16 x 65536], size % 16 == 0
+  uint32_t bytes;         // 0 = not compressible
+  float bias;             // even integer >= 2 (keeps round-to-nearest-even parity of the index)
+  uint32_t shift;         // 23 - m
+  uint32_t anchor_off;    // 0 - 4 * first  (mod 2^32): byte address of anchor[b] = ((bits >> shift) << 2) + anchor_off
+  float delta_scale;      // 2^-148 as a float (denormal): delta byte address = bits(fma(i + bias, delta_scale, delta_base))
+  float delta_base;       // (delta_off - 2 * bias) * 2^-149 (denormal)
 };
 
 }  // namespace ph

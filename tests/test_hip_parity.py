@@ -158,15 +158,32 @@ def test_combine_vs_oracle_1080p(n):
 
 def test_lut_registry_reports_lds_form():
     import hip_harness as hh
-    for spec in ("709", "2020", "601-625"):
-        _, lut, _ = hh.ColourParams.reader(spec, spec)
+    for spec in ("709", "2020", "601-625", "sRGB"):
+        _, lut, _ = hh.ColourParams.reader(spec, "709")
         info = hh.ctx().lut_info(lut)
         assert 0 < info["lds_bytes"] <= 160 * 1024, info
         _, wlut = hh.ColourParams.writer(spec)
         assert 0 < hh.ctx().lut_info(wlut)["lds_bytes"] <= 160 * 1024
-    # the sRGB gamma->linear table does not compress into 160 KiB: it must stay plain and still work
-    _, lut, _ = hh.ColourParams.reader("sRGB", "709")
-    assert hh.ctx().lut_info(lut)["lds_bytes"] == 0
+
+
+def test_incompressible_lut_falls_back_to_gather_kernels():
+    """A table that is not locally smooth cannot be held exactly in LDS: it must stay plain and
+    the global-gather kernels must still give the exact answer."""
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    rng = np.random.default_rng(7)
+    lut = rng.random(65536, dtype=np.float32)
+    dlut = hh.dev(lut)
+    assert hh.ctx().register_lut(dlut, lut) is False
+    assert hh.ctx().lut_info(dlut)["lds_bytes"] == 0
+    w, h = 96, 4
+    words = frames.v210_random(w, h, 3)
+    cm, gm = capi.ycbcr2rgb_matrix("709"), capi.rgb2rgb_matrix("709", "709")
+    out = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+    hh.ctx().v210_read(hh.dev(words), out, w, h, hh.dev(cm), dlut, hh.dev(np.concatenate([gm, np.zeros(3, np.float32)])))
+    assert_bits(hh.host(out), orc.v210_read(words, w, h, cm, lut, gm), "plain LUT")
+    hh.ctx().unregister_lut(dlut)
 
 
 def test_combine_rejects_single_layer():
