@@ -60,9 +60,9 @@ __device__ __forceinline__ void lds_lut_load(const LutView &v) {
 }
 
 // table[clamp(rint(x), 0, 65535)] for x = (gamma- or linear-domain value) * 65535, see ph_lut.h:
-// 4 float ops, 3 integer ops, 2 LDS reads.
-//   * x + bias then v_rndne: the same round-to-nearest-even as convert_ushort_sat_rte (bias is an
-//     even integer, so ties fall the same way);
+// 5 float ops, 3 integer ops, 2 LDS reads.
+//   * v_rndne FIRST, then + bias (exact on integers).  Adding the bias before rounding would round
+//     twice: x + bias has a coarser ulp than x just above a power of two and can manufacture a tie;
 //   * the float's own exponent/mantissa bits are the logarithmic block number: one shift;
 //   * the delta address is produced by an fma whose result is a DENORMAL: (2*(i+bias) + base)
 //     * 2^-149 has exactly that integer as its bit pattern, so no int multiply/add is needed
@@ -76,7 +76,7 @@ __device__ __forceinline__ LutK make_lut_k(const LutView &v) {
 }
 __device__ __forceinline__ float lds_lut_at(const LutK &k, float x) {
   x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 65535.0f);  // v_med3_f32; NaN -> 0 like the reference
-  const float fb = __builtin_rintf(x + k.bias);               // (float)(idx + bias)
+  const float fb = __builtin_rintf(x) + k.bias;               // (float)(idx + bias), exact
   const uint32_t a_addr = ((__float_as_uint(fb) >> k.shift) << 2) + k.anchor_off;
   const uint32_t d_addr = __float_as_uint(fma_rn(fb, k.delta_scale, k.delta_base));
   const uint32_t a = *reinterpret_cast<const uint32_t *>(g_lds + a_addr);
