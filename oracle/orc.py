@@ -34,8 +34,8 @@ def build(force=False):
     else:  # host CPU without FMA/AVX2: same source, generic code
         name, arch = "liboracle_generic.so", ""
     path = os.path.join(_HERE, name)
-    src = os.path.join(_HERE, "phaneron_oracle.c")
-    stale = (not os.path.exists(path)) or os.path.getmtime(path) < os.path.getmtime(src)
+    srcs = [os.path.join(_HERE, f) for f in ("phaneron_oracle.c", "phaneron_oracle_formats.c", "phaneron_oracle.h")]
+    stale = (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         cmd = ["make", "-C", _HERE, "OUT=" + name]
         if arch is not None:
@@ -85,6 +85,13 @@ def lib():
         l.orc_wipe.restype = None
         l.orc_pipeline_v210_combine.argtypes = [C.c_int, C.POINTER(C.c_void_p), _u32p, C.c_uint32, C.c_uint32,
                                                 _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
+        l.orc_pack_pitch.argtypes = [C.c_int, C.c_uint32]
+        l.orc_pack_pitch.restype = C.c_uint32
+        l.orc_pack_plane_bytes.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]
+        l.orc_pack_read.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _f32p, C.c_uint32, C.c_uint32,
+                                    C.c_void_p, _f32p, _f32p]
+        l.orc_pack_write.argtypes = [C.c_int, _f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                     C.c_uint32, C.c_void_p, _f32p]
         l.orc_num_threads.restype = C.c_int
         l.orc_set_num_threads.argtypes = [C.c_int]
         l.orc_set_num_threads.restype = None
@@ -159,6 +166,48 @@ def v210_write(rgba, width, height, interlace, col_matrix, lut, out=None):
     lib().orc_v210_write(np.ascontiguousarray(rgba, np.float32).reshape(-1), out, width, height, interlace,
                          np.ascontiguousarray(col_matrix, np.float32), lut)
     return out
+
+
+# ---- other pack formats ------------------------------------------------------------------------
+FORMATS = {"v210": 0, "yuv422p10": 1, "yuv422p8": 2, "yuv420p": 3, "nv12": 4, "rgba8": 5, "bgra8": 6}
+# Reader/Writer constants of each format: (numBits, lumaBlack, lumaWhite, chromaRange), None = RGB
+FORMAT_RANGE = {"v210": (10, 64, 940, 896), "yuv422p10": (10, 64, 940, 896), "yuv422p8": (8, 16, 235, 224),
+                "yuv420p": (8, 16, 235, 224), "nv12": (8, 16, 235, 224), "rgba8": None, "bgra8": None}
+
+
+def pack_plane_bytes(fmt, width, height):
+    b = (C.c_size_t * 3)()
+    n = lib().orc_pack_plane_bytes(FORMATS[fmt], width, height, b)
+    return [int(b[i]) for i in range(n)]
+
+
+def _planes3(planes):
+    ps = [np.ascontiguousarray(p) for p in planes]
+    ptrs = [p.ctypes.data for p in ps] + [None] * (3 - len(ps))
+    return ps, ptrs
+
+
+def pack_read(fmt, planes, width, height, col_matrix, lut, gamut):
+    """planes: list of uint8 arrays (raw plane bytes).  col_matrix None for the RGB formats."""
+    ps, ptrs = _planes3(planes)
+    out = np.zeros(width * height * 4, np.float32)
+    cm = None if col_matrix is None else np.ascontiguousarray(col_matrix, np.float32)
+    rc = lib().orc_pack_read(FORMATS[fmt], ptrs[0], ptrs[1], ptrs[2], out, width, height,
+                             None if cm is None else cm.ctypes.data, lut, np.ascontiguousarray(gamut, np.float32))
+    assert rc == 0
+    return out.reshape(height, width, 4)
+
+
+def pack_write(fmt, rgba, width, height, interlace, col_matrix, lut, planes=None):
+    """Returns the list of plane byte arrays (uint8).  planes: pre-filled destinations (copied)."""
+    sizes = pack_plane_bytes(fmt, width, height)
+    ps = [np.zeros(s, np.uint8) for s in sizes] if planes is None else [np.array(p, np.uint8, copy=True) for p in planes]
+    ptrs = [p.ctypes.data for p in ps] + [None] * (3 - len(ps))
+    cm = None if col_matrix is None else np.ascontiguousarray(col_matrix, np.float32)
+    rc = lib().orc_pack_write(FORMATS[fmt], np.ascontiguousarray(rgba, np.float32).reshape(-1), ptrs[0], ptrs[1], ptrs[2],
+                              width, height, interlace, None if cm is None else cm.ctypes.data, lut)
+    assert rc == 0
+    return ps
 
 
 # ---- image ops --------------------------------------------------------------------------------
@@ -290,6 +339,10 @@ def ref():
         r.ref_transition_dissolve.argtypes = [_f32p, _f32p, C.c_float, C.c_int, C.c_int, _f32p]
         r.ref_transition_wipe.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, _f32p]
         r.ref_combine.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, _f32p]
+        r.ref_pack_read.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _f32p, C.c_uint, C.c_uint, C.c_void_p,
+                                    _f32p, _f32p]
+        r.ref_pack_write.argtypes = [C.c_int, _f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint,
+                                     C.c_void_p, _f32p]
         for n in ("ref_v210_read", "ref_v210_write", "ref_yadif", "ref_transform", "ref_resize", "ref_mixer",
                   "ref_wipe", "ref_transition_dissolve", "ref_transition_wipe"):
             getattr(r, n).restype = None

@@ -60,6 +60,26 @@ void orc_v210_write(const float *in, uint32_t *out, uint32_t width, uint32_t hei
                     uint32_t interlace, const float *col_matrix12,
                     const float *gamma_lut);                                    /* :113-195 */
 
+/* ---- the other pack formats (phaneron_oracle_formats.c) ------------------------ */
+enum {
+  ORC_FMT_V210 = 0,
+  ORC_FMT_YUV422P10 = 1, /* yuv422p10.ts */
+  ORC_FMT_YUV422P8 = 2,  /* yuv422p8.ts  */
+  ORC_FMT_YUV420P = 3,   /* yuv420p.ts   */
+  ORC_FMT_NV12 = 4,      /* nv12.ts      */
+  ORC_FMT_RGBA8 = 5,     /* rgba8.ts     */
+  ORC_FMT_BGRA8 = 6      /* bgra8.ts     */
+};
+uint32_t orc_pack_pitch(int fmt, uint32_t width);
+/* returns the number of planes (1..3), fills their sizes */
+int orc_pack_plane_bytes(int fmt, uint32_t width, uint32_t height, size_t bytes[3]);
+int orc_pack_read(int fmt, const void *p0, const void *p1, const void *p2, float *out, uint32_t width,
+                  uint32_t height, const float *col_matrix12, const float *gamma_lut,
+                  const float *gamut_matrix9);
+int orc_pack_write(int fmt, const float *in, void *p0, void *p1, void *p2, uint32_t width,
+                   uint32_t height, uint32_t interlace, const float *col_matrix12,
+                   const float *gamma_lut);
+
 /* ---- image ops ----------------------------------------------------------------------------- */
 void orc_yadif(const float *prev, const float *cur, const float *next, int width, int height,
                int parity, int tff, int skip_spatial, float *out);        /* yadifCl.ts:28-167 */

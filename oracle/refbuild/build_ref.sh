@@ -21,10 +21,12 @@ for cl in "$OUT"/*.cl; do
   "$LLVM/clang" $CLFLAGS -c "$cl" -o "$o"
   OBJS="$OBJS $o"
 done
-# the v210 kernels are literally named read/write: rename so they do not shadow libc
-"$LLVM/llvm-objcopy" --redefine-sym read=refk_v210_read --redefine-sym write=refk_v210_write \
-  --redefine-sym __clang_ocl_kern_imp_read=refk_imp_v210_read \
-  --redefine-sym __clang_ocl_kern_imp_write=refk_imp_v210_write "$OUT/v210.o"
+# every pack format names its kernels read/write: rename per format (and away from libc's)
+for fmt in v210 yuv422p10 yuv422p8 yuv420p nv12 rgba8 bgra8; do
+  "$LLVM/llvm-objcopy" --redefine-sym read=refk_${fmt}_read --redefine-sym write=refk_${fmt}_write \
+    --redefine-sym __clang_ocl_kern_imp_read=refk_imp_${fmt}_read \
+    --redefine-sym __clang_ocl_kern_imp_write=refk_imp_${fmt}_write "$OUT/$fmt.o"
+done
 "$LLVM/clang++" -O1 -fPIC -ffp-contract=off -std=c++17 -c "$HERE/ocl_shim.cpp" -o "$OUT/ocl_shim.o"
 "$LLVM/clang++" -shared -o "$OUT/libphaneron_ref.so" "$OUT/ocl_shim.o" $OBJS -lm
 echo "built $OUT/libphaneron_ref.so"

@@ -7,7 +7,8 @@ they lie and written under oracle/_ref/ (git-ignored); nothing derived from it i
 committed except golden input/output *data* under tests/golden/.
 
 Static kernels are template strings (`const xxxKernel = `...``):
-  src/process/v210.ts:24-196, yadifCl.ts:27-168, transform.ts:24-60, resize.ts:24-60,
+  src/process/v210.ts:24-196, yuv422p10.ts:24-219, yuv422p8.ts:24-219, yuv420p.ts:24-250,
+  nv12.ts:24-245, rgba8.ts:24-102, bgra8.ts:24-102, yadifCl.ts:27-168, transform.ts:24-60, resize.ts:24-60,
   mix.ts:23-46, wipe.ts:23-48
 Generated kernels come from two string-builder arrow functions which are evaluated
 under node after dropping their TypeScript annotations:
@@ -23,6 +24,12 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "_ref")
 
 STATIC = [
     ("v210.ts", "v210Kernel", "v210"),
+    ("yuv422p10.ts", "yuv422p10leKernel", "yuv422p10"),
+    ("yuv422p8.ts", "yuv422p8Kernel", "yuv422p8"),
+    ("yuv420p.ts", "yuv420pKernel", "yuv420p"),
+    ("nv12.ts", "nv12Kernel", "nv12"),
+    ("rgba8.ts", "rgba8Kernel", "rgba8"),
+    ("bgra8.ts", "bgra8Kernel", "bgra8"),
     ("yadifCl.ts", "yadifKernel", "yadif"),
     ("transform.ts", "transformKernel", "transform"),
     ("resize.ts", "resizeKernel", "resize"),

@@ -24,6 +24,7 @@ typedef float float3 __attribute__((ext_vector_type(3)));
 typedef float float4 __attribute__((ext_vector_type(4)));
 typedef int int2 __attribute__((ext_vector_type(2)));
 typedef unsigned short ushort4 __attribute__((ext_vector_type(4)));
+typedef unsigned char uchar4 __attribute__((ext_vector_type(4)));
 typedef unsigned int uint4 __attribute__((ext_vector_type(4)));
 
 struct Img {
@@ -54,6 +55,8 @@ float4 b_fmin4(float4 a, float4 b) asm("_Z4fminDv4_fS_");
 float4 b_fmax4(float4 a, float4 b) asm("_Z4fmaxDv4_fS_");
 float b_round(float a) asm("_Z5roundf");
 float4 b_cvt_f4_us4(ushort4 a) asm("_Z14convert_float4Dv4_t");
+float4 b_cvt_f4_uc4(uchar4 a) asm("_Z14convert_float4Dv4_h");
+unsigned char b_cvt_uc_sat_rte(float a) asm("_Z21convert_uchar_sat_rtef");
 unsigned short b_cvt_us_sat(float a) asm("_Z18convert_ushort_satf");
 unsigned short b_cvt_us_sat_rte(float a) asm("_Z22convert_ushort_sat_rtef");
 unsigned short b_cvt_us_sat_rtz(float a) asm("_Z22convert_ushort_sat_rtzf");
@@ -94,6 +97,17 @@ float4 b_cvt_f4_us4(ushort4 a) {
   float4 r;
   for (int i = 0; i < 4; ++i) r[i] = (float)a[i];
   return r;
+}
+float4 b_cvt_f4_uc4(uchar4 a) {
+  float4 r;
+  for (int i = 0; i < 4; ++i) r[i] = (float)a[i];
+  return r;
+}
+unsigned char b_cvt_uc_sat_rte(float a) {  // rint -> max 0 -> min 255 -> fptoui (device-lib form)
+  float x = rintf(a);
+  if (!(x > 0.0f)) return 0;
+  if (x >= 255.0f) return 255;
+  return (unsigned char)x;
 }
 static inline unsigned short clamp_us(float x) {
   // NaN -> 0 like the device's max(x,0) (fmax ignores NaN)
@@ -162,6 +176,19 @@ void refk_v210_read(uint4 *in, float4 *out, unsigned width, float4 *colMatrix, f
                     float4 *gamutMatrix);
 void refk_v210_write(float4 *in, uint4 *out, unsigned width, unsigned interlace, float4 *colMatrix,
                      float *gammaLut);
+// the other pack formats (planes are passed as untyped pointers: vector loads are plain loads on x86)
+void refk_yuv422p10_read(void *y, void *u, void *v, float4 *out, unsigned w, float4 *cm, float *lut, float4 *gm);
+void refk_yuv422p10_write(float4 *in, void *y, void *u, void *v, unsigned w, unsigned il, float4 *cm, float *lut);
+void refk_yuv422p8_read(void *y, void *u, void *v, float4 *out, unsigned w, float4 *cm, float *lut, float4 *gm);
+void refk_yuv422p8_write(float4 *in, void *y, void *u, void *v, unsigned w, unsigned il, float4 *cm, float *lut);
+void refk_yuv420p_read(void *y, void *u, void *v, float4 *out, unsigned w, float4 *cm, float *lut, float4 *gm);
+void refk_yuv420p_write(float4 *in, void *y, void *u, void *v, unsigned w, unsigned il, float4 *cm, float *lut);
+void refk_nv12_read(void *y, void *c, float4 *out, unsigned w, float4 *cm, float *lut, float4 *gm);
+void refk_nv12_write(float4 *in, void *y, void *c, unsigned w, unsigned il, float4 *cm, float *lut);
+void refk_rgba8_read(void *in, float4 *out, unsigned w, float *lut, float4 *gm);
+void refk_rgba8_write(float4 *in, void *out, unsigned w, unsigned il, float *lut);
+void refk_bgra8_read(void *in, float4 *out, unsigned w, float *lut, float4 *gm);
+void refk_bgra8_write(float4 *in, void *out, unsigned w, unsigned il, float *lut);
 void yadif(Img *prev, Img *cur, Img *next, int parity, int tff, int skipSpatial, Img *out);
 void transform(Img *in, float4 *m, Img *out);
 void resize(Img *in, float scale, float offX, float offY, float *flip, Img *out);
@@ -224,6 +251,61 @@ void ref_v210_write(const float *in, uint32_t *out, unsigned width, unsigned hei
       g_gid[0] = grp * wipg + lid;
       refk_v210_write((float4 *)in, (uint4 *)out, width, interlace, (float4 *)cm, (float *)lut);
     }
+}
+
+// fmt: 1 yuv422p10, 2 yuv422p8, 3 yuv420p, 4 nv12, 5 rgba8, 6 bgra8.  Geometry as the Readers /
+// Writers: work items per line = ceil(pitch / 64) (yuv422p10.ts:302-303 etc.), one group per line
+// (4:2:2, RGBA) or per line PAIR (4:2:0: yuv420p.ts:345, nv12.ts:332).
+static unsigned pitch8(unsigned w) { return w + 7 - ((w - 1) % 8); }
+static void set_item(unsigned grp, unsigned lid, unsigned wipg) {
+  g_grp = grp, g_lid = lid, g_lsz = wipg, g_gid[0] = grp * wipg + lid;
+}
+
+int ref_pack_read(int fmt, void *p0, void *p1, void *p2, float *out, unsigned width, unsigned height,
+                  const float *colMatrix12, const float *lut, const float *gamut9) {
+  float cm[12] = {0}, gm[12] = {0};
+  if (colMatrix12) memcpy(cm, colMatrix12, sizeof cm);
+  memcpy(gm, gamut9, 9 * sizeof(float));
+  const bool rgb = fmt >= 5;
+  const unsigned wipg = rgb ? (width + 63) / 64 : (pitch8(width) + 63) / 64;
+  const unsigned groups = (fmt == 3 || fmt == 4) ? height / 2 : height;
+  for (unsigned grp = 0; grp < groups; ++grp)
+    for (unsigned lid = 0; lid < wipg; ++lid) {
+      set_item(grp, lid, wipg);
+      switch (fmt) {
+        case 1: refk_yuv422p10_read(p0, p1, p2, (float4 *)out, width, (float4 *)cm, (float *)lut, (float4 *)gm); break;
+        case 2: refk_yuv422p8_read(p0, p1, p2, (float4 *)out, width, (float4 *)cm, (float *)lut, (float4 *)gm); break;
+        case 3: refk_yuv420p_read(p0, p1, p2, (float4 *)out, width, (float4 *)cm, (float *)lut, (float4 *)gm); break;
+        case 4: refk_nv12_read(p0, p1, (float4 *)out, width, (float4 *)cm, (float *)lut, (float4 *)gm); break;
+        case 5: refk_rgba8_read(p0, (float4 *)out, width, (float *)lut, (float4 *)gm); break;
+        case 6: refk_bgra8_read(p0, (float4 *)out, width, (float *)lut, (float4 *)gm); break;
+        default: return -1;
+      }
+    }
+  return 0;
+}
+
+int ref_pack_write(int fmt, const float *in, void *p0, void *p1, void *p2, unsigned width, unsigned height,
+                   unsigned interlace, const float *colMatrix12, const float *lut) {
+  float cm[12] = {0};
+  if (colMatrix12) memcpy(cm, colMatrix12, sizeof cm);
+  const bool rgb = fmt >= 5, v420 = (fmt == 3 || fmt == 4);
+  const unsigned wipg = rgb ? (width + 63) / 64 : (pitch8(width) + 63) / 64;
+  const unsigned groups = v420 ? height / 2 : (interlace ? height / 2 : height);
+  for (unsigned grp = 0; grp < groups; ++grp)
+    for (unsigned lid = 0; lid < wipg; ++lid) {
+      set_item(grp, lid, wipg);
+      switch (fmt) {
+        case 1: refk_yuv422p10_write((float4 *)in, p0, p1, p2, width, interlace, (float4 *)cm, (float *)lut); break;
+        case 2: refk_yuv422p8_write((float4 *)in, p0, p1, p2, width, interlace, (float4 *)cm, (float *)lut); break;
+        case 3: refk_yuv420p_write((float4 *)in, p0, p1, p2, width, interlace, (float4 *)cm, (float *)lut); break;
+        case 4: refk_nv12_write((float4 *)in, p0, p1, width, interlace, (float4 *)cm, (float *)lut); break;
+        case 5: refk_rgba8_write((float4 *)in, p0, width, interlace, (float *)lut); break;
+        case 6: refk_bgra8_write((float4 *)in, p0, width, interlace, (float *)lut); break;
+        default: return -1;
+      }
+    }
+  return 0;
 }
 
 void ref_yadif(const float *prev, const float *cur, const float *next, int w, int h, int parity,

@@ -106,6 +106,12 @@ FILES = [
     "process/loadSave.ts",
     "process/io.ts",
     "process/v210.ts",
+    "process/yuv422p10.ts",
+    "process/yuv422p8.ts",
+    "process/yuv420p.ts",
+    "process/nv12.ts",
+    "process/rgba8.ts",
+    "process/bgra8.ts",
     "process/yadifCl.ts",
     "process/yadif.ts",
     "process/transform.ts",

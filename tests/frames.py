@@ -123,3 +123,75 @@ def mask_ramp(width, height):
     m[..., 0] = (np.arange(width, dtype=np.float32) / np.float32(max(width - 1, 1)))[None, :]
     m[..., 3] = 1.0
     return m
+
+
+# ---- the other pack formats (planes as raw uint8 byte arrays, like the node Buffers) -----------------
+def pack_pitch(fmt, width):
+    """luma samples per line: getPitch() of each reference format"""
+    if fmt in ("rgba8", "bgra8"):
+        return width
+    if fmt == "v210":
+        return v210_pitch_pixels(width)
+    return width + 7 - ((width - 1) % 8)
+
+
+def pack_plane_bytes(fmt, width, height):
+    p = pack_pitch(fmt, width)
+    if fmt == "v210":
+        return [v210_pitch_bytes(width) * height]
+    if fmt == "yuv422p10":
+        return [p * 2 * height, p * height, p * height]
+    if fmt == "yuv422p8":
+        return [p * height, p * height // 2, p * height // 2]
+    if fmt == "yuv420p":
+        return [p * height, p * height // 4, p * height // 4]
+    if fmt == "nv12":
+        return [p * height, p * height // 2]
+    return [p * 4 * height]
+
+
+def pack_random(fmt, width, height, seed):
+    """Random planes: every 8-bit code, or every 10-bit code for yuv422p10 (legal and illegal)."""
+    sizes = pack_plane_bytes(fmt, width, height)
+    out = []
+    for i, n in enumerate(sizes):
+        if fmt == "yuv422p10":
+            v = (splitmix64(seed * 7 + i, n // 2) % np.uint64(1024)).astype(np.uint16)
+            out.append(v.view(np.uint8).copy())
+        else:
+            out.append((splitmix64(seed * 7 + i, n) % np.uint64(256)).astype(np.uint8))
+    return out
+
+
+def pack_ramp(fmt, width, height):
+    """numpy restatement of each format's reference test pattern (fillBuf): pinned by sha256 of
+    the concatenated planes against the reference run under node (host_maths.json "ramp_fmt")."""
+    p = pack_pitch(fmt, width)
+    if fmt in ("rgba8", "bgra8"):
+        px = np.array([16, 32, 64, 255] if fmt == "rgba8" else [16, 16, 16, 255], np.uint8)
+        return [np.tile(px, width * height)]
+    pairs = width // 2
+    if fmt in ("yuv422p10", "yuv422p8"):
+        wide = fmt == "yuv422p10"
+        lo, n, dt = (64, 438, np.uint16) if wide else (16, 110, np.uint8)
+        k = np.arange(pairs * height, dtype=np.int64).reshape(height, pairs)
+        y0 = lo + 2 * (k % n)
+        Y = np.full((height, p), 64 if wide else 16, dt)
+        Y[:, 0:2 * pairs:2] = y0
+        Y[:, 1:2 * pairs:2] = y0 + 1
+        C = np.full((height, p // 2), 512 if wide else 128, dt)
+        return [Y.reshape(-1).view(np.uint8).copy(), C.reshape(-1).view(np.uint8).copy(), C.reshape(-1).view(np.uint8).copy()]
+    # 4:2:0: line pairs, Y0 ramps up on the first line, Y1 ramps down on the second
+    hp = height // 2
+    k = np.arange(pairs * hp, dtype=np.int64).reshape(hp, pairs)
+    y0 = 16 + 2 * (k % 110)
+    y1 = 234 - 2 * (k % 110)
+    Y = np.full((height, p), 16, np.uint8)
+    Y[0::2, 0:2 * pairs:2] = y0
+    Y[0::2, 1:2 * pairs:2] = y0 + 1
+    Y[1::2, 0:2 * pairs:2] = y1 + 1
+    Y[1::2, 1:2 * pairs:2] = y1
+    if fmt == "yuv420p":
+        C = np.full(hp * (p // 2), 128, np.uint8)
+        return [Y.reshape(-1), C, C.copy()]
+    return [Y.reshape(-1), np.full(hp * p, 128, np.uint8)]

@@ -81,6 +81,20 @@ CASES = [
     _c("wipe_0.5_33x7", "wipe", w=33, h=7, seed=81, wipe=0.5),
 ]
 
+# ---- the other pack formats: read and write, full-range random planes, tail widths ----
+FMT_SPECS = {"yuv422p10": ("709", "709"), "yuv422p8": ("601-625", "709"), "yuv420p": ("709", "2020"),
+             "nv12": ("709", "709"), "rgba8": ("sRGB", "709"), "bgra8": ("sRGB", "sRGB")}
+for _i, (_f, (_sp, _osp)) in enumerate(FMT_SPECS.items()):
+    _widths = (128, 64) if _f in ("rgba8", "bgra8") else (128, 78, 76, 74)   # 78 % 8 = 6, 76 % 8 = 4, 74 % 8 = 2
+    for _w in _widths:
+        CASES.append(_c("fmt_read_%s_%dx4" % (_f, _w), "pack_read", fmt=_f, w=_w, h=4, seed=300 + 10 * _i, spec=_sp,
+                        out_spec=_osp))
+        for _il in (0, 1, 3):
+            if _il and _w != _widths[0]:
+                continue
+            CASES.append(_c("fmt_write_%s_%dx4_il%d" % (_f, _w, _il), "pack_write", fmt=_f, w=_w, h=4,
+                            seed=400 + 10 * _i + _il, lo=-0.1, hi=1.1, spec=_osp, interlace=_il))
+
 BY_NAME = {c["name"]: c for c in CASES}
 
 
@@ -97,6 +111,11 @@ def inputs(c):
         return dict(words=v210_source(c))
     if op == "v210_write":
         dst = np.full(frames.v210_pitch_bytes(c["w"]) * c["h"] // 4, POISON, np.uint32)
+        return dict(rgba=frames.rgba_random(c["w"], c["h"], c["seed"], c["lo"], c["hi"]), dst=dst)
+    if op == "pack_read":
+        return dict(planes=frames.pack_random(c["fmt"], c["w"], c["h"], c["seed"]))
+    if op == "pack_write":
+        dst = [np.full(n, 0xA5, np.uint8) for n in frames.pack_plane_bytes(c["fmt"], c["w"], c["h"])]
         return dict(rgba=frames.rgba_random(c["w"], c["h"], c["seed"], c["lo"], c["hi"]), dst=dst)
     if op == "yadif":
         s = c["seed"] * 1000

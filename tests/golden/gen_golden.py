@@ -63,6 +63,24 @@ def main():
             cm = f32_from_hex(hm["rgb2ycbcr"][c["spec"] + "/10"])
             o = inp["dst"].copy()
             ref.ref_v210_write(inp["rgba"].reshape(-1), o, c["w"], c["h"], c["interlace"], cm, lut("l2g", c["spec"]))
+        elif op == "pack_read":
+            rng = orc.FORMAT_RANGE[c["fmt"]]
+            cm = None if rng is None else f32_from_hex(hm["ycbcr2rgb"]["%s/%d" % (c["spec"], rng[0])])
+            gm = f32_from_hex(hm["rgb2rgb"]["%s->%s" % (c["spec"], c["out_spec"])])
+            o = np.zeros(c["w"] * c["h"] * 4, np.float32)
+            pl = [np.ascontiguousarray(p) for p in inp["planes"]]
+            ptrs = [p.ctypes.data for p in pl] + [None] * (3 - len(pl))
+            assert 0 == ref.ref_pack_read(orc.FORMATS[c["fmt"]], ptrs[0], ptrs[1], ptrs[2], o, c["w"], c["h"],
+                                          None if cm is None else cm.ctypes.data, lut("g2l", c["spec"]), gm)
+        elif op == "pack_write":
+            rng = orc.FORMAT_RANGE[c["fmt"]]
+            cm = None if rng is None else f32_from_hex(hm["rgb2ycbcr"]["%s/%d" % (c["spec"], rng[0])])
+            pl = [p.copy() for p in inp["dst"]]
+            ptrs = [p.ctypes.data for p in pl] + [None] * (3 - len(pl))
+            assert 0 == ref.ref_pack_write(orc.FORMATS[c["fmt"]], inp["rgba"].reshape(-1), ptrs[0], ptrs[1], ptrs[2],
+                                           c["w"], c["h"], c["interlace"], None if cm is None else cm.ctypes.data,
+                                           lut("l2g", c["spec"]))
+            o = np.concatenate(pl)
         elif op == "yadif":
             o = np.zeros(c["w"] * c["h"] * 4, np.float32)
             ref.ref_yadif(inp["prev"].reshape(-1), inp["cur"].reshape(-1), inp["next"].reshape(-1), c["w"], c["h"],
@@ -110,6 +128,28 @@ def main():
     }
     assert kat["ramp_1080p_roundtrip_identical"], "reference round trip is expected to be lossless"
     assert kat["ramp_1080p_sha256"] == hm["ramp"]["1920x1080"], "frames.v210_ramp != reference fillBuf"
+    # the reference's own round-trip scripts (src/process/test/*.ts): test pattern -> read -> write;
+    # they print Buffer.compare() without asserting it - record what the reference kernels give.
+    for fmt, (w, h), spec in (("yuv422p10", (1920, 1080), "709"), ("yuv420p", (1920, 1080), "709"),
+                              ("nv12", (1920, 1080), "709"), ("yuv422p8", (718, 480), "709"),
+                              ("rgba8", (1920, 1080), "sRGB"), ("bgra8", (1920, 1080), "sRGB")):
+        planes = frames.pack_ramp(fmt, w, h)
+        assert hashlib.sha256(np.concatenate(planes).tobytes()).hexdigest() == hm["ramp_fmt"]["%s/%dx%d" % (fmt, w, h)], \
+            "frames.pack_ramp(%s) != reference fillBuf" % fmt
+        rng = orc.FORMAT_RANGE[fmt]
+        rcm = None if rng is None else f32_from_hex(hm["ycbcr2rgb"]["%s/%d" % (spec, rng[0])])
+        wcm = None if rng is None else f32_from_hex(hm["rgb2ycbcr"]["%s/%d" % (spec, rng[0])])
+        rgba = np.zeros(w * h * 4, np.float32)
+        ptrs = [p.ctypes.data for p in planes] + [None] * (3 - len(planes))
+        ref.ref_pack_read(orc.FORMATS[fmt], ptrs[0], ptrs[1], ptrs[2], rgba, w, h, None if rcm is None else rcm.ctypes.data,
+                          lut("g2l", spec), f32_from_hex(hm["rgb2rgb"]["%s->%s" % (spec, spec)]))
+        back = [np.zeros_like(p) for p in planes]
+        bptrs = [p.ctypes.data for p in back] + [None] * (3 - len(back))
+        ref.ref_pack_write(orc.FORMATS[fmt], rgba, bptrs[0], bptrs[1], bptrs[2], w, h, 0,
+                           None if wcm is None else wcm.ctypes.data, lut("l2g", spec))
+        kat["%s_%dx%d_rgba_sha256" % (fmt, w, h)] = hashlib.sha256(rgba.tobytes()).hexdigest()
+        kat["%s_%dx%d_back_sha256" % (fmt, w, h)] = hashlib.sha256(np.concatenate(back).tobytes()).hexdigest()
+        kat["%s_%dx%d_roundtrip_identical" % (fmt, w, h)] = bool(all(np.array_equal(a, b) for a, b in zip(planes, back)))
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)
         f.write("\n")

@@ -54,6 +54,26 @@ for (const [w, h] of [[1920, 1080], [3840, 2160], [1280, 720], [96, 4], [100, 3]
 	out.ramp[`${w}x${h}`] = sha(buf)
 }
 
+// the other pack formats: test pattern hashes and Reader / Writer geometry (SURVEY 8f-1)
+out.ramp_fmt = {}
+out.format_geometry = {}
+for (const fmt of ['yuv422p10', 'yuv422p8', 'yuv420p', 'nv12', 'rgba8', 'bgra8']) {
+	const m = require(path.join(root, 'process', `${fmt}.js`))
+	for (const [w, h] of [[1920, 1080], [718, 480], [128, 4]]) {
+		if ((fmt === 'rgba8' || fmt === 'bgra8') && w === 718) continue
+		const r = new m.Reader(w, h)
+		const wr = new m.Writer(w, h, true)
+		const buf = Buffer.alloc(r.getTotalBytes(), 0x5a)
+		m.fillBuf(buf, w, h)
+		out.ramp_fmt[`${fmt}/${w}x${h}`] = sha(buf)
+		out.format_geometry[`${fmt}/${w}x${h}`] = {
+			numBytes: r.getNumBytes(), readWipg: r.getWorkItemsPerGroup(), readGwi: r.getGlobalWorkItems(),
+			writeWipgInterlaced: wr.getWorkItemsPerGroup(), writeGwiInterlaced: wr.getGlobalWorkItems(),
+			numBits: r.numBits, lumaBlack: r.lumaBlack, lumaWhite: r.lumaWhite, chromaRange: r.chromaRange, isRGB: r.getIsRGB(), name: r.getName()
+		}
+	}
+}
+
 // Transform.getKernelParams against a recording stand-in for the nodencl context: the
 // matrix it uploads is what the device kernel receives (transform.ts:119-175).
 const paramSets = [

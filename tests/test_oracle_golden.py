@@ -90,6 +90,16 @@ def run_oracle(c, inp):
     if op == "v210_write":
         return orc.v210_write(inp["rgba"], c["w"], c["h"], c["interlace"], orc.rgb2ycbcr_matrix(c["spec"]),
                               orc.linear2gamma_lut(c["spec"]), out=inp["dst"].copy())
+    if op == "pack_read":
+        rng = orc.FORMAT_RANGE[c["fmt"]]
+        cm = None if rng is None else orc.ycbcr2rgb_matrix(c["spec"], *rng)
+        return orc.pack_read(c["fmt"], inp["planes"], c["w"], c["h"], cm, orc.gamma2linear_lut(c["spec"]),
+                             orc.rgb2rgb_matrix(c["spec"], c["out_spec"]))
+    if op == "pack_write":
+        rng = orc.FORMAT_RANGE[c["fmt"]]
+        cm = None if rng is None else orc.rgb2ycbcr_matrix(c["spec"], *rng)
+        return np.concatenate(orc.pack_write(c["fmt"], inp["rgba"], c["w"], c["h"], c["interlace"], cm,
+                                             orc.linear2gamma_lut(c["spec"]), planes=inp["dst"]))
     if op == "yadif":
         return orc.yadif(inp["prev"], inp["cur"], inp["next"], c["parity"], c["tff"], c["skip"])
     if op == "transform":
@@ -120,7 +130,7 @@ def test_kernel_matches_reference(name):
     c = cases.BY_NAME[name]
     got = run_oracle(c, cases.inputs(c))
     want = NPZ[name]
-    if got.dtype == np.uint32:
+    if got.dtype in (np.uint32, np.uint8):
         assert np.array_equal(got.reshape(-1), want.reshape(-1))
     else:
         bad = np.flatnonzero(got.reshape(-1).view(np.uint32) != want.reshape(-1).view(np.uint32))
@@ -146,6 +156,39 @@ def test_known_answer_1080p_ramp_roundtrip():
     assert hashlib.sha256(rgba.tobytes()).hexdigest() == KAT["ramp_1080p_read709_rgba_sha256"]
     back = orc.v210_write(rgba, w, h, 0, orc.rgb2ycbcr_matrix("709"), orc.linear2gamma_lut("709"))
     assert np.array_equal(back, ramp)
+
+
+FMT_KATS = [("yuv422p10", 1920, 1080, "709"), ("yuv420p", 1920, 1080, "709"), ("nv12", 1920, 1080, "709"),
+            ("yuv422p8", 718, 480, "709"), ("rgba8", 1920, 1080, "sRGB"), ("bgra8", 1920, 1080, "sRGB")]
+
+
+@pytest.mark.parametrize("fmt,w,h,spec", FMT_KATS)
+def test_reference_roundtrip_scripts(fmt, w, h, spec):
+    """src/process/test/{nv12,yuv420p,yuv422p8,yuv422p10}Test.ts (and the same for the RGBA formats):
+    test pattern -> ToRGBA -> FromRGBA; the reference kernels reproduce the input byte for byte."""
+    planes = frames.pack_ramp(fmt, w, h)
+    assert hashlib.sha256(np.concatenate(planes).tobytes()).hexdigest() == HM["ramp_fmt"]["%s/%dx%d" % (fmt, w, h)]
+    rng = orc.FORMAT_RANGE[fmt]
+    rcm = None if rng is None else orc.ycbcr2rgb_matrix(spec, *rng)
+    wcm = None if rng is None else orc.rgb2ycbcr_matrix(spec, *rng)
+    rgba = orc.pack_read(fmt, planes, w, h, rcm, orc.gamma2linear_lut(spec), orc.rgb2rgb_matrix(spec, spec))
+    assert hashlib.sha256(rgba.tobytes()).hexdigest() == KAT["%s_%dx%d_rgba_sha256" % (fmt, w, h)]
+    back = orc.pack_write(fmt, rgba, w, h, 0, wcm, orc.linear2gamma_lut(spec))
+    assert hashlib.sha256(np.concatenate(back).tobytes()).hexdigest() == KAT["%s_%dx%d_back_sha256" % (fmt, w, h)]
+    assert KAT["%s_%dx%d_roundtrip_identical" % (fmt, w, h)] is True
+    assert all(np.array_equal(a, b) for a, b in zip(planes, back))
+
+
+@pytest.mark.parametrize("key", sorted(HM["format_geometry"]))
+def test_format_geometry_matches_reference(key):
+    fmt, dims = key.split("/")
+    w, h = (int(v) for v in dims.split("x"))
+    g = HM["format_geometry"][key]
+    assert orc.pack_plane_bytes(fmt, w, h) == g["numBytes"] == frames.pack_plane_bytes(fmt, w, h)
+    if not g["isRGB"]:
+        assert orc.FORMAT_RANGE[fmt] == (g["numBits"], g["lumaBlack"], g["lumaWhite"], g["chromaRange"])
+    else:
+        assert orc.FORMAT_RANGE[fmt] is None
 
 
 def test_pipeline_chain_equals_separate_ops():
