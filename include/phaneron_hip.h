@@ -87,7 +87,8 @@ int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, s
 /* ---- programs: `createProgram(kernelSrc, {name, globalWorkItems, workItemsPerGroup})`
  *      (imageProcess.ts:69-72, packer.ts:97-103).  The OpenCL C text is NOT compiled: it (or a
  *      "phaneron:<op>" tag) only selects a precompiled gfx950 kernel by kernel name + argument
- *      list.  Names: read/write (v210), yadif, transform, resize, combine_N, transition_dissolve,
+ *      list.  Names: read/write (v210, yuv422p10le, yuv422p8, yuv420p, nv12, rgba8, bgra8 - told
+ *      apart by their argument lists), yadif, transform, resize, combine_N, transition_dissolve,
  *      transition_wipe, mixer, wipe. ------------------------------------------------------------ */
 int ph_program_create(ph_ctx *ctx, const char *kernel_src, const char *name,
                       const uint32_t *global_work_items, int n_dims,
@@ -154,6 +155,27 @@ int ph_mixer(ph_ctx *ctx, int queue, const void *in0, const void *in1, float mix
              int height, void *out);
 int ph_wipe(ph_ctx *ctx, int queue, const void *in0, const void *in1, float wipe, int width,
             int height, void *out);
+
+/* ---- the other pack formats (src/process/{yuv422p10,yuv422p8,yuv420p,nv12,rgba8,bgra8}.ts):
+ *      planes as the reference's Readers/Writers lay them out (numBytes[] of each format).  v210
+ *      is accepted too (format 0, one plane).  col_matrix12 is NULL for the RGB formats (their
+ *      Loader/Saver skip it: loadSave.ts:52-61,141-149).  Returns the number of planes. ---------- */
+enum {
+  PH_FMT_V210 = 0,
+  PH_FMT_YUV422P10 = 1,
+  PH_FMT_YUV422P8 = 2,
+  PH_FMT_YUV420P = 3,
+  PH_FMT_NV12 = 4,
+  PH_FMT_RGBA8 = 5,
+  PH_FMT_BGRA8 = 6
+};
+int ph_pack_plane_bytes(int format, uint32_t width, uint32_t height, size_t bytes[3]);
+int ph_pack_read(ph_ctx *ctx, int queue, int format, const void *const planes[3], void *out,
+                 uint32_t width, uint32_t height, const void *col_matrix12, const void *gamma_lut,
+                 const void *gamut_matrix9);
+int ph_pack_write(ph_ctx *ctx, int queue, int format, const void *in, void *const planes[3],
+                  uint32_t width, uint32_t height, uint32_t interlace, const void *col_matrix12,
+                  const void *gamma_lut);
 
 /* ---- fused channel pipeline (no reference equivalent: it is the reference's job batch
  *      [v210 read] x n -> combine_n -> v210 write executed as ONE kernel with the

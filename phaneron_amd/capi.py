@@ -27,6 +27,7 @@ EXPORTS = [
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
     "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option", "ph_compose_write_v210",
+    "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write",
 ]
 
 
@@ -109,6 +110,9 @@ def lib():
         "ph_lut_unregister": (ci, [vp, vp]),
         "ph_lut_query": (ci, [vp, vp, C.POINTER(cu), C.POINTER(cu), C.POINTER(cu)]),
         "ph_ctx_set_option": (ci, [vp, C.c_char_p, ci]),
+        "ph_pack_plane_bytes": (ci, [ci, cu, cu, C.POINTER(cs)]),
+        "ph_pack_read": (ci, [vp, ci, ci, C.POINTER(vp), vp, cu, cu, vp, vp, vp]),
+        "ph_pack_write": (ci, [vp, ci, ci, vp, C.POINTER(vp), cu, cu, cu, vp, vp]),
         "ph_compose_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), vp, cu, cu, cu, vp, vp]),
     }
     for name, (res, args) in sig.items():
@@ -165,6 +169,20 @@ def transform_matrix(width, height, flip_h=False, flip_v=False, anchor_x=0.0, an
 
 def v210_pitch_bytes(width):
     return int(lib().ph_v210_pitch_bytes(width))
+
+
+FORMATS = {"v210": 0, "yuv422p10": 1, "yuv422p8": 2, "yuv420p": 3, "nv12": 4, "rgba8": 5, "bgra8": 6}
+# (numBits, lumaBlack, lumaWhite, chromaRange) of each format's Reader/Writer; None = RGB (no YCbCr matrix)
+FORMAT_RANGE = {"v210": (10, 64, 940, 896), "yuv422p10": (10, 64, 940, 896), "yuv422p8": (8, 16, 235, 224),
+                "yuv420p": (8, 16, 235, 224), "nv12": (8, 16, 235, 224), "rgba8": None, "bgra8": None}
+
+
+def pack_plane_bytes(fmt, width, height):
+    b = (C.c_size_t * 3)()
+    n = lib().ph_pack_plane_bytes(FORMATS[fmt], width, height, b)
+    if n < 0:
+        check(n)
+    return [int(b[i]) for i in range(n)]
 
 
 # ---- device side ---------------------------------------------------------------------------------
@@ -264,6 +282,16 @@ class Context:
 
     def wipe(self, in0, in1, wipe, dst, width, height, queue=QUEUE_PROCESS):
         check(lib().ph_wipe(self.h, queue, _ptr(in0), _ptr(in1), wipe, width, height, _ptr(dst)), self.h)
+
+    def pack_read(self, fmt, planes, dst, width, height, col_matrix, lut, gamut, queue=QUEUE_PROCESS):
+        arr = (C.c_void_p * 3)(*([_ptr(p).value for p in planes] + [None] * (3 - len(planes))))
+        check(lib().ph_pack_read(self.h, queue, FORMATS[fmt], arr, _ptr(dst), width, height,
+                                 None if col_matrix is None else _ptr(col_matrix), _ptr(lut), _ptr(gamut)), self.h)
+
+    def pack_write(self, fmt, src, planes, width, height, interlace, col_matrix, lut, queue=QUEUE_PROCESS):
+        arr = (C.c_void_p * 3)(*([_ptr(p).value for p in planes] + [None] * (3 - len(planes))))
+        check(lib().ph_pack_write(self.h, queue, FORMATS[fmt], _ptr(src), arr, width, height, interlace,
+                                  None if col_matrix is None else _ptr(col_matrix), _ptr(lut)), self.h)
 
     def compose_write_v210(self, layers, dst, out_w, out_h, interlace, wr_cm, wr_lut, queue=QUEUE_PROCESS):
         """layers: list of (rgba tensor, width, height, matrix tensor or None)"""

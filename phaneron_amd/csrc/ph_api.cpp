@@ -67,6 +67,8 @@ struct ph_buf {
 };
 
 enum KernelId {
+  K_PACK_READ,   // any pack format other than v210 (ph_program::format)
+  K_PACK_WRITE,
   K_V210_READ,
   K_V210_WRITE,
   K_YADIF,
@@ -83,6 +85,7 @@ struct ph_program {
   ph_ctx *ctx;
   KernelId id;
   int n_layers;  // combine_N
+  int format;    // PH_FMT_* of a read/write program
   std::string kernel;
   uint32_t global[2];
   uint32_t local;
@@ -401,19 +404,39 @@ static void refresh_buf_lut(ph_ctx *ctx, ph_buf *b) {
 int ph_program_create(ph_ctx *ctx, const char *src, const char *name, const uint32_t *gwi, int n_dims, uint32_t wipg,
                       ph_program **out) {
   if (!ctx || !name || !out) return fail(PH_E_INVALID, "ph_program_create: NULL argument");
-  ph_program p{ctx, K_V210_READ, 0, "", {0, 0}, wipg};
+  ph_program p{ctx, K_V210_READ, 0, PH_FMT_V210, "", {0, 0}, wipg};
   for (int i = 0; i < n_dims && i < 2; ++i) p.global[i] = gwi ? gwi[i] : 0;
   const bool tagged = src && 0 == strncmp(src, "phaneron:", 9);
   const char *tag = tagged ? src + 9 : "";
   if (0 == strcmp(name, "read") || 0 == strcmp(name, "write")) {
-    // several pack formats name their kernels read/write; the argument list tells them apart
+    // every pack format names its kernels read/write; tag or argument list tells them apart
     const bool is_read = name[0] == 'r';
-    const bool v210 = tagged ? 0 == strcmp(tag, "v210")
-                             : (src_kernel_has_arg(src, name, "uint4") && src_kernel_has_arg(src, name, "colMatrix") &&
-                                !src_kernel_has_arg(src, name, "inputY") && !src_kernel_has_arg(src, name, "outputY"));
-    if (!v210) return fail(PH_E_UNKNOWN_KERNEL, "no gfx950 kernel for pack format of '%s' (only v210 is built)", name);
-    p.id = is_read ? K_V210_READ : K_V210_WRITE;
-    p.kernel = is_read ? "v210_read" : "v210_write";
+    static const char *fmt_names[] = {"v210", "yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"};
+    int fmt = -1;
+    if (tagged) {
+      for (int i = 0; i < 7; ++i)
+        if (0 == strcmp(tag, fmt_names[i])) fmt = i;
+    } else if (src_kernel_has_arg(src, name, "uint4") && src_kernel_has_arg(src, name, "colMatrix")) {
+      fmt = PH_FMT_V210;  // v210.ts:25-30,113-118
+    } else if (src_kernel_has_arg(src, name, is_read ? "inputC" : "outputC")) {
+      fmt = PH_FMT_NV12;  // nv12.ts:25-26
+    } else if (src_kernel_has_arg(src, name, "ushort8")) {
+      fmt = PH_FMT_YUV422P10;  // yuv422p10.ts:25
+    } else if (src_kernel_has_arg(src, name, is_read ? "inputU" : "outputU")) {
+      // yuv422p8 and yuv420p share a signature; only the 4:2:0 kernels address line pairs
+      fmt = (src && strstr(src, is_read ? "inOffUV" : "outOffUV")) ? PH_FMT_YUV420P : PH_FMT_YUV422P8;
+    } else if (src_kernel_has_arg(src, name, "uchar4") && !src_kernel_has_arg(src, name, "colMatrix")) {
+      fmt = (src && strstr(src, "bgra")) ? PH_FMT_BGRA8 : PH_FMT_RGBA8;  // bgra8.ts:49
+    }
+    if (fmt < 0) return fail(PH_E_UNKNOWN_KERNEL, "cannot tell which pack format the '%s' kernel belongs to", name);
+    p.format = fmt;
+    if (fmt == PH_FMT_V210) {
+      p.id = is_read ? K_V210_READ : K_V210_WRITE;
+      p.kernel = is_read ? "v210_read" : "v210_write";
+    } else {
+      p.id = is_read ? K_PACK_READ : K_PACK_WRITE;
+      p.kernel = std::string(fmt_names[fmt]) + (is_read ? "_read" : "_write");
+    }
   } else if (0 == strcmp(name, "yadif")) {
     p.id = K_YADIF, p.kernel = "yadif";
   } else if (0 == strcmp(name, "transform")) {
@@ -468,6 +491,41 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
 #define TRY(x) \
   if ((rc = (x)) != PH_OK) return rc
   switch (prog->id) {
+    case K_PACK_READ:
+    case K_PACK_WRITE: {
+      const bool rd = prog->id == K_PACK_READ;
+      const int fmt = prog->format;
+      const bool rgb = fmt >= PH_FMT_RGBA8, v420 = (fmt == PH_FMT_YUV420P || fmt == PH_FMT_NV12);
+      double il = 0;
+      TRY(need_num(args, n, "width", &num));
+      if (!rd) TRY(need_num(args, n, "interlace", &il));
+      const uint32_t width = (uint32_t)num, interlace = (uint32_t)il;
+      if (!prog->local || !width) return fail(PH_E_INVALID, "%s: width / workItemsPerGroup not set", prog->kernel.c_str());
+      // Readers: global = wipg*height (4:2:0: /2).  Writers: /2 when interlaced, 4:2:0 always /2
+      uint32_t height = prog->global[0] / prog->local;
+      if (v420) height *= 2;
+      else if (!rd && interlace) height *= 2;
+      size_t pb[3];
+      const int np = ph_pack_plane_bytes(fmt, width, height, pb);
+      static const char *in_names[3][3] = {{"input", "", ""}, {"inputY", "inputC", ""}, {"inputY", "inputU", "inputV"}};
+      static const char *out_names[3][3] = {{"output", "", ""}, {"outputY", "outputC", ""}, {"outputY", "outputU", "outputV"}};
+      const void *planes[3] = {nullptr, nullptr, nullptr};
+      ph_buf *pl = nullptr;
+      for (int i = 0; i < np; ++i) {
+        TRY(need_buf(args, n, (rd ? in_names : out_names)[np - 1][i], pb[i], &pl));
+        planes[i] = pl->dptr;
+      }
+      TRY(need_buf(args, n, rd ? "output" : "input", (size_t)width * height * 16, &o));
+      if (!rgb) TRY(need_buf(args, n, "colMatrix", 48, &b));
+      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
+      refresh_buf_lut(ctx, c);
+      if (rd) {
+        TRY(need_buf(args, n, "gamutMatrix", 36, &d));
+        return ph_pack_read(ctx, queue, fmt, planes, o->dptr, width, height, rgb ? nullptr : b->dptr, c->dptr, d->dptr);
+      }
+      return ph_pack_write(ctx, queue, fmt, o->dptr, const_cast<void *const *>(planes), width, height, interlace,
+                           rgb ? nullptr : b->dptr, c->dptr);
+    }
     case K_V210_READ: {
       TRY(need_num(args, n, "width", &num));
       const uint32_t width = (uint32_t)num;
@@ -654,6 +712,43 @@ int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *laye
     }
   }
   PH_LAUNCH(ph::launch_fused_v210_combine(stream_of(ctx, queue), n, a));
+}
+
+int ph_pack_plane_bytes(int format, uint32_t width, uint32_t height, size_t bytes[3]) {
+  if (!bytes || !width) return fail(PH_E_INVALID, "ph_pack_plane_bytes: NULL/zero argument");
+  const int n = ph::pack_plane_bytes(format, width, height, bytes);
+  return n < 0 ? fail(PH_E_INVALID, "ph_pack_plane_bytes: unknown format %d", format) : n;
+}
+
+int ph_pack_read(ph_ctx *ctx, int queue, int format, const void *const planes[3], void *out, uint32_t width,
+                 uint32_t height, const void *cm, const void *lut, const void *gm) {
+  if (!ctx || !planes || !out || !lut || !gm || !width) return fail(PH_E_INVALID, "ph_pack_read: NULL/zero argument");
+  if (format == PH_FMT_V210) return ph_v210_read(ctx, queue, planes[0], out, width, height, cm, lut, gm);
+  size_t pb[3];
+  const int np = ph::pack_plane_bytes(format, width, height, pb);
+  if (np < 0) return fail(PH_E_INVALID, "ph_pack_read: unknown format %d", format);
+  for (int i = 0; i < np; ++i)
+    if (!planes[i]) return fail(PH_E_INVALID, "ph_pack_read: plane %d is NULL", i);
+  if (format < PH_FMT_RGBA8 && !cm) return fail(PH_E_INVALID, "ph_pack_read: YCbCr formats need a colMatrix");
+  if (!height) return PH_OK;
+  PH_LAUNCH(ph::launch_pack_read(stream_of(ctx, queue), format, planes, out, width, height, cm, lut, gm, lds_view(ctx, lut),
+                                 (uint32_t)ctx->props.multiProcessorCount));
+}
+
+int ph_pack_write(ph_ctx *ctx, int queue, int format, const void *in, void *const planes[3], uint32_t width,
+                  uint32_t height, uint32_t interlace, const void *cm, const void *lut) {
+  if (!ctx || !planes || !in || !lut || !width) return fail(PH_E_INVALID, "ph_pack_write: NULL/zero argument");
+  if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_pack_write: interlace must be 0, 1 or 3");
+  if (format == PH_FMT_V210) return ph_v210_write(ctx, queue, in, planes[0], width, height, interlace, cm, lut);
+  size_t pb[3];
+  const int np = ph::pack_plane_bytes(format, width, height, pb);
+  if (np < 0) return fail(PH_E_INVALID, "ph_pack_write: unknown format %d", format);
+  for (int i = 0; i < np; ++i)
+    if (!planes[i]) return fail(PH_E_INVALID, "ph_pack_write: plane %d is NULL", i);
+  if (format < PH_FMT_RGBA8 && !cm) return fail(PH_E_INVALID, "ph_pack_write: YCbCr formats need a colMatrix");
+  if (!height) return PH_OK;
+  PH_LAUNCH(ph::launch_pack_write(stream_of(ctx, queue), format, in, planes, width, height, interlace, cm, lut,
+                                  lds_view(ctx, lut), (uint32_t)ctx->props.multiProcessorCount));
 }
 
 int ph_compose_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers, void *out, uint32_t out_w,

@@ -54,6 +54,15 @@ hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32
                                 const void *cm, const void *gm, const LutView &lut, uint32_t num_cus);
 hipError_t launch_v210_write_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
                                  uint32_t interlace, const void *cm, const LutView &lut, uint32_t num_cus);
+// the other pack formats (ph_kernels_fmt.hip); lv == NULL selects the global-gather form
+uint32_t pack_pitch(int fmt, uint32_t width);
+int pack_plane_bytes(int fmt, uint32_t width, uint32_t height, size_t bytes[3]);
+hipError_t launch_pack_read(hipStream_t s, int fmt, const void *const planes[3], void *out, uint32_t width,
+                            uint32_t height, const void *cm, const void *table, const void *gm, const LutView *lv,
+                            uint32_t num_cus);
+hipError_t launch_pack_write(hipStream_t s, int fmt, const void *in, void *const planes[3], uint32_t width,
+                             uint32_t height, uint32_t interlace, const void *cm, const void *table, const LutView *lv,
+                             uint32_t num_cus);
 hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32_t num_cus);
 hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int parity,
                         int tff, int skip, void *out);

@@ -49,6 +49,26 @@ class ColourParams:
         return cls._cache[key]
 
     @classmethod
+    def fmt_reader(cls, fmt, spec, out_spec):
+        """(colMatrix or None, lut, gamut) for a pack format: matrices use the format's own code ranges"""
+        key = ("fr", fmt, spec, out_spec)
+        if key not in cls._cache:
+            rng = capi.FORMAT_RANGE[fmt]
+            _, lut, _ = cls.reader(spec, out_spec)
+            cm = None if rng is None else dev(capi.ycbcr2rgb_matrix(spec, *rng))
+            cls._cache[key] = (cm, lut, dev(np.concatenate([capi.rgb2rgb_matrix(spec, out_spec), np.zeros(3, np.float32)])))
+        return cls._cache[key]
+
+    @classmethod
+    def fmt_writer(cls, fmt, spec):
+        key = ("fw", fmt, spec)
+        if key not in cls._cache:
+            rng = capi.FORMAT_RANGE[fmt]
+            _, lut = cls.writer(spec)
+            cls._cache[key] = (None if rng is None else dev(capi.rgb2ycbcr_matrix(spec, *rng)), lut)
+        return cls._cache[key]
+
+    @classmethod
     def writer(cls, spec):
         key = ("w", spec)
         if key not in cls._cache:
@@ -75,6 +95,18 @@ def run_case(c, inp, hm=None):
         src = dev(inp["rgba"])
         k.v210_write(src, out, c["w"], c["h"], c["interlace"], cm, lut)
         return host(out, np.uint32)
+    if op == "pack_read":
+        cm, lut, gm = ColourParams.fmt_reader(c["fmt"], c["spec"], c["out_spec"])
+        out = torch.zeros(c["h"] * c["w"] * 4, dtype=torch.float32, device="cuda")
+        planes = [dev(p) for p in inp["planes"]]
+        k.pack_read(c["fmt"], planes, out, c["w"], c["h"], cm, lut, gm)
+        return host(out)
+    if op == "pack_write":
+        cm, lut = ColourParams.fmt_writer(c["fmt"], c["spec"])
+        planes = [dev(p) for p in inp["dst"]]
+        src = dev(inp["rgba"])
+        k.pack_write(c["fmt"], src, planes, c["w"], c["h"], c["interlace"], cm, lut)
+        return np.concatenate([host(p) for p in planes])
     if op == "yadif":
         out = torch.zeros(c["h"] * c["w"] * 4, dtype=torch.float32, device="cuda")
         p, cu, n = dev(inp["prev"]), dev(inp["cur"]), dev(inp["next"])

@@ -34,8 +34,12 @@ def lut_path(request):
 
 
 def assert_bits(got, want, what=""):
-    g = np.ascontiguousarray(got).reshape(-1).view(np.uint32)
-    w = np.ascontiguousarray(want).reshape(-1).view(np.uint32)
+    got, want = np.ascontiguousarray(got).reshape(-1), np.ascontiguousarray(want).reshape(-1)
+    if got.dtype == np.uint8:
+        assert np.array_equal(got, want), "%s: %d bytes differ" % (what, int((got != want).sum()))
+        return
+    g = got.view(np.uint32)
+    w = want.view(np.uint32)
     assert g.shape == w.shape, (g.shape, w.shape)
     bad = np.flatnonzero(g != w)
     assert bad.size == 0, "%s: %d of %d words differ, first at %d: %08x vs %08x" % (
@@ -256,6 +260,59 @@ def test_compose_write_refuses_unregistered_lut():
     with pytest.raises(capi.PhaneronError, match="LDS form"):
         hh.ctx().compose_write_v210([(t, 96, 4, None), (t, 96, 4, None)], torch.zeros(96 * 4, dtype=torch.int32, device="cuda"),
                                     96, 4, 0, hh.ColourParams.writer("709")[0], raw)
+
+
+FMT_KATS = [("yuv422p10", 1920, 1080, "709"), ("yuv420p", 1920, 1080, "709"), ("nv12", 1920, 1080, "709"),
+            ("yuv422p8", 718, 480, "709"), ("rgba8", 1920, 1080, "sRGB"), ("bgra8", 1920, 1080, "sRGB")]
+
+
+@pytest.mark.parametrize("fmt,w,h,spec", FMT_KATS)
+def test_reference_roundtrip_scripts_on_gpu(fmt, w, h, spec):
+    """The reference's src/process/test/*Test.ts scripts: test pattern -> ToRGBA -> FromRGBA ->
+    Buffer.compare == 0, at their own sizes (1920x1080; 718 wide for yuv422p8)."""
+    import torch
+    import hip_harness as hh
+    planes = frames.pack_ramp(fmt, w, h)
+    k = hh.ctx()
+    rcm, rlut, rgm = hh.ColourParams.fmt_reader(fmt, spec, spec)
+    wcm, wlut = hh.ColourParams.fmt_writer(fmt, spec)
+    rgba = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+    dplanes = [hh.dev(p) for p in planes]
+    back = [torch.zeros_like(p) for p in dplanes]
+    k.pack_read(fmt, dplanes, rgba, w, h, rcm, rlut, rgm)
+    k.pack_write(fmt, rgba, back, w, h, 0, wcm, wlut)
+    assert hashlib.sha256(hh.host(rgba).tobytes()).hexdigest() == KAT["%s_%dx%d_rgba_sha256" % (fmt, w, h)]
+    for a, b in zip(planes, back):
+        assert np.array_equal(a, hh.host(b))
+
+
+@pytest.mark.parametrize("fmt", ["yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"])
+def test_pack_formats_vs_oracle_1080(fmt):
+    """Full-range random planes at 1920x270 (+ an odd tail width), both fields, against the oracle."""
+    import torch
+    import hip_harness as hh
+    for w, h in ((1920, 270), (718, 10)):
+        if fmt in ("rgba8", "bgra8") and w == 718:
+            w = 704
+        planes = frames.pack_random(fmt, w, h, 77)
+        rng = orc.FORMAT_RANGE[fmt]
+        spec, ospec = "709", "2020"
+        rcm, rlut, rgm = hh.ColourParams.fmt_reader(fmt, spec, ospec)
+        out = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+        hh.ctx().pack_read(fmt, [hh.dev(p) for p in planes], out, w, h, rcm, rlut, rgm)
+        want = orc.pack_read(fmt, planes, w, h, None if rng is None else orc.ycbcr2rgb_matrix(spec, *rng),
+                             orc.gamma2linear_lut(spec), orc.rgb2rgb_matrix(spec, ospec))
+        assert_bits(hh.host(out), want, "%s read %dx%d" % (fmt, w, h))
+        rgba = frames.rgba_random(w, h, 78, -0.05, 1.05)
+        wcm, wlut = hh.ColourParams.fmt_writer(fmt, ospec)
+        for il in (0, 1, 3):
+            dst = [np.full(n, 0x5A, np.uint8) for n in frames.pack_plane_bytes(fmt, w, h)]
+            dplanes = [hh.dev(p) for p in dst]
+            hh.ctx().pack_write(fmt, hh.dev(rgba), dplanes, w, h, il, wcm, wlut)
+            want = orc.pack_write(fmt, rgba, w, h, il, None if rng is None else orc.rgb2ycbcr_matrix(ospec, *rng),
+                                  orc.linear2gamma_lut(ospec), planes=dst)
+            for i, (g, wnt) in enumerate(zip(dplanes, want)):
+                assert np.array_equal(hh.host(g), wnt), "%s write il=%d plane %d %dx%d" % (fmt, il, i, w, h)
 
 
 def test_fused_equals_unfused_kernels_2160p():
