@@ -5,6 +5,7 @@
 // reads <workdir>/job.json + input .bin files, writes output .bin files and result.json.
 const fs = require('fs')
 const path = require('path')
+const crypto = require('crypto')
 const { clContext } = require('../index.js')
 const { ClProcessJobs } = require('../clJobQueue.js')
 const { ToRGBA, FromRGBA } = require('../process/io.js')
@@ -110,6 +111,43 @@ async function main() {
 			fs.writeFileSync(path.join(dir, `yadif_out${i}.bin`), outs[i])
 		}
 		yadif.release()
+	}
+
+	// 4. the reference's other round-trip scripts (src/process/test/<fmt>Test.ts): pattern -> read -> write
+	//    (progressive) -> compare with the input; RGBA and output hashes are checked against the
+	//    reference kernels' own results (tests/golden/kat.json)
+	result.formats = {}
+	for (const { fmt, width: W, height: H, spec } of job.formats || []) {
+		const mod = require(`../process/${fmt}.js`)
+		const toRGBA = new ToRGBA(ctx, spec, spec, new mod.Reader(W, H), jobs)
+		await toRGBA.init()
+		const fromRGBA = new FromRGBA(ctx, spec, new mod.Writer(W, H, false), jobs)
+		await fromRGBA.init()
+		const srcs = await toRGBA.createSources(fmt)
+		const rgba = await toRGBA.createDest({ width: W, height: H }, fmt)
+		const dsts = await fromRGBA.createDests(fmt)
+		const whole = Buffer.alloc(toRGBA.getTotalBytes())
+		mod.fillBuf(whole, W, H)
+		const planes = []
+		let off = 0
+		for (const n of toRGBA.getNumBytes()) { planes.push(whole.slice(off, off + n)); off += n }
+		await toRGBA.loadFrame(planes, srcs, ctx.queue.load)
+		await ctx.waitFinish(ctx.queue.load)
+		rgba.addRef() // keep it for the read-back below; the writer's callback releases one reference
+		toRGBA.processFrame(`${fmt} rd`, srcs, rgba)
+		await jobs.runQueue({ source: `${fmt} rd`, timestamp: 0 })
+		fromRGBA.processFrame(`${fmt} wr`, rgba, dsts, Interlace.Progressive)
+		await jobs.runQueue({ source: `${fmt} wr`, timestamp: 0 })
+		await fromRGBA.saveFrame(dsts, ctx.queue.unload)
+		await rgba.hostAccess('readonly', ctx.queue.unload)
+		const back = Buffer.concat(dsts.map((d) => Buffer.from(d)))
+		result.formats[fmt] = {
+			compare: whole.compare(back),
+			rgbaSha256: crypto.createHash('sha256').update(rgba).digest('hex'),
+			backSha256: crypto.createHash('sha256').update(back).digest('hex')
+		}
+		rgba.release()
+		dsts.forEach((d) => d.release())
 	}
 
 	result.buffers = ctx.logBuffers()

@@ -156,6 +156,38 @@ async function main() {
 	await wipe.run({ input0: layers[0], input1: layers[1], wipe: 0.37, output: rgbaI }, { source: 'sw', timestamp: ts }, () => {})
 	await jobs.runQueue({ source: 'sw', timestamp: ts++ }) // one batch, two kernels, one waitFinish
 
+	note(trace, 'the other pack formats: load -> read -> write (both fields) -> save, plane-count errors')
+	const fmtColours = { yuv422p10: ['709', '709'], yuv422p8: ['601-625', '709'], yuv420p: ['709', '2020'], nv12: ['709', '709'], rgba8: ['sRGB', '709'], bgra8: ['sRGB', 'sRGB'] }
+	for (const fmt of Object.keys(fmtColours)) {
+		const mod = req(`process/${fmt}.js`)
+		const [inSpec, outSpec] = fmtColours[fmt]
+		const rd = new mod.Reader(W, H)
+		const to = new ToRGBA(ctx, inSpec, outSpec, rd, jobs)
+		await to.init()
+		const wrI = new mod.Writer(W, H, true)
+		const from = new FromRGBA(ctx, outSpec, wrI, jobs)
+		await from.init()
+		trace.push({ op: 'formatGeometry', fmt, name: rd.getName(), numBytes: rd.getNumBytes(), total: rd.getTotalBytes(), rgba: rd.getNumBytesRGBA(), isRGB: rd.getIsRGB(), readWipg: rd.getWorkItemsPerGroup(), readGwi: rd.getGlobalWorkItems(), writeWipg: wrI.getWorkItemsPerGroup(), writeGwi: wrI.getGlobalWorkItems(), progGwi: new mod.Writer(W, H, false).getGlobalWorkItems() })
+		const fs = await to.createSources(`${fmt} src`)
+		const fd = await to.createDest(dims, `${fmt} src`)
+		const fo = await from.createDests(`${fmt} out`)
+		const whole = Buffer.alloc(to.getTotalBytes())
+		mod.fillBuf(whole, W, H)
+		const planes = []
+		let off = 0
+		for (const n of to.getNumBytes()) { planes.push(whole.slice(off, off + n)); off += n }
+		await to.loadFrame(planes.length === 1 ? whole : planes, fs, ctx.queue.load)
+		await ctx.waitFinish(ctx.queue.load)
+		to.processFrame(`${fmt} rd`, fs, fd)
+		await jobs.runQueue({ source: `${fmt} rd`, timestamp: 0 })
+		from.processFrame(`${fmt} wr`, fd, fo, Interlace.TopField)
+		from.processFrame(`${fmt} wr`, fd, fo, Interlace.BottomField)
+		await jobs.runQueue({ source: `${fmt} wr`, timestamp: 0 })
+		await from.saveFrame(fo, ctx.queue.unload)
+		await expectThrow(trace, `${fmt} reader plane count`, async () => rd.getKernelParams({ sources: fs.concat(fs), dest: fd }))
+		await expectThrow(trace, `${fmt} writer plane count`, async () => wrI.getKernelParams({ source: fd, dests: [] }))
+	}
+
 	note(trace, 'dispatcher: FIFO across keys, late arrivals, clearQueue (clJobQueue.ts:53-141)')
 	const order = []
 	const mk = (src, t, tag) => mix.run({ input0: layers[0], input1: layers[1], mix: t / 10, output: rgbaI }, { source: src, timestamp: t }, () => order.push(tag))

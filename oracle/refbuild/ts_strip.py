@@ -75,8 +75,10 @@ def strip(src, local_modules):
     src = re.sub(r"\)\s*:\s*%s\s*(\{|=>)" % TYPE, r") \1", src)
     # parameter / variable / field annotations:  name?: T
     src = re.sub(r"(\b\w+)\??\s*:\s*%s(?=\s*[,)=;\n])" % TYPE, r"\1", src)
-    # optional chaining (node 12)
-    src = src.replace("?.", ".")
+    # optional chaining (node 12 has none): the path's files only use the statement form
+    # `this.field?.method(...)`, which is rewritten to a guarded call with the same semantics
+    src = re.sub(r"^(\s*)((?:this\.)?\w+)\?\.(\w+\([^\n]*\))\s*$", r"\1if (\2 != null) \2.\3", src, flags=re.M)
+    assert "?." not in src, "optional chaining in an unsupported position"
     # V8 7.8 rejects a class field literally named `in`
     src = re.sub(r"^(\s*)in = ", r"\1;['in'] = ", src, flags=re.M)
 

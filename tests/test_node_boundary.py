@@ -62,6 +62,11 @@ def test_napi_addon_builds_loads_and_refuses_without_gpu():
         assert "no HIP device" in r.stdout, r.stdout + r.stderr
 
 
+# the round trips gen_golden.py recorded from the reference kernels (kat.json "<fmt>_<w>x<h>_*")
+FORMAT_KATS = [("yuv422p10", 1920, 1080, "709"), ("yuv420p", 1920, 1080, "709"), ("nv12", 1920, 1080, "709"),
+               ("yuv422p8", 718, 480, "709"), ("rgba8", 1920, 1080, "sRGB"), ("bgra8", 1920, 1080, "sRGB")]
+
+
 @needs_node
 @pytest.mark.gpu
 def test_node_layer_end_to_end_on_gpu(tmp_path):
@@ -79,7 +84,8 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
         f.tofile(tmp_path / ("field%d.bin" % i))
     job = dict(channel=dict(width=w, height=h, layers=["layer%d.bin" % i for i in range(n)], readSpec="709",
                             writeSpec="2020", pip=pip),
-               yadif=dict(width=yw, height=yh, frames=["field%d.bin" % i for i in range(4)], tff=True))
+               yadif=dict(width=yw, height=yh, frames=["field%d.bin" % i for i in range(4)], tff=True),
+               formats=[dict(fmt=f, width=fw, height=fh, spec=sp) for f, fw, fh, sp in FORMAT_KATS])
     (tmp_path / "job.json").write_text(json.dumps(job))
     r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "gpu_run.js"), str(tmp_path)], capture_output=True,
                        text=True, timeout=300)
@@ -106,3 +112,13 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
             got = np.fromfile(tmp_path / ("yadif_out%d.bin" % k), np.float32)
             assert np.array_equal(got.view(np.uint32), want.reshape(-1).view(np.uint32)), k
             k += 1
+
+    # the other formats' round-trip scripts: same bytes back, and RGBA / output hashes equal to what the
+    # reference's own kernels produced for the same pattern
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json")))
+    for f, fw, fh, _ in FORMAT_KATS:
+        got = res["formats"][f]
+        key = "%s_%dx%d" % (f, fw, fh)
+        assert got["rgbaSha256"] == kat[key + "_rgba_sha256"], f
+        assert got["backSha256"] == kat[key + "_back_sha256"], f
+        assert (got["compare"] == 0) == kat[key + "_roundtrip_identical"], f
