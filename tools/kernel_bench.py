@@ -15,6 +15,7 @@ from phaneron_amd import capi
 
 def main():
     w, h = 3840, 2160
+    only_formats = [a for a in sys.argv[1:] if not a.startswith('-')]
     ctx = capi.Context(0)
     stream = ctx.torch_stream()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -39,6 +40,8 @@ def main():
     vb, ib = words * 4, w * h * 16
 
     def timeit(name, fn, bytes_, reps=30):
+        if only_formats and not name.startswith("pack_"):
+            return
         for i in range(3):
             fn(i)
         ctx.wait()
@@ -76,6 +79,22 @@ def main():
             timeit("fused_v210_combine_%d 2160p" % n,
                    lambda i, n=n: ctx.fused_v210_combine([v[(i + j) % R] for j in range(n)], out_v[i % 2], w, h, *rd, *wr),
                    (n + 1) * vb)
+    # the other pack formats: read and write at 2160p (8-bit matrices for the 8-bit YUV formats)
+    rng = {"yuv422p10": (10, 64, 940, 896), "yuv422p8": (8, 16, 235, 224), "yuv420p": (8, 16, 235, 224),
+           "nv12": (8, 16, 235, 224), "rgba8": None, "bgra8": None}
+    for fmt in only_formats or rng:
+        sizes = capi.pack_plane_bytes(fmt, w, h)
+        rcm = None if rng[fmt] is None else dev(capi.ycbcr2rgb_matrix("709", *rng[fmt]))
+        wcm = None if rng[fmt] is None else dev(capi.rgb2ycbcr_matrix("2020", *rng[fmt]))
+        mask = 0x03FF03FF if fmt == "yuv422p10" else -1
+        planes = [[torch.randint(0, 2 ** 31, ((n + 3) // 4,), dtype=torch.int32, device="cuda") & mask for n in sizes]
+                  for _ in range(R)]
+        outp = [[torch.empty((n + 3) // 4, dtype=torch.int32, device="cuda") for n in sizes] for _ in range(2)]
+        torch.cuda.synchronize()
+        timeit("pack_read %s 2160p" % fmt, lambda i: ctx.pack_read(fmt, planes[i % R], out_img[i % 2], w, h, rcm, rd[1], rd[2]),
+               sum(sizes) + ib)
+        timeit("pack_write %s 2160p" % fmt, lambda i: ctx.pack_write(fmt, img[i % R], outp[i % 2], w, h, 0, wcm, wr[1]),
+               sum(sizes) + ib)
     ctx.close()
 
 
