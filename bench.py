@@ -58,8 +58,11 @@ def synth_v210(torch, width, height, seed, device):
 
 
 def cpu_baseline(args, budget_s):
-    """The oracle's restatement of the same pipeline (read x4 -> combine_4 -> write) on the
-    host cores, on a bounded sample: whole 2160p frames until the budget is used."""
+    """The same pipeline (read x4 -> combine_4 -> write) on the host cores, on a bounded sample:
+    whole frames until the budget is used.  kind "reference" = the reference's own kernel text
+    compiled for x86 (oracle/_ref, built in the build container and shipped prebuilt), its work
+    groups spread over the host threads; kind "port" = the oracle's restatement, if that build
+    is absent or the host CPU lacks AVX2/FMA."""
     import numpy as np
     import frames
     from oracle import orc
@@ -69,19 +72,27 @@ def cpu_baseline(args, budget_s):
     wr = (orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
     scratch = np.empty((n + 1) * w * h * 4, np.float32)
     cores = orc.effective_cpus()  # cgroup quota, not the 256 logical CPUs the box reports
-    orc.set_num_threads(cores)
-    orc.pipeline_v210_combine(layers, w, h, *rd, *wr, scratch=scratch)  # warm-up (page faults)
+    if orc.have_ref_fast():
+        r = orc.ref_fast()
+        r.ref_set_num_threads(cores)
+        kind, what = "reference", "the reference's OpenCL kernels compiled for x86 (oracle/_ref, -O3 -mavx2 -mfma; " \
+                                  "read x%d, combine_%d, write as separate passes; work groups over %d threads)" % (n, n, cores)
+        run = lambda: orc.ref_pipeline_v210_combine(r, layers, w, h, *rd, *wr, scratch=scratch)
+    else:
+        orc.set_num_threads(cores)
+        kind, what = "port", "oracle/ restatement (OpenMP over lines, %d threads)" % cores
+        run = lambda: orc.pipeline_v210_combine(layers, w, h, *rd, *wr, scratch=scratch)
+    run()  # warm-up (page faults)
     t0 = time.perf_counter()
     frames_done = 0
     while True:
-        orc.pipeline_v210_combine(layers, w, h, *rd, *wr, scratch=scratch)
+        run()
         frames_done += 1
         el = time.perf_counter() - t0
         if el >= budget_s or frames_done >= 200:
             break
-    return {"value": round(frames_done / el, 3), "unit": "frames/sec", "cores": cores, "kind": "port",
-            "sample": "%d whole %dx%d %d-layer frames through oracle/ (OpenMP over lines, %d threads) in %.1f s"
-                      % (frames_done, w, h, n, cores, el)}
+    return {"value": round(frames_done / el, 3), "unit": "frames/sec", "cores": cores, "kind": kind,
+            "sample": "%d whole %dx%d %d-layer frames in %.1f s through %s" % (frames_done, w, h, n, el, what)}
 
 
 def recorded_traffic():

@@ -81,6 +81,27 @@ int ph_buf_dims(const ph_buf *buf, int *width, int *height);
 enum { PH_HOST_READONLY = 0, PH_HOST_WRITEONLY = 1, PH_HOST_NONE = 2 };
 int ph_buf_host_access(ph_buf *buf, int dir, int queue, const void *src, size_t bytes);
 void *ph_buf_host_ptr(ph_buf *buf); /* pinned host mirror (allocated on first use) */
+/* Staged producers / consumers (the queue.load / queue.unload roles of io.ts:79-98,
+ * 166-174).  nodencl orders its three queues through host-side `waitFinish`; these two calls let a
+ * caller that keeps a ring of frames in flight order them on the device instead, so uploads of frame
+ * n+1 and downloads of frame n-1 overlap the kernels of frame n without a host round trip:
+ *   ph_queue_wait_queue : work enqueued on `waiter` after this call starts only once everything
+ *                         enqueued on `signal` before this call has finished (event record + wait).
+ *   ph_buf_download_async: device -> pinned host mirror on `queue`, no host synchronisation; the
+ *                         bytes at ph_buf_host_ptr() are valid after ph_wait_finish(queue) or after a
+ *                         ph_event recorded behind it has been waited for.
+ * (Upload without a host wait already exists: PH_HOST_WRITEONLY with no src, fill the mirror,
+ * PH_HOST_NONE.) */
+int ph_queue_wait_queue(ph_ctx *ctx, int waiter_queue, int signal_queue);
+int ph_buf_download_async(ph_buf *buf, int queue);
+/* a point in a queue the host can wait for without draining what was enqueued after it (one per
+ * ring slot in a staged chain).  ph_event_wait returns when the work enqueued before the record has
+ * finished; the event stays valid until ph_event_destroy. */
+typedef struct ph_event ph_event;
+int ph_event_record(ph_ctx *ctx, int queue, ph_event **out);
+int ph_event_wait(ph_event *ev);
+int ph_event_query(ph_event *ev); /* 1 = finished, 0 = still running, negative = error */
+int ph_event_destroy(ph_event *ev);
 /* the `logBuffers()` debug hook (src/index.ts:184): live buffers / pooled bytes */
 int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes);
 

@@ -27,6 +27,14 @@ export interface OpenCLBuffer extends Buffer {
 	addRef(): void
 	release(): void
 	refCount(): number
+	/** staging extension: device -> mirror on `queue` (default unload) without a host wait */
+	downloadAsync(queue?: number): void
+}
+
+/** staging extension: a recorded point in a queue */
+export interface QueueEvent {
+	wait(): Promise<void>
+	done(): boolean
 }
 
 export interface OpenCLProgram {
@@ -54,5 +62,9 @@ export class clContext {
 	createProgram(kernel: string, options: { name: string; globalWorkItems?: number | Uint32Array | number[]; workItemsPerGroup?: number }): Promise<OpenCLProgram>
 	runProgram(program: OpenCLProgram, params: KernelParams, queue?: number): Promise<RunTimings>
 	waitFinish(queue?: number): Promise<void>
+	/** staging extension: later work on `waiter` starts after everything enqueued so far on `signal` */
+	queueWaitQueue(waiter: number, signal: number): void
+	/** staging extension */
+	recordEvent(queue?: number): QueueEvent
 	logBuffers(): { liveBuffers: number; liveBytes: number; pooledBytes: number }
 }

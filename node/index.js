@@ -42,6 +42,9 @@ function makeOpenCLBuffer(native, created, numBytes, imageDims, owner) {
 	buf.addRef = () => { native.bufAddRef(handle) }
 	buf.release = () => { native.bufRelease(handle) }
 	buf.refCount = () => native.bufRefCount(handle)
+	// staging extension (not nodencl): device -> mirror on `queue` without a host wait; the bytes are
+	// valid after waitFinish(queue) or after an event recorded behind it has been awaited
+	buf.downloadAsync = (queue) => native.downloadAsync(handle, queue === undefined ? 2 : queue)
 	return buf
 }
 
@@ -114,6 +117,19 @@ class clContext {
 
 	async waitFinish(queue) {
 		return this._need().waitFinish(this._ctx, queue === undefined ? this.queue.process : queue)
+	}
+
+	// ---- staging extensions (not nodencl; SURVEY 8f-3, node/staging.js) -----------------------------
+	// later work on `waiter` starts only after everything enqueued so far on `signal` has finished
+	queueWaitQueue(waiter, signal) {
+		this._need().queueWaitQueue(this._ctx, waiter, signal)
+	}
+
+	// a point in `queue`: { wait(): Promise<void>, done(): boolean }
+	recordEvent(queue) {
+		const native = this._need()
+		const ev = native.eventRecord(this._ctx, queue === undefined ? this.queue.process : queue)
+		return { wait: () => native.eventWait(ev), done: () => native.eventDone(ev) }
 	}
 
 	logBuffers() {

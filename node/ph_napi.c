@@ -182,7 +182,7 @@ static napi_value BufRefCount(napi_env env, napi_callback_info info) {
 }
 
 /* ---- async plumbing ----------------------------------------------------------------------- */
-typedef enum { JOB_WAIT, JOB_HOST_ACCESS, JOB_RUN_TIMED } job_kind;
+typedef enum { JOB_WAIT, JOB_HOST_ACCESS, JOB_RUN_TIMED, JOB_EVENT_WAIT } job_kind;
 
 typedef struct {
   job_kind kind;
@@ -190,6 +190,7 @@ typedef struct {
   napi_deferred deferred;
   ph_ctx *ctx;
   int queue;
+  ph_event *event; /* JOB_EVENT_WAIT */
   /* host access */
   ph_buf *buf;
   int dir;
@@ -214,6 +215,7 @@ static void job_execute(napi_env env, void *data) {
     case JOB_WAIT: j->rc = ph_wait_finish(j->ctx, j->queue); break;
     case JOB_HOST_ACCESS: j->rc = ph_buf_host_access(j->buf, j->dir, j->queue, j->src, j->src_bytes); break;
     case JOB_RUN_TIMED: j->rc = ph_run_program(j->ctx, j->prog, j->args, j->n_args, j->queue, &j->timings); break;
+    case JOB_EVENT_WAIT: j->rc = ph_event_wait(j->event); break;
   }
   if (j->rc != PH_OK) snprintf(j->err, sizeof j->err, "%s", ph_last_error(NULL)); /* thread-local: copy here */
 }
@@ -305,6 +307,81 @@ static napi_value HostAccess(napi_env env, napi_callback_info info) {
     napi_create_reference(env, argv[3], 1, &j->src_ref);
   }
   return start_job(env, j, "phaneron.hostAccess");
+}
+
+/* ---- staging primitives (include/phaneron_hip.h "Staged producers / consumers") ---------------- */
+/* queueWaitQueue(ctx, waiterQueue, signalQueue) */
+static napi_value QueueWaitQueue(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3], out;
+  ctx_box *c;
+  int32_t waiter = 0, signal = 0;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 3 || !get_box(env, argv[0], (void **)&c) || !get_i32(env, argv[1], &waiter) || !get_i32(env, argv[2], &signal))
+    return throw_ph(env, "queueWaitQueue(ctx, waiter, signal)");
+  if (ph_queue_wait_queue(c->ctx, waiter, signal) != PH_OK) return throw_ph(env, "queueWaitQueue");
+  NAPI_OK(napi_get_undefined(env, &out));
+  return out;
+}
+
+/* downloadAsync(buf, queue): device -> mirror, no host wait */
+static napi_value DownloadAsync(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2], out;
+  buf_box *b;
+  int32_t q = PH_QUEUE_UNLOAD;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&b) || !b->buf) return throw_ph(env, "downloadAsync on a released buffer");
+  if (argc > 1) get_i32(env, argv[1], &q);
+  if (ph_buf_download_async(b->buf, q) != PH_OK) return throw_ph(env, "downloadAsync");
+  NAPI_OK(napi_get_undefined(env, &out));
+  return out;
+}
+
+static void event_finalize(napi_env env, void *data, void *hint) {
+  (void)env, (void)hint;
+  ph_event_destroy((ph_event *)data);
+}
+
+/* eventRecord(ctx, queue) -> external (destroyed with the JS object) */
+static napi_value EventRecord(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2], out;
+  ctx_box *c;
+  int32_t q = PH_QUEUE_PROCESS;
+  ph_event *ev = NULL;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&c)) return throw_ph(env, "eventRecord: bad context");
+  if (argc > 1) get_i32(env, argv[1], &q);
+  if (ph_event_record(c->ctx, q, &ev) != PH_OK) return throw_ph(env, "eventRecord");
+  NAPI_OK(napi_create_external(env, ev, event_finalize, NULL, &out));
+  return out;
+}
+
+/* eventWait(event) -> Promise<void> (on the libuv pool) */
+static napi_value EventWait(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  ph_event *ev;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&ev)) return throw_ph(env, "eventWait: bad event");
+  job *j = (job *)calloc(1, sizeof *j);
+  j->kind = JOB_EVENT_WAIT, j->event = ev;
+  napi_create_reference(env, argv[0], 1, &j->src_ref); /* the event outlives the wait */
+  return start_job(env, j, "phaneron.eventWait");
+}
+
+/* eventDone(event) -> boolean */
+static napi_value EventDone(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], out;
+  ph_event *ev;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&ev)) return throw_ph(env, "eventDone: bad event");
+  int r = ph_event_query(ev);
+  if (r < 0) return throw_ph(env, "eventDone");
+  NAPI_OK(napi_get_boolean(env, r == 1, &out));
+  return out;
 }
 
 /* createProgram(ctx, kernelSrc, name, globalWorkItems[], workItemsPerGroup) -> external */
@@ -444,6 +521,8 @@ NAPI_MODULE_INIT() {
       {"createBuffer", CreateBuffer}, {"bufAddRef", BufAddRef},       {"bufRelease", BufRelease},
       {"bufRefCount", BufRefCount}, {"hostAccess", HostAccess},       {"waitFinish", WaitFinish},
       {"createProgram", CreateProgram}, {"runProgram", RunProgram},   {"bufferStats", BufferStats},
+      {"queueWaitQueue", QueueWaitQueue}, {"downloadAsync", DownloadAsync}, {"eventRecord", EventRecord},
+      {"eventWait", EventWait},     {"eventDone", EventDone},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
     napi_value f;

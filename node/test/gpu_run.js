@@ -150,6 +150,45 @@ async function main() {
 		dsts.forEach((d) => d.release())
 	}
 
+	// 5. staged ring (node/staging.js) around the fused channel program: frames with different content
+	//    through 3 slots, outputs written per frame; also the same frames through the dispatcher
+	if (job.staged) {
+		const { width: W, height: H, layers: N, frames: F } = job.staged
+		const { StagedChannel } = require('../staging.js')
+		const { FusedV210Channel } = require('../process/fusedChannel.js')
+		const fused = new FusedV210Channel(ctx, job.staged.readSpec, job.staged.writeSpec, N, W, H, jobs)
+		await fused.init()
+		const vb = fused.getNumBytes()
+		const chan = new StagedChannel(ctx, Array(N).fill(vb), vb, (sources, output) => fused.launch(sources, output), 3, 'staged')
+		await chan.init()
+		const order = []
+		const consume = async (f, out) => { order.push(f); fs.writeFileSync(path.join(dir, `staged_out${f}.bin`), out) }
+		const fill = async (f, sources) => {
+			for (let l = 0; l < N; ++l) fs.readFileSync(path.join(dir, `staged_f${f}_l${l}.bin`)).copy(sources[l])
+		}
+		for (let f = 0; f < F; ++f) await chan.submit(fill, consume)
+		await chan.drain(consume)
+		result.stagedOrder = order
+		await chan.close()
+		// the same program through the job queue (one frame)
+		const srcs = []
+		for (let l = 0; l < N; ++l) {
+			const s = await fused.createSource(`L${l}`)
+			await s.hostAccess('writeonly', ctx.queue.load, fs.readFileSync(path.join(dir, `staged_f0_l${l}.bin`)))
+			srcs.push(s)
+		}
+		await ctx.waitFinish(ctx.queue.load)
+		const dst = await fused.createDest('q')
+		let fired = false
+		fused.processFrame({ source: 'fused chan', timestamp: 0 }, srcs, dst, () => { fired = true })
+		await jobs.runQueue({ source: 'fused chan', timestamp: 0 })
+		await dst.hostAccess('readonly', ctx.queue.unload)
+		fs.writeFileSync(path.join(dir, 'fused_queue_out.bin'), dst)
+		result.fusedCallbackFired = fired
+		srcs.forEach((s) => s.release())
+		dst.release()
+	}
+
 	result.buffers = ctx.logBuffers()
 	fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify(result))
 }

@@ -324,11 +324,9 @@ def ref_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libphaneron_ref.so"))
 
 
-def ref():
-    """ctypes handle of the reference-kernel library (only where oracle/_ref was built)."""
-    global _ref
-    if _ref is None:
-        r = C.CDLL(os.path.join(_HERE, "_ref", "libphaneron_ref.so"))
+def _bind_ref(path):
+    if True:
+        r = C.CDLL(path)
         r.ref_v210_read.argtypes = [_u32p, _f32p, C.c_uint, C.c_uint, _f32p, _f32p, _f32p]
         r.ref_v210_write.argtypes = [_f32p, _u32p, C.c_uint, C.c_uint, C.c_uint, _f32p, _f32p]
         r.ref_yadif.argtypes = [_f32p, _f32p, _f32p] + [C.c_int] * 5 + [_f32p]
@@ -346,5 +344,51 @@ def ref():
         for n in ("ref_v210_read", "ref_v210_write", "ref_yadif", "ref_transform", "ref_resize", "ref_mixer",
                   "ref_wipe", "ref_transition_dissolve", "ref_transition_wipe"):
             getattr(r, n).restype = None
-        _ref = r
+        r.ref_pipeline_v210_combine.argtypes = [C.c_int, C.POINTER(C.c_void_p), _u32p, C.c_uint, C.c_uint, _f32p, _f32p,
+                                                _f32p, _f32p, _f32p, _f32p]
+        r.ref_set_num_threads.argtypes = [C.c_int]
+    return r
+
+
+def ref():
+    """ctypes handle of the reference-kernel library (only where oracle/_ref was built)."""
+    global _ref
+    if _ref is None:
+        _ref = _bind_ref(os.path.join(_HERE, "_ref", "libphaneron_ref.so"))
     return _ref
+
+
+_ref_fast = None
+
+
+def have_ref_fast():
+    """The -O3 -mavx2 -mfma build of the same reference kernels, usable on this host's CPU?"""
+    if not os.path.exists(os.path.join(_HERE, "_ref", "libphaneron_ref_fast.so")):
+        return False
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+    except Exception:
+        return False
+    return "avx2" in flags and "fma" in flags
+
+
+def ref_fast():
+    global _ref_fast
+    if _ref_fast is None:
+        _ref_fast = _bind_ref(os.path.join(_HERE, "_ref", "libphaneron_ref_fast.so"))
+    return _ref_fast
+
+
+def ref_pipeline_v210_combine(r, layers, width, height, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut, scratch=None):
+    """The reference kernels' own chain (read x n -> combine_n -> write) through library `r`."""
+    n = len(layers)
+    ls = [np.ascontiguousarray(l, np.uint32) for l in layers]
+    out = np.zeros(v210_pitch_bytes(width) * height // 4, np.uint32)
+    if scratch is None:
+        scratch = np.empty((n + 1) * width * height * 4, np.float32)
+    rc = r.ref_pipeline_v210_combine(n, _ptr_array(ls), out, width, height, np.ascontiguousarray(rd_cm, np.float32),
+                                     rd_lut, np.ascontiguousarray(rd_gm, np.float32),
+                                     np.ascontiguousarray(wr_cm, np.float32), wr_lut, scratch)
+    if rc != 0:
+        raise ValueError("bad layer count")
+    return out

@@ -18,6 +18,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 typedef float float2 __attribute__((ext_vector_type(2)));
 typedef float float3 __attribute__((ext_vector_type(3)));
@@ -207,13 +209,32 @@ void transition_wipe(Img *a, Img *b, Img *mask, Img *out);
 
 static inline unsigned v210_pitch_px(unsigned w) { return w + 47 - ((w - 1) % 48); }
 
+// Work-groups / image rows are independent: the CPU-baseline leg of bench.py spreads them over
+// host threads the way an OpenCL CPU device would (work-item ids are thread_local).  1 = serial.
+static int g_threads = 1;
+template <typename F> static void parallel_rows(unsigned n, F f) {
+  unsigned t = g_threads < 1 ? 1 : (unsigned)g_threads;
+  if (t > n) t = n ? n : 1;
+  if (t <= 1) {
+    for (unsigned i = 0; i < n; ++i) f(i);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (unsigned k = 0; k < t; ++k)
+    pool.emplace_back([=] {
+      for (unsigned i = (unsigned)((uint64_t)n * k / t), e = (unsigned)((uint64_t)n * (k + 1) / t); i < e; ++i) f(i);
+    });
+  for (auto &th : pool) th.join();
+}
+
 template <typename F> static void for_each_pixel(int w, int h, F f) {
-  for (int y = 0; y < h; ++y)
+  parallel_rows((unsigned)h, [=](unsigned y) {
     for (int x = 0; x < w; ++x) {
       g_gid[0] = x;
       g_gid[1] = y;
       f();
     }
+  });
 }
 
 // ---- C entry points used by tests/golden/gen_golden.py ----------------------------------
@@ -226,14 +247,16 @@ void ref_v210_read(const uint32_t *in, float *out, unsigned width, unsigned heig
   memcpy(cm, colMatrix12, sizeof cm);
   memcpy(gm, gamut9, 9 * sizeof(float));  // kernel reads 3 float4s of a 36-byte buffer
   unsigned wipg = v210_pitch_px(width) / 48;
-  for (unsigned line = 0; line < height; ++line)
+  float *cmp = cm, *gmp = gm;
+  parallel_rows(height, [=](unsigned line) {
     for (unsigned lid = 0; lid < wipg; ++lid) {
       g_grp = line;
       g_lid = lid;
       g_lsz = wipg;
       g_gid[0] = line * wipg + lid;
-      refk_v210_read((uint4 *)in, (float4 *)out, width, (float4 *)cm, (float *)lut, (float4 *)gm);
+      refk_v210_read((uint4 *)in, (float4 *)out, width, (float4 *)cmp, (float *)lut, (float4 *)gmp);
     }
+  });
 }
 
 // geometry as Writer (v210.ts:312-324): groups = height (or height/2 when interlaced)
@@ -243,14 +266,16 @@ void ref_v210_write(const float *in, uint32_t *out, unsigned width, unsigned hei
   memcpy(cm, colMatrix12, sizeof cm);
   unsigned wipg = v210_pitch_px(width) / 48;
   unsigned groups = interlace ? height / 2 : height;
-  for (unsigned grp = 0; grp < groups; ++grp)
+  float *cmp = cm;
+  parallel_rows(groups, [=](unsigned grp) {
     for (unsigned lid = 0; lid < wipg; ++lid) {
       g_grp = grp;
       g_lid = lid;
       g_lsz = wipg;
       g_gid[0] = grp * wipg + lid;
-      refk_v210_write((float4 *)in, (uint4 *)out, width, interlace, (float4 *)cm, (float *)lut);
+      refk_v210_write((float4 *)in, (uint4 *)out, width, interlace, (float4 *)cmp, (float *)lut);
     }
+  });
 }
 
 // fmt: 1 yuv422p10, 2 yuv422p8, 3 yuv420p, 4 nv12, 5 rgba8, 6 bgra8.  Geometry as the Readers /
@@ -365,6 +390,31 @@ int ref_combine(int n, const float *const *layers, int w, int h, float *out) {
       case 8: combine_8(&l[0], &l[1], &l[2], &l[3], &l[4], &l[5], &l[6], &l[7], &o); break;
     }
   });
+  return 0;
+}
+
+void ref_set_num_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int ref_num_threads(void) { return g_threads; }
+
+// The reference's own chain for one output frame, stage by stage as its job queue runs it:
+// n x v210 read -> combine_n -> v210 write, float RGBA intermediates in `scratch`
+// ((n+1) * width*height*4 floats).  bench.py's cpu_baseline ("reference") times this.
+int ref_pipeline_v210_combine(int n, const uint32_t *const *layers, uint32_t *out, unsigned width, unsigned height,
+                              const float *rd_cm12, const float *rd_lut, const float *rd_gamut9, const float *wr_cm12,
+                              const float *wr_lut, float *scratch) {
+  if (n < 1 || n > 8) return -1;
+  const size_t img = (size_t)width * height * 4;
+  const float *rgba[8];
+  for (int i = 0; i < n; ++i) {
+    ref_v210_read(layers[i], scratch + img * i, width, height, rd_cm12, rd_lut, rd_gamut9);
+    rgba[i] = scratch + img * i;
+  }
+  const float *top = rgba[0];
+  if (n >= 2) {  // combiner.ts:222-228 passes a single layer through
+    if (ref_combine(n, rgba, (int)width, (int)height, scratch + img * n)) return -1;
+    top = scratch + img * n;
+  }
+  ref_v210_write(top, out, width, height, 0, wr_cm12, wr_lut);
   return 0;
 }
 

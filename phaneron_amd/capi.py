@@ -27,7 +27,8 @@ EXPORTS = [
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
     "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option", "ph_compose_write_v210",
-    "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write",
+    "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
+    "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy",
 ]
 
 
@@ -83,6 +84,12 @@ def lib():
         "ph_buf_dims": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
         "ph_buf_host_access": (ci, [vp, ci, ci, vp, cs]),
         "ph_buf_host_ptr": (vp, [vp]),
+        "ph_queue_wait_queue": (ci, [vp, ci, ci]),
+        "ph_buf_download_async": (ci, [vp, ci]),
+        "ph_event_record": (ci, [vp, ci, C.POINTER(vp)]),
+        "ph_event_wait": (ci, [vp]),
+        "ph_event_query": (ci, [vp]),
+        "ph_event_destroy": (ci, [vp]),
         "ph_ctx_buffer_stats": (ci, [vp, C.POINTER(cs), C.POINTER(cs), C.POINTER(cs)]),
         "ph_program_create": (ci, [vp, C.c_char_p, C.c_char_p, C.POINTER(cu), ci, cu, C.POINTER(vp)]),
         "ph_program_destroy": (ci, [vp]),
@@ -307,3 +314,139 @@ class Context:
         arr = (C.c_void_p * len(layers))(*[_ptr(l).value for l in layers])
         check(lib().ph_fused_v210_combine(self.h, queue, len(layers), arr, _ptr(dst), width, height, _ptr(rd_cm),
                                           _ptr(rd_lut), _ptr(rd_gm), _ptr(wr_cm), _ptr(wr_lut)), self.h)
+
+    # ---- nodencl-shaped surface: buffers, programs, queues -----------------------------------------
+    def create_buffer(self, nbytes, access="readwrite", svm="coarse", dims=None, owner=""):
+        """`clContext.createBuffer(bytes, access, svmType, imageDims?, owner?)`"""
+        return Buffer(self, nbytes, access, svm, dims, owner)
+
+    def create_program(self, source, name, global_work_items, work_items_per_group=0):
+        """`clContext.createProgram(kernelSrc, {name, globalWorkItems, workItemsPerGroup})`"""
+        return Program(self, source, name, global_work_items, work_items_per_group)
+
+    def run_program(self, program, params, queue=QUEUE_PROCESS):
+        """`clContext.runProgram(program, params, queue)`: params maps kernel argument NAMES to a
+        Buffer, an int or a float (floats must be Python floats).  Returns the RunTimings in us."""
+        n = len(params)
+        arr = (PhArg * n)()
+        keep = []
+        for i, (k, v) in enumerate(params.items()):
+            kb = k.encode()
+            keep.append(kb)
+            arr[i].name = kb
+            if isinstance(v, Buffer):
+                arr[i].kind, arr[i].v.buf = ARG_BUF, v.h
+            elif isinstance(v, bool):
+                arr[i].kind, arr[i].v.u32 = ARG_U32, int(v)
+            elif isinstance(v, int):
+                if v < 0:
+                    arr[i].kind, arr[i].v.i32 = ARG_I32, v
+                else:
+                    arr[i].kind, arr[i].v.u32 = ARG_U32, v
+            elif isinstance(v, float):
+                arr[i].kind, arr[i].v.f32 = ARG_F32, v
+            else:
+                raise TypeError("kernel parameter %r: unsupported value %r" % (k, type(v)))
+        t = RunTimings()
+        check(lib().ph_run_program(self.h, program.h, arr, n, queue, C.byref(t)), self.h)
+        return {"dataToKernel": t.data_to_kernel, "kernelExec": t.kernel_exec, "totalTime": t.total_time}
+
+    def queue_wait_queue(self, waiter, signal):
+        check(lib().ph_queue_wait_queue(self.h, waiter, signal), self.h)
+
+    def record_event(self, queue):
+        return Event(self, queue)
+
+    def buffer_stats(self):
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        check(lib().ph_ctx_buffer_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), self.h)
+        return {"live_buffers": a.value, "live_bytes": b.value, "pooled_bytes": c.value}
+
+
+_ACCESS = {"readonly": 0, "writeonly": 1, "readwrite": 2}
+_SVM = {"none": 0, "coarse": 1, "fine": 2}
+
+
+class Buffer:
+    """A nodencl `OpenCLBuffer`: ref-counted device block from the context's pool + pinned host mirror."""
+
+    def __init__(self, ctx, nbytes, access="readwrite", svm="coarse", dims=None, owner=""):
+        h = C.c_void_p()
+        w, hh = dims if dims else (0, 0)
+        check(lib().ph_buf_create(ctx.h, nbytes, _ACCESS[access], _SVM[svm], w, hh, owner.encode(), C.byref(h)), ctx.h)
+        self.ctx, self.h, self.nbytes, self.timestamp = ctx, h, nbytes, 0
+
+    def add_ref(self):
+        return lib().ph_buf_addref(self.h)
+
+    def release(self):
+        return lib().ph_buf_release(self.h)
+
+    def refcount(self):
+        return lib().ph_buf_refcount(self.h)
+
+    def device_ptr(self):
+        return lib().ph_buf_device_ptr(self.h)
+
+    def host(self, dtype="uint8"):
+        """numpy view of the pinned host mirror"""
+        import numpy as np
+        p = lib().ph_buf_host_ptr(self.h)
+        if not p:
+            check(-1, self.ctx.h)
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.nbytes,))
+        return a.view(dtype)
+
+    def host_access(self, direction, queue=QUEUE_LOAD, src=None):
+        """`buf.hostAccess(dir, queue, src?)`"""
+        d = {"readonly": HOST_READONLY, "writeonly": HOST_WRITEONLY, "none": HOST_NONE}[direction]
+        if src is not None:
+            import numpy as np
+            a = np.ascontiguousarray(src).view(np.uint8).reshape(-1)
+            check(lib().ph_buf_host_access(self.h, d, queue, a.ctypes.data, a.nbytes), self.ctx.h)
+        else:
+            check(lib().ph_buf_host_access(self.h, d, queue, None, 0), self.ctx.h)
+
+    def download_async(self, queue=QUEUE_UNLOAD):
+        check(lib().ph_buf_download_async(self.h, queue), self.ctx.h)
+
+
+class Event:
+    """A recorded point in a queue (ph_event): wait() blocks the host until it has been reached."""
+
+    def __init__(self, ctx, queue):
+        h = C.c_void_p()
+        check(lib().ph_event_record(ctx.h, queue, C.byref(h)), ctx.h)
+        self.ctx, self.h = ctx, h
+
+    def wait(self):
+        check(lib().ph_event_wait(self.h), self.ctx.h)
+
+    def done(self):
+        r = lib().ph_event_query(self.h)
+        if r < 0:
+            check(r, self.ctx.h)
+        return bool(r)
+
+    def destroy(self):
+        if self.h:
+            lib().ph_event_destroy(self.h)
+            self.h = None
+
+
+class Program:
+    def __init__(self, ctx, source, name, global_work_items, work_items_per_group=0):
+        g = global_work_items if isinstance(global_work_items, (list, tuple)) else [global_work_items]
+        arr = (C.c_uint32 * len(g))(*[int(x) for x in g])
+        h = C.c_void_p()
+        check(lib().ph_program_create(ctx.h, source.encode() if source is not None else None, name.encode(), arr, len(g),
+                                      int(work_items_per_group), C.byref(h)), ctx.h)
+        self.ctx, self.h = ctx, h
+
+    def kernel(self):
+        return lib().ph_program_kernel(self.h).decode()
+
+    def destroy(self):
+        if self.h:
+            lib().ph_program_destroy(self.h)
+            self.h = None

@@ -78,7 +78,8 @@ enum KernelId {
   K_DISSOLVE,
   K_TWIPE,
   K_MIXER,
-  K_WIPE
+  K_WIPE,
+  K_FUSED_V210  // extension: v210 x N -> read, combine_N, write in one launch (ph_fused_v210_combine)
 };
 
 struct ph_program {
@@ -329,6 +330,74 @@ int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t by
   }
 }
 
+int ph_queue_wait_queue(ph_ctx *ctx, int waiter_queue, int signal_queue) {
+  if (!ctx) return fail(PH_E_INVALID, "ph_queue_wait_queue: ctx is NULL");
+  if (waiter_queue < 0 || waiter_queue > 2 || signal_queue < 0 || signal_queue > 2)
+    return fail(PH_E_INVALID, "ph_queue_wait_queue: queues are 0..2");
+  if (waiter_queue == signal_queue) return PH_OK;  // in-order already
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  hipEvent_t ev;
+  PH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, ctx->streams[signal_queue]);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->streams[waiter_queue], ev, 0);
+  hipEventDestroy(ev);  // released by the runtime once the recorded work has completed
+  if (e != hipSuccess) return fail(PH_E_HIP, "ph_queue_wait_queue: %s", hipGetErrorString(e));
+  return PH_OK;
+}
+
+int ph_buf_download_async(ph_buf *b, int queue) {
+  if (!b) return fail(PH_E_INVALID, "ph_buf_download_async: NULL buffer");
+  int rc = set_device(b->ctx);
+  if (rc) return rc;
+  if (!ph_buf_host_ptr(b)) return PH_E_HIP;
+  PH_HIP(hipMemcpyAsync(b->hptr, b->dptr, b->bytes, hipMemcpyDeviceToHost, stream_of(b->ctx, queue)));
+  return PH_OK;
+}
+
+struct ph_event {
+  ph_ctx *ctx;
+  hipEvent_t ev;
+};
+
+int ph_event_record(ph_ctx *ctx, int queue, ph_event **out) {
+  if (!ctx || !out) return fail(PH_E_INVALID, "ph_event_record: NULL argument");
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  hipEvent_t ev;
+  PH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, stream_of(ctx, queue));
+  if (e != hipSuccess) {
+    hipEventDestroy(ev);
+    return fail(PH_E_HIP, "ph_event_record: %s", hipGetErrorString(e));
+  }
+  *out = new ph_event{ctx, ev};
+  return PH_OK;
+}
+
+int ph_event_wait(ph_event *ev) {
+  if (!ev) return fail(PH_E_INVALID, "ph_event_wait: NULL event");
+  int rc = set_device(ev->ctx);
+  if (rc) return rc;
+  PH_HIP(hipEventSynchronize(ev->ev));
+  return PH_OK;
+}
+
+int ph_event_query(ph_event *ev) {
+  if (!ev) return fail(PH_E_INVALID, "ph_event_query: NULL event");
+  hipError_t e = hipEventQuery(ev->ev);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  return fail(PH_E_HIP, "ph_event_query: %s", hipGetErrorString(e));
+}
+
+int ph_event_destroy(ph_event *ev) {
+  if (!ev) return PH_OK;
+  hipEventDestroy(ev->ev);
+  delete ev;
+  return PH_OK;
+}
+
 int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes) {
   if (!ctx) return fail(PH_E_INVALID, "ph_ctx_buffer_stats: ctx is NULL");
   if (live_buffers) *live_buffers = ctx->live_buffers;
@@ -447,6 +516,11 @@ int ph_program_create(ph_ctx *ctx, const char *src, const char *name, const uint
     const int n = atoi(name + 8);
     if (n < 2 || n > ph::kMaxLayers) return fail(PH_E_UNKNOWN_KERNEL, "combine_%d: 2..%d layers are built", n, ph::kMaxLayers);
     p.id = K_COMBINE, p.n_layers = n, p.kernel = name;
+  } else if (0 == strncmp(name, "fused_v210_combine_", 19)) {
+    // not a reference kernel: the headline chain as one program, global = [width, height]
+    const int n = atoi(name + 19);
+    if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_UNKNOWN_KERNEL, "fused_v210_combine_%d: 1..%d layers are built", n, ph::kMaxLayers);
+    p.id = K_FUSED_V210, p.n_layers = n, p.kernel = name;
   } else if (0 == strcmp(name, "transition_dissolve")) {
     p.id = K_DISSOLVE, p.kernel = name;
   } else if (0 == strcmp(name, "transition_wipe")) {
@@ -600,6 +674,30 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
         layers[i] = a->dptr;
       }
       return ph_combine(ctx, queue, prog->n_layers, layers, w, h, o->dptr);
+    }
+    case K_FUSED_V210: {
+      // l<i>In: v210 sources; colMatrix / gammaLut / gamutMatrix: the Loader's; outColMatrix / outGammaLut: the Saver's
+      const uint32_t width = prog->global[0], height = prog->global[1];
+      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
+      const size_t vb = (size_t)ph_v210_pitch_bytes(width) * height;
+      const void *layers[ph::kMaxLayers];
+      ph_buf *wcm = nullptr, *wl = nullptr;
+      for (int i = 0; i < prog->n_layers; ++i) {
+        char nm[16];
+        snprintf(nm, sizeof nm, "l%dIn", i);
+        TRY(need_buf(args, n, nm, vb, &a));
+        layers[i] = a->dptr;
+      }
+      TRY(need_buf(args, n, "output", vb, &o));
+      TRY(need_buf(args, n, "colMatrix", 48, &b));
+      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
+      TRY(need_buf(args, n, "gamutMatrix", 36, &d));
+      TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
+      TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
+      refresh_buf_lut(ctx, c);
+      refresh_buf_lut(ctx, wl);
+      return ph_fused_v210_combine(ctx, queue, prog->n_layers, layers, o->dptr, width, height, b->dptr, c->dptr, d->dptr,
+                                   wcm->dptr, wl->dptr);
     }
     case K_DISSOLVE:
     case K_MIXER:

@@ -1,0 +1,199 @@
+"""GPU tests (-m gpu) of the nodencl-shaped C-ABI surface itself, driven from Python exactly as the
+N-API addon drives it: pooled ref-counted buffers with pinned mirrors, hostAccess in its three
+directions, createProgram by kernel name / source, runProgram with arguments keyed by OpenCL argument
+name, queue ordering primitives and the staged producer -> GPU -> consumer ring.
+Results are checked against the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import frames
+from oracle import orc
+from phaneron_amd import capi, staging
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def upload(ctx, arr, access="readonly", svm="none", owner="test"):
+    a = np.ascontiguousarray(arr)
+    b = ctx.create_buffer(a.nbytes, access, svm, owner=owner)
+    b.host_access("writeonly", capi.QUEUE_LOAD, a)
+    return b
+
+
+class Colour:
+    """Loader / Saver parameter buffers as loadSave.ts:50-99,139-160 creates them."""
+
+    def __init__(self, ctx, spec, out_spec):
+        self.rd_cm = upload(ctx, capi.ycbcr2rgb_matrix(spec))
+        self.rd_lut = upload(ctx, capi.gamma2linear_lut(spec), svm="coarse")
+        self.rd_gm = upload(ctx, capi.rgb2rgb_matrix(spec, out_spec))          # 36 bytes, like the reference
+        self.wr_cm = upload(ctx, capi.rgb2ycbcr_matrix(out_spec))
+        self.wr_lut = upload(ctx, capi.linear2gamma_lut(out_spec), svm="coarse")
+        ctx.wait(capi.QUEUE_LOAD)
+        self.oracle_rd = (orc.ycbcr2rgb_matrix(spec), orc.gamma2linear_lut(spec), orc.rgb2rgb_matrix(spec, out_spec))
+        self.oracle_wr = (orc.rgb2ycbcr_matrix(out_spec), orc.linear2gamma_lut(out_spec))
+
+    def release(self):
+        for b in (self.rd_cm, self.rd_lut, self.rd_gm, self.wr_cm, self.wr_lut):
+            b.release()
+
+
+def test_buffers_are_pooled_and_refcounted(ctx):
+    base = ctx.buffer_stats()
+    a = ctx.create_buffer(1 << 20, owner="a")
+    assert a.refcount() == 1
+    assert ctx.buffer_stats()["live_buffers"] == base["live_buffers"] + 1
+    ptr = a.device_ptr()
+    a.add_ref()
+    assert a.refcount() == 2
+    a.release()
+    a.release()                                   # last release: storage goes back to the pool
+    after = ctx.buffer_stats()
+    assert after["live_buffers"] == base["live_buffers"]
+    assert after["pooled_bytes"] >= base["pooled_bytes"] + (1 << 20)
+    b = ctx.create_buffer(1 << 20, owner="b")     # same size: the pooled block is handed out again
+    assert b.device_ptr() == ptr
+    b.release()
+
+
+def test_host_access_round_trip_and_range_check(ctx):
+    data = (frames.splitmix64(77, 4096) & np.uint64(0xFF)).astype(np.uint8)
+    b = ctx.create_buffer(4096)
+    b.host_access("writeonly", capi.QUEUE_LOAD, data)
+    ctx.wait(capi.QUEUE_LOAD)
+    b.host()[:] = 0                                # scribble over the mirror: READONLY must restore it
+    b.host_access("readonly", capi.QUEUE_UNLOAD)
+    assert np.array_equal(b.host(), data)
+    with pytest.raises(capi.PhaneronError):
+        b.host_access("writeonly", capi.QUEUE_LOAD, np.zeros(8192, np.uint8))
+    # expose -> fill -> 'none' (Loader.init, loadSave.ts:76-99)
+    b.host_access("writeonly", capi.QUEUE_LOAD)
+    b.host()[:] = data[::-1]
+    b.host_access("none", capi.QUEUE_LOAD)
+    ctx.wait(capi.QUEUE_LOAD)
+    b.host()[:] = 0
+    b.host_access("readonly", capi.QUEUE_UNLOAD)
+    assert np.array_equal(b.host(), data[::-1])
+    b.release()
+
+
+def test_run_program_by_argument_name_matches_oracle(ctx):
+    """The reference's job queue shape: createProgram(name) + runProgram({argName: value})."""
+    w, h = 1920, 8
+    col = Colour(ctx, "709", "2020")
+    src = frames.v210_random(w, h, 4242)
+    wipg = frames.v210_pitch_pixels(w) // 48
+    rd = ctx.create_program("phaneron:v210", "read", wipg * h, wipg)
+    wr = ctx.create_program("phaneron:v210", "write", wipg * h, wipg)
+    assert rd.kernel() == "v210_read" and wr.kernel() == "v210_write"
+    vin = upload(ctx, src, svm="coarse")
+    ctx.wait(capi.QUEUE_LOAD)
+    rgba = ctx.create_buffer(w * h * 16, dims=(w, h))
+    vout = ctx.create_buffer(src.nbytes, "writeonly")
+    t = ctx.run_program(rd, {"input": vin, "output": rgba, "width": w, "colMatrix": col.rd_cm, "gammaLut": col.rd_lut,
+                             "gamutMatrix": col.rd_gm})
+    assert set(t) == {"dataToKernel", "kernelExec", "totalTime"} and t["totalTime"] >= t["kernelExec"]
+    # argument order is irrelevant, names are what binds
+    ctx.run_program(wr, {"gammaLut": col.wr_lut, "colMatrix": col.wr_cm, "interlace": 0, "width": w, "output": vout,
+                         "input": rgba})
+    ctx.wait()
+    rgba.host_access("readonly", capi.QUEUE_UNLOAD)
+    want_rgba = orc.v210_read(src, w, h, *col.oracle_rd)
+    assert np.array_equal(rgba.host(np.uint32), want_rgba.reshape(-1).view(np.uint32))
+    vout.host_access("readonly", capi.QUEUE_UNLOAD)
+    assert np.array_equal(vout.host(np.uint32), orc.v210_write(want_rgba, w, h, 0, *col.oracle_wr))
+    # errors: a missing argument and an unknown kernel are reported, not ignored
+    with pytest.raises(capi.PhaneronError, match="colMatrix"):
+        ctx.run_program(rd, {"input": vin, "output": rgba, "width": w, "gammaLut": col.rd_lut, "gamutMatrix": col.rd_gm})
+    with pytest.raises(capi.PhaneronError):
+        ctx.create_program("__kernel void sharpen() {}", "sharpen", [w, h])
+    for b in (vin, rgba, vout):
+        b.release()
+    rd.destroy(), wr.destroy()
+    col.release()
+
+
+def test_image_programs_by_name(ctx):
+    w, h = 64, 32
+    imgs = [frames.rgba_random(w, h, 900 + i) for i in range(3)]
+    bufs = [upload(ctx, im, "readwrite", "coarse") for im in imgs]
+    ctx.wait(capi.QUEUE_LOAD)
+    out = ctx.create_buffer(w * h * 16, dims=(w, h))
+    comb = ctx.create_program("phaneron:combine", "combine_3", [w, h])
+    ctx.run_program(comb, {"l0In": bufs[0], "l1In": bufs[1], "l2In": bufs[2], "output": out})
+    out.host_access("readonly", capi.QUEUE_UNLOAD)
+    assert np.array_equal(out.host(np.uint32), orc.combine(imgs).reshape(-1).view(np.uint32))
+    dis = ctx.create_program("phaneron:transition", "transition_dissolve", [w, h])
+    ctx.run_program(dis, {"input0": bufs[0], "input1": bufs[1], "mix": 0.3, "output": out})
+    out.host_access("readonly", capi.QUEUE_UNLOAD)
+    assert np.array_equal(out.host(np.uint32), orc.transition_dissolve(imgs[0], imgs[1], 0.3).reshape(-1).view(np.uint32))
+    yad = ctx.create_program("phaneron:yadif", "yadif", [w, h])
+    ctx.run_program(yad, {"prev": bufs[0], "cur": bufs[1], "next": bufs[2], "parity": 1, "tff": 1, "skipSpatial": 0,
+                          "output": out})
+    out.host_access("readonly", capi.QUEUE_UNLOAD)
+    assert np.array_equal(out.host(np.uint32), orc.yadif(imgs[0], imgs[1], imgs[2], 1, True, False).reshape(-1).view(np.uint32))
+    for b in bufs + [out]:
+        b.release()
+
+
+def test_events_and_queue_ordering(ctx):
+    """A kernel on PROCESS ordered behind an upload on LOAD by ph_queue_wait_queue, and a download on
+    UNLOAD ordered behind the kernel, with no host wait in between."""
+    w, h = 1920, 64
+    a, b = frames.rgba_random(w, h, 1), frames.rgba_random(w, h, 2)
+    ba, bb = ctx.create_buffer(a.nbytes, dims=(w, h)), ctx.create_buffer(a.nbytes, dims=(w, h))
+    out = ctx.create_buffer(a.nbytes, dims=(w, h))
+    ctx.wait(capi.QUEUE_LOAD)
+    for buf, src in ((ba, a), (bb, b)):
+        buf.host_access("writeonly", capi.QUEUE_LOAD)
+        buf.host(np.float32)[:] = src.reshape(-1)
+        buf.host_access("none", capi.QUEUE_LOAD)
+    ctx.queue_wait_queue(capi.QUEUE_PROCESS, capi.QUEUE_LOAD)
+    ctx.mixer(ba.device_ptr(), bb.device_ptr(), 0.25, out.device_ptr(), w, h)
+    ctx.queue_wait_queue(capi.QUEUE_UNLOAD, capi.QUEUE_PROCESS)
+    out.download_async(capi.QUEUE_UNLOAD)
+    ev = ctx.record_event(capi.QUEUE_UNLOAD)
+    ev.wait()
+    assert ev.done()
+    ev.destroy()
+    assert np.array_equal(out.host(np.uint32), orc.mixer(a, b, 0.25).reshape(-1).view(np.uint32))
+    for x in (ba, bb, out):
+        x.release()
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_staged_channel_ring_reuse(ctx, depth):
+    """7 different frames through a ring of `depth` slots: every output equals the oracle's chain
+    for THAT frame (no slot is overwritten while its frame is still in flight)."""
+    w, h, n, nframes = 1920, 12, 4, 7
+    col = Colour(ctx, "709", "2020")
+    vbytes = frames.v210_pitch_bytes(w) * h
+    src = [[frames.v210_random(w, h, frames.layer_seed(f, i)) for i in range(n)] for f in range(nframes)]
+
+    def process(c, sources, output):
+        c.fused_v210_combine([s.device_ptr() for s in sources], output.device_ptr(), w, h, col.rd_cm.device_ptr(),
+                             col.rd_lut.device_ptr(), col.rd_gm.device_ptr(), col.wr_cm.device_ptr(),
+                             col.wr_lut.device_ptr())
+
+    def fill(f, mirrors):
+        for m, words in zip(mirrors, src[f]):
+            m.view(np.uint32)[:] = words
+
+    got = {}
+    chan = staging.StagedChannel(ctx, [vbytes] * n, vbytes, process, depth=depth)
+    for f in range(nframes):
+        chan.submit(fill, lambda fr, mirror: got.__setitem__(fr, mirror.view(np.uint32).copy()))
+    chan.drain(lambda fr, mirror: got.__setitem__(fr, mirror.view(np.uint32).copy()))
+    assert sorted(got) == list(range(nframes))
+    for f in range(nframes):
+        want = orc.pipeline_v210_combine(src[f], w, h, *col.oracle_rd, *col.oracle_wr)
+        assert np.array_equal(got[f], want), f
+    chan.close()
+    col.release()

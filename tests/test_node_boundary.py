@@ -47,7 +47,8 @@ def test_napi_addon_builds_loads_and_refuses_without_gpu():
     subprocess.run([sys.executable, os.path.join(ROOT, "node", "build.py")], check=True)
     js = ("const a=require('%s');"
           "const want=['abiVersion','createContext','contextInfo','createBuffer','bufAddRef','bufRelease','bufRefCount',"
-          "'hostAccess','waitFinish','createProgram','runProgram','bufferStats'];"
+          "'hostAccess','waitFinish','createProgram','runProgram','bufferStats','queueWaitQueue','downloadAsync',"
+          "'eventRecord','eventWait','eventDone'];"
           "for (const k of want) if (typeof a[k] !== 'function') { console.log('missing', k); process.exit(2) }"
           "console.log(a.abiVersion())") % os.path.join(ROOT, "node", "phaneron_napi.node")
     r = subprocess.run([NODE, "-e", js], capture_output=True, text=True)
@@ -85,7 +86,12 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
     job = dict(channel=dict(width=w, height=h, layers=["layer%d.bin" % i for i in range(n)], readSpec="709",
                             writeSpec="2020", pip=pip),
                yadif=dict(width=yw, height=yh, frames=["field%d.bin" % i for i in range(4)], tff=True),
-               formats=[dict(fmt=f, width=fw, height=fh, spec=sp) for f, fw, fh, sp in FORMAT_KATS])
+               formats=[dict(fmt=f, width=fw, height=fh, spec=sp) for f, fw, fh, sp in FORMAT_KATS],
+               staged=dict(width=1920, height=24, layers=3, frames=5, readSpec="709", writeSpec="2020"))
+    staged_src = [[frames.v210_random(1920, 24, frames.layer_seed(8 + f, l)) for l in range(3)] for f in range(5)]
+    for f, ls in enumerate(staged_src):
+        for l, words in enumerate(ls):
+            words.tofile(tmp_path / ("staged_f%d_l%d.bin" % (f, l)))
     (tmp_path / "job.json").write_text(json.dumps(job))
     r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "gpu_run.js"), str(tmp_path)], capture_output=True,
                        text=True, timeout=300)
@@ -122,3 +128,13 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
         assert got["rgbaSha256"] == kat[key + "_rgba_sha256"], f
         assert got["backSha256"] == kat[key + "_back_sha256"], f
         assert (got["compare"] == 0) == kat[key + "_roundtrip_identical"], f
+
+    # staged ring + fused channel program: each frame's output equals the oracle chain for that frame
+    assert res["stagedOrder"] == [0, 1, 2, 3, 4]
+    wr = (orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    for f, ls in enumerate(staged_src):
+        want = orc.pipeline_v210_combine(ls, 1920, 24, *rd, *wr)
+        assert np.array_equal(np.fromfile(tmp_path / ("staged_out%d.bin" % f), np.uint32), want), f
+    assert res["fusedCallbackFired"] is True
+    assert np.array_equal(np.fromfile(tmp_path / "fused_queue_out.bin", np.uint32),
+                          orc.pipeline_v210_combine(staged_src[0], 1920, 24, *rd, *wr))

@@ -213,3 +213,20 @@ def test_oracle_is_thread_count_invariant():
     orc.set_num_threads(0)
     b = orc.v210_read(src, w, h, *rd)
     assert bits_equal(a, b)
+
+
+@pytest.mark.skipif(not orc.ref_available(), reason="oracle/_ref is only built where the reference checkout exists")
+def test_reference_kernel_chain_equals_oracle_chain_any_build_any_thread_count():
+    """bench.py's cpu_baseline "reference" leg: the reference kernels' read x4 -> combine_4 -> write
+    (both builds of oracle/_ref, serial and threaded) give the oracle pipeline's words."""
+    w, h = 1920, 6
+    layers = [frames.v210_random(w, h, frames.layer_seed(2, i)) for i in range(4)]
+    rd = (orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
+    wr = (orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    want = orc.pipeline_v210_combine(layers, w, h, *rd, *wr)
+    libs = [orc.ref()] + ([orc.ref_fast()] if orc.have_ref_fast() else [])
+    for r in libs:
+        for threads in (1, 3):
+            r.ref_set_num_threads(threads)
+            assert np.array_equal(orc.ref_pipeline_v210_combine(r, layers, w, h, *rd, *wr), want)
+        r.ref_set_num_threads(1)
