@@ -22,12 +22,15 @@ __device__ __forceinline__ float dot3(float a0, float a1, float a2, float m0, fl
   return fma_rn(a2, m2, fma_rn(a1, m1, a0 * m0));
 }
 
-// convert_ushort_sat_rte: v_rndne_f32, v_max (NaN -> 0), v_min, v_cvt_u32_f32
+// convert_ushort_sat_rte(x) = clamp(rint(x), 0, 65535) = rint(clamp(x, 0, 65535)) (integer bounds,
+// rint monotone).  Evaluated as v_med3_f32 (NaN -> 0), then ONE f32 add of 1.5 * 2^23: the sum has
+// ulp 1, so the add itself rounds to nearest-even and the integer sits in the low mantissa bits
+// (v_and).  One op and two slow-class ops (v_rndne, v_cvt) less than rint / clamp / convert -
+// tools/opbench2.hip has the per-instruction costs.
+constexpr float kRoundMagic = 12582912.0f;  // 1.5 * 2^23 = 0x4B400000
 __device__ __forceinline__ uint32_t sat_u16_rte(float x) {
-  x = __builtin_rintf(x);
-  x = __builtin_fmaxf(x, 0.0f);
-  x = __builtin_fminf(x, 65535.0f);
-  return (uint32_t)x;
+  x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 65535.0f);
+  return __float_as_uint(x + kRoundMagic) & 0xFFFFu;
 }
 // convert_ushort_sat / _rtz: truncating
 __device__ __forceinline__ uint32_t sat_u16_trunc(float x) {

@@ -22,9 +22,9 @@ enum { F_V210 = 0, F_YUV422P10 = 1, F_YUV422P8 = 2, F_YUV420P = 3, F_NV12 = 4, F
 
 template <typename LUT>
 __device__ __forceinline__ float4 yuv_to_rgba(float y, float u, float v, const ReadK &k, const LUT &lut) {
-  const float r = lut.at(dot4(y, u, v, 1.0f, k.r) * 65535.0f);  // e.g. yuv422p10.ts:74-78
-  const float g = lut.at(dot4(y, u, v, 1.0f, k.g) * 65535.0f);
-  const float b = lut.at(dot4(y, u, v, 1.0f, k.b) * 65535.0f);
+  const float r = lut.at_unit(dot4(y, u, v, 1.0f, k.r));  // e.g. yuv422p10.ts:74-78
+  const float g = lut.at_unit(dot4(y, u, v, 1.0f, k.g));
+  const float b = lut.at_unit(dot4(y, u, v, 1.0f, k.b));
   return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
                      dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
 }
@@ -107,7 +107,7 @@ struct FmtWriteArgs {
 template <typename LUT>
 __device__ __forceinline__ void px_codes(const float4 px, const WriteK &k, const LUT &lut, bool tail, uint32_t &y,
                                          uint32_t &u, uint32_t &v) {
-  const float gr = lut.at(px.x * 65535.0f), gg = lut.at(px.y * 65535.0f), gb = lut.at(px.z * 65535.0f);
+  const float gr = lut.at_unit(px.x), gg = lut.at_unit(px.y), gb = lut.at_unit(px.z);
   float ty = dot4(gr, gg, gb, 1.0f, k.y), tu = dot4(gr, gg, gb, 1.0f, k.u), tv = dot4(gr, gg, gb, 1.0f, k.v);
   if (tail) ty = __builtin_roundf(ty), tu = __builtin_roundf(tu), tv = __builtin_roundf(tv);  // :186-188
   y = sat_u16_rte(ty), u = sat_u16_rte(tu), v = sat_u16_rte(tv);
@@ -122,7 +122,7 @@ __device__ __forceinline__ void fmt_write_body(const FmtWriteArgs &a, const LUT 
       const uint32_t g = p / a.width, x = p - g * a.width;
       const uint32_t line = g * (a.interlace ? 2 : 1) + ((3 == a.interlace) ? 1 : 0);
       const float4 px = a.in[(size_t)line * a.width + x];
-      const float r = lut.at(px.x * 65535.0f), gg = lut.at(px.y * 65535.0f), b = lut.at(px.z * 65535.0f);
+      const float r = lut.at_unit(px.x), gg = lut.at_unit(px.y), b = lut.at_unit(px.z);
       const uint32_t r8 = (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(r * 255.0f), 0.f), 255.f);
       const uint32_t g8 = (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(gg * 255.0f), 0.f), 255.f);
       const uint32_t b8 = (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(b * 255.0f), 0.f), 255.f);

@@ -20,17 +20,17 @@
 namespace ph {
 
 __device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const ReadK &k, const LutK &lut) {
-  const float r = lds_lut_at(lut, dot4(y, cb, cr, 1.0f, k.r) * 65535.0f);
-  const float g = lds_lut_at(lut, dot4(y, cb, cr, 1.0f, k.g) * 65535.0f);
-  const float b = lds_lut_at(lut, dot4(y, cb, cr, 1.0f, k.b) * 65535.0f);
+  const float r = lds_lut_at_unit(lut, dot4(y, cb, cr, 1.0f, k.r));
+  const float g = lds_lut_at_unit(lut, dot4(y, cb, cr, 1.0f, k.g));
+  const float b = lds_lut_at_unit(lut, dot4(y, cb, cr, 1.0f, k.b));
   return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
                      dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
 }
 
 __device__ __forceinline__ Yuv1 write_px_lds(float r, float g, float b, const WriteK &k, const LutK &lut) {
-  const float gr = lds_lut_at(lut, r * 65535.0f);
-  const float gg = lds_lut_at(lut, g * 65535.0f);
-  const float gb = lds_lut_at(lut, b * 65535.0f);
+  const float gr = lds_lut_at_unit(lut, r);
+  const float gg = lds_lut_at_unit(lut, g);
+  const float gb = lds_lut_at_unit(lut, b);
   Yuv1 o;
   o.y = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
   o.u = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.u));
@@ -38,9 +38,9 @@ __device__ __forceinline__ Yuv1 write_px_lds(float r, float g, float b, const Wr
   return o;
 }
 __device__ __forceinline__ uint32_t write_px_luma_lds(float r, float g, float b, const WriteK &k, const LutK &lut) {
-  const float gr = lds_lut_at(lut, r * 65535.0f);
-  const float gg = lds_lut_at(lut, g * 65535.0f);
-  const float gb = lds_lut_at(lut, b * 65535.0f);
+  const float gr = lds_lut_at_unit(lut, r);
+  const float gg = lds_lut_at_unit(lut, g);
+  const float gb = lds_lut_at_unit(lut, b);
   return sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
 }
 
@@ -98,13 +98,22 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
             // acc starts at 0, so layer 0 goes through the same fma: fma(0, k, t) == t, and the
             // sign of a zero can never reach the packed output (combine.ts:45-65 for l >= 1)
             const float kk = 1.0f - t.w;
+            // acc = fma(acc, kk, t) written as the three-operand v_fma_f32 with acc as destination.
+            // Left to itself LLVM picks v_fmac (d = a*b + d, so the result lands in t's register) and
+            // pays for it with a v_mov per accumulator per layer to get the loop-carried value back.
+            // The asm also pins the accumulators here: without a pin LLVM sinks the whole
+            // decode/gamut/combine arithmetic to its first use in phase 2 (past the barrier and the
+            // table swap) and keeps the 2 raw LDS words of every lookup alive: hundreds of spills.
+#if PH_COMBINE_ASM
+            asm volatile("v_fma_f32 %0, %0, %3, %4\n\tv_fma_f32 %1, %1, %3, %5\n\tv_fma_f32 %2, %2, %3, %6"
+                         : "+v"(acc[p][3 * j]), "+v"(acc[p][3 * j + 1]), "+v"(acc[p][3 * j + 2])
+                         : "v"(kk), "v"(t.x), "v"(t.y), "v"(t.z));
+#else
             acc[p][3 * j] = fma_rn(acc[p][3 * j], kk, t.x);
             acc[p][3 * j + 1] = fma_rn(acc[p][3 * j + 1], kk, t.y);
             acc[p][3 * j + 2] = fma_rn(acc[p][3 * j + 2], kk, t.z);
-            // Pin the accumulators here.  Without this LLVM sinks the whole decode/gamut/combine
-            // arithmetic to its first use in phase 2 (past the barrier and the table swap) and
-            // keeps the 2 raw LDS words of every lookup alive instead: hundreds of spilled VGPRs.
             asm volatile("" : "+v"(acc[p][3 * j]), "+v"(acc[p][3 * j + 1]), "+v"(acc[p][3 * j + 2]));
+#endif
             if (j & 1) PH_FENCE(2);
           }
           w = nxt;

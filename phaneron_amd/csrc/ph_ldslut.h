@@ -19,6 +19,16 @@ constexpr int kLdsBlock = 1024;
 #ifndef PH_TABLE_DMA
 #define PH_TABLE_DMA 1
 #endif
+// PH_LDS_ABS 1 = absolute LDS addresses (no per-read base add); PH_COMBINE_ASM 1 = in-place v_fma_f32
+#ifndef PH_LDS_ABS
+#define PH_LDS_ABS 1
+#endif
+#ifndef PH_COMBINE_ASM
+#define PH_COMBINE_ASM 1
+#endif
+#ifndef PH_ABLATE
+#define PH_ABLATE 0
+#endif
 #define PH_FENCE(level)                                         \
   do {                                                          \
     if (PH_SCHED_LEVEL >= (level)) __builtin_amdgcn_sched_barrier(0); \
@@ -29,6 +39,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 // all lanes of the workgroup copy the table blob global -> LDS (16 bytes per lane per step)
 template <int BS = kLdsBlock>
 __device__ __forceinline__ void lds_lut_load(const LutView &v) {
+#if PH_ABLATE & 2  // timing experiment only: no table loads
+  return;
+#endif
   const uint32_t n = v.bytes / 16;
 #if PH_TABLE_DMA
   // LDS-DMA: each wave instruction moves 1 KiB global -> LDS (wave-uniform LDS base + lane*16)
@@ -50,40 +63,81 @@ __device__ __forceinline__ void lds_lut_load(const LutView &v) {
 }
 
 // table[clamp(rint(x), 0, 65535)] for x = (gamma- or linear-domain value) * 65535, see ph_lut.h:
-// 5 float ops, 3 integer ops, 2 LDS reads.
-//   * v_rndne FIRST, then + bias (exact on integers).  Adding the bias before rounding would round
+// 4 float ops, 3 integer ops, 2 LDS reads.
+//   * round FIRST, then + bias (exact on integers).  Adding the bias before rounding would round
 //     twice: x + bias has a coarser ulp than x just above a power of two and can manufacture a tie;
 //   * the float's own exponent/mantissa bits are the logarithmic block number: one shift;
 //   * the delta address is produced by an fma whose result is a DENORMAL: (2*(i+bias) + base)
 //     * 2^-149 has exactly that integer as its bit pattern, so no int multiply/add is needed
-//     (f32 denormals are enabled in HIP kernels and cost nothing extra on gfx950).
+//     (f32 denormals are enabled in HIP kernels and cost nothing extra on gfx950);
+//   * both addresses are ABSOLUTE LDS addresses (the position of g_lds inside the workgroup's LDS is
+//     folded into anchor_off / delta_base once per kernel) and are dereferenced as address-space-3
+//     pointers made from integers: going through `g_lds + offset` costs one v_add_u32 per read,
+//     because the symbol's address is only known at link time.
+//   * rounding is the magic-number add of ph_device.h (y = x + 1.5*2^23 is M + idx exactly), the
+//     delta address comes straight from y (the -M is folded into the fma's addend) and only the
+//     anchor's logarithmic block needs (float)(idx + bias) = y - (M - bias).
 struct LutK {
-  float bias, delta_scale, delta_base;
+  float magic_minus_bias, delta_scale, delta_base;  // delta_base already holds -M*scale, +2*bias and the LDS base
   uint32_t shift, anchor_off;
 };
+typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+typedef const __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
 __device__ __forceinline__ LutK make_lut_k(const LutView &v) {
-  return LutK{v.bias, v.delta_scale, v.delta_base, v.shift, v.anchor_off};
+#if PH_LDS_ABS
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)g_lds;
+#else
+  const uint32_t lds0 = 0;
+#endif
+  // d_addr = 2*(idx + bias) + base + lds0 = bits(fma(M + idx, 2^-148, B)) with
+  // B = (base + lds0 + 2*bias) * 2^-149 - M * 2^-148.  Every term is a multiple of 2^-148 below 2^24
+  // of them (base, lds0 are even), so each float operation here is exact.
+  const float small = (v.delta_base + __uint_as_float(lds0)) + v.bias * v.delta_scale;  // denormal sums
+  const float b = small - kRoundMagic * v.delta_scale;
+  return LutK{kRoundMagic - v.bias, v.delta_scale, b, v.shift, v.anchor_off + lds0};
 }
-__device__ __forceinline__ float lds_lut_at(const LutK &k, float x) {
-  x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 65535.0f);  // v_med3_f32; NaN -> 0 like the reference
-  const float fb = __builtin_rintf(x) + k.bias;               // (float)(idx + bias), exact
+// y = M + idx (idx already clamped and rounded by the add that produced y)
+__device__ __forceinline__ float lds_lut_fetch(const LutK &k, float y) {
+  const float fb = y - k.magic_minus_bias;  // (float)(idx + bias), exact
   const uint32_t a_addr = ((__float_as_uint(fb) >> k.shift) << 2) + k.anchor_off;
-  const uint32_t d_addr = __float_as_uint(fma_rn(fb, k.delta_scale, k.delta_base));
+  const uint32_t d_addr = __float_as_uint(fma_rn(y, k.delta_scale, k.delta_base));
+#if PH_ABLATE & 1  // timing experiment only (wrong results): no LDS reads
+  const uint32_t a = a_addr, d = d_addr;
+#elif PH_ABLATE & 4  // timing experiment only: anchor read only
+  const uint32_t a = *(lds_u32_ptr)a_addr, d = d_addr;
+#elif PH_LDS_ABS
+  const uint32_t a = *(lds_u32_ptr)a_addr;
+  const uint32_t d = *(lds_u16_ptr)d_addr;
+#else
   const uint32_t a = *reinterpret_cast<const uint32_t *>(g_lds + a_addr);
   const uint32_t d = *reinterpret_cast<const uint16_t *>(g_lds + d_addr);
+#endif
   return __uint_as_float(a + d);
 }
-
+// table[sat_rte(x)], x in table-index units
+__device__ __forceinline__ float lds_lut_at(const LutK &k, float x) {
+  x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 65535.0f);  // v_med3_f32; NaN -> 0 like the reference
+  return lds_lut_fetch(k, x + kRoundMagic);
+}
+// table[sat_rte(t * 65535)] for a unit-range t: clamping t to [0,1] BEFORE the multiply gives the same
+// index (the product and its rounding are monotone, 0 and 1 map to the bounds) and is free - the
+// clamp becomes the output modifier of whatever instruction produced t.
+__device__ __forceinline__ float lds_lut_at_unit(const LutK &k, float t) {
+  t = __builtin_fminf(__builtin_fmaxf(t, 0.0f), 1.0f);
+  return lds_lut_fetch(k, t * 65535.0f + kRoundMagic);
+}
 
 // A gamma LUT as the kernels see it: either the compressed table in LDS or the plain f32 table
 // in global memory (tables that do not compress, or the "lds_lut" option switched off).
 struct LutInLds {
   LutK k;
   __device__ __forceinline__ float at(float x) const { return lds_lut_at(k, x); }
+  __device__ __forceinline__ float at_unit(float t) const { return lds_lut_at_unit(k, t); }
 };
 struct LutInGlobal {
   const float *__restrict__ t;
   __device__ __forceinline__ float at(float x) const { return t[sat_u16_rte(x)]; }
+  __device__ __forceinline__ float at_unit(float u) const { return t[sat_u16_rte(u * 65535.0f)]; }
 };
 
 }  // namespace ph

@@ -65,14 +65,20 @@ bool lut_compress(const float *lut, uint32_t max_bytes, std::vector<uint32_t> &b
     }
   }
   if (!found) return false;
-  // Exhaustive self-check with the very operations the kernels use (ph_kernels_lds.hip
-  // lds_lut_at): float add, shift, and the denormal fma that yields the delta byte address.
+  // Exhaustive self-check with the very operations the kernels use (ph_ldslut.h make_lut_k /
+  // lds_lut_fetch): the magic-number add that rounds, the subtraction that gives (float)(i + bias),
+  // the shift, and the fma whose denormal result is the delta byte address.
   const LutView v = lut_view(info, nullptr);
+  const float magic = 12582912.0f;  // kRoundMagic
+  const float mmb = magic - v.bias;
+  const float dbase = (v.delta_base + v.bias * v.delta_scale) - magic * v.delta_scale;
   const uint8_t *bytes = reinterpret_cast<const uint8_t *>(blob.data());
   for (uint32_t i = 0; i < 65536; ++i) {
-    const float fb = (float)i + v.bias;
+    const float y = (float)i + magic;
+    const float fb = y - mmb;
+    if (fb != (float)i + v.bias) return false;
     const uint32_t a_addr = ((f2u(fb) >> v.shift) << 2) + v.anchor_off;
-    const uint32_t d_addr = f2u(std::fmaf(fb, v.delta_scale, v.delta_base));
+    const uint32_t d_addr = f2u(std::fmaf(y, v.delta_scale, dbase));
     if (a_addr + 4 > info.delta_off || d_addr != info.delta_off + 2 * i) return false;
     uint32_t a;
     uint16_t d;
