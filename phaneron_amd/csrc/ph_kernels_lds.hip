@@ -44,6 +44,22 @@ __device__ __forceinline__ uint32_t write_px_luma_lds(float r, float g, float b,
   return sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
 }
 
+// the same from ready-made LUT indices (floats M + idx, ph_ldslut.h): phase 2 of the fused kernel
+__device__ __forceinline__ uint4 write_quad_idx_lds(const float (&yi)[18], const WriteK &wk, const LutK &lut) {
+  uint32_t y[6], u[3], v[3];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float gr = lds_lut_fetch(lut, yi[3 * j]), gg = lds_lut_fetch(lut, yi[3 * j + 1]);
+    const float gb = lds_lut_fetch(lut, yi[3 * j + 2]);
+    y[j] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.y));
+    if ((j & 1) == 0) {
+      u[j >> 1] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.u));
+      v[j >> 1] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.v));
+    }
+  }
+  return pack_quad(y, u, v);
+}
+
 __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const WriteK &wk, const LutK &lut) {
   uint32_t y[6], u[3], v[3];
 #pragma unroll
@@ -60,7 +76,11 @@ __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const Wr
 }
 
 // ------------------------------------------------------------------------------------------
-// fused [v210 read] x N -> combine_N -> v210 write, two LDS phases per tile of 1024*P quads
+// fused [v210 read] x N -> combine_N -> v210 write, two LDS phases per tile of BS*P quads.
+// Between the phases a quad is carried as its 18 writer-LUT INDICES (clamped, rounded, 16 bits each,
+// two per VGPR), not as 18 floats: 9 registers per quad, which is what lets one workgroup hold
+// P = 6 quads per lane - a whole 2160p share (5400 quads per CU) in ONE tile, so each frame costs two
+// table loads instead of four.
 // ------------------------------------------------------------------------------------------
 template <int N, int P, int BS>
 __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs a) {
@@ -68,13 +88,13 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
   const WriteK wk = load_write_k(a.f.wr_cm);
   const LutK rlut = make_lut_k(a.rd), wlut = make_lut_k(a.wr);
   // Every workgroup owns one contiguous, equally sized range of quads (all CUs finish together)
-  // and walks it in tiles of 1024*P quads; only the last tile of a range is partially filled.
+  // and walks it in tiles of BS*P quads; only the last tile of a range is partially filled.
   const uint32_t per_wg = (a.f.total_quads + gridDim.x - 1) / gridDim.x;
   const uint32_t wg_begin = blockIdx.x * per_wg;
   const uint32_t wg_end = wg_begin + per_wg < a.f.total_quads ? wg_begin + per_wg : a.f.total_quads;
   const uint32_t tile_quads = BS * P;
   for (uint32_t tile_begin = wg_begin; tile_begin < wg_end; tile_begin += tile_quads) {
-    float acc[P][18];
+    uint32_t st[P][9];
     lds_lut_load<BS>(a.rd);
     __syncthreads();
 #pragma unroll
@@ -83,10 +103,11 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
       f = f < wg_end ? f : wg_end - 1;                         // tail lanes recompute the last quad
       if (p * BS < wg_end - tile_begin) {               // uniform: skip empty slices of the last tile
         // layers are streamed one at a time with a one-deep prefetch: 8 VGPRs of input in
-        // flight instead of 4*N, which is what keeps P quads of accumulators in registers
+        // flight instead of 4*N
         uint4 w = reinterpret_cast<const uint4 *>(a.f.layers[0])[f];
+        float acc[18];
 #pragma unroll
-        for (int i = 0; i < 18; ++i) acc[p][i] = 0.0f;
+        for (int i = 0; i < 18; ++i) acc[i] = 0.0f;
 #pragma unroll 1  // rolled: one copy of the per-layer code whatever N is (I-cache, compile time)
         for (int l = 0; l < N; ++l) {
           uint4 nxt = w;
@@ -101,23 +122,32 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
             // acc = fma(acc, kk, t) written as the three-operand v_fma_f32 with acc as destination.
             // Left to itself LLVM picks v_fmac (d = a*b + d, so the result lands in t's register) and
             // pays for it with a v_mov per accumulator per layer to get the loop-carried value back.
-            // The asm also pins the accumulators here: without a pin LLVM sinks the whole
-            // decode/gamut/combine arithmetic to its first use in phase 2 (past the barrier and the
-            // table swap) and keeps the 2 raw LDS words of every lookup alive: hundreds of spills.
 #if PH_COMBINE_ASM
             asm volatile("v_fma_f32 %0, %0, %3, %4\n\tv_fma_f32 %1, %1, %3, %5\n\tv_fma_f32 %2, %2, %3, %6"
-                         : "+v"(acc[p][3 * j]), "+v"(acc[p][3 * j + 1]), "+v"(acc[p][3 * j + 2])
+                         : "+v"(acc[3 * j]), "+v"(acc[3 * j + 1]), "+v"(acc[3 * j + 2])
                          : "v"(kk), "v"(t.x), "v"(t.y), "v"(t.z));
 #else
-            acc[p][3 * j] = fma_rn(acc[p][3 * j], kk, t.x);
-            acc[p][3 * j + 1] = fma_rn(acc[p][3 * j + 1], kk, t.y);
-            acc[p][3 * j + 2] = fma_rn(acc[p][3 * j + 2], kk, t.z);
-            asm volatile("" : "+v"(acc[p][3 * j]), "+v"(acc[p][3 * j + 1]), "+v"(acc[p][3 * j + 2]));
+            acc[3 * j] = fma_rn(acc[3 * j], kk, t.x);
+            acc[3 * j + 1] = fma_rn(acc[3 * j + 1], kk, t.y);
+            acc[3 * j + 2] = fma_rn(acc[3 * j + 2], kk, t.z);
+            asm volatile("" : "+v"(acc[3 * j]), "+v"(acc[3 * j + 1]), "+v"(acc[3 * j + 2]));
 #endif
             if (j & 1) PH_FENCE(2);
           }
           w = nxt;
           PH_FENCE(1);
+        }
+        // the writer's first step (v210.ts:148-150 index = sat_rte(rgb * 65535)) needs no table: do it
+        // here and keep only the 16-bit indices, two per register (v_perm_b32)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const uint32_t lo = __float_as_uint(lds_lut_index_unit(acc[2 * i]));
+          const uint32_t hi = __float_as_uint(lds_lut_index_unit(acc[2 * i + 1]));
+          st[p][i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+          // Pin the packed state here.  Without a pin LLVM sinks the whole decode / gamut / combine
+          // arithmetic to its first use in phase 2 (past the barrier and the table swap) and keeps
+          // the raw LDS words of every lookup alive instead: hundreds of spilled VGPRs.
+          asm volatile("" : "+v"(st[p][i]));
         }
       }
     }
@@ -128,7 +158,13 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
     for (int p = 0; p < P; ++p) {
       const uint32_t f = tile_begin + p * BS + threadIdx.x;
       if (p * BS < wg_end - tile_begin) {
-        const uint4 packed = write_quad_lds(acc[p], wk, wlut);
+        float yi[18];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {  // M + idx: the index ORed into the mantissa of 1.5 * 2^23
+          yi[2 * i] = __uint_as_float((st[p][i] & 0xFFFFu) | 0x4B400000u);
+          yi[2 * i + 1] = __uint_as_float((st[p][i] >> 16) | 0x4B400000u);
+        }
+        const uint4 packed = write_quad_idx_lds(yi, wk, wlut);
         if (f < wg_end) reinterpret_cast<uint4 *>(a.f.out)[f] = packed;
       }
       PH_FENCE(1);
@@ -293,11 +329,9 @@ static hipError_t launch_fused_npb(hipStream_t s, const FusedLdsArgs &a, uint32_
   return hipGetLastError();
 }
 
-// Geometry: one workgroup per CU either way (the table fills the LDS).
-//   1024 lanes x P=4 quads : 128 VGPRs per lane, 4 waves per SIMD, tiles of 4096 quads
-//    512 lanes x P=11 quads: 256 VGPRs per lane, 2 waves per SIMD, tiles of 5632 quads - a whole
-//                            2160p share (5400 quads per CU) in ONE tile: 2 table loads, not 4
-// PH_FUSED_GEOM=1024|512 overrides for A/B runs.
+// Geometry: one workgroup of 1024 lanes per CU (the table fills the LDS), 4 waves per SIMD, at most
+// 128 VGPRs per lane.  P = 6 quads per lane (54 VGPRs of packed state) covers a 2160p share (5400
+// quads per CU) in one tile; PH_FUSED_GEOM=4|8 selects other P for A/B runs.
 template <int N>
 static hipError_t launch_fused_n(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
   static const int geom_env = [] {
@@ -306,9 +340,10 @@ static hipError_t launch_fused_n(hipStream_t s, const FusedLdsArgs &a, uint32_t 
   }();
   const uint32_t per_wg = (a.f.total_quads + grid - 1) / grid;
   (void)per_wg;
-  int geom = geom_env ? geom_env : 1024;  // measured: 71.6 us (1024x4) vs 74.5 us (512x11) at 2160p x4
-  if (geom == 512) return launch_fused_npb<N, 11, 512>(s, a, grid, lds);
-  return launch_fused_npb<N, 4, 1024>(s, a, grid, lds);
+  int geom = geom_env ? geom_env : 6;
+  if (geom == 4) return launch_fused_npb<N, 4, 1024>(s, a, grid, lds);
+  if (geom == 8) return launch_fused_npb<N, 8, 1024>(s, a, grid, lds);
+  return launch_fused_npb<N, 6, 1024>(s, a, grid, lds);
 }
 
 hipError_t launch_fused_v210_combine_lds(hipStream_t s, int n, const FusedLdsArgs &a, uint32_t num_cus) {

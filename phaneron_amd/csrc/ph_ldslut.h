@@ -114,6 +114,11 @@ __device__ __forceinline__ float lds_lut_fetch(const LutK &k, float y) {
 #endif
   return __uint_as_float(a + d);
 }
+// The rounded, clamped index of a unit-range value as the float M + idx (idx = its low 16 bits).
+__device__ __forceinline__ float lds_lut_index_unit(float t) {
+  t = __builtin_fminf(__builtin_fmaxf(t, 0.0f), 1.0f);
+  return t * 65535.0f + kRoundMagic;
+}
 // table[sat_rte(x)], x in table-index units
 __device__ __forceinline__ float lds_lut_at(const LutK &k, float x) {
   x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 65535.0f);  // v_med3_f32; NaN -> 0 like the reference
@@ -123,8 +128,7 @@ __device__ __forceinline__ float lds_lut_at(const LutK &k, float x) {
 // index (the product and its rounding are monotone, 0 and 1 map to the bounds) and is free - the
 // clamp becomes the output modifier of whatever instruction produced t.
 __device__ __forceinline__ float lds_lut_at_unit(const LutK &k, float t) {
-  t = __builtin_fminf(__builtin_fmaxf(t, 0.0f), 1.0f);
-  return lds_lut_fetch(k, t * 65535.0f + kRoundMagic);
+  return lds_lut_fetch(k, lds_lut_index_unit(t));
 }
 
 // A gamma LUT as the kernels see it: either the compressed table in LDS or the plain f32 table
