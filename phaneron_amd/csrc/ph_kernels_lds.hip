@@ -15,14 +15,35 @@
 
 #include <cstdlib>
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace ph {
 
+// Every YCbCr->RGB matrix colourMaths.ts:276-332 can produce has the same shape: one luma gain in all
+// three rows, no Cb term in R, no Cr term in B (SURVEY a4 goldens: y2r709 = 3a95a025 00000000 ... /
+// 3a95a025 b95b.. ba08.. / 3a95a025 3b07.. 00000000 ...).  With that shape (checked on the device, bit
+// for bit) Y*m0 is computed once per pixel and the two fma by zero are skipped: fma(c, +-0, p) == p
+// for the finite, non-negative code value c - except that it can turn p = -0 into +0, which the
+// clamp / round that follows maps to the same table index.  8 operations per pixel instead of 12.
+__device__ __forceinline__ bool ycbcr_matrix_is_standard(const ReadK &k) {
+  return k.r.y == 0.0f && k.b.z == 0.0f && k.r.x == k.g.x && k.g.x == k.b.x;
+}
+template <bool STD = false>
 __device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const ReadK &k, const LutK &lut) {
-  const float r = lds_lut_at_unit(lut, dot4(y, cb, cr, 1.0f, k.r));
-  const float g = lds_lut_at_unit(lut, dot4(y, cb, cr, 1.0f, k.g));
-  const float b = lds_lut_at_unit(lut, dot4(y, cb, cr, 1.0f, k.b));
+  float tr, tg, tb;
+  if (STD) {
+    const float ym = y * k.r.x;
+    tr = fma_rn(1.0f, k.r.w, fma_rn(cr, k.r.z, ym));
+    tg = fma_rn(1.0f, k.g.w, fma_rn(cr, k.g.z, fma_rn(cb, k.g.y, ym)));
+    tb = fma_rn(1.0f, k.b.w, fma_rn(cb, k.b.y, ym));
+  } else {
+    tr = dot4(y, cb, cr, 1.0f, k.r), tg = dot4(y, cb, cr, 1.0f, k.g), tb = dot4(y, cb, cr, 1.0f, k.b);
+  }
+  const float r = lds_lut_at_unit(lut, tr);
+  const float g = lds_lut_at_unit(lut, tg);
+  const float b = lds_lut_at_unit(lut, tb);
   return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
                      dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
 }
@@ -87,6 +108,7 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
   const ReadK rk = load_read_k(a.f.rd_cm, a.f.rd_gm);
   const WriteK wk = load_write_k(a.f.wr_cm);
   const LutK rlut = make_lut_k(a.rd), wlut = make_lut_k(a.wr);
+  const bool std_matrix = ycbcr_matrix_is_standard(rk);  // uniform
   // Every workgroup owns one contiguous, equally sized range of quads (all CUs finish together)
   // and walks it in tiles of BS*P quads; only the last tile of a range is partially filled.
   const uint32_t per_wg = (a.f.total_quads + gridDim.x - 1) / gridDim.x;
@@ -95,60 +117,77 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
   const uint32_t tile_quads = BS * P;
   for (uint32_t tile_begin = wg_begin; tile_begin < wg_end; tile_begin += tile_quads) {
     uint32_t st[P][9];
+    // Input words are streamed with a one-deep prefetch that runs THROUGH the slices: while layer l
+    // of slice p is being decoded the next word (layer l+1, or layer 0 of slice p+1) is in flight -
+    // 8 VGPRs of input instead of 4*N*P, and no slice starts by waiting for HBM.  The very first word
+    // is requested before the table load so its latency hides behind the DMA.
+    auto quad_of = [&](int p) {
+      const uint32_t f = tile_begin + p * BS + threadIdx.x;  // width % 48 == 0: flat index == offset
+      return f < wg_end ? f : wg_end - 1;                     // tail lanes recompute the last quad
+    };
+    uint4 w = reinterpret_cast<const uint4 *>(a.f.layers[0])[quad_of(0)];
+    // Phase 1 of one slice: N layers of one quad per lane -> combine -> the 18 writer-LUT indices,
+    // packed.  Takes the slice's layer-0 word and returns the next slice's (prefetch chain).  A
+    // generic lambda instantiated for both matrix shapes; everything it touches stays in registers
+    // (a by-reference `w` or argument struct ends up in scratch).
+    auto phase1_slice = [&](auto tag, uint4 w, uint32_t f, uint32_t f_next, bool more, uint32_t(&st)[9]) -> uint4 {
+      float acc[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) acc[i] = 0.0f;
+#pragma unroll 1  // rolled: one copy of the per-layer code whatever N is (I-cache, compile time)
+      for (int l = 0; l < N; ++l) {
+        uint4 nxt = w;
+        if (l + 1 < N) nxt = reinterpret_cast<const uint4 *>(a.f.layers[l + 1])[f];
+        else if (more) nxt = reinterpret_cast<const uint4 *>(a.f.layers[0])[f_next];
+        const Yuv6 q = unpack_quad(w);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float4 t = read_px_lds<decltype(tag)::value>(q.y[j], q.cb[j >> 1], q.cr[j >> 1], rk, rlut);
+          // acc starts at 0, so layer 0 goes through the same fma: fma(0, k, t) == t, and the
+          // sign of a zero can never reach the packed output (combine.ts:45-65 for l >= 1)
+          const float kk = 1.0f - t.w;
+          // acc = fma(acc, kk, t) written as the three-operand v_fma_f32 with acc as destination.
+          // Left to itself LLVM picks v_fmac (d = a*b + d, so the result lands in t's register) and
+          // pays for it with a v_mov per accumulator per layer to get the loop-carried value back.
+    #if PH_COMBINE_ASM
+          asm volatile("v_fma_f32 %0, %0, %3, %4\n\tv_fma_f32 %1, %1, %3, %5\n\tv_fma_f32 %2, %2, %3, %6"
+                       : "+v"(acc[3 * j]), "+v"(acc[3 * j + 1]), "+v"(acc[3 * j + 2])
+                       : "v"(kk), "v"(t.x), "v"(t.y), "v"(t.z));
+    #else
+          acc[3 * j] = fma_rn(acc[3 * j], kk, t.x);
+          acc[3 * j + 1] = fma_rn(acc[3 * j + 1], kk, t.y);
+          acc[3 * j + 2] = fma_rn(acc[3 * j + 2], kk, t.z);
+          asm volatile("" : "+v"(acc[3 * j]), "+v"(acc[3 * j + 1]), "+v"(acc[3 * j + 2]));
+    #endif
+          if (j & 1) PH_FENCE(2);
+        }
+        w = nxt;
+        PH_FENCE(1);
+      }
+      // the writer's first step (v210.ts:148-150 index = sat_rte(rgb * 65535)) needs no table: do it
+      // here and keep only the 16-bit indices, two per register (v_perm_b32)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const uint32_t lo = __float_as_uint(lds_lut_index_unit(acc[2 * i]));
+        const uint32_t hi = __float_as_uint(lds_lut_index_unit(acc[2 * i + 1]));
+        st[i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        // Pin the packed state here.  Without a pin LLVM sinks the whole decode / gamut / combine
+        // arithmetic to its first use in phase 2 (past the barrier and the table swap) and keeps
+        // the raw LDS words of every lookup alive instead: hundreds of spilled VGPRs.
+        asm volatile("" : "+v"(st[i]));
+      }
+      return w;
+    };
     lds_lut_load<BS>(a.rd);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      uint32_t f = tile_begin + p * BS + threadIdx.x;  // width % 48 == 0: flat index == offset
-      f = f < wg_end ? f : wg_end - 1;                         // tail lanes recompute the last quad
+      const uint32_t f = quad_of(p);
       if (p * BS < wg_end - tile_begin) {               // uniform: skip empty slices of the last tile
-        // layers are streamed one at a time with a one-deep prefetch: 8 VGPRs of input in
-        // flight instead of 4*N
-        uint4 w = reinterpret_cast<const uint4 *>(a.f.layers[0])[f];
-        float acc[18];
-#pragma unroll
-        for (int i = 0; i < 18; ++i) acc[i] = 0.0f;
-#pragma unroll 1  // rolled: one copy of the per-layer code whatever N is (I-cache, compile time)
-        for (int l = 0; l < N; ++l) {
-          uint4 nxt = w;
-          if (l + 1 < N) nxt = reinterpret_cast<const uint4 *>(a.f.layers[l + 1])[f];
-          const Yuv6 q = unpack_quad(w);
-#pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            const float4 t = read_px_lds(q.y[j], q.cb[j >> 1], q.cr[j >> 1], rk, rlut);
-            // acc starts at 0, so layer 0 goes through the same fma: fma(0, k, t) == t, and the
-            // sign of a zero can never reach the packed output (combine.ts:45-65 for l >= 1)
-            const float kk = 1.0f - t.w;
-            // acc = fma(acc, kk, t) written as the three-operand v_fma_f32 with acc as destination.
-            // Left to itself LLVM picks v_fmac (d = a*b + d, so the result lands in t's register) and
-            // pays for it with a v_mov per accumulator per layer to get the loop-carried value back.
-#if PH_COMBINE_ASM
-            asm volatile("v_fma_f32 %0, %0, %3, %4\n\tv_fma_f32 %1, %1, %3, %5\n\tv_fma_f32 %2, %2, %3, %6"
-                         : "+v"(acc[3 * j]), "+v"(acc[3 * j + 1]), "+v"(acc[3 * j + 2])
-                         : "v"(kk), "v"(t.x), "v"(t.y), "v"(t.z));
-#else
-            acc[3 * j] = fma_rn(acc[3 * j], kk, t.x);
-            acc[3 * j + 1] = fma_rn(acc[3 * j + 1], kk, t.y);
-            acc[3 * j + 2] = fma_rn(acc[3 * j + 2], kk, t.z);
-            asm volatile("" : "+v"(acc[3 * j]), "+v"(acc[3 * j + 1]), "+v"(acc[3 * j + 2]));
-#endif
-            if (j & 1) PH_FENCE(2);
-          }
-          w = nxt;
-          PH_FENCE(1);
-        }
-        // the writer's first step (v210.ts:148-150 index = sat_rte(rgb * 65535)) needs no table: do it
-        // here and keep only the 16-bit indices, two per register (v_perm_b32)
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          const uint32_t lo = __float_as_uint(lds_lut_index_unit(acc[2 * i]));
-          const uint32_t hi = __float_as_uint(lds_lut_index_unit(acc[2 * i + 1]));
-          st[p][i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-          // Pin the packed state here.  Without a pin LLVM sinks the whole decode / gamut / combine
-          // arithmetic to its first use in phase 2 (past the barrier and the table swap) and keeps
-          // the raw LDS words of every lookup alive instead: hundreds of spilled VGPRs.
-          asm volatile("" : "+v"(st[p][i]));
-        }
+        const bool more = (p + 1 < P) && ((p + 1) * BS < wg_end - tile_begin);  // uniform
+        const uint32_t f_next = more ? quad_of(p + 1) : f;
+        if (std_matrix) w = phase1_slice(std::true_type{}, w, f, f_next, more, st[p]);
+        else w = phase1_slice(std::false_type{}, w, f, f_next, more, st[p]);
       }
     }
     __syncthreads();

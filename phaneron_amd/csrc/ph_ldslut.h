@@ -101,7 +101,10 @@ __device__ __forceinline__ float lds_lut_fetch(const LutK &k, float y) {
   const float fb = y - k.magic_minus_bias;  // (float)(idx + bias), exact
   const uint32_t a_addr = ((__float_as_uint(fb) >> k.shift) << 2) + k.anchor_off;
   const uint32_t d_addr = __float_as_uint(fma_rn(y, k.delta_scale, k.delta_base));
-#if PH_ABLATE & 1  // timing experiment only (wrong results): no LDS reads
+#if PH_ABLATE & 8  // timing experiment only (wrong results): both reads issued, but conflict-free
+  const uint32_t a = *(lds_u32_ptr)(a_addr & 4u);
+  const uint32_t d = *(lds_u16_ptr)(d_addr & 2u);
+#elif PH_ABLATE & 1  // timing experiment only (wrong results): no LDS reads
   const uint32_t a = a_addr, d = d_addr;
 #elif PH_ABLATE & 4  // timing experiment only: anchor read only
   const uint32_t a = *(lds_u32_ptr)a_addr, d = d_addr;

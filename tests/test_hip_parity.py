@@ -216,6 +216,35 @@ def test_fused_pipeline_vs_oracle_chain(n, w, h, rspec, wspec):
     assert_bits(hh.host(out, np.uint32), want, "fused n=%d" % n)
 
 
+@pytest.mark.parametrize("shape", ["full", "negative_luma_gain", "cb_in_red_only", "standard_with_negative_zero"])
+def test_fused_pipeline_with_non_standard_matrices(shape):
+    """The fused kernel has a fast path for the matrix shape colourMaths produces (one luma gain, no Cb
+    in R, no Cr in B) chosen on the device from the coefficient values.  Matrices that miss the shape
+    by one coefficient - or hit it with a -0 - must still equal the oracle chain, bit for bit."""
+    import torch
+    import hip_harness as hh
+    w, h, n = 1920, 10, 3
+    layers = [frames.v210_random(w, h, frames.layer_seed(5, i), legal=(i != 1)) for i in range(n)]
+    m = orc.ycbcr2rgb_matrix("709").copy()
+    if shape == "full":          # every coefficient non-zero, three different luma gains
+        m = (m.reshape(3, 4) * np.array([[1.0], [1.03125], [0.96875]], np.float32)).reshape(-1).astype(np.float32)
+        m[1], m[10] = np.float32(1.5e-4), np.float32(-2.5e-4)
+    elif shape == "negative_luma_gain":  # same gain in all rows, but negative: Y * m0 can be -0
+        m[0] = m[4] = m[8] = np.float32(-m[0])
+    elif shape == "cb_in_red_only":
+        m[1] = np.float32(3.0e-4)
+    else:                         # the standard shape with a NEGATIVE zero where the zeros are
+        m[1], m[10] = np.float32(-0.0), np.float32(-0.0)
+    gm = orc.rgb2rgb_matrix("709", "2020")
+    lut = orc.gamma2linear_lut("709")
+    _, dlut, dgm = hh.ColourParams.reader("709", "2020")
+    wcm, wlut = hh.ColourParams.writer("2020")
+    out = torch.zeros(frames.v210_pitch_bytes(w) * h // 4, dtype=torch.int32, device="cuda")
+    hh.ctx().fused_v210_combine([hh.dev(l) for l in layers], out, w, h, hh.dev(m), dlut, dgm, wcm, wlut)
+    want = orc.pipeline_v210_combine(layers, w, h, m, lut, gm, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    assert_bits(hh.host(out, np.uint32), want, shape)
+
+
 @pytest.mark.parametrize("case", ["pip_1080", "upscale2x", "single_layer", "interlaced"])
 def test_compose_write_vs_oracle_chain(case, lut_path):
     """ph_compose_write_v210 == transform x N -> combine_N -> v210 write of the oracle."""
