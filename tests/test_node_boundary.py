@@ -138,3 +138,84 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
     assert res["fusedCallbackFired"] is True
     assert np.array_equal(np.fromfile(tmp_path / "fused_queue_out.bin", np.uint32),
                           orc.pipeline_v210_combine(staged_src[0], 1920, 24, *rd, *wr))
+
+
+@needs_node
+def test_valve_graph_host_logic_on_mock():
+    """node/valves (Mixer -> Transitioner -> Combiner) on the recording mock: what it asks
+    the device to do follows mixer.ts:209-223, transitioner.ts:143-176,269 and combiner.ts:211-254."""
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "valves_scenario.js")], capture_output=True, text=True,
+                         check=True).stdout
+    d = json.loads(out)
+    # the combiner renumbers its output 0.. and hands out exactly one reference (no route forks)
+    assert [(o["ts"], o["refs"]) for o in d["outputs"]] == [(i, 1) for i in range(7)]
+    names = [k["name"] for k in d["kernels"]]
+    assert names.count("combine_3") == 7 and names.count("transition_dissolve") == 4
+    # dissolve of 4 frames: numFrames = 3, mix = 1 - cur/3, keyed on the incoming source's timestamp
+    dis = [k for k in d["kernels"] if k["name"] == "transition_dissolve"]
+    assert [k["ts"] for k in dis] == [300, 301, 302, 303]
+    want = [1.0, float(np.float32(1.0 - 1 / 3)), float(np.float32(1.0 - 2 / 3)), 0.0]
+    assert [k["mix"] for k in dis] == want
+    # every transform runs under its producer's timestamp; the PiP layer uploads a different matrix
+    xf = [k for k in d["kernels"] if k["name"] == "transform"]
+    assert len({k["matrix"] for k in xf}) == 2
+    assert sorted(k["ts"] for k in xf if k["ts"] < 200) == list(range(100, 107))
+    # the empty layer contributes its black frame (the same buffer every time) as the third input
+    third = {k["inputs"][2] for k in d["kernels"] if k["name"] == "combine_3"}
+    assert len(third) == 1
+    # the transitioner reports the source timestamps per step (layerUpdate), [] for the empty layer
+    assert {"layer": "L2", "ts": [202, 300]} in d["layerEvents"] and {"layer": "L3", "ts": []} in d["layerEvents"]
+    # nothing leaks: every source frame was released; only the black frames and matrices stay alive
+    assert d["leakedFrames"] == []
+    assert sorted(o["owner"].split("-")[0] for o in d["liveOwners"]) == ["black"] * 4 + ["transformMatrix"] * 3
+
+
+def mixer_matrix(w, h, p):
+    """Mixer.mixVidValve's parameter mapping (mixer.ts:209-223) into the Transform matrix"""
+    return orc_mod().transform_matrix(w, h, False, False, p["anchor"]["x"] - 0.5, p["anchor"]["y"] - 0.5, p["fill"]["xScale"],
+                                      p["fill"]["yScale"], -p["fill"]["xOffset"], -p["fill"]["yOffset"], -p["rotation"] / 360.0)
+
+
+def orc_mod():
+    from oracle import orc
+    return orc
+
+
+@needs_node
+@pytest.mark.gpu
+def test_valve_graph_on_gpu(tmp_path):
+    """The same graph on the real addon: every output frame equals the oracle's chain for that frame."""
+    import frames
+    orc = orc_mod()
+    w, h, nf = 192, 64, 7
+    default = dict(anchor=dict(x=0, y=0), rotation=0, fill=dict(xOffset=0, yOffset=0, xScale=1, yScale=1), volume=1)
+    pip = dict(anchor=dict(x=0.25, y=0.75), rotation=30, fill=dict(xOffset=0.25, yOffset=-0.125, xScale=0.5, yScale=0.5),
+               volume=1)
+    src = {n: [frames.rgba_random(w, h, 9000 + 100 * k + i) for i in range(nf)] for k, n in enumerate(("A", "B0", "B1"))}
+    for n, fs_ in src.items():
+        for i, f in enumerate(fs_):
+            f.tofile(tmp_path / ("%s_%d.bin" % (n, i)))
+    job = dict(width=w, height=h, frames=nf, pip=pip, dissolveAt=2, dissolveLen=4, cutAt=6)
+    (tmp_path / "job.json").write_text(json.dumps(job))
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "valves_run.js"), str(tmp_path)], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads((tmp_path / "result.json").read_text())
+    assert res["stamps"] == list(range(nf))
+    md, mp = mixer_matrix(w, h, default), mixer_matrix(w, h, pip)
+    black = np.zeros((h, w, 4), np.float32)
+    b1 = 0  # frames of B1 consumed so far
+    for f in range(nf):
+        a = orc.transform(src["A"][f], md, w, h)
+        if f < 2:
+            b = orc.transform(src["B0"][f], mp, w, h)
+        elif f < 6:
+            mix = np.float32(1.0 - (f - 2) / 3)
+            b = orc.transition_dissolve(orc.transform(src["B0"][f], mp, w, h), orc.transform(src["B1"][b1], md, w, h), float(mix))
+            b1 += 1
+        else:
+            b = orc.transform(src["B1"][b1], md, w, h)
+            b1 += 1
+        want = orc.combine([a, b, black])
+        got = np.fromfile(tmp_path / ("out_%d.bin" % f), np.float32)
+        assert np.array_equal(got.view(np.uint32), want.reshape(-1).view(np.uint32)), f
