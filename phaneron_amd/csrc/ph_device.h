@@ -133,4 +133,46 @@ __device__ __forceinline__ uint4 pack_quad(const uint32_t y[6], const uint32_t u
   return w;
 }
 
+// ------------------------------------------------------------------------------------------
+// bilinear sampler (OpenCL 1.2 s8.2: NORMALIZED | CLAMP (border 0) | LINEAR).  The f32
+// evaluation order is fixed: weights first, then ((w00*t00 + w10*t10) + w01*t01) + w11*t11,
+// plain mul/add, no fma (DESIGN.md "sampler").
+// Branch-free: the four taps are loaded unconditionally from coordinates forced into the image and
+// zeroed afterwards where the real coordinate was outside (border colour 0).  A per-tap `if` makes
+// four dependent branch-and-load round trips per sample; this way the four loads are in flight
+// together.  (float -> int conversion saturates and NaN converts to 0, so wild coordinates stay safe;
+// the index arithmetic is unsigned 32-bit: images have fewer than 2^32 pixels.)
+// ------------------------------------------------------------------------------------------
+// `direct` (uniform): skip the filter and return the texel (dx, dy) itself - through the same four
+// loads and a final select, so that a compositor can run sampled and 1:1 layers without a branch.
+template <bool MAY_BE_DIRECT = false>
+__device__ __forceinline__ float4 sample_linear(const float4 *__restrict__ img, int w, int h, float s, float t,
+                                                bool direct = false, uint32_t dx = 0, uint32_t dy = 0) {
+  const float u = s * (float)w, v = t * (float)h;
+  const float fu = u - 0.5f, fv = v - 0.5f;
+  const float flu = __builtin_floorf(fu), flv = __builtin_floorf(fv);
+  uint32_t i0 = (uint32_t)(int)flu, j0 = (uint32_t)(int)flv;
+  if (MAY_BE_DIRECT) i0 = direct ? dx : i0, j0 = direct ? dy : j0;
+  const uint32_t i1 = i0 + 1u, j1 = j0 + 1u;
+  const float a = fu - flu, b = fv - flv;
+  const float oma = 1.0f - a, omb = 1.0f - b;
+  const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
+  const bool xa = i0 < (uint32_t)w, xb = i1 < (uint32_t)w, ya = j0 < (uint32_t)h, yb = j1 < (uint32_t)h;
+  const uint32_t r0 = (ya ? j0 : 0u) * (uint32_t)w, r1 = (yb ? j1 : 0u) * (uint32_t)w;
+  const uint32_t c0 = xa ? i0 : 0u, c1 = xb ? i1 : 0u;
+  float4 t00 = img[r0 + c0], t10 = img[r0 + c1], t01 = img[r1 + c0], t11 = img[r1 + c1];
+  // component-wise selects (v_cndmask): selecting between whole float4 objects goes through scratch
+  const bool k00 = xa && ya, k10 = xb && ya, k01 = xa && yb, k11 = xb && yb;
+#define PH_KEEP(T, K) T.x = (K) ? T.x : 0.f, T.y = (K) ? T.y : 0.f, T.z = (K) ? T.z : 0.f, T.w = (K) ? T.w : 0.f
+  PH_KEEP(t00, k00), PH_KEEP(t10, k10), PH_KEEP(t01, k01), PH_KEEP(t11, k11);
+#undef PH_KEEP
+  float4 r;
+  r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+  r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+  r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+  r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+  if (MAY_BE_DIRECT) r.x = direct ? t00.x : r.x, r.y = direct ? t00.y : r.y, r.z = direct ? t00.z : r.z, r.w = direct ? t00.w : r.w;
+  return r;
+}
+
 }  // namespace ph

@@ -295,33 +295,6 @@ __global__ __launch_bounds__(kBlock) void yadif_kernel(const float4 *__restrict_
   out[(size_t)y * w + x] = make_float4(res[0], res[1], res[2], alpha);  // :164 alpha from cur
 }
 
-// ------------------------------------------------------------------------------------------
-// bilinear sampler (OpenCL 1.2 s8.2: NORMALIZED | CLAMP (border 0) | LINEAR).  The f32
-// evaluation order is fixed: weights first, then ((w00*t00 + w10*t10) + w01*t01) + w11*t11,
-// plain mul/add, no fma (DESIGN.md "sampler").
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 texel_border(const float4 *__restrict__ img, int w, int h, int x, int y) {
-  if (x < 0 || y < 0 || x >= w || y >= h) return make_float4(0.f, 0.f, 0.f, 0.f);
-  return img[(size_t)y * w + x];
-}
-__device__ __forceinline__ float4 sample_linear(const float4 *__restrict__ img, int w, int h, float s, float t) {
-  const float u = s * (float)w, v = t * (float)h;
-  const float fu = u - 0.5f, fv = v - 0.5f;
-  const float flu = __builtin_floorf(fu), flv = __builtin_floorf(fv);
-  const int i0 = (int)flu, j0 = (int)flv;
-  const float a = fu - flu, b = fv - flv;
-  const float oma = 1.0f - a, omb = 1.0f - b;
-  const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
-  const float4 t00 = texel_border(img, w, h, i0, j0), t10 = texel_border(img, w, h, i0 + 1, j0);
-  const float4 t01 = texel_border(img, w, h, i0, j0 + 1), t11 = texel_border(img, w, h, i0 + 1, j0 + 1);
-  float4 r;
-  r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
-  r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
-  r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
-  r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
-  return r;
-}
-
 // transform.ts:36-59.  2-D grid; 64x4 blocks keep a wave on one output row.
 __global__ __launch_bounds__(kBlock) void transform_kernel(const float4 *__restrict__ in, int iw, int ih,
                                                            const float *__restrict__ m, float4 *__restrict__ out,

@@ -279,28 +279,6 @@ __global__ __launch_bounds__(kLdsBlock) void v210_write_lds_kernel(const float4 
 // frames in between; bit-identical to running those kernels one after the other.
 // Single phase: only the writer table is needed.  One output quad per lane.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 texel_border0(const float4 *__restrict__ img, int w, int h, int x, int y) {
-  if (x < 0 || y < 0 || x >= w || y >= h) return make_float4(0.f, 0.f, 0.f, 0.f);
-  return img[(size_t)y * w + x];
-}
-__device__ __forceinline__ float4 sample_linear0(const float4 *__restrict__ img, int w, int h, float s, float t) {
-  const float u = s * (float)w, v = t * (float)h;
-  const float fu = u - 0.5f, fv = v - 0.5f;
-  const float flu = __builtin_floorf(fu), flv = __builtin_floorf(fv);
-  const int i0 = (int)flu, j0 = (int)flv;
-  const float a = fu - flu, b = fv - flv;
-  const float oma = 1.0f - a, omb = 1.0f - b;
-  const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
-  const float4 t00 = texel_border0(img, w, h, i0, j0), t10 = texel_border0(img, w, h, i0 + 1, j0);
-  const float4 t01 = texel_border0(img, w, h, i0, j0 + 1), t11 = texel_border0(img, w, h, i0 + 1, j0 + 1);
-  float4 r;
-  r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
-  r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
-  r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
-  r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
-  return r;
-}
-
 __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_kernel(ComposeArgs a) {
   const WriteK wk = load_write_k(a.wr_cm);
   const LutK lk = make_lut_k(a.wr);
@@ -328,7 +306,7 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_kernel(ComposeAr
           const float px = (float)x / (float)(int)a.out_w - 0.5f;
           const float s = dot3(m0, m1, m2, px, py, 1.0f) + 0.5f;
           const float tt = dot3(m3, m4, m5, px, py, 1.0f) + 0.5f;
-          t = sample_linear0(img, lw, lh, s, tt);
+          t = sample_linear(img, lw, lh, s, tt);
         } else {
           t = img[(size_t)line * a.out_w + x];
         }
@@ -348,6 +326,105 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_kernel(ComposeAr
     for (int j = 0; j < 6; ++j) rgb[3 * j] = acc[4 * j], rgb[3 * j + 1] = acc[4 * j + 1], rgb[3 * j + 2] = acc[4 * j + 2];
     reinterpret_cast<uint4 *>(a.out)[(size_t)line * qpl + g] = write_quad_lds(rgb, wk, lk);
   }
+}
+
+// The same compositor with ONE PIXEL PER LANE.  A quad-per-lane mapping puts the lanes of a wave 6
+// pixels apart, so every bilinear tap of a wave touches ~6x the cache lines it needs (the texture
+// path is then the bound: 170 us for 4 x 1080p -> 2160p).  Here a wave samples 64 consecutive pixels
+// per step (taps of neighbouring lanes fall into the same lines), combines, runs the writer LUT and
+// matrix per pixel, and parks the 16-bit code values of 192 pixels in a small LDS area behind the table;
+// lanes 0..31 then pack the chunk's 32 quads and store 512 contiguous bytes.  Bit-identical results.
+constexpr uint32_t kComposeChunk = 192;                                   // pixels per wave per step: 32 quads
+constexpr uint32_t kComposeStageBytes = (kLdsBlock / 64) * kComposeChunk * 4;  // Y[192] + U[96] + V[96] u16 per wave
+template <int N, bool ALL_DIRECT>
+__global__ __launch_bounds__(kLdsBlock) void compose_write_v210_px_kernel(ComposeArgs a, uint32_t stage_off) {
+  const WriteK wk = load_write_k(a.wr_cm);
+  const LutK lk = make_lut_k(a.wr);
+  // transform matrices once per kernel, not once per pixel: a load inside the layer loop puts a second
+  // memory round trip in front of every sample
+  float mm[N][6];
+  bool direct[N];
+#pragma unroll
+  for (int l = 0; l < N; ++l) {
+    direct[l] = a.matrix[l] == nullptr;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mm[l][i] = direct[l] ? 0.0f : a.matrix[l][i];
+  }
+  lds_lut_load(a.wr);
+  __syncthreads();
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint16_t *ys = reinterpret_cast<uint16_t *>(g_lds + stage_off + wave * kComposeChunk * 4);
+  uint16_t *us = ys + kComposeChunk, *vs = us + kComposeChunk / 2;
+  const uint32_t qpl = a.out_w / 6;                       // out_w % 48 == 0
+  const uint32_t total_px = a.out_w * a.lines;            // a multiple of 48: chunks end on quad boundaries
+  const uint32_t waves_total = gridDim.x * (kLdsBlock / 64);
+  for (uint32_t base = (blockIdx.x * (kLdsBlock / 64) + wave) * kComposeChunk; base < total_px;
+       base += waves_total * kComposeChunk) {
+#pragma unroll 1
+    for (uint32_t k = 0; k < kComposeChunk / 64; ++k) {
+      const uint32_t local = k * 64 + lane;
+      uint32_t p = base + local;
+      p = p < total_px ? p : total_px - 1;
+      const uint32_t li = p / a.out_w, x = p - li * a.out_w;
+      const uint32_t line = a.first_line + li * a.line_step;
+      const float py = (float)(int)line / (float)(int)a.out_h - 0.5f;
+      const float px = (float)(int)x / (float)(int)a.out_w - 0.5f;
+      // all layers are sampled before any is combined: N x 4 independent loads in flight
+      float4 t[N];
+#pragma unroll
+      for (int l = 0; l < N; ++l) {  // transform.ts:53-57; a layer without a matrix is taken 1:1
+        if (ALL_DIRECT) {  // no layer is sampled (host knows): one load per layer
+          t[l] = reinterpret_cast<const float4 *>(a.layers[l])[(size_t)line * a.out_w + x];
+          continue;
+        }
+        const float s = dot3(mm[l][0], mm[l][1], mm[l][2], px, py, 1.0f) + 0.5f;
+        const float tt = dot3(mm[l][3], mm[l][4], mm[l][5], px, py, 1.0f) + 0.5f;
+        t[l] = sample_linear<true>(reinterpret_cast<const float4 *>(a.layers[l]), a.lw[l], a.lh[l], s, tt, direct[l], x, line);
+      }
+      float r = t[0].x, g = t[0].y, b = t[0].z;
+#pragma unroll
+      for (int l = 1; l < N; ++l) {  // combine.ts:45-65 (alpha of the result is never used by the writer)
+        const float kk = 1.0f - t[l].w;
+        r = fma_rn(r, kk, t[l].x), g = fma_rn(g, kk, t[l].y), b = fma_rn(b, kk, t[l].z);
+      }
+      const Yuv1 c = write_px_lds(r, g, b, wk, lk);  // v210.ts:145-156
+      ys[local] = (uint16_t)c.y;
+      if (!(x & 1)) us[local >> 1] = (uint16_t)c.u, vs[local >> 1] = (uint16_t)c.v;
+    }
+    // one wave writes and reads its own staging area: LDS operations of a wave complete in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < kComposeChunk / 6) {
+      const uint32_t first_px = base + lane * 6;
+      if (first_px < total_px) {
+        uint32_t y[6], u[3], v[3];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) y[j] = ys[lane * 6 + j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) u[j] = us[lane * 3 + j], v[j] = vs[lane * 3 + j];
+        const uint32_t li = first_px / a.out_w, x = first_px - li * a.out_w;
+        const uint32_t line = a.first_line + li * a.line_step;
+        reinterpret_cast<uint4 *>(a.out)[(size_t)line * qpl + x / 6] = pack_quad(y, u, v);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the next step overwrites the staging area
+  }
+}
+
+template <int N, bool ALL_DIRECT>
+static hipError_t launch_compose_px_nd(hipStream_t s, const ComposeArgs &a, uint32_t grid, uint32_t stage_off) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(compose_write_v210_px_kernel<N, ALL_DIRECT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(stage_off + kComposeStageBytes));
+  if (e != hipSuccess) return e;
+  compose_write_v210_px_kernel<N, ALL_DIRECT><<<grid, kLdsBlock, stage_off + kComposeStageBytes, s>>>(a, stage_off);
+  return hipGetLastError();
+}
+template <int N>
+static hipError_t launch_compose_px_n(hipStream_t s, const ComposeArgs &a, uint32_t grid, uint32_t stage_off) {
+  bool all_direct = true;
+  for (int l = 0; l < N; ++l) all_direct = all_direct && a.matrix[l] == nullptr;
+  return all_direct ? launch_compose_px_nd<N, true>(s, a, grid, stage_off) : launch_compose_px_nd<N, false>(s, a, grid, stage_off);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -401,10 +478,32 @@ hipError_t launch_fused_v210_combine_lds(hipStream_t s, int n, const FusedLdsArg
 }
 
 hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32_t num_cus) {
-  hipError_t e = allow_lds(compose_write_v210_kernel, a.wr.bytes);
-  if (e != hipSuccess) return e;
   const uint32_t total = a.out_w / 6 * a.lines;
   if (!total) return hipSuccess;
+  static const int quad_env = [] {
+    const char *e = getenv("PH_COMPOSE_QUAD");  // 1 = the quad-per-lane kernel (A/B runs)
+    return e ? atoi(e) : 0;
+  }();
+  // pixel-per-lane form: needs the staging area behind the table (160 KiB of LDS per workgroup)
+  const uint32_t stage_off = (a.wr.bytes + 15u) & ~15u;
+  if (!quad_env && stage_off + kComposeStageBytes <= 160u * 1024u) {
+    const uint32_t chunks = (a.out_w * a.lines + kComposeChunk - 1) / kComposeChunk;
+    const uint32_t want = (chunks + kLdsBlock / 64 - 1) / (kLdsBlock / 64);
+    const uint32_t grid = want < num_cus ? want : num_cus;
+    switch (a.n) {
+      case 1: return launch_compose_px_n<1>(s, a, grid, stage_off);
+      case 2: return launch_compose_px_n<2>(s, a, grid, stage_off);
+      case 3: return launch_compose_px_n<3>(s, a, grid, stage_off);
+      case 4: return launch_compose_px_n<4>(s, a, grid, stage_off);
+      case 5: return launch_compose_px_n<5>(s, a, grid, stage_off);
+      case 6: return launch_compose_px_n<6>(s, a, grid, stage_off);
+      case 7: return launch_compose_px_n<7>(s, a, grid, stage_off);
+      case 8: return launch_compose_px_n<8>(s, a, grid, stage_off);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  hipError_t e = allow_lds(compose_write_v210_kernel, a.wr.bytes);
+  if (e != hipSuccess) return e;
   const uint32_t want = (total + kLdsBlock - 1) / kLdsBlock;
   compose_write_v210_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, a.wr.bytes, s>>>(a);
   return hipGetLastError();

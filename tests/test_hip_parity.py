@@ -245,7 +245,7 @@ def test_fused_pipeline_with_non_standard_matrices(shape):
     assert_bits(hh.host(out, np.uint32), want, shape)
 
 
-@pytest.mark.parametrize("case", ["pip_1080", "upscale2x", "single_layer", "interlaced"])
+@pytest.mark.parametrize("case", ["pip_1080", "upscale2x", "single_layer", "interlaced", "all_direct"])
 def test_compose_write_vs_oracle_chain(case, lut_path):
     """ph_compose_write_v210 == transform x N -> combine_N -> v210 write of the oracle."""
     import torch
@@ -264,6 +264,9 @@ def test_compose_write_vs_oracle_chain(case, lut_path):
     elif case == "single_layer":
         ow, oh, il = 192, 40, 0
         specs = [(96, 20, dict(flip_h=True))]
+    elif case == "all_direct":  # no layer sampled: the one-load-per-layer variant of the kernel
+        ow, oh, il = 480, 50, 1
+        specs = [(480, 50, None) for _ in range(3)]
     else:
         ow, oh, il = 480, 64, 3
         specs = [(480, 64, None), (240, 32, dict(scale_x=0.75, scale_y=0.75))]
