@@ -1,0 +1,69 @@
+#!/bin/bash
+# One gpurun call that regenerates every measured artifact under profiles/ (written to
+# gpurun_out/profile/, copied into profiles/ afterwards).  usage: bash tools/profile_round.sh <tag>
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/profile; rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py"
+
+# 1. the bench line exactly as the driver runs it
+$BENCH > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+tail -1 $OUT/${TAG}_bench.json
+
+# 2. rocprofv3 kernel stats of the same command (shorter K)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --cpu-seconds 0 > $OUT/stats.log 2>&1
+f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && (head -1 "$f"; grep "ph::" "$f") > $OUT/${TAG}_bench_kernel_stats.csv
+
+# 3. HBM traffic: separate --pmc passes, calibrated on a 1 GiB copy (tools/microbench copy16)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_bench_$c -- $BENCH --steps 40 --warmup 5 --cpu-seconds 0 > $OUT/pmc_bench_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_micro_$c -- $ROOT/tools/microbench > $OUT/pmc_micro_$c.log 2>&1
+done
+python3 - "$OUT" "$TAG" <<'PY'
+import csv, glob, json, sys
+out, tag = sys.argv[1], sys.argv[2]
+def mean(dirname, counter, kernel_sub):
+    vals = []
+    for f in glob.glob("%s/%s/**/*counter_collection.csv" % (out, dirname), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]:
+                vals.append(float(r["Counter_Value"]))
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+res = {}
+cal = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    res[c], n = mean("pmc_bench_" + c, c, "fused_v210_combine")
+    res["dispatches"] = n
+    cal[c], _ = mean("pmc_micro_" + c, c, "copy16")
+gib_kb = 1024.0 * 1024.0
+fc = gib_kb / cal["FETCH_SIZE"] if cal["FETCH_SIZE"] else None
+wc = gib_kb / cal["WRITE_SIZE"] if cal["WRITE_SIZE"] else None
+traffic = None
+if fc and wc and res["FETCH_SIZE"] is not None:
+    traffic = int(round((res["FETCH_SIZE"] * fc + res["WRITE_SIZE"] * wc) * 1024))
+doc = {"fused_v210_combine_4_2160p_bytes_per_launch": traffic,
+       "detail": {"FETCH_SIZE_KB_mean": res["FETCH_SIZE"], "WRITE_SIZE_KB_mean": res["WRITE_SIZE"], "dispatches": res["dispatches"],
+                  "calibration": {"kernel": "tools/microbench copy16 (1 GiB read + 1 GiB written per launch)",
+                                  "FETCH_SIZE_KB": cal["FETCH_SIZE"], "WRITE_SIZE_KB": cal["WRITE_SIZE"],
+                                  "fetch_correction": fc, "write_correction": wc},
+                  "algorithmic_bytes": 110592000,
+                  "ratio_traffic_over_algorithmic": traffic / 110592000.0 if traffic else None,
+                  "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 40 --warmup 5 --cpu-seconds 0"}}
+json.dump(doc, open("%s/pmc_traffic.json" % out, "w"), indent=1)
+print("traffic", traffic)
+PY
+
+# 4. SQ counters of the fused kernel
+bash $ROOT/tools/pmc_sq.sh > $OUT/${TAG}_pmc_sq.txt 2>&1
+rm -rf $ROOT/gpurun_out/pmc_sq/*/  # keep the summary only
+
+# 5. per-kernel, per-config, per-instruction and staging measurements
+python $ROOT/tools/kernel_bench.py 2>/dev/null | grep '^{' > $OUT/${TAG}_kernel_bench.jsonl
+python $ROOT/tools/config_bench.py 2>/dev/null | grep '^{' > $OUT/${TAG}_config_bench.jsonl
+$ROOT/tools/opbench2 > $OUT/${TAG}_opbench2.jsonl 2>/dev/null
+python $ROOT/tools/staging_bench.py 60 2>/dev/null | grep '^{' > $OUT/${TAG}_staging_bench.jsonl
+$ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
+rm -rf $OUT/stats $OUT/pmc_bench_* $OUT/pmc_micro_*
+ls -la $OUT
