@@ -9,10 +9,30 @@ from phaneron_amd import capi
 _ctx = None
 
 
+class _TorchOrdered:
+    """The library launches on its OWN streams; torch fills / copies / random generators run on
+    torch's.  Nothing orders the two, so a `torch.zeros` output can be zeroed AFTER the kernel under
+    test wrote it.  Every call made through this proxy first drains the device (the product does not
+    need this: its callers own their ordering, e.g. bench.py synchronises once before timing)."""
+
+    def __init__(self, c):
+        self._c = c
+
+    def __getattr__(self, name):
+        attr = getattr(self._c, name)
+        if not callable(attr):
+            return attr
+
+        def ordered(*args, **kw):
+            torch.cuda.synchronize()
+            return attr(*args, **kw)
+        return ordered
+
+
 def ctx():
     global _ctx
     if _ctx is None:
-        _ctx = capi.Context(0)
+        _ctx = _TorchOrdered(capi.Context(0))
     return _ctx
 
 

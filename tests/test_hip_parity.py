@@ -375,6 +375,33 @@ def test_fused_equals_unfused_kernels_2160p():
     assert torch.equal(fused, top)
 
 
+@pytest.mark.parametrize("w,h,n", [(7680, 4320, 2), (7680, 1082, 3), (48, 1, 3), (96, 3, 4)])
+def test_fused_tile_walk_equals_unfused_kernels(w, h, n):
+    """Sizes that make a workgroup walk several tiles (4320p: 21 600 quads per CU = 3 full tiles of
+    6144 + a partial one), a ragged last tile, and frames smaller than one slice: the fused kernel
+    against the separate HIP kernels (pinned to the oracle elsewhere)."""
+    import torch
+    import hip_harness as hh
+    k = hh.ctx()
+    words = frames.v210_pitch_bytes(w) * h // 4
+    g = torch.Generator(device="cuda").manual_seed(w * 31 + h)
+    layers = [torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device="cuda", generator=g) for _ in range(n)]
+    cm, lut, gm = hh.ColourParams.reader("709", "2020")
+    wcm, wlut = hh.ColourParams.writer("2020")
+    fused = torch.zeros(words, dtype=torch.int32, device="cuda")
+    k.fused_v210_combine(layers, fused, w, h, cm, lut, gm, wcm, wlut)
+    rgba = [torch.empty(w * h * 4, dtype=torch.float32, device="cuda") for _ in range(n)]
+    for l, r in zip(layers, rgba):
+        k.v210_read(l, r, w, h, cm, lut, gm)
+    comb = torch.empty(w * h * 4, dtype=torch.float32, device="cuda")
+    k.combine(rgba, comb, w, h)
+    unfused = torch.zeros_like(fused)
+    k.v210_write(comb, unfused, w, h, 0, wcm, wlut)
+    k.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(fused, unfused)
+
+
 def test_roundtrip_2160p_properties():
     """Full UHD size, size-independent properties:
     (1) the reference's ramp pattern survives read(2020->2020) -> write(2020) byte for byte;
