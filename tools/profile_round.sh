@@ -65,5 +65,6 @@ python $ROOT/tools/config_bench.py 2>/dev/null | grep '^{' > $OUT/${TAG}_config_
 $ROOT/tools/opbench2 > $OUT/${TAG}_opbench2.jsonl 2>/dev/null
 python $ROOT/tools/staging_bench.py 60 2>/dev/null | grep '^{' > $OUT/${TAG}_staging_bench.jsonl
 $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
+(node $ROOT/node/test/bench_node.js 200; node $ROOT/node/test/bench_node.js 300 1920 1080 4) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_bench.jsonl
 rm -rf $OUT/stats $OUT/pmc_bench_* $OUT/pmc_micro_*
 ls -la $OUT
