@@ -56,6 +56,9 @@ const char *ph_last_error(ph_ctx *ctx);
 void *ph_ctx_stream(ph_ctx *ctx, int queue);
 /* `waitFinish(queue)` (clJobQueue.ts:131, io.ts callers): returns when the stream is idle. */
 int ph_wait_finish(ph_ctx *ctx, int queue);
+/* non-blocking: 1 = the queue is idle, 0 = work still in flight, negative = error.  Lets a caller
+ * that expects the work to end within microseconds poll briefly instead of paying a thread hand-off. */
+int ph_queue_query(ph_ctx *ctx, int queue);
 
 /* ---- buffers: `createBuffer(bytes, access, svmType, imageDims?, owner?)` (19 call sites, e.g.
  *      io.ts:61-77,144-150, mixer.ts:196-205, combiner.ts:230-239, yadif.ts:76-86) -------------- */

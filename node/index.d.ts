@@ -54,7 +54,7 @@ export interface PlatformInfo {
 }
 
 export class clContext {
-	constructor(params?: { platformIndex?: number; deviceIndex?: number; overlapping?: boolean; profile?: boolean })
+	constructor(params?: { platformIndex?: number; deviceIndex?: number; overlapping?: boolean; profile?: boolean; spinWaitMicros?: number })
 	readonly queue: { load: number; process: number; unload: number }
 	initialise(): Promise<void>
 	getPlatformInfo(): PlatformInfo

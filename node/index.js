@@ -55,6 +55,9 @@ class clContext {
 		this.deviceIndex = params.deviceIndex || 0
 		this.overlapping = params.overlapping !== false
 		this.profile = !!params.profile // true: runProgram records hipEvents and returns real RunTimings
+		// extension: waitFinish first polls the queue on the JS thread for up to this many microseconds
+		// before handing the wait to the libuv pool (a hand-off costs ~30 us; 0 = always hand off)
+		this.spinWaitMicros = params.spinWaitMicros || 0
 		this.queue = this.overlapping ? { load: 0, process: 1, unload: 2 } : { load: 1, process: 1, unload: 1 }
 		this._ctx = null
 		this._native = null
@@ -116,7 +119,10 @@ class clContext {
 	}
 
 	async waitFinish(queue) {
-		return this._need().waitFinish(this._ctx, queue === undefined ? this.queue.process : queue)
+		const native = this._need()
+		const q = queue === undefined ? this.queue.process : queue
+		if (this.spinWaitMicros > 0 && native.waitFinishSpin(this._ctx, q, this.spinWaitMicros)) return
+		return native.waitFinish(this._ctx, q)
 	}
 
 	// ---- staging extensions (not nodencl; SURVEY 8f-3, node/staging.js) -----------------------------

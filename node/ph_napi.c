@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../include/phaneron_hip.h"
 
@@ -284,6 +285,31 @@ static napi_value WaitFinish(napi_env env, napi_callback_info info) {
   return start_job(env, j, "phaneron.waitFinish");
 }
 
+/* waitFinishSpin(ctx, queue, micros) -> boolean: polls the queue on the calling thread for at most
+ * `micros`; true = it went idle (no thread hand-off needed), false = still busy (use waitFinish). */
+static napi_value WaitFinishSpin(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3], out;
+  ctx_box *c;
+  int32_t q = PH_QUEUE_PROCESS, micros = 0;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&c)) return throw_ph(env, "waitFinishSpin: bad context");
+  if (argc > 1) get_i32(env, argv[1], &q);
+  if (argc > 2) get_i32(env, argv[2], &micros);
+  struct timespec t0, t;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  int idle = 0;
+  for (;;) {
+    idle = ph_queue_query(c->ctx, q);
+    if (idle != 0) break;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    if ((t.tv_sec - t0.tv_sec) * 1000000L + (t.tv_nsec - t0.tv_nsec) / 1000L >= micros) break;
+  }
+  if (idle < 0) return throw_ph(env, "waitFinishSpin");
+  NAPI_OK(napi_get_boolean(env, idle == 1, &out));
+  return out;
+}
+
 /* hostAccess(buf, dir, queue, srcBuffer?) -> Promise<void> */
 static napi_value HostAccess(napi_env env, napi_callback_info info) {
   size_t argc = 4;
@@ -522,7 +548,7 @@ NAPI_MODULE_INIT() {
       {"bufRefCount", BufRefCount}, {"hostAccess", HostAccess},       {"waitFinish", WaitFinish},
       {"createProgram", CreateProgram}, {"runProgram", RunProgram},   {"bufferStats", BufferStats},
       {"queueWaitQueue", QueueWaitQueue}, {"downloadAsync", DownloadAsync}, {"eventRecord", EventRecord},
-      {"eventWait", EventWait},     {"eventDone", EventDone},
+      {"eventWait", EventWait},     {"eventDone", EventDone},       {"waitFinishSpin", WaitFinishSpin},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
     napi_value f;

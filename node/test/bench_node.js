@@ -15,7 +15,8 @@ const { FusedV210Channel } = require('../process/fusedChannel.js')
 async function main() {
 	const frames = parseInt(process.argv[2] || '200', 10)
 	const W = parseInt(process.argv[3] || '3840', 10), H = parseInt(process.argv[4] || '2160', 10), N = parseInt(process.argv[5] || '4', 10)
-	const ctx = new clContext({ platformIndex: 0, deviceIndex: 0, overlapping: true })
+	const spin = parseInt(process.env.PH_SPIN_WAIT_US || '0', 10)
+	const ctx = new clContext({ platformIndex: 0, deviceIndex: 0, overlapping: true, spinWaitMicros: spin })
 	await ctx.initialise()
 	const jobs = new ClProcessJobs(ctx).getJobs()
 	const dims = { width: W, height: H }
@@ -67,7 +68,7 @@ async function main() {
 		const t0 = process.hrtime.bigint()
 		for (let f = 0; f < frames; ++f) await fn(1000 + f)
 		const el = Number(process.hrtime.bigint() - t0) / 1e9
-		console.log(JSON.stringify({ path: name, frames, size: `${W}x${H}`, layers: N, frames_per_sec: +(frames / el).toFixed(1), ms_per_frame: +(1000 * el / frames).toFixed(3) }))
+		console.log(JSON.stringify({ path: name, spinWaitMicros: spin, frames, size: `${W}x${H}`, layers: N, frames_per_sec: +(frames / el).toFixed(1), ms_per_frame: +(1000 * el / frames).toFixed(3) }))
 	}
 	await time(`node: reference-shaped, ${N + 2} job keys per frame (read x${N}, combine, write)`, (f) => shaped(f, true))
 	await time(`node: reference-shaped, one job key per frame (${N + 2} kernels, one waitFinish)`, (f) => shaped(f, false))

@@ -28,7 +28,7 @@ EXPORTS = [
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
     "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option", "ph_compose_write_v210",
     "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
-    "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy",
+    "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy", "ph_queue_query",
 ]
 
 
@@ -86,6 +86,7 @@ def lib():
         "ph_buf_host_ptr": (vp, [vp]),
         "ph_queue_wait_queue": (ci, [vp, ci, ci]),
         "ph_buf_download_async": (ci, [vp, ci]),
+        "ph_queue_query": (ci, [vp, ci]),
         "ph_event_record": (ci, [vp, ci, C.POINTER(vp)]),
         "ph_event_wait": (ci, [vp]),
         "ph_event_query": (ci, [vp]),
@@ -350,6 +351,12 @@ class Context:
         t = RunTimings()
         check(lib().ph_run_program(self.h, program.h, arr, n, queue, C.byref(t)), self.h)
         return {"dataToKernel": t.data_to_kernel, "kernelExec": t.kernel_exec, "totalTime": t.total_time}
+
+    def queue_idle(self, queue=QUEUE_PROCESS):
+        r = lib().ph_queue_query(self.h, queue)
+        if r < 0:
+            check(r, self.h)
+        return bool(r)
 
     def queue_wait_queue(self, waiter, signal):
         check(lib().ph_queue_wait_queue(self.h, waiter, signal), self.h)

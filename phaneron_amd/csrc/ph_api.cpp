@@ -330,6 +330,16 @@ int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t by
   }
 }
 
+int ph_queue_query(ph_ctx *ctx, int queue) {
+  if (!ctx) return fail(PH_E_INVALID, "ph_queue_query: ctx is NULL");
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  hipError_t e = hipStreamQuery(stream_of(ctx, queue));
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  return fail(PH_E_HIP, "ph_queue_query: %s", hipGetErrorString(e));
+}
+
 int ph_queue_wait_queue(ph_ctx *ctx, int waiter_queue, int signal_queue) {
   if (!ctx) return fail(PH_E_INVALID, "ph_queue_wait_queue: ctx is NULL");
   if (waiter_queue < 0 || waiter_queue > 2 || signal_queue < 0 || signal_queue > 2)

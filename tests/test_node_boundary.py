@@ -48,7 +48,7 @@ def test_napi_addon_builds_loads_and_refuses_without_gpu():
     js = ("const a=require('%s');"
           "const want=['abiVersion','createContext','contextInfo','createBuffer','bufAddRef','bufRelease','bufRefCount',"
           "'hostAccess','waitFinish','createProgram','runProgram','bufferStats','queueWaitQueue','downloadAsync',"
-          "'eventRecord','eventWait','eventDone'];"
+          "'eventRecord','eventWait','eventDone','waitFinishSpin'];"
           "for (const k of want) if (typeof a[k] !== 'function') { console.log('missing', k); process.exit(2) }"
           "console.log(a.abiVersion())") % os.path.join(ROOT, "node", "phaneron_napi.node")
     r = subprocess.run([NODE, "-e", js], capture_output=True, text=True)
