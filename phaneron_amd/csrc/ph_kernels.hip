@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void v210_read_kernel(const uint4 *__restri
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
     const size_t p = px0 + s * kWave + lane;
-    if (p < px_end) out[p] = tile[wave][s * kWave + lane];
+    if (p < px_end) store_stream(out + p, tile[wave][s * kWave + lane]);
   }
 }
 
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void v210_write_kernel(const float4 *__rest
       y[j] = write_px_luma(px.x, px.y, px.z, k, lut);
     }
   }
-  out[(size_t)line * quads_per_line_pitch + g] = pack_quad(y, u, v);
+  store_stream(out + (size_t)line * quads_per_line_pitch + g, pack_quad(y, u, v));
 }
 
 // Any width: one lane per quad slot; implements the tail (remain = width % 6 pixels with the
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void v210_write_tail_kernel(const float4 *_
     return;  // no padding quads exist
   }
   // quads past the tail inside the last 48-pixel block are cleared, like the reference
-  out[(size_t)line * quads_per_line_pitch + g] = w;
+  store_stream(out + (size_t)line * quads_per_line_pitch + g, w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void fused_v210_combine_kernel(FusedArgs a)
       y[j] = write_px_luma(acc[j].x, acc[j].y, acc[j].z, wk, a.wr_lut);
     }
   }
-  reinterpret_cast<uint4 *>(a.out)[off] = pack_quad(y, u, v);
+  store_stream(reinterpret_cast<uint4 *>(a.out) + off, pack_quad(y, u, v));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void yadif_kernel(const float4 *__restrict_
   __shared__ float4 rows[2][kBlock + 6];
   const int y = blockIdx.y, x0 = blockIdx.x * kBlock, x = x0 + (int)threadIdx.x;
   if ((y & 1) == parity) {  // keep the primary field (yadifCl.ts:117-121)
-    if (x < w) out[(size_t)y * w + x] = cur[(size_t)y * w + x];
+    if (x < w) store_stream(out + (size_t)y * w + x, cur[(size_t)y * w + x]);
     return;
   }
   const int ym1 = clampi(y - 1, 0, h - 1), yp1 = clampi(y + 1, 0, h - 1);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void yadif_kernel(const float4 *__restrict_
     res[c] = yadif_temporal(PH_C4(A, c), PH_C4(B, c), PH_C4(C, c), PH_C4(D, c), PH_C4(E, c), PH_C4(F, c),
                             PH_C4(G, c), PH_C4(H, c), PH_C4(I, c), PH_C4(J, c), PH_C4(K, c), PH_C4(L, c), sp, skip);
   }
-  out[(size_t)y * w + x] = make_float4(res[0], res[1], res[2], alpha);  // :164 alpha from cur
+  store_stream(out + (size_t)y * w + x, make_float4(res[0], res[1], res[2], alpha));  // :164 alpha from cur
 }
 
 // transform.ts:36-59.  2-D grid; 64x4 blocks keep a wave on one output row.
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void transform_kernel(const float4 *__restr
   const float px = (float)x / (float)ow - 0.5f, py = (float)y / (float)oh - 0.5f;
   const float s = dot3(m[0], m[1], m[2], px, py, 1.0f) + 0.5f;
   const float t = dot3(m[3], m[4], m[5], px, py, 1.0f) + 0.5f;
-  out[(size_t)y * ow + x] = sample_linear(in, iw, ih, s, t);
+  store_stream(out + (size_t)y * ow + x, sample_linear(in, iw, ih, s, t));
 }
 
 // resize.ts:35-59
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void resize_kernel(const float4 *__restrict
   const float ox = fma_rn(cx, flip[1], flip[0]), oy = fma_rn(cy, flip[3], flip[2]);
   const float mx = flip[1] / scale, my = flip[3] / scale;
   const float s = fma_rn((float)x / (float)ow, mx, ox), t = fma_rn((float)y / (float)oh, my, oy);
-  out[(size_t)y * ow + x] = sample_linear(in, iw, ih, s, t);
+  store_stream(out + (size_t)y * ow + x, sample_linear(in, iw, ih, s, t));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineArgs a) {
       acc.z = fma_rn(acc.z, k, t.z);
       acc.w = fma_rn(acc.w, 0.0f, t.w);
     }
-    reinterpret_cast<float4 *>(a.out)[p] = acc;
+    store_stream(reinterpret_cast<float4 *>(a.out) + p, acc);
   }
 }
 
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(kBlock) void dissolve_kernel(const float4 *__restri
   const float rmix = 1.0f - mix;
   for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock) {
     const float4 a = in0[p], b = in1[p];
-    out[p] = make_float4(fma_rn(a.x, mix, b.x * rmix), fma_rn(a.y, mix, b.y * rmix), fma_rn(a.z, mix, b.z * rmix),
-                         fma_rn(a.w, mix, b.w * rmix));
+    store_stream(out + p, make_float4(fma_rn(a.x, mix, b.x * rmix), fma_rn(a.y, mix, b.y * rmix), fma_rn(a.z, mix, b.z * rmix),
+                         fma_rn(a.w, mix, b.w * rmix)));
   }
 }
 
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(kBlock) void twipe_kernel(const float4 *__restrict_
   for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock) {
     const float4 a = in0[p], b = in1[p];
     const float m = mask[p].x, rm = 1.0f - m;
-    out[p] = make_float4(fma_rn(b.x, m, a.x * rm), fma_rn(b.y, m, a.y * rm), fma_rn(b.z, m, a.z * rm),
-                         fma_rn(b.w, m, a.w * rm));
+    store_stream(out + p, make_float4(fma_rn(b.x, m, a.x * rm), fma_rn(b.y, m, a.y * rm), fma_rn(b.z, m, a.z * rm),
+                         fma_rn(b.w, m, a.w * rm)));
   }
 }
 
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void wipe_kernel(const float4 *__restrict__
   const size_t npx = (size_t)w * h;
   for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock) {
     const int x = (int)(p % (size_t)w);
-    out[p] = ((float)x > edge) ? in1[p] : in0[p];
+    store_stream(out + p, ((float)x > edge) ? in1[p] : in0[p]);
   }
 }
 

@@ -75,7 +75,7 @@ __device__ __forceinline__ void fmt_read_body(const FmtReadArgs &a, const LUT &l
       }
       o = yuv_to_rgba(y, u, v, k, lut);
     }
-    a.out[p] = o;
+    store_stream(a.out + p, o);
   }
 }
 

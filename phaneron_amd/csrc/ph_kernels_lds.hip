@@ -204,7 +204,7 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
           yi[2 * i + 1] = __uint_as_float((st[p][i] >> 16) | 0x4B400000u);
         }
         const uint4 packed = write_quad_idx_lds(yi, wk, wlut);
-        if (f < wg_end) reinterpret_cast<uint4 *>(a.f.out)[f] = packed;
+        if (f < wg_end) store_stream(reinterpret_cast<uint4 *>(a.f.out) + f, packed);
       }
       PH_FENCE(1);
     }
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_kernel(const uint4 *_
     const float yf = (float)((wy >> sy) & 0x3ff);
     const float cbf = (float)((wcb >> (10u * pr)) & 0x3ff);
     const float crf = (float)((wcr >> scr) & 0x3ff);
-    out[p] = read_px_lds(yf, cbf, crf, k, lk);
+    store_stream(out + p, read_px_lds(yf, cbf, crf, k, lk));
   }
 }
 
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_write_lds_kernel(const float4 
       const float4 p = px[j];
       rgb[3 * j] = p.x, rgb[3 * j + 1] = p.y, rgb[3 * j + 2] = p.z;
     }
-    out[(size_t)line * quads_per_line + g] = write_quad_lds(rgb, k, lk);
+    store_stream(out + (size_t)line * quads_per_line + g, write_quad_lds(rgb, k, lk));
   }
 }
 
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_kernel(ComposeAr
     float rgb[18];
 #pragma unroll
     for (int j = 0; j < 6; ++j) rgb[3 * j] = acc[4 * j], rgb[3 * j + 1] = acc[4 * j + 1], rgb[3 * j + 2] = acc[4 * j + 2];
-    reinterpret_cast<uint4 *>(a.out)[(size_t)line * qpl + g] = write_quad_lds(rgb, wk, lk);
+    store_stream(reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + g, write_quad_lds(rgb, wk, lk));
   }
 }
 
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_px_kernel(Compos
         for (int j = 0; j < 3; ++j) u[j] = us[lane * 3 + j], v[j] = vs[lane * 3 + j];
         const uint32_t li = first_px / a.out_w, x = first_px - li * a.out_w;
         const uint32_t line = a.first_line + li * a.line_step;
-        reinterpret_cast<uint4 *>(a.out)[(size_t)line * qpl + x / 6] = pack_quad(y, u, v);
+        store_stream(reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + x / 6, pack_quad(y, u, v));
       }
     }
     __builtin_amdgcn_wave_barrier();  // the next step overwrites the staging area
