@@ -5,6 +5,7 @@
 // word quad (16-byte coalesced load/store); the 6 float4 pixels that go with it are moved
 // between "quad order" and "pixel order" through LDS so the f32 side is also accessed as
 // contiguous 1 KiB wave transactions.
+#include <cstdlib>
 #include "ph_device.h"
 #include "ph_kernels.h"
 
@@ -295,6 +296,81 @@ __global__ __launch_bounds__(kBlock) void yadif_kernel(const float4 *__restrict_
   store_stream(out + (size_t)y * w + x, make_float4(res[0], res[1], res[2], alpha));  // :164 alpha from cur
 }
 
+// The same filter walking DOWN a strip of rows with the five-row windows of the three frames in
+// registers.  The row-per-block kernel above re-reads every source row for each output row that
+// uses it (13 loads per interpolated pixel, served by L2: the L2 is the bound, 129 us at 2160p);
+// here every row a strip needs is loaded once - five float4 loads and two stores per PAIR of output
+// rows, less than the "every input once" figure because the field not being rebuilt never needs the
+// even rows of one neighbour frame.  250 of a block's 256 columns produce output, the outer three on
+// each side only feed the spatial predictor's x-3..x+3 taps through LDS (clamped at the image edge).
+#ifndef PH_YADIF_ROWS
+#define PH_YADIF_ROWS 16
+#endif
+constexpr int kYadifRows = PH_YADIF_ROWS, kYadifCols = kBlock - 6;
+__global__ __launch_bounds__(kBlock) void yadif_rows_kernel(const float4 *__restrict__ prev, const float4 *__restrict__ cur,
+                                                            const float4 *__restrict__ next, int w, int h, int parity,
+                                                            int tff, int skip, float4 *__restrict__ out) {
+  __shared__ float4 rows[2][2][kBlock];  // [step parity][row y-1 / row y+1][column]
+  const int lane = threadIdx.x;
+  const int xr = blockIdx.x * kYadifCols - 3 + lane, x = clampi(xr, 0, w - 1);  // CLAMP_TO_EDGE
+  const bool emit = lane >= 3 && lane < kBlock - 3 && xr < w;
+  const int y0 = blockIdx.y * kYadifRows, y_end = (y0 + kYadifRows < h) ? y0 + kYadifRows : h;
+  const int second = !(parity ^ tff);  // yadifCl.ts:143
+  auto row = [&](const float4 *img, int y) { return img[(size_t)clampi(y, 0, h - 1) * w + x]; };
+  // the interpolated row of the first pair: y0 is even, rows with (y & 1) == parity are copied
+  int yi = y0 + (parity == 0 ? 1 : 0);
+  // windows around the interpolated row yi: cur rows yi-2..yi+2; prev / next rows yi-1, yi+1; and the
+  // even rows yi-2, yi, yi+2 of the one neighbour frame the temporal check reads (next for the second
+  // field, prev for the first: yadifCl.ts:146-151).  Plain values, never arrays addressed through a
+  // select - that would move them to scratch.
+  const float4 *other = second ? next : prev;
+  float4 C[5], E[3];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) C[k] = row(cur, yi - 2 + k);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) E[k] = row(other, yi - 2 + 2 * k);
+  float4 P1 = row(prev, yi - 1), P3 = row(prev, yi + 1), N1 = row(next, yi - 1), N3 = row(next, yi + 1);
+  // pairs: (copy yi-1, interpolated yi) when parity == 0, (interpolated yi, copy yi+1) when parity == 1
+  for (int step = 0; (parity == 0 ? yi - 1 : yi) < y_end; ++step, yi += 2) {
+    const int buf = step & 1;
+    rows[buf][0][lane] = C[1], rows[buf][1][lane] = C[3];
+    __syncthreads();  // one barrier per pair: the buffers alternate
+    if (emit) {
+      const int yc = parity == 0 ? yi - 1 : yi + 1;  // the copied row of this pair (yadifCl.ts:117-121)
+      if (yc < h) {
+        float4 cp;
+        cp.x = parity == 0 ? C[1].x : C[3].x, cp.y = parity == 0 ? C[1].y : C[3].y;
+        cp.z = parity == 0 ? C[1].z : C[3].z, cp.w = parity == 0 ? C[1].w : C[3].w;
+        store_stream(out + (size_t)yc * w + xr, cp);
+      }
+      if (yi < h) {
+        float4 ra[7], rb[7];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) ra[t] = rows[buf][0][lane - 3 + t], rb[t] = rows[buf][1][lane - 3 + t];
+        float res[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float sp = yadif_spatial(PH_C4(ra[0], c), PH_C4(ra[1], c), PH_C4(ra[2], c), PH_C4(ra[3], c),
+                                         PH_C4(ra[4], c), PH_C4(ra[5], c), PH_C4(ra[6], c), PH_C4(rb[0], c),
+                                         PH_C4(rb[1], c), PH_C4(rb[2], c), PH_C4(rb[3], c), PH_C4(rb[4], c),
+                                         PH_C4(rb[5], c), PH_C4(rb[6], c));
+          // second field: s0 = cur, s1 = next; first field: s0 = prev, s1 = cur
+          const float c0 = PH_C4(C[0], c), c2 = PH_C4(C[2], c), c4 = PH_C4(C[4], c);
+          const float e0 = PH_C4(E[0], c), e1 = PH_C4(E[1], c), e2 = PH_C4(E[2], c);
+          res[c] = yadif_temporal(PH_C4(P1, c), PH_C4(P3, c), second ? c0 : e0, second ? c2 : e1, second ? c4 : e2,
+                                  PH_C4(C[1], c), PH_C4(C[3], c), second ? e0 : c0, second ? e1 : c2, second ? e2 : c4,
+                                  PH_C4(N1, c), PH_C4(N3, c), sp, skip);
+        }
+        store_stream(out + (size_t)yi * w + xr, make_float4(res[0], res[1], res[2], C[2].w));  // :164 alpha from cur
+      }
+    }
+    // slide the windows down two rows
+    C[0] = C[2], C[1] = C[3], C[2] = C[4], C[3] = row(cur, yi + 3), C[4] = row(cur, yi + 4);
+    E[0] = E[1], E[1] = E[2], E[2] = row(other, yi + 4);
+    P1 = P3, P3 = row(prev, yi + 3), N1 = N3, N3 = row(next, yi + 3);
+  }
+}
+
 // transform.ts:36-59.  2-D grid; 64x4 blocks keep a wave on one output row.
 __global__ __launch_bounds__(kBlock) void transform_kernel(const float4 *__restrict__ in, int iw, int ih,
                                                            const float *__restrict__ m, float4 *__restrict__ out,
@@ -432,9 +508,19 @@ hipError_t launch_fused_v210_combine(hipStream_t s, int n, const FusedArgs &a) {
 
 hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int parity,
                         int tff, int skip, void *out) {
-  dim3 grid(div_up(w, kBlock), h);
-  yadif_kernel<<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, parity,
-                                       tff, skip, (float4 *)out);
+  static const int per_row = [] {
+    const char *e = getenv("PH_YADIF_PER_ROW");  // 1 = the row-per-block kernel (A/B runs)
+    return e ? atoi(e) : 0;
+  }();
+  if (per_row) {
+    dim3 grid(div_up(w, kBlock), h);
+    yadif_kernel<<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, parity,
+                                         tff, skip, (float4 *)out);
+  } else {
+    dim3 grid(div_up(w, kYadifCols), div_up(h, kYadifRows));
+    yadif_rows_kernel<<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h,
+                                              parity, tff, skip, (float4 *)out);
+  }
   return hipGetLastError();
 }
 
