@@ -205,8 +205,8 @@ __global__ __launch_bounds__(kBlock) void fused_v210_combine_kernel(FusedArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// yadif (reference yadifCl.ts:28-167).  grid = (ceil(w/256), h); interpolated rows stage the
-// two neighbouring `cur` rows (x0-3 .. x0+258) in LDS for the 14-tap spatial predictor.
+// yadif (reference yadifCl.ts:28-167).  grid = (ceil(w/250), ceil(h/16)); the two neighbouring `cur`
+// rows of an interpolated row are staged in LDS for the 14-tap spatial predictor.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float yadif_spatial(float a, float b, float c, float d, float e, float f, float g,
                                                float h, float i, float j, float k, float l, float m, float n) {
@@ -254,51 +254,9 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 #define PH_C4(v, c) ((c) == 0 ? (v).x : (c) == 1 ? (v).y : (c) == 2 ? (v).z : (v).w)
 
-__global__ __launch_bounds__(kBlock) void yadif_kernel(const float4 *__restrict__ prev, const float4 *__restrict__ cur,
-                                                       const float4 *__restrict__ next, int w, int h, int parity,
-                                                       int tff, int skip, float4 *__restrict__ out) {
-  __shared__ float4 rows[2][kBlock + 6];
-  const int y = blockIdx.y, x0 = blockIdx.x * kBlock, x = x0 + (int)threadIdx.x;
-  if ((y & 1) == parity) {  // keep the primary field (yadifCl.ts:117-121)
-    if (x < w) store_stream(out + (size_t)y * w + x, cur[(size_t)y * w + x]);
-    return;
-  }
-  const int ym1 = clampi(y - 1, 0, h - 1), yp1 = clampi(y + 1, 0, h - 1);
-  for (int t = threadIdx.x; t < kBlock + 6; t += kBlock) {
-    const int xs = clampi(x0 - 3 + t, 0, w - 1);  // CLAMP_TO_EDGE
-    rows[0][t] = cur[(size_t)ym1 * w + xs];
-    rows[1][t] = cur[(size_t)yp1 * w + xs];
-  }
-  __syncthreads();
-  if (x >= w) return;
-  const int second = !(parity ^ tff);  // yadifCl.ts:143
-  const float4 *s0 = second ? cur : prev, *s1 = second ? next : cur;
-  const int ym2 = clampi(y - 2, 0, h - 1), yp2 = clampi(y + 2, 0, h - 1);
-  const float4 A = prev[(size_t)ym1 * w + x], B = prev[(size_t)yp1 * w + x];
-  const float4 C = s0[(size_t)ym2 * w + x], D = s0[(size_t)y * w + x], E = s0[(size_t)yp2 * w + x];
-  const float4 H = s1[(size_t)ym2 * w + x], I = s1[(size_t)y * w + x], J = s1[(size_t)yp2 * w + x];
-  const float4 K = next[(size_t)ym1 * w + x], L = next[(size_t)yp1 * w + x];
-  const float alpha = cur[(size_t)y * w + x].w;
-  float4 ra[7], rb[7];
-#pragma unroll
-  for (int t = 0; t < 7; ++t) ra[t] = rows[0][threadIdx.x + t], rb[t] = rows[1][threadIdx.x + t];
-  const float4 F = ra[3], G = rb[3];
-  float res[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float sp = yadif_spatial(PH_C4(ra[0], c), PH_C4(ra[1], c), PH_C4(ra[2], c), PH_C4(ra[3], c),
-                                   PH_C4(ra[4], c), PH_C4(ra[5], c), PH_C4(ra[6], c), PH_C4(rb[0], c),
-                                   PH_C4(rb[1], c), PH_C4(rb[2], c), PH_C4(rb[3], c), PH_C4(rb[4], c),
-                                   PH_C4(rb[5], c), PH_C4(rb[6], c));
-    res[c] = yadif_temporal(PH_C4(A, c), PH_C4(B, c), PH_C4(C, c), PH_C4(D, c), PH_C4(E, c), PH_C4(F, c),
-                            PH_C4(G, c), PH_C4(H, c), PH_C4(I, c), PH_C4(J, c), PH_C4(K, c), PH_C4(L, c), sp, skip);
-  }
-  store_stream(out + (size_t)y * w + x, make_float4(res[0], res[1], res[2], alpha));  // :164 alpha from cur
-}
-
-// The same filter walking DOWN a strip of rows with the five-row windows of the three frames in
-// registers.  The row-per-block kernel above re-reads every source row for each output row that
-// uses it (13 loads per interpolated pixel, served by L2: the L2 is the bound, 129 us at 2160p);
+// The filter walks DOWN a strip of rows with the five-row windows of the three frames in registers.
+// A row-per-block mapping re-reads every source row for each output row that uses it (13 loads per
+// interpolated pixel, served by L2: the L2 becomes the bound, 129 us at 2160p against 94 us);
 // here every row a strip needs is loaded once - five float4 loads and two stores per PAIR of output
 // rows, less than the "every input once" figure because the field not being rebuilt never needs the
 // even rows of one neighbour frame.  250 of a block's 256 columns produce output, the outer three on
@@ -508,19 +466,9 @@ hipError_t launch_fused_v210_combine(hipStream_t s, int n, const FusedArgs &a) {
 
 hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int parity,
                         int tff, int skip, void *out) {
-  static const int per_row = [] {
-    const char *e = getenv("PH_YADIF_PER_ROW");  // 1 = the row-per-block kernel (A/B runs)
-    return e ? atoi(e) : 0;
-  }();
-  if (per_row) {
-    dim3 grid(div_up(w, kBlock), h);
-    yadif_kernel<<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, parity,
-                                         tff, skip, (float4 *)out);
-  } else {
-    dim3 grid(div_up(w, kYadifCols), div_up(h, kYadifRows));
-    yadif_rows_kernel<<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h,
-                                              parity, tff, skip, (float4 *)out);
-  }
+  dim3 grid(div_up(w, kYadifCols), div_up(h, kYadifRows));
+  yadif_rows_kernel<<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, parity,
+                                            tff, skip, (float4 *)out);
   return hipGetLastError();
 }
 

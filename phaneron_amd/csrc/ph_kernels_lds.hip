@@ -90,7 +90,6 @@ __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const Wr
       y[j] = c.y, u[j >> 1] = c.u, v[j >> 1] = c.v;
     } else {
       y[j] = write_px_luma_lds(rgb[3 * j], rgb[3 * j + 1], rgb[3 * j + 2], wk, lut);
-      PH_FENCE(2);
     }
   }
   return pack_quad(y, u, v);
@@ -149,20 +148,11 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
           // acc = fma(acc, kk, t) written as the three-operand v_fma_f32 with acc as destination.
           // Left to itself LLVM picks v_fmac (d = a*b + d, so the result lands in t's register) and
           // pays for it with a v_mov per accumulator per layer to get the loop-carried value back.
-    #if PH_COMBINE_ASM
           asm volatile("v_fma_f32 %0, %0, %3, %4\n\tv_fma_f32 %1, %1, %3, %5\n\tv_fma_f32 %2, %2, %3, %6"
                        : "+v"(acc[3 * j]), "+v"(acc[3 * j + 1]), "+v"(acc[3 * j + 2])
                        : "v"(kk), "v"(t.x), "v"(t.y), "v"(t.z));
-    #else
-          acc[3 * j] = fma_rn(acc[3 * j], kk, t.x);
-          acc[3 * j + 1] = fma_rn(acc[3 * j + 1], kk, t.y);
-          acc[3 * j + 2] = fma_rn(acc[3 * j + 2], kk, t.z);
-          asm volatile("" : "+v"(acc[3 * j]), "+v"(acc[3 * j + 1]), "+v"(acc[3 * j + 2]));
-    #endif
-          if (j & 1) PH_FENCE(2);
-        }
+            }
         w = nxt;
-        PH_FENCE(1);
       }
       // the writer's first step (v210.ts:148-150 index = sat_rte(rgb * 65535)) needs no table: do it
       // here and keep only the 16-bit indices, two per register (v_perm_b32)
@@ -206,7 +196,6 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
         const uint4 packed = write_quad_idx_lds(yi, wk, wlut);
         if (f < wg_end) store_stream(reinterpret_cast<uint4 *>(a.f.out) + f, packed);
       }
-      PH_FENCE(1);
     }
     __syncthreads();
   }

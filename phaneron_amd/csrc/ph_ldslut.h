@@ -11,28 +11,12 @@ namespace ph {
 
 constexpr int kLdsBlock = 1024;
 
-// A/B knobs (profiles/): PH_SCHED_LEVEL 0 = no scheduling fences, 1 = one per layer / quad,
-// 2 = one per pixel pair.  PH_TABLE_DMA 1 = table swaps by global_load_lds (LDS-DMA, no VGPRs).
-#ifndef PH_SCHED_LEVEL
-#define PH_SCHED_LEVEL 0
-#endif
-#ifndef PH_TABLE_DMA
-#define PH_TABLE_DMA 1
-#endif
-// PH_LDS_ABS 1 = absolute LDS addresses (no per-read base add); PH_COMBINE_ASM 1 = in-place v_fma_f32
-#ifndef PH_LDS_ABS
-#define PH_LDS_ABS 1
-#endif
-#ifndef PH_COMBINE_ASM
-#define PH_COMBINE_ASM 1
-#endif
+// PH_ABLATE builds timing experiments of the fused kernel (WRONG results, never shipped): bit 0 = no
+// LDS reads, bit 1 = no table loads, bit 2 = anchor read only, bit 3 = both reads but conflict-free.
+// DESIGN.md section 4 quotes what they measured.
 #ifndef PH_ABLATE
 #define PH_ABLATE 0
 #endif
-#define PH_FENCE(level)                                         \
-  do {                                                          \
-    if (PH_SCHED_LEVEL >= (level)) __builtin_amdgcn_sched_barrier(0); \
-  } while (0)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
@@ -43,7 +27,6 @@ __device__ __forceinline__ void lds_lut_load(const LutView &v) {
   return;
 #endif
   const uint32_t n = v.bytes / 16;
-#if PH_TABLE_DMA
   // LDS-DMA: each wave instruction moves 1 KiB global -> LDS (wave-uniform LDS base + lane*16)
   // without touching VGPRs; all of a wave's pieces are in flight before the single wait.
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -55,11 +38,6 @@ __device__ __forceinline__ void lds_lut_load(const LutView &v) {
                                        (__attribute__((address_space(3))) void *)(g_lds + 16 * base), 16, 0, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-  const uint4 *src = reinterpret_cast<const uint4 *>(v.blob);
-  uint4 *dst = reinterpret_cast<uint4 *>(g_lds);
-  for (uint32_t i = threadIdx.x; i < n; i += BS) dst[i] = src[i];
-#endif
 }
 
 // table[clamp(rint(x), 0, 65535)] for x = (gamma- or linear-domain value) * 65535, see ph_lut.h:
@@ -84,11 +62,7 @@ struct LutK {
 typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
 typedef const __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
 __device__ __forceinline__ LutK make_lut_k(const LutView &v) {
-#if PH_LDS_ABS
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)g_lds;
-#else
-  const uint32_t lds0 = 0;
-#endif
   // d_addr = 2*(idx + bias) + base + lds0 = bits(fma(M + idx, 2^-148, B)) with
   // B = (base + lds0 + 2*bias) * 2^-149 - M * 2^-148.  Every term is a multiple of 2^-148 below 2^24
   // of them (base, lds0 are even), so each float operation here is exact.
@@ -108,12 +82,9 @@ __device__ __forceinline__ float lds_lut_fetch(const LutK &k, float y) {
   const uint32_t a = a_addr, d = d_addr;
 #elif PH_ABLATE & 4  // timing experiment only: anchor read only
   const uint32_t a = *(lds_u32_ptr)a_addr, d = d_addr;
-#elif PH_LDS_ABS
+#else
   const uint32_t a = *(lds_u32_ptr)a_addr;
   const uint32_t d = *(lds_u16_ptr)d_addr;
-#else
-  const uint32_t a = *reinterpret_cast<const uint32_t *>(g_lds + a_addr);
-  const uint32_t d = *reinterpret_cast<const uint16_t *>(g_lds + d_addr);
 #endif
   return __uint_as_float(a + d);
 }
