@@ -74,12 +74,14 @@ def cpu_baseline(args, budget_s):
     cores = orc.effective_cpus()  # cgroup quota, not the 256 logical CPUs the box reports
     if orc.have_ref_fast():
         r = orc.ref_fast()
-        r.ref_set_num_threads(cores)
+        set_threads = r.ref_set_num_threads
+        set_threads(cores)
         kind, what = "reference", "the reference's OpenCL kernels compiled for x86 (oracle/_ref, -O3 -mavx2 -mfma; " \
                                   "read x%d, combine_%d, write as separate passes; work groups over %d threads)" % (n, n, cores)
         run = lambda: orc.ref_pipeline_v210_combine(r, layers, w, h, *rd, *wr, scratch=scratch)
     else:
-        orc.set_num_threads(cores)
+        set_threads = orc.set_num_threads
+        set_threads(cores)
         kind, what = "port", "oracle/ restatement (OpenMP over lines, %d threads)" % cores
         run = lambda: orc.pipeline_v210_combine(layers, w, h, *rd, *wr, scratch=scratch)
     run()  # warm-up (page faults)
@@ -91,8 +93,16 @@ def cpu_baseline(args, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s or frames_done >= 200:
             break
+    # the same code on ONE host thread (SURVEY 8d asks for both): two frames
+    set_threads(1)
+    t1 = time.perf_counter()
+    run(), run()
+    one = 2.0 / (time.perf_counter() - t1)
+    set_threads(cores)
     return {"value": round(frames_done / el, 3), "unit": "frames/sec", "cores": cores, "kind": kind,
-            "sample": "%d whole %dx%d %d-layer frames in %.1f s through %s" % (frames_done, w, h, n, el, what)}
+            "one_core_value": round(one, 3),
+            "sample": "%d whole %dx%d %d-layer frames in %.1f s through %s; one_core_value = 2 more frames on 1 thread"
+                      % (frames_done, w, h, n, el, what)}
 
 
 def recorded_traffic():
