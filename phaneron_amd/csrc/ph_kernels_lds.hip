@@ -151,7 +151,7 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
           asm volatile("v_fma_f32 %0, %0, %3, %4\n\tv_fma_f32 %1, %1, %3, %5\n\tv_fma_f32 %2, %2, %3, %6"
                        : "+v"(acc[3 * j]), "+v"(acc[3 * j + 1]), "+v"(acc[3 * j + 2])
                        : "v"(kk), "v"(t.x), "v"(t.y), "v"(t.z));
-            }
+        }
         w = nxt;
       }
       // the writer's first step (v210.ts:148-150 index = sat_rte(rgb * 65535)) needs no table: do it
