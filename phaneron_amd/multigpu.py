@@ -65,11 +65,14 @@ class RouteExchange:
     Receive buffers are allocated once (a frame is 132 710 400 B at 2160p f32 RGBA)."""
 
     def __init__(self, routes: Sequence[Route], rank: int, world: int, frame_numel: int, dtype, device,
-                 channels_per_rank: int = 0):
+                 channels_per_rank: int = 0, via_host: bool = False):
+        """via_host: stage every message through host memory (for process groups that cannot move
+        device tensors, i.e. gloo with frames on a GPU: functional tests on one GPU)."""
         import torch
         self.plan = plan_routes(routes, rank, world, channels_per_rank)
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.via_host = rank, world, via_host
         self.recv_bufs = {rt: torch.empty(frame_numel, dtype=dtype, device=device) for rt, _ in self.plan.recvs}
+        self.host_bufs = {rt: torch.empty(frame_numel, dtype=dtype) for rt, _ in self.plan.recvs} if via_host else {}
         self.bytes_per_frame = frame_numel * torch.empty((), dtype=dtype).element_size()
 
     def exchange(self, frames: Dict[int, "object"]) -> Dict[int, "object"]:
@@ -79,13 +82,15 @@ class RouteExchange:
             out[rt.dst] = frames[rt.src]  # same device: share the buffer (reference: addRef per fork)
         ops = []
         for rt, peer in self.plan.sends:
-            ops.append(dist.P2POp(dist.isend, frames[rt.src], peer))
+            ops.append(dist.P2POp(dist.isend, frames[rt.src].cpu() if self.via_host else frames[rt.src], peer))
         for rt, peer in self.plan.recvs:
-            ops.append(dist.P2POp(dist.irecv, self.recv_bufs[rt], peer))
+            ops.append(dist.P2POp(dist.irecv, self.host_bufs[rt] if self.via_host else self.recv_bufs[rt], peer))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         for rt, _ in self.plan.recvs:
+            if self.via_host:
+                self.recv_bufs[rt].copy_(self.host_bufs[rt])
             out[rt.dst] = self.recv_bufs[rt]
         return out
 

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: C channels per GPU, every channel's fourth layer is the ROUTE of another
+channel's combiner output (f32 RGBA, 132.7 MB at 2160p) - channel k shows channel (k + total/2) mod
+total, so with more than one rank every route crosses GPUs (routeProducer.ts:63-126; RCCL send/recv
+over xGMI, phaneron_amd/multigpu.py).  Per channel and frame: v210 read x3 -> combine_4 with the routed
+frame of the PREVIOUS step (a route is one frame late in the reference too) -> v210 write.
+
+  python tools/route_bench.py                                       # one GPU: both routes are local aliases
+  torchrun --nproc-per-node 8 tools/route_bench.py                  # 16 channels on 8 GPUs
+  torchrun --nproc-per-node 2 tools/route_bench.py --backend gloo --same-gpu --check   # functional test on one GPU
+
+Prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--channels-per-gpu", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--same-gpu", action="store_true", help="every rank uses cuda:0 (functional test)")
+    ap.add_argument("--check", action="store_true", help="verify that a routed layer is the source channel's output")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from phaneron_amd import capi, multigpu
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend, **({"device_id": device} if args.backend == "nccl" else {}))
+    w, h, C = args.width, args.height, args.channels_per_gpu
+    total = world * C
+    mine = multigpu.channels_of_rank(rank, total, world, C)
+    routes = [multigpu.Route(src=(k + total // 2) % total, dst=k) for k in range(total)]
+    ctx = capi.Context(local)
+    words, npx = capi.v210_pitch_bytes(w) * h // 4, w * h
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+    rd = [dev(capi.ycbcr2rgb_matrix("709")), dev(capi.gamma2linear_lut("709")),
+          dev(np.concatenate([capi.rgb2rgb_matrix("709", "2020"), np.zeros(3, np.float32)]))]
+    wr = [dev(capi.rgb2ycbcr_matrix("2020")), dev(capi.linear2gamma_lut("2020"))]
+    torch.cuda.synchronize()
+    ctx.register_lut(rd[1], capi.gamma2linear_lut("709"))
+    ctx.register_lut(wr[1], capi.linear2gamma_lut("2020"))
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    chan = {}
+    for ch in mine:
+        chan[ch] = dict(
+            layers=[torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device=device, generator=g) for _ in range(3)],
+            rgba=[torch.empty(npx * 4, dtype=torch.float32, device=device) for _ in range(3)],
+            out=[torch.zeros(npx * 4, dtype=torch.float32, device=device) for _ in range(2)],  # [previous, current]
+            v210=torch.empty(words, dtype=torch.int32, device=device))
+        chan[ch]["out"][0][3::4] = 1.0  # frame -1 of every channel: opaque black
+    ex = multigpu.RouteExchange(routes, rank, world, npx * 4, torch.float32, device, C, via_host=(args.backend == "gloo"))
+    torch.cuda.synchronize()
+    exch_s = [0.0]
+
+    def step(i):
+        ctx.wait()                                   # previous outputs are complete before they travel
+        t0 = time.perf_counter()
+        routed = ex.exchange({ch: chan[ch]["out"][0] for ch in mine})
+        torch.cuda.synchronize()                     # RCCL runs on torch's stream, the kernels on the library's
+        exch_s[0] += time.perf_counter() - t0
+        for ch in mine:
+            c = chan[ch]
+            for l in range(3):
+                ctx.v210_read(c["layers"][l], c["rgba"][l], w, h, *rd)
+            ctx.combine(c["rgba"] + [routed[ch]], c["out"][1], w, h)
+            ctx.v210_write(c["out"][1], c["v210"], w, h, 0, *wr)
+        ctx.wait()
+        for ch in mine:
+            chan[ch]["out"].reverse()
+
+    def sync():
+        ctx.wait()
+        torch.cuda.synchronize()
+
+    if args.check:  # two steps by hand: what arrives as channel k's routed layer is channel src(k)'s output
+        step(0)
+        sums = torch.zeros(total, dtype=torch.float64, device=device)
+        for ch in mine:
+            sums[ch] = chan[ch]["out"][0].double().sum()
+        if dist is not None:
+            cpu = sums.cpu()
+            dist.all_reduce(cpu)
+            sums = cpu.to(device)
+        ctx.wait()
+        routed = ex.exchange({ch: chan[ch]["out"][0] for ch in mine})
+        torch.cuda.synchronize()
+        for ch in mine:
+            src = (ch + total // 2) % total
+            got = float(routed[ch].double().sum())
+            assert abs(got - float(sums[src])) <= 1e-6 * max(1.0, abs(got)), (ch, src, got, float(sums[src]))
+        if rank == 0:
+            print("route check ok: %d channels on %d rank(s)" % (total, world), flush=True)
+    exch_s[0] = 0.0
+    elapsed = multigpu.timed_steps(step, args.steps, args.warmup, sync, dist, device if args.backend == "nccl" else None)
+    if rank == 0:
+        fps = total * args.steps / elapsed
+        per_step_exch = exch_s[0] / (args.steps + args.warmup)
+        print(json.dumps({
+            "workload": "config 5: %d channels of %dx%d on %d GPU(s), 3 v210 layers + 1 routed RGBA layer each" % (total, w, h, world),
+            "frames_per_sec": round(fps, 1), "steps": args.steps, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "routes_crossing_ranks_per_rank": len(ex.plan.sends), "route_bytes_per_rank_per_step": ex.traffic_bytes(),
+            "exchange_ms_per_step_rank0": round(1e3 * per_step_exch, 3),
+            "exchange_GBps_rank0": round(ex.traffic_bytes() / per_step_exch / 1e9, 1) if per_step_exch > 0 and ex.traffic_bytes() else None,
+            "backend": args.backend if world > 1 else "none (single rank: routes alias local buffers)"}), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
