@@ -69,7 +69,55 @@ async function main() {
 	})
 	const liveOwners = ctx.trace.filter((e) => e.op === 'createBuffer' && ctx.live.has(e.buf)).map((e) => ({ buf: e.buf, owner: e.owner, refs: ctx.live.get(e.buf)._refs }))
 	const leakedFrames = made.filter((id) => ctx.live.has(id))
-	process.stdout.write(JSON.stringify({ outputs, kernels, layerEvents, liveOwners, leakedFrames, sourceFrames: made }))
+	const second = await endAndWipe()
+	process.stdout.write(JSON.stringify({ outputs, kernels, layerEvents, liveOwners, leakedFrames, sourceFrames: made, second }))
+}
+
+// Second graph: a source that ENDS after three frames (its layer falls back to the transitioner's black
+// frame, transitioner.ts:186-192), a wipe transition with a mask source (:168-170), and a combiner with
+// one route fork (every output carries one reference per fork, combiner.ts:255).
+async function endAndWipe() {
+	const ctx = makeMock()
+	const jobs = new ClProcessJobs(ctx).getJobs()
+	const fmt = { width: 32, height: 18 }
+	const made = []
+	const source = (name, n, ts0) => {
+		let i = 0
+		return redio(async () => {
+			if (i >= n) return end
+			const b = await ctx.createBuffer(fmt.width * fmt.height * 16, 'readwrite', 'coarse', fmt, `${name} ${i}`)
+			b.timestamp = ts0 + i++
+			made.push(b._mockId)
+			return b
+		})
+	}
+	const mix = async (id, pipe) => {
+		const m = new Mixer(ctx, fmt, jobs)
+		await m.init(id, pipe)
+		return m.getMixVideo()
+	}
+	const short = new Transitioner(ctx, 'S', fmt, jobs)
+	await short.initialise()
+	short.update('cut', 0, [await mix('S src', source('S', 3, 10))])
+	const wiper = new Transitioner(ctx, 'W', fmt, jobs)
+	await wiper.initialise()
+	wiper.update('wipe', 6, [await mix('W a', source('Wa', 6, 20)), await mix('W b', source('Wb', 6, 30)), await mix('W mask', source('Wm', 6, 40))])
+	const comb = new Combiner(ctx, 'chan2', fmt, jobs)
+	await comb.initialise()
+	comb.updateLayers([new CombineLayer(short.getVideoPipe()), new CombineLayer(wiper.getVideoPipe())])
+	const tap = comb.getSourcePipes() // one fork = the only reader here
+	const outputs = []
+	for (let f = 0; f < 6; ++f) {
+		const frame = await tap.video.next()
+		if (!isValue(frame)) { outputs.push({ frame: f, ended: true }); break }
+		outputs.push({ frame: f, ts: frame.timestamp, refs: frame._refs })
+		frame.release()
+	}
+	tap.release()
+	const kernels = ctx.trace.filter((e) => e.op === 'runProgram').map((e) => ({ name: e.name, inputs: Object.keys(e.params).filter((k) => /^(input\d?|l\dIn|maskIn)$/.test(k)).sort() }))
+	const blackId = ctx.trace.find((e) => e.op === 'createBuffer' && e.owner === 'black-S transition').buf
+	const combineFirstInputs = ctx.trace.filter((e) => e.op === 'runProgram' && e.name === 'combine_2').map((e) => e.params.l0In.buf)
+	return { outputs, kernels, blackId, combineFirstInputs, leakedFrames: made.filter((id) => ctx.live.has(id)), forksAfterRelease: comb.numForks }
 }
 
 main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })

@@ -169,6 +169,17 @@ def test_valve_graph_host_logic_on_mock():
     assert d["leakedFrames"] == []
     assert sorted(o["owner"].split("-")[0] for o in d["liveOwners"]) == ["black"] * 4 + ["transformMatrix"] * 3
 
+    # second graph: a source that ends, a wipe with a mask source, one route fork
+    e = d["second"]
+    assert [(o["ts"], o["refs"]) for o in e["outputs"]] == [(i, 1) for i in range(6)]   # one fork: one reference
+    names = [k["name"] for k in e["kernels"]]
+    assert names.count("transition_wipe") == 6 and names.count("combine_2") == 6
+    assert all(k["inputs"] == ["input0", "input1", "maskIn"] for k in e["kernels"] if k["name"] == "transition_wipe")
+    # the ended layer keeps its place in the composite as the transitioner's black frame (transitioner.ts:186-192)
+    assert e["combineFirstInputs"][3:] == [e["blackId"]] * 3 and e["blackId"] not in e["combineFirstInputs"][:3]
+    assert names.count("transform") == 3 * 4 + 3 * 3          # the ended source is no longer transformed
+    assert e["leakedFrames"] == [] and e["forksAfterRelease"] == 0
+
 
 def mixer_matrix(w, h, p):
     """Mixer.mixVidValve's parameter mapping (mixer.ts:209-223) into the Transform matrix"""
