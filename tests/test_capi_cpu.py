@@ -83,3 +83,41 @@ def test_product_never_imports_oracle():
             continue  # node/test/ is test infrastructure (it drives the checker on purpose)
         if os.path.isfile(path) and path.endswith((".py", ".cpp", ".hip", ".h", ".js", ".c")):
             assert "oracle" not in open(path).read().replace("no oracle", ""), path
+
+
+def test_argument_validation_needs_no_device():
+    """Every typed entry point rejects NULL / zero / out-of-range arguments before it touches the device,
+    with a message that names the problem (no compute call is made here: there is no GPU)."""
+    import ctypes as C
+    l = capi.lib()
+    one = C.c_void_p(16)  # a non-NULL pointer that is never dereferenced on these paths
+    arr3 = (C.c_void_p * 3)(16, 16, 16)
+    cases = [
+        (lambda: l.ph_v210_read(None, 1, None, one, 1920, 1080, one, one, one), "ph_v210_read"),
+        (lambda: l.ph_v210_write(None, 1, one, one, 1920, 1080, 2, one, one), "interlace must be 0, 1 or 3"),
+        (lambda: l.ph_fused_v210_combine(None, 1, 9, arr3, one, 1920, 1080, one, one, one, one, one), "1..8 layers"),
+        (lambda: l.ph_fused_v210_combine(None, 1, 3, arr3, one, 1280, 720, one, one, one, one, one), "multiple of 48"),
+        (lambda: l.ph_combine(None, 1, 1, arr3, 64, 64, one), "between 2 and 8"),
+        (lambda: l.ph_yadif(None, 1, None, one, one, 64, 64, 0, 1, 0, one), "ph_yadif"),
+        (lambda: l.ph_transform(None, 1, one, 0, 64, one, one, 64, 64), "ph_transform"),
+        (lambda: l.ph_pack_read(None, 1, 99, arr3, one, 64, 64, one, one, one), "ph_pack_read"),
+        (lambda: l.ph_queue_wait_queue(None, 0, 1), "ctx is NULL"),
+        (lambda: l.ph_buf_host_access(None, 0, 0, None, 0), "NULL buffer"),
+        (lambda: l.ph_ctx_set_option(None, b"lds_lut", 1), "NULL"),
+    ]
+    for call, needle in cases:
+        rc = call()
+        assert rc < 0, needle
+        assert needle in l.ph_last_error(None).decode(), (needle, l.ph_last_error(None))
+    # zero-height frames are a no-op, not an error (an empty field)
+    assert l.ph_v210_read(None, 1, one, one, 1920, 0, one, one, one) == 0
+    assert l.ph_fused_v210_combine(None, 1, 2, arr3, one, 1920, 0, one, one, one, one, one) == 0
+
+
+def test_pack_geometry():
+    want = {"yuv422p10": [1920 * 2 * 1080, 1920 * 1080, 1920 * 1080], "yuv422p8": [1920 * 1080, 960 * 1080, 960 * 1080],
+            "yuv420p": [1920 * 1080, 960 * 540, 960 * 540], "nv12": [1920 * 1080, 1920 * 540], "rgba8": [1920 * 4 * 1080],
+            "bgra8": [1920 * 4 * 1080], "v210": [5120 * 1080]}
+    for fmt, sizes in want.items():
+        assert capi.pack_plane_bytes(fmt, 1920, 1080) == sizes, fmt
+    assert capi.pack_plane_bytes("yuv422p8", 718, 480) == [720 * 480, 360 * 480, 360 * 480]  # pitch rounds up to 8
