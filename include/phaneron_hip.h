@@ -105,6 +105,20 @@ int ph_event_record(ph_ctx *ctx, int queue, ph_event **out);
 int ph_event_wait(ph_event *ev);
 int ph_event_query(ph_event *ev); /* 1 = finished, 0 = still running, negative = error */
 int ph_event_destroy(ph_event *ev);
+/* Recorded batches.  The reference submits a channel's per-frame batch (read x N, transform x N, wipe,
+ * combine, write: 13 kernels at config 2) one `runProgram` at a time; at 1080p those kernels run for
+ * 5-15 us each and the gaps between launches are a fifth of the frame.  A caller whose batch touches
+ * the same buffers every frame (ring slots) can record it once and replay it as ONE submission:
+ *   ph_graph_begin(ctx, queue)  - every launch issued on `queue` from this thread is recorded, not run
+ *                                 (hipStreamBeginCapture); no waitFinish / hostAccess('readonly') inside
+ *   ph_graph_end(ctx, queue, &g) - stop recording, build the executable graph
+ *   ph_graph_launch(g, queue)   - replay on `queue` (asynchronous, ordered like any other launch)
+ * Scalars and pointers are frozen at recording time. */
+typedef struct ph_graph ph_graph;
+int ph_graph_begin(ph_ctx *ctx, int queue);
+int ph_graph_end(ph_ctx *ctx, int queue, ph_graph **out);
+int ph_graph_launch(ph_graph *graph, int queue);
+int ph_graph_destroy(ph_graph *graph);
 /* the `logBuffers()` debug hook (src/index.ts:184): live buffers / pooled bytes */
 int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes);
 

@@ -29,6 +29,7 @@ EXPORTS = [
     "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option", "ph_compose_write_v210",
     "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
     "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy", "ph_queue_query",
+    "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy",
 ]
 
 
@@ -87,6 +88,10 @@ def lib():
         "ph_queue_wait_queue": (ci, [vp, ci, ci]),
         "ph_buf_download_async": (ci, [vp, ci]),
         "ph_queue_query": (ci, [vp, ci]),
+        "ph_graph_begin": (ci, [vp, ci]),
+        "ph_graph_end": (ci, [vp, ci, C.POINTER(vp)]),
+        "ph_graph_launch": (ci, [vp, ci]),
+        "ph_graph_destroy": (ci, [vp]),
         "ph_event_record": (ci, [vp, ci, C.POINTER(vp)]),
         "ph_event_wait": (ci, [vp]),
         "ph_event_query": (ci, [vp]),
@@ -352,6 +357,17 @@ class Context:
         check(lib().ph_run_program(self.h, program.h, arr, n, queue, C.byref(t)), self.h)
         return {"dataToKernel": t.data_to_kernel, "kernelExec": t.kernel_exec, "totalTime": t.total_time}
 
+    def record(self, fn, queue=QUEUE_PROCESS):
+        """Record the launches `fn()` issues on `queue` into a replayable Graph (ph_graph_*)."""
+        check(lib().ph_graph_begin(self.h, queue), self.h)
+        try:
+            fn()
+        finally:
+            g = C.c_void_p()
+            rc = lib().ph_graph_end(self.h, queue, C.byref(g))
+        check(rc, self.h)
+        return Graph(self, g)
+
     def queue_idle(self, queue=QUEUE_PROCESS):
         r = lib().ph_queue_query(self.h, queue)
         if r < 0:
@@ -438,6 +454,21 @@ class Event:
     def destroy(self):
         if self.h:
             lib().ph_event_destroy(self.h)
+            self.h = None
+
+
+class Graph:
+    """A recorded batch of launches: launch() replays it as one submission."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def launch(self, queue=QUEUE_PROCESS):
+        check(lib().ph_graph_launch(self.h, queue), self.ctx.h)
+
+    def destroy(self):
+        if self.h:
+            lib().ph_graph_destroy(self.h)
             self.h = None
 
 

@@ -408,6 +408,54 @@ int ph_event_destroy(ph_event *ev) {
   return PH_OK;
 }
 
+struct ph_graph {
+  ph_ctx *ctx;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+int ph_graph_begin(ph_ctx *ctx, int queue) {
+  if (!ctx) return fail(PH_E_INVALID, "ph_graph_begin: ctx is NULL");
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  // relaxed: other threads (the libuv pool of the node addon) may keep calling into HIP meanwhile
+  PH_HIP(hipStreamBeginCapture(stream_of(ctx, queue), hipStreamCaptureModeRelaxed));
+  return PH_OK;
+}
+
+int ph_graph_end(ph_ctx *ctx, int queue, ph_graph **out) {
+  if (!ctx || !out) return fail(PH_E_INVALID, "ph_graph_end: NULL argument");
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  hipGraph_t g = nullptr;
+  PH_HIP(hipStreamEndCapture(stream_of(ctx, queue), &g));
+  if (!g) return fail(PH_E_HIP, "ph_graph_end: nothing was recorded");
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    hipGraphDestroy(g);
+    return fail(PH_E_HIP, "ph_graph_end: hipGraphInstantiate: %s", hipGetErrorString(e));
+  }
+  *out = new ph_graph{ctx, g, exec};
+  return PH_OK;
+}
+
+int ph_graph_launch(ph_graph *g, int queue) {
+  if (!g) return fail(PH_E_INVALID, "ph_graph_launch: NULL graph");
+  int rc = set_device(g->ctx);
+  if (rc) return rc;
+  PH_HIP(hipGraphLaunch(g->exec, stream_of(g->ctx, queue)));
+  return PH_OK;
+}
+
+int ph_graph_destroy(ph_graph *g) {
+  if (!g) return PH_OK;
+  hipGraphExecDestroy(g->exec);
+  hipGraphDestroy(g->graph);
+  delete g;
+  return PH_OK;
+}
+
 int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes) {
   if (!ctx) return fail(PH_E_INVALID, "ph_ctx_buffer_stats: ctx is NULL");
   if (live_buffers) *live_buffers = ctx->live_buffers;

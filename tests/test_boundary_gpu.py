@@ -197,3 +197,43 @@ def test_staged_channel_ring_reuse(ctx, depth):
         assert np.array_equal(got[f], want), f
     chan.close()
     col.release()
+
+
+def test_recorded_batch_replays_with_new_contents(ctx):
+    """ph_graph_*: the reference-shaped batch read x2 -> combine_2 -> write recorded once and replayed on
+    the same buffers with new frame contents each time equals the oracle chain for those contents."""
+    w, h = 1920, 16
+    col = Colour(ctx, "709", "2020")
+    vbytes = frames.v210_pitch_bytes(w) * h
+    srcs = [ctx.create_buffer(vbytes, "readonly", "coarse") for _ in range(2)]
+    rgba = [ctx.create_buffer(w * h * 16, dims=(w, h)) for _ in range(2)]
+    comb = ctx.create_buffer(w * h * 16, dims=(w, h))
+    out = ctx.create_buffer(vbytes, "writeonly")
+    for b in srcs:  # something to read while recording (a capture launches nothing)
+        b.host_access("writeonly", capi.QUEUE_LOAD, np.zeros(vbytes, np.uint8))
+    ctx.wait(capi.QUEUE_LOAD)
+    ctx.register_lut(col.rd_lut.device_ptr(), capi.gamma2linear_lut("709"))
+    ctx.register_lut(col.wr_lut.device_ptr(), capi.linear2gamma_lut("2020"))
+
+    def batch():
+        for s, r in zip(srcs, rgba):
+            ctx.v210_read(s.device_ptr(), r.device_ptr(), w, h, col.rd_cm.device_ptr(), col.rd_lut.device_ptr(),
+                          col.rd_gm.device_ptr())
+        ctx.combine([r.device_ptr() for r in rgba], comb.device_ptr(), w, h)
+        ctx.v210_write(comb.device_ptr(), out.device_ptr(), w, h, 0, col.wr_cm.device_ptr(), col.wr_lut.device_ptr())
+
+    graph = ctx.record(batch)
+    for f in range(3):
+        layers = [frames.v210_random(w, h, frames.layer_seed(20 + f, i)) for i in range(2)]
+        for b, l in zip(srcs, layers):
+            b.host_access("writeonly", capi.QUEUE_LOAD, l)
+        ctx.wait(capi.QUEUE_LOAD)
+        graph.launch()
+        ctx.wait()
+        out.host_access("readonly", capi.QUEUE_UNLOAD)
+        want = orc.pipeline_v210_combine(layers, w, h, *col.oracle_rd, *col.oracle_wr)
+        assert np.array_equal(out.host(np.uint32), want), f
+    graph.destroy()
+    for b in srcs + rgba + [comb, out]:
+        b.release()
+    col.release()
