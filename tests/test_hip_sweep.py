@@ -144,3 +144,49 @@ def test_pack_formats_random_sizes(fmt):
             want = orc.pack_write(fmt, rgba, w, h, il, owcm, orc.linear2gamma_lut("2020"), planes=[d.copy() for d in dst])
             for i, (gp, wp) in enumerate(zip(dplanes, want)):
                 bits_eq(hh.host(gp), wp, "%s write %dx%d il%d plane %d" % (fmt, w, h, il, i))
+
+
+def test_special_float_values_in_write_paths():
+    """NaN, +-Inf, -0, denormals and huge values in the float RGBA input of the writers: the reference's
+    convert_ushort_sat_rte sends NaN to 0 and saturates the rest; the packed outputs must match the
+    oracle exactly.  (Float outputs are compared with NaN == NaN: payload bits are not specified.)"""
+    import torch
+    import hip_harness as hh
+    w, h = 96, 4
+    rgba = frames.rgba_random(w, h, 4711, -0.2, 1.2)
+    flat = rgba.reshape(-1)
+    specials = np.array([np.nan, np.inf, -np.inf, -0.0, 1e-42, -1e-42, 3.0e38, -3.0e38, 1.0, 0.0, 0.5 / 65535, 1.5 / 65535,
+                         2.5 / 65535, 65534.5 / 65535], np.float32)
+    idx = np.random.default_rng(5).choice(flat.size, size=600, replace=False)
+    flat[idx] = specials[np.arange(600) % specials.size]
+    for il in (0, 1, 3):
+        dst = np.full(frames.v210_pitch_bytes(w) * h // 4, cases.POISON, np.uint32)
+        wcm, wlut = hh.ColourParams.writer("709")
+        o = hh.dev(dst)
+        hh.ctx().v210_write(hh.dev(rgba), o, w, h, il, wcm, wlut)
+        bits_eq(hh.host(o, np.uint32), orc.v210_write(rgba, w, h, il, orc.rgb2ycbcr_matrix("709"), orc.linear2gamma_lut("709"),
+                                                       out=dst.copy()), "v210_write specials il%d" % il)
+    for fmt in ("yuv422p10", "nv12", "rgba8"):
+        rng = orc.FORMAT_RANGE[fmt]
+        wcm, wlut = hh.ColourParams.fmt_writer(fmt, "709")
+        dst = [np.full(nb, 0xA5, np.uint8) for nb in frames.pack_plane_bytes(fmt, w, h)]
+        dplanes = [hh.dev(d) for d in dst]
+        hh.ctx().pack_write(fmt, hh.dev(rgba), dplanes, w, h, 0, wcm, wlut)
+        want = orc.pack_write(fmt, rgba, w, h, 0, None if rng is None else orc.rgb2ycbcr_matrix("709", *rng),
+                              orc.linear2gamma_lut("709"), planes=[d.copy() for d in dst])
+        for i, (gp, wp) in enumerate(zip(dplanes, want)):
+            bits_eq(hh.host(gp), wp, "%s write specials plane %d" % (fmt, i))
+    # float kernels: same values, NaN positions must agree and every non-NaN word must be identical
+    other = frames.rgba_random(w, h, 4712)
+    out = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+    for name, run, want in (
+            ("combine", lambda: hh.ctx().combine([hh.dev(other), hh.dev(rgba), hh.dev(other)], out, w, h),
+             orc.combine([other, rgba, other])),
+            ("dissolve", lambda: hh.ctx().transition_dissolve(hh.dev(rgba), hh.dev(other), 0.3, out, w, h),
+             orc.transition_dissolve(rgba, other, 0.3))):
+        run()
+        got = hh.host(out).reshape(-1)
+        want = np.asarray(want, np.float32).reshape(-1)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), name
+        ok = ~np.isnan(want)
+        assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32)), name
