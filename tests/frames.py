@@ -117,6 +117,19 @@ def rgba_random(width, height, seed, lo=0.0, hi=1.0, alpha=None):
     return np.ascontiguousarray(img)
 
 
+def rgba_specials(width, height, seed):
+    """rgba_random with NaN, +-Inf, -0, denormals, huge values and exact LUT-index ties sprinkled in
+    (600 positions, deterministic): what convert_ushort_sat_rte and the table index do with them."""
+    img = rgba_random(width, height, seed, -0.2, 1.2)
+    flat = img.reshape(-1)
+    specials = np.array([np.nan, np.inf, -np.inf, -0.0, 1e-42, -1e-42, 3.0e38, -3.0e38, 1.0, 0.0, 0.5 / 65535,
+                         1.5 / 65535, 2.5 / 65535, 65534.5 / 65535], np.float32)
+    n = min(600, flat.size // 2)
+    idx = (splitmix64(seed ^ 0x5BEC, n) % np.uint64(flat.size)).astype(np.int64)
+    flat[idx] = specials[np.arange(n) % specials.size]
+    return img
+
+
 def mask_ramp(width, height):
     """Horizontal ramp mask (r = x/(w-1)) used for transition_wipe."""
     m = np.zeros((height, width, 4), np.float32)

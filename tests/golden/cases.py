@@ -38,6 +38,7 @@ CASES = [
     _c("write_rand_100x1_709_tail4", "v210_write", w=100, h=1, seed=24, lo=0.0, hi=1.0, spec="709", interlace=0),
     _c("write_rand_1280x1_601_tail2", "v210_write", w=1280, h=1, seed=25, lo=0.0, hi=1.0, spec="601_525", interlace=0),
     _c("write_rand_3840x1_2020", "v210_write", w=3840, h=1, seed=26, lo=-0.5, hi=1.5, spec="2020", interlace=0),
+    _c("write_specials_96x4_709", "v210_write", w=96, h=4, seed=27, lo=0.0, hi=1.0, spec="709", interlace=0, specials=True),
     # ---- yadif (yadifCl.ts:105-167) -----------------------------------------------------------
 ] + [
     _c("yadif_64x16_p%d_t%d_s%d" % (p, t, s), "yadif", w=64, h=16, seed=31, parity=p, tff=t, skip=s)
@@ -95,6 +96,11 @@ for _i, (_f, (_sp, _osp)) in enumerate(FMT_SPECS.items()):
             CASES.append(_c("fmt_write_%s_%dx4_il%d" % (_f, _w, _il), "pack_write", fmt=_f, w=_w, h=4,
                             seed=400 + 10 * _i + _il, lo=-0.1, hi=1.1, spec=_osp, interlace=_il))
 
+CASES.append(_c("fmt_write_yuv422p10_96x4_specials", "pack_write", fmt="yuv422p10", w=96, h=4, seed=499, lo=0.0, hi=1.0,
+                spec="709", interlace=0, specials=True))
+CASES.append(_c("fmt_write_rgba8_128x4_specials", "pack_write", fmt="rgba8", w=128, h=4, seed=498, lo=0.0, hi=1.0,
+                spec="709", interlace=0, specials=True))
+
 BY_NAME = {c["name"]: c for c in CASES}
 
 
@@ -111,12 +117,16 @@ def inputs(c):
         return dict(words=v210_source(c))
     if op == "v210_write":
         dst = np.full(frames.v210_pitch_bytes(c["w"]) * c["h"] // 4, POISON, np.uint32)
-        return dict(rgba=frames.rgba_random(c["w"], c["h"], c["seed"], c["lo"], c["hi"]), dst=dst)
+        rgba = frames.rgba_specials(c["w"], c["h"], c["seed"]) if c.get("specials") else \
+            frames.rgba_random(c["w"], c["h"], c["seed"], c["lo"], c["hi"])
+        return dict(rgba=rgba, dst=dst)
     if op == "pack_read":
         return dict(planes=frames.pack_random(c["fmt"], c["w"], c["h"], c["seed"]))
     if op == "pack_write":
         dst = [np.full(n, 0xA5, np.uint8) for n in frames.pack_plane_bytes(c["fmt"], c["w"], c["h"])]
-        return dict(rgba=frames.rgba_random(c["w"], c["h"], c["seed"], c["lo"], c["hi"]), dst=dst)
+        rgba = frames.rgba_specials(c["w"], c["h"], c["seed"]) if c.get("specials") else \
+            frames.rgba_random(c["w"], c["h"], c["seed"], c["lo"], c["hi"])
+        return dict(rgba=rgba, dst=dst)
     if op == "yadif":
         s = c["seed"] * 1000
         return dict(prev=frames.rgba_random(c["w"], c["h"], s + 1), cur=frames.rgba_random(c["w"], c["h"], s + 2),
