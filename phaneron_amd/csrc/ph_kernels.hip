@@ -360,10 +360,12 @@ __global__ __launch_bounds__(kBlock) void resize_kernel(const float4 *__restrict
 template <int N>
 __global__ __launch_bounds__(kBlock) void combine_kernel(CombineArgs a) {
   for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < a.npx; p += (size_t)gridDim.x * kBlock) {
-    float4 acc = reinterpret_cast<const float4 *>(a.layers[0])[p];
+    float4 acc = N >= 3 ? load_stream(reinterpret_cast<const float4 *>(a.layers[0]) + p)
+                        : reinterpret_cast<const float4 *>(a.layers[0])[p];
 #pragma unroll
     for (int l = 1; l < N; ++l) {
-      const float4 t = reinterpret_cast<const float4 *>(a.layers[l])[p];
+      const float4 t = N >= 3 ? load_stream(reinterpret_cast<const float4 *>(a.layers[l]) + p)
+                              : reinterpret_cast<const float4 *>(a.layers[l])[p];
       const float k = 1.0f - t.w;
       acc.x = fma_rn(acc.x, k, t.x);
       acc.y = fma_rn(acc.y, k, t.y);
@@ -388,8 +390,8 @@ __global__ __launch_bounds__(kBlock) void twipe_kernel(const float4 *__restrict_
                                                        const float4 *__restrict__ mask, size_t npx,
                                                        float4 *__restrict__ out) {
   for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock) {
-    const float4 a = in0[p], b = in1[p];
-    const float m = mask[p].x, rm = 1.0f - m;
+    const float4 a = load_stream(in0 + p), b = load_stream(in1 + p);
+    const float m = load_stream(mask + p).x, rm = 1.0f - m;
     store_stream(out + p, make_float4(fma_rn(b.x, m, a.x * rm), fma_rn(b.y, m, a.y * rm), fma_rn(b.z, m, a.z * rm),
                          fma_rn(b.w, m, a.w * rm)));
   }
