@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_px_kernel(Compos
 #pragma unroll
       for (int l = 0; l < N; ++l) {  // transform.ts:53-57; a layer without a matrix is taken 1:1
         if (ALL_DIRECT) {  // no layer is sampled (host knows): one load per layer
-          t[l] = reinterpret_cast<const float4 *>(a.layers[l])[(size_t)line * a.out_w + x];
+          t[l] = load_stream(reinterpret_cast<const float4 *>(a.layers[l]) + (size_t)line * a.out_w + x);
           continue;
         }
         const float s = dot3(mm[l][0], mm[l][1], mm[l][2], px, py, 1.0f) + 0.5f;
