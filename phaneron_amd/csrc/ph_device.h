@@ -155,6 +155,10 @@ __device__ __forceinline__ float4 load_stream(const float4 *p) {
   const ph_f4v v = __builtin_nontemporal_load(reinterpret_cast<const ph_f4v *>(p));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ uint4 load_stream(const uint4 *p) {  // fused kernel inputs: read once, 16 B per lane, +1 %
+  const ph_u4v v = __builtin_nontemporal_load(reinterpret_cast<const ph_u4v *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void store_stream(uint4 *p, const uint4 v) {
 #if PH_NT_STORE
   __builtin_nontemporal_store(ph_u4v{v.x, v.y, v.z, v.w}, reinterpret_cast<ph_u4v *>(p));

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
       const uint32_t f = tile_begin + p * BS + threadIdx.x;  // width % 48 == 0: flat index == offset
       return f < wg_end ? f : wg_end - 1;                     // tail lanes recompute the last quad
     };
-    uint4 w = reinterpret_cast<const uint4 *>(a.f.layers[0])[quad_of(0)];
+    uint4 w = load_stream(reinterpret_cast<const uint4 *>(a.f.layers[0]) + quad_of(0));
     // Phase 1 of one slice: N layers of one quad per lane -> combine -> the 18 writer-LUT indices,
     // packed.  Takes the slice's layer-0 word and returns the next slice's (prefetch chain).  A
     // generic lambda instantiated for both matrix shapes; everything it touches stays in registers
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
 #pragma unroll 1  // rolled: one copy of the per-layer code whatever N is (I-cache, compile time)
       for (int l = 0; l < N; ++l) {
         uint4 nxt = w;
-        if (l + 1 < N) nxt = reinterpret_cast<const uint4 *>(a.f.layers[l + 1])[f];
-        else if (more) nxt = reinterpret_cast<const uint4 *>(a.f.layers[0])[f_next];
+        if (l + 1 < N) nxt = load_stream(reinterpret_cast<const uint4 *>(a.f.layers[l + 1]) + f);
+        else if (more) nxt = load_stream(reinterpret_cast<const uint4 *>(a.f.layers[0]) + f_next);
         const Yuv6 q = unpack_quad(w);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
