@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--ring", type=int, default=8, help="distinct frame sets cycled through (cache defeat)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--channels", type=int, default=1,
+                    help="channels per GPU, composited in ONE batched launch per step (default 1: the headline)")
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
@@ -150,17 +152,22 @@ def main():
     ctx.register_lut(wr[1], capi.linear2gamma_lut("2020"))
     if os.environ.get("PH_BENCH_GLOBAL_LUT"):
         ctx.set_option("lds_lut", 0)
-    ring = []
+    C = max(1, args.channels)
+    ring = []  # per slot: C channels' layer lists and outputs
     for r in range(args.ring):
-        ins = [synth_v210(torch, w, h, 0x5EED0000 + 16 * (rank * 64 + r) + l, device) for l in range(n)]
-        ring.append((ins, torch.empty(frame_words, dtype=torch.int32, device=device)))
+        ins = [[synth_v210(torch, w, h, 0x5EED0000 + 16 * ((rank * C + c) * 64 + r) + l, device) for l in range(n)]
+               for c in range(C)]
+        ring.append((ins, [torch.empty(frame_words, dtype=torch.int32, device=device) for _ in range(C)]))
     torch.cuda.synchronize()
 
     stream = ctx.torch_stream(capi.QUEUE_PROCESS)
 
     def step(i):
-        ins, out = ring[i % args.ring]
-        ctx.fused_v210_combine(ins, out, w, h, *rd, *wr)
+        ins, outs = ring[i % args.ring]
+        if C == 1:
+            ctx.fused_v210_combine(ins[0], outs[0], w, h, *rd, *wr)
+        else:  # one batched launch for the GPU's channels (ph_fused_v210_combine_batch)
+            ctx.fused_v210_combine_batch(ins, outs, w, h, *rd, *wr)
 
     from phaneron_amd import multigpu
 
@@ -184,8 +191,8 @@ def main():
     lds = ctx.lut_info(rd[1])["lds_bytes"] and ctx.lut_info(wr[1])["lds_bytes"] and not os.environ.get("PH_BENCH_GLOBAL_LUT")
     kernel_name = ("fused_v210_combine_lds_kernel<%d,...>" if lds else "fused_v210_combine_kernel<%d>") % n
     if rank == 0:
-        fps = world * args.steps / elapsed
-        algo_bytes = (n + 1) * frame_words * 4  # each input byte once + each output byte once
+        fps = world * C * args.steps / elapsed
+        algo_bytes = C * (n + 1) * frame_words * 4  # each input byte once + each output byte once
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "frames/sec, 4-layer 2160p50 composite pipeline (v210 unpack->CSC->combine->CSC->v210 pack)",
@@ -193,9 +200,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "headline: 1 channel per GPU, %d x %dx%d v210 layers -> fused unpack/CSC(709->2020)/"
-                                   "combine_%d/CSC/pack -> 1 v210 frame" % (n, w, h, n),
-                       "ring_frame_sets": args.ring, "channels": world, "realtime_target_fps": 50},
+            "config": {"workload": "%s: %d channel%s per GPU, %d x %dx%d v210 layers -> fused unpack/CSC(709->2020)/"
+                                   "combine_%d/CSC/pack -> 1 v210 frame%s"
+                                   % ("headline" if C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS) else "variant", C,
+                                      "" if C == 1 else "s", n, w, h, n, "" if C == 1 else " each, one batched launch per step"),
+                       "ring_frame_sets": args.ring, "channels": world * C, "realtime_target_fps": 50},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(),
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,

@@ -224,6 +224,15 @@ int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *laye
                           uint32_t width, uint32_t height, const void *rd_col_matrix12,
                           const void *rd_gamma_lut, const void *rd_gamut_matrix9,
                           const void *wr_col_matrix12, const void *wr_gamma_lut);
+/* The same for `jobs` frames in ONE launch (channels of identical geometry and colour parameters, e.g.
+ * the 1080p channels of BASELINE config 4 / 5 sharing a GPU): layers[j * n + l] is layer l of job j,
+ * outs[j] its output.  The CUs are divided between the jobs, so launch, table loads and the
+ * partially filled last slice are paid once per batch instead of once per frame: four 1080p frames
+ * cost what one 2160p frame costs.  Up to 8 jobs; results identical to `jobs` separate calls. */
+int ph_fused_v210_combine_batch(ph_ctx *ctx, int queue, int jobs, int n, const void *const *layers,
+                                void *const *outs, uint32_t width, uint32_t height, const void *rd_col_matrix12,
+                                const void *rd_gamma_lut, const void *rd_gamut_matrix9, const void *wr_col_matrix12,
+                                const void *wr_gamma_lut);
 
 /* ---- fused layer compositor (no single reference equivalent): the reference's job batches
  *      [transform] per layer (producer/mixer.ts:189-228) -> combine_N (combiner.ts:219-254) ->

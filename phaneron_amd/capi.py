@@ -29,7 +29,7 @@ EXPORTS = [
     "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option", "ph_compose_write_v210",
     "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
     "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy", "ph_queue_query",
-    "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy",
+    "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
         "ph_mixer": (ci, [vp, ci, vp, vp, cf, ci, ci, vp]),
         "ph_wipe": (ci, [vp, ci, vp, vp, cf, ci, ci, vp]),
         "ph_fused_v210_combine": (ci, [vp, ci, ci, C.POINTER(vp), vp, cu, cu, vp, vp, vp, vp, vp]),
+        "ph_fused_v210_combine_batch": (ci, [vp, ci, ci, ci, C.POINTER(vp), C.POINTER(vp), cu, cu, vp, vp, vp, vp, vp]),
         "ph_colour_gamma2linear_lut": (ci, [C.c_char_p, f32p]),
         "ph_colour_linear2gamma_lut": (ci, [C.c_char_p, f32p]),
         "ph_colour_ycbcr2rgb_matrix": (ci, [C.c_char_p, ci, ci, ci, ci, f32p]),
@@ -320,6 +321,15 @@ class Context:
         arr = (C.c_void_p * len(layers))(*[_ptr(l).value for l in layers])
         check(lib().ph_fused_v210_combine(self.h, queue, len(layers), arr, _ptr(dst), width, height, _ptr(rd_cm),
                                           _ptr(rd_lut), _ptr(rd_gm), _ptr(wr_cm), _ptr(wr_lut)), self.h)
+
+    def fused_v210_combine_batch(self, jobs, dsts, width, height, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut, queue=QUEUE_PROCESS):
+        """jobs: list of per-frame layer lists (equal length); dsts: one output per job"""
+        n = len(jobs[0])
+        flat = [_ptr(l).value for job in jobs for l in job]
+        arr = (C.c_void_p * len(flat))(*flat)
+        outs = (C.c_void_p * len(dsts))(*[_ptr(d).value for d in dsts])
+        check(lib().ph_fused_v210_combine_batch(self.h, queue, len(jobs), n, arr, outs, width, height, _ptr(rd_cm),
+                                                _ptr(rd_lut), _ptr(rd_gm), _ptr(wr_cm), _ptr(wr_lut)), self.h)
 
     # ---- nodencl-shaped surface: buffers, programs, queues -----------------------------------------
     def create_buffer(self, nbytes, access="readwrite", svm="coarse", dims=None, owner=""):

@@ -863,7 +863,8 @@ int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *laye
   if (ctx) {
     const ph::LutView *rv = lds_view(ctx, rd_lut), *wv = lds_view(ctx, wr_lut);
     if (rv && wv) {
-      ph::FusedLdsArgs la{a, *rv, *wv};
+      ph::FusedLdsArgs la{};
+      la.f = a, la.rd = *rv, la.wr = *wv, la.jobs = 1;
       PH_LAUNCH(ph::launch_fused_v210_combine_lds(stream_of(ctx, queue), n, la, (uint32_t)ctx->props.multiProcessorCount));
     }
   }
@@ -874,6 +875,43 @@ int ph_pack_plane_bytes(int format, uint32_t width, uint32_t height, size_t byte
   if (!bytes || !width) return fail(PH_E_INVALID, "ph_pack_plane_bytes: NULL/zero argument");
   const int n = ph::pack_plane_bytes(format, width, height, bytes);
   return n < 0 ? fail(PH_E_INVALID, "ph_pack_plane_bytes: unknown format %d", format) : n;
+}
+
+int ph_fused_v210_combine_batch(ph_ctx *ctx, int queue, int jobs, int n, const void *const *layers, void *const *outs,
+                                uint32_t width, uint32_t height, const void *rd_cm, const void *rd_lut, const void *rd_gm,
+                                const void *wr_cm, const void *wr_lut) {
+  if (jobs < 1 || jobs > ph::kMaxBatch) return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: 1..%d jobs", ph::kMaxBatch);
+  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: 1..%d layers", ph::kMaxLayers);
+  if (!layers || !outs) return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: NULL argument");
+  for (int j = 0; j < jobs; ++j) {
+    if (!outs[j]) return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: output %d is NULL", j);
+    for (int l = 0; l < n; ++l)
+      if (!layers[j * n + l]) return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: job %d layer %d is NULL", j, l);
+  }
+  const ph::LutView *rv = ctx ? lds_view(ctx, rd_lut) : nullptr, *wv = ctx ? lds_view(ctx, wr_lut) : nullptr;
+  if (jobs == 1 || !rv || !wv || !width || width % 48 || !height) {
+    // one job, or no LDS form of the tables: the plain entry point per job (same results)
+    for (int j = 0; j < jobs; ++j) {
+      int rc = ph_fused_v210_combine(ctx, queue, n, layers + (size_t)j * n, outs[j], width, height, rd_cm, rd_lut, rd_gm,
+                                     wr_cm, wr_lut);
+      if (rc != PH_OK) return rc;
+    }
+    return PH_OK;
+  }
+  ph::FusedLdsArgs la{};
+  for (int l = 0; l < n; ++l) la.f.layers[l] = layers[l];
+  la.f.out = outs[0];
+  la.f.quads_per_line_used = width / 6;
+  la.f.quads_per_line_pitch = ph::v210_pitch_bytes(width) / 16;
+  la.f.total_quads = la.f.quads_per_line_used * height;
+  la.f.rd_cm = (const float *)rd_cm, la.f.rd_lut = (const float *)rd_lut, la.f.rd_gm = (const float *)rd_gm;
+  la.f.wr_cm = (const float *)wr_cm, la.f.wr_lut = (const float *)wr_lut;
+  la.rd = *rv, la.wr = *wv, la.jobs = (uint32_t)jobs;
+  for (int j = 1; j < jobs; ++j) {
+    for (int l = 0; l < n; ++l) la.more_layers[j - 1][l] = layers[(size_t)j * n + l];
+    la.more_out[j - 1] = outs[j];
+  }
+  PH_LAUNCH(ph::launch_fused_v210_combine_lds(stream_of(ctx, queue), n, la, (uint32_t)ctx->props.multiProcessorCount));
 }
 
 int ph_pack_read(ph_ctx *ctx, int queue, int format, const void *const planes[3], void *out, uint32_t width,

@@ -19,9 +19,15 @@ struct FusedArgs {
   const float *rd_cm, *rd_lut, *rd_gm, *wr_cm, *wr_lut;
 };
 
+constexpr int kMaxBatch = 8;
 struct FusedLdsArgs {
-  FusedArgs f;
+  FusedArgs f;     // job 0 (and the geometry / colour parameters of every job)
   LutView rd, wr;  // compressed reader / writer tables (ph_lut.h)
+  // batched launch: `jobs` frames of identical geometry and colour parameters, each with its own
+  // layers and output; workgroups [j * wg_per_job, (j + 1) * wg_per_job) work on job j
+  uint32_t jobs, wg_per_job;
+  const void *more_layers[kMaxBatch - 1][kMaxLayers];
+  void *more_out[kMaxBatch - 1];
 };
 
 struct ComposeArgs {

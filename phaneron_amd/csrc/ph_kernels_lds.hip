@@ -110,8 +110,13 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
   const bool std_matrix = ycbcr_matrix_is_standard(rk);  // uniform
   // Every workgroup owns one contiguous, equally sized range of quads (all CUs finish together)
   // and walks it in tiles of BS*P quads; only the last tile of a range is partially filled.
-  const uint32_t per_wg = (a.f.total_quads + gridDim.x - 1) / gridDim.x;
-  const uint32_t wg_begin = blockIdx.x * per_wg;
+  // Batched launches give every job its own group of workgroups (uniform per workgroup, so the layer
+  // pointers stay scalar loads from the kernel arguments).
+  const uint32_t job = blockIdx.x / a.wg_per_job, wg_in_job = blockIdx.x - job * a.wg_per_job;
+  auto layer_ptr = [&](int l) { return reinterpret_cast<const uint4 *>(job ? a.more_layers[job - 1][l] : a.f.layers[l]); };
+  uint4 *const out_ptr = reinterpret_cast<uint4 *>(job ? a.more_out[job - 1] : a.f.out);
+  const uint32_t per_wg = (a.f.total_quads + a.wg_per_job - 1) / a.wg_per_job;
+  const uint32_t wg_begin = wg_in_job * per_wg;
   const uint32_t wg_end = wg_begin + per_wg < a.f.total_quads ? wg_begin + per_wg : a.f.total_quads;
   const uint32_t tile_quads = BS * P;
   for (uint32_t tile_begin = wg_begin; tile_begin < wg_end; tile_begin += tile_quads) {
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
       const uint32_t f = tile_begin + p * BS + threadIdx.x;  // width % 48 == 0: flat index == offset
       return f < wg_end ? f : wg_end - 1;                     // tail lanes recompute the last quad
     };
-    uint4 w = load_stream(reinterpret_cast<const uint4 *>(a.f.layers[0]) + quad_of(0));
+    uint4 w = load_stream(layer_ptr(0) + quad_of(0));
     // Phase 1 of one slice: N layers of one quad per lane -> combine -> the 18 writer-LUT indices,
     // packed.  Takes the slice's layer-0 word and returns the next slice's (prefetch chain).  A
     // generic lambda instantiated for both matrix shapes; everything it touches stays in registers
@@ -136,8 +141,8 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
 #pragma unroll 1  // rolled: one copy of the per-layer code whatever N is (I-cache, compile time)
       for (int l = 0; l < N; ++l) {
         uint4 nxt = w;
-        if (l + 1 < N) nxt = load_stream(reinterpret_cast<const uint4 *>(a.f.layers[l + 1]) + f);
-        else if (more) nxt = load_stream(reinterpret_cast<const uint4 *>(a.f.layers[0]) + f_next);
+        if (l + 1 < N) nxt = load_stream(layer_ptr(l + 1) + f);
+        else if (more) nxt = load_stream(layer_ptr(0) + f_next);
         const Yuv6 q = unpack_quad(w);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
           yi[2 * i + 1] = __uint_as_float((st[p][i] >> 16) | 0x4B400000u);
         }
         const uint4 packed = write_quad_idx_lds(yi, wk, wlut);
-        if (f < wg_end) store_stream(reinterpret_cast<uint4 *>(a.f.out) + f, packed);
+        if (f < wg_end) store_stream(out_ptr + f, packed);
       }
     }
     __syncthreads();
@@ -429,8 +434,12 @@ template <int N, int P, int BS>
 static hipError_t launch_fused_npb(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
   hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P, BS>, lds);
   if (e != hipSuccess) return e;
-  const uint32_t slices = (a.f.total_quads + BS - 1) / BS;  // never more workgroups than slices
-  fused_v210_combine_lds_kernel<N, P, BS><<<slices < grid ? slices : grid, BS, lds, s>>>(a);
+  const uint32_t slices = (a.f.total_quads + BS - 1) / BS;  // never more workgroups per job than slices
+  FusedLdsArgs b = a;
+  if (b.jobs < 1) b.jobs = 1;
+  b.wg_per_job = grid / b.jobs ? grid / b.jobs : 1;
+  if (b.wg_per_job > slices) b.wg_per_job = slices;
+  fused_v210_combine_lds_kernel<N, P, BS><<<b.wg_per_job * b.jobs, BS, lds, s>>>(b);
   return hipGetLastError();
 }
 

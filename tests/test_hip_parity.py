@@ -402,6 +402,31 @@ def test_fused_tile_walk_equals_unfused_kernels(w, h, n):
     assert torch.equal(fused, unfused)
 
 
+@pytest.mark.parametrize("jobs,n,w,h", [(2, 4, 1920, 1080), (4, 3, 1920, 270), (3, 2, 96, 5), (8, 1, 480, 36)])
+def test_fused_batch_equals_separate_calls(jobs, n, w, h):
+    """ph_fused_v210_combine_batch: several frames in one launch (the CUs are divided between the jobs)
+    give exactly what one call per frame gives - including job counts that do not divide the CU count
+    and frames smaller than a slice."""
+    import torch
+    import hip_harness as hh
+    k = hh.ctx()
+    words = frames.v210_pitch_bytes(w) * h // 4
+    g = torch.Generator(device="cuda").manual_seed(jobs * 1000 + n)
+    layers = [[torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device="cuda", generator=g) for _ in range(n)]
+              for _ in range(jobs)]
+    cm, lut, gm = hh.ColourParams.reader("709", "2020")
+    wcm, wlut = hh.ColourParams.writer("2020")
+    batched = [torch.zeros(words, dtype=torch.int32, device="cuda") for _ in range(jobs)]
+    single = [torch.zeros(words, dtype=torch.int32, device="cuda") for _ in range(jobs)]
+    k.fused_v210_combine_batch(layers, batched, w, h, cm, lut, gm, wcm, wlut)
+    for j in range(jobs):
+        k.fused_v210_combine(layers[j], single[j], w, h, cm, lut, gm, wcm, wlut)
+    k.wait()
+    torch.cuda.synchronize()
+    for j in range(jobs):
+        assert torch.equal(batched[j], single[j]), j
+
+
 def test_roundtrip_2160p_properties():
     """Full UHD size, size-independent properties:
     (1) the reference's ramp pattern survives read(2020->2020) -> write(2020) byte for byte;
