@@ -13,6 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 
@@ -94,6 +95,11 @@ def lib():
                                      C.c_uint32, C.c_void_p, _f32p]
         l.orc_num_threads.restype = C.c_int
         l.orc_set_num_threads.argtypes = [C.c_int]
+        l.orc_prim_dot4.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
+        l.orc_prim_dot3.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
+        l.orc_prim_convert_range.argtypes = [C.c_int, C.c_uint32, C.c_uint32, _u16p]
+        for n in ("orc_prim_dot4", "orc_prim_dot3", "orc_prim_convert_range"):
+            getattr(l, n).restype = None
         l.orc_set_num_threads.restype = None
         _lib = l
     return _lib
@@ -316,12 +322,60 @@ def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
 
 
+# ---- the built-in semantics the oracle assumes, in bulk (pinned to AMD's device library by the tests) ----
+CONVERTS = {"convert_ushort_sat_rte": 0, "convert_ushort_sat_rtz": 1, "convert_ushort_sat": 2,
+            "convert_uchar_sat_rte": 3, "convert_ushort_sat_rtz(round(x))": 4}
+
+
+def prim_dot(a, b):
+    """a, b: (n, 3) or (n, 4) float32 -> (n,) float32 with the oracle's dot3 / dot4."""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    out = np.empty(a.shape[0], np.float32)
+    (lib().orc_prim_dot4 if a.shape[1] == 4 else lib().orc_prim_dot3)(a, b, out, a.shape[0])
+    return out
+
+
+def prim_convert_range(which, first_bits, n):
+    out = np.empty(n, np.uint16)
+    lib().orc_prim_convert_range(which, first_bits, n, out)
+    return out
+
+
+def ref_builtin_dot(r, a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    out = np.empty(a.shape[0], np.float32)
+    (r.ref_builtin_dot4 if a.shape[1] == 4 else r.ref_builtin_dot3)(a, b, out, a.shape[0])
+    return out
+
+
+def ref_builtin_convert_range(r, which, first_bits, n):
+    out = np.empty(n, np.uint16)
+    r.ref_builtin_convert_range(which, first_bits, n, out)
+    return out
+
+
+def ref_builtin_convert_list(r, which, bits):
+    bits = np.ascontiguousarray(bits, np.uint32)
+    out = np.empty(bits.size, np.uint16)
+    r.ref_builtin_convert_list(which, bits, bits.size, out)
+    return out
+
+
 # ---- oracle/_ref: the reference's own kernel text (build container only) -----------------------
 _ref = None
 
 
+def _cpu_has(*want):
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+    except Exception:
+        return False
+    return all(w in flags for w in want)
+
+
 def ref_available():
-    return os.path.exists(os.path.join(_HERE, "_ref", "libphaneron_ref.so"))
+    # the device-library object inside it is built with -mfma (its dot() must fuse like the GPU does)
+    return os.path.exists(os.path.join(_HERE, "_ref", "libphaneron_ref.so")) and _cpu_has("fma")
 
 
 def _bind_ref(path):
@@ -347,6 +401,14 @@ def _bind_ref(path):
         r.ref_pipeline_v210_combine.argtypes = [C.c_int, C.POINTER(C.c_void_p), _u32p, C.c_uint, C.c_uint, _f32p, _f32p,
                                                 _f32p, _f32p, _f32p, _f32p]
         r.ref_set_num_threads.argtypes = [C.c_int]
+        r.ref_builtin_dot4.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
+        r.ref_builtin_dot3.argtypes = [_f32p, _f32p, _f32p, C.c_size_t]
+        r.ref_builtin_fma.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_size_t]
+        r.ref_builtin_convert_range.argtypes = [C.c_int, C.c_uint32, C.c_uint32, _u16p]
+        r.ref_builtin_convert_list.argtypes = [C.c_int, _u32p, C.c_uint32, _u16p]
+        for n in ("ref_builtin_dot4", "ref_builtin_dot3", "ref_builtin_fma", "ref_builtin_convert_range",
+                  "ref_builtin_convert_list"):
+            getattr(r, n).restype = None
     return r
 
 
@@ -363,13 +425,7 @@ _ref_fast = None
 
 def have_ref_fast():
     """The -O3 -mavx2 -mfma build of the same reference kernels, usable on this host's CPU?"""
-    if not os.path.exists(os.path.join(_HERE, "_ref", "libphaneron_ref_fast.so")):
-        return False
-    try:
-        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
-    except Exception:
-        return False
-    return "avx2" in flags and "fma" in flags
+    return os.path.exists(os.path.join(_HERE, "_ref", "libphaneron_ref_fast.so")) and _cpu_has("avx2", "fma")
 
 
 def ref_fast():

@@ -272,6 +272,35 @@ static inline uint32_t sat_u16_trunc(float x) { /* convert_ushort_sat / _rtz */
 }
 static inline uint32_t sat_u16_rte(float x) { return sat_u16_trunc(rintf(x)); }
 
+/* Bulk forms of the primitives above, so that tests can pin them to AMD's device-library definitions
+ * (oracle/_ref's ref_builtin_* hooks; tests/test_oracle_golden.py).  `which` as ref_builtin_convert_range:
+ * 0 _sat_rte, 1 _sat_rtz, 2 _sat, 4 (ushort)_sat_rtz(round(x)); 3 (uchar) lives in phaneron_oracle_formats.c. */
+void orc_prim_dot4(const float *a, const float *b, float *out, size_t n) {
+  size_t i;
+  for (i = 0; i < n; ++i) out[i] = dot4(a + 4 * i, b + 4 * i);
+}
+void orc_prim_dot3(const float *a, const float *b, float *out, size_t n) {
+  size_t i;
+  for (i = 0; i < n; ++i) out[i] = dot3(a + 3 * i, b + 3 * i);
+}
+extern uint32_t orc_prim_sat_u8_rte(float x);
+void orc_prim_convert_range(int which, uint32_t first_bits, uint32_t n, uint16_t *out) {
+  int64_t i;
+  ORC_PAR_FOR
+  for (i = 0; i < (int64_t)n; ++i) {
+    const uint32_t bits = first_bits + (uint32_t)i;
+    float x;
+    memcpy(&x, &bits, 4);
+    switch (which) {
+      case 0: out[i] = (uint16_t)sat_u16_rte(x); break;
+      case 1:
+      case 2: out[i] = (uint16_t)sat_u16_trunc(x); break;
+      case 3: out[i] = (uint16_t)orc_prim_sat_u8_rte(x); break;
+      default: out[i] = (uint16_t)sat_u16_trunc(roundf(x)); break;
+    }
+  }
+}
+
 /* ======================================================================================== */
 /* v210.ts                                                                                  */
 /* ======================================================================================== */

@@ -106,6 +106,13 @@ int orc_pipeline_v210_combine(int n, const uint32_t *const *layers, uint32_t *ou
                               const float *rd_gamut9, const float *wr_col_matrix12,
                               const float *wr_lut, float *scratch);
 
+/* ---- the OpenCL built-in semantics this file assumes, in bulk (test hooks) --------------------- */
+void orc_prim_dot4(const float *a4, const float *b4, float *out, size_t n);
+void orc_prim_dot3(const float *a3, const float *b3, float *out, size_t n);
+/* which: 0 convert_ushort_sat_rte, 1 _sat_rtz, 2 _sat, 3 convert_uchar_sat_rte, 4 _sat_rtz(round(x));
+ * inputs are the float bit patterns first_bits .. first_bits + n - 1 */
+void orc_prim_convert_range(int which, uint32_t first_bits, uint32_t n, uint16_t *out);
+
 /* number of OpenMP threads the image loops will use (1 when built without OpenMP) */
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

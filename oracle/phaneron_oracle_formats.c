@@ -31,6 +31,8 @@ static inline uint32_t sat_u8_rte(float x) { /* convert_uchar_sat_rte */
   return (uint32_t)x;
 }
 
+uint32_t orc_prim_sat_u8_rte(float x) { return sat_u8_rte(x); } /* test hook, see orc_prim_convert_range */
+
 uint32_t orc_pack_pitch(int fmt, uint32_t width) { /* samples per luma line: getPitch() of each format */
   if (fmt == ORC_FMT_RGBA8 || fmt == ORC_FMT_BGRA8) return width;            /* rgba8.ts:103-105 */
   if (fmt == ORC_FMT_V210) return orc_v210_pitch_pixels(width);

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Extract the reference's OpenCL C kernel text into oracle/_ref/ (never committed).
+"""Extract the reference's OpenCL C kernel text into oracle/_ref/work/cl/ (never committed, never shipped to the GPU box).
 
 TEST INFRASTRUCTURE ONLY.  Runs only in the build container, where the reference
 checkout exists at /root/reference.  The kernel text is read from the sources where
-they lie and written under oracle/_ref/ (git-ignored); nothing derived from it is
+they lie and written under oracle/_ref/work/ (git-ignored, gpurun-ignored); nothing derived from it is
 committed except golden input/output *data* under tests/golden/.
 
 Static kernels are template strings (`const xxxKernel = `...``):
@@ -20,7 +20,7 @@ import subprocess
 import sys
 
 REF = os.environ.get("PHANERON_REFERENCE", "/root/reference")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "_ref")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "_ref", "work", "cl")
 
 STATIC = [
     ("v210.ts", "v210Kernel", "v210"),

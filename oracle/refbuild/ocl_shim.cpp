@@ -1,18 +1,18 @@
-// ocl_shim.cpp - host-side definitions of the OpenCL C built-ins the reference's kernel
-// text calls, so that text (compiled unmodified for x86 by the same clang) can execute here.
+// ocl_shim.cpp - the part of an OpenCL runtime that AMD's device library does not contain, so
+// that the reference's kernel text (compiled unmodified for x86 by the same clang) can execute here:
+// work-item ids, image / sampler access, and the loops that play the NDRange.
 //
-// TEST INFRASTRUCTURE ONLY.  This file contains no reference code: it is the runtime the
-// reference's kernels expect from an OpenCL implementation.  Definitions follow
-//   * ROCm 7.2 device-lib (`/opt/rocm/amdgcn/bitcode/opencl.bc`, inspect with llvm-dis):
-//       dot(float4) = fma(a.w,b.w, fma(a.z,b.z, fma(a.y,b.y, a.x*b.x)))   (@_Z3dotDv4_fS_)
-//       dot(float3) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))                 (@_Z3dotDv3_fS_)
-//       convert_ushort_sat_rte(x) = (ushort)min(max(rint(x),0),65535)
-//       convert_ushort_sat[_rtz](x) = truncating conversion with the same clamp
-//   * OpenCL 1.2 spec section 8.2 for read_imagef (nearest / linear, clamp / clamp-to-edge).
+// TEST INFRASTRUCTURE ONLY.  This file contains no reference code.
+//   * The ARITHMETIC built-ins the kernels call (dot, fma, fabs, fmin, fmax, round, convert_*_sat*,
+//     convert_float4) are NOT written here: they are the function bodies of ROCm 7.2's
+//     /opt/rocm/amdgcn/bitcode/opencl.bc + ocml.bc, retargeted to x86-64 by devlib_builtins.py and
+//     linked in by build_ref.sh.  tests/test_builtins_gpu.py runs the same bitcode on the MI355X and
+//     checks that both agree with the product's and the oracle's primitives.
+//   * read_imagef / write_imagef follow OpenCL 1.2 section 8.2 (nearest / linear, clamp / clamp-to-edge).
 //     LINEAR filtering evaluates the spec formula in f32, left to right, no fma:
 //       T = (1-a)(1-b)*T00 + a(1-b)*T10 + (1-a)b*T01 + ab*T11
-//     (CDNA GPUs have no sampler hardware, so no device result exists to compare with:
-//      parity for LINEAR is pinned to this formula only.)
+//     (CDNA GPUs have no sampler hardware and ROCm's OpenCL reports no image support on them, so no
+//      device result exists to compare with: parity for LINEAR is pinned to this formula only.)
 // Build: oracle/refbuild/build_ref.sh.  Must be compiled by the same clang as the kernels
 // (vector arguments use that compiler's SysV vector ABI), with -ffp-contract=off.
 #include <cmath>
@@ -47,79 +47,18 @@ unsigned long wi_group_id(unsigned d) { return d == 0 ? g_grp : 0; }
 unsigned long wi_local_size(unsigned d) { return d == 0 ? g_lsz : 1; }
 
 // ---- arithmetic built-ins ---------------------------------------------------------------
+// NOT defined here.  dot / fma / fabs / fmin / fmax / round / convert_*_sat* / convert_float4 are AMD's
+// own definitions: devlib_builtins.py takes them out of /opt/rocm/amdgcn/bitcode/{opencl,ocml}.bc,
+// retargets the unchanged function bodies to x86-64 and build_ref.sh links the object in.  The
+// declarations below only give this file's test hooks (bottom) access to them.
 float b_dot3(float3 a, float3 b) asm("_Z3dotDv3_fS_");
 float b_dot4(float4 a, float4 b) asm("_Z3dotDv4_fS_");
 float b_fma1(float a, float b, float c) asm("_Z3fmafff");
-float2 b_fma2(float2 a, float2 b, float2 c) asm("_Z3fmaDv2_fS_S_");
-float4 b_fma4(float4 a, float4 b, float4 c) asm("_Z3fmaDv4_fS_S_");
-float4 b_fabs4(float4 a) asm("_Z4fabsDv4_f");
-float4 b_fmin4(float4 a, float4 b) asm("_Z4fminDv4_fS_");
-float4 b_fmax4(float4 a, float4 b) asm("_Z4fmaxDv4_fS_");
 float b_round(float a) asm("_Z5roundf");
-float4 b_cvt_f4_us4(ushort4 a) asm("_Z14convert_float4Dv4_t");
-float4 b_cvt_f4_uc4(uchar4 a) asm("_Z14convert_float4Dv4_h");
 unsigned char b_cvt_uc_sat_rte(float a) asm("_Z21convert_uchar_sat_rtef");
 unsigned short b_cvt_us_sat(float a) asm("_Z18convert_ushort_satf");
 unsigned short b_cvt_us_sat_rte(float a) asm("_Z22convert_ushort_sat_rtef");
 unsigned short b_cvt_us_sat_rtz(float a) asm("_Z22convert_ushort_sat_rtzf");
-
-float b_dot3(float3 a, float3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
-float b_dot4(float4 a, float4 b) {
-  return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
-}
-float b_fma1(float a, float b, float c) { return fmaf(a, b, c); }
-float2 b_fma2(float2 a, float2 b, float2 c) {
-  float2 r;
-  r.x = fmaf(a.x, b.x, c.x);
-  r.y = fmaf(a.y, b.y, c.y);
-  return r;
-}
-float4 b_fma4(float4 a, float4 b, float4 c) {
-  float4 r;
-  for (int i = 0; i < 4; ++i) r[i] = fmaf(a[i], b[i], c[i]);
-  return r;
-}
-float4 b_fabs4(float4 a) {
-  float4 r;
-  for (int i = 0; i < 4; ++i) r[i] = fabsf(a[i]);
-  return r;
-}
-float4 b_fmin4(float4 a, float4 b) {
-  float4 r;
-  for (int i = 0; i < 4; ++i) r[i] = fminf(a[i], b[i]);
-  return r;
-}
-float4 b_fmax4(float4 a, float4 b) {
-  float4 r;
-  for (int i = 0; i < 4; ++i) r[i] = fmaxf(a[i], b[i]);
-  return r;
-}
-float b_round(float a) { return roundf(a); }
-float4 b_cvt_f4_us4(ushort4 a) {
-  float4 r;
-  for (int i = 0; i < 4; ++i) r[i] = (float)a[i];
-  return r;
-}
-float4 b_cvt_f4_uc4(uchar4 a) {
-  float4 r;
-  for (int i = 0; i < 4; ++i) r[i] = (float)a[i];
-  return r;
-}
-unsigned char b_cvt_uc_sat_rte(float a) {  // rint -> max 0 -> min 255 -> fptoui (device-lib form)
-  float x = rintf(a);
-  if (!(x > 0.0f)) return 0;
-  if (x >= 255.0f) return 255;
-  return (unsigned char)x;
-}
-static inline unsigned short clamp_us(float x) {
-  // NaN -> 0 like the device's max(x,0) (fmax ignores NaN)
-  if (!(x > 0.0f)) return 0;
-  if (x >= 65535.0f) return 65535;
-  return (unsigned short)x;  // truncation; callers pre-round when rte is wanted
-}
-unsigned short b_cvt_us_sat(float a) { return clamp_us(a); }
-unsigned short b_cvt_us_sat_rtz(float a) { return clamp_us(a); }
-unsigned short b_cvt_us_sat_rte(float a) { return clamp_us(rintf(a)); }
 
 // ---- images and samplers ----------------------------------------------------------------
 enum { S_NORM = 1, S_EDGE = 2, S_CLAMP = 4, S_NEAREST = 0x10, S_LINEAR = 0x20 };
@@ -416,6 +355,46 @@ int ref_pipeline_v210_combine(int n, const uint32_t *const *layers, uint32_t *ou
   }
   ref_v210_write(top, out, width, height, 0, wr_cm12, wr_lut);
   return 0;
+}
+
+
+// ---- test hooks over the device-library built-ins (tests/test_oracle_golden.py, test_builtins_gpu.py):
+// bulk evaluation so that Python can compare them with the oracle's and the product's primitives.
+void ref_builtin_dot4(const float *a, const float *b, float *out, size_t n) {
+  for (size_t i = 0; i < n; ++i) out[i] = b_dot4(*(const float4 *)(a + 4 * i), *(const float4 *)(b + 4 * i));
+}
+void ref_builtin_dot3(const float *a, const float *b, float *out, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    float3 x = {a[3 * i], a[3 * i + 1], a[3 * i + 2]}, y = {b[3 * i], b[3 * i + 1], b[3 * i + 2]};
+    out[i] = b_dot3(x, y);
+  }
+}
+void ref_builtin_fma(const float *a, const float *b, const float *c, float *out, size_t n) {
+  for (size_t i = 0; i < n; ++i) out[i] = b_fma1(a[i], b[i], c[i]);
+}
+// which: 0 convert_ushort_sat_rte, 1 convert_ushort_sat_rtz, 2 convert_ushort_sat, 3 convert_uchar_sat_rte,
+// 4 (ushort)round(x) with the _rtz clamp (the v210 tail path, v210.ts:176-183).  Inputs are the float
+// bit patterns first_bits .. first_bits + n - 1, so that a caller can sweep all 2^32 of them.
+static inline uint16_t convert_one(int which, uint32_t bits) {
+  float x;
+  memcpy(&x, &bits, 4);
+  switch (which) {
+    case 0: return b_cvt_us_sat_rte(x);
+    case 1: return b_cvt_us_sat_rtz(x);
+    case 2: return b_cvt_us_sat(x);
+    case 3: return b_cvt_uc_sat_rte(x);
+    default: return b_cvt_us_sat_rtz(b_round(x));
+  }
+}
+void ref_builtin_convert_range(int which, uint32_t first_bits, uint32_t n, uint16_t *out) {
+  parallel_rows(64, [=](unsigned part) {
+    for (uint64_t i = (uint64_t)n * part / 64, e = (uint64_t)n * (part + 1) / 64; i < e; ++i)
+      out[i] = convert_one(which, first_bits + (uint32_t)i);
+  });
+}
+// the same for a list of bit patterns
+void ref_builtin_convert_list(int which, const uint32_t *bits, uint32_t n, uint16_t *out) {
+  for (uint32_t i = 0; i < n; ++i) out[i] = convert_one(which, bits[i]);
 }
 
 }  // extern "C"

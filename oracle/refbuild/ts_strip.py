@@ -3,7 +3,7 @@
 src/clJobQueue.ts, so the reference's OWN host code can be executed under node 12 (there
 is no tsc in this image) against a recording mock of `nodencl`.
 
-TEST INFRASTRUCTURE ONLY: output goes to oracle/_ref/js/ (git-ignored, never committed);
+TEST INFRASTRUCTURE ONLY: output goes to oracle/_ref/work/js/ (git-ignored, never committed);
 only golden *data* captured from running it is committed (tests/golden/).
 
 It is not a general TS compiler - it handles exactly the constructs those files use:
@@ -139,4 +139,4 @@ def main(out_dir):
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
-    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "_ref", "js"))
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "_ref", "work", "js"))

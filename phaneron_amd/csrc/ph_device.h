@@ -39,6 +39,11 @@ __device__ __forceinline__ uint32_t sat_u16_trunc(float x) {
   return (uint32_t)x;
 }
 
+// convert_uchar_sat_rte (rgba8.ts / bgra8.ts writers): rint -> max 0 -> min 255 -> fptoui, as the device library
+__device__ __forceinline__ uint32_t sat_u8_rte(float x) {
+  return (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(x), 0.f), 255.f);
+}
+
 // Reader-side constants (v210.ts:42-52): 3x4 YCbCr->RGB matrix, 3x3 gamut matrix.
 struct ReadK {
   float4 r, g, b;

@@ -123,9 +123,9 @@ __device__ __forceinline__ void fmt_write_body(const FmtWriteArgs &a, const LUT 
       const uint32_t line = g * (a.interlace ? 2 : 1) + ((3 == a.interlace) ? 1 : 0);
       const float4 px = a.in[(size_t)line * a.width + x];
       const float r = lut.at_unit(px.x), gg = lut.at_unit(px.y), b = lut.at_unit(px.z);
-      const uint32_t r8 = (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(r * 255.0f), 0.f), 255.f);
-      const uint32_t g8 = (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(gg * 255.0f), 0.f), 255.f);
-      const uint32_t b8 = (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf(b * 255.0f), 0.f), 255.f);
+      const uint32_t r8 = sat_u8_rte(r * 255.0f);
+      const uint32_t g8 = sat_u8_rte(gg * 255.0f);
+      const uint32_t b8 = sat_u8_rte(b * 255.0f);
       const uint32_t w = FMT == F_RGBA8 ? (r8 | g8 << 8 | b8 << 16 | 0xff000000u) : (b8 | g8 << 8 | r8 << 16 | 0xff000000u);
       reinterpret_cast<uint32_t *>(a.p0)[(size_t)line * a.pitch + x] = w;
     }

@@ -36,7 +36,7 @@ def main():
         raise SystemExit("reference checkout missing: goldens can only be generated in the build container")
     subprocess.run([os.path.join(ROOT, "oracle", "refbuild", "build_ref.sh")], check=True)
     subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "refbuild", "ts_strip.py")], check=True)
-    lut_dir = os.path.join(ROOT, "oracle", "_ref", "luts")
+    lut_dir = os.path.join(ROOT, "oracle", "_ref", "work", "luts")
     os.makedirs(lut_dir, exist_ok=True)
     env = dict(os.environ, REF_LUT_DIR=lut_dir)
     host = subprocess.run(["node", os.path.join(HERE, "ref_host_dump.js")], check=True, capture_output=True,
@@ -155,7 +155,7 @@ def main():
         f.write("\n")
     # host-logic trace: the reference's own operator + dispatcher code against the recording mock
     tr = subprocess.run(["node", os.path.join(ROOT, "node", "test", "scenario.js"),
-                         os.path.join(ROOT, "oracle", "_ref", "js")], check=True, capture_output=True, text=True).stdout
+                         os.path.join(ROOT, "oracle", "_ref", "work", "js")], check=True, capture_output=True, text=True).stdout
     with open(os.path.join(HERE, "host_trace.json"), "w") as f:
         json.dump(json.loads(tr), f, indent=0, sort_keys=True)
         f.write("\n")

@@ -1,10 +1,10 @@
 'use strict'
 // Runs the REFERENCE's own host maths (src/process/colourMaths.ts, transform.ts, v210.ts fillBuf),
-// type-stripped into oracle/_ref/js by oracle/refbuild/ts_strip.py, under node 12 and prints the
+// type-stripped into oracle/_ref/work/js by oracle/refbuild/ts_strip.py, under node 12 and prints the
 // results as JSON (f32 bit patterns / sha256).  Build container only; called by gen_golden.py.
 const path = require('path')
 const crypto = require('crypto')
-const root = path.join(__dirname, '..', '..', 'oracle', '_ref', 'js')
+const root = path.join(__dirname, '..', '..', 'oracle', '_ref', 'work', 'js')
 const cm = require(path.join(root, 'process', 'colourMaths.js'))
 const v210 = require(path.join(root, 'process', 'v210.js'))
 const Transform = require(path.join(root, 'process', 'transform.js')).default

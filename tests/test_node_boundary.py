@@ -30,7 +30,7 @@ def test_js_operator_layer_matches_reference_trace():
 @needs_node
 def test_reference_trace_still_reproducible_here():
     """Where the reference checkout exists the golden trace must regenerate identically."""
-    ref_js = os.path.join(ROOT, "oracle", "_ref", "js", "clJobQueue.js")
+    ref_js = os.path.join(ROOT, "oracle", "_ref", "work", "js", "clJobQueue.js")
     if not os.path.exists(ref_js):
         pytest.skip("oracle/_ref/js not built (reference checkout absent)")
     out = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "scenario.js"), os.path.dirname(ref_js)],

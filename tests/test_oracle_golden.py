@@ -230,3 +230,53 @@ def test_reference_kernel_chain_equals_oracle_chain_any_build_any_thread_count()
             r.ref_set_num_threads(threads)
             assert np.array_equal(orc.ref_pipeline_v210_combine(r, layers, w, h, *rd, *wr), want)
         r.ref_set_num_threads(1)
+
+
+# ---- the OpenCL built-ins: oracle restatement vs AMD's own device-library bodies ------------------------
+# oracle/_ref links dot / fma / convert_*_sat* taken from /opt/rocm/amdgcn/bitcode/{opencl,ocml}.bc
+# (oracle/refbuild/devlib_builtins.py: function bodies unchanged, retargeted to x86-64).  These tests pin
+# the oracle's own spelling of those built-ins (phaneron_oracle.c "OpenCL built-in semantics") to them;
+# tests/test_builtins_gpu.py runs the same bitcode natively on the MI355X against the product's primitives.
+def _wild_floats(rng, shape):
+    """float32 values covering every exponent, both signs, denormals, zeros, infinities and NaNs."""
+    bits = rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32)
+    tame = (rng.standard_normal(shape) * 10.0 ** rng.integers(-6, 6, size=shape)).astype(np.float32)
+    pick = rng.random(shape) < 0.5
+    return np.where(pick, bits.view(np.float32), tame)
+
+
+@pytest.mark.skipif(not orc.ref_available(), reason="oracle/_ref is only built where the reference checkout exists")
+@pytest.mark.parametrize("k", [3, 4])
+def test_oracle_dot_equals_device_library_dot(k):
+    rng = np.random.default_rng(1234 + k)
+    n = 4_000_000
+    a, b = _wild_floats(rng, (n, k)), _wild_floats(rng, (n, k))
+    # colour-matrix-like operands too: code values against small coefficients
+    a[: n // 4] = rng.integers(0, 1024, size=(n // 4, k)).astype(np.float32)
+    b[: n // 4] = (rng.standard_normal((n // 4, k)) * 0.01).astype(np.float32)
+    want = orc.ref_builtin_dot(orc.ref(), a, b)
+    got = orc.prim_dot(a, b)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+    if orc.have_ref_fast():  # the -O3 -mavx2 build links the same bodies
+        assert np.array_equal(orc.ref_builtin_dot(orc.ref_fast(), a, b).view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+
+
+@pytest.mark.skipif(not orc.ref_available(), reason="oracle/_ref is only built where the reference checkout exists")
+@pytest.mark.parametrize("name", sorted(orc.CONVERTS))
+def test_oracle_converts_equal_device_library_over_all_floats(name):
+    """All 2^32 float bit patterns (NaNs, infinities, denormals, ties included), in chunks of 2^26."""
+    which = orc.CONVERTS[name]
+    r = orc.ref()
+    r.ref_set_num_threads(orc.effective_cpus())
+    try:
+        step = 1 << 26
+        for first in range(0, 1 << 32, step):
+            want = orc.ref_builtin_convert_range(r, which, first, step)
+            got = orc.prim_convert_range(which, first, step)
+            if not np.array_equal(got, want):
+                i = int(np.flatnonzero(got != want)[0])
+                raise AssertionError("%s(bits 0x%08x): oracle %d, device library %d" % (name, first + i, got[i], want[i]))
+    finally:
+        r.ref_set_num_threads(1)
