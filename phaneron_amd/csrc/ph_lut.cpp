@@ -34,8 +34,9 @@ LutView lut_view(const LutHostInfo &info, const void *blob_dev) {
 }
 
 bool lut_compress(const float *lut, uint32_t max_bytes, std::vector<uint32_t> &blob, LutHostInfo &info) {
-  static uint32_t p[65536], blk[65536];
-  std::memcpy(p, lut, sizeof p);
+  // per-call scratch: callers may compress tables from several threads (the node addon's libuv pool)
+  std::vector<uint32_t> p(65536), blk(65536);
+  std::memcpy(p.data(), lut, 65536 * sizeof(uint32_t));
   bool found = false;
   for (float bias : {16.0f, 32.0f, 64.0f, 128.0f}) {
     for (uint32_t m = 7; m <= 10; ++m) {
