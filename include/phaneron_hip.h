@@ -131,6 +131,13 @@ int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, s
 int ph_program_create(ph_ctx *ctx, const char *kernel_src, const char *name,
                       const uint32_t *global_work_items, int n_dims,
                       uint32_t work_items_per_group, ph_program **out);
+/* The selection alone, without a context or a device (same rules, same errors): writes the resolved
+ * kernel id ("v210_read", "yuv420p_write", "combine_4", ...), the PH_FMT_* of a read / write program
+ * (-1 otherwise) and HOW it was selected - by "phaneron:" tag, by unique kernel name, by the exact text of
+ * one of the reference's seven pack-format sources, or (any other text) by the kernel's argument list. */
+enum { PH_RESOLVED_BY_TAG = 0, PH_RESOLVED_BY_NAME = 1, PH_RESOLVED_BY_TEXT = 2, PH_RESOLVED_BY_SIGNATURE = 3 };
+int ph_program_resolve(const char *kernel_src, const char *name, char *kernel_id, size_t kernel_id_len,
+                       int *format, int *how);
 int ph_program_destroy(ph_program *prog);
 const char *ph_program_kernel(const ph_program *prog); /* resolved kernel id, e.g. "v210_read" */
 

@@ -68,3 +68,18 @@ export class clContext {
 	recordEvent(queue?: number): QueueEvent
 	logBuffers(): { liveBuffers: number; liveBytes: number; pooledBytes: number }
 }
+
+/** which precompiled kernel createProgram(kernelSrc, {name}) selects - needs no context and no GPU */
+export function resolveProgram(kernelSrc: string, name: string): { kernel: string; format: string | null; how: 'tag' | 'name' | 'text' | 'signature' }
+
+/** the library's host colour maths (the numbers src/process/colourMaths.ts and transform.ts:119-171 produce) */
+export const colour: {
+	gamma2linearLUT(colSpec: string): Float32Array
+	linear2gammaLUT(colSpec: string): Float32Array
+	ycbcr2rgbMatrix(colSpec: string, numBits?: number, lumaBlack?: number, lumaWhite?: number, chromaRange?: number): Float32Array
+	rgb2ycbcrMatrix(colSpec: string, numBits?: number, lumaBlack?: number, lumaWhite?: number, chromaRange?: number): Float32Array
+	rgb2rgbMatrix(srcColSpec: string, dstColSpec: string): Float32Array
+	transformMatrix(width: number, height: number, params?: { flipH?: boolean; flipV?: boolean; anchorX?: number; anchorY?: number; scaleX?: number; scaleY?: number; offsetX?: number; offsetY?: number; rotate?: number }): Float32Array
+}
+export const FORMATS: string[]
+export function planeBytes(format: string, width: number, height: number): number[]

@@ -145,4 +145,33 @@ class clContext {
 	}
 }
 
-module.exports = { clContext }
+// ---- device-free helpers (no context, no GPU) ----------------------------------------------------
+// which precompiled kernel createProgram(kernelSrc, {name}) selects: { kernel, format, how }
+function resolveProgram(kernelSrc, name) {
+	return loadAddon().resolveProgram(String(kernelSrc), name)
+}
+
+// the library's host colour maths (the numbers src/process/colourMaths.ts gives the reference's Loader / Saver)
+const colour = {
+	gamma2linearLUT: (spec) => loadAddon().gammaLut('gamma2linear', spec),
+	linear2gammaLUT: (spec) => loadAddon().gammaLut('linear2gamma', spec),
+	ycbcr2rgbMatrix: (spec, numBits = 10, lumaBlack = 64, lumaWhite = 940, chromaRange = 896) =>
+		loadAddon().colourMatrix('ycbcr2rgb', spec, numBits, lumaBlack, lumaWhite, chromaRange),
+	rgb2ycbcrMatrix: (spec, numBits = 10, lumaBlack = 64, lumaWhite = 940, chromaRange = 896) =>
+		loadAddon().colourMatrix('rgb2ycbcr', spec, numBits, lumaBlack, lumaWhite, chromaRange),
+	rgb2rgbMatrix: (srcSpec, dstSpec) => loadAddon().colourMatrix('rgb2rgb', srcSpec, dstSpec),
+	// p: { flipH, flipV, anchorX, anchorY, scaleX, scaleY, offsetX, offsetY, rotate } as transform.ts:119-171 takes them
+	transformMatrix: (width, height, p = {}) => loadAddon().transformMatrix(width, height, p.flipH ? 1 : 0, p.flipV ? 1 : 0,
+		p.anchorX || 0, p.anchorY || 0, p.scaleX === undefined ? 1 : p.scaleX, p.scaleY === undefined ? 1 : p.scaleY,
+		p.offsetX || 0, p.offsetY || 0, p.rotate || 0)
+}
+
+const FORMATS = ['v210', 'yuv422p10', 'yuv422p8', 'yuv420p', 'nv12', 'rgba8', 'bgra8']
+// bytes per plane of a frame in `format`: the numBytes of the reference's Readers / Writers
+function planeBytes(format, width, height) {
+	const f = FORMATS.indexOf(format)
+	if (f < 0) throw new Error(`unknown pack format '${format}'`)
+	return loadAddon().planeBytes(f, width, height)
+}
+
+module.exports = { clContext, resolveProgram, colour, planeBytes, FORMATS }

@@ -31,7 +31,8 @@ typedef struct {
 } ctx_box;
 
 typedef struct {
-  ph_buf *buf; /* NULL once the last reference has been released */
+  ph_buf *buf; /* NULL once the last JS reference has been released */
+  int js_refs; /* addRef / release calls made from JS (async jobs hold library references of their own) */
 } buf_box;
 
 typedef struct {
@@ -54,8 +55,9 @@ static void ctx_finalize(napi_env env, void *data, void *hint) {
 static void buf_finalize(napi_env env, void *data, void *hint) {
   (void)env, (void)hint;
   buf_box *b = (buf_box *)data;
-  while (b->buf && ph_buf_refcount(b->buf) > 1) ph_buf_release(b->buf); /* leaked refs die with the JS object */
-  if (b->buf) ph_buf_release(b->buf);
+  /* references leaked by JS die with the JS object; the library keeps the context alive until the last
+   * buffer is gone (ph_api.cpp "Lifetime"), so the order in which the collector finalises things is free */
+  for (; b->buf && b->js_refs > 0; --b->js_refs) ph_buf_release(b->buf);
   free(b);
 }
 static void prog_finalize(napi_env env, void *data, void *hint) {
@@ -123,6 +125,7 @@ static napi_value CreateBuffer(napi_env env, napi_callback_info info) {
   if (argc > 5) get_i32(env, argv[5], &h);
   if (argc > 6) napi_get_value_string_utf8(env, argv[6], owner, sizeof owner, &len);
   buf_box *box = (buf_box *)calloc(1, sizeof *box);
+  box->js_refs = 1;
   if (ph_buf_create(c->ctx, (size_t)bytes, access, svm, w, h, owner, &box->buf) != PH_OK) {
     free(box);
     return throw_ph(env, "createBuffer");
@@ -151,7 +154,7 @@ static napi_value BufAddRef(napi_env env, napi_callback_info info) {
     return NULL;
   }
   ph_buf_addref(b->buf);
-  NAPI_OK(napi_create_int32(env, ph_buf_refcount(b->buf), &out));
+  NAPI_OK(napi_create_int32(env, ++b->js_refs, &out));
   return out;
 }
 
@@ -165,8 +168,8 @@ static napi_value BufRelease(napi_env env, napi_callback_info info) {
     napi_throw_error(env, NULL, "release on a released buffer");
     return NULL;
   }
-  left = ph_buf_refcount(b->buf) - 1;
-  ph_buf_release(b->buf);
+  left = --b->js_refs;
+  ph_buf_release(b->buf); /* an async job still using the buffer holds its own reference */
   if (left <= 0) b->buf = NULL;
   NAPI_OK(napi_create_int32(env, left, &out));
   return out;
@@ -178,7 +181,7 @@ static napi_value BufRefCount(napi_env env, napi_callback_info info) {
   buf_box *b;
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   if (argc < 1 || !get_box(env, argv[0], (void **)&b)) return throw_ph(env, "refCount: bad buffer");
-  NAPI_OK(napi_create_int32(env, b->buf ? ph_buf_refcount(b->buf) : 0, &out));
+  NAPI_OK(napi_create_int32(env, b->buf ? b->js_refs : 0, &out));
   return out;
 }
 
@@ -198,6 +201,9 @@ typedef struct {
   const void *src;
   size_t src_bytes;
   napi_ref src_ref; /* keeps the source Buffer alive while the copy runs */
+  napi_ref pin[2];  /* context / program externals of a job running on the pool */
+  ph_buf **held;    /* buffers the job uses: one library reference each until it completes */
+  int n_held;
   /* timed run */
   ph_program *prog;
   ph_arg *args;
@@ -250,6 +256,10 @@ static void job_complete(napi_env env, napi_status status, void *data) {
     napi_reject_deferred(env, j->deferred, v);
   }
   if (j->src_ref) napi_delete_reference(env, j->src_ref);
+  for (int i = 0; i < 2; ++i)
+    if (j->pin[i]) napi_delete_reference(env, j->pin[i]);
+  for (int i = 0; i < j->n_held; ++i) ph_buf_release(j->held[i]);
+  free(j->held);
   napi_delete_async_work(env, j->work);
   free(j->args);
   free(j->names);
@@ -262,6 +272,8 @@ static napi_value start_job(napi_env env, job *j, const char *name) {
       napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &resname) != napi_ok ||
       napi_create_async_work(env, NULL, resname, job_execute, job_complete, j, &j->work) != napi_ok ||
       napi_queue_async_work(env, j->work) != napi_ok) {
+    for (int i = 0; i < j->n_held; ++i) ph_buf_release(j->held[i]);
+    free(j->held);
     free(j->args);
     free(j->names);
     free(j);
@@ -282,6 +294,7 @@ static napi_value WaitFinish(napi_env env, napi_callback_info info) {
   if (argc > 1) get_i32(env, argv[1], &q);
   job *j = (job *)calloc(1, sizeof *j);
   j->kind = JOB_WAIT, j->ctx = c->ctx, j->queue = q;
+  napi_create_reference(env, argv[0], 1, &j->pin[0]);
   return start_job(env, j, "phaneron.waitFinish");
 }
 
@@ -326,6 +339,9 @@ static napi_value HostAccess(napi_env env, napi_callback_info info) {
   if (argc > 2) get_i32(env, argv[2], &q);
   job *j = (job *)calloc(1, sizeof *j);
   j->kind = JOB_HOST_ACCESS, j->buf = b->buf, j->dir = dir, j->queue = q;
+  j->held = (ph_buf **)malloc(sizeof *j->held);
+  j->held[0] = b->buf, j->n_held = 1;
+  ph_buf_addref(b->buf); /* release() before the promise settles must not free it under the copy */
   if (argc > 3 && napi_is_buffer(env, argv[3], &is_buf) == napi_ok && is_buf) {
     void *p;
     napi_get_buffer_info(env, argv[3], &p, &j->src_bytes);
@@ -507,6 +523,11 @@ static napi_value RunProgram(napi_env env, napi_callback_info info) {
     job *j = (job *)calloc(1, sizeof *j);
     j->kind = JOB_RUN_TIMED, j->ctx = c->ctx, j->prog = p->prog, j->args = args, j->names = names;
     j->n_args = (int)n, j->queue = q;
+    napi_create_reference(env, argv[0], 1, &j->pin[0]);
+    napi_create_reference(env, argv[1], 1, &j->pin[1]);
+    j->held = (ph_buf **)calloc(n ? n : 1, sizeof *j->held);
+    for (uint32_t i = 0; i < n; ++i)
+      if (args[i].kind == PH_ARG_BUF) ph_buf_addref(j->held[j->n_held++] = args[i].v.buf);
     return start_job(env, j, "phaneron.runProgram");
   }
   int rc = ph_run_program(c->ctx, p->prog, args, (int)n, q, NULL);
@@ -531,6 +552,119 @@ static napi_value BufferStats(napi_env env, napi_callback_info info) {
   return out;
 }
 
+/* ---- device-free helpers: kernel selection and the host colour maths (src/process/colourMaths.ts is run
+ *      by the reference's Loader / Saver; a caller that builds its own parameter buffers gets the same
+ *      numbers from the library) --------------------------------------------------------------------- */
+static int get_str(napi_env env, napi_value v, char *buf, size_t n) {
+  size_t len = 0;
+  return napi_get_value_string_utf8(env, v, buf, n, &len) == napi_ok;
+}
+static napi_value f32_array(napi_env env, const float *data, size_t n) {
+  napi_value ab, ta;
+  void *p = NULL;
+  if (napi_create_arraybuffer(env, n * 4, &p, &ab) != napi_ok) return NULL;
+  memcpy(p, data, n * 4);
+  if (napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta) != napi_ok) return NULL;
+  return ta;
+}
+
+/* resolveProgram(kernelSrc, name) -> { kernel, format, how } */
+static napi_value ResolveProgram(napi_env env, napi_callback_info info) {
+  size_t argc = 2, srclen = 0;
+  napi_value argv[2], out, v;
+  char name[128] = "", kernel[64] = "";
+  char *src = NULL;
+  int fmt = -1, how = 0;
+  static const char *hows[] = {"tag", "name", "text", "signature"};
+  static const char *fmts[] = {"v210", "yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"};
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 2 || !get_str(env, argv[1], name, sizeof name)) return throw_ph(env, "resolveProgram(kernelSrc, name)");
+  if (napi_get_value_string_utf8(env, argv[0], NULL, 0, &srclen) == napi_ok) {
+    src = (char *)malloc(srclen + 1);
+    napi_get_value_string_utf8(env, argv[0], src, srclen + 1, &srclen);
+  }
+  int rc = ph_program_resolve(src, name, kernel, sizeof kernel, &fmt, &how);
+  free(src);
+  if (rc != PH_OK) return throw_ph(env, "resolveProgram");
+  NAPI_OK(napi_create_object(env, &out));
+  napi_create_string_utf8(env, kernel, NAPI_AUTO_LENGTH, &v), napi_set_named_property(env, out, "kernel", v);
+  if (fmt >= 0 && fmt < 7) napi_create_string_utf8(env, fmts[fmt], NAPI_AUTO_LENGTH, &v);
+  else napi_get_null(env, &v);
+  napi_set_named_property(env, out, "format", v);
+  napi_create_string_utf8(env, hows[how & 3], NAPI_AUTO_LENGTH, &v), napi_set_named_property(env, out, "how", v);
+  return out;
+}
+
+/* gammaLut(kind: 'gamma2linear' | 'linear2gamma', colSpec) -> Float32Array(65536) */
+static napi_value GammaLut(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  char kind[32] = "", spec[32] = "";
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 2 || !get_str(env, argv[0], kind, sizeof kind) || !get_str(env, argv[1], spec, sizeof spec))
+    return throw_ph(env, "gammaLut(kind, colSpec)");
+  float *lut = (float *)malloc(65536 * 4);
+  int rc = 0 == strcmp(kind, "linear2gamma") ? ph_colour_linear2gamma_lut(spec, lut) : ph_colour_gamma2linear_lut(spec, lut);
+  napi_value out = rc == PH_OK ? f32_array(env, lut, 65536) : NULL;
+  free(lut);
+  return out ? out : throw_ph(env, "gammaLut");
+}
+
+/* colourMatrix(kind: 'ycbcr2rgb' | 'rgb2ycbcr', colSpec, numBits, lumaBlack, lumaWhite, chromaRange) -> Float32Array(12)
+ * colourMatrix('rgb2rgb', srcSpec, dstSpec) -> Float32Array(9) */
+static napi_value ColourMatrix(napi_env env, napi_callback_info info) {
+  size_t argc = 6;
+  napi_value argv[6];
+  char kind[32] = "", a[32] = "", b[32] = "";
+  int32_t n[4] = {10, 64, 940, 896};
+  float m[12];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 2 || !get_str(env, argv[0], kind, sizeof kind) || !get_str(env, argv[1], a, sizeof a))
+    return throw_ph(env, "colourMatrix(kind, colSpec, ...)");
+  if (0 == strcmp(kind, "rgb2rgb")) {
+    if (argc < 3 || !get_str(env, argv[2], b, sizeof b)) return throw_ph(env, "colourMatrix('rgb2rgb', src, dst)");
+    if (ph_colour_rgb2rgb_matrix(a, b, m) != PH_OK) return throw_ph(env, "colourMatrix");
+    return f32_array(env, m, 9);
+  }
+  for (size_t i = 0; i < 4 && i + 2 < argc; ++i) get_i32(env, argv[i + 2], &n[i]);
+  int rc = 0 == strcmp(kind, "rgb2ycbcr") ? ph_colour_rgb2ycbcr_matrix(a, n[0], n[1], n[2], n[3], m)
+                                          : ph_colour_ycbcr2rgb_matrix(a, n[0], n[1], n[2], n[3], m);
+  if (rc != PH_OK) return throw_ph(env, "colourMatrix");
+  return f32_array(env, m, 12);
+}
+
+/* transformMatrix(width, height, flipH, flipV, anchorX, anchorY, scaleX, scaleY, offsetX, offsetY, rotate) -> Float32Array(9)
+ * (transform.ts:119-171) */
+static napi_value TransformMatrix(napi_env env, napi_callback_info info) {
+  size_t argc = 11;
+  napi_value argv[11];
+  double d[11] = {0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0};
+  float m[9];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  for (size_t i = 0; i < argc && i < 11; ++i) {
+    napi_value num;
+    if (napi_coerce_to_number(env, argv[i], &num) == napi_ok) napi_get_value_double(env, num, &d[i]);
+  }
+  if (ph_transform_matrix((int)d[0], (int)d[1], d[2] != 0, d[3] != 0, d[4], d[5], d[6], d[7], d[8], d[9], d[10], m) != PH_OK)
+    return throw_ph(env, "transformMatrix");
+  return f32_array(env, m, 9);
+}
+
+/* planeBytes(format 0..6, width, height) -> [bytes per plane] (the Readers' / Writers' numBytes) */
+static napi_value PlaneBytes(napi_env env, napi_callback_info info) {
+  size_t argc = 3, pb[3] = {0, 0, 0};
+  napi_value argv[3], out, v;
+  int32_t fmt = 0, w = 0, h = 0;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 3 || !get_i32(env, argv[0], &fmt) || !get_i32(env, argv[1], &w) || !get_i32(env, argv[2], &h))
+    return throw_ph(env, "planeBytes(format, width, height)");
+  int n = fmt == 0 ? (pb[0] = (size_t)ph_v210_pitch_bytes((uint32_t)w) * (size_t)h, 1) : ph_pack_plane_bytes(fmt, (uint32_t)w, (uint32_t)h, pb);
+  if (n < 0) return throw_ph(env, "planeBytes");
+  NAPI_OK(napi_create_array_with_length(env, (size_t)n, &out));
+  for (int i = 0; i < n; ++i) napi_create_double(env, (double)pb[i], &v), napi_set_element(env, out, (uint32_t)i, v);
+  return out;
+}
+
 static napi_value AbiVersion(napi_env env, napi_callback_info info) {
   napi_value v;
   (void)info;
@@ -549,6 +683,8 @@ NAPI_MODULE_INIT() {
       {"createProgram", CreateProgram}, {"runProgram", RunProgram},   {"bufferStats", BufferStats},
       {"queueWaitQueue", QueueWaitQueue}, {"downloadAsync", DownloadAsync}, {"eventRecord", EventRecord},
       {"eventWait", EventWait},     {"eventDone", EventDone},       {"waitFinishSpin", WaitFinishSpin},
+      {"resolveProgram", ResolveProgram}, {"gammaLut", GammaLut},   {"colourMatrix", ColourMatrix},
+      {"transformMatrix", TransformMatrix}, {"planeBytes", PlaneBytes},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
     napi_value f;

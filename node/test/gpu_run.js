@@ -1,196 +1,183 @@
 'use strict'
-// GPU end-to-end check of the node boundary: the JS operator layer + dispatcher (node/) on the
-// real clContext (N-API addon -> libphaneron_hip.so).  Driven by tests/test_node_boundary.py:
-//   node gpu_run.js <workdir>
-// reads <workdir>/job.json + input .bin files, writes output .bin files and result.json.
+// GPU end-to-end run of the node boundary (tests/test_node_boundary.py drives it and checks every output
+// against the oracle): the N-API addon + index.js + this repo's own front end (device.js, jobs.js,
+// staging.js).  usage: node gpu_run.js <dir with job.json and input files>; writes result.json + *.bin.
 const fs = require('fs')
 const path = require('path')
 const crypto = require('crypto')
-const { clContext } = require('../index.js')
-const { ClProcessJobs } = require('../clJobQueue.js')
-const { ToRGBA, FromRGBA } = require('../process/io.js')
-const v210 = require('../process/v210.js')
-const { Interlace } = require('../process/packer.js')
-const ImageProcess = require('../process/imageProcess.js').default
-const Combine = require('../process/combine.js').default
-const Yadif = require('../process/yadif.js').default
-const Transform = require('../process/transform.js').default
+const { Rig } = require('../device.js')
+const { StagedChannel } = require('../staging.js')
+
+const dir = process.argv[2]
+const job = JSON.parse(fs.readFileSync(path.join(dir, 'job.json')))
+const load = (f) => fs.readFileSync(path.join(dir, f))
+const save = (f, b) => fs.writeFileSync(path.join(dir, f), b)
+const sha = (bufs) => { const h = crypto.createHash('sha256'); bufs.forEach((b) => h.update(b)); return h.digest('hex') }
 
 async function main() {
-	const dir = process.argv[2]
-	const job = JSON.parse(fs.readFileSync(path.join(dir, 'job.json')))
-	const result = {}
-	const ctx = new clContext({ platformIndex: 0, deviceIndex: 0, overlapping: true })
-	await ctx.initialise()
-	result.platform = ctx.getPlatformInfo()
-	const jobs = new ClProcessJobs(ctx).getJobs()
+	const rig = await Rig.open({ deviceIndex: 0 })
+	const ctx = rig.ctx
+	const result = { platform: ctx.getPlatformInfo() }
 
-	// 1. the reference's implied known-answer test: ramp -> read -> write == input
+	// ---- 1. one channel: n v210 layers -> read -> (layer 1 placed as a PiP) -> combine -> write v210 -----------
 	{
-		const W = 1920, H = 1080
-		const toRGBA = new ToRGBA(ctx, '709', '709', new v210.Reader(W, H), jobs)
-		await toRGBA.init()
-		const fromRGBA = new FromRGBA(ctx, '709', new v210.Writer(W, H, false), jobs)
-		await fromRGBA.init()
-		const srcs = await toRGBA.createSources('kat')
-		const rgba = await toRGBA.createDest({ width: W, height: H }, 'kat')
-		const dsts = await fromRGBA.createDests('kat')
-		const yuvSrc = Buffer.allocUnsafe(toRGBA.getTotalBytes())
-		v210.fillBuf(yuvSrc, W, H)
-		await toRGBA.loadFrame(yuvSrc, srcs, ctx.queue.load)
-		await ctx.waitFinish(ctx.queue.load)
-		toRGBA.processFrame('yuvRead', srcs, rgba)
-		await jobs.runQueue({ source: 'yuvRead', timestamp: 0 })
-		fromRGBA.processFrame('yuvWrite', rgba, dsts, Interlace.Progressive)
-		await jobs.runQueue({ source: 'yuvWrite', timestamp: 0 })
-		await fromRGBA.saveFrame(dsts, ctx.queue.unload)
-		result.rampCompare = yuvSrc.compare(Buffer.from(dsts[0]))
-		dsts[0].release()
+		const c = job.channel
+		const n = c.layers.length
+		const read = await rig.unpack('v210', c.width, c.height, c.readSpec, c.writeSpec)
+		const write = await rig.pack('v210', c.width, c.height, c.writeSpec, false)
+		const xf = await rig.transform(c.width, c.height)
+		const combine = await rig.combine(n, c.width, c.height)
+		const rgba = []
+		for (let l = 0; l < n; ++l) {
+			const src = await rig.planes('v210', c.width, c.height, 'readonly', `L${l} src`)
+			await rig.upload(src[0], load(c.layers[l]))
+			const img = await rig.image(c.width, c.height, `L${l}`)
+			rig.post({ source: `L${l}`, timestamp: 0 }, read(src, img), () => src[0].release())
+			rgba.push(img)
+		}
+		await rig.sync(ctx.queue.load)
+		const placed = await rig.image(c.width, c.height, 'L1 placed')
+		rig.post({ source: 'L1', timestamp: 0 }, xf(rgba[1], placed, await xf.matrix(c.pip)), () => rgba[1].release())
+		const layers = rgba.slice()
+		layers[1] = placed
+		const combined = await rig.image(c.width, c.height, 'combined')
+		const out = await rig.planes('v210', c.width, c.height, 'writeonly', 'out')
+		rig.post({ source: 'chan', timestamp: 0 }, combine(layers, combined), () => layers.forEach((b) => b.release()))
+		rig.post({ source: 'chan', timestamp: 0 }, write(combined, out, 0), () => combined.release())
+		// flushes requested together are served in order and drained once (jobs.js)
+		const ids = [0, 1, 2, 3].slice(0, n).map((l) => ({ source: `L${l}`, timestamp: 0 }))
+		await Promise.all(ids.concat([{ source: 'chan', timestamp: 0 }]).map((id) => rig.board.flush(id)))
+		await rig.download(out[0])
+		save('channel_out.bin', out[0])
+		out[0].release()
+		result.boardStats = Object.assign({}, rig.board.stats)
 	}
 
-	// 2. N-layer channel: read xN -> transform(layer 1 only, PiP) -> combine_N -> write, like
-	//    producer -> Mixer -> Combiner -> consumer (SURVEY 3.3)
+	// ---- 2. the reference scripts' known answer: ramp -> read -> write gives the ramp back ("Compare returned 0")
 	{
-		const { width: W, height: H, layers, readSpec, writeSpec } = job.channel
-		const dims = { width: W, height: H }
-		const toRGBA = new ToRGBA(ctx, readSpec, writeSpec, new v210.Reader(W, H), jobs)
-		await toRGBA.init()
-		const fromRGBA = new FromRGBA(ctx, writeSpec, new v210.Writer(W, H, false), jobs)
-		await fromRGBA.init()
-		const xf = new ImageProcess(ctx, new Transform(ctx, W, H), jobs)
-		await xf.init()
-		const comb = new ImageProcess(ctx, new Combine(layers.length, W, H), jobs)
-		await comb.init()
+		const w = 1920
+		const h = 1080
+		const read = await rig.unpack('v210', w, h, '709', '709')
+		const write = await rig.pack('v210', w, h, '709', false)
+		const src = await rig.planes('v210', w, h)
+		const dst = await rig.planes('v210', w, h, 'writeonly')
+		const img = await rig.image(w, h)
+		const ramp = load(job.ramp)
+		await rig.upload(src[0], ramp)
+		await rig.sync(ctx.queue.load)
+		await rig.run(read(src, img))
+		await rig.run(write(img, dst, 0))
+		await rig.sync()
+		await rig.download(dst[0])
+		result.rampCompare = Buffer.compare(ramp, dst[0])
+		;[src[0], dst[0], img].forEach((b) => b.release())
+	}
+
+	// ---- 3. yadif, send_field over a window of three frames (yadif.ts:88-145): two outputs per frame that has
+	//         both neighbours, parity = tff ^ !second, timestamps cur and cur + 1 --------------------------------
+	{
+		const y = job.yadif
+		const deint = await rig.yadif(y.width, y.height)
 		const frames = []
-		for (let l = 0; l < layers.length; ++l) {
-			const srcs = await toRGBA.createSources(`L${l}`)
-			await toRGBA.loadFrame(fs.readFileSync(path.join(dir, layers[l])), srcs, ctx.queue.load)
-			await ctx.waitFinish(ctx.queue.load)
-			let rgba = await toRGBA.createDest(dims, `L${l}`)
-			toRGBA.processFrame(`P${l}`, srcs, rgba)
-			if (l === 1) {
-				const dst = await ctx.createBuffer(W * H * 16, 'readwrite', 'coarse', dims, 'mixer')
-				const src = rgba
-				await xf.run(Object.assign({ input: src, output: dst }, job.channel.pip), { source: `P${l}`, timestamp: 0 }, () => src.release())
-				rgba = dst
+		for (let f = 0; f < y.frames.length; ++f) {
+			const img = await rig.image(y.width, y.height, `field ${f}`)
+			await rig.upload(img, load(y.frames[f]))
+			img.timestamp = 2 * f
+			frames.push(img)
+		}
+		await rig.sync(ctx.queue.load)
+		const stamps = []
+		let k = 0
+		for (let cur = 1; cur + 1 < frames.length; ++cur) {
+			for (const second of [false, true]) {
+				const out = await rig.image(y.width, y.height, 'deint')
+				out.timestamp = frames[cur].timestamp + (second ? 1 : 0)
+				const parity = (y.tff ? 1 : 0) ^ (second ? 0 : 1)
+				await rig.run(deint(frames[cur - 1], frames[cur], frames[cur + 1], out, { parity, tff: y.tff, skipSpatial: false }))
+				await rig.sync()
+				await rig.download(out)
+				save(`yadif_out${k++}.bin`, out)
+				stamps.push(out.timestamp)
+				out.release()
 			}
-			await jobs.runQueue({ source: `P${l}`, timestamp: 0 })
-			frames.push(rgba)
 		}
-		const out = await ctx.createBuffer(W * H * 16, 'readwrite', 'coarse', dims, 'chan')
-		await comb.run({ inputs: frames, output: out }, { source: 'chan combine', timestamp: 0 }, () => frames.forEach((f) => f.release()))
-		await jobs.runQueue({ source: 'chan combine', timestamp: 0 })
-		const dsts = await fromRGBA.createDests('chan')
-		fromRGBA.processFrame('chan out', out, dsts, Interlace.Progressive)
-		await jobs.runQueue({ source: 'chan out', timestamp: 0 })
-		await fromRGBA.saveFrame(dsts, ctx.queue.unload)
-		fs.writeFileSync(path.join(dir, 'channel_out.bin'), dsts[0])
-		dsts[0].release()
+		result.yadifTimestamps = stamps
+		frames.forEach((b) => b.release())
 	}
 
-	// 3. yadif send_field through the Yadif wrapper over already converted RGBA fields
-	{
-		const { width: W, height: H, frames: files, tff } = job.yadif
-		const dims = { width: W, height: H }
-		const yadif = new Yadif(ctx, jobs, W, H, { mode: 'send_field', tff }, true)
-		await yadif.init()
-		const outs = []
-		for (let f = 0; f < files.length; ++f) {
-			const b = await ctx.createBuffer(W * H * 16, 'readwrite', 'coarse', dims, `field${f}`)
-			await b.hostAccess('writeonly', ctx.queue.load, fs.readFileSync(path.join(dir, files[f])))
-			await ctx.waitFinish(ctx.queue.load)
-			b.timestamp = 2 * f
-			// the producer queues its loader job under this key; give runQueue something to run
-			jobs.add({ source: 'P9', timestamp: b.timestamp }, 'noop', null, {}, () => {})
-			jobs.get({ source: 'P9', timestamp: b.timestamp }).length = 0
-			await yadif.processFrame(b, outs, 'P9')
-		}
-		result.yadifTimestamps = outs.map((o) => o.timestamp)
-		for (let i = 0; i < outs.length; ++i) {
-			await outs[i].hostAccess('readonly', ctx.queue.unload)
-			fs.writeFileSync(path.join(dir, `yadif_out${i}.bin`), outs[i])
-		}
-		yadif.release()
-	}
-
-	// 4. the reference's other round-trip scripts (src/process/test/<fmt>Test.ts): pattern -> read -> write
-	//    (progressive) -> compare with the input; RGBA and output hashes are checked against the
-	//    reference kernels' own results (tests/golden/kat.json)
+	// ---- 4. the other wire formats: pattern -> read -> write (both fields) -> the same bytes back ------------------
 	result.formats = {}
-	for (const { fmt, width: W, height: H, spec } of job.formats || []) {
-		const mod = require(`../process/${fmt}.js`)
-		const toRGBA = new ToRGBA(ctx, spec, spec, new mod.Reader(W, H), jobs)
-		await toRGBA.init()
-		const fromRGBA = new FromRGBA(ctx, spec, new mod.Writer(W, H, false), jobs)
-		await fromRGBA.init()
-		const srcs = await toRGBA.createSources(fmt)
-		const rgba = await toRGBA.createDest({ width: W, height: H }, fmt)
-		const dsts = await fromRGBA.createDests(fmt)
-		const whole = Buffer.alloc(toRGBA.getTotalBytes())
-		mod.fillBuf(whole, W, H)
-		const planes = []
+	for (const f of job.formats) {
+		const read = await rig.unpack(f.fmt, f.width, f.height, f.spec, f.spec)
+		const write = await rig.pack(f.fmt, f.width, f.height, f.spec, true)
+		const src = await rig.planes(f.fmt, f.width, f.height)
+		const dst = await rig.planes(f.fmt, f.width, f.height, 'writeonly')
+		const img = await rig.image(f.width, f.height)
+		const pattern = load(f.file)
 		let off = 0
-		for (const n of toRGBA.getNumBytes()) { planes.push(whole.slice(off, off + n)); off += n }
-		await toRGBA.loadFrame(planes, srcs, ctx.queue.load)
-		await ctx.waitFinish(ctx.queue.load)
-		rgba.addRef() // keep it for the read-back below; the writer's callback releases one reference
-		toRGBA.processFrame(`${fmt} rd`, srcs, rgba)
-		await jobs.runQueue({ source: `${fmt} rd`, timestamp: 0 })
-		fromRGBA.processFrame(`${fmt} wr`, rgba, dsts, Interlace.Progressive)
-		await jobs.runQueue({ source: `${fmt} wr`, timestamp: 0 })
-		await fromRGBA.saveFrame(dsts, ctx.queue.unload)
-		await rgba.hostAccess('readonly', ctx.queue.unload)
-		const back = Buffer.concat(dsts.map((d) => Buffer.from(d)))
-		result.formats[fmt] = {
-			compare: whole.compare(back),
-			rgbaSha256: crypto.createHash('sha256').update(rgba).digest('hex'),
-			backSha256: crypto.createHash('sha256').update(back).digest('hex')
-		}
-		rgba.release()
-		dsts.forEach((d) => d.release())
+		const parts = []
+		for (const p of src) { parts.push(pattern.slice(off, off + p.length)); off += p.length }
+		for (let i = 0; i < src.length; ++i) await rig.upload(src[i], parts[i])
+		await rig.sync(ctx.queue.load)
+		await rig.run(read(src, img))
+		await rig.run(write(img, dst, 1))
+		await rig.run(write(img, dst, 3))
+		await rig.sync()
+		await rig.download(img)
+		for (const d of dst) await rig.download(d)
+		result.formats[f.fmt] = { rgbaSha256: sha([img]), backSha256: sha(dst), compare: Buffer.compare(Buffer.concat(parts), Buffer.concat(dst)) }
+		;[...src, ...dst, img].forEach((b) => b.release())
 	}
 
-	// 5. staged ring (node/staging.js) around the fused channel program: frames with different content
-	//    through 3 slots, outputs written per frame; also the same frames through the dispatcher
-	if (job.staged) {
-		const { width: W, height: H, layers: N, frames: F } = job.staged
-		const { StagedChannel } = require('../staging.js')
-		const { FusedV210Channel } = require('../process/fusedChannel.js')
-		const fused = new FusedV210Channel(ctx, job.staged.readSpec, job.staged.writeSpec, N, W, H, jobs)
-		await fused.init()
-		const vb = fused.getNumBytes()
-		const chan = new StagedChannel(ctx, Array(N).fill(vb), vb, (sources, output) => fused.launch(sources, output), 3, 'staged')
+	// ---- 5. staged ring (queue.load / process / unload overlapped on the device) around the fused channel program -----
+	{
+		const s = job.staged
+		const fused = await rig.fused(s.layers, s.width, s.height, s.readSpec, s.writeSpec)
+		const bytes = require('../index.js').planeBytes('v210', s.width, s.height)[0]
+		const chan = new StagedChannel(ctx, new Array(s.layers).fill(bytes), bytes, (sources, output) => rig.run(fused(sources, output)), 3, 'staged')
 		await chan.init()
 		const order = []
-		const consume = async (f, out) => { order.push(f); fs.writeFileSync(path.join(dir, `staged_out${f}.bin`), out) }
-		const fill = async (f, sources) => {
-			for (let l = 0; l < N; ++l) fs.readFileSync(path.join(dir, `staged_f${f}_l${l}.bin`)).copy(sources[l])
-		}
-		for (let f = 0; f < F; ++f) await chan.submit(fill, consume)
+		const consume = async (frameNo, out) => { order.push(frameNo); save(`staged_out${frameNo}.bin`, Buffer.from(out)) }
+		for (let f = 0; f < s.frames; ++f)
+			await chan.submit(async (frameNo, sources) => { sources.forEach((b, l) => load(`staged_f${frameNo}_l${l}.bin`).copy(b)) }, consume)
 		await chan.drain(consume)
-		result.stagedOrder = order
 		await chan.close()
-		// the same program through the job queue (one frame)
-		const srcs = []
-		for (let l = 0; l < N; ++l) {
-			const s = await fused.createSource(`L${l}`)
-			await s.hostAccess('writeonly', ctx.queue.load, fs.readFileSync(path.join(dir, `staged_f0_l${l}.bin`)))
-			srcs.push(s)
+		result.stagedOrder = order
+		// the same program through the JobBoard: its callback fires after the batch has run
+		const src = []
+		for (let l = 0; l < s.layers; ++l) {
+			const b = (await rig.planes('v210', s.width, s.height))[0]
+			await rig.upload(b, load(`staged_f0_l${l}.bin`))
+			src.push(b)
 		}
-		await ctx.waitFinish(ctx.queue.load)
-		const dst = await fused.createDest('q')
+		await rig.sync(ctx.queue.load)
+		const out = (await rig.planes('v210', s.width, s.height, 'writeonly'))[0]
 		let fired = false
-		fused.processFrame({ source: 'fused chan', timestamp: 0 }, srcs, dst, () => { fired = true })
-		await jobs.runQueue({ source: 'fused chan', timestamp: 0 })
-		await dst.hostAccess('readonly', ctx.queue.unload)
-		fs.writeFileSync(path.join(dir, 'fused_queue_out.bin'), dst)
+		rig.post({ source: 'fused', timestamp: 9 }, fused(src, out), () => { fired = true })
+		await rig.board.flush({ source: 'fused', timestamp: 9 })
 		result.fusedCallbackFired = fired
-		srcs.forEach((s) => s.release())
-		dst.release()
+		await rig.download(out)
+		save('fused_queue_out.bin', out)
+		;[...src, out].forEach((b) => b.release())
 	}
 
-	result.buffers = ctx.logBuffers()
-	fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify(result))
+	// ---- 6. errors surface as rejected promises / thrown Errors with the library's message -----------------------------
+	{
+		const errors = {}
+		const grab = async (label, fn) => { try { await fn(); errors[label] = null } catch (e) { errors[label] = e instanceof Error ? e.message : String(e) } }
+		await grab('unknownKey', () => rig.board.flush({ source: 'nobody', timestamp: 5 }))
+		await grab('unknownKernel', () => ctx.createProgram('phaneron:x', { name: 'sharpen', globalWorkItems: 1 }))
+		await grab('missingArgument', async () => {
+			const p = await ctx.createProgram('phaneron:v210', { name: 'read', globalWorkItems: 40, workItemsPerGroup: 40 })
+			await ctx.runProgram(p, { width: 1920 }, ctx.queue.process)
+		})
+		await grab('combineOne', () => rig.combine(1, 64, 64))
+		result.errors = errors
+	}
+
+	rig.close()
+	result.liveAfter = ctx.logBuffers ? rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers : -1
+	save('result.json', JSON.stringify(result))
 }
 
-main().catch((e) => { console.error(e && e.stack || e); process.exit(1) })
+main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })

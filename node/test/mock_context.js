@@ -1,11 +1,13 @@
 'use strict'
-// A recording stand-in for a nodencl-shaped clContext: no device, every call is appended to a
-// trace.  The same scenario (scenario.js) is run against the REFERENCE's operator code
-// (type-stripped, build container only -> tests/golden/host_trace.json) and against node/ -
-// the traces must be identical: same buffers, programs, kernel parameters, refcounts, order.
+// A recording stand-in for a nodencl-shaped clContext: no device, every call is appended to a trace.
+// scenario.js runs the REFERENCE's own operator + dispatcher code (type-stripped, build container only)
+// against it; the trace - buffers, programs, kernel parameters by argument name, refcounts, order - is
+// committed as tests/golden/host_trace.json and replayed on the real addon by replay.js.
+// options.resolve(kernelSrc, name): if given, its result is recorded with every createProgram (the
+// addon's device-free kernel selection applied to the text the reference really passes).
 const crypto = require('crypto')
 
-function makeMock() {
+function makeMock(mockOptions = {}) {
 	const trace = []
 	let nextBuf = 0
 	let nextProg = 0
@@ -48,22 +50,27 @@ function makeMock() {
 		},
 		async createProgram(kernel, options) {
 			const prog = { id: nextProg++, name: options.name }
-			trace.push({
-				op: 'createProgram', prog: prog.id, name: options.name,
+			const resolved = mockOptions.resolve ? { resolved: mockOptions.resolve(kernel, options.name) } : {}
+			trace.push(Object.assign(resolved, {
+				op: 'createProgram', prog: prog.id, name: options.name, srcSha: hash(Buffer.from(String(kernel))),
 				globalWorkItems: options.globalWorkItems === undefined ? null : (typeof options.globalWorkItems === 'number' ? options.globalWorkItems : Array.from(options.globalWorkItems)),
 				workItemsPerGroup: options.workItemsPerGroup === undefined ? null : options.workItemsPerGroup
-			})
+			}))
 			return prog
 		},
 		async runProgram(program, params, queue) {
 			const p = {}
 			const data = {}
+			const hex = {}
 			for (const k of Object.keys(params)) {
 				p[k] = describe(params[k])
 				// small read-only operands (matrices, LUTs, flip vectors): pin their contents too
-				if (Buffer.isBuffer(params[k]) && params[k].length <= 262144 && !/^(output|input|prev|cur|next|l\dIn|input\d|maskIn)$/.test(k)) data[k] = hash(params[k])
+				if (Buffer.isBuffer(params[k]) && params[k].length <= 262144 && !/^(output|input|prev|cur|next|l\dIn|input\d|maskIn)$/.test(k)) {
+					data[k] = hash(params[k])
+					if (params[k].length <= 64) hex[k] = params[k].toString('hex') // matrices, flip vectors: the values themselves
+				}
 			}
-			trace.push({ op: 'runProgram', prog: program.id, name: program.name, queue, params: p, data })
+			trace.push({ op: 'runProgram', prog: program.id, name: program.name, queue, params: p, data, hex })
 			return { dataToKernel: 0, kernelExec: 0, totalTime: 0 }
 		},
 		async waitFinish(queue) { trace.push({ op: 'waitFinish', queue: queue === undefined ? null : queue }) },

@@ -1,7 +1,9 @@
 'use strict'
-// The host-logic scenario: drives the operator layer + dispatcher under `root` (either the
-// type-stripped reference in oracle/_ref/js or this repo's node/) against the recording mock
-// and prints the trace as JSON.  usage: node scenario.js <root>
+// The host-logic scenario: drives the REFERENCE's operator layer + dispatcher (src/process/*, src/clJobQueue.ts,
+// type-stripped into <root> by oracle/refbuild/ts_strip.py - build container only) against the recording mock
+// and prints the trace as JSON.  usage: node scenario.js <root> [--resolve]
+//   --resolve: every createProgram also records what the addon's device-free resolver makes of the kernel text
+//              the reference passed (packer.ts:98, imageProcess.ts:69)
 const path = require('path')
 const { makeMock } = require('./mock_context')
 
@@ -31,7 +33,8 @@ async function expectThrow(trace, label, fn) {
 }
 
 async function main() {
-	const ctx = makeMock()
+	const resolve = process.argv.includes('--resolve') ? require('../index.js').resolveProgram : undefined
+	const ctx = makeMock({ resolve })
 	const trace = ctx.trace
 	const processJobs = new ClProcessJobs(ctx)
 	const jobs = processJobs.getJobs()
@@ -53,6 +56,7 @@ async function main() {
 	await ctx.waitFinish(ctx.queue.load)
 	toRGBA.processFrame('yuvRead', srcs, rgba)
 	await jobs.runQueue({ source: 'yuvRead', timestamp: 0 })
+	rgba.addRef() // FromRGBA releases its source when the job has run (io.ts:152-164); this scenario uses the frame again below
 	fromRGBA.processFrame('yuvWrite', rgba, dsts, Interlace.Progressive)
 	await jobs.runQueue({ source: 'yuvWrite', timestamp: 0 })
 	await fromRGBA.saveFrame(dsts, ctx.queue.unload)
@@ -65,7 +69,8 @@ async function main() {
 	const idsts = await fromI.createDests('outI')
 	const rgbaI = await ctx.createBuffer(W * H * 16, 'readwrite', 'coarse', dims, 'combined')
 	rgbaI.timestamp = 7
-	rgbaI.addRef()
+	rgbaI.addRef() // one reference per field job, each dropped when its job has run ...
+	rgbaI.addRef() // ... and the creator's stays: the frame is reused below
 	fromI.processFrame('chan1 decklink', rgbaI, idsts, Interlace.TopField)
 	fromI.processFrame('chan1 decklink', rgbaI, idsts, Interlace.BottomField)
 	await jobs.runQueue({ source: 'chan1 decklink', timestamp: 7 })
@@ -180,6 +185,7 @@ async function main() {
 		await ctx.waitFinish(ctx.queue.load)
 		to.processFrame(`${fmt} rd`, fs, fd)
 		await jobs.runQueue({ source: `${fmt} rd`, timestamp: 0 })
+		fd.addRef() // one reference per field job (macadamConsumer.ts:224-244 does the same for its two fields)
 		from.processFrame(`${fmt} wr`, fd, fo, Interlace.TopField)
 		from.processFrame(`${fmt} wr`, fd, fo, Interlace.BottomField)
 		await jobs.runQueue({ source: `${fmt} wr`, timestamp: 0 })

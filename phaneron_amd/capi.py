@@ -30,6 +30,7 @@ EXPORTS = [
     "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
     "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy", "ph_queue_query",
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
+    "ph_program_resolve",
 ]
 
 
@@ -98,6 +99,7 @@ def lib():
         "ph_event_destroy": (ci, [vp]),
         "ph_ctx_buffer_stats": (ci, [vp, C.POINTER(cs), C.POINTER(cs), C.POINTER(cs)]),
         "ph_program_create": (ci, [vp, C.c_char_p, C.c_char_p, C.POINTER(cu), ci, cu, C.POINTER(vp)]),
+        "ph_program_resolve": (ci, [C.c_char_p, C.c_char_p, C.c_char_p, cs, C.POINTER(ci), C.POINTER(ci)]),
         "ph_program_destroy": (ci, [vp]),
         "ph_program_kernel": (C.c_char_p, [vp]),
         "ph_run_program": (ci, [vp, vp, C.POINTER(PhArg), ci, ci, C.POINTER(RunTimings)]),
@@ -179,6 +181,20 @@ def transform_matrix(width, height, flip_h=False, flip_v=False, anchor_x=0.0, an
     check(lib().ph_transform_matrix(width, height, int(flip_h), int(flip_v), anchor_x, anchor_y, scale_x, scale_y,
                                     offset_x, offset_y, rotate, out))
     return out
+
+
+RESOLVED_HOW = {0: "tag", 1: "name", 2: "text", 3: "signature"}
+
+
+def resolve_program(source, name):
+    """Which precompiled kernel createProgram(source, {name}) selects - no context, no device.
+    Returns (kernel id, pack format name or None, how: "tag" | "name" | "text" | "signature")."""
+    buf = C.create_string_buffer(64)
+    fmt, how = C.c_int(), C.c_int()
+    src = source.encode() if isinstance(source, str) else source
+    check(lib().ph_program_resolve(src, name.encode(), buf, 64, C.byref(fmt), C.byref(how)))
+    names = {v: k for k, v in FORMATS.items()}
+    return buf.value.decode(), names.get(fmt.value), RESOLVED_HOW[how.value]
 
 
 def v210_pitch_bytes(width):

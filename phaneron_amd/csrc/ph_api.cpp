@@ -3,17 +3,23 @@
 // `runProgram` contract the reference's clJobQueue drives) and the typed entry points.
 //
 // No CPU path exists here: every entry point that does work needs a HIP device.
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/phaneron_hip.h"
 #include "ph_kernels.h"
 #include "ph_lut_host.h"
+#include "ph_program.h"
+
+using ph::KernelId;
+using namespace ph;  // K_* kernel ids
 
 namespace {
 
@@ -42,6 +48,12 @@ struct LutEntry {
   void *blob_dev = nullptr;
 };
 
+// Lifetime: buffers, programs, events and graphs each hold a reference on their context, so the storage a
+// handle points into outlives the handle whatever order a garbage collector finalises them in.
+// ph_ctx_destroy drains the queues, marks the context closed (new work is refused) and drops the creator's
+// reference; the last handle released tears the device state down.
+// Threading: `mu` guards the pool, the LUT registry and the counters (the node addon calls hostAccess and
+// timed runProgram from libuv pool threads while the JS thread creates and releases buffers).
 struct ph_ctx {
   int device = 0;
   std::map<const void *, LutEntry> luts;  // device f32 table -> compressed LDS form
@@ -50,7 +62,9 @@ struct ph_ctx {
   hipDeviceProp_t props;
   std::multimap<size_t, void *> pool;  // free device blocks by exact size
   size_t pooled_bytes = 0, live_buffers = 0, live_bytes = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::mutex mu;
+  std::atomic<int> refs{1};
+  std::atomic<bool> closed{false};
 };
 
 struct ph_buf {
@@ -59,28 +73,13 @@ struct ph_buf {
   void *hptr;  // pinned host mirror, lazily allocated
   size_t bytes;
   int width, height;
-  int refs;
+  std::atomic<int> refs;
   bool owned;
   bool host_dirty;
-  bool lut_dirty;  // 256 KiB of host data went in since the table was last compressed
+  bool lut_dirty;  // host data went into a table-sized buffer since its LDS form was last built
   std::string owner;
 };
 
-enum KernelId {
-  K_PACK_READ,   // any pack format other than v210 (ph_program::format)
-  K_PACK_WRITE,
-  K_V210_READ,
-  K_V210_WRITE,
-  K_YADIF,
-  K_TRANSFORM,
-  K_RESIZE,
-  K_COMBINE,
-  K_DISSOLVE,
-  K_TWIPE,
-  K_MIXER,
-  K_WIPE,
-  K_FUSED_V210  // extension: v210 x N -> read, combine_N, write in one launch (ph_fused_v210_combine)
-};
 
 struct ph_program {
   ph_ctx *ctx;
@@ -95,6 +94,7 @@ struct ph_program {
 namespace {
 
 int set_device(ph_ctx *ctx) {
+  if (ctx->closed.load()) return fail(PH_E_INVALID, "the context has been destroyed");
   PH_HIP(hipSetDevice(ctx->device));
   return PH_OK;
 }
@@ -102,12 +102,15 @@ int set_device(ph_ctx *ctx) {
 hipStream_t stream_of(ph_ctx *ctx, int queue) { return ctx->streams[(queue >= 0 && queue < 3) ? queue : PH_QUEUE_PROCESS]; }
 
 int pool_alloc(ph_ctx *ctx, size_t bytes, void **out) {
-  auto it = ctx->pool.find(bytes);
-  if (it != ctx->pool.end()) {
-    *out = it->second;
-    ctx->pool.erase(it);
-    ctx->pooled_bytes -= bytes;
-    return PH_OK;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    auto it = ctx->pool.find(bytes);
+    if (it != ctx->pool.end()) {
+      *out = it->second;
+      ctx->pool.erase(it);
+      ctx->pooled_bytes -= bytes;
+      return PH_OK;
+    }
   }
   PH_HIP(hipMalloc(out, bytes ? bytes : 1));
   return PH_OK;
@@ -117,21 +120,29 @@ void pool_free(ph_ctx *ctx, size_t bytes, void *p) {
   // Recycling is stream-safe because all kernels touching a buffer were enqueued (in order)
   // before its last release, and the next user enqueues after it on the same in-order queues;
   // cross-queue users call ph_wait_finish first, exactly as the reference does (io.ts, clJobQueue.ts:131).
+  std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->pool.emplace(bytes, p);
   ctx->pooled_bytes += bytes;
 }
 
-// Does the OpenCL C text define `__kernel void <name>(` with an argument called `arg`?
-bool src_kernel_has_arg(const char *src, const char *name, const char *arg) {
-  if (!src) return false;
-  std::string pat = std::string("void ") + name + "(";
-  const char *k = strstr(src, pat.c_str());
-  if (!k) return false;
-  const char *end = strchr(k, ')');
-  if (!end) return false;
-  std::string sig(k, end);
-  return sig.find(arg) != std::string::npos;
+void ctx_ref(ph_ctx *ctx) { ctx->refs.fetch_add(1); }
+
+// drops one reference; the last one frees the device state (streams, pool, LUT blobs)
+void ctx_unref(ph_ctx *ctx) {
+  if (ctx->refs.fetch_sub(1) != 1) return;
+  hipSetDevice(ctx->device);
+  for (int i = 0; i < 3; ++i)
+    if (ctx->streams[i]) {
+      hipStreamSynchronize(ctx->streams[i]);
+      hipStreamDestroy(ctx->streams[i]);
+    }
+  for (auto &kv : ctx->pool) hipFree(kv.second);
+  for (auto &kv : ctx->luts)
+    if (kv.second.blob_dev) hipFree(kv.second.blob_dev);
+  delete ctx;
 }
+
+int closed_error(const char *fn) { return fail(PH_E_INVALID, "%s: the context has been destroyed", fn); }
 
 const ph_arg *find_arg(const ph_arg *args, int n, const char *name) {
   for (int i = 0; i < n; ++i)
@@ -184,26 +195,17 @@ int ph_ctx_create(int device_index, ph_ctx **out) {
   PH_HIP(hipSetDevice(device_index));
   PH_HIP(hipGetDeviceProperties(&ctx->props, device_index));
   for (int i = 0; i < 3; ++i) PH_HIP(hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking));
-  PH_HIP(hipEventCreate(&ctx->ev0));
-  PH_HIP(hipEventCreate(&ctx->ev1));
   *out = ctx;
   return PH_OK;
 }
 
 int ph_ctx_destroy(ph_ctx *ctx) {
   if (!ctx) return PH_OK;
+  if (ctx->closed.exchange(true)) return PH_OK;  // second destroy: the creator's reference is already gone
   hipSetDevice(ctx->device);
   for (int i = 0; i < 3; ++i)
-    if (ctx->streams[i]) {
-      hipStreamSynchronize(ctx->streams[i]);
-      hipStreamDestroy(ctx->streams[i]);
-    }
-  for (auto &kv : ctx->pool) hipFree(kv.second);
-  for (auto &kv : ctx->luts)
-    if (kv.second.blob_dev) hipFree(kv.second.blob_dev);
-  if (ctx->ev0) hipEventDestroy(ctx->ev0);
-  if (ctx->ev1) hipEventDestroy(ctx->ev1);
-  delete ctx;
+    if (ctx->streams[i]) hipStreamSynchronize(ctx->streams[i]);
+  ctx_unref(ctx);  // handles still alive keep the storage they point into; the last one tears down
   return PH_OK;
 }
 
@@ -218,6 +220,7 @@ void *ph_ctx_stream(ph_ctx *ctx, int queue) { return ctx ? (void *)stream_of(ctx
 
 int ph_wait_finish(ph_ctx *ctx, int queue) {
   if (!ctx) return fail(PH_E_INVALID, "ph_wait_finish: ctx is NULL");
+  if (ctx->closed.load()) return closed_error("ph_wait_finish");
   PH_HIP(hipStreamSynchronize(stream_of(ctx, queue)));
   return PH_OK;
 }
@@ -235,44 +238,55 @@ int ph_buf_create(ph_ctx *ctx, size_t bytes, int access, int svm_type, int width
   void *d = nullptr;
   rc = pool_alloc(ctx, bytes, &d);
   if (rc) return rc;
-  ph_buf *b = new ph_buf{ctx, d, nullptr, bytes, width > 0 ? width : 0, height > 0 ? height : 0, 1, true, false,
+  ph_buf *b = new ph_buf{ctx, d, nullptr, bytes, width > 0 ? width : 0, height > 0 ? height : 0, {1}, true, false,
                          false, owner ? owner : ""};
-  ctx->live_buffers++;
-  ctx->live_bytes += bytes;
+  ctx_ref(ctx);
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->live_buffers++;
+    ctx->live_bytes += bytes;
+  }
   *out = b;
   return PH_OK;
 }
 
 int ph_buf_wrap(ph_ctx *ctx, void *device_ptr, size_t bytes, int width, int height, ph_buf **out) {
   if (!ctx || !out || !device_ptr) return fail(PH_E_INVALID, "ph_buf_wrap: NULL argument");
-  *out = new ph_buf{ctx, device_ptr, nullptr, bytes, width > 0 ? width : 0, height > 0 ? height : 0, 1, false, false,
+  if (ctx->closed.load()) return closed_error("ph_buf_wrap");
+  *out = new ph_buf{ctx, device_ptr, nullptr, bytes, width > 0 ? width : 0, height > 0 ? height : 0, {1}, false, false,
                     false, "wrapped"};
-  ctx->live_buffers++;
+  ctx_ref(ctx);
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->live_buffers++;
+  }
   return PH_OK;
 }
 
 int ph_buf_addref(ph_buf *b) {
   if (!b) return fail(PH_E_INVALID, "ph_buf_addref: NULL buffer");
-  return ++b->refs, PH_OK;
+  return b->refs.fetch_add(1), PH_OK;
 }
 
 int ph_buf_release(ph_buf *b) {
   if (!b) return fail(PH_E_INVALID, "ph_buf_release: NULL buffer");
-  if (--b->refs > 0) return PH_OK;
+  if (b->refs.fetch_sub(1) > 1) return PH_OK;
   ph_ctx *ctx = b->ctx;
   hipSetDevice(ctx->device);
   ph_lut_unregister(ctx, b->dptr);  // the storage goes back to the pool: forget any LUT form of it
-  if (b->owned) {
-    pool_free(ctx, b->bytes, b->dptr);
-    ctx->live_bytes -= b->bytes;
-  }
+  if (b->owned) pool_free(ctx, b->bytes, b->dptr);
   if (b->hptr) hipHostFree(b->hptr);
-  ctx->live_buffers--;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (b->owned) ctx->live_bytes -= b->bytes;
+    ctx->live_buffers--;
+  }
   delete b;
+  ctx_unref(ctx);
   return PH_OK;
 }
 
-int ph_buf_refcount(const ph_buf *b) { return b ? b->refs : 0; }
+int ph_buf_refcount(const ph_buf *b) { return b ? b->refs.load() : 0; }
 size_t ph_buf_bytes(const ph_buf *b) { return b ? b->bytes : 0; }
 void *ph_buf_device_ptr(ph_buf *b) { return b ? b->dptr : nullptr; }
 int ph_buf_dims(const ph_buf *b, int *w, int *h) {
@@ -309,7 +323,7 @@ int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t by
         memcpy(b->hptr, src, bytes);
         PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, bytes, hipMemcpyHostToDevice, s));
         b->host_dirty = false;
-        b->lut_dirty = (bytes == 65536 * 4);
+        b->lut_dirty = b->lut_dirty || b->bytes >= 65536 * 4;
       } else {
         b->host_dirty = true;  // caller fills the mirror, then calls hostAccess('none')
       }
@@ -318,7 +332,7 @@ int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t by
       if (b->host_dirty) {
         PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, b->bytes, hipMemcpyHostToDevice, s));
         b->host_dirty = false;
-        b->lut_dirty = (b->bytes == 65536 * 4);
+        b->lut_dirty = b->lut_dirty || b->bytes >= 65536 * 4;
       }
       return PH_OK;
     case PH_HOST_READONLY:
@@ -382,6 +396,7 @@ int ph_event_record(ph_ctx *ctx, int queue, ph_event **out) {
     return fail(PH_E_HIP, "ph_event_record: %s", hipGetErrorString(e));
   }
   *out = new ph_event{ctx, ev};
+  ctx_ref(ctx);
   return PH_OK;
 }
 
@@ -403,8 +418,10 @@ int ph_event_query(ph_event *ev) {
 
 int ph_event_destroy(ph_event *ev) {
   if (!ev) return PH_OK;
+  ph_ctx *ctx = ev->ctx;
   hipEventDestroy(ev->ev);
   delete ev;
+  ctx_unref(ctx);
   return PH_OK;
 }
 
@@ -437,6 +454,7 @@ int ph_graph_end(ph_ctx *ctx, int queue, ph_graph **out) {
     return fail(PH_E_HIP, "ph_graph_end: hipGraphInstantiate: %s", hipGetErrorString(e));
   }
   *out = new ph_graph{ctx, g, exec};
+  ctx_ref(ctx);
   return PH_OK;
 }
 
@@ -450,14 +468,17 @@ int ph_graph_launch(ph_graph *g, int queue) {
 
 int ph_graph_destroy(ph_graph *g) {
   if (!g) return PH_OK;
+  ph_ctx *ctx = g->ctx;
   hipGraphExecDestroy(g->exec);
   hipGraphDestroy(g->graph);
   delete g;
+  ctx_unref(ctx);
   return PH_OK;
 }
 
 int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes) {
   if (!ctx) return fail(PH_E_INVALID, "ph_ctx_buffer_stats: ctx is NULL");
+  std::lock_guard<std::mutex> lock(ctx->mu);
   if (live_buffers) *live_buffers = ctx->live_buffers;
   if (live_bytes) *live_bytes = ctx->live_bytes;
   if (pooled_bytes) *pooled_bytes = ctx->pooled_bytes;
@@ -467,14 +488,19 @@ int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, s
 // ---- gamma LUT registry ------------------------------------------------------------------------
 int ph_lut_unregister(ph_ctx *ctx, const void *dev) {
   if (!ctx) return fail(PH_E_INVALID, "ph_lut_unregister: ctx is NULL");
-  auto it = ctx->luts.find(dev);
-  if (it == ctx->luts.end()) return PH_OK;
-  if (it->second.blob_dev) {
+  void *blob = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    auto it = ctx->luts.find(dev);
+    if (it == ctx->luts.end()) return PH_OK;
+    blob = it->second.blob_dev;
+    ctx->luts.erase(it);
+  }
+  if (blob) {
     // kernels already enqueued may still read the blob: drain before freeing
     for (int q = 0; q < 3; ++q) hipStreamSynchronize(ctx->streams[q]);
-    hipFree(it->second.blob_dev);
+    hipFree(blob);
   }
-  ctx->luts.erase(it);
   return PH_OK;
 }
 
@@ -491,12 +517,16 @@ int ph_lut_register(ph_ctx *ctx, const void *dev, const float *host) {
     PH_HIP(hipMemcpy(e.blob_dev, blob.data(), info.bytes, hipMemcpyHostToDevice));
     e.view = ph::lut_view(info, e.blob_dev);
   }
-  ctx->luts[dev] = e;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->luts[dev] = e;
+  }
   return e.view.bytes ? 1 : 0;
 }
 
 int ph_lut_query(ph_ctx *ctx, const void *dev, uint32_t *lds_bytes, uint32_t *toe, uint32_t *shift) {
   if (!ctx) return fail(PH_E_INVALID, "ph_lut_query: ctx is NULL");
+  std::lock_guard<std::mutex> lock(ctx->mu);
   auto it = ctx->luts.find(dev);
   const bool have = it != ctx->luts.end();
   if (lds_bytes) *lds_bytes = have ? it->second.view.bytes : 0;
@@ -512,10 +542,18 @@ int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
 }
 
 // the compressed form of a device LUT pointer, or NULL (unknown / plain / LDS path switched off)
+// Returned by value into a small per-thread ring (a call site holds at most two at a time): the registry
+// entry itself may be replaced by another thread once the lock is dropped.
 static const ph::LutView *lds_view(ph_ctx *ctx, const void *dev) {
   if (!ctx->use_lds_lut) return nullptr;
+  thread_local ph::LutView slots[4];
+  thread_local unsigned next = 0;
+  std::lock_guard<std::mutex> lock(ctx->mu);
   auto it = ctx->luts.find(dev);
-  return (it != ctx->luts.end() && it->second.view.bytes) ? &it->second.view : nullptr;
+  if (it == ctx->luts.end() || !it->second.view.bytes) return nullptr;
+  ph::LutView *v = &slots[next++ & 3u];
+  *v = it->second.view;
+  return v;
 }
 
 // a ph_buf used as `gammaLut`: (re)compress from its host mirror if new data went in
@@ -528,74 +566,37 @@ static void refresh_buf_lut(ph_ctx *ctx, ph_buf *b) {
 }
 
 // ---- programs ---------------------------------------------------------------------------------
+int ph_program_resolve(const char *src, const char *name, char *kernel_id, size_t kernel_id_len, int *format, int *how) {
+  ph::ProgramChoice c;
+  std::string err;
+  const int rc = ph::resolve_program(src, name, c, err);
+  if (rc != PH_OK) return fail(rc, "%s", err.c_str());
+  if (kernel_id && kernel_id_len) snprintf(kernel_id, kernel_id_len, "%s", c.kernel.c_str());
+  if (format) *format = (c.id <= K_V210_WRITE) ? c.format : -1;
+  if (how) *how = c.how;
+  return PH_OK;
+}
+
 int ph_program_create(ph_ctx *ctx, const char *src, const char *name, const uint32_t *gwi, int n_dims, uint32_t wipg,
                       ph_program **out) {
   if (!ctx || !name || !out) return fail(PH_E_INVALID, "ph_program_create: NULL argument");
-  ph_program p{ctx, K_V210_READ, 0, PH_FMT_V210, "", {0, 0}, wipg};
+  ph::ProgramChoice c;
+  std::string err;
+  const int rc = ph::resolve_program(src, name, c, err);
+  if (rc != PH_OK) return fail(rc, "%s", err.c_str());
+  ph_program p{ctx, c.id, c.n_layers, c.format, c.kernel, {0, 0}, wipg};
   for (int i = 0; i < n_dims && i < 2; ++i) p.global[i] = gwi ? gwi[i] : 0;
-  const bool tagged = src && 0 == strncmp(src, "phaneron:", 9);
-  const char *tag = tagged ? src + 9 : "";
-  if (0 == strcmp(name, "read") || 0 == strcmp(name, "write")) {
-    // every pack format names its kernels read/write; tag or argument list tells them apart
-    const bool is_read = name[0] == 'r';
-    static const char *fmt_names[] = {"v210", "yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"};
-    int fmt = -1;
-    if (tagged) {
-      for (int i = 0; i < 7; ++i)
-        if (0 == strcmp(tag, fmt_names[i])) fmt = i;
-    } else if (src_kernel_has_arg(src, name, "uint4") && src_kernel_has_arg(src, name, "colMatrix")) {
-      fmt = PH_FMT_V210;  // v210.ts:25-30,113-118
-    } else if (src_kernel_has_arg(src, name, is_read ? "inputC" : "outputC")) {
-      fmt = PH_FMT_NV12;  // nv12.ts:25-26
-    } else if (src_kernel_has_arg(src, name, "ushort8")) {
-      fmt = PH_FMT_YUV422P10;  // yuv422p10.ts:25
-    } else if (src_kernel_has_arg(src, name, is_read ? "inputU" : "outputU")) {
-      // yuv422p8 and yuv420p share a signature; only the 4:2:0 kernels address line pairs
-      fmt = (src && strstr(src, is_read ? "inOffUV" : "outOffUV")) ? PH_FMT_YUV420P : PH_FMT_YUV422P8;
-    } else if (src_kernel_has_arg(src, name, "uchar4") && !src_kernel_has_arg(src, name, "colMatrix")) {
-      fmt = (src && strstr(src, "bgra")) ? PH_FMT_BGRA8 : PH_FMT_RGBA8;  // bgra8.ts:49
-    }
-    if (fmt < 0) return fail(PH_E_UNKNOWN_KERNEL, "cannot tell which pack format the '%s' kernel belongs to", name);
-    p.format = fmt;
-    if (fmt == PH_FMT_V210) {
-      p.id = is_read ? K_V210_READ : K_V210_WRITE;
-      p.kernel = is_read ? "v210_read" : "v210_write";
-    } else {
-      p.id = is_read ? K_PACK_READ : K_PACK_WRITE;
-      p.kernel = std::string(fmt_names[fmt]) + (is_read ? "_read" : "_write");
-    }
-  } else if (0 == strcmp(name, "yadif")) {
-    p.id = K_YADIF, p.kernel = "yadif";
-  } else if (0 == strcmp(name, "transform")) {
-    p.id = K_TRANSFORM, p.kernel = "transform";
-  } else if (0 == strcmp(name, "resize")) {
-    p.id = K_RESIZE, p.kernel = "resize";
-  } else if (0 == strncmp(name, "combine_", 8)) {
-    const int n = atoi(name + 8);
-    if (n < 2 || n > ph::kMaxLayers) return fail(PH_E_UNKNOWN_KERNEL, "combine_%d: 2..%d layers are built", n, ph::kMaxLayers);
-    p.id = K_COMBINE, p.n_layers = n, p.kernel = name;
-  } else if (0 == strncmp(name, "fused_v210_combine_", 19)) {
-    // not a reference kernel: the headline chain as one program, global = [width, height]
-    const int n = atoi(name + 19);
-    if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_UNKNOWN_KERNEL, "fused_v210_combine_%d: 1..%d layers are built", n, ph::kMaxLayers);
-    p.id = K_FUSED_V210, p.n_layers = n, p.kernel = name;
-  } else if (0 == strcmp(name, "transition_dissolve")) {
-    p.id = K_DISSOLVE, p.kernel = name;
-  } else if (0 == strcmp(name, "transition_wipe")) {
-    p.id = K_TWIPE, p.kernel = name;
-  } else if (0 == strcmp(name, "mixer")) {
-    p.id = K_MIXER, p.kernel = name;
-  } else if (0 == strcmp(name, "wipe")) {
-    p.id = K_WIPE, p.kernel = name;
-  } else {
-    return fail(PH_E_UNKNOWN_KERNEL, "unknown kernel '%s'", name);
-  }
+  if (ctx->closed.load()) return closed_error("ph_program_create");
   *out = new ph_program(p);
+  ctx_ref(ctx);
   return PH_OK;
 }
 
 int ph_program_destroy(ph_program *p) {
+  if (!p) return PH_OK;
+  ph_ctx *ctx = p->ctx;
   delete p;
+  ctx_unref(ctx);
   return PH_OK;
 }
 
@@ -610,7 +611,7 @@ static int flush_dirty_args(ph_ctx *ctx, const ph_arg *args, int n, int queue) {
     if (b->host_dirty && b->hptr) {
       PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, b->bytes, hipMemcpyHostToDevice, stream_of(ctx, queue)));
       b->host_dirty = false;
-      b->lut_dirty = (b->bytes == 65536 * 4);
+      b->lut_dirty = b->lut_dirty || b->bytes >= 65536 * 4;
     }
   }
   return PH_OK;
@@ -791,13 +792,24 @@ int ph_run_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args
   if (!t) return dispatch(ctx, prog, args, n_args, queue);
   hipStream_t s = stream_of(ctx, queue);
   const auto t0 = std::chrono::steady_clock::now();
-  PH_HIP(hipEventRecord(ctx->ev0, s));
-  rc = dispatch(ctx, prog, args, n_args, queue);
-  if (rc) return rc;
-  PH_HIP(hipEventRecord(ctx->ev1, s));
-  PH_HIP(hipEventSynchronize(ctx->ev1));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // per call: timed runs may come from several threads
+  PH_HIP(hipEventCreate(&ev0));
+  if (hipEventCreate(&ev1) != hipSuccess) {
+    hipEventDestroy(ev0);
+    return fail(PH_E_HIP, "ph_run_program: hipEventCreate failed");
+  }
+  hipError_t te = hipEventRecord(ev0, s);
+  rc = te == hipSuccess ? dispatch(ctx, prog, args, n_args, queue) : fail(PH_E_HIP, "hipEventRecord: %s", hipGetErrorString(te));
   float ms = 0.f;
-  PH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (rc == PH_OK) {
+    te = hipEventRecord(ev1, s);
+    if (te == hipSuccess) te = hipEventSynchronize(ev1);
+    if (te == hipSuccess) te = hipEventElapsedTime(&ms, ev0, ev1);
+    if (te != hipSuccess) rc = fail(PH_E_HIP, "ph_run_program: timing failed: %s", hipGetErrorString(te));
+  }
+  hipEventDestroy(ev0);
+  hipEventDestroy(ev1);
+  if (rc) return rc;
   const auto t1 = std::chrono::steady_clock::now();
   t->data_to_kernel = 0;  // arguments are device-resident: nothing moves at launch
   t->kernel_exec = (uint32_t)(ms * 1000.0f + 0.5f);
@@ -882,7 +894,8 @@ int ph_fused_v210_combine_batch(ph_ctx *ctx, int queue, int jobs, int n, const v
                                 const void *wr_cm, const void *wr_lut) {
   if (jobs < 1 || jobs > ph::kMaxBatch) return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: 1..%d jobs", ph::kMaxBatch);
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: 1..%d layers", ph::kMaxLayers);
-  if (!layers || !outs) return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: NULL argument");
+  if (!layers || !outs || !rd_cm || !rd_lut || !rd_gm || !wr_cm || !wr_lut)
+    return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: NULL argument");
   for (int j = 0; j < jobs; ++j) {
     if (!outs[j]) return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: output %d is NULL", j);
     for (int l = 0; l < n; ++l)

@@ -1,0 +1,34 @@
+// ph_program.h - device-free kernel selection for createProgram (ph_program.cpp)
+#pragma once
+#include <string>
+
+namespace ph {
+
+enum KernelId {
+  K_PACK_READ,   // any pack format other than v210 (ProgramChoice::format)
+  K_PACK_WRITE,
+  K_V210_READ,
+  K_V210_WRITE,
+  K_YADIF,
+  K_TRANSFORM,
+  K_RESIZE,
+  K_COMBINE,
+  K_DISSOLVE,
+  K_TWIPE,
+  K_MIXER,
+  K_WIPE,
+  K_FUSED_V210  // extension: v210 x N -> read, combine_N, write in one launch (ph_fused_v210_combine)
+};
+
+struct ProgramChoice {
+  KernelId id;
+  int n_layers;        // combine_N / fused_v210_combine_N
+  int format;          // PH_FMT_* of a read / write program
+  std::string kernel;  // "v210_read", "yuv420p_write", "combine_4", ...
+  int how;             // PH_RESOLVED_*
+};
+
+// PH_OK, or PH_E_UNKNOWN_KERNEL / PH_E_INVALID with a message in err
+int resolve_program(const char *kernel_src, const char *name, ProgramChoice &choice, std::string &err);
+
+}  // namespace ph

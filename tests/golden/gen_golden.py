@@ -159,6 +159,15 @@ def main():
     with open(os.path.join(HERE, "host_trace.json"), "w") as f:
         json.dump(json.loads(tr), f, indent=0, sort_keys=True)
         f.write("\n")
+    # which pack format each `read` / `write` program of that trace belongs to, keyed by the fingerprint the
+    # mock recorded of the kernel text (a hash, so the trace can be replayed where the text cannot go)
+    shas = {}
+    for fmt in ("v210", "yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"):
+        txt = open(os.path.join(ROOT, "oracle", "_ref", "work", "cl", fmt + ".cl")).read()
+        shas[hashlib.sha256(txt.encode()).hexdigest()[:16]] = fmt
+    with open(os.path.join(HERE, "kernel_text_sha.json"), "w") as f:
+        json.dump(shas, f, indent=1, sort_keys=True)
+        f.write("\n")
     np.savez_compressed(os.path.join(HERE, "kernels.npz"), **out)
     print("wrote %d kernel cases, host_maths.json, kat.json" % len(out))
 

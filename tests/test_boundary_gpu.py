@@ -237,3 +237,33 @@ def test_recorded_batch_replays_with_new_contents(ctx):
     for b in srcs + rgba + [comb, out]:
         b.release()
     col.release()
+
+
+def test_handles_outlive_their_context_in_any_order():
+    """A garbage collector finalises a clContext and its OpenCLBuffers / programs / events in no particular
+    order (node/ph_napi.c).  Destroying the context first must leave every handle releasable, refuse new
+    work with a message, and free the device state with the last handle."""
+    import ctypes as C
+    l = capi.lib()
+    c = capi.Context(0)
+    buf = c.create_buffer(1 << 20, owner="orphan")
+    lut = upload(c, capi.gamma2linear_lut("709"), svm="coarse")
+    prog = c.create_program("phaneron:v210", "read", 40 * 8, 40)
+    ev = c.record_event(capi.QUEUE_PROCESS)
+    c.wait(capi.QUEUE_LOAD)
+    h = c.h
+    c.close()                                       # context first ...
+    assert l.ph_wait_finish(h, 1) < 0 and b"destroyed" in l.ph_last_error(None)
+    out = C.c_void_p()
+    assert l.ph_buf_create(h, 64, 0, 0, 0, 0, b"late", C.byref(out)) < 0
+    assert b"destroyed" in l.ph_last_error(None)
+    assert buf.refcount() == 1
+    buf.add_ref()
+    assert buf.release() == 0 and buf.release() == 0  # ... then its buffers (the pool it returns to still exists)
+    assert lut.release() == 0
+    assert l.ph_program_destroy(prog.h) == 0
+    ev.destroy()                                    # the last handle tears the device state down
+    c2 = capi.Context(0)                            # and the device is usable again
+    b2 = c2.create_buffer(1 << 20)
+    b2.release()
+    c2.close()

@@ -121,3 +121,62 @@ def test_pack_geometry():
     for fmt, sizes in want.items():
         assert capi.pack_plane_bytes(fmt, 1920, 1080) == sizes, fmt
     assert capi.pack_plane_bytes("yuv422p8", 718, 480) == [720 * 480, 360 * 480, 360 * 480]  # pitch rounds up to 8
+
+
+# ---- createProgram: which precompiled kernel a (source text, kernel name) pair selects -------------------
+PACK_FORMATS = ["v210", "yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"]
+IMAGE_KERNELS = ["yadif", "transform", "resize", "transition_dissolve", "transition_wipe", "mixer", "wipe"] + \
+                ["combine_%d" % n for n in range(2, 9)]
+REF_CL = os.path.join(ROOT, "oracle", "_ref", "work", "cl")
+needs_ref_text = pytest.mark.skipif(not os.path.isdir(REF_CL), reason="the reference's kernel text exists only in the build container")
+
+
+def _want_kernel(fmt, name):
+    return "%s_%s" % (fmt, name)
+
+
+def test_program_resolution_by_tag_and_by_name_needs_no_device():
+    for fmt in PACK_FORMATS:
+        for name in ("read", "write"):
+            assert capi.resolve_program("phaneron:" + fmt, name) == (_want_kernel(fmt, name), fmt, "tag")
+    for k in IMAGE_KERNELS:
+        assert capi.resolve_program("", k) == (k, None, "name")
+    assert capi.resolve_program("phaneron:x", "fused_v210_combine_4")[0] == "fused_v210_combine_4"
+    for src, name, needle in (("", "sharpen", "unknown kernel"), ("", "combine_9", "layers are built"),
+                              ("", "combine_1", "layers are built"), ("phaneron:v211", "read", "cannot tell which pack format"),
+                              ("__kernel void read(__global float* a) {}", "read", "cannot tell which pack format")):
+        with pytest.raises(capi.PhaneronError, match=needle):
+            capi.resolve_program(src, name)
+
+
+@needs_ref_text
+def test_reference_kernel_text_selects_the_right_kernel():
+    """The strings the reference passes at packer.ts:98 and imageProcess.ts:69, unchanged: every pack-format
+    source is recognised by its exact text, every image kernel by its name."""
+    for fmt in PACK_FORMATS:
+        src = open(os.path.join(REF_CL, fmt + ".cl")).read()
+        for name in ("read", "write"):
+            assert capi.resolve_program(src, name) == (_want_kernel(fmt, name), fmt, "text"), (fmt, name)
+        # re-indented / CRLF text is the same program
+        assert capi.resolve_program(src.replace("\n", "\r\n").replace("  ", "\t"), "read")[2] == "text"
+    for stem, names in (("yadif", ["yadif"]), ("transform", ["transform"]), ("resize", ["resize"]), ("mix", ["mixer"]),
+                        ("wipe", ["wipe"]), ("transition_dissolve", ["transition_dissolve"]),
+                        ("transition_wipe", ["transition_wipe"])):
+        src = open(os.path.join(REF_CL, stem + ".cl")).read()
+        for name in names:
+            assert capi.resolve_program(src, name) == (name, None, "name")
+    for n in range(2, 9):
+        src = open(os.path.join(REF_CL, "combine_%d.cl" % n)).read()
+        assert capi.resolve_program(src, "combine_%d" % n) == ("combine_%d" % n, None, "name")
+
+
+@needs_ref_text
+def test_edited_kernel_text_is_still_told_apart_by_signature_and_body():
+    """A maintainer's edited copy no longer matches a fingerprint: the argument list decides, plus one probe of
+    the kernel BODY where two formats share a signature.  Comments must not fool it (an rgba8 source that
+    mentions bgra, a 4:2:2 source that mentions inOffUV)."""
+    decoys = "// bgra inOffUV outOffUV ushort8 inputC colMatrix uint4\n/* bgra8.s2 = x; inOffUV */\n"
+    for fmt in PACK_FORMATS:
+        src = decoys + open(os.path.join(REF_CL, fmt + ".cl")).read() + "\n// edited\n"
+        for name in ("read", "write"):
+            assert capi.resolve_program(src, name) == (_want_kernel(fmt, name), fmt, "signature"), (fmt, name)
