@@ -40,7 +40,32 @@ def parse():
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--plan", action="store_true",
+                    help="print how --gpus N would be launched (one JSON line) and exit; needs no GPU")
     return ap.parse_args()
+
+
+FIXED_WARMUP = 200  # untimed launches before --warmup is honoured: a 20-step run must still measure settled clocks
+
+
+def launch_plan(args, argv):
+    """How this invocation runs.  Started by torchrun (WORLD_SIZE set): one rank per GPU, as told.  Started bare with
+    --gpus N > 1: re-launch itself as N ranks of ONE node through torch.distributed.run (one process per GPU,
+    RCCL rendezvous on 127.0.0.1) - the contract `python bench.py --gpus N` must honour on its own."""
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        return {"mode": "rank", "world": world, "rank": int(os.environ.get("RANK", "0")),
+                "gpus_flag_matches": args.gpus in (1, world)}
+    if args.gpus <= 1:
+        return {"mode": "single", "world": 1}
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--plan"]
+    return {"mode": "spawn", "world": args.gpus, "ranks": list(range(args.gpus)), "cmd": cmd}
 
 
 def synth_v210(torch, width, height, seed, device):
@@ -120,7 +145,20 @@ def recorded_traffic():
 
 def main():
     args = parse()
+    plan = launch_plan(args, sys.argv[1:])
+    if args.plan:
+        print(json.dumps(plan), flush=True)
+        return 0
+    if plan["mode"] == "rank" and not plan["gpus_flag_matches"]:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, plan["world"]))
     import torch
+    if plan["mode"] == "spawn":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible" % (args.gpus, have))
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        return subprocess.run(plan["cmd"], env=env).returncode  # rank 0 of the children prints the JSON line
     from phaneron_amd import capi
     import numpy as np
 
@@ -129,6 +167,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libphaneron_hip has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -185,13 +225,22 @@ def main():
         if i == args.warmup + args.steps - 1:
             ev1.record(stream)
 
+    for i in range(FIXED_WARMUP):  # clocks, caches and the allocator settle before the contract's own warm-up
+        step(i)
+    sync()
     elapsed = multigpu.timed_steps(timed_step, args.steps, args.warmup, sync, dist, device)
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # average launch duration on the kernel's stream
+    # frames every rank really composited in the timed region, summed over ranks (not assumed equal)
+    frames_done = C * args.steps
+    if dist is not None:
+        t = torch.tensor([frames_done], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        frames_done = int(t.item())
 
     lds = ctx.lut_info(rd[1])["lds_bytes"] and ctx.lut_info(wr[1])["lds_bytes"] and not os.environ.get("PH_BENCH_GLOBAL_LUT")
     kernel_name = ("fused_v210_combine_lds_kernel<%d,...>" if lds else "fused_v210_combine_kernel<%d>") % n
     if rank == 0:
-        fps = world * C * args.steps / elapsed
+        fps = frames_done / elapsed
         algo_bytes = C * (n + 1) * frame_words * 4  # each input byte once + each output byte once
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         line = {
@@ -207,6 +256,8 @@ def main():
                        "ring_frame_sets": args.ring, "channels": world * C, "realtime_target_fps": 50},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(),
+                         "traffic_source": "recorded: profiles/pmc_traffic.json, rocprofv3 FETCH_SIZE / WRITE_SIZE passes "
+                                           "of this command (tools/profile_round.sh), not measured in this run",
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": round(kernel_ms, 5)},
         }
@@ -218,7 +269,8 @@ def main():
     ctx.close()
     if dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -126,3 +126,34 @@ def test_route_exchange_every_route_crosses_ranks():
         assert ns == 2 and nr == 2
         for dst, first in got.items():
             assert dst in mine and first == 1000.0 * ((dst + 2) % 4)
+
+
+def test_bench_gpus_flag_plans_one_rank_per_gpu():
+    """`python bench.py --gpus N` must run N ranks on its own: bare, it plans a torch.distributed.run launch of N
+    processes on 127.0.0.1; under a launcher it is one rank of the world it was given; and it refuses (non-zero
+    exit) when fewer than N GPUs are visible - here, none."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    bench = os.path.join(root, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+
+    def plan(args, extra_env=None):
+        out = subprocess.run([sys.executable, bench, "--plan"] + args, env=dict(env, **(extra_env or {})), check=True,
+                             capture_output=True, text=True).stdout
+        return json.loads(out.strip().splitlines()[-1])
+
+    p = plan(["--gpus", "2", "--steps", "7"])
+    assert p["mode"] == "spawn" and p["world"] == 2 and p["ranks"] == [0, 1]
+    cmd = p["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "7"] and "--plan" not in cmd
+    assert plan([]) == {"mode": "single", "world": 1}
+    r = plan(["--gpus", "8"], {"WORLD_SIZE": "8", "RANK": "3"})
+    assert r == {"mode": "rank", "world": 8, "rank": 3, "gpus_flag_matches": True}
+    assert plan(["--gpus", "2"], {"WORLD_SIZE": "8", "RANK": "0"})["gpus_flag_matches"] is False
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3"], env=env, capture_output=True, text=True)
+        assert r.returncode != 0 and "only 0 GPU(s) are visible" in r.stderr
