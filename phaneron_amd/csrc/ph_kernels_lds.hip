@@ -19,6 +19,52 @@
 
 #pragma clang fp contract(off)
 
+// PH_PROBE builds (tools/fused_probe.py; never the shipped library): wave 0 of every workgroup of the fused kernel
+// stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) at the phase boundaries of its first tile, so the
+// sustained shader clock and the share of each phase can be read off the real kernel instead of a microbenchmark.
+#ifndef PH_PROBE
+#define PH_PROBE 0
+#endif
+#if PH_PROBE
+__device__ unsigned long long g_fused_probe[2048 * 12];
+extern "C" int ph_debug_fused_probe(unsigned long long *out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_probe), (size_t)n_words * 8);
+}
+#define PH_STAMP(k)                                                                  \
+  do {                                                                               \
+    if (threadIdx.x == 0 && tile_begin == wg_begin) {                                \
+      g_fused_probe[blockIdx.x * 12 + 2 * (k)] = __builtin_amdgcn_s_memtime();       \
+      g_fused_probe[blockIdx.x * 12 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                \
+  } while (0)
+#else
+#define PH_STAMP(k) do { } while (0)
+#endif
+
+// The four waves of a SIMD are served oldest first, so left alone the oldest wave of a workgroup races through its
+// slices and then idles at the phase barrier while the youngest is still working - and a SIMD with one or two
+// waves left issues a VALU instruction only every 5 / 2.6 cycles instead of every 2.3 (tools/fused_probe.py:
+// wave 0 waited a third of the tile at the barrier).  Wave priority outranks age: a wave LOWERS its priority as
+// it advances through its slices, so whoever is behind is served first and the waves reach the barrier together.
+// PH_BALANCE_WAVES=0 builds without it (A/B).
+#ifndef PH_BALANCE_WAVES
+#define PH_BALANCE_WAVES 1
+#endif
+#if PH_BALANCE_WAVES
+// s_setprio takes an immediate: the switch folds once the slice loop is unrolled
+__device__ __forceinline__ void ph_set_wave_priority(int level) {
+  switch (level) {
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+  }
+}
+#define PH_BALANCE(p) ph_set_wave_priority(3 - ((p) * 4) / P)
+#else
+#define PH_BALANCE(p) do { } while (0)
+#endif
+
 namespace ph {
 
 // Every YCbCr->RGB matrix colourMaths.ts:276-332 can produce has the same shape: one luma gain in all
@@ -65,6 +111,41 @@ __device__ __forceinline__ uint32_t write_px_luma_lds(float r, float g, float b,
   return sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
 }
 
+// ---- the same two pixel stages split at the LDS reads (ph_ldslut.h lds_lut_issue / lds_lut_finish), for the
+// software-pipelined fused kernel: `issue` does everything up to and including the start of the six reads,
+// `finish` everything from their results on.
+struct PxPending {
+  LutPending r, g, b;
+};
+template <bool STD>
+__device__ __forceinline__ PxPending read_px_issue(float y, float cb, float cr, const ReadK &k, const LutK &lut) {
+  float tr, tg, tb;
+  if (STD) {
+    const float ym = y * k.r.x;
+    tr = fma_rn(1.0f, k.r.w, fma_rn(cr, k.r.z, ym));
+    tg = fma_rn(1.0f, k.g.w, fma_rn(cr, k.g.z, fma_rn(cb, k.g.y, ym)));
+    tb = fma_rn(1.0f, k.b.w, fma_rn(cb, k.b.y, ym));
+  } else {
+    tr = dot4(y, cb, cr, 1.0f, k.r), tg = dot4(y, cb, cr, 1.0f, k.g), tb = dot4(y, cb, cr, 1.0f, k.b);
+  }
+  PxPending p;
+  p.r = lds_lut_issue(lut, lds_lut_index_unit(tr));
+  p.g = lds_lut_issue(lut, lds_lut_index_unit(tg));
+  p.b = lds_lut_issue(lut, lds_lut_index_unit(tb));
+  return p;
+}
+__device__ __forceinline__ float4 read_px_finish(const PxPending &p, const ReadK &k) {
+  const float r = lds_lut_finish(p.r), g = lds_lut_finish(p.g), b = lds_lut_finish(p.b);
+  return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
+                     dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
+}
+// writer side, from ready-made indices (floats M + idx)
+__device__ __forceinline__ PxPending write_px_issue(float yr, float yg, float yb, const LutK &lut) {
+  PxPending p;
+  p.r = lds_lut_issue(lut, yr), p.g = lds_lut_issue(lut, yg), p.b = lds_lut_issue(lut, yb);
+  return p;
+}
+
 // the same from ready-made LUT indices (floats M + idx, ph_ldslut.h): phase 2 of the fused kernel
 __device__ __forceinline__ uint4 write_quad_idx_lds(const float (&yi)[18], const WriteK &wk, const LutK &lut) {
   uint32_t y[6], u[3], v[3];
@@ -102,7 +183,7 @@ __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const Wr
 // P = 6 quads per lane - a whole 2160p share (5400 quads per CU) in ONE tile, so each frame costs two
 // table loads instead of four.
 // ------------------------------------------------------------------------------------------
-template <int N, int P, int BS>
+template <int N, int P, int BS, bool PIPE = false>
 __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs a) {
   const ReadK rk = load_read_k(a.f.rd_cm, a.f.rd_gm);
   const WriteK wk = load_write_k(a.f.wr_cm);
@@ -173,25 +254,143 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
       }
       return w;
     };
+    PH_STAMP(0);
     lds_lut_load<BS>(a.rd);
     __syncthreads();
+    PH_STAMP(1);
+    const uint32_t tile_left = wg_end - tile_begin;  // uniform; slice p holds quads iff p * BS < tile_left
+    if constexpr (PIPE) {
+      // Software-pipelined phases (ph_ldslut.h lds_lut_issue): the six LDS reads of pixel i + 1 are started BEFORE
+      // the results of pixel i are consumed, all the way through quads, layers and slices, so a whole pixel of
+      // arithmetic (~45 VALU instructions) sits between every read and its first use.  sched_barrier keeps LLVM
+      // from re-serialising the two halves.  Results are the same operations in the same order per pixel.
+      auto phase1_all = [&](auto tag) {
+        constexpr bool STD = decltype(tag)::value;
+        auto issue_first = [&](const uint4 &word) {  // pixel 0 of a quad: Y0, Cb0, Cr0 all sit in word x (v210.ts:58)
+          return read_px_issue<STD>((float)((word.x >> 10) & 0x3ff), (float)(word.x & 0x3ff), (float)((word.x >> 20) & 0x3ff), rk, rlut);
+        };
+        // pixel j of a quad (v210.ts:58-63): Y in word {0,1,1,2,3,3} at bit {10,0,20,10,0,20}, the pair's Cb in word
+        // {0,1,2} at bit {0,10,20}, its Cr in word {0,2,3} at bit {20,0,10}; j is a compile-time constant
+        auto issue_px = [&](const uint4 &word, int j) {
+          const uint32_t wy = j == 0 ? word.x : j < 3 ? word.y : j == 3 ? word.z : word.w;
+          const uint32_t sy = (j == 0 || j == 3) ? 10u : (j == 1 || j == 4) ? 0u : 20u;
+          const int pr = j >> 1;
+          const uint32_t wcb = pr == 0 ? word.x : pr == 1 ? word.y : word.z, scb = 10u * pr;
+          const uint32_t wcr = pr == 0 ? word.x : pr == 1 ? word.z : word.w, scr = pr == 0 ? 20u : pr == 1 ? 0u : 10u;
+          return read_px_issue<STD>((float)((wy >> sy) & 0x3ff), (float)((wcb >> scb) & 0x3ff), (float)((wcr >> scr) & 0x3ff), rk, rlut);
+        };
+        PxPending pend = issue_first(w);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if (p * BS < tile_left) {  // uniform: skip empty slices of the last tile
+            PH_BALANCE(p);
+            const uint32_t f = quad_of(p);
+            const bool more = (p + 1 < P) && ((p + 1) * BS < tile_left);  // uniform
+            const uint32_t f_next = more ? quad_of(p + 1) : f;
+            float acc[18];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) acc[i] = 0.0f;
+#pragma unroll 1
+            for (int l = 0; l < N; ++l) {
+              uint4 nxt = w;
+              if (l + 1 < N) nxt = load_stream(layer_ptr(l + 1) + f);
+              else if (more) nxt = load_stream(layer_ptr(0) + f_next);
+#pragma unroll
+              for (int j = 0; j < 6; ++j) {
+                PxPending nx;
+                // the three code values of pixel j + 1 are extracted here, not for the whole quad up front: the
+                // scheduling fences would keep all eighteen alive across the loop (spills)
+                if (j < 5) nx = issue_px(w, j + 1);
+                else {
+                  // next layer's / next slice's first pixel (the last one of a tile is never consumed).  The word was
+                  // requested at the top of this iteration; pinning its first use HERE keeps LLVM from extracting its
+                  // fields right after the request, which would put the whole HBM latency in front of every quad
+                  uint4 first = nxt;
+                  asm volatile("" : "+v"(first.x));
+                  nx = issue_first(first);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 t = read_px_finish(pend, rk);
+                const float kk = 1.0f - t.w;
+                asm volatile("v_fma_f32 %0, %0, %3, %4\n\tv_fma_f32 %1, %1, %3, %5\n\tv_fma_f32 %2, %2, %3, %6"
+                             : "+v"(acc[3 * j]), "+v"(acc[3 * j + 1]), "+v"(acc[3 * j + 2])
+                             : "v"(kk), "v"(t.x), "v"(t.y), "v"(t.z));
+                __builtin_amdgcn_sched_barrier(0);
+                pend = nx;
+              }
+              w = nxt;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+              const uint32_t lo = __float_as_uint(lds_lut_index_unit(acc[2 * i]));
+              const uint32_t hi = __float_as_uint(lds_lut_index_unit(acc[2 * i + 1]));
+              st[p][i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+              asm volatile("" : "+v"(st[p][i]));
+            }
+          }
+        }
+      };
+      if (std_matrix) phase1_all(std::true_type{});
+      else phase1_all(std::false_type{});
+      PH_STAMP(2);
+      __syncthreads();
+      lds_lut_load<BS>(a.wr);
+      __syncthreads();
+      PH_STAMP(3);
+      // phase 2, pipelined the same way: indices -> writer table -> matrix -> codes -> packed words
+      auto idx_at = [&](int p, int i) {  // M + idx: the 16-bit index ORed into the mantissa of 1.5 * 2^23
+        const uint32_t v = st[p][i >> 1];
+        return __uint_as_float(((i & 1) ? (v >> 16) : (v & 0xFFFFu)) | 0x4B400000u);
+      };
+      PxPending wp = write_px_issue(idx_at(0, 0), idx_at(0, 1), idx_at(0, 2), wlut);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (p * BS < tile_left) {
+          PH_BALANCE(p);
+          const uint32_t f = tile_begin + p * BS + threadIdx.x;
+          uint32_t y[6], u[3], v[3];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            PxPending nx = wp;
+            if (j < 5) nx = write_px_issue(idx_at(p, 3 * j + 3), idx_at(p, 3 * j + 4), idx_at(p, 3 * j + 5), wlut);
+            else if (p + 1 < P) {
+              if ((p + 1) * BS < tile_left) nx = write_px_issue(idx_at(p + 1 < P ? p + 1 : p, 0), idx_at(p + 1 < P ? p + 1 : p, 1), idx_at(p + 1 < P ? p + 1 : p, 2), wlut);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float gr = lds_lut_finish(wp.r), gg = lds_lut_finish(wp.g), gb = lds_lut_finish(wp.b);
+            y[j] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.y));
+            if ((j & 1) == 0) {
+              u[j >> 1] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.u));
+              v[j >> 1] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.v));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wp = nx;
+          }
+          if (f < wg_end) store_stream(out_ptr + f, pack_quad(y, u, v));
+        }
+      }
+    } else {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const uint32_t f = quad_of(p);
       if (p * BS < wg_end - tile_begin) {               // uniform: skip empty slices of the last tile
+        PH_BALANCE(p);
         const bool more = (p + 1 < P) && ((p + 1) * BS < wg_end - tile_begin);  // uniform
         const uint32_t f_next = more ? quad_of(p + 1) : f;
         if (std_matrix) w = phase1_slice(std::true_type{}, w, f, f_next, more, st[p]);
         else w = phase1_slice(std::false_type{}, w, f, f_next, more, st[p]);
       }
     }
+    PH_STAMP(2);
     __syncthreads();
     lds_lut_load<BS>(a.wr);
     __syncthreads();
+    PH_STAMP(3);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const uint32_t f = tile_begin + p * BS + threadIdx.x;
       if (p * BS < wg_end - tile_begin) {
+        PH_BALANCE(p);
         float yi[18];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {  // M + idx: the index ORed into the mantissa of 1.5 * 2^23
@@ -202,6 +401,8 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
         if (f < wg_end) store_stream(out_ptr + f, packed);
       }
     }
+    }
+    PH_STAMP(4);
     __syncthreads();
   }
 }
@@ -430,16 +631,16 @@ static hipError_t allow_lds(K kernel, uint32_t bytes) {
                              (int)bytes);
 }
 
-template <int N, int P, int BS>
+template <int N, int P, int BS, bool PIPE = false>
 static hipError_t launch_fused_npb(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
-  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P, BS>, lds);
+  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P, BS, PIPE>, lds);
   if (e != hipSuccess) return e;
   const uint32_t slices = (a.f.total_quads + BS - 1) / BS;  // never more workgroups per job than slices
   FusedLdsArgs b = a;
   if (b.jobs < 1) b.jobs = 1;
   b.wg_per_job = grid / b.jobs ? grid / b.jobs : 1;
   if (b.wg_per_job > slices) b.wg_per_job = slices;
-  fused_v210_combine_lds_kernel<N, P, BS><<<b.wg_per_job * b.jobs, BS, lds, s>>>(b);
+  fused_v210_combine_lds_kernel<N, P, BS, PIPE><<<b.wg_per_job * b.jobs, BS, lds, s>>>(b);
   return hipGetLastError();
 }
 
@@ -455,6 +656,11 @@ static hipError_t launch_fused_n(hipStream_t s, const FusedLdsArgs &a, uint32_t 
   const uint32_t per_wg = (a.f.total_quads + grid - 1) / grid;
   (void)per_wg;
   int geom = geom_env ? geom_env : 6;
+  static const int pipe_env = [] {
+    const char *e = getenv("PH_FUSED_PIPE");  // 1 = the software-pipelined phases (measured 3 % SLOWER: DESIGN.md 4)
+    return e ? atoi(e) : 0;
+  }();
+  if (pipe_env && geom == 6) return launch_fused_npb<N, 6, 1024, true>(s, a, grid, lds);
   if (geom == 4) return launch_fused_npb<N, 4, 1024>(s, a, grid, lds);
   if (geom == 8) return launch_fused_npb<N, 8, 1024>(s, a, grid, lds);
   return launch_fused_npb<N, 6, 1024>(s, a, grid, lds);

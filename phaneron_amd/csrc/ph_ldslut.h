@@ -88,6 +88,29 @@ __device__ __forceinline__ float lds_lut_fetch(const LutK &k, float y) {
 #endif
   return __uint_as_float(a + d);
 }
+// The same lookup in two halves, for software-pipelined callers: `issue` computes both addresses and starts the
+// two LDS reads, `finish` adds anchor and delta.  One wave alone can start a VALU instruction only every ~5
+// cycles and an LDS read takes 64+ cycles to come back (128+ with bank conflicts), so a caller that consumes a
+// lookup right after issuing it leaves its SIMD to the other three waves - and all four stall the same way.
+// Issuing pixel j+1's reads BEFORE consuming pixel j's puts a whole pixel of arithmetic between every read and
+// its use (tools/opbench3.hip).
+struct LutPending {
+  uint32_t a, d;
+};
+__device__ __forceinline__ LutPending lds_lut_issue(const LutK &k, float y) {
+  const float fb = y - k.magic_minus_bias;  // (float)(idx + bias), exact
+  const uint32_t a_addr = ((__float_as_uint(fb) >> k.shift) << 2) + k.anchor_off;
+  const uint32_t d_addr = __float_as_uint(fma_rn(y, k.delta_scale, k.delta_base));
+#if PH_ABLATE & 8
+  return LutPending{*(lds_u32_ptr)(a_addr & 4u), *(lds_u16_ptr)(d_addr & 2u)};
+#elif PH_ABLATE & 1
+  return LutPending{a_addr, d_addr};
+#else
+  return LutPending{*(lds_u32_ptr)a_addr, *(lds_u16_ptr)d_addr};
+#endif
+}
+__device__ __forceinline__ float lds_lut_finish(const LutPending &p) { return __uint_as_float(p.a + p.d); }
+
 // The rounded, clamped index of a unit-range value as the float M + idx (idx = its low 16 bits).
 __device__ __forceinline__ float lds_lut_index_unit(float t) {
   t = __builtin_fminf(__builtin_fmaxf(t, 0.0f), 1.0f);
