@@ -119,6 +119,36 @@ int ph_graph_begin(ph_ctx *ctx, int queue);
 int ph_graph_end(ph_ctx *ctx, int queue, ph_graph **out);
 int ph_graph_launch(ph_graph *graph, int queue);
 int ph_graph_destroy(ph_graph *graph);
+/* ---- ROUTE across GPUs (src/producer/routeProducer.ts:63-126, src/channel.ts:290-300).  In the reference a
+ *      route producer taps another channel's combiner output by taking a reference on the same OpenCL buffer:
+ *      one process, one device.  Here channels are partitioned one process per GPU, so a route whose
+ *      two ends live on different GPUs becomes ONE point-to-point message per frame: RCCL send / recv over xGMI
+ *      on a communication stream of its own, ordered against the compute queues on the device:
+ *        source rank:  combine ... ; ph_route_after_queue(r, PROCESS); ph_route_send(r, frame, peer)
+ *        sink rank:    ph_route_recv(r, frame, peer); ph_queue_after_route(r, PROCESS); combine(... frame ...)
+ *      so the transfer overlaps whatever else the sink's process queue runs before that combine (its own layers'
+ *      v210 reads), and no host thread waits.  Sends / receives of one frame period go between
+ *      ph_route_group_begin / _end (ncclGroupStart / End): every rank may then post them in any order.
+ *      librccl is loaded on first use (dlopen); a process that never routes never needs it.
+ *      ph_route_unique_id: 128 bytes made by ONE rank and handed to the others out of band (the caller's own
+ *      control channel - torch.distributed in this repo's tools, a socket in a node deployment). ------------- */
+typedef struct ph_route ph_route;
+#define PH_ROUTE_ID_BYTES 128
+int ph_route_unique_id(void *id128);
+int ph_route_init(ph_ctx *ctx, const void *id128, int rank, int world, ph_route **out);
+int ph_route_destroy(ph_route *route);
+int ph_route_group_begin(ph_route *route);
+int ph_route_group_end(ph_route *route);
+/* device pointers (ph_buf_device_ptr / a wrapped tensor); bytes % 4 == 0; peer == own rank is allowed inside a group */
+int ph_route_send(ph_route *route, const void *device_src, size_t bytes, int peer);
+int ph_route_recv(ph_route *route, void *device_dst, size_t bytes, int peer);
+/* the communication stream waits for everything enqueued so far on `queue` (the frame being sent is complete) */
+int ph_route_after_queue(ph_route *route, int queue);
+/* `queue` waits for everything enqueued so far on the communication stream (the received frame has landed) */
+int ph_queue_after_route(ph_route *route, int queue);
+int ph_route_wait(ph_route *route); /* host wait for the communication stream (tests, shutdown) */
+void *ph_route_stream(ph_route *route);
+
 /* the `logBuffers()` debug hook (src/index.ts:184): live buffers / pooled bytes */
 int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes);
 

@@ -37,6 +37,20 @@ export interface QueueEvent {
 	done(): boolean
 }
 
+export interface RouteLink {
+	readonly rank: number
+	readonly world: number
+	/** sends and receives of one frame period go inside one group */
+	group(fn: () => void): void
+	send(buf: OpenCLBuffer, peer: number): void
+	recv(buf: OpenCLBuffer, peer: number): void
+	/** the communication stream waits for everything enqueued so far on `queue` */
+	afterQueue(queue?: number): void
+	/** `queue` waits for everything enqueued so far on the communication stream */
+	queueAfter(queue?: number): void
+	wait(): void
+}
+
 export interface OpenCLProgram {
 	readonly name: string
 	readonly globalWorkItems: number[]
@@ -66,6 +80,9 @@ export class clContext {
 	queueWaitQueue(waiter: number, signal: number): void
 	/** staging extension */
 	recordEvent(queue?: number): QueueEvent
+	/** ROUTE across GPUs: RCCL send / recv on a communication stream of its own, ordered on the device */
+	openRoute(id: Buffer, rank: number, world: number): RouteLink
+	static routeUniqueId(): Buffer
 	logBuffers(): { liveBuffers: number; liveBytes: number; pooledBytes: number }
 }
 

@@ -138,6 +138,26 @@ class clContext {
 		return { wait: () => native.eventWait(ev), done: () => native.eventDone(ev) }
 	}
 
+	// ---- ROUTE across GPUs (not nodencl; routeProducer.ts:63-126 with source and sink on different GPUs) ------
+	// id: clContext.routeUniqueId() made on ONE rank and handed to the others by the application.
+	// Returns { send(buf, peer), recv(buf, peer), group(fn), afterQueue(q), queueAfter(q), wait() }: RCCL send /
+	// recv on a communication stream of its own; afterQueue / queueAfter order it against a queue ON THE DEVICE.
+	openRoute(id, rank, world) {
+		const native = this._need()
+		const h = native.routeInit(this._ctx, id, rank, world)
+		const q = (queue) => (queue === undefined ? this.queue.process : queue)
+		return {
+			rank, world,
+			group: (fn) => { native.routeOp(h, 0); try { fn() } finally { native.routeOp(h, 1) } },
+			afterQueue: (queue) => native.routeOp(h, 2, q(queue)),
+			queueAfter: (queue) => native.routeOp(h, 3, q(queue)),
+			wait: () => native.routeOp(h, 4),
+			send: (buf, peer) => native.routeOp(h, 5, buf._handle, peer),
+			recv: (buf, peer) => native.routeOp(h, 6, buf._handle, peer)
+		}
+	}
+	static routeUniqueId() { return loadAddon().routeUniqueId() }
+
 	logBuffers() {
 		const s = this._need().bufferStats(this._ctx)
 		console.log(`phaneron HIP buffers: ${s.liveBuffers} live (${s.liveBytes} bytes), ${s.pooledBytes} bytes pooled`)

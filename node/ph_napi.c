@@ -665,6 +665,70 @@ static napi_value PlaneBytes(napi_env env, napi_callback_info info) {
   return out;
 }
 
+/* ---- ROUTE across GPUs (include/phaneron_hip.h "ROUTE"): RCCL point-to-point on its own stream --------------- */
+static void route_finalize(napi_env env, void *data, void *hint) {
+  (void)env, (void)hint;
+  ph_route_destroy((ph_route *)data);
+}
+/* routeUniqueId() -> Buffer(128): made on ONE rank, handed to the others by the caller */
+static napi_value RouteUniqueId(napi_env env, napi_callback_info info) {
+  napi_value out;
+  void *p = NULL;
+  (void)info;
+  NAPI_OK(napi_create_buffer(env, PH_ROUTE_ID_BYTES, &p, &out));
+  if (ph_route_unique_id(p) != PH_OK) return throw_ph(env, "routeUniqueId");
+  return out;
+}
+/* routeInit(ctx, idBuffer, rank, world) -> external */
+static napi_value RouteInit(napi_env env, napi_callback_info info) {
+  size_t argc = 4, len = 0;
+  napi_value argv[4], out;
+  ctx_box *c;
+  void *id = NULL;
+  int32_t rank = 0, world = 1;
+  ph_route *r = NULL;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 4 || !get_box(env, argv[0], (void **)&c) || napi_get_buffer_info(env, argv[1], &id, &len) != napi_ok ||
+      len != PH_ROUTE_ID_BYTES || !get_i32(env, argv[2], &rank) || !get_i32(env, argv[3], &world))
+    return throw_ph(env, "routeInit(ctx, id128, rank, world)");
+  if (ph_route_init(c->ctx, id, rank, world, &r) != PH_OK) return throw_ph(env, "routeInit");
+  NAPI_OK(napi_create_external(env, r, route_finalize, NULL, &out));
+  return out;
+}
+/* routeOp(route, op, a, b): op 0 groupBegin, 1 groupEnd, 2 afterQueue(a = queue), 3 queueAfterRoute(a = queue), 4 wait
+ *                          5 send(a = buffer handle, b = peer), 6 recv(a = buffer handle, b = peer) */
+static napi_value RouteOp(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4], out;
+  ph_route *r;
+  int32_t op = -1, a = 0, b = 0;
+  int rc = PH_E_INVALID;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 2 || !get_box(env, argv[0], (void **)&r) || !get_i32(env, argv[1], &op)) return throw_ph(env, "routeOp(route, op, ...)");
+  if (op == 5 || op == 6) {
+    buf_box *bb;
+    if (argc < 4 || !get_box(env, argv[2], (void **)&bb) || !bb->buf || !get_i32(env, argv[3], &b)) {
+      napi_throw_error(env, NULL, "route send / recv needs a live buffer and a peer rank");
+      return NULL;
+    }
+    rc = op == 5 ? ph_route_send(r, ph_buf_device_ptr(bb->buf), ph_buf_bytes(bb->buf), b)
+                 : ph_route_recv(r, ph_buf_device_ptr(bb->buf), ph_buf_bytes(bb->buf), b);
+  } else {
+    if (argc > 2) get_i32(env, argv[2], &a);
+    switch (op) {
+      case 0: rc = ph_route_group_begin(r); break;
+      case 1: rc = ph_route_group_end(r); break;
+      case 2: rc = ph_route_after_queue(r, a); break;
+      case 3: rc = ph_queue_after_route(r, a); break;
+      case 4: rc = ph_route_wait(r); break;
+      default: break;
+    }
+  }
+  if (rc != PH_OK) return throw_ph(env, "route");
+  NAPI_OK(napi_get_undefined(env, &out));
+  return out;
+}
+
 static napi_value AbiVersion(napi_env env, napi_callback_info info) {
   napi_value v;
   (void)info;
@@ -685,6 +749,7 @@ NAPI_MODULE_INIT() {
       {"eventWait", EventWait},     {"eventDone", EventDone},       {"waitFinishSpin", WaitFinishSpin},
       {"resolveProgram", ResolveProgram}, {"gammaLut", GammaLut},   {"colourMatrix", ColourMatrix},
       {"transformMatrix", TransformMatrix}, {"planeBytes", PlaneBytes},
+      {"routeUniqueId", RouteUniqueId}, {"routeInit", RouteInit},   {"routeOp", RouteOp},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
     napi_value f;

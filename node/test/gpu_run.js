@@ -175,6 +175,33 @@ async function main() {
 		result.errors = errors
 	}
 
+	// ---- 7. ROUTE hand-off on the library's path: a frame produced on the process queue travels through RCCL (to the
+	//         own rank: one GPU here) on the communication stream and is consumed by a kernel on the process queue,
+	//         ordered on the device only --------------------------------------------------------------------------
+	{
+		const { clContext } = require('../index.js')
+		const w = 1920
+		const h = 64
+		const link = ctx.openRoute(clContext.routeUniqueId(), 0, 1)
+		const read = await rig.unpack('v210', w, h, '709', '709')
+		const write = await rig.pack('v210', w, h, '709', false)
+		const src = await rig.planes('v210', w, h)
+		await rig.upload(src[0], load(job.ramp).slice(0, src[0].length))
+		await rig.sync(ctx.queue.load)
+		const made = await rig.image(w, h, 'route source frame')
+		const got = await rig.image(w, h, 'routed frame')
+		const out = await rig.planes('v210', w, h, 'writeonly')
+		await rig.run(read(src, made))                 // the source channel's output, on the process queue
+		link.afterQueue()
+		link.group(() => { link.send(made, 0); link.recv(got, 0) })
+		link.queueAfter()
+		await rig.run(write(got, out, 0))              // the sink consumes the routed frame
+		await rig.sync()
+		await rig.download(out[0])
+		result.routeLoopbackCompare = Buffer.compare(load(job.ramp).slice(0, out[0].length), out[0])
+		;[src[0], made, got, out[0]].forEach((b) => b.release())
+	}
+
 	rig.close()
 	result.liveAfter = ctx.logBuffers ? rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers : -1
 	save('result.json', JSON.stringify(result))

@@ -52,7 +52,7 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", lib] + objs
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", lib] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

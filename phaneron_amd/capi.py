@@ -30,7 +30,9 @@ EXPORTS = [
     "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
     "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy", "ph_queue_query",
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
-    "ph_program_resolve",
+    "ph_program_resolve", "ph_route_unique_id", "ph_route_init", "ph_route_destroy", "ph_route_group_begin",
+    "ph_route_group_end", "ph_route_send", "ph_route_recv", "ph_route_after_queue", "ph_queue_after_route",
+    "ph_route_wait", "ph_route_stream",
 ]
 
 
@@ -130,6 +132,17 @@ def lib():
         "ph_pack_read": (ci, [vp, ci, ci, C.POINTER(vp), vp, cu, cu, vp, vp, vp]),
         "ph_pack_write": (ci, [vp, ci, ci, vp, C.POINTER(vp), cu, cu, cu, vp, vp]),
         "ph_compose_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), vp, cu, cu, cu, vp, vp]),
+        "ph_route_unique_id": (ci, [vp]),
+        "ph_route_init": (ci, [vp, vp, ci, ci, C.POINTER(vp)]),
+        "ph_route_destroy": (ci, [vp]),
+        "ph_route_group_begin": (ci, [vp]),
+        "ph_route_group_end": (ci, [vp]),
+        "ph_route_send": (ci, [vp, vp, cs, ci]),
+        "ph_route_recv": (ci, [vp, vp, cs, ci]),
+        "ph_route_after_queue": (ci, [vp, ci]),
+        "ph_queue_after_route": (ci, [vp, ci]),
+        "ph_route_wait": (ci, [vp]),
+        "ph_route_stream": (vp, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(l, name)  # AttributeError here = the header and the library disagree
@@ -458,6 +471,54 @@ class Buffer:
 
     def download_async(self, queue=QUEUE_UNLOAD):
         check(lib().ph_buf_download_async(self.h, queue), self.ctx.h)
+
+
+def route_unique_id():
+    """128 bytes made by ONE rank; hand them to every other rank before Route(...)"""
+    buf = C.create_string_buffer(128)
+    check(lib().ph_route_unique_id(buf))
+    return buf.raw
+
+
+class Route:
+    """Cross-GPU frame hand-off of the ROUTE producer (ph_route_*): RCCL point-to-point on a communication stream
+    of its own, ordered against the context's queues on the device."""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        h = C.c_void_p()
+        check(lib().ph_route_init(ctx.h, C.c_char_p(unique_id), rank, world, C.byref(h)), ctx.h)
+        self.ctx, self.h, self.rank, self.world = ctx, h, rank, world
+
+    def group(self):
+        route = self
+
+        class _Group:
+            def __enter__(self):
+                check(lib().ph_route_group_begin(route.h))
+
+            def __exit__(self, *a):
+                check(lib().ph_route_group_end(route.h))
+        return _Group()
+
+    def send(self, tensor, peer, nbytes=None):
+        check(lib().ph_route_send(self.h, _ptr(tensor), nbytes if nbytes is not None else tensor.numel() * tensor.element_size(), peer))
+
+    def recv(self, tensor, peer, nbytes=None):
+        check(lib().ph_route_recv(self.h, _ptr(tensor), nbytes if nbytes is not None else tensor.numel() * tensor.element_size(), peer))
+
+    def after_queue(self, queue=QUEUE_PROCESS):
+        check(lib().ph_route_after_queue(self.h, queue))
+
+    def queue_after(self, queue=QUEUE_PROCESS):
+        check(lib().ph_queue_after_route(self.h, queue))
+
+    def wait(self):
+        check(lib().ph_route_wait(self.h))
+
+    def destroy(self):
+        if self.h:
+            lib().ph_route_destroy(self.h)
+            self.h = None
 
 
 class Event:

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -475,6 +476,170 @@ int ph_graph_destroy(ph_graph *g) {
   ctx_unref(ctx);
   return PH_OK;
 }
+
+// ---- ROUTE: RCCL point-to-point on a communication stream of its own ----------------------------------
+// RCCL is loaded with dlopen(RTLD_LOCAL): the library has no link-time dependency on it, and a host process
+// that already carries another copy (PyTorch ships one) keeps the two apart.
+struct Id128 {  // ncclUniqueId, passed to ncclCommInitRank by value
+  char bytes[128];
+};
+namespace {
+struct Rccl {
+  void *handle = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+const int kNcclUint32 = 3;  // ncclUint32 (rccl.h ncclDataType_t)
+
+int load_rccl() {
+  std::lock_guard<std::mutex> lock(g_rccl_mu);
+  if (g_rccl.handle) return PH_OK;
+  const char *names[] = {getenv("PH_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *n : names)
+    if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!h) return fail(PH_E_HIP, "ROUTE needs RCCL and librccl.so could not be loaded (%s)", dlerror());
+#define PH_SYM(field, name)                                                              \
+  if (!(*(void **)(&g_rccl.field) = dlsym(h, name))) {                                    \
+    dlclose(h);                                                                          \
+    return fail(PH_E_HIP, "librccl.so lacks %s", name);                                  \
+  }
+  PH_SYM(GetUniqueId, "ncclGetUniqueId")
+  PH_SYM(CommInitRank, "ncclCommInitRank")
+  PH_SYM(CommDestroy, "ncclCommDestroy")
+  PH_SYM(Send, "ncclSend")
+  PH_SYM(Recv, "ncclRecv")
+  PH_SYM(GroupStart, "ncclGroupStart")
+  PH_SYM(GroupEnd, "ncclGroupEnd")
+  PH_SYM(GetErrorString, "ncclGetErrorString")
+#undef PH_SYM
+  g_rccl.handle = h;
+  return PH_OK;
+}
+#define PH_NCCL(call)                                                                               \
+  do {                                                                                              \
+    int r_ = (call);                                                                                \
+    if (r_ != 0) return fail(PH_E_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(r_));          \
+  } while (0)
+}  // namespace
+
+struct ph_route {
+  ph_ctx *ctx;
+  void *comm;
+  hipStream_t stream;
+  int rank, world;
+};
+
+int ph_route_unique_id(void *id128) {
+  if (!id128) return fail(PH_E_INVALID, "ph_route_unique_id: NULL argument");
+  int rc = load_rccl();
+  if (rc) return rc;
+  static_assert(PH_ROUTE_ID_BYTES == sizeof(Id128), "ncclUniqueId is 128 bytes");
+  PH_NCCL(g_rccl.GetUniqueId(id128));
+  return PH_OK;
+}
+
+int ph_route_init(ph_ctx *ctx, const void *id128, int rank, int world, ph_route **out) {
+  if (!ctx || !id128 || !out) return fail(PH_E_INVALID, "ph_route_init: NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(PH_E_INVALID, "ph_route_init: rank %d of %d", rank, world);
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  rc = load_rccl();
+  if (rc) return rc;
+  Id128 id;
+  memcpy(id.bytes, id128, sizeof id.bytes);
+  void *comm = nullptr;
+  PH_NCCL(g_rccl.CommInitRank(&comm, world, id, rank));
+  hipStream_t s = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    g_rccl.CommDestroy(comm);
+    return fail(PH_E_HIP, "ph_route_init: hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  *out = new ph_route{ctx, comm, s, rank, world};
+  ctx_ref(ctx);
+  return PH_OK;
+}
+
+int ph_route_destroy(ph_route *r) {
+  if (!r) return PH_OK;
+  hipSetDevice(r->ctx->device);
+  hipStreamSynchronize(r->stream);
+  g_rccl.CommDestroy(r->comm);
+  hipStreamDestroy(r->stream);
+  ph_ctx *ctx = r->ctx;
+  delete r;
+  ctx_unref(ctx);
+  return PH_OK;
+}
+
+int ph_route_group_begin(ph_route *r) {
+  if (!r) return fail(PH_E_INVALID, "ph_route_group_begin: NULL route");
+  PH_NCCL(g_rccl.GroupStart());
+  return PH_OK;
+}
+int ph_route_group_end(ph_route *r) {
+  if (!r) return fail(PH_E_INVALID, "ph_route_group_end: NULL route");
+  int rc = set_device(r->ctx);
+  if (rc) return rc;
+  PH_NCCL(g_rccl.GroupEnd());
+  return PH_OK;
+}
+
+static int route_args(ph_route *r, const void *p, size_t bytes, int peer, const char *fn) {
+  if (!r || !p) return fail(PH_E_INVALID, "%s: NULL argument", fn);
+  if (bytes % 4) return fail(PH_E_INVALID, "%s: %zu bytes is not a multiple of 4", fn, bytes);
+  if (peer < 0 || peer >= r->world) return fail(PH_E_INVALID, "%s: peer %d of %d ranks", fn, peer, r->world);
+  return set_device(r->ctx);
+}
+int ph_route_send(ph_route *r, const void *src, size_t bytes, int peer) {
+  int rc = route_args(r, src, bytes, peer, "ph_route_send");
+  if (rc) return rc;
+  PH_NCCL(g_rccl.Send(src, bytes / 4, kNcclUint32, peer, r->comm, r->stream));
+  return PH_OK;
+}
+int ph_route_recv(ph_route *r, void *dst, size_t bytes, int peer) {
+  int rc = route_args(r, dst, bytes, peer, "ph_route_recv");
+  if (rc) return rc;
+  PH_NCCL(g_rccl.Recv(dst, bytes / 4, kNcclUint32, peer, r->comm, r->stream));
+  return PH_OK;
+}
+
+static int order_streams(ph_ctx *ctx, hipStream_t waiter, hipStream_t signal, const char *fn) {
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  hipEvent_t ev;
+  PH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, signal);
+  if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
+  hipEventDestroy(ev);
+  if (e != hipSuccess) return fail(PH_E_HIP, "%s: %s", fn, hipGetErrorString(e));
+  return PH_OK;
+}
+int ph_route_after_queue(ph_route *r, int queue) {
+  if (!r || queue < 0 || queue > 2) return fail(PH_E_INVALID, "ph_route_after_queue: bad argument");
+  return order_streams(r->ctx, r->stream, r->ctx->streams[queue], "ph_route_after_queue");
+}
+int ph_queue_after_route(ph_route *r, int queue) {
+  if (!r || queue < 0 || queue > 2) return fail(PH_E_INVALID, "ph_queue_after_route: bad argument");
+  return order_streams(r->ctx, r->ctx->streams[queue], r->stream, "ph_queue_after_route");
+}
+int ph_route_wait(ph_route *r) {
+  if (!r) return fail(PH_E_INVALID, "ph_route_wait: NULL route");
+  int rc = set_device(r->ctx);
+  if (rc) return rc;
+  PH_HIP(hipStreamSynchronize(r->stream));
+  return PH_OK;
+}
+void *ph_route_stream(ph_route *r) { return r ? (void *)r->stream : nullptr; }
 
 int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes) {
   if (!ctx) return fail(PH_E_INVALID, "ph_ctx_buffer_stats: ctx is NULL");

@@ -99,6 +99,75 @@ class RouteExchange:
         return self.bytes_per_frame * (len(self.plan.sends) + len(self.plan.recvs))
 
 
+class DeviceRouteExchange:
+    """The same hand-off on the library's own path (ph_route_*, include/phaneron_hip.h): RCCL send / recv on a
+    communication stream of its own, ordered against the context's process queue ON THE DEVICE - no host wait, and
+    the transfer overlaps whatever the process queue runs between `start` and `finish` (the sink's v210 reads).
+
+        ex.start(frames)      # comm stream waits for the process queue's work so far, then posts this period's
+                              # sends and receives as one RCCL group
+        ... enqueue work that does not need the routed frames ...
+        routed = ex.finish()  # the process queue waits for the comm stream; returns {dst channel: tensor}
+
+    loopback=True sends same-rank routes through RCCL too (peer == own rank) instead of aliasing the buffer: the
+    way to exercise this path on a single GPU."""
+
+    def __init__(self, ctx, routes: Sequence[Route], rank: int, world: int, frame_numel: int, dtype, device,
+                 channels_per_rank: int = 0, unique_id: bytes = None, loopback: bool = False):
+        import torch
+        from . import capi
+        self.plan = plan_routes(routes, rank, world, channels_per_rank)
+        if loopback:
+            self.plan = RoutePlan([], [(rt, rank) for rt in self.plan.local] + self.plan.sends,
+                                  [(rt, rank) for rt in self.plan.local] + self.plan.recvs)
+        self.route = capi.Route(ctx, unique_id, rank, world)
+        self.recv_bufs = {rt: torch.empty(frame_numel, dtype=dtype, device=device) for rt, _ in self.plan.recvs}
+        self.bytes_per_frame = frame_numel * torch.empty((), dtype=dtype).element_size()
+        self._out = {}
+
+    def start(self, frames: Dict[int, "object"]) -> None:
+        self._out = {rt.dst: frames[rt.src] for rt in self.plan.local}  # same device: share the buffer
+        if not (self.plan.sends or self.plan.recvs):
+            return
+        self.route.after_queue()
+        with self.route.group():
+            for rt, peer in self.plan.sends:
+                self.route.send(frames[rt.src], peer, self.bytes_per_frame)
+            for rt, peer in self.plan.recvs:
+                self.route.recv(self.recv_bufs[rt], peer, self.bytes_per_frame)
+
+    def finish(self) -> Dict[int, "object"]:
+        if self.plan.sends or self.plan.recvs:
+            self.route.queue_after()
+        for rt, _ in self.plan.recvs:
+            self._out[rt.dst] = self.recv_bufs[rt]
+        return self._out
+
+    def traffic_bytes(self) -> int:
+        return self.bytes_per_frame * (len(self.plan.sends) + len(self.plan.recvs))
+
+    def close(self):
+        self.route.destroy()
+
+
+def share_route_id(dist, rank: int):
+    """One ph_route_unique_id for the job: made on rank 0, handed round over the existing process group."""
+    from . import capi
+    box = [capi.route_unique_id() if rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def frame_fingerprint(t):
+    """Position-sensitive 64-bit fingerprint of a frame, computed on its device (a permuted or partly stale frame
+    changes it; a plain sum would not notice)."""
+    import torch
+    v = t.view(torch.int32).to(torch.int64)
+    k = (torch.arange(v.numel(), device=v.device, dtype=torch.int64) * 2654435761 + 40503) | 1
+    return int(((v * k).sum()).item())
+
+
 def timed_steps(step, steps: int, warmup: int, sync, dist=None, device=None) -> float:
     """The bench timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by
     barrier + device sync on both sides; returns the MAX elapsed seconds over ranks."""

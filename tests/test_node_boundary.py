@@ -103,7 +103,7 @@ def test_napi_addon_builds_loads_and_refuses_without_gpu():
           "const want=['abiVersion','createContext','contextInfo','createBuffer','bufAddRef','bufRelease','bufRefCount',"
           "'hostAccess','waitFinish','createProgram','runProgram','bufferStats','queueWaitQueue','downloadAsync',"
           "'eventRecord','eventWait','eventDone','waitFinishSpin','resolveProgram','gammaLut','colourMatrix',"
-          "'transformMatrix','planeBytes'];"
+          "'transformMatrix','planeBytes','routeUniqueId','routeInit','routeOp'];"
           "for (const k of want) if (typeof a[k] !== 'function') { console.log('missing', k); process.exit(2) }"
           "console.log(a.abiVersion())") % os.path.join(ROOT, "node", "phaneron_napi.node")
     r = subprocess.run([NODE, "-e", js], capture_output=True, text=True)
@@ -288,6 +288,7 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
     # five flushes requested together: served in order, one drain (jobs.js)
     assert res["boardStats"] == {"flushes": 5, "drains": 1, "kernels": 7}
     assert res["liveAfter"] == 0
+    assert res["routeLoopbackCompare"] == 0     # a frame through ph_route (RCCL, own rank) and back to v210: the ramp again
 
 
 def mixer_matrix(w, h, p):

@@ -1,7 +1,11 @@
-"""GPU test (-m gpu) of BASELINE config 5's shape on ONE GPU: two processes (one per "GPU", both on
-cuda:0, gloo staged through host memory because RCCL needs distinct devices), two channels each,
-every channel's fourth layer routed from a channel of the OTHER process.  tools/route_bench.py --check
-verifies that what arrives is the source channel's combiner output."""
+"""GPU tests (-m gpu) of BASELINE config 5's shape on ONE GPU.  tools/route_bench.py --check verifies, bit for
+bit (position-sensitive fingerprint computed on the device), that what arrives as a channel's routed layer is the
+source channel's combiner output.
+  - one rank, routes alias local buffers (the reference's own case: addRef on the same buffer);
+  - one rank, --loopback: the same routes through the library's ROUTE path (ph_route_*: RCCL send / recv to the own
+    rank on the communication stream, event-ordered against the process queue) - RCCL refuses two ranks on one
+    device, so this is how the C path, its stream ordering and librccl itself run on a single-GPU box;
+  - two processes on cuda:0 with gloo staged through host memory: the cross-rank plan (who sends what to whom)."""
 import json
 import os
 import subprocess
@@ -26,6 +30,27 @@ def test_routes_alias_locally_on_one_rank():
     assert "route check ok: 2 channels on 1 rank(s)" in out
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["routes_crossing_ranks_per_rank"] == 0 and line["route_bytes_per_rank_per_step"] == 0
+
+
+def test_routes_through_the_library_route_path_rccl_loopback():
+    out = run([sys.executable, "tools/route_bench.py", "--loopback", "--check", "--steps", "5", "--warmup", "2", "--width", "1920",
+               "--height", "270"])
+    assert "route check ok: 2 channels on 1 rank(s), ph_route (RCCL)" in out
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["path"].startswith("ph_route")
+    # both channels' outputs travel: 2 sends + 2 receives of 1920x270 f32 RGBA per step
+    assert line["routes_crossing_ranks_per_rank"] == 2 and line["route_bytes_per_rank_per_step"] == 4 * 1920 * 270 * 16
+
+
+def test_route_results_do_not_depend_on_the_path(tmp_path):
+    """The composited output of every channel after a few steps is the same whether routed frames alias or travel
+    through RCCL (the routed layer is one step late either way)."""
+    outs = []
+    for extra in ([], ["--loopback"]):
+        o = run([sys.executable, "tools/route_bench.py", "--steps", "4", "--warmup", "0", "--width", "1920", "--height", "270",
+                 "--print-fingerprints"] + extra)
+        outs.append([l for l in o.splitlines() if l.startswith("fingerprints")][-1])
+    assert outs[0] == outs[1]
 
 
 def test_routes_cross_ranks_world_2():

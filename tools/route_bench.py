@@ -6,8 +6,13 @@ over xGMI, phaneron_amd/multigpu.py).  Per channel and frame: v210 read x3 -> co
 frame of the PREVIOUS step (a route is one frame late in the reference too) -> v210 write.
 
   python tools/route_bench.py                                       # one GPU: both routes are local aliases
-  torchrun --nproc-per-node 8 tools/route_bench.py                  # 16 channels on 8 GPUs
+  python tools/route_bench.py --loopback --check                    # one GPU, routes through RCCL to the own rank
+  torchrun --nproc-per-node 8 tools/route_bench.py                  # 16 channels on 8 GPUs (RCCL over xGMI)
   torchrun --nproc-per-node 2 tools/route_bench.py --backend gloo --same-gpu --check   # functional test on one GPU
+
+With RCCL (backend nccl, or --loopback) the hand-off runs on the library's path (ph_route_*): a communication stream
+of its own, event-ordered against the process queue, overlapping the three v210 reads of the receiving channels.
+The gloo variant stages through host memory with torch.distributed (functional test only).
 
 Prints one JSON line on rank 0."""
 import argparse
@@ -30,7 +35,9 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--same-gpu", action="store_true", help="every rank uses cuda:0 (functional test)")
-    ap.add_argument("--check", action="store_true", help="verify that a routed layer is the source channel's output")
+    ap.add_argument("--check", action="store_true", help="verify (bit for bit) that a routed layer is the source channel's output")
+    ap.add_argument("--print-fingerprints", action="store_true", help="print a fingerprint of every channel's final v210 output")
+    ap.add_argument("--loopback", action="store_true", help="send same-rank routes through RCCL too (peer = own rank)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -70,23 +77,37 @@ def main():
             out=[torch.zeros(npx * 4, dtype=torch.float32, device=device) for _ in range(2)],  # [previous, current]
             v210=torch.empty(words, dtype=torch.int32, device=device))
         chan[ch]["out"][0][3::4] = 1.0  # frame -1 of every channel: opaque black
-    ex = multigpu.RouteExchange(routes, rank, world, npx * 4, torch.float32, device, C, via_host=(args.backend == "gloo"))
+    on_device = args.backend == "nccl" and (world > 1 or args.loopback)
+    if on_device:
+        ex = multigpu.DeviceRouteExchange(ctx, routes, rank, world, npx * 4, torch.float32, device, C,
+                                          unique_id=multigpu.share_route_id(dist, rank), loopback=args.loopback)
+    else:
+        ex = multigpu.RouteExchange(routes, rank, world, npx * 4, torch.float32, device, C, via_host=(args.backend == "gloo"))
     torch.cuda.synchronize()
     exch_s = [0.0]
 
     def step(i):
-        ctx.wait()                                   # previous outputs are complete before they travel
-        t0 = time.perf_counter()
-        routed = ex.exchange({ch: chan[ch]["out"][0] for ch in mine})
-        torch.cuda.synchronize()                     # RCCL runs on torch's stream, the kernels on the library's
-        exch_s[0] += time.perf_counter() - t0
+        if on_device:
+            # the routed frames of the previous step travel on the communication stream WHILE this step's reads run;
+            # nothing waits on the host
+            ex.start({ch: chan[ch]["out"][0] for ch in mine})
+            for ch in mine:
+                for l in range(3):
+                    ctx.v210_read(chan[ch]["layers"][l], chan[ch]["rgba"][l], w, h, *rd)
+            routed = ex.finish()                     # process queue waits for the comm stream (on the device)
+        else:
+            ctx.wait()                               # previous outputs are complete before they travel
+            t0 = time.perf_counter()
+            routed = ex.exchange({ch: chan[ch]["out"][0] for ch in mine})
+            torch.cuda.synchronize()                 # torch.distributed runs on torch's stream, the kernels on the library's
+            exch_s[0] += time.perf_counter() - t0
+            for ch in mine:
+                for l in range(3):
+                    ctx.v210_read(chan[ch]["layers"][l], chan[ch]["rgba"][l], w, h, *rd)
         for ch in mine:
             c = chan[ch]
-            for l in range(3):
-                ctx.v210_read(c["layers"][l], c["rgba"][l], w, h, *rd)
             ctx.combine(c["rgba"] + [routed[ch]], c["out"][1], w, h)
             ctx.v210_write(c["out"][1], c["v210"], w, h, 0, *wr)
-        ctx.wait()
         for ch in mine:
             chan[ch]["out"].reverse()
 
@@ -94,24 +115,33 @@ def main():
         ctx.wait()
         torch.cuda.synchronize()
 
-    if args.check:  # two steps by hand: what arrives as channel k's routed layer is channel src(k)'s output
+    if args.check:  # by hand: what arrives as channel k's routed layer is, bit for bit, channel src(k)'s output
         step(0)
-        sums = torch.zeros(total, dtype=torch.float64, device=device)
+        sync()
+        prints = torch.zeros(total, dtype=torch.int64)
         for ch in mine:
-            sums[ch] = chan[ch]["out"][0].double().sum()
+            prints[ch] = multigpu.frame_fingerprint(chan[ch]["out"][0])
         if dist is not None:
-            cpu = sums.cpu()
-            dist.all_reduce(cpu)
-            sums = cpu.to(device)
-        ctx.wait()
-        routed = ex.exchange({ch: chan[ch]["out"][0] for ch in mine})
-        torch.cuda.synchronize()
+            if args.backend == "nccl":
+                p = prints.to(device)
+                dist.all_reduce(p)
+                prints = p.cpu()
+            else:
+                dist.all_reduce(prints)
+        if on_device:
+            ex.start({ch: chan[ch]["out"][0] for ch in mine})
+            routed = ex.finish()
+        else:
+            routed = ex.exchange({ch: chan[ch]["out"][0] for ch in mine})
+        sync()
         for ch in mine:
             src = (ch + total // 2) % total
-            got = float(routed[ch].double().sum())
-            assert abs(got - float(sums[src])) <= 1e-6 * max(1.0, abs(got)), (ch, src, got, float(sums[src]))
+            got = multigpu.frame_fingerprint(routed[ch])
+            assert got == int(prints[src]), (ch, src, got, int(prints[src]))
+            assert on_device or world > 1 or routed[ch] is chan[src]["out"][0]
         if rank == 0:
-            print("route check ok: %d channels on %d rank(s)" % (total, world), flush=True)
+            print("route check ok: %d channels on %d rank(s), %s" % (total, world, "ph_route (RCCL)" if on_device else
+                  "torch.distributed" if world > 1 else "local alias"), flush=True)
     exch_s[0] = 0.0
     elapsed = multigpu.timed_steps(step, args.steps, args.warmup, sync, dist, device if args.backend == "nccl" else None)
     if rank == 0:
@@ -123,7 +153,13 @@ def main():
             "routes_crossing_ranks_per_rank": len(ex.plan.sends), "route_bytes_per_rank_per_step": ex.traffic_bytes(),
             "exchange_ms_per_step_rank0": round(1e3 * per_step_exch, 3),
             "exchange_GBps_rank0": round(ex.traffic_bytes() / per_step_exch / 1e9, 1) if per_step_exch > 0 and ex.traffic_bytes() else None,
-            "backend": args.backend if world > 1 else "none (single rank: routes alias local buffers)"}), flush=True)
+            "path": "ph_route: RCCL on its own stream, event-ordered, overlapped with the v210 reads" if on_device else
+                    ("torch.distributed %s, host-synchronised" % args.backend) if world > 1 else "single rank: routes alias local buffers"}), flush=True)
+    if args.print_fingerprints:
+        sync()
+        print("fingerprints rank %d: %s" % (rank, " ".join("%d:%x" % (ch, multigpu.frame_fingerprint(chan[ch]["v210"]) & (2 ** 64 - 1)) for ch in mine)), flush=True)
+    if on_device:
+        ex.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
