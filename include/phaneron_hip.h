@@ -287,6 +287,25 @@ int ph_compose_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers,
                           uint32_t out_width, uint32_t out_height, uint32_t interlace,
                           const void *wr_col_matrix12, const void *wr_gamma_lut);
 
+/* ---- fused field pipeline (no single reference equivalent): the per-field job batch of a de-interlacing,
+ *      scaling channel - Yadif per layer (yadif.ts:115-145) -> transform per layer (producer/mixer.ts:209-223)
+ *      -> combine_N (combiner.ts:219-254) -> v210 write (io.ts:152-164) - as ONE kernel: de-interlaced source
+ *      windows are staged in LDS and sampled from there, so neither the de-interlaced nor the placed nor the
+ *      combined f32 frames reach HBM.  Bit-identical to ph_yadif + ph_transform + ph_combine + ph_v210_write.
+ *      Limits (PH_E_INVALID otherwise - run the separate kernels): every transform axis-aligned and not mirrored
+ *      (matrix[1] == matrix[3] == 0, matrix[0] > 0, matrix[4] > 0), the source window of a 192 x 16 output slice
+ *      within the LDS (up-scales and 1:1), out_width % 192 == 0, progressive output, the writer LUT registered. */
+typedef struct ph_field_layer {
+  const void *prev, *cur, *next; /* device, float RGBA, width x height (prev / next unused when deinterlace == 0) */
+  int width, height;
+  const void *matrix9;           /* device 3x3 transform matrix (ph_transform_matrix) */
+  const float *matrix9_host;     /* the same nine values on the host */
+  int deinterlace;               /* 0 = progressive source (cur as it is), 1 = yadif */
+  int parity, tff, skip_spatial; /* as ph_yadif */
+} ph_field_layer;
+int ph_fused_field_v210(ph_ctx *ctx, int queue, int n, const ph_field_layer *layers, void *out, uint32_t out_width,
+                        uint32_t out_height, const void *wr_col_matrix12, const void *wr_gamma_lut);
+
 /* ---- gamma LUT placement.  The reference hands its kernels a 65536-entry f32 `gammaLut` buffer
  *      (loadSave.ts:65-73,152-160) and gathers from it 3x per pixel.  Registering the table's
  *      host contents lets the library keep an exact compressed copy for the CU's LDS

@@ -63,6 +63,8 @@ struct ph_ctx {
   hipDeviceProp_t props;
   std::multimap<size_t, void *> pool;  // free device blocks by exact size
   size_t pooled_bytes = 0, live_buffers = 0, live_bytes = 0;
+  void *field_scratch = nullptr;  // index frame of the field pipeline (ph_fused_field_v210)
+  size_t field_scratch_bytes = 0;
   std::mutex mu;
   std::atomic<int> refs{1};
   std::atomic<bool> closed{false};
@@ -140,6 +142,7 @@ void ctx_unref(ph_ctx *ctx) {
   for (auto &kv : ctx->pool) hipFree(kv.second);
   for (auto &kv : ctx->luts)
     if (kv.second.blob_dev) hipFree(kv.second.blob_dev);
+  if (ctx->field_scratch) hipFree(ctx->field_scratch);
   delete ctx;
 }
 
@@ -1148,6 +1151,58 @@ int ph_compose_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers,
   a.wr_cm = (const float *)wr_cm, a.wr = *wv;
   if (!a.lines) return PH_OK;
   PH_LAUNCH(ph::launch_compose_write_v210(stream_of(ctx, queue), a, (uint32_t)ctx->props.multiProcessorCount));
+}
+
+int ph_fused_field_v210(ph_ctx *ctx, int queue, int n, const ph_field_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
+                        const void *wr_cm, const void *wr_lut) {
+  if (!ctx || !layers || !out || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_fused_field_v210: NULL argument");
+  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_fused_field_v210: 1..%d layers", ph::kMaxLayers);
+  if (!out_w || out_w % 192) return fail(PH_E_INVALID, "ph_fused_field_v210: width %u is not a multiple of 192; run the separate kernels", out_w);
+  const ph::LutView *wv = lds_view(ctx, wr_lut);
+  if (!wv) return fail(PH_E_INVALID, "ph_fused_field_v210: the writer gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)");
+  ph::FieldArgs a{};
+  a.n = n;
+  uint32_t need = 1, widest = 1;
+  for (int i = 0; i < n; ++i) {
+    const ph_field_layer &L = layers[i];
+    if (!L.cur || !L.matrix9 || !L.matrix9_host || L.width <= 0 || L.height <= 0)
+      return fail(PH_E_INVALID, "ph_fused_field_v210: layer %d is incomplete", i);
+    if (L.deinterlace && (!L.prev || !L.next)) return fail(PH_E_INVALID, "ph_fused_field_v210: layer %d de-interlaces but has no prev / next frame", i);
+    const float *m = L.matrix9_host;
+    if (m[1] != 0.0f || m[3] != 0.0f || !(m[0] > 0.0f) || !(m[4] > 0.0f))
+      return fail(PH_E_INVALID, "ph_fused_field_v210: layer %d is rotated or mirrored; run the separate kernels", i);
+    uint32_t wc = 0, wr = 0;
+    ph::field_window_extent(m, L.width, L.height, out_w, out_h, &wc, &wr);
+    const uint32_t px = wc * wr;
+    widest = wc > widest ? wc : widest;
+    if (px > 160u * 1024u / 16u)
+      return fail(PH_E_INVALID, "ph_fused_field_v210: layer %d is shrunk too far for the LDS window (%u pixels per slice); run the separate kernels", i, px);
+    need = px > need ? px : need;
+    a.prev[i] = L.prev, a.cur[i] = L.cur, a.next[i] = L.next, a.matrix[i] = (const float *)L.matrix9;
+    a.lw[i] = L.width, a.lh[i] = L.height, a.mode[i] = L.deinterlace ? 1 : 0;
+    a.parity[i] = L.parity ? 1 : 0, a.tff[i] = L.tff ? 1 : 0, a.skip[i] = L.skip_spatial ? 1 : 0;
+  }
+  a.out = out, a.out_w = out_w, a.out_h = out_h, a.window_capacity = need, a.window_max_width = widest;
+  a.wr_cm = (const float *)wr_cm, a.wr = *wv;
+  if (!out_h) return PH_OK;
+  // the index frame between the two stages (6 bytes per pixel): one per context, grown on demand.  Successive calls on
+  // different queues would share it - the field pipeline of a channel runs on one queue.
+  const size_t need_bytes = ph::field_index_bytes(out_w, out_h);
+  {
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->field_scratch_bytes < need_bytes) {
+      if (ctx->field_scratch) {
+        for (int q = 0; q < 3; ++q) hipStreamSynchronize(ctx->streams[q]);
+        hipFree(ctx->field_scratch);
+        ctx->field_scratch = nullptr, ctx->field_scratch_bytes = 0;
+      }
+      PH_HIP(hipMalloc(&ctx->field_scratch, need_bytes));
+      ctx->field_scratch_bytes = need_bytes;
+    }
+  }
+  PH_LAUNCH(ph::launch_field_compose_v210(stream_of(ctx, queue), a, ctx->field_scratch, (uint32_t)ctx->props.multiProcessorCount));
 }
 
 int ph_yadif(ph_ctx *ctx, int queue, const void *prev, const void *cur, const void *next, int w, int h, int parity,

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include "ph_device.h"
 #include "ph_kernels.h"
+#include "ph_yadif.h"
 
 #pragma clang fp contract(off)
 
@@ -208,52 +209,6 @@ __global__ __launch_bounds__(kBlock) void fused_v210_combine_kernel(FusedArgs a)
 // yadif (reference yadifCl.ts:28-167).  grid = (ceil(w/250), ceil(h/16)); the two neighbouring `cur`
 // rows of an interpolated row are staged in LDS for the 14-tap spatial predictor.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float yadif_spatial(float a, float b, float c, float d, float e, float f, float g,
-                                               float h, float i, float j, float k, float l, float m, float n) {
-  float pred = (d + k) / 2.0f;
-  float best = __builtin_fabsf(c - j) + __builtin_fabsf(d - k) + __builtin_fabsf(e - l);
-  float score = __builtin_fabsf(b - k) + __builtin_fabsf(c - l) + __builtin_fabsf(d - m);
-  bool cmp = score < best;
-  pred = cmp ? (c + l) / 2.0f : pred;
-  best = cmp ? score : best;
-  score = cmp ? __builtin_fabsf(a - l) + __builtin_fabsf(b - m) + __builtin_fabsf(c - n) : score;
-  cmp = cmp && (score < best);
-  pred = cmp ? (b + m) / 2.0f : pred;
-  best = cmp ? score : best;
-
-  score = __builtin_fabsf(d - i) + __builtin_fabsf(e - j) + __builtin_fabsf(f - k);
-  cmp = score < best;
-  pred = cmp ? (e + j) / 2.0f : pred;
-  best = cmp ? score : best;
-  score = cmp ? __builtin_fabsf(e - h) + __builtin_fabsf(f - i) + __builtin_fabsf(g - j) : score;
-  cmp = cmp && (score < best);
-  pred = cmp ? (f + i) / 2.0f : pred;
-  return pred;
-}
-
-__device__ __forceinline__ float yadif_temporal(float A, float B, float C, float D, float E, float F, float G,
-                                                float H, float I, float J, float K, float L, float pred,
-                                                int skip) {
-  const float p0 = (C + H) / 2.0f, p1 = F, p2 = (D + I) / 2.0f, p3 = G, p4 = (E + J) / 2.0f;
-  const float t0 = __builtin_fabsf(D - I);
-  const float t1 = (__builtin_fabsf(A - F) + __builtin_fabsf(B - G)) / 2.0f;
-  const float t2 = (__builtin_fabsf(K - F) + __builtin_fabsf(G - L)) / 2.0f;
-  float diff = __builtin_fmaxf(__builtin_fmaxf(t0, t1), t2);
-  if (!skip) {
-    const float p2mp3 = p2 - p3, p2mp1 = p2 - p1, p0mp1 = p0 - p1, p4mp3 = p4 - p3;
-    const float maxi = __builtin_fmaxf(__builtin_fmaxf(p2mp3, p2mp1), __builtin_fminf(p0mp1, p4mp3));
-    const float mini = __builtin_fminf(__builtin_fminf(p2mp3, p2mp1), __builtin_fmaxf(p0mp1, p4mp3));
-    diff = __builtin_fmaxf(__builtin_fmaxf(diff, mini), -maxi);
-  }
-  pred = (pred > (p2 + diff)) ? p2 + diff : pred;
-  pred = (pred < (p2 - diff)) ? p2 - diff : pred;
-  return pred;
-}
-
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-#define PH_C4(v, c) ((c) == 0 ? (v).x : (c) == 1 ? (v).y : (c) == 2 ? (v).z : (v).w)
-
 // The filter walks DOWN a strip of rows with the five-row windows of the three frames in registers.
 // A row-per-block mapping re-reads every source row for each output row that uses it (13 loads per
 // interpolated pixel, served by L2: the L2 becomes the bound, 129 us at 2160p against 94 us);

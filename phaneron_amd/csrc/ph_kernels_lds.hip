@@ -146,22 +146,6 @@ __device__ __forceinline__ PxPending write_px_issue(float yr, float yg, float yb
   return p;
 }
 
-// the same from ready-made LUT indices (floats M + idx, ph_ldslut.h): phase 2 of the fused kernel
-__device__ __forceinline__ uint4 write_quad_idx_lds(const float (&yi)[18], const WriteK &wk, const LutK &lut) {
-  uint32_t y[6], u[3], v[3];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const float gr = lds_lut_fetch(lut, yi[3 * j]), gg = lds_lut_fetch(lut, yi[3 * j + 1]);
-    const float gb = lds_lut_fetch(lut, yi[3 * j + 2]);
-    y[j] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.y));
-    if ((j & 1) == 0) {
-      u[j >> 1] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.u));
-      v[j >> 1] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.v));
-    }
-  }
-  return pack_quad(y, u, v);
-}
-
 __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const WriteK &wk, const LutK &lut) {
   uint32_t y[6], u[3], v[3];
 #pragma unroll

@@ -128,6 +128,23 @@ __device__ __forceinline__ float lds_lut_at_unit(const LutK &k, float t) {
   return lds_lut_fetch(k, lds_lut_index_unit(t));
 }
 
+// One packed v210 quad from eighteen ready-made writer-table indices (floats M + idx): gamma table, RGB->YCbCr
+// matrix, rounding, packing (v210.ts:145-162).  Phase 2 of the two-phase kernels (fused channel, field pipeline).
+__device__ __forceinline__ uint4 write_quad_idx_lds(const float (&yi)[18], const WriteK &wk, const LutK &lut) {
+  uint32_t y[6], u[3], v[3];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float gr = lds_lut_fetch(lut, yi[3 * j]), gg = lds_lut_fetch(lut, yi[3 * j + 1]);
+    const float gb = lds_lut_fetch(lut, yi[3 * j + 2]);
+    y[j] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.y));
+    if ((j & 1) == 0) {
+      u[j >> 1] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.u));
+      v[j >> 1] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.v));
+    }
+  }
+  return pack_quad(y, u, v);
+}
+
 // A gamma LUT as the kernels see it: either the compressed table in LDS or the plain f32 table
 // in global memory (tables that do not compress, or the "lds_lut" option switched off).
 struct LutInLds {
