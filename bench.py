@@ -40,10 +40,16 @@ def parse():
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 2 and 3 (the `secondary` field)")
     ap.add_argument("--plan", action="store_true",
                     help="print how --gpus N would be launched (one JSON line) and exit; needs no GPU")
     return ap.parse_args()
 
+
+# Issue-rate ceiling of the VALU: one wave64 instruction per SIMD every 2 cycles at 2.4 GHz on 1024 SIMDs
+# (MI355X_MICROARCH.md; tools/opbench3.hip sustains one per 2.2 - 2.4 cycles at 1.9 - 2.4 GHz).  The headline kernel's
+# instruction count per launch comes from the committed SQ_INSTS_VALU pass (profiles/): it is a property of the binary.
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2.0
 
 FIXED_WARMUP = 200  # untimed launches before --warmup is honoured: a 20-step run must still measure settled clocks
 
@@ -130,6 +136,17 @@ def cpu_baseline(args, budget_s):
             "one_core_value": round(one, 3),
             "sample": "%d whole %dx%d %d-layer frames in %.1f s through %s; one_core_value = 2 more frames on 1 thread"
                       % (frames_done, w, h, n, el, what)}
+
+
+def recorded_valu_instructions():
+    """wave64 VALU instructions per launch of the fused kernel (rocprofv3 SQ_INSTS_VALU pass), if recorded"""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt")), reverse=True):
+        for line in open(p):
+            f = line.split()
+            if len(f) >= 2 and f[0] == "SQ_INSTS_VALU":
+                return float(f[1]), os.path.basename(p)
+    return None, None
 
 
 def recorded_traffic():
@@ -261,6 +278,20 @@ def main():
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": round(kernel_ms, 5)},
         }
+        insts, src = recorded_valu_instructions()
+        if insts and C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS):
+            rate = insts / (kernel_ms * 1e-3)
+            line["roofline"]["valu"] = {"achieved": round(rate / 1e12, 4), "peak": round(VALU_PEAK_WAVE_INSTR_PER_S / 1e12, 4),
+                                        "unit": "T wave64-instr/s", "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4),
+                                        "instructions_per_launch": insts, "source": "recorded: profiles/" + src}
+        if world == 1 and not args.no_secondary and C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS):
+            # BASELINE configs 2 and 3 (the compositing configs: real alpha, transforms, de-interlace), fastest route of each,
+            # measured after the timed region; tools/config_bench.py prints every route
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import config_bench
+            del ring[:]
+            torch.cuda.empty_cache()
+            line["secondary"] = config_bench.measure(ctx, torch, np, capi, "best", reps=150)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:

@@ -61,7 +61,8 @@ def main():
     timeit("combine_2 2160p", lambda i: ctx.combine([img[(i + j) % R] for j in range(2)], out_img[i % 2], w, h), 3 * ib)
     timeit("transition_dissolve 2160p", lambda i: ctx.transition_dissolve(img[i % R], img[(i + 1) % R], 0.3, out_img[i % 2], w, h), 3 * ib)
     timeit("transition_wipe 2160p", lambda i: ctx.transition_wipe(img[i % R], img[(i + 1) % R], img[(i + 2) % R], out_img[i % 2], w, h), 4 * ib)
-    timeit("wipe 2160p", lambda i: ctx.wipe(img[i % R], img[(i + 1) % R], 0.4, out_img[i % 2], w, h), 3 * ib)
+    # wipe picks ONE of its two inputs per pixel: one image read + one written
+    timeit("wipe 2160p", lambda i: ctx.wipe(img[i % R], img[(i + 1) % R], 0.4, out_img[i % 2], w, h), 2 * ib)
     timeit("yadif 2160p", lambda i: ctx.yadif(img[i % R], img[(i + 1) % R], img[(i + 2) % R], out_img[i % 2], w, h, 0, 1), 4 * ib)
     timeit("transform identity 2160p", lambda i: ctx.transform(img[i % R], w, h, m, out_img[i % 2], w, h), 2 * ib)
     timeit("transform 1080->2160", lambda i: ctx.transform(src1080[i % R], 1920, 1080, m, out_img[i % 2], w, h), ib + ib // 4)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that regenerates every measured artifact under profiles/ (written to
 # gpurun_out/profile/, copied into profiles/ afterwards).  usage: bash tools/profile_round.sh <tag>
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profile; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -18,7 +18,7 @@ f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
 
 # 3. HBM traffic: separate --pmc passes, calibrated on a 1 GiB copy (tools/microbench copy16)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_bench_$c -- $BENCH --steps 40 --warmup 5 --cpu-seconds 0 > $OUT/pmc_bench_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_bench_$c -- $BENCH --steps 40 --warmup 5 --cpu-seconds 0 --no-secondary > $OUT/pmc_bench_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_micro_$c -- $ROOT/tools/microbench > $OUT/pmc_micro_$c.log 2>&1
 done
 python3 - "$OUT" "$TAG" <<'PY'
@@ -50,7 +50,7 @@ doc = {"fused_v210_combine_4_2160p_bytes_per_launch": traffic,
                                   "fetch_correction": fc, "write_correction": wc},
                   "algorithmic_bytes": 110592000,
                   "ratio_traffic_over_algorithmic": traffic / 110592000.0 if traffic else None,
-                  "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 40 --warmup 5 --cpu-seconds 0"}}
+                  "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 40 --warmup 5 --cpu-seconds 0 --no-secondary"}}
 json.dump(doc, open("%s/pmc_traffic.json" % out, "w"), indent=1)
 print("traffic", traffic)
 PY
@@ -62,10 +62,12 @@ rm -rf $ROOT/gpurun_out/pmc_sq/*/  # keep the summary only
 # 5. per-kernel, per-config, per-instruction and staging measurements
 python $ROOT/tools/kernel_bench.py 2>/dev/null | grep '^{' > $OUT/${TAG}_kernel_bench.jsonl
 python $ROOT/tools/config_bench.py 2>/dev/null | grep '^{' > $OUT/${TAG}_config_bench.jsonl
-$ROOT/tools/opbench2 > $OUT/${TAG}_opbench2.jsonl 2>/dev/null
+$ROOT/tools/opbench3 > $OUT/${TAG}_opbench3.jsonl 2>/dev/null
+$ROOT/tools/opbench4 > $OUT/${TAG}_opbench4.jsonl 2>/dev/null
+python $ROOT/tools/route_bench.py --loopback 2>/dev/null | grep '^{' > $OUT/${TAG}_route_loopback.jsonl
 python $ROOT/tools/staging_bench.py 60 2>/dev/null | grep '^{' > $OUT/${TAG}_staging_bench.jsonl
 $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
 (node $ROOT/node/test/bench_node.js 200; node $ROOT/node/test/bench_node.js 300 1920 1080 4) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_bench.jsonl
-(for v in "--width 1920 --height 1080" "--width 1920 --height 1080 --channels 2" "--width 1920 --height 1080 --channels 4" "--channels 2 --ring 4"; do $BENCH $v --steps 1500 --cpu-seconds 0; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_bench_variants.jsonl
+(for v in "--no-secondary" "--width 1920 --height 1080" "--width 1920 --height 1080 --channels 2" "--width 1920 --height 1080 --channels 4" "--channels 2 --ring 4"; do $BENCH $v --steps 1500 --cpu-seconds 0; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_bench_variants.jsonl
 rm -rf $OUT/stats $OUT/pmc_bench_* $OUT/pmc_micro_*
 ls -la $OUT
