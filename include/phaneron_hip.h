@@ -212,6 +212,11 @@ int ph_v210_write(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t wi
 /* yadifCl.ts:105-167 */
 int ph_yadif(ph_ctx *ctx, int queue, const void *prev, const void *cur, const void *next, int width,
              int height, int parity, int tff, int skip_spatial, void *out);
+/* Both output fields of one frame in one pass: out_parity0 / out_parity1 receive exactly what ph_yadif writes with
+ * parity 0 / parity 1 (the Yadif wrapper's send_field mode runs the filter twice per frame over the same window,
+ * parity 1 ^ tff then parity tff: yadif.ts:100-145).  Each source row is read once instead of up to twice. */
+int ph_yadif_pair(ph_ctx *ctx, int queue, const void *prev, const void *cur, const void *next, int width,
+                  int height, int tff, int skip_spatial, void *out_parity0, void *out_parity1);
 /* transform.ts:36-59 (matrix9: device pointer to the 3x3 row-major matrix) */
 int ph_transform(ph_ctx *ctx, int queue, const void *in, int in_w, int in_h, const void *matrix9,
                  void *out, int out_w, int out_h);

@@ -22,7 +22,7 @@ EXPORTS = [
     "ph_wait_finish", "ph_buf_create", "ph_buf_wrap", "ph_buf_addref", "ph_buf_release", "ph_buf_refcount",
     "ph_buf_bytes", "ph_buf_device_ptr", "ph_buf_dims", "ph_buf_host_access", "ph_buf_host_ptr",
     "ph_ctx_buffer_stats", "ph_program_create", "ph_program_destroy", "ph_program_kernel", "ph_run_program",
-    "ph_v210_pitch_bytes", "ph_v210_read", "ph_v210_write", "ph_yadif", "ph_transform", "ph_resize", "ph_combine",
+    "ph_v210_pitch_bytes", "ph_v210_read", "ph_v210_write", "ph_yadif", "ph_yadif_pair", "ph_transform", "ph_resize", "ph_combine",
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
@@ -115,6 +115,7 @@ def lib():
         "ph_v210_read": (ci, [vp, ci, vp, vp, cu, cu, vp, vp, vp]),
         "ph_v210_write": (ci, [vp, ci, vp, vp, cu, cu, cu, vp, vp]),
         "ph_yadif": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+        "ph_yadif_pair": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
         "ph_transform": (ci, [vp, ci, vp, ci, ci, vp, vp, ci, ci]),
         "ph_resize": (ci, [vp, ci, vp, ci, ci, cf, cf, cf, vp, vp, ci, ci]),
         "ph_combine": (ci, [vp, ci, ci, C.POINTER(vp), ci, ci, vp]),
@@ -308,6 +309,11 @@ class Context:
     def yadif(self, prev, cur, nxt, dst, width, height, parity, tff, skip_spatial=False, queue=QUEUE_PROCESS):
         check(lib().ph_yadif(self.h, queue, _ptr(prev), _ptr(cur), _ptr(nxt), width, height, int(parity), int(tff),
                              int(skip_spatial), _ptr(dst)), self.h)
+
+    def yadif_pair(self, prev, cur, nxt, dst_parity0, dst_parity1, width, height, tff, skip_spatial=False, queue=QUEUE_PROCESS):
+        """both fields of one frame in one pass: dst_parity0 / dst_parity1 = yadif(..., parity=0 / 1)"""
+        check(lib().ph_yadif_pair(self.h, queue, _ptr(prev), _ptr(cur), _ptr(nxt), width, height, int(tff), int(skip_spatial),
+                                  _ptr(dst_parity0), _ptr(dst_parity1)), self.h)
 
     def transform(self, src, in_w, in_h, matrix, dst, out_w, out_h, queue=QUEUE_PROCESS):
         check(lib().ph_transform(self.h, queue, _ptr(src), in_w, in_h, _ptr(matrix), _ptr(dst), out_w, out_h), self.h)

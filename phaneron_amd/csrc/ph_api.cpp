@@ -1211,6 +1211,13 @@ int ph_yadif(ph_ctx *ctx, int queue, const void *prev, const void *cur, const vo
   PH_LAUNCH(ph::launch_yadif(stream_of(ctx, queue), prev, cur, next, w, h, parity, tff ? 1 : 0, skip ? 1 : 0, out));
 }
 
+int ph_yadif_pair(ph_ctx *ctx, int queue, const void *prev, const void *cur, const void *next, int w, int h, int tff,
+                  int skip, void *out_parity0, void *out_parity1) {
+  if (!prev || !cur || !next || !out_parity0 || !out_parity1 || w <= 0 || h <= 0) return fail(PH_E_INVALID, "ph_yadif_pair: NULL/zero argument");
+  if (out_parity0 == out_parity1) return fail(PH_E_INVALID, "ph_yadif_pair: the two outputs are the same buffer");
+  PH_LAUNCH(ph::launch_yadif_pair(stream_of(ctx, queue), prev, cur, next, w, h, tff ? 1 : 0, skip ? 1 : 0, out_parity0, out_parity1));
+}
+
 int ph_transform(ph_ctx *ctx, int queue, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh) {
   if (!in || !m9 || !out || iw <= 0 || ih <= 0 || ow <= 0 || oh <= 0) return fail(PH_E_INVALID, "ph_transform: NULL/zero argument");
   PH_LAUNCH(ph::launch_transform(stream_of(ctx, queue), in, iw, ih, m9, out, ow, oh));

@@ -90,6 +90,8 @@ hipError_t launch_field_compose_v210(hipStream_t s, const FieldArgs &a, void *in
 void field_window_extent(const float m[6], int lw, int lh, uint32_t out_w, uint32_t out_h, uint32_t *cols, uint32_t *rows);
 hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int parity,
                         int tff, int skip, void *out);
+hipError_t launch_yadif_pair(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int tff,
+                             int skip, void *out0, void *out1);
 hipError_t launch_transform(hipStream_t s, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh);
 hipError_t launch_resize(hipStream_t s, const void *in, int iw, int ih, float scale, float ox, float oy,
                          const void *flip4, void *out, int ow, int oh);

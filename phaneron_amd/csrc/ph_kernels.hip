@@ -9,6 +9,7 @@
 #include "ph_device.h"
 #include "ph_kernels.h"
 #include "ph_yadif.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -284,6 +285,67 @@ __global__ __launch_bounds__(kBlock) void yadif_rows_kernel(const float4 *__rest
   }
 }
 
+// Both fields of one frame in one pass (the send_field mode of yadif.ts:88-145 runs the filter twice over the same
+// three frames, parity 1 ^ tff then parity tff).  Every row is interpolated in exactly one of the two outputs and
+// copied into the other, and between them the two runs read every row of prev, cur and next: this kernel walks a
+// strip ROW BY ROW with the five-row windows of all three frames in registers, loads each source row once (three
+// loads per row) and stores the row twice - 5 frames of traffic per pair of fields instead of 7.  out0 / out1 are
+// exactly what yadif_rows_kernel writes for parity 0 / parity 1.  The `cur` rows are staged once each in a ring of
+// four LDS rows (row y + 1 at step y; it is row y' - 1 two steps later), one barrier per row.
+template <int TFF>
+__global__ __launch_bounds__(kBlock) void yadif_pair_kernel(const float4 *__restrict__ prev, const float4 *__restrict__ cur,
+                                                            const float4 *__restrict__ next, int w, int h, int skip,
+                                                            float4 *__restrict__ out0, float4 *__restrict__ out1) {
+  __shared__ float4 rows[4][kBlock];
+  const int lane = threadIdx.x;
+  const int xr = blockIdx.x * kYadifCols - 3 + lane, x = clampi(xr, 0, w - 1);  // CLAMP_TO_EDGE
+  const bool emit = lane >= 3 && lane < kBlock - 3 && xr < w;
+  const int y0 = blockIdx.y * kYadifRows, y_end = (y0 + kYadifRows < h) ? y0 + kYadifRows : h;  // y0 is even
+  auto row = [&](const float4 *img, int y) { return img[(size_t)clampi(y, 0, h - 1) * w + x]; };
+  float4 C[5], P[5], N[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) C[k] = row(cur, y0 - 2 + k), P[k] = row(prev, y0 - 2 + k), N[k] = row(next, y0 - 2 + k);
+  rows[(y0 + 3) & 3][lane] = C[1], rows[y0 & 3][lane] = C[2];  // rows y0 - 1 and y0; every later row is staged as "y + 1"
+  // one row: interpolated into the output whose parity is (y & 1) ^ 1, copied into the other.  SECOND
+  // (yadifCl.ts:143, !(parity ^ tff)) is a compile-time constant of the row's evenness.
+  auto step = [&](int y, auto second_tag, float4 *__restrict__ out_interp, float4 *__restrict__ out_copy) {
+    constexpr bool second = decltype(second_tag)::value;
+    rows[(y + 1) & 3][lane] = C[3];
+    __syncthreads();
+    if (emit) {
+      store_stream(out_copy + (size_t)y * w + xr, C[2]);  // yadifCl.ts:117-121
+      float4 ra[7], rb[7];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) ra[t] = rows[(y + 3) & 3][lane - 3 + t], rb[t] = rows[(y + 1) & 3][lane - 3 + t];
+      float res[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float sp = yadif_spatial(PH_C4(ra[0], c), PH_C4(ra[1], c), PH_C4(ra[2], c), PH_C4(ra[3], c),
+                                       PH_C4(ra[4], c), PH_C4(ra[5], c), PH_C4(ra[6], c), PH_C4(rb[0], c),
+                                       PH_C4(rb[1], c), PH_C4(rb[2], c), PH_C4(rb[3], c), PH_C4(rb[4], c),
+                                       PH_C4(rb[5], c), PH_C4(rb[6], c));
+        // second field: s0 = cur, s1 = next; first field: s0 = prev, s1 = cur (yadifCl.ts:146-151)
+        const float c0 = PH_C4(C[0], c), c2 = PH_C4(C[2], c), c4 = PH_C4(C[4], c);
+        const float e0 = second ? PH_C4(N[0], c) : PH_C4(P[0], c), e1 = second ? PH_C4(N[2], c) : PH_C4(P[2], c),
+                    e2 = second ? PH_C4(N[4], c) : PH_C4(P[4], c);
+        res[c] = yadif_temporal(PH_C4(P[1], c), PH_C4(P[3], c), second ? c0 : e0, second ? c2 : e1, second ? c4 : e2,
+                                PH_C4(C[1], c), PH_C4(C[3], c), second ? e0 : c0, second ? e1 : c2, second ? e2 : c4,
+                                PH_C4(N[1], c), PH_C4(N[3], c), sp, skip);
+      }
+      store_stream(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], C[2].w));  // :164 alpha from cur
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) C[k] = C[k + 1], P[k] = P[k + 1], N[k] = N[k + 1];
+    C[4] = row(cur, y + 3), P[4] = row(prev, y + 3), N[4] = row(next, y + 3);
+  };
+  for (int y = y0; y < y_end; y += 2) {
+    // even row: interpolated in the parity-1 output, second = !(1 ^ tff) = tff
+    step(y, std::integral_constant<bool, TFF != 0>{}, out1, out0);
+    // odd row: interpolated in the parity-0 output, second = !(0 ^ tff) = !tff
+    if (y + 1 < y_end) step(y + 1, std::integral_constant<bool, TFF == 0>{}, out0, out1);
+  }
+}
+
 // transform.ts:36-59.  2-D grid; 64x4 blocks keep a wave on one output row.
 __global__ __launch_bounds__(kBlock) void transform_kernel(const float4 *__restrict__ in, int iw, int ih,
                                                            const float *__restrict__ m, float4 *__restrict__ out,
@@ -426,6 +488,18 @@ hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const 
   dim3 grid(div_up(w, kYadifCols), div_up(h, kYadifRows));
   yadif_rows_kernel<<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, parity,
                                             tff, skip, (float4 *)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_yadif_pair(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int tff,
+                             int skip, void *out0, void *out1) {
+  dim3 grid(div_up(w, kYadifCols), div_up(h, kYadifRows));
+  if (tff)
+    yadif_pair_kernel<1><<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, skip,
+                                                 (float4 *)out0, (float4 *)out1);
+  else
+    yadif_pair_kernel<0><<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, skip,
+                                                 (float4 *)out0, (float4 *)out1);
   return hipGetLastError();
 }
 

@@ -591,6 +591,196 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_px_kernel(Compos
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The pixel-per-lane compositor again, with the sampler's address and border work handed to the
+// buffer addressing hardware.  Same arithmetic, same results; per sampled layer-pixel ~60 VALU
+// instructions instead of ~100:
+//   * taps are RAW BUFFER loads (one 128-bit resource per layer, num_records = the image's bytes).
+//     A tap outside the image must read as 0 (transform.ts: CLK_ADDRESS_CLAMP, border 0): its byte
+//     offset is made >= num_records and the hardware returns 0 without touching memory - no
+//     per-texel selects (16 v_cndmask), no clamped addresses, no 64-bit pointer arithmetic.
+//     Rows: j0 is clamped to [-2, h] and multiplied by the pitch, so rows -2, -1, h, h+1 land outside
+//     [0, num_records) by themselves (offsets wrap to just below 2^32 or reach num_records).
+//     Columns: an outside column contributes 2^31 instead of 16 x.  Needs num_records + 2 pitches
+//     <= 2^31 (host-checked: images below 2 GiB);
+//   * a chunk (192 pixels) lies in one output row (out_w % 192 == 0, host-checked), so the row is
+//     wave-uniform: for a layer whose matrix has m1 == m3 == 0 (every placement without rotation)
+//     t', the two row offsets and the vertical weight are computed once per chunk, not per pixel;
+//   * a layer none of whose taps is inside for a whole wave (the outside of a picture-in-picture
+//     inset) skips its loads and its blend: its sample is the border value 0;
+//   * 1:1 layers and sampled layers take uniform branches instead of selects.
+// ------------------------------------------------------------------------------------------
+typedef uint32_t ph_u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kTapOutside = 0x80000000u;
+
+struct RowTaps {  // one sampled layer, one source row pair
+  uint32_t r0, r1;  // byte offsets of rows j0 and j0 + 1 (outside rows: outside [0, num_records))
+  float b, omb;
+  bool any;         // at least one of the two rows is inside
+};
+
+__device__ __forceinline__ RowTaps row_taps(float tt, int lw, int lh) {  // the `v` half of sample_linear
+  const float v = tt * (float)lh;
+  const float fv = v - 0.5f;
+  const float flv = __builtin_floorf(fv);
+  int j0 = (int)flv;
+  j0 = j0 < -2 ? -2 : j0;
+  j0 = j0 > lh ? lh : j0;
+  RowTaps t;
+  t.b = fv - flv, t.omb = 1.0f - t.b;
+  t.r0 = (uint32_t)__mul24(j0, lw * 16);
+  t.r1 = t.r0 + (uint32_t)(lw * 16);
+  t.any = (uint32_t)(j0 + 1) <= (uint32_t)lh;  // j0 in [-1, h - 1]
+  return t;
+}
+
+__device__ __forceinline__ float4 as_float4(const ph_u32x4 v) {
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// One chunk row of the compositor.  ALIGNED: every sampled layer has m1 == m3 == 0 (row taps once per chunk);
+// MIXED: some layers are taken 1:1 (selects, no branches: the loads of all layers stay in flight together).
+template <int N, bool MIXED, bool ALIGNED>
+__device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const float (&mm)[N][6], const bool (&direct)[N],
+                                                  const __amdgpu_buffer_rsrc_t (&img)[N], const WriteK &wk, const LutK &lk,
+                                                  uint16_t *ys, uint16_t *us, uint16_t *vs, uint32_t wave, uint32_t lane) {
+  const uint32_t qpl = a.out_w / 6;
+  const uint32_t total_px = a.out_w * a.lines;            // out_w % 192 == 0: a chunk never leaves its row
+  const uint32_t waves_total = gridDim.x * (kLdsBlock / 64);
+  const float fow = (float)(int)a.out_w, foh = (float)(int)a.out_h;
+  for (uint32_t base = (blockIdx.x * (kLdsBlock / 64) + wave) * kComposeChunk; base < total_px;
+       base += waves_total * kComposeChunk) {
+    const uint32_t li = base / a.out_w, x_first = base - li * a.out_w;
+    const uint32_t line = a.first_line + li * a.line_step;
+    const float py = (float)(int)line / foh - 0.5f;
+    RowTaps row[N];
+    if (ALIGNED) {
+#pragma unroll
+      for (int l = 0; l < N; ++l)  // transform.ts:53-57 with m3 == 0: t' does not depend on x
+        row[l] = row_taps(dot3(mm[l][3], mm[l][4], mm[l][5], 0.0f, py, 1.0f) + 0.5f, a.lw[l], a.lh[l]);
+    }
+#pragma unroll 1
+    for (uint32_t k = 0; k < kComposeChunk / 64; ++k) {
+      const uint32_t local = k * 64 + lane;
+      const uint32_t x = x_first + local;
+      const float px = (float)(int)x / fow - 0.5f;
+      const uint32_t own = (line * a.out_w + x) * 16u;  // a 1:1 layer's texel
+      ph_u32x4 tap[N][4];
+      float wa[N], wb[N];
+      // every layer's loads are issued before any is blended: 4 N independent loads in flight
+#pragma unroll
+      for (int l = 0; l < N; ++l) {
+        const RowTaps r = ALIGNED ? row[l] : row_taps(dot3(mm[l][3], mm[l][4], mm[l][5], px, py, 1.0f) + 0.5f, a.lw[l], a.lh[l]);
+        const float s = dot3(mm[l][0], mm[l][1], mm[l][2], px, py, 1.0f) + 0.5f;
+        const float u = s * (float)a.lw[l];
+        const float fu = u - 0.5f;
+        const float flu = __builtin_floorf(fu);
+        const uint32_t i0 = (uint32_t)(int)flu, i1 = i0 + 1u;
+        const uint32_t c0 = i0 < (uint32_t)a.lw[l] ? i0 << 4 : kTapOutside, c1 = i1 < (uint32_t)a.lw[l] ? i1 << 4 : kTapOutside;
+        wa[l] = fu - flu, wb[l] = r.b;
+        uint32_t o00 = r.r0 + c0, o10 = r.r0 + c1, o01 = r.r1 + c0, o11 = r.r1 + c1;
+        if (MIXED) o00 = direct[l] ? own : o00;
+        tap[l][0] = __builtin_amdgcn_raw_buffer_load_b128(img[l], (int)o00, 0, 0);
+#ifdef PH_TAPS_ONE_LOAD  // timing experiment (wrong results): one tap per sample instead of four
+        tap[l][1] = tap[l][0] + o10, tap[l][2] = tap[l][0] + o01, tap[l][3] = tap[l][0] + o11;
+#else
+        tap[l][1] = __builtin_amdgcn_raw_buffer_load_b128(img[l], (int)o10, 0, 0);
+        tap[l][2] = __builtin_amdgcn_raw_buffer_load_b128(img[l], (int)o01, 0, 0);
+        tap[l][3] = __builtin_amdgcn_raw_buffer_load_b128(img[l], (int)o11, 0, 0);
+#endif
+      }
+      float r = 0.0f, g = 0.0f, b = 0.0f;
+#pragma unroll
+      for (int l = 0; l < N; ++l) {  // OpenCL 1.2 8.2, evaluated as DESIGN.md 2 states it
+        const float4 t00 = as_float4(tap[l][0]), t10 = as_float4(tap[l][1]), t01 = as_float4(tap[l][2]), t11 = as_float4(tap[l][3]);
+        const float oma = 1.0f - wa[l], omb = 1.0f - wb[l];
+        const float w00 = oma * omb, w10 = wa[l] * omb, w01 = oma * wb[l], w11 = wa[l] * wb[l];
+        float4 t;
+        t.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+        t.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+        t.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+        t.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+        if (MIXED) t.x = direct[l] ? t00.x : t.x, t.y = direct[l] ? t00.y : t.y, t.z = direct[l] ? t00.z : t.z, t.w = direct[l] ? t00.w : t.w;
+        if (l == 0) {
+          r = t.x, g = t.y, b = t.z;
+        } else {  // combine.ts:45-65 (alpha of the result is never used by the writer)
+          const float kk = 1.0f - t.w;
+          r = fma_rn(r, kk, t.x), g = fma_rn(g, kk, t.y), b = fma_rn(b, kk, t.z);
+        }
+      }
+      const Yuv1 c = write_px_lds(r, g, b, wk, lk);  // v210.ts:145-156
+      ys[local] = (uint16_t)c.y;
+      if (!(x & 1)) us[local >> 1] = (uint16_t)c.u, vs[local >> 1] = (uint16_t)c.v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < kComposeChunk / 6) {
+      uint32_t y[6], u[3], v[3];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) y[j] = ys[lane * 6 + j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) u[j] = us[lane * 3 + j], v[j] = vs[lane * 3 + j];
+      store_stream(reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + (x_first + lane * 6) / 6, pack_quad(y, u, v));
+    }
+    __builtin_amdgcn_wave_barrier();  // the next step overwrites the staging area
+  }
+}
+
+template <int N, bool MIXED>
+__global__ __launch_bounds__(kLdsBlock) void compose_write_v210_taps_kernel(ComposeArgs a, uint32_t stage_off) {
+  const WriteK wk = load_write_k(a.wr_cm);
+  const LutK lk = make_lut_k(a.wr);
+  float mm[N][6];
+  bool direct[N];
+  __amdgpu_buffer_rsrc_t img[N];
+  bool all_aligned = true;
+#pragma unroll
+  for (int l = 0; l < N; ++l) {
+    direct[l] = a.matrix[l] == nullptr;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mm[l][i] = direct[l] ? 0.0f : a.matrix[l][i];
+    all_aligned = all_aligned && mm[l][1] == 0.0f && mm[l][3] == 0.0f;
+    img[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.layers[l]), 0, a.lw[l] * a.lh[l] * 16, 0x00020000);
+  }
+  lds_lut_load(a.wr);
+  __syncthreads();
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  uint16_t *ys = reinterpret_cast<uint16_t *>(g_lds + stage_off + wave * kComposeChunk * 4);
+  uint16_t *us = ys + kComposeChunk, *vs = us + kComposeChunk / 2;
+  if (all_aligned)
+    compose_taps_body<N, MIXED, true>(a, mm, direct, img, wk, lk, ys, us, vs, wave, lane);
+  else
+    compose_taps_body<N, MIXED, false>(a, mm, direct, img, wk, lk, ys, us, vs, wave, lane);
+}
+
+template <int N>
+static hipError_t launch_compose_taps_n(hipStream_t s, const ComposeArgs &a, uint32_t grid, uint32_t stage_off) {
+  bool mixed = false;
+  for (int l = 0; l < N; ++l) mixed = mixed || a.matrix[l] == nullptr;
+  const void *fn = mixed ? reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, true>)
+                         : reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(stage_off + kComposeStageBytes));
+  if (e != hipSuccess) return e;
+  if (mixed)
+    compose_write_v210_taps_kernel<N, true><<<grid, kLdsBlock, stage_off + kComposeStageBytes, s>>>(a, stage_off);
+  else
+    compose_write_v210_taps_kernel<N, false><<<grid, kLdsBlock, stage_off + kComposeStageBytes, s>>>(a, stage_off);
+  return hipGetLastError();
+}
+
+// the buffer-addressed kernel serves a job when a chunk stays in its row and every offset fits the border scheme
+static bool compose_taps_eligible(const ComposeArgs &a) {
+  if (a.out_w % kComposeChunk) return false;
+  bool sampled = false;
+  for (int l = 0; l < a.n; ++l) {
+    const uint64_t bytes = (uint64_t)a.lw[l] * (uint64_t)a.lh[l] * 16u, pitch = (uint64_t)a.lw[l] * 16u;
+    if (bytes + 2 * pitch > 0x80000000ull || pitch >= (1u << 23) || a.lh[l] >= (1 << 22)) return false;
+    sampled = sampled || a.matrix[l] != nullptr;
+  }
+  return sampled;  // all layers 1:1: the streaming kernel above is HBM-bound already
+}
+
 template <int N, bool ALL_DIRECT>
 static hipError_t launch_compose_px_nd(hipStream_t s, const ComposeArgs &a, uint32_t grid, uint32_t stage_off) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(compose_write_v210_px_kernel<N, ALL_DIRECT>),
@@ -678,6 +868,23 @@ hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32
     const uint32_t chunks = (a.out_w * a.lines + kComposeChunk - 1) / kComposeChunk;
     const uint32_t want = (chunks + kLdsBlock / 64 - 1) / (kLdsBlock / 64);
     const uint32_t grid = want < num_cus ? want : num_cus;
+    static const int taps_env = [] {
+      const char *e = getenv("PH_COMPOSE_TAPS");  // 0 = the pointer-addressed sampler (A/B runs)
+      return e ? atoi(e) : 1;
+    }();
+    if (taps_env && compose_taps_eligible(a)) {
+      switch (a.n) {
+        case 1: return launch_compose_taps_n<1>(s, a, grid, stage_off);
+        case 2: return launch_compose_taps_n<2>(s, a, grid, stage_off);
+        case 3: return launch_compose_taps_n<3>(s, a, grid, stage_off);
+        case 4: return launch_compose_taps_n<4>(s, a, grid, stage_off);
+        case 5: return launch_compose_taps_n<5>(s, a, grid, stage_off);
+        case 6: return launch_compose_taps_n<6>(s, a, grid, stage_off);
+        case 7: return launch_compose_taps_n<7>(s, a, grid, stage_off);
+        case 8: return launch_compose_taps_n<8>(s, a, grid, stage_off);
+        default: return hipErrorInvalidValue;
+      }
+    }
     switch (a.n) {
       case 1: return launch_compose_px_n<1>(s, a, grid, stage_off);
       case 2: return launch_compose_px_n<2>(s, a, grid, stage_off);

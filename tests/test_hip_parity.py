@@ -120,6 +120,23 @@ def test_yadif_vs_oracle(w, h):
             assert_bits(hh.host(out), orc.yadif(p, c, n, parity, tff, False), "yadif %dx%d p%d t%d" % (w, h, parity, tff))
 
 
+@pytest.mark.parametrize("w,h", [(1920, 540), (301, 33), (3, 2), (250, 17), (64, 1)])
+def test_yadif_pair_vs_oracle(w, h):
+    """both fields of a frame in one pass == the filter run once per parity (yadif.ts:100-145, send_field)"""
+    import torch
+    import hip_harness as hh
+    p, c, n = (frames.rgba_random(w, h, 950 + i) for i in range(3))
+    for tff in (0, 1):
+        for skip in (False, True):
+            out = [torch.full((w * h * 4,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(2)]
+            hh.ctx().yadif_pair(hh.dev(p), hh.dev(c), hh.dev(n), out[0], out[1], w, h, tff, skip)
+            for parity in (0, 1):
+                assert_bits(hh.host(out[parity]), orc.yadif(p, c, n, parity, tff, skip),
+                            "yadif_pair %dx%d p%d t%d s%d" % (w, h, parity, tff, skip))
+    with pytest.raises(Exception, match="same buffer"):
+        hh.ctx().yadif_pair(hh.dev(p), hh.dev(c), hh.dev(n), out[0], out[0], w, h, 1, False)
+
+
 @pytest.mark.parametrize("iw,ih,ow,oh,kw", [
     (1920, 1080, 3840, 2160, {}),
     (960, 540, 960, 540, dict(scale_x=0.5, scale_y=0.5, offset_x=0.25, offset_y=-0.25)),

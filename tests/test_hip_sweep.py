@@ -41,6 +41,21 @@ def test_yadif_random_sizes():
             bits_eq(hh.host(out), orc.yadif(p, c, n, parity, tff, skip), "yadif %dx%d p%d t%d s%d" % (w, h, parity, tff, skip))
 
 
+def test_yadif_pair_random_sizes():
+    import torch
+    import hip_harness as hh
+    r = rng_for("yadif pair")
+    sizes = [(250, 16), (251, 17), (249, 15), (500, 33), (501, 1), (1, 40), (7, 2), (256, 31), (750, 18), (33, 3)]
+    sizes += [(int(r.integers(1, 700)), int(r.integers(1, 70))) for _ in range(8)]
+    for (w, h) in sizes:
+        p, c, n = (frames.rgba_random(w, h, 3100 + 7 * w + h + i) for i in range(3))
+        tff, skip = int(r.integers(0, 2)), bool(r.integers(0, 2))
+        out = [torch.zeros(w * h * 4, dtype=torch.float32, device="cuda") for _ in range(2)]
+        hh.ctx().yadif_pair(hh.dev(p), hh.dev(c), hh.dev(n), out[0], out[1], w, h, tff, skip)
+        for parity in (0, 1):
+            bits_eq(hh.host(out[parity]), orc.yadif(p, c, n, parity, tff, skip), "yadif_pair %dx%d p%d t%d s%d" % (w, h, parity, tff, skip))
+
+
 def test_v210_read_write_random_sizes():
     import torch
     import hip_harness as hh

@@ -134,10 +134,23 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
             ctx.yadif(win[l][0], win[l][1], win[l][2], deint[l], sw, sh, parity, 1, False)
         ctx.compose_write_v210([(deint[l], sw, sh, m) for l in range(4)], out, ow, oh, 0, *wr)
 
+    deint2 = [img(sw, sh, 2) for _ in range(4)]       # both fields of the current frame, per layer
+
+    def config3_pair(i):  # both fields of a frame de-interlaced in one pass per layer; one compositor launch per field
+        if not (i & 1):
+            new_frames(i)
+            for l in range(4):
+                ctx.yadif_pair(win[l][0], win[l][1], win[l][2], deint2[l][0], deint2[l][1], sw, sh, 1, False)
+        parity = 1 ^ (0 if (i & 1) else 1)
+        ctx.compose_write_v210([(deint2[l][parity], sw, sh, m) for l in range(4)], out, ow, oh, 0, *wr)
+
     algo3 = 4 * 3 * capi.v210_pitch_bytes(sw) * sh + capi.v210_pitch_bytes(ow) * oh  # 88 473 600
     name3 = "3: 1 channel, 4 x 1080i50 -> yadif -> 2x up-scale -> 709->2020 -> combine_4 -> 2160p50 (per output field)"
-    record(name3, "fused compositor: read x4 every other field, yadif x4, [transform x4 + combine_4 + write]", "field",
-           timeit(config3_fused, reps), algo3, 7)
+    record(name3, "fused compositor, field pairs: per frame read x4 + yadif_pair x4 (both fields in one pass), per field "
+           "[transform x4 + combine_4 + write]", "field", timeit(config3_pair, reps), algo3, 5)
+    if routes == "all":
+        record(name3, "fused compositor: read x4 every other field, yadif x4, [transform x4 + combine_4 + write]", "field",
+               timeit(config3_fused, reps), algo3, 7)
     if routes == "all":
         up = img(ow, oh, 4)
         comb3 = img(ow, oh)[0]
