@@ -205,6 +205,10 @@ uint32_t ph_v210_pitch_bytes(uint32_t width); /* v210.ts:198-204 */
 /* v210.ts:25-111 */
 int ph_v210_read(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t width, uint32_t height,
                  const void *col_matrix12, const void *gamma_lut, const void *gamut_matrix9);
+/* n frames of one size and one colour recipe (the layers of a channel) unpacked in one launch; outs[i] receives exactly
+ * what ph_v210_read(ins[i]) writes.  The launch and the per-CU table load are paid once per batch. */
+int ph_v210_read_batch(ph_ctx *ctx, int queue, int n, const void *const *ins, void *const *outs, uint32_t width,
+                       uint32_t height, const void *col_matrix12, const void *gamma_lut, const void *gamut_matrix9);
 /* v210.ts:113-195; interlace 0 / 1 (top, even lines) / 3 (bottom, odd lines) (packer.ts:24-28) */
 int ph_v210_write(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t width,
                   uint32_t height, uint32_t interlace, const void *col_matrix12,
@@ -217,6 +221,20 @@ int ph_yadif(ph_ctx *ctx, int queue, const void *prev, const void *cur, const vo
  * parity 1 ^ tff then parity tff: yadif.ts:100-145).  Each source row is read once instead of up to twice. */
 int ph_yadif_pair(ph_ctx *ctx, int queue, const void *prev, const void *cur, const void *next, int width,
                   int height, int tff, int skip_spatial, void *out_parity0, void *out_parity1);
+/* ---- fused de-interlacing reader (no single reference equivalent): per layer, ToRGBA on the frames of the Yadif
+ *      window (v210.ts:25-111) and both send_field outputs of Yadif (yadif.ts:100-145) as ONE kernel.  The window
+ *      stays in v210; its rows are unpacked, matrixed and gamma-corrected on the fly, and only the two de-interlaced
+ *      RGBA frames are written.  out_parity0 / out_parity1 are bit-identical to ph_v210_read on prev, cur and next
+ *      followed by ph_yadif with parity 0 / 1.  n sources of one size and one colour recipe per call (the layers of a
+ *      channel).  Needs width % 6 == 0 and the reader LUT registered (PH_E_INVALID otherwise - run the separate kernels). */
+typedef struct ph_deint_source {
+  const void *prev, *cur, *next;      /* device, v210, width x height */
+  void *out_parity0, *out_parity1;    /* device, float RGBA, width x height */
+} ph_deint_source;
+int ph_v210_yadif_pair(ph_ctx *ctx, int queue, int n, const ph_deint_source *sources, uint32_t width, uint32_t height,
+                       int tff, int skip_spatial, const void *rd_col_matrix12, const void *rd_gamma_lut,
+                       const void *rd_gamut_matrix9);
+
 /* transform.ts:36-59 (matrix9: device pointer to the 3x3 row-major matrix) */
 int ph_transform(ph_ctx *ctx, int queue, const void *in, int in_w, int in_h, const void *matrix9,
                  void *out, int out_w, int out_h);

@@ -22,7 +22,7 @@ EXPORTS = [
     "ph_wait_finish", "ph_buf_create", "ph_buf_wrap", "ph_buf_addref", "ph_buf_release", "ph_buf_refcount",
     "ph_buf_bytes", "ph_buf_device_ptr", "ph_buf_dims", "ph_buf_host_access", "ph_buf_host_ptr",
     "ph_ctx_buffer_stats", "ph_program_create", "ph_program_destroy", "ph_program_kernel", "ph_run_program",
-    "ph_v210_pitch_bytes", "ph_v210_read", "ph_v210_write", "ph_yadif", "ph_yadif_pair", "ph_transform", "ph_resize", "ph_combine",
+    "ph_v210_pitch_bytes", "ph_v210_read", "ph_v210_read_batch", "ph_v210_write", "ph_yadif", "ph_yadif_pair", "ph_v210_yadif_pair", "ph_transform", "ph_resize", "ph_combine",
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
@@ -50,6 +50,10 @@ class PhArg(C.Structure):
 
 class PhLayer(C.Structure):
     _fields_ = [("rgba", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("matrix9", C.c_void_p)]
+
+
+class PhDeintSource(C.Structure):
+    _fields_ = [("prev", C.c_void_p), ("cur", C.c_void_p), ("next", C.c_void_p), ("out_parity0", C.c_void_p), ("out_parity1", C.c_void_p)]
 
 
 class PhFieldLayer(C.Structure):
@@ -113,9 +117,11 @@ def lib():
         "ph_run_program": (ci, [vp, vp, C.POINTER(PhArg), ci, ci, C.POINTER(RunTimings)]),
         "ph_v210_pitch_bytes": (cu, [cu]),
         "ph_v210_read": (ci, [vp, ci, vp, vp, cu, cu, vp, vp, vp]),
+        "ph_v210_read_batch": (ci, [vp, ci, ci, vp, vp, cu, cu, vp, vp, vp]),
         "ph_v210_write": (ci, [vp, ci, vp, vp, cu, cu, cu, vp, vp]),
         "ph_yadif": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
         "ph_yadif_pair": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+        "ph_v210_yadif_pair": (ci, [vp, ci, ci, vp, cu, cu, ci, ci, vp, vp, vp]),
         "ph_transform": (ci, [vp, ci, vp, ci, ci, vp, vp, ci, ci]),
         "ph_resize": (ci, [vp, ci, vp, ci, ci, cf, cf, cf, vp, vp, ci, ci]),
         "ph_combine": (ci, [vp, ci, ci, C.POINTER(vp), ci, ci, vp]),
@@ -302,6 +308,13 @@ class Context:
         check(lib().ph_v210_read(self.h, queue, _ptr(src), _ptr(dst), width, height, _ptr(col_matrix), _ptr(lut),
                                  _ptr(gamut)), self.h)
 
+    def v210_read_batch(self, srcs, dsts, width, height, col_matrix, lut, gamut, queue=QUEUE_PROCESS):
+        """several frames of one size and colour recipe in one launch; dsts[i] = v210_read(srcs[i])"""
+        n = len(srcs)
+        ins = (C.c_void_p * n)(*[_ptr(b).value for b in srcs])
+        outs = (C.c_void_p * n)(*[_ptr(b).value for b in dsts])
+        check(lib().ph_v210_read_batch(self.h, queue, n, ins, outs, width, height, _ptr(col_matrix), _ptr(lut), _ptr(gamut)), self.h)
+
     def v210_write(self, src, dst, width, height, interlace, col_matrix, lut, queue=QUEUE_PROCESS):
         check(lib().ph_v210_write(self.h, queue, _ptr(src), _ptr(dst), width, height, interlace, _ptr(col_matrix),
                                   _ptr(lut)), self.h)
@@ -314,6 +327,16 @@ class Context:
         """both fields of one frame in one pass: dst_parity0 / dst_parity1 = yadif(..., parity=0 / 1)"""
         check(lib().ph_yadif_pair(self.h, queue, _ptr(prev), _ptr(cur), _ptr(nxt), width, height, int(tff), int(skip_spatial),
                                   _ptr(dst_parity0), _ptr(dst_parity1)), self.h)
+
+    def v210_yadif_pair(self, sources, width, height, tff, skip_spatial, col_matrix, lut, gamut, queue=QUEUE_PROCESS):
+        """sources: [(prev, cur, next, dst_parity0, dst_parity1)] - v210 windows in, both de-interlaced RGBA fields out;
+        == v210_read x 3 -> yadif x 2 per source, as one kernel"""
+        arr = (PhDeintSource * len(sources))()
+        for i, s in enumerate(sources):
+            arr[i].prev, arr[i].cur, arr[i].next = (_ptr(b).value for b in s[:3])
+            arr[i].out_parity0, arr[i].out_parity1 = _ptr(s[3]).value, _ptr(s[4]).value
+        check(lib().ph_v210_yadif_pair(self.h, queue, len(sources), arr, width, height, int(tff), int(skip_spatial),
+                                       _ptr(col_matrix), _ptr(lut), _ptr(gamut)), self.h)
 
     def transform(self, src, in_w, in_h, matrix, dst, out_w, out_h, queue=QUEUE_PROCESS):
         check(lib().ph_transform(self.h, queue, _ptr(src), in_w, in_h, _ptr(matrix), _ptr(dst), out_w, out_h), self.h)

@@ -1009,6 +1009,24 @@ int ph_v210_read(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t wid
   PH_LAUNCH(ph::launch_v210_read(stream_of(ctx, queue), in, out, width, height, cm, lut, gm));
 }
 
+int ph_v210_read_batch(ph_ctx *ctx, int queue, int n, const void *const *ins, void *const *outs, uint32_t width,
+                       uint32_t height, const void *cm, const void *lut, const void *gm) {
+  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_v210_read_batch: 1..%d frames", ph::kMaxLayers);
+  if (!ins || !outs || !cm || !lut || !gm || !width) return fail(PH_E_INVALID, "ph_v210_read_batch: NULL/zero argument");
+  for (int i = 0; i < n; ++i)
+    if (!ins[i] || !outs[i]) return fail(PH_E_INVALID, "ph_v210_read_batch: frame %d is NULL", i);
+  if (!height) return PH_OK;
+  if (ctx && width % 6 == 0)
+    if (const ph::LutView *v = lds_view(ctx, lut))
+      PH_LAUNCH(ph::launch_v210_read_lds_batch(stream_of(ctx, queue), n, ins, outs, width, height, cm, gm, *v,
+                                               (uint32_t)ctx->props.multiProcessorCount));
+  for (int i = 0; i < n; ++i) {  // table not LDS-resident / ragged width: one gather-kernel launch per frame
+    const int rc = ph_v210_read(ctx, queue, ins[i], outs[i], width, height, cm, lut, gm);
+    if (rc) return rc;
+  }
+  return PH_OK;
+}
+
 int ph_v210_write(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t width, uint32_t height,
                   uint32_t interlace, const void *cm, const void *lut) {
   if (!in || !out || !cm || !lut || !width) return fail(PH_E_INVALID, "ph_v210_write: NULL/zero argument");
@@ -1216,6 +1234,28 @@ int ph_yadif_pair(ph_ctx *ctx, int queue, const void *prev, const void *cur, con
   if (!prev || !cur || !next || !out_parity0 || !out_parity1 || w <= 0 || h <= 0) return fail(PH_E_INVALID, "ph_yadif_pair: NULL/zero argument");
   if (out_parity0 == out_parity1) return fail(PH_E_INVALID, "ph_yadif_pair: the two outputs are the same buffer");
   PH_LAUNCH(ph::launch_yadif_pair(stream_of(ctx, queue), prev, cur, next, w, h, tff ? 1 : 0, skip ? 1 : 0, out_parity0, out_parity1));
+}
+
+int ph_v210_yadif_pair(ph_ctx *ctx, int queue, int n, const ph_deint_source *src, uint32_t width, uint32_t height, int tff,
+                       int skip, const void *cm, const void *lut, const void *gm) {
+  if (!ctx || !src || !cm || !lut || !gm) return fail(PH_E_INVALID, "ph_v210_yadif_pair: NULL argument");
+  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_v210_yadif_pair: 1..%d sources", ph::kMaxLayers);
+  if (!width || width % 6) return fail(PH_E_INVALID, "ph_v210_yadif_pair: width %u is not a multiple of 6; run the separate kernels", width);
+  const ph::LutView *v = lds_view(ctx, lut);
+  if (!v) return fail(PH_E_INVALID, "ph_v210_yadif_pair: the reader gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)");
+  ph::DeintArgs a{};
+  for (int i = 0; i < n; ++i) {
+    const ph_deint_source &s = src[i];
+    if (!s.prev || !s.cur || !s.next || !s.out_parity0 || !s.out_parity1)
+      return fail(PH_E_INVALID, "ph_v210_yadif_pair: source %d is incomplete", i);
+    if (s.out_parity0 == s.out_parity1) return fail(PH_E_INVALID, "ph_v210_yadif_pair: source %d: the two outputs are the same buffer", i);
+    a.prev[i] = (const uint4 *)s.prev, a.cur[i] = (const uint4 *)s.cur, a.next[i] = (const uint4 *)s.next;
+    a.out0[i] = (float4 *)s.out_parity0, a.out1[i] = (float4 *)s.out_parity1;
+  }
+  if (!height) return PH_OK;
+  a.n = n, a.skip = skip ? 1 : 0, a.width = width, a.height = height, a.quads_pitch = ph_v210_pitch_bytes(width) / 16;
+  a.cm = (const float *)cm, a.gm = (const float *)gm, a.lut = *v;
+  PH_LAUNCH(ph::launch_v210_yadif_pair(stream_of(ctx, queue), a, tff ? 1 : 0, (uint32_t)ctx->props.multiProcessorCount));
 }
 
 int ph_transform(ph_ctx *ctx, int queue, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh) {

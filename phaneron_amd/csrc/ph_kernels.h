@@ -41,6 +41,16 @@ struct ComposeArgs {
   LutView wr;
 };
 
+struct DeintArgs {  // ph_kernels_deint.hip
+  const uint4 *prev[kMaxLayers], *cur[kMaxLayers], *next[kMaxLayers];  // v210 frames, width x height
+  float4 *out0[kMaxLayers], *out1[kMaxLayers];                         // RGBA f32: yadif parity 0 / parity 1
+  int n, skip;
+  uint32_t width, height, quads_pitch;
+  uint32_t rows_per_strip, strips, col_blocks;  // filled in by the launcher
+  const float *cm, *gm;
+  LutView lut;
+};
+
 struct FieldArgs {  // ph_kernels_field.hip
   const void *prev[kMaxLayers], *cur[kMaxLayers], *next[kMaxLayers];  // RGBA f32, lw x lh
   const float *matrix[kMaxLayers];                                    // device 3x3 transform matrix
@@ -73,6 +83,8 @@ hipError_t launch_fused_v210_combine(hipStream_t s, int n, const FusedArgs &a);
 hipError_t launch_fused_v210_combine_lds(hipStream_t s, int n, const FusedLdsArgs &a, uint32_t num_cus);
 hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
                                 const void *cm, const void *gm, const LutView &lut, uint32_t num_cus);
+hipError_t launch_v210_read_lds_batch(hipStream_t s, int n, const void *const *ins, void *const *outs, uint32_t width,
+                                      uint32_t height, const void *cm, const void *gm, const LutView &lut, uint32_t num_cus);
 hipError_t launch_v210_write_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
                                  uint32_t interlace, const void *cm, const LutView &lut, uint32_t num_cus);
 // the other pack formats (ph_kernels_fmt.hip); lv == NULL selects the global-gather form
@@ -86,6 +98,7 @@ hipError_t launch_pack_write(hipStream_t s, int fmt, const void *in, void *const
                              uint32_t num_cus);
 hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32_t num_cus);
 uint32_t field_index_bytes(uint32_t out_w, uint32_t out_h);  // scratch the two-stage field pipeline needs (6 bytes per pixel)
+hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t num_cus);
 hipError_t launch_field_compose_v210(hipStream_t s, const FieldArgs &a, void *index_scratch, uint32_t num_cus);
 void field_window_extent(const float m[6], int lw, int lh, uint32_t out_w, uint32_t out_h, uint32_t *cols, uint32_t *rows);
 hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int parity,

@@ -1,0 +1,147 @@
+// ph_kernels_deint.hip - v210 unpack + yadif for both fields of a frame, as one kernel.
+//
+// The per-frame job batch of a de-interlacing channel is, per layer, ToRGBA (v210.ts:25-111) on the newest frame
+// and then Yadif twice over the window of three RGBA frames (yadif.ts:100-145, send_field: parity 1 ^ tff, then
+// parity tff).  Run as separate kernels that is 33 MB of f32 RGBA written per frame and 3 x 33 MB read back per
+// field at 1080i.  Here the window stays in v210 (5.5 MB per frame): every row the filter needs is unpacked,
+// matrixed and passed through the reader's gamma table ON THE FLY - three times over a frame's life, as next, cur
+// and prev - and only the two de-interlaced frames are written.  HBM traffic per layer and frame: 3 x 5.5 MB in,
+// 2 x 33 MB out, instead of 5.5 + 33 + 3 x 33 + 2 x 33.  The arithmetic per value is the reader's and the
+// filter's own, so out_parity0 / out_parity1 are bit-identical to ph_v210_read x 3 -> ph_yadif x 2.
+//
+// Shape: the reader's table fills the LDS, so one 1024-lane workgroup per CU, persistent; the unit of work is one
+// WAVE walking one strip (58 columns x R rows) of one layer with the five-row windows of the three frames in
+// registers (RGB only: the reader's alpha is the constant 1).  Nothing is shared between waves - the spatial
+// predictor's x +- 3 taps come from the neighbouring lanes through ds_bpermute (the wave carries a 3-column halo
+// on each side) - so there is no barrier after the table load.
+#include "ph_device.h"
+#include "ph_kernels.h"
+#include "ph_ldslut.h"
+#include "ph_yadif.h"
+
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+namespace ph {
+
+constexpr int kDeintCols = 64 - 6;  // columns a wave produces
+
+struct Rgb {
+  float r, g, b;
+};
+
+// the lane's pixel of one v210 line: word / shift selectors depend on x only (v210.ts:58-63)
+struct LanePick {
+  uint32_t g, j, pr, sy, scr;
+};
+__device__ __forceinline__ LanePick lane_pick(uint32_t x) {
+  LanePick p;
+  p.g = x / 6, p.j = x - 6 * p.g, p.pr = p.j >> 1;
+  p.sy = (p.j == 0 || p.j == 3) ? 10u : (p.j == 1 || p.j == 4) ? 0u : 20u;
+  p.scr = p.pr == 0 ? 20u : p.pr == 1 ? 0u : 10u;
+  return p;
+}
+__device__ __forceinline__ Rgb unpack_row_px(const uint4 *__restrict__ frame, uint32_t quads_pitch, int line, const LanePick &p,
+                                             const ReadK &k, const LutK &lk) {
+  const uint4 w = frame[(size_t)line * quads_pitch + p.g];
+  const uint32_t wy = (p.j == 0) ? w.x : (p.j < 3) ? w.y : (p.j == 3) ? w.z : w.w;
+  const uint32_t wcb = p.pr == 0 ? w.x : p.pr == 1 ? w.y : w.z;
+  const uint32_t wcr = p.pr == 0 ? w.x : p.pr == 1 ? w.z : w.w;
+  const float yf = (float)((wy >> p.sy) & 0x3ff);
+  const float cbf = (float)((wcb >> (10u * p.pr)) & 0x3ff);
+  const float crf = (float)((wcr >> p.scr) & 0x3ff);
+  const float4 v = read_px_lds(yf, cbf, crf, k, lk);
+  return Rgb{v.x, v.y, v.z};
+}
+
+__device__ __forceinline__ float lane_tap(float v, uint32_t lane, int d) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane + (uint32_t)d) << 2), __float_as_int(v)));
+}
+
+#define PH_RGB(v, c) ((c) == 0 ? (v).r : (c) == 1 ? (v).g : (v).b)
+
+template <int TFF>
+__global__ __launch_bounds__(kLdsBlock) void v210_yadif_pair_kernel(DeintArgs a) {
+  const ReadK k = load_read_k(a.cm, a.gm);
+  const LutK lk = make_lut_k(a.lut);
+  lds_lut_load(a.lut);
+  __syncthreads();
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int w = (int)a.width, h = (int)a.height;
+  const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;
+  for (uint32_t t = blockIdx.x * (kLdsBlock / 64) + wave; t < tasks; t += gridDim.x * (kLdsBlock / 64)) {
+    const uint32_t cb = t % a.col_blocks, rest = t / a.col_blocks, strip = rest % a.strips, l = rest / a.strips;
+    const uint4 *__restrict__ prev = a.prev[l], *__restrict__ cur = a.cur[l], *__restrict__ next = a.next[l];
+    float4 *__restrict__ out0 = a.out0[l], *__restrict__ out1 = a.out1[l];
+    const int xr = (int)(cb * kDeintCols) - 3 + (int)lane, x = clampi(xr, 0, w - 1);  // CLAMP_TO_EDGE
+    const bool emit = lane >= 3 && lane < 64 - 3 && xr < w;
+    const LanePick pick = lane_pick((uint32_t)x);
+    const int y0 = (int)(strip * a.rows_per_strip), y_end = (y0 + (int)a.rows_per_strip < h) ? y0 + (int)a.rows_per_strip : h;
+    auto row = [&](const uint4 *frame, int y) { return unpack_row_px(frame, a.quads_pitch, clampi(y, 0, h - 1), pick, k, lk); };
+    Rgb C[5], P[5], N[5];  // rows y - 2 .. y + 2
+#pragma unroll
+    for (int i = 0; i < 5; ++i) C[i] = row(cur, y0 - 2 + i), P[i] = row(prev, y0 - 2 + i), N[i] = row(next, y0 - 2 + i);
+    // one row: interpolated into the output whose parity is (y & 1) ^ 1, copied into the other; SECOND
+    // (yadifCl.ts:143, !(parity ^ tff)) is a compile-time constant of the row's evenness (as yadif_pair_kernel)
+    auto step = [&](int y, auto second_tag, float4 *__restrict__ out_interp, float4 *__restrict__ out_copy) {
+      constexpr bool second = decltype(second_tag)::value;
+      float res[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float up = PH_RGB(C[1], c), dn = PH_RGB(C[3], c);
+        const float sp = yadif_spatial(lane_tap(up, lane, -3), lane_tap(up, lane, -2), lane_tap(up, lane, -1), up,
+                                       lane_tap(up, lane, 1), lane_tap(up, lane, 2), lane_tap(up, lane, 3),
+                                       lane_tap(dn, lane, -3), lane_tap(dn, lane, -2), lane_tap(dn, lane, -1), dn,
+                                       lane_tap(dn, lane, 1), lane_tap(dn, lane, 2), lane_tap(dn, lane, 3));
+        // second field: s0 = cur, s1 = next; first field: s0 = prev, s1 = cur (yadifCl.ts:146-151)
+        const float c0 = PH_RGB(C[0], c), c2 = PH_RGB(C[2], c), c4 = PH_RGB(C[4], c);
+        const float e0 = second ? PH_RGB(N[0], c) : PH_RGB(P[0], c), e1 = second ? PH_RGB(N[2], c) : PH_RGB(P[2], c),
+                    e2 = second ? PH_RGB(N[4], c) : PH_RGB(P[4], c);
+        res[c] = yadif_temporal(PH_RGB(P[1], c), PH_RGB(P[3], c), second ? c0 : e0, second ? c2 : e1, second ? c4 : e2,
+                                PH_RGB(C[1], c), PH_RGB(C[3], c), second ? e0 : c0, second ? e1 : c2, second ? e2 : c4,
+                                PH_RGB(N[1], c), PH_RGB(N[3], c), sp, a.skip);
+      }
+      if (emit) {
+        store_stream(out_copy + (size_t)y * w + xr, make_float4(C[2].r, C[2].g, C[2].b, 1.0f));      // yadifCl.ts:117-121
+        store_stream(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], 1.0f));    // :164 alpha from cur
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) C[i] = C[i + 1], P[i] = P[i + 1], N[i] = N[i + 1];
+      C[4] = row(cur, y + 3), P[4] = row(prev, y + 3), N[4] = row(next, y + 3);
+    };
+    for (int y = y0; y < y_end; y += 2) {  // y0 is even
+      step(y, std::integral_constant<bool, TFF != 0>{}, out1, out0);
+      if (y + 1 < y_end) step(y + 1, std::integral_constant<bool, TFF == 0>{}, out0, out1);
+    }
+  }
+}
+
+hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t num_cus) {
+  // strip height: even, and such that the waves of the chip are filled in whole rounds - cost ~ rounds x (R + 4 halo rows)
+  const uint32_t slots = num_cus * (kLdsBlock / 64);
+  a.col_blocks = (a.width + kDeintCols - 1) / kDeintCols;
+  uint32_t best_r = 16;
+  uint64_t best_cost = ~0ull;
+  for (uint32_t r = 8; r <= 64; r += 2) {
+    const uint32_t strips = (a.height + r - 1) / r;
+    const uint64_t tasks = (uint64_t)a.n * strips * a.col_blocks, rounds = (tasks + slots - 1) / slots;
+    const uint64_t cost = rounds * (r + 4);
+    if (cost < best_cost) best_cost = cost, best_r = r;
+  }
+  a.rows_per_strip = best_r;
+  a.strips = (a.height + best_r - 1) / best_r;
+  const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;
+  const uint32_t want = (tasks + kLdsBlock / 64 - 1) / (kLdsBlock / 64);
+  const uint32_t grid = want < num_cus ? want : num_cus;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tff ? v210_yadif_pair_kernel<1> : v210_yadif_pair_kernel<0>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lut.bytes);
+  if (e != hipSuccess) return e;
+  if (tff)
+    v210_yadif_pair_kernel<1><<<grid, kLdsBlock, a.lut.bytes, s>>>(a);
+  else
+    v210_yadif_pair_kernel<0><<<grid, kLdsBlock, a.lut.bytes, s>>>(a);
+  return hipGetLastError();
+}
+
+}  // namespace ph

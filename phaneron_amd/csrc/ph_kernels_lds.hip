@@ -67,49 +67,6 @@ __device__ __forceinline__ void ph_set_wave_priority(int level) {
 
 namespace ph {
 
-// Every YCbCr->RGB matrix colourMaths.ts:276-332 can produce has the same shape: one luma gain in all
-// three rows, no Cb term in R, no Cr term in B (SURVEY a4 goldens: y2r709 = 3a95a025 00000000 ... /
-// 3a95a025 b95b.. ba08.. / 3a95a025 3b07.. 00000000 ...).  With that shape (checked on the device, bit
-// for bit) Y*m0 is computed once per pixel and the two fma by zero are skipped: fma(c, +-0, p) == p
-// for the finite, non-negative code value c - except that it can turn p = -0 into +0, which the
-// clamp / round that follows maps to the same table index.  8 operations per pixel instead of 12.
-__device__ __forceinline__ bool ycbcr_matrix_is_standard(const ReadK &k) {
-  return k.r.y == 0.0f && k.b.z == 0.0f && k.r.x == k.g.x && k.g.x == k.b.x;
-}
-template <bool STD = false>
-__device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const ReadK &k, const LutK &lut) {
-  float tr, tg, tb;
-  if (STD) {
-    const float ym = y * k.r.x;
-    tr = fma_rn(1.0f, k.r.w, fma_rn(cr, k.r.z, ym));
-    tg = fma_rn(1.0f, k.g.w, fma_rn(cr, k.g.z, fma_rn(cb, k.g.y, ym)));
-    tb = fma_rn(1.0f, k.b.w, fma_rn(cb, k.b.y, ym));
-  } else {
-    tr = dot4(y, cb, cr, 1.0f, k.r), tg = dot4(y, cb, cr, 1.0f, k.g), tb = dot4(y, cb, cr, 1.0f, k.b);
-  }
-  const float r = lds_lut_at_unit(lut, tr);
-  const float g = lds_lut_at_unit(lut, tg);
-  const float b = lds_lut_at_unit(lut, tb);
-  return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
-                     dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
-}
-
-__device__ __forceinline__ Yuv1 write_px_lds(float r, float g, float b, const WriteK &k, const LutK &lut) {
-  const float gr = lds_lut_at_unit(lut, r);
-  const float gg = lds_lut_at_unit(lut, g);
-  const float gb = lds_lut_at_unit(lut, b);
-  Yuv1 o;
-  o.y = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
-  o.u = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.u));
-  o.v = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.v));
-  return o;
-}
-__device__ __forceinline__ uint32_t write_px_luma_lds(float r, float g, float b, const WriteK &k, const LutK &lut) {
-  const float gr = lds_lut_at_unit(lut, r);
-  const float gg = lds_lut_at_unit(lut, g);
-  const float gb = lds_lut_at_unit(lut, b);
-  return sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
-}
 
 // ---- the same two pixel stages split at the LDS reads (ph_ldslut.h lds_lut_issue / lds_lut_finish), for the
 // software-pipelined fused kernel: `issue` does everything up to and including the start of the six reads,
@@ -415,6 +372,41 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_kernel(const uint4 *_
     // v210.ts:58-63: Y of pixel j sits in word {0,1,1,2,3,3} at bit {10,0,20,10,0,20};
     // Cb of pair pr in word {0,1,2} at bit {0,10,20}; Cr in word {0,2,3} at bit {20,0,10}
     const uint32_t wy = (j == 0) ? w.x : (j < 3) ? w.y : (j == 3) ? w.z : w.w;
+    const uint32_t sy = (j == 0 || j == 3) ? 10u : (j == 1 || j == 4) ? 0u : 20u;
+    const uint32_t wcb = pr == 0 ? w.x : pr == 1 ? w.y : w.z;
+    const uint32_t wcr = pr == 0 ? w.x : pr == 1 ? w.z : w.w;
+    const uint32_t scr = pr == 0 ? 20u : pr == 1 ? 0u : 10u;
+    const float yf = (float)((wy >> sy) & 0x3ff);
+    const float cbf = (float)((wcb >> (10u * pr)) & 0x3ff);
+    const float crf = (float)((wcr >> scr) & 0x3ff);
+    store_stream(out + p, read_px_lds(yf, cbf, crf, k, lk));
+  }
+}
+
+// Several frames of one size and one colour recipe in ONE launch (the layers of a channel arrive together): the
+// workgroups are divided between the frames (frame index uniform per workgroup, pointers stay scalar loads), so the
+// launch and the 148 KiB table load per CU are paid once per batch, not once per frame - at 1080p they are half of
+// a single read's 13.6 us.
+struct ReadBatchArgs {
+  const uint4 *in[kMaxLayers];
+  float4 *out[kMaxLayers];
+  uint32_t wg_per_frame;
+};
+__global__ __launch_bounds__(kLdsBlock) void v210_read_lds_batch_kernel(ReadBatchArgs a, uint32_t width, uint32_t quads_per_line_pitch,
+                                                                         uint32_t total_px, const float *__restrict__ cm,
+                                                                         const float *__restrict__ gm, LutView lut) {
+  const ReadK k = load_read_k(cm, gm);
+  const LutK lk = make_lut_k(lut);
+  lds_lut_load(lut);
+  __syncthreads();
+  const uint32_t frame = blockIdx.x / a.wg_per_frame, wg = blockIdx.x - frame * a.wg_per_frame;
+  const uint4 *__restrict__ in = a.in[frame];
+  float4 *__restrict__ out = a.out[frame];
+  for (uint32_t p = wg * kLdsBlock + threadIdx.x; p < total_px; p += a.wg_per_frame * kLdsBlock) {
+    const uint32_t line = p / width, x = p - line * width;
+    const uint32_t g = x / 6, j = x - 6 * g, pr = j >> 1;
+    const uint4 w = in[(size_t)line * quads_per_line_pitch + g];
+    const uint32_t wy = (j == 0) ? w.x : (j < 3) ? w.y : (j == 3) ? w.z : w.w;  // as v210_read_lds_kernel
     const uint32_t sy = (j == 0 || j == 3) ? 10u : (j == 1 || j == 4) ? 0u : 20u;
     const uint32_t wcb = pr == 0 ? w.x : pr == 1 ? w.y : w.z;
     const uint32_t wcr = pr == 0 ? w.x : pr == 1 ? w.z : w.w;
@@ -913,6 +905,21 @@ hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32
   v210_read_lds_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, lut.bytes, s>>>(
       (const uint4 *)in, (float4 *)out, width, v210_pitch_bytes(width) / 16, total, (const float *)cm, (const float *)gm,
       lut);
+  return hipGetLastError();
+}
+
+hipError_t launch_v210_read_lds_batch(hipStream_t s, int n, const void *const *ins, void *const *outs, uint32_t width,
+                                      uint32_t height, const void *cm, const void *gm, const LutView &lut, uint32_t num_cus) {
+  hipError_t e = allow_lds(v210_read_lds_batch_kernel, lut.bytes);
+  if (e != hipSuccess) return e;
+  ReadBatchArgs a{};
+  for (int i = 0; i < n; ++i) a.in[i] = (const uint4 *)ins[i], a.out[i] = (float4 *)outs[i];
+  const uint32_t total = width * height;
+  const uint32_t want = (total + kLdsBlock - 1) / kLdsBlock;
+  uint32_t per = num_cus / (uint32_t)n ? num_cus / (uint32_t)n : 1;
+  a.wg_per_frame = want < per ? want : per;
+  v210_read_lds_batch_kernel<<<a.wg_per_frame * n, kLdsBlock, lut.bytes, s>>>(a, width, v210_pitch_bytes(width) / 16, total,
+                                                                              (const float *)cm, (const float *)gm, lut);
   return hipGetLastError();
 }
 

@@ -158,4 +158,48 @@ struct LutInGlobal {
   __device__ __forceinline__ float at_unit(float u) const { return t[sat_u16_rte(u * 65535.0f)]; }
 };
 
+// Every YCbCr->RGB matrix colourMaths.ts:276-332 can produce has the same shape: one luma gain in all
+// three rows, no Cb term in R, no Cr term in B (SURVEY a4 goldens: y2r709 = 3a95a025 00000000 ... /
+// 3a95a025 b95b.. ba08.. / 3a95a025 3b07.. 00000000 ...).  With that shape (checked on the device, bit
+// for bit) Y*m0 is computed once per pixel and the two fma by zero are skipped: fma(c, +-0, p) == p
+// for the finite, non-negative code value c - except that it can turn p = -0 into +0, which the
+// clamp / round that follows maps to the same table index.  8 operations per pixel instead of 12.
+__device__ __forceinline__ bool ycbcr_matrix_is_standard(const ReadK &k) {
+  return k.r.y == 0.0f && k.b.z == 0.0f && k.r.x == k.g.x && k.g.x == k.b.x;
+}
+template <bool STD = false>
+__device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const ReadK &k, const LutK &lut) {
+  float tr, tg, tb;
+  if (STD) {
+    const float ym = y * k.r.x;
+    tr = fma_rn(1.0f, k.r.w, fma_rn(cr, k.r.z, ym));
+    tg = fma_rn(1.0f, k.g.w, fma_rn(cr, k.g.z, fma_rn(cb, k.g.y, ym)));
+    tb = fma_rn(1.0f, k.b.w, fma_rn(cb, k.b.y, ym));
+  } else {
+    tr = dot4(y, cb, cr, 1.0f, k.r), tg = dot4(y, cb, cr, 1.0f, k.g), tb = dot4(y, cb, cr, 1.0f, k.b);
+  }
+  const float r = lds_lut_at_unit(lut, tr);
+  const float g = lds_lut_at_unit(lut, tg);
+  const float b = lds_lut_at_unit(lut, tb);
+  return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
+                     dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
+}
+
+__device__ __forceinline__ Yuv1 write_px_lds(float r, float g, float b, const WriteK &k, const LutK &lut) {
+  const float gr = lds_lut_at_unit(lut, r);
+  const float gg = lds_lut_at_unit(lut, g);
+  const float gb = lds_lut_at_unit(lut, b);
+  Yuv1 o;
+  o.y = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
+  o.u = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.u));
+  o.v = sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.v));
+  return o;
+}
+__device__ __forceinline__ uint32_t write_px_luma_lds(float r, float g, float b, const WriteK &k, const LutK &lut) {
+  const float gr = lds_lut_at_unit(lut, r);
+  const float gg = lds_lut_at_unit(lut, g);
+  const float gb = lds_lut_at_unit(lut, b);
+  return sat_u16_rte(dot4(gr, gg, gb, 1.0f, k.y));
+}
+
 }  // namespace ph

@@ -120,6 +120,22 @@ def test_yadif_vs_oracle(w, h):
             assert_bits(hh.host(out), orc.yadif(p, c, n, parity, tff, False), "yadif %dx%d p%d t%d" % (w, h, parity, tff))
 
 
+@pytest.mark.parametrize("w,h,n", [(1920, 1080, 5), (96, 7, 3), (1282, 3, 2), (6, 1, 8), (3840, 64, 1)])
+def test_v210_read_batch_vs_oracle(w, h, n):
+    """n frames in one launch == n single reads (both the LDS-table kernel and, for ragged widths, the gather kernel)"""
+    import torch
+    import hip_harness as hh
+    rcm, rlut, rgm = hh.ColourParams.reader("709", "2020")
+    srcs = [frames.v210_random(w, h, 7000 + 13 * i + w) for i in range(n)]
+    outs = [torch.full((w * h * 4,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+    hh.ctx().v210_read_batch([hh.dev(s) for s in srcs], outs, w, h, rcm, rlut, rgm)
+    for i in range(n):
+        want = orc.v210_read(srcs[i], w, h, orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
+        assert_bits(hh.host(outs[i]), want, "v210_read_batch %dx%d frame %d of %d" % (w, h, i, n))
+    with pytest.raises(Exception, match="1..8 frames"):
+        hh.ctx().v210_read_batch([], [], w, h, rcm, rlut, rgm)
+
+
 @pytest.mark.parametrize("w,h", [(1920, 540), (301, 33), (3, 2), (250, 17), (64, 1)])
 def test_yadif_pair_vs_oracle(w, h):
     """both fields of a frame in one pass == the filter run once per parity (yadif.ts:100-145, send_field)"""
@@ -135,6 +151,33 @@ def test_yadif_pair_vs_oracle(w, h):
                             "yadif_pair %dx%d p%d t%d s%d" % (w, h, parity, tff, skip))
     with pytest.raises(Exception, match="same buffer"):
         hh.ctx().yadif_pair(hh.dev(p), hh.dev(c), hh.dev(n), out[0], out[0], w, h, 1, False)
+
+
+@pytest.mark.parametrize("w,h,n", [(1920, 270, 2), (96, 33, 3), (6, 2, 1), (348, 17, 1), (354, 64, 4), (1920, 1, 1)])
+def test_v210_yadif_pair_vs_oracle(w, h, n, lut_path):
+    """the fused de-interlacing reader == ToRGBA on the three window frames, then Yadif once per parity"""
+    import torch
+    import hip_harness as hh
+    rcm, rlut, rgm = hh.ColourParams.reader("709", "2020")
+    if lut_path == "global_lut":  # the kernel exists in the LDS-table form only and says so
+        with pytest.raises(Exception, match="no LDS form"):
+            hh.ctx().v210_yadif_pair([(rlut, rlut, rlut, rlut, rgm)], w, h, 1, False, rcm, rlut, rgm)
+        return
+    o_args = (orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
+    for tff, skip in ((1, False), (0, False), (1, True)):
+        wins = [[frames.v210_random(w, h, 8100 + 31 * l + 7 * i + w + tff) for i in range(3)] for l in range(n)]
+        outs = [[torch.full((w * h * 4,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(2)] for _ in range(n)]
+        hh.ctx().v210_yadif_pair([(hh.dev(wins[l][0]), hh.dev(wins[l][1]), hh.dev(wins[l][2]), outs[l][0], outs[l][1]) for l in range(n)],
+                                 w, h, tff, skip, rcm, rlut, rgm)
+        for l in range(n):
+            p, c, nx = (orc.v210_read(f, w, h, *o_args) for f in wins[l])
+            for parity in (0, 1):
+                assert_bits(hh.host(outs[l][parity]), orc.yadif(p, c, nx, parity, tff, skip),
+                            "v210_yadif_pair %dx%d layer %d p%d t%d s%d" % (w, h, l, parity, tff, skip))
+    with pytest.raises(Exception, match="multiple of 6"):
+        hh.ctx().v210_yadif_pair([(hh.dev(wins[0][0]), hh.dev(wins[0][1]), hh.dev(wins[0][2]), outs[0][0], outs[0][1])], 100, 4, 1, False, rcm, rlut, rgm)
+    with pytest.raises(Exception, match="same buffer"):
+        hh.ctx().v210_yadif_pair([(hh.dev(wins[0][0]), hh.dev(wins[0][1]), hh.dev(wins[0][2]), outs[0][0], outs[0][0])], w, h, 1, False, rcm, rlut, rgm)
 
 
 @pytest.mark.parametrize("iw,ih,ow,oh,kw", [

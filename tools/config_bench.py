@@ -89,10 +89,13 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
         ctx.combine([xf[0], xf[1], xf[2], trans], comb, w, h)
         ctx.v210_write(comb, out, w, h, 0, *wr)
 
-    def config2_fused(i):  # same frame with transform x3 + combine_4 + write as one kernel
+    def config2_fused(i, batch=False):  # same frame with transform x3 + combine_4 + write as one kernel
         s = src[i % R]
-        for l in range(5):
-            ctx.v210_read(s[l], rgba[l], w, h, *rd)
+        if batch:
+            ctx.v210_read_batch(s, rgba, w, h, *rd)
+        else:
+            for l in range(5):
+                ctx.v210_read(s[l], rgba[l], w, h, *rd)
         ctx.transform(rgba[3], w, h, mats[3], xf[3], w, h)
         ctx.transition_wipe(xf[3], rgba[4], mask, trans, w, h)
         ctx.compose_write_v210([(rgba[0], w, h, mats[0]), (rgba[1], w, h, mats[1]), (rgba[2], w, h, mats[2]),
@@ -101,9 +104,11 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     # 4 layers + second source + the mask counted as one more v210-sized input + 1 output (38 707 200 during a transition)
     algo2 = 7 * capi.v210_pitch_bytes(w) * h
     name2 = "2: 1 channel, 4-layer 1080p50, three quarter-size insets, wipe transition on the top layer"
-    record(name2, "fused compositor: read x5, transform, transition_wipe, [transform x3 + combine_4 + write]", "frame",
-           timeit(config2_fused, reps), algo2, 8)
+    record(name2, "fused compositor, batched reads: [read x5], transform, transition_wipe, [transform x3 + combine_4 + write]", "frame",
+           timeit(lambda i: config2_fused(i, True), reps), algo2, 4)
     if routes == "all":
+        record(name2, "fused compositor: read x5, transform, transition_wipe, [transform x3 + combine_4 + write]", "frame",
+               timeit(config2_fused, reps), algo2, 8)
         record(name2, "one kernel per operator (the reference's job batch)", "frame", timeit(config2, reps), algo2, 13)
         graphs = [ctx.record(lambda i=i: config2_fused(i)) for i in range(R)]
         record(name2, "fused compositor, each frame's batch replayed as one hipGraph", "frame",
@@ -120,12 +125,15 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     m = dev(mh)
     torch.cuda.synchronize()
 
-    def new_frames(i):  # a new source frame is unpacked every second field (send_field: two outputs per frame)
+    def new_frames(i, batch=False):  # a new source frame is unpacked every second field (send_field: two outputs per frame)
         s = srcs[(i // 2) % R]
         if not (i & 1):
             for l in range(4):
                 win[l] = [win[l][1], win[l][2], win[l][0]]
-                ctx.v210_read(s[l], win[l][2], sw, sh, *rd)
+                if not batch:
+                    ctx.v210_read(s[l], win[l][2], sw, sh, *rd)
+            if batch:
+                ctx.v210_read_batch(s, [win[l][2] for l in range(4)], sw, sh, *rd)
         return 1 ^ (0 if (i & 1) else 1)             # parity = tff ^ !second (yadif.ts:104), tff = 1
 
     def config3_fused(i):  # yadif per layer, then upscale x4 + combine_4 + write as one kernel
@@ -138,17 +146,30 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
 
     def config3_pair(i):  # both fields of a frame de-interlaced in one pass per layer; one compositor launch per field
         if not (i & 1):
-            new_frames(i)
+            new_frames(i, True)
             for l in range(4):
                 ctx.yadif_pair(win[l][0], win[l][1], win[l][2], deint2[l][0], deint2[l][1], sw, sh, 1, False)
         parity = 1 ^ (0 if (i & 1) else 1)
         ctx.compose_write_v210([(deint2[l][parity], sw, sh, m) for l in range(4)], out, ow, oh, 0, *wr)
 
+    vwin = [[srcs[k % R][l] for k in range(3)] for l in range(4)]  # v210 windows: prev / cur / next per layer
+
+    def config3_deint(i):  # per frame ONE launch: unpack + yadif of both fields, all four layers; per field the compositor
+        if not (i & 1):
+            s = srcs[(i // 2) % R]
+            for l in range(4):
+                vwin[l] = [vwin[l][1], vwin[l][2], s[l]]
+            ctx.v210_yadif_pair([(vwin[l][0], vwin[l][1], vwin[l][2], deint2[l][0], deint2[l][1]) for l in range(4)], sw, sh, 1, False, *rd)
+        parity = 1 ^ (0 if (i & 1) else 1)
+        ctx.compose_write_v210([(deint2[l][parity], sw, sh, m) for l in range(4)], out, ow, oh, 0, *wr)
+
     algo3 = 4 * 3 * capi.v210_pitch_bytes(sw) * sh + capi.v210_pitch_bytes(ow) * oh  # 88 473 600
     name3 = "3: 1 channel, 4 x 1080i50 -> yadif -> 2x up-scale -> 709->2020 -> combine_4 -> 2160p50 (per output field)"
-    record(name3, "fused compositor, field pairs: per frame read x4 + yadif_pair x4 (both fields in one pass), per field "
-           "[transform x4 + combine_4 + write]", "field", timeit(config3_pair, reps), algo3, 5)
+    record(name3, "fused de-interlacing reader + fused compositor: per frame [unpack + yadif, both fields, x4 layers] (ph_v210_yadif_pair), "
+           "per field [transform x4 + combine_4 + write]", "field", timeit(config3_deint, reps), algo3, 1.5)
     if routes == "all":
+        record(name3, "fused compositor, field pairs: per frame [read x4] + yadif_pair x4 (both fields in one pass), per field "
+               "[transform x4 + combine_4 + write]", "field", timeit(config3_pair, reps), algo3, 3.5)
         record(name3, "fused compositor: read x4 every other field, yadif x4, [transform x4 + combine_4 + write]", "field",
                timeit(config3_fused, reps), algo3, 7)
     if routes == "all":

@@ -69,6 +69,10 @@ def main():
     timeit("resize 1080->2160", lambda i: ctx.resize(src1080[i % R], 1920, 1080, 1.0, 0.0, 0.0, flip, out_img[i % 2], w, h), ib + ib // 4)
     src540 = [torch.rand(1920 * 1080 * 4, dtype=torch.float32, device="cuda") for _ in range(4)]
     timeit("yadif 1080p", lambda i: ctx.yadif(src1080[i % R], src1080[(i + 1) % R], src1080[(i + 2) % R], out_img[0], 1920, 1080, 0, 1), 4 * ib // 4)
+    out1080 = [torch.empty(1920 * 1080 * 4, dtype=torch.float32, device="cuda") for _ in range(2)]
+    # both fields of a frame in one pass: 3 frames read, 2 written
+    timeit("yadif_pair 1080p (two fields)", lambda i: ctx.yadif_pair(src1080[i % R], src1080[(i + 1) % R], src1080[(i + 2) % R], out1080[0], out1080[1], 1920, 1080, 1), 5 * ib // 4)
+    timeit("yadif_pair 2160p (two fields)", lambda i: ctx.yadif_pair(img[i % R], img[(i + 1) % R], img[(i + 2) % R], out_img[0], out_img[1], w, h, 1), 5 * ib)
     timeit("compose_write 4 x (1080p -> 2160p bilinear) -> v210",
            lambda i: ctx.compose_write_v210([(src1080[(i + j) % R], 1920, 1080, m) for j in range(4)], out_v[i % 2], w, h, 0, *wr),
            ib + vb)
