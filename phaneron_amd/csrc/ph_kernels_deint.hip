@@ -31,27 +31,35 @@ struct Rgb {
   float r, g, b;
 };
 
-// the lane's pixel of one v210 line: word / shift selectors depend on x only (v210.ts:58-63)
+// the lane's pixel of one v210 line: which 32-bit word holds its Y, its pair's Cb and Cr, and at which bit
+// (v210.ts:58-63) depends on x only, so the lane loads exactly those three words of every line (three dword loads
+// at lane-constant offsets from the line's start - no 16-byte load followed by seven selects)
 struct LanePick {
-  uint32_t g, j, pr, sy, scr;
+  uint32_t off_y, off_cb, off_cr;  // byte offsets inside a line
+  uint32_t sy, scb, scr;
 };
 __device__ __forceinline__ LanePick lane_pick(uint32_t x) {
+  const uint32_t g = x / 6, j = x - 6 * g, pr = j >> 1;
+  const uint32_t wy = (j == 0) ? 0u : (j < 3) ? 1u : (j == 3) ? 2u : 3u;
+  const uint32_t wcb = pr, wcr = pr == 0 ? 0u : pr + 1u;
   LanePick p;
-  p.g = x / 6, p.j = x - 6 * p.g, p.pr = p.j >> 1;
-  p.sy = (p.j == 0 || p.j == 3) ? 10u : (p.j == 1 || p.j == 4) ? 0u : 20u;
-  p.scr = p.pr == 0 ? 20u : p.pr == 1 ? 0u : 10u;
+  p.off_y = 16u * g + 4u * wy, p.off_cb = 16u * g + 4u * wcb, p.off_cr = 16u * g + 4u * wcr;
+  p.sy = (j == 0 || j == 3) ? 10u : (j == 1 || j == 4) ? 0u : 20u;
+  p.scb = 10u * pr;
+  p.scr = pr == 0 ? 20u : pr == 1 ? 0u : 10u;
   return p;
 }
-__device__ __forceinline__ Rgb unpack_row_px(const uint4 *__restrict__ frame, uint32_t quads_pitch, int line, const LanePick &p,
+template <bool STD>
+__device__ __forceinline__ Rgb unpack_row_px(const unsigned char *__restrict__ frame, uint32_t pitch_bytes, int line, const LanePick &p,
                                              const ReadK &k, const LutK &lk) {
-  const uint4 w = frame[(size_t)line * quads_pitch + p.g];
-  const uint32_t wy = (p.j == 0) ? w.x : (p.j < 3) ? w.y : (p.j == 3) ? w.z : w.w;
-  const uint32_t wcb = p.pr == 0 ? w.x : p.pr == 1 ? w.y : w.z;
-  const uint32_t wcr = p.pr == 0 ? w.x : p.pr == 1 ? w.z : w.w;
+  const unsigned char *row = frame + (size_t)line * pitch_bytes;  // uniform
+  const uint32_t wy = *reinterpret_cast<const uint32_t *>(row + p.off_y);
+  const uint32_t wcb = *reinterpret_cast<const uint32_t *>(row + p.off_cb);
+  const uint32_t wcr = *reinterpret_cast<const uint32_t *>(row + p.off_cr);
   const float yf = (float)((wy >> p.sy) & 0x3ff);
-  const float cbf = (float)((wcb >> (10u * p.pr)) & 0x3ff);
+  const float cbf = (float)((wcb >> p.scb) & 0x3ff);
   const float crf = (float)((wcr >> p.scr) & 0x3ff);
-  const float4 v = read_px_lds(yf, cbf, crf, k, lk);
+  const float4 v = read_px_lds<STD>(yf, cbf, crf, k, lk);
   return Rgb{v.x, v.y, v.z};
 }
 
@@ -61,24 +69,22 @@ __device__ __forceinline__ float lane_tap(float v, uint32_t lane, int d) {
 
 #define PH_RGB(v, c) ((c) == 0 ? (v).r : (c) == 1 ? (v).g : (v).b)
 
-template <int TFF>
-__global__ __launch_bounds__(kLdsBlock) void v210_yadif_pair_kernel(DeintArgs a) {
-  const ReadK k = load_read_k(a.cm, a.gm);
-  const LutK lk = make_lut_k(a.lut);
-  lds_lut_load(a.lut);
-  __syncthreads();
+template <int TFF, bool STD>
+__device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const ReadK &k, const LutK &lk) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = (int)a.width, h = (int)a.height;
   const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;
   for (uint32_t t = blockIdx.x * (kLdsBlock / 64) + wave; t < tasks; t += gridDim.x * (kLdsBlock / 64)) {
     const uint32_t cb = t % a.col_blocks, rest = t / a.col_blocks, strip = rest % a.strips, l = rest / a.strips;
-    const uint4 *__restrict__ prev = a.prev[l], *__restrict__ cur = a.cur[l], *__restrict__ next = a.next[l];
+    const unsigned char *__restrict__ prev = reinterpret_cast<const unsigned char *>(a.prev[l]);
+    const unsigned char *__restrict__ cur = reinterpret_cast<const unsigned char *>(a.cur[l]);
+    const unsigned char *__restrict__ next = reinterpret_cast<const unsigned char *>(a.next[l]);
     float4 *__restrict__ out0 = a.out0[l], *__restrict__ out1 = a.out1[l];
     const int xr = (int)(cb * kDeintCols) - 3 + (int)lane, x = clampi(xr, 0, w - 1);  // CLAMP_TO_EDGE
     const bool emit = lane >= 3 && lane < 64 - 3 && xr < w;
     const LanePick pick = lane_pick((uint32_t)x);
     const int y0 = (int)(strip * a.rows_per_strip), y_end = (y0 + (int)a.rows_per_strip < h) ? y0 + (int)a.rows_per_strip : h;
-    auto row = [&](const uint4 *frame, int y) { return unpack_row_px(frame, a.quads_pitch, clampi(y, 0, h - 1), pick, k, lk); };
+    auto row = [&](const unsigned char *frame, int y) { return unpack_row_px<STD>(frame, a.quads_pitch * 16u, clampi(y, 0, h - 1), pick, k, lk); };
     Rgb C[5], P[5], N[5];  // rows y - 2 .. y + 2
 #pragma unroll
     for (int i = 0; i < 5; ++i) C[i] = row(cur, y0 - 2 + i), P[i] = row(prev, y0 - 2 + i), N[i] = row(next, y0 - 2 + i);
@@ -115,6 +121,18 @@ __global__ __launch_bounds__(kLdsBlock) void v210_yadif_pair_kernel(DeintArgs a)
       if (y + 1 < y_end) step(y + 1, std::integral_constant<bool, TFF == 0>{}, out0, out1);
     }
   }
+}
+
+template <int TFF>
+__global__ __launch_bounds__(kLdsBlock) void v210_yadif_pair_kernel(DeintArgs a) {
+  const ReadK k = load_read_k(a.cm, a.gm);
+  const LutK lk = make_lut_k(a.lut);
+  lds_lut_load(a.lut);
+  __syncthreads();
+  if (ycbcr_matrix_is_standard(k))  // every matrix colourMaths produces (ph_ldslut.h): 8 operations per pixel instead of 12
+    v210_yadif_pair_body<TFF, true>(a, k, lk);
+  else
+    v210_yadif_pair_body<TFF, false>(a, k, lk);
 }
 
 hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t num_cus) {

@@ -632,7 +632,9 @@ __device__ __forceinline__ float4 as_float4(const ph_u32x4 v) {
 
 // One chunk row of the compositor.  ALIGNED: every sampled layer has m1 == m3 == 0 (row taps once per chunk);
 // MIXED: some layers are taken 1:1 (selects, no branches: the loads of all layers stay in flight together).
-template <int N, bool MIXED, bool ALIGNED>
+// SHARED: every layer is sampled through the same matrix buffer at the same source size (full-frame layers of one
+// channel): tap offsets and weights are computed once per pixel, only the resource differs per layer.
+template <int N, bool MIXED, bool ALIGNED, bool SHARED = false>
 __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const float (&mm)[N][6], const bool (&direct)[N],
                                                   const __amdgpu_buffer_rsrc_t (&img)[N], const WriteK &wk, const LutK &lk,
                                                   uint16_t *ys, uint16_t *us, uint16_t *vs, uint32_t wave, uint32_t lane) {
@@ -648,7 +650,7 @@ __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const fl
     RowTaps row[N];
     if (ALIGNED) {
 #pragma unroll
-      for (int l = 0; l < N; ++l)  // transform.ts:53-57 with m3 == 0: t' does not depend on x
+      for (int l = 0; l < (SHARED ? 1 : N); ++l)  // transform.ts:53-57 with m3 == 0: t' does not depend on x
         row[l] = row_taps(dot3(mm[l][3], mm[l][4], mm[l][5], 0.0f, py, 1.0f) + 0.5f, a.lw[l], a.lh[l]);
     }
 #pragma unroll 1
@@ -659,9 +661,18 @@ __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const fl
       const uint32_t own = (line * a.out_w + x) * 16u;  // a 1:1 layer's texel
       ph_u32x4 tap[N][4];
       float wa[N], wb[N];
+      uint32_t o00 = 0, o10 = 0, o01 = 0, o11 = 0;
       // every layer's loads are issued before any is blended: 4 N independent loads in flight
 #pragma unroll
       for (int l = 0; l < N; ++l) {
+        if (SHARED && l > 0) {
+          wa[l] = wa[0], wb[l] = wb[0];
+          tap[l][0] = __builtin_amdgcn_raw_buffer_load_b128(img[l], (int)o00, 0, 0);
+          tap[l][1] = __builtin_amdgcn_raw_buffer_load_b128(img[l], (int)o10, 0, 0);
+          tap[l][2] = __builtin_amdgcn_raw_buffer_load_b128(img[l], (int)o01, 0, 0);
+          tap[l][3] = __builtin_amdgcn_raw_buffer_load_b128(img[l], (int)o11, 0, 0);
+          continue;
+        }
         const RowTaps r = ALIGNED ? row[l] : row_taps(dot3(mm[l][3], mm[l][4], mm[l][5], px, py, 1.0f) + 0.5f, a.lw[l], a.lh[l]);
         const float s = dot3(mm[l][0], mm[l][1], mm[l][2], px, py, 1.0f) + 0.5f;
         const float u = s * (float)a.lw[l];
@@ -670,7 +681,7 @@ __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const fl
         const uint32_t i0 = (uint32_t)(int)flu, i1 = i0 + 1u;
         const uint32_t c0 = i0 < (uint32_t)a.lw[l] ? i0 << 4 : kTapOutside, c1 = i1 < (uint32_t)a.lw[l] ? i1 << 4 : kTapOutside;
         wa[l] = fu - flu, wb[l] = r.b;
-        uint32_t o00 = r.r0 + c0, o10 = r.r0 + c1, o01 = r.r1 + c0, o11 = r.r1 + c1;
+        o00 = r.r0 + c0, o10 = r.r0 + c1, o01 = r.r1 + c0, o11 = r.r1 + c1;
         if (MIXED) o00 = direct[l] ? own : o00;
         tap[l][0] = __builtin_amdgcn_raw_buffer_load_b128(img[l], (int)o00, 0, 0);
 #ifdef PH_TAPS_ONE_LOAD  // timing experiment (wrong results): one tap per sample instead of four
@@ -719,7 +730,7 @@ __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const fl
   }
 }
 
-template <int N, bool MIXED>
+template <int N, bool MIXED, bool SHARED = false>
 __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_taps_kernel(ComposeArgs a, uint32_t stage_off) {
   const WriteK wk = load_write_k(a.wr_cm);
   const LutK lk = make_lut_k(a.wr);
@@ -741,20 +752,27 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_taps_kernel(Comp
   uint16_t *ys = reinterpret_cast<uint16_t *>(g_lds + stage_off + wave * kComposeChunk * 4);
   uint16_t *us = ys + kComposeChunk, *vs = us + kComposeChunk / 2;
   if (all_aligned)
-    compose_taps_body<N, MIXED, true>(a, mm, direct, img, wk, lk, ys, us, vs, wave, lane);
+    compose_taps_body<N, MIXED, true, SHARED>(a, mm, direct, img, wk, lk, ys, us, vs, wave, lane);
   else
-    compose_taps_body<N, MIXED, false>(a, mm, direct, img, wk, lk, ys, us, vs, wave, lane);
+    compose_taps_body<N, MIXED, false, SHARED>(a, mm, direct, img, wk, lk, ys, us, vs, wave, lane);
 }
 
 template <int N>
 static hipError_t launch_compose_taps_n(hipStream_t s, const ComposeArgs &a, uint32_t grid, uint32_t stage_off) {
-  bool mixed = false;
-  for (int l = 0; l < N; ++l) mixed = mixed || a.matrix[l] == nullptr;
-  const void *fn = mixed ? reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, true>)
-                         : reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, false>);
+  bool mixed = false, shared = N > 1;
+  for (int l = 0; l < N; ++l) {
+    mixed = mixed || a.matrix[l] == nullptr;
+    // one placement for all layers: the same matrix BUFFER (so the same nine values) and the same source size
+    shared = shared && a.matrix[l] != nullptr && a.matrix[l] == a.matrix[0] && a.lw[l] == a.lw[0] && a.lh[l] == a.lh[0];
+  }
+  const void *fn = shared ? reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, false, true>)
+                   : mixed ? reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, true>)
+                           : reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(stage_off + kComposeStageBytes));
   if (e != hipSuccess) return e;
-  if (mixed)
+  if (shared)
+    compose_write_v210_taps_kernel<N, false, true><<<grid, kLdsBlock, stage_off + kComposeStageBytes, s>>>(a, stage_off);
+  else if (mixed)
     compose_write_v210_taps_kernel<N, true><<<grid, kLdsBlock, stage_off + kComposeStageBytes, s>>>(a, stage_off);
   else
     compose_write_v210_taps_kernel<N, false><<<grid, kLdsBlock, stage_off + kComposeStageBytes, s>>>(a, stage_off);

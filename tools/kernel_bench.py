@@ -73,6 +73,15 @@ def main():
     # both fields of a frame in one pass: 3 frames read, 2 written
     timeit("yadif_pair 1080p (two fields)", lambda i: ctx.yadif_pair(src1080[i % R], src1080[(i + 1) % R], src1080[(i + 2) % R], out1080[0], out1080[1], 1920, 1080, 1), 5 * ib // 4)
     timeit("yadif_pair 2160p (two fields)", lambda i: ctx.yadif_pair(img[i % R], img[(i + 1) % R], img[(i + 2) % R], out_img[0], out_img[1], w, h, 1), 5 * ib)
+    v1080 = [torch.randint(0, 2 ** 30, (capi.v210_pitch_bytes(1920) * 1080 // 4,), dtype=torch.int32, device="cuda") & 0x3FFFFFFF for _ in range(12)]
+    o1080 = [torch.empty(1920 * 1080 * 4, dtype=torch.float32, device="cuda") for _ in range(8)]
+    # per layer 3 v210 frames in, 2 RGBA frames out
+    timeit("v210_yadif_pair 4 x 1080i (unpack + both fields, one launch)",
+           lambda i: ctx.v210_yadif_pair([(v1080[(i + 3 * l) % 12], v1080[(i + 3 * l + 1) % 12], v1080[(i + 3 * l + 2) % 12], o1080[2 * l], o1080[2 * l + 1])
+                                          for l in range(4)], 1920, 1080, 1, False, *rd),
+           4 * (3 * capi.v210_pitch_bytes(1920) * 1080 + 2 * ib // 4))
+    timeit("v210_read_batch 4 x 1080p", lambda i: ctx.v210_read_batch([v1080[(i + l) % 12] for l in range(4)], o1080[:4], 1920, 1080, *rd),
+           4 * (capi.v210_pitch_bytes(1920) * 1080 + ib // 4))
     timeit("compose_write 4 x (1080p -> 2160p bilinear) -> v210",
            lambda i: ctx.compose_write_v210([(src1080[(i + j) % R], 1920, 1080, m) for j in range(4)], out_v[i % 2], w, h, 0, *wr),
            ib + vb)
