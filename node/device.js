@@ -121,6 +121,29 @@ class Rig {
 			params: { prev, cur, next, parity: o.parity ? 1 : 0, tff: o.tff ? 1 : 0, skipSpatial: o.skipSpatial ? 1 : 0, output }
 		})
 	}
+	// both send_field outputs of a frame in one pass: out[0] / out[1] are what yadif writes with parity 0 / 1
+	async yadifPair(width, height) {
+		const program = await this.program('yadif_pair', 'yadif', { globalWorkItems: [width, height] })
+		return (prev, cur, next, out, o) => ({
+			name: 'yadif_pair', program,
+			params: { prev, cur, next, tff: o.tff ? 1 : 0, skipSpatial: o.skipSpatial ? 1 : 0, output0: out[0], output1: out[1] }
+		})
+	}
+	// ToRGBA over the v210 windows of n layers + both de-interlaced fields of each, one kernel:
+	// stage([{ prev, cur, next, out: [parity0, parity1] }, ...], { tff, skipSpatial })
+	async deinterlaceReader(layers, width, height, readSpec, writeSpec) {
+		const c = await this.colourIn('v210', readSpec, writeSpec)
+		const program = await this.program(`v210_yadif_pair_${layers}`, 'deint', { globalWorkItems: [width, height] })
+		return (windows, o) => {
+			if (windows.length !== layers) throw new Error(`deinterlaceReader: ${layers} layers expected, got ${windows.length}`)
+			const params = { colMatrix: c.colMatrix, gammaLut: c.gammaLut, gamutMatrix: c.gamutMatrix, tff: o.tff ? 1 : 0, skipSpatial: o.skipSpatial ? 1 : 0 }
+			windows.forEach((wn, i) => {
+				params[`l${i}Prev`] = wn.prev; params[`l${i}Cur`] = wn.cur; params[`l${i}Next`] = wn.next
+				params[`l${i}Out0`] = wn.out[0]; params[`l${i}Out1`] = wn.out[1]
+			})
+			return { name: `v210_yadif_pair_${layers}`, program, params }
+		}
+	}
 	// stage(input, output, placement): the 3x3 matrix of a placement is uploaded once per distinct placement
 	async transform(outWidth, outHeight) {
 		const program = await this.program('transform', 'transform', { globalWorkItems: [outWidth, outHeight] })

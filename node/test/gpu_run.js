@@ -202,6 +202,44 @@ async function main() {
 		;[src[0], made, got, out[0]].forEach((b) => b.release())
 	}
 
+	// ---- 8. the de-interlacing fusions under their program names: 'yadif_pair' on the RGBA fields of step 3, and
+	//         'v210_yadif_pair_<n>' (ToRGBA of the v210 window + both fields) on two layers ----------------------------
+	{
+		const y = job.yadif
+		const pair = await rig.yadifPair(y.width, y.height)
+		const f = []
+		for (let i = 0; i < 3; ++i) {
+			const img = await rig.image(y.width, y.height, `pair field ${i}`)
+			await rig.upload(img, load(y.frames[i]))
+			f.push(img)
+		}
+		await rig.sync(ctx.queue.load)
+		const out = [await rig.image(y.width, y.height), await rig.image(y.width, y.height)]
+		await rig.run(pair(f[0], f[1], f[2], out, { tff: y.tff, skipSpatial: false }))
+		await rig.sync()
+		for (let p = 0; p < 2; ++p) { await rig.download(out[p]); save(`yadif_pair_p${p}.bin`, out[p]) }
+		;[...f, ...out].forEach((b) => b.release())
+
+		const d = job.deint
+		const reader = await rig.deinterlaceReader(d.layers.length, d.width, d.height, d.readSpec, d.writeSpec)
+		const windows = []
+		for (let l = 0; l < d.layers.length; ++l) {
+			const win = []
+			for (const file of d.layers[l]) {
+				const b = (await rig.planes('v210', d.width, d.height))[0]
+				await rig.upload(b, load(file))
+				win.push(b)
+			}
+			windows.push({ prev: win[0], cur: win[1], next: win[2], out: [await rig.image(d.width, d.height), await rig.image(d.width, d.height)] })
+		}
+		await rig.sync(ctx.queue.load)
+		await rig.run(reader(windows, { tff: d.tff, skipSpatial: false }))
+		await rig.sync()
+		for (let l = 0; l < windows.length; ++l)
+			for (let p = 0; p < 2; ++p) { await rig.download(windows[l].out[p]); save(`deint_l${l}_p${p}.bin`, windows[l].out[p]) }
+		windows.forEach((wn) => [wn.prev, wn.cur, wn.next, ...wn.out].forEach((b) => b.release()))
+	}
+
 	rig.close()
 	result.liveAfter = ctx.logBuffers ? rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers : -1
 	save('result.json', JSON.stringify(result))

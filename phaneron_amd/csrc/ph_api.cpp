@@ -868,6 +868,54 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_num(args, n, "skipSpatial", &skip));
       return ph_yadif(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, (int)parity, (int)tff, (int)skip, o->dptr);
     }
+    case K_YADIF_PAIR: {  // output0 / output1: what 'yadif' writes with parity 0 / 1
+      double tff, skip;
+      ph_buf *o1 = nullptr;
+      TRY(need_buf(args, n, "output0", 0, &o));
+      TRY(need_image(o, "output0", &w, &h));
+      const size_t img = (size_t)w * h * 16;
+      TRY(need_buf(args, n, "output1", img, &o1));
+      TRY(need_buf(args, n, "prev", img, &a));
+      TRY(need_buf(args, n, "cur", img, &b));
+      TRY(need_buf(args, n, "next", img, &c));
+      TRY(need_num(args, n, "tff", &tff));
+      TRY(need_num(args, n, "skipSpatial", &skip));
+      return ph_yadif_pair(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, (int)tff, (int)skip, o->dptr, o1->dptr);
+    }
+    case K_V210_YADIF_PAIR: {
+      // l<i>Prev / l<i>Cur / l<i>Next: v210 window; l<i>Out0 / l<i>Out1: RGBA; colMatrix / gammaLut / gamutMatrix: the Loader's
+      const uint32_t width = prog->global[0], height = prog->global[1];
+      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
+      const size_t vb = (size_t)ph_v210_pitch_bytes(width) * height, img = (size_t)width * height * 16;
+      double tff, skip;
+      ph_deint_source src[ph::kMaxLayers];
+      for (int i = 0; i < prog->n_layers; ++i) {
+        char nm[16];
+        ph_buf *x = nullptr;
+        snprintf(nm, sizeof nm, "l%dPrev", i);
+        TRY(need_buf(args, n, nm, vb, &x));
+        src[i].prev = x->dptr;
+        snprintf(nm, sizeof nm, "l%dCur", i);
+        TRY(need_buf(args, n, nm, vb, &x));
+        src[i].cur = x->dptr;
+        snprintf(nm, sizeof nm, "l%dNext", i);
+        TRY(need_buf(args, n, nm, vb, &x));
+        src[i].next = x->dptr;
+        snprintf(nm, sizeof nm, "l%dOut0", i);
+        TRY(need_buf(args, n, nm, img, &x));
+        src[i].out_parity0 = x->dptr;
+        snprintf(nm, sizeof nm, "l%dOut1", i);
+        TRY(need_buf(args, n, nm, img, &x));
+        src[i].out_parity1 = x->dptr;
+      }
+      TRY(need_buf(args, n, "colMatrix", 48, &b));
+      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
+      TRY(need_buf(args, n, "gamutMatrix", 36, &d));
+      TRY(need_num(args, n, "tff", &tff));
+      TRY(need_num(args, n, "skipSpatial", &skip));
+      refresh_buf_lut(ctx, c);
+      return ph_v210_yadif_pair(ctx, queue, prog->n_layers, src, width, height, (int)tff, (int)skip, b->dptr, c->dptr, d->dptr);
+    }
     case K_TRANSFORM: {
       int iw, ih;
       TRY(need_buf(args, n, "input", 0, &a));

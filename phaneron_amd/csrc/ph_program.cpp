@@ -180,6 +180,8 @@ int resolve_program(const char *src, const char *name, ProgramChoice &c, std::st
     return set(c, id, name, how);
   };
   if (0 == strcmp(name, "yadif")) return set(c, K_YADIF, name, how);
+  if (0 == strcmp(name, "yadif_pair")) return set(c, K_YADIF_PAIR, name, how);
+  if (0 == strncmp(name, "v210_yadif_pair_", 16)) return layers("v210_yadif_pair_", 1, K_V210_YADIF_PAIR);
   if (0 == strcmp(name, "transform")) return set(c, K_TRANSFORM, name, how);
   if (0 == strcmp(name, "resize")) return set(c, K_RESIZE, name, how);
   if (0 == strncmp(name, "combine_", 8)) return layers("combine_", 2, K_COMBINE);

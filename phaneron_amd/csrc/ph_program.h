@@ -10,6 +10,8 @@ enum KernelId {
   K_V210_READ,
   K_V210_WRITE,
   K_YADIF,
+  K_YADIF_PAIR,       // both send_field outputs in one pass (ph_yadif_pair)
+  K_V210_YADIF_PAIR,  // ToRGBA of the window + both outputs, n layers (ph_v210_yadif_pair)
   K_TRANSFORM,
   K_RESIZE,
   K_COMBINE,

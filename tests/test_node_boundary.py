@@ -228,7 +228,13 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
                ramp="ramp.bin",
                yadif=dict(width=yw, height=yh, frames=["field%d.bin" % i for i in range(4)], tff=True),
                formats=[dict(fmt=f, width=fw, height=fh, spec=sp, file="pattern_%s.bin" % f) for f, fw, fh, sp in FORMAT_KATS],
-               staged=dict(width=1920, height=24, layers=3, frames=5, readSpec="709", writeSpec="2020"))
+               staged=dict(width=1920, height=24, layers=3, frames=5, readSpec="709", writeSpec="2020"),
+               deint=dict(width=384, height=22, tff=True, readSpec="709", writeSpec="2020",
+                          layers=[["deint_l%d_f%d.bin" % (l, i) for i in range(3)] for l in range(2)]))
+    deint_src = [[frames.v210_random(384, 22, 9300 + 10 * l + i) for i in range(3)] for l in range(2)]
+    for l, win in enumerate(deint_src):
+        for i, words in enumerate(win):
+            words.tofile(tmp_path / ("deint_l%d_f%d.bin" % (l, i)))
     staged_src = [[frames.v210_random(1920, 24, frames.layer_seed(8 + f, l)) for l in range(3)] for f in range(5)]
     for f, ls in enumerate(staged_src):
         for l, words in enumerate(ls):
@@ -259,6 +265,17 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
             got = np.fromfile(tmp_path / ("yadif_out%d.bin" % k), np.float32)
             assert np.array_equal(got.view(np.uint32), want.reshape(-1).view(np.uint32)), k
             k += 1
+
+    # the de-interlacing fusions under their program names: both fields in one pass, and ToRGBA + both fields
+    for parity in (0, 1):
+        want = orc.yadif(fields[0], fields[1], fields[2], parity, True, False)
+        got = np.fromfile(tmp_path / ("yadif_pair_p%d.bin" % parity), np.float32)
+        assert np.array_equal(got.view(np.uint32), want.reshape(-1).view(np.uint32)), parity
+    for l, win in enumerate(deint_src):
+        p, c, nx = (orc.v210_read(f, 384, 22, *rd) for f in win)
+        for parity in (0, 1):
+            got = np.fromfile(tmp_path / ("deint_l%d_p%d.bin" % (l, parity)), np.float32)
+            assert np.array_equal(got.view(np.uint32), orc.yadif(p, c, nx, parity, True, False).reshape(-1).view(np.uint32)), (l, parity)
 
     # the other formats' round-trip scripts: same bytes back, and RGBA / output hashes equal to what the
     # reference's own kernels produced for the same pattern
