@@ -132,6 +132,51 @@ def test_compose_random_layers():
         bits_eq(hh.host(out, np.uint32), want, "compose %d: %dx%d n=%d il=%d" % (k, ow, oh, n, il))
 
 
+def test_compose_buffer_addressed_taps():
+    """The compositor's buffer-addressed sampler (out_w % 192 == 0): border taps answered by the addressing hardware,
+    row taps hoisted for unrotated placements, one shared placement for all layers, 1:1 layers mixed in - against the
+    oracle chain, including placements that put most or all taps outside the source."""
+    import hip_harness as hh
+    from phaneron_amd import capi
+    r = rng_for("compose taps")
+    hh.ctx().set_option("lds_lut", True)
+    wcm, wlut = hh.ColourParams.writer("2020")
+    extreme = [dict(scale_x=0.02, scale_y=0.02), dict(scale_x=40.0, scale_y=40.0), dict(offset_x=3.0, offset_y=-2.5),
+               dict(scale_x=1e-6, scale_y=1e6), dict(flip_h=True, flip_v=True, scale_x=0.7, scale_y=1.3),
+               dict(rotate=0.25), dict(rotate=0.5, scale_x=2.0, scale_y=2.0), dict(offset_x=0.5, offset_y=0.5),
+               dict(scale_x=1.0, scale_y=1.0, offset_x=-1.0 / 384, offset_y=1.0 / 24)]
+    for k in range(14):
+        ow, oh = 192 * int(r.integers(1, 4)), int(r.integers(2, 24))
+        n = int(r.integers(1, 7))
+        il = int(r.choice([0, 1, 3]))
+        shared = k % 3 == 0 and n > 1          # all layers through ONE matrix buffer and one source size
+        specs = []
+        sw, sh = int(r.integers(2, 260)), int(r.integers(2, 90))
+        kw_shared = extreme[k % len(extreme)] if k % 2 else dict(scale_x=float(r.uniform(0.5, 2.5)), scale_y=float(r.uniform(0.5, 2.5)))
+        for l in range(n):
+            if shared:
+                specs.append((sw, sh, kw_shared))
+            elif r.integers(0, 4) == 0:
+                specs.append((ow, oh, None))
+            elif r.integers(0, 2) == 0:
+                specs.append((int(r.integers(1, 260)), int(r.integers(1, 90)), extreme[int(r.integers(0, len(extreme)))]))
+            else:                                  # unrotated: the hoisted-row path when every sampled layer is
+                specs.append((int(r.integers(2, 260)), int(r.integers(2, 90)),
+                              dict(scale_x=float(r.uniform(0.3, 3.0)), scale_y=float(r.uniform(0.3, 3.0)),
+                                   offset_x=float(r.uniform(-0.6, 0.6)), offset_y=float(r.uniform(-0.6, 0.6)))))
+        imgs = [frames.rgba_random(w, h, 8600 + 10 * k + i) for i, (w, h, _) in enumerate(specs)]
+        mats = [None if kw is None else capi.transform_matrix(ow, oh, **kw) for (_, _, kw) in specs]
+        one = hh.dev(mats[0]) if shared else None
+        dst0 = np.full(frames.v210_pitch_bytes(ow) * oh // 4, cases.POISON, np.uint32)
+        out = hh.dev(dst0)
+        layers = [(hh.dev(im), w, h, None if m is None else (one if shared else hh.dev(m))) for im, (w, h, _), m in zip(imgs, specs, mats)]
+        hh.ctx().compose_write_v210(layers, out, ow, oh, il, wcm, wlut)
+        xf = [im if m is None else orc.transform(im, m, ow, oh) for im, m in zip(imgs, mats)]
+        comb = xf[0] if len(xf) == 1 else orc.combine(xf)
+        want = orc.v210_write(comb, ow, oh, il, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"), out=dst0.copy())
+        bits_eq(hh.host(out, np.uint32), want, "compose taps %d: %dx%d n=%d il=%d shared=%s %r" % (k, ow, oh, n, il, shared, [s[2] for s in specs]))
+
+
 @pytest.mark.parametrize("fmt", ["yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"])
 def test_pack_formats_random_sizes(fmt):
     import torch
