@@ -184,15 +184,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libphaneron_hip has no CPU path")
+    # test hooks (tests/test_bench_gpu.py; never set by the driver): PH_BENCH_SHARE_GPU=1 lets several ranks share the
+    # one GPU of a test box (gloo process group: RCCL refuses two ranks on one device), PH_BENCH_FORCE_DIST=1 creates the
+    # RCCL process group even for a single rank, so that the N > 1 code path runs on one GPU.
+    share_gpu = os.environ.get("PH_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PH_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
+    reduce_device = torch.device("cpu") if share_gpu else device
 
     w, h, n = args.width, args.height, args.layers
     ctx = capi.Context(local_rank)
@@ -245,12 +258,12 @@ def main():
     for i in range(FIXED_WARMUP):  # clocks, caches and the allocator settle before the contract's own warm-up
         step(i)
     sync()
-    elapsed = multigpu.timed_steps(timed_step, args.steps, args.warmup, sync, dist, device)
+    elapsed = multigpu.timed_steps(timed_step, args.steps, args.warmup, sync, dist, reduce_device)
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # average launch duration on the kernel's stream
     # frames every rank really composited in the timed region, summed over ranks (not assumed equal)
     frames_done = C * args.steps
     if dist is not None:
-        t = torch.tensor([frames_done], dtype=torch.int64, device=device)
+        t = torch.tensor([frames_done], dtype=torch.int64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         frames_done = int(t.item())
 

@@ -1,0 +1,65 @@
+"""GPU tests (-m gpu) of bench.py itself: the JSON contract of the default line, and the N > 1 code path (process
+group, barrier, max-over-ranks time, frames summed over ranks) exercised on the ONE GPU a test box has."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+pytestmark = pytest.mark.gpu
+
+
+def run(cmd, extra_env=None, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **(extra_env or {}))
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout   # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def check_line(line, n_gpus, steps, warmup):
+    assert line["unit"] == "frames/sec" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["n_gpus"] == n_gpus and line["steps"] == steps and line["warmup"] == warmup
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - n_gpus * 1e3 / line["ms_per_step"]) < 0.02 * line["value"]
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # the kernel's own time (HIP events on its stream) can never exceed the wall clock per step
+    assert rf["avg_launch_ms"] <= line["ms_per_step"] * 1.02
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / rf["avg_launch_ms"] / 1e6) < 0.01 * rf["achieved"]
+
+
+def test_default_line_as_the_driver_runs_it():
+    """python bench.py --gpus 1 --steps 20 --warmup 5 (the driver's command): roofline, secondary, cpu_baseline present"""
+    line = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2"])
+    check_line(line, 1, 20, 5)
+    assert line["roofline"]["valu"]["frac"] > 0.2
+    assert [s["config"][0] for s in line["secondary"]] == ["2", "3"]
+    for s in line["secondary"]:
+        assert 0 < s["roofline"]["frac"] < 1
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert line["value"] > 100 * cb["value"]
+
+
+def test_rank_path_under_torchrun_with_rccl_on_one_gpu():
+    """one rank started the way the driver starts N: the RCCL process group, barrier and all-reduce run for real"""
+    line = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29571", "bench.py", "--gpus", "1", "--steps", "30", "--warmup", "5", "--cpu-seconds", "0", "--no-secondary"],
+               {"PH_BENCH_FORCE_DIST": "1"})
+    check_line(line, 1, 30, 5)
+
+
+def test_two_ranks_sum_their_frames():
+    """two ranks on the one GPU (gloo): value is the whole job's rate, one line from rank 0, no cpu_baseline / secondary at N > 1"""
+    line = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29572", "bench.py", "--gpus", "2", "--steps", "30", "--warmup", "5", "--width", "1920", "--height", "1080"],
+               {"PH_BENCH_SHARE_GPU": "1"})
+    check_line(line, 2, 30, 5)
+    assert line["cpu_baseline"] is None and "secondary" not in line
+    assert line["config"]["channels"] == 2
