@@ -343,7 +343,11 @@ int ph_lut_unregister(ph_ctx *ctx, const void *device_lut_f32);
  * describe the logarithmic block layout chosen for the table (ph_lut.h) */
 int ph_lut_query(ph_ctx *ctx, const void *device_lut_f32, uint32_t *lds_bytes, uint32_t *index_bias,
                  uint32_t *blocks_per_octave_log2);
-/* options: "lds_lut" (default 1): 0 forces the global-gather kernels (A/B tests, profiles) */
+/* options: "lds_lut" (default 1): 0 forces the global-gather kernels (A/B tests, profiles);
+ *          "stream_images" (default 0): 1 stores f32 image outputs (ToRGBA, Yadif, Transform, Combine ...) past the
+ *          caches, for a caller that knows nothing on the device reads the image soon.  By default an image is
+ *          treated as what it is in a channel, an intermediate the next operator reads back; wire-format outputs
+ *          always stream. */
 int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value);
 
 /* ---- host colour maths (src/process/colourMaths.ts, run by Loader/Saver constructors

@@ -154,6 +154,19 @@ __device__ __forceinline__ void store_stream(float4 *p, const float4 v) {
   *p = v;
 #endif
 }
+// f32 IMAGE outputs.  An image is an intermediate: the next operator of the channel reads it back within a few
+// kernels, and for the frame sizes of the path (33 MB at 1080p, 133 MB at 2160p) a stream-past-the-caches store sends
+// that consumer to HBM.  Measured on whole chains (tools/config_bench.py, all routes): plain stores make config 2
+// 10 % and the reference-shaped config 3 batch 8 % faster, although each producer alone is slower (v210 read 2160p
+// 31 -> 45 us).  So images are stored plainly unless the context asks for streaming (ph_ctx_set_option
+// "stream_images", for a caller that knows nothing on the device reads the image soon); wire-format outputs, which
+// leave the device, always stream.  `nt` is a kernel argument (uniform): one scalar branch per store.
+__device__ __forceinline__ void store_image(float4 *p, const float4 v, uint32_t nt) {
+  if (nt)
+    __builtin_nontemporal_store(ph_f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<ph_f4v *>(p));
+  else
+    *p = v;
+}
 // Streaming loads for kernels that pull three or more full frames per output frame (combine_N with
 // N >= 3, transition_wipe): measured +4 % there, -4 % on the two-input kernels, so those stay plain.
 __device__ __forceinline__ float4 load_stream(const float4 *p) {

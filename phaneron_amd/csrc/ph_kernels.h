@@ -10,6 +10,10 @@ namespace ph {
 
 constexpr int kMaxLayers = 8;
 
+// 1 = f32 image outputs of the launches issued by this thread are streamed past the caches (ph_device.h store_image);
+// set from the context's "stream_images" option before every launch (ph_api.cpp set_device)
+extern thread_local uint32_t t_stream_images;
+
 struct FusedArgs {
   const void *layers[kMaxLayers];
   void *out;
@@ -46,7 +50,7 @@ struct DeintArgs {  // ph_kernels_deint.hip
   float4 *out0[kMaxLayers], *out1[kMaxLayers];                         // RGBA f32: yadif parity 0 / parity 1
   int n, skip;
   uint32_t width, height, quads_pitch;
-  uint32_t rows_per_strip, strips, col_blocks;  // filled in by the launcher
+  uint32_t rows_per_strip, strips, col_blocks, nt;  // filled in by the launcher
   const float *cm, *gm;
   LutView lut;
 };
@@ -70,6 +74,7 @@ struct CombineArgs {
   const void *layers[kMaxLayers];
   void *out;
   size_t npx;
+  uint32_t nt;  // filled in by the launcher
 };
 
 uint32_t v210_pitch_bytes(uint32_t width);

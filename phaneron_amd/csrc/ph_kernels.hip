@@ -15,6 +15,8 @@
 
 namespace ph {
 
+thread_local uint32_t t_stream_images = 0;
+
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(kBlock) void v210_read_kernel(const uint4 *__restri
                                                            float4 *__restrict__ out, uint32_t quads_per_line_used,
                                                            uint32_t quads_per_line_pitch, uint32_t total_quads,
                                                            const float *__restrict__ cm, const float *__restrict__ lut,
-                                                           const float *__restrict__ gm) {
+                                                           const float *__restrict__ gm, uint32_t nt) {
   __shared__ float4 tile[kBlock / kWave][kWave * 6];
   const ReadK k = load_read_k(cm, gm);
   const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void v210_read_kernel(const uint4 *__restri
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
     const size_t p = px0 + s * kWave + lane;
-    if (p < px_end) store_stream(out + p, tile[wave][s * kWave + lane]);
+    if (p < px_end) store_image(out + p, tile[wave][s * kWave + lane], nt);
   }
 }
 
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void fused_v210_combine_kernel(FusedArgs a)
 constexpr int kYadifRows = PH_YADIF_ROWS, kYadifCols = kBlock - 6;
 __global__ __launch_bounds__(kBlock) void yadif_rows_kernel(const float4 *__restrict__ prev, const float4 *__restrict__ cur,
                                                             const float4 *__restrict__ next, int w, int h, int parity,
-                                                            int tff, int skip, float4 *__restrict__ out) {
+                                                            int tff, int skip, float4 *__restrict__ out, uint32_t nt) {
   __shared__ float4 rows[2][2][kBlock];  // [step parity][row y-1 / row y+1][column]
   const int lane = threadIdx.x;
   const int xr = blockIdx.x * kYadifCols - 3 + lane, x = clampi(xr, 0, w - 1);  // CLAMP_TO_EDGE
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void yadif_rows_kernel(const float4 *__rest
         float4 cp;
         cp.x = parity == 0 ? C[1].x : C[3].x, cp.y = parity == 0 ? C[1].y : C[3].y;
         cp.z = parity == 0 ? C[1].z : C[3].z, cp.w = parity == 0 ? C[1].w : C[3].w;
-        store_stream(out + (size_t)yc * w + xr, cp);
+        store_image(out + (size_t)yc * w + xr, cp, nt);
       }
       if (yi < h) {
         float4 ra[7], rb[7];
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void yadif_rows_kernel(const float4 *__rest
                                   PH_C4(C[1], c), PH_C4(C[3], c), second ? e0 : c0, second ? e1 : c2, second ? e2 : c4,
                                   PH_C4(N1, c), PH_C4(N3, c), sp, skip);
         }
-        store_stream(out + (size_t)yi * w + xr, make_float4(res[0], res[1], res[2], C[2].w));  // :164 alpha from cur
+        store_image(out + (size_t)yi * w + xr, make_float4(res[0], res[1], res[2], C[2].w), nt);  // :164 alpha from cur
       }
     }
     // slide the windows down two rows
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void yadif_rows_kernel(const float4 *__rest
 template <int TFF>
 __global__ __launch_bounds__(kBlock) void yadif_pair_kernel(const float4 *__restrict__ prev, const float4 *__restrict__ cur,
                                                             const float4 *__restrict__ next, int w, int h, int skip,
-                                                            float4 *__restrict__ out0, float4 *__restrict__ out1) {
+                                                            float4 *__restrict__ out0, float4 *__restrict__ out1, uint32_t nt) {
   // component planes: the spatial predictor reads its 14 taps one component at a time (conflict-free ds_read_b32,
   // 14 live registers instead of 56 for whole float4 taps: 6 waves per SIMD instead of 4)
   __shared__ float rows[4][4][kBlock];  // [row & 3][component][column]
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void yadif_pair_kernel(const float4 *__rest
     stage(y + 1, C[3]);
     __syncthreads();
     if (emit) {
-      store_stream(out_copy + (size_t)y * w + xr, C[2]);  // yadifCl.ts:117-121
+      store_image(out_copy + (size_t)y * w + xr, C[2], nt);  // yadifCl.ts:117-121
       float res[4];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void yadif_pair_kernel(const float4 *__rest
                                 PH_C4(C[1], c), PH_C4(C[3], c), second ? e0 : c0, second ? e1 : c2, second ? e2 : c4,
                                 PH_C4(N[1], c), PH_C4(N[3], c), sp, skip);
       }
-      store_stream(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], C[2].w));  // :164 alpha from cur
+      store_image(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], C[2].w), nt);  // :164 alpha from cur
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) C[k] = C[k + 1], P[k] = P[k + 1], N[k] = N[k + 1];
@@ -349,26 +351,26 @@ __global__ __launch_bounds__(kBlock) void yadif_pair_kernel(const float4 *__rest
 // transform.ts:36-59.  2-D grid; 64x4 blocks keep a wave on one output row.
 __global__ __launch_bounds__(kBlock) void transform_kernel(const float4 *__restrict__ in, int iw, int ih,
                                                            const float *__restrict__ m, float4 *__restrict__ out,
-                                                           int ow, int oh) {
+                                                           int ow, int oh, uint32_t nt) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= ow || y >= oh) return;
   const float px = (float)x / (float)ow - 0.5f, py = (float)y / (float)oh - 0.5f;
   const float s = dot3(m[0], m[1], m[2], px, py, 1.0f) + 0.5f;
   const float t = dot3(m[3], m[4], m[5], px, py, 1.0f) + 0.5f;
-  store_stream(out + (size_t)y * ow + x, sample_linear(in, iw, ih, s, t));
+  store_image(out + (size_t)y * ow + x, sample_linear(in, iw, ih, s, t), nt);
 }
 
 // resize.ts:35-59
 __global__ __launch_bounds__(kBlock) void resize_kernel(const float4 *__restrict__ in, int iw, int ih, float scale,
                                                         float off_x, float off_y, const float *__restrict__ flip,
-                                                        float4 *__restrict__ out, int ow, int oh) {
+                                                        float4 *__restrict__ out, int ow, int oh, uint32_t nt) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= ow || y >= oh) return;
   const float cx = (-0.5f - off_x) / scale + 0.5f, cy = (-0.5f - off_y) / scale + 0.5f;
   const float ox = fma_rn(cx, flip[1], flip[0]), oy = fma_rn(cy, flip[3], flip[2]);
   const float mx = flip[1] / scale, my = flip[3] / scale;
   const float s = fma_rn((float)x / (float)ow, mx, ox), t = fma_rn((float)y / (float)oh, my, oy);
-  store_stream(out + (size_t)y * ow + x, sample_linear(in, iw, ih, s, t));
+  store_image(out + (size_t)y * ow + x, sample_linear(in, iw, ih, s, t), nt);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -389,38 +391,38 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(CombineArgs a) {
       acc.z = fma_rn(acc.z, k, t.z);
       acc.w = fma_rn(acc.w, 0.0f, t.w);
     }
-    store_stream(reinterpret_cast<float4 *>(a.out) + p, acc);
+    store_image(reinterpret_cast<float4 *>(a.out) + p, acc, a.nt);
   }
 }
 
 __global__ __launch_bounds__(kBlock) void dissolve_kernel(const float4 *__restrict__ in0, const float4 *__restrict__ in1,
-                                                          float mix, size_t npx, float4 *__restrict__ out) {
+                                                          float mix, size_t npx, float4 *__restrict__ out, uint32_t nt) {
   const float rmix = 1.0f - mix;
   for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock) {
     const float4 a = in0[p], b = in1[p];
-    store_stream(out + p, make_float4(fma_rn(a.x, mix, b.x * rmix), fma_rn(a.y, mix, b.y * rmix), fma_rn(a.z, mix, b.z * rmix),
-                         fma_rn(a.w, mix, b.w * rmix)));
+    store_image(out + p, make_float4(fma_rn(a.x, mix, b.x * rmix), fma_rn(a.y, mix, b.y * rmix), fma_rn(a.z, mix, b.z * rmix),
+                        fma_rn(a.w, mix, b.w * rmix)), nt);
   }
 }
 
 __global__ __launch_bounds__(kBlock) void twipe_kernel(const float4 *__restrict__ in0, const float4 *__restrict__ in1,
                                                        const float4 *__restrict__ mask, size_t npx,
-                                                       float4 *__restrict__ out) {
+                                                       float4 *__restrict__ out, uint32_t nt) {
   for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock) {
     const float4 a = load_stream(in0 + p), b = load_stream(in1 + p);
     const float m = load_stream(mask + p).x, rm = 1.0f - m;
-    store_stream(out + p, make_float4(fma_rn(b.x, m, a.x * rm), fma_rn(b.y, m, a.y * rm), fma_rn(b.z, m, a.z * rm),
-                         fma_rn(b.w, m, a.w * rm)));
+    store_image(out + p, make_float4(fma_rn(b.x, m, a.x * rm), fma_rn(b.y, m, a.y * rm), fma_rn(b.z, m, a.z * rm),
+                        fma_rn(b.w, m, a.w * rm)), nt);
   }
 }
 
 __global__ __launch_bounds__(kBlock) void wipe_kernel(const float4 *__restrict__ in0, const float4 *__restrict__ in1,
-                                                      float wipe, int w, int h, float4 *__restrict__ out) {
+                                                      float wipe, int w, int h, float4 *__restrict__ out, uint32_t nt) {
   const float edge = (float)w * wipe;  // wipe.ts:44
   const size_t npx = (size_t)w * h;
   for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock) {
     const int x = (int)(p % (size_t)w);
-    store_stream(out + p, ((float)x > edge) ? in1[p] : in0[p]);
+    store_image(out + p, ((float)x > edge) ? in1[p] : in0[p], nt);
   }
 }
 
@@ -441,7 +443,8 @@ hipError_t launch_v210_read(hipStream_t s, const void *in, void *out, uint32_t w
   if (width % 6 == 0) {
     const uint32_t used = width / 6, total = used * height;
     v210_read_kernel<<<div_up(total, kBlock), kBlock, 0, s>>>((const uint4 *)in, (float4 *)out, used, qpl, total,
-                                                             (const float *)cm, (const float *)lut, (const float *)gm);
+                                                             (const float *)cm, (const float *)lut, (const float *)gm,
+                                                             t_stream_images);
   } else {
     const uint32_t slots = width / 6 + 1;
     v210_read_tail_kernel<<<div_up((uint64_t)slots * height, kBlock), kBlock, 0, s>>>(
@@ -487,7 +490,7 @@ hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const 
                         int tff, int skip, void *out) {
   dim3 grid(div_up(w, kYadifCols), div_up(h, kYadifRows));
   yadif_rows_kernel<<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, parity,
-                                            tff, skip, (float4 *)out);
+                                            tff, skip, (float4 *)out, t_stream_images);
   return hipGetLastError();
 }
 
@@ -496,16 +499,16 @@ hipError_t launch_yadif_pair(hipStream_t s, const void *prev, const void *cur, c
   dim3 grid(div_up(w, kYadifCols), div_up(h, kYadifRows));
   if (tff)
     yadif_pair_kernel<1><<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, skip,
-                                                 (float4 *)out0, (float4 *)out1);
+                                                 (float4 *)out0, (float4 *)out1, t_stream_images);
   else
     yadif_pair_kernel<0><<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, skip,
-                                                 (float4 *)out0, (float4 *)out1);
+                                                 (float4 *)out0, (float4 *)out1, t_stream_images);
   return hipGetLastError();
 }
 
 hipError_t launch_transform(hipStream_t s, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh) {
   dim3 grid(div_up(ow, 64), div_up(oh, 4));
-  transform_kernel<<<grid, kBlock, 0, s>>>((const float4 *)in, iw, ih, (const float *)m9, (float4 *)out, ow, oh);
+  transform_kernel<<<grid, kBlock, 0, s>>>((const float4 *)in, iw, ih, (const float *)m9, (float4 *)out, ow, oh, t_stream_images);
   return hipGetLastError();
 }
 
@@ -513,11 +516,13 @@ hipError_t launch_resize(hipStream_t s, const void *in, int iw, int ih, float sc
                          const void *flip4, void *out, int ow, int oh) {
   dim3 grid(div_up(ow, 64), div_up(oh, 4));
   resize_kernel<<<grid, kBlock, 0, s>>>((const float4 *)in, iw, ih, scale, ox, oy, (const float *)flip4, (float4 *)out,
-                                        ow, oh);
+                                        ow, oh, t_stream_images);
   return hipGetLastError();
 }
 
-hipError_t launch_combine(hipStream_t s, int n, const CombineArgs &a) {
+hipError_t launch_combine(hipStream_t s, int n, const CombineArgs &args) {
+  CombineArgs a = args;
+  a.nt = t_stream_images;
   const uint32_t grid = stream_grid(a.npx);
   switch (n) {
     case 2: combine_kernel<2><<<grid, kBlock, 0, s>>>(a); break;
@@ -534,20 +539,20 @@ hipError_t launch_combine(hipStream_t s, int n, const CombineArgs &a) {
 
 hipError_t launch_dissolve(hipStream_t s, const void *in0, const void *in1, float mix, int w, int h, void *out) {
   const size_t npx = (size_t)w * h;
-  dissolve_kernel<<<stream_grid(npx), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, mix, npx, (float4 *)out);
+  dissolve_kernel<<<stream_grid(npx), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, mix, npx, (float4 *)out, t_stream_images);
   return hipGetLastError();
 }
 
 hipError_t launch_twipe(hipStream_t s, const void *in0, const void *in1, const void *mask, int w, int h, void *out) {
   const size_t npx = (size_t)w * h;
   twipe_kernel<<<stream_grid(npx), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, (const float4 *)mask, npx,
-                                                   (float4 *)out);
+                                                   (float4 *)out, t_stream_images);
   return hipGetLastError();
 }
 
 hipError_t launch_wipe(hipStream_t s, const void *in0, const void *in1, float wipe, int w, int h, void *out) {
   wipe_kernel<<<stream_grid((size_t)w * h), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, wipe, w, h,
-                                                           (float4 *)out);
+                                                           (float4 *)out, t_stream_images);
   return hipGetLastError();
 }
 

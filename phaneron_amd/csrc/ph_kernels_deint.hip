@@ -85,40 +85,54 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
     const LanePick pick = lane_pick((uint32_t)x);
     const int y0 = (int)(strip * a.rows_per_strip), y_end = (y0 + (int)a.rows_per_strip < h) ? y0 + (int)a.rows_per_strip : h;
     auto row = [&](const unsigned char *frame, int y) { return unpack_row_px<STD>(frame, a.quads_pitch * 16u, clampi(y, 0, h - 1), pick, k, lk); };
-    Rgb C[5], P[5], N[5];  // rows y - 2 .. y + 2
+    // rows y - 2 .. y + 2 of each frame live in a RING of five registers: the step with rotation R finds row y - 2 + i
+    // in slot (R + i) % 5 and refills slot R % 5 (row y - 2, no longer needed) with row y + 3 - no window shifts
+    // (36 v_mov per row otherwise).  Ten steps (lcm of the ring and of the even / odd row roles) make one loop body.
+    Rgb C[5], P[5], N[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) C[i] = row(cur, y0 - 2 + i), P[i] = row(prev, y0 - 2 + i), N[i] = row(next, y0 - 2 + i);
     // one row: interpolated into the output whose parity is (y & 1) ^ 1, copied into the other; SECOND
     // (yadifCl.ts:143, !(parity ^ tff)) is a compile-time constant of the row's evenness (as yadif_pair_kernel)
-    auto step = [&](int y, auto second_tag, float4 *__restrict__ out_interp, float4 *__restrict__ out_copy) {
-      constexpr bool second = decltype(second_tag)::value;
+    auto step = [&](int y, auto rot_tag) {
+      constexpr int R = decltype(rot_tag)::value;
+      constexpr bool even = (R & 1) == 0;                      // y0 is even and R counts rows from y0 (mod 10)
+      constexpr bool second = even ? (TFF != 0) : (TFF == 0);  // even row: parity-1 output, !(1 ^ tff); odd: !(0 ^ tff)
+      float4 *__restrict__ out_interp = even ? out1 : out0, *__restrict__ out_copy = even ? out0 : out1;
+#define PH_W(A, i) A[(R + (i)) % 5]
       float res[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float up = PH_RGB(C[1], c), dn = PH_RGB(C[3], c);
+        const float up = PH_RGB(PH_W(C, 1), c), dn = PH_RGB(PH_W(C, 3), c);
         const float sp = yadif_spatial(lane_tap(up, lane, -3), lane_tap(up, lane, -2), lane_tap(up, lane, -1), up,
                                        lane_tap(up, lane, 1), lane_tap(up, lane, 2), lane_tap(up, lane, 3),
                                        lane_tap(dn, lane, -3), lane_tap(dn, lane, -2), lane_tap(dn, lane, -1), dn,
                                        lane_tap(dn, lane, 1), lane_tap(dn, lane, 2), lane_tap(dn, lane, 3));
         // second field: s0 = cur, s1 = next; first field: s0 = prev, s1 = cur (yadifCl.ts:146-151)
-        const float c0 = PH_RGB(C[0], c), c2 = PH_RGB(C[2], c), c4 = PH_RGB(C[4], c);
-        const float e0 = second ? PH_RGB(N[0], c) : PH_RGB(P[0], c), e1 = second ? PH_RGB(N[2], c) : PH_RGB(P[2], c),
-                    e2 = second ? PH_RGB(N[4], c) : PH_RGB(P[4], c);
-        res[c] = yadif_temporal(PH_RGB(P[1], c), PH_RGB(P[3], c), second ? c0 : e0, second ? c2 : e1, second ? c4 : e2,
-                                PH_RGB(C[1], c), PH_RGB(C[3], c), second ? e0 : c0, second ? e1 : c2, second ? e2 : c4,
-                                PH_RGB(N[1], c), PH_RGB(N[3], c), sp, a.skip);
+        const float c0 = PH_RGB(PH_W(C, 0), c), c2 = PH_RGB(PH_W(C, 2), c), c4 = PH_RGB(PH_W(C, 4), c);
+        const float e0 = second ? PH_RGB(PH_W(N, 0), c) : PH_RGB(PH_W(P, 0), c), e1 = second ? PH_RGB(PH_W(N, 2), c) : PH_RGB(PH_W(P, 2), c),
+                    e2 = second ? PH_RGB(PH_W(N, 4), c) : PH_RGB(PH_W(P, 4), c);
+        res[c] = yadif_temporal(PH_RGB(PH_W(P, 1), c), PH_RGB(PH_W(P, 3), c), second ? c0 : e0, second ? c2 : e1, second ? c4 : e2,
+                                PH_RGB(PH_W(C, 1), c), PH_RGB(PH_W(C, 3), c), second ? e0 : c0, second ? e1 : c2, second ? e2 : c4,
+                                PH_RGB(PH_W(N, 1), c), PH_RGB(PH_W(N, 3), c), sp, a.skip);
       }
       if (emit) {
-        store_stream(out_copy + (size_t)y * w + xr, make_float4(C[2].r, C[2].g, C[2].b, 1.0f));      // yadifCl.ts:117-121
-        store_stream(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], 1.0f));    // :164 alpha from cur
+        store_image(out_copy + (size_t)y * w + xr, make_float4(PH_W(C, 2).r, PH_W(C, 2).g, PH_W(C, 2).b, 1.0f), a.nt);  // yadifCl.ts:117-121
+        store_image(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], 1.0f), a.nt);                  // :164 alpha from cur
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) C[i] = C[i + 1], P[i] = P[i + 1], N[i] = N[i + 1];
-      C[4] = row(cur, y + 3), P[4] = row(prev, y + 3), N[4] = row(next, y + 3);
+      PH_W(C, 0) = row(cur, y + 3), PH_W(P, 0) = row(prev, y + 3), PH_W(N, 0) = row(next, y + 3);
+#undef PH_W
     };
-    for (int y = y0; y < y_end; y += 2) {  // y0 is even
-      step(y, std::integral_constant<bool, TFF != 0>{}, out1, out0);
-      if (y + 1 < y_end) step(y + 1, std::integral_constant<bool, TFF == 0>{}, out0, out1);
+    for (int y = y0; y < y_end; y += 10) {  // y0 is even
+      step(y, std::integral_constant<int, 0>{});
+      if (y + 1 < y_end) step(y + 1, std::integral_constant<int, 1>{});
+      if (y + 2 < y_end) step(y + 2, std::integral_constant<int, 2>{});
+      if (y + 3 < y_end) step(y + 3, std::integral_constant<int, 3>{});
+      if (y + 4 < y_end) step(y + 4, std::integral_constant<int, 4>{});
+      if (y + 5 < y_end) step(y + 5, std::integral_constant<int, 5>{});
+      if (y + 6 < y_end) step(y + 6, std::integral_constant<int, 6>{});
+      if (y + 7 < y_end) step(y + 7, std::integral_constant<int, 7>{});
+      if (y + 8 < y_end) step(y + 8, std::integral_constant<int, 8>{});
+      if (y + 9 < y_end) step(y + 9, std::integral_constant<int, 9>{});
     }
   }
 }
@@ -147,6 +161,7 @@ hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t 
     const uint64_t cost = rounds * (r + 4);
     if (cost < best_cost) best_cost = cost, best_r = r;
   }
+  a.nt = t_stream_images;
   a.rows_per_strip = best_r;
   a.strips = (a.height + best_r - 1) / best_r;
   const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;

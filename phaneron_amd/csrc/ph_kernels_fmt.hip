@@ -34,6 +34,7 @@ struct FmtReadArgs {
   float4 *out;
   uint32_t width, lines, pitch;  // pitch in luma samples (RGBA: pixels)
   const float *cm, *gm;
+  uint32_t nt;  // stream the image output past the caches (ph_device.h store_image)
 };
 
 // FMT is a template parameter: plane layout and sample width are compile-time
@@ -75,7 +76,7 @@ __device__ __forceinline__ void fmt_read_body(const FmtReadArgs &a, const LUT &l
       }
       o = yuv_to_rgba(y, u, v, k, lut);
     }
-    store_stream(a.out + p, o);
+    store_image(a.out + p, o, a.nt);
   }
 }
 
@@ -270,7 +271,7 @@ hipError_t launch_pack_read(hipStream_t s, int fmt, const void *const planes[3],
                             uint32_t num_cus) {
   const bool v420 = (fmt == F_YUV420P || fmt == F_NV12);
   FmtReadArgs a{planes[0], planes[1], planes[2], (float4 *)out, width, v420 ? (height / 2) * 2 : height,
-                pack_pitch(fmt, width), (const float *)cm, (const float *)gm};
+                pack_pitch(fmt, width), (const float *)cm, (const float *)gm, t_stream_images};
   switch (fmt) {
     case F_YUV422P10: return launch_read_fmt<F_YUV422P10>(s, a, (const float *)table, lv, num_cus);
     case F_YUV422P8: return launch_read_fmt<F_YUV422P8>(s, a, (const float *)table, lv, num_cus);

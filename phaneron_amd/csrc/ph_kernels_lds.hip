@@ -360,7 +360,7 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
 __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_kernel(const uint4 *__restrict__ in, float4 *__restrict__ out,
                                                                    uint32_t width, uint32_t quads_per_line_pitch,
                                                                    uint32_t total_px, const float *__restrict__ cm,
-                                                                   const float *__restrict__ gm, LutView lut) {
+                                                                   const float *__restrict__ gm, LutView lut, uint32_t nt) {
   const ReadK k = load_read_k(cm, gm);
   const LutK lk = make_lut_k(lut);
   lds_lut_load(lut);
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_kernel(const uint4 *_
     const float yf = (float)((wy >> sy) & 0x3ff);
     const float cbf = (float)((wcb >> (10u * pr)) & 0x3ff);
     const float crf = (float)((wcr >> scr) & 0x3ff);
-    store_stream(out + p, read_px_lds(yf, cbf, crf, k, lk));
+    store_image(out + p, read_px_lds(yf, cbf, crf, k, lk), nt);
   }
 }
 
@@ -394,7 +394,7 @@ struct ReadBatchArgs {
 };
 __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_batch_kernel(ReadBatchArgs a, uint32_t width, uint32_t quads_per_line_pitch,
                                                                          uint32_t total_px, const float *__restrict__ cm,
-                                                                         const float *__restrict__ gm, LutView lut) {
+                                                                         const float *__restrict__ gm, LutView lut, uint32_t nt) {
   const ReadK k = load_read_k(cm, gm);
   const LutK lk = make_lut_k(lut);
   lds_lut_load(lut);
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_batch_kernel(ReadBatc
     const float yf = (float)((wy >> sy) & 0x3ff);
     const float cbf = (float)((wcb >> (10u * pr)) & 0x3ff);
     const float crf = (float)((wcr >> scr) & 0x3ff);
-    store_stream(out + p, read_px_lds(yf, cbf, crf, k, lk));
+    store_image(out + p, read_px_lds(yf, cbf, crf, k, lk), nt);
   }
 }
 
@@ -639,11 +639,30 @@ __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const fl
                                                   const __amdgpu_buffer_rsrc_t (&img)[N], const WriteK &wk, const LutK &lk,
                                                   uint16_t *ys, uint16_t *us, uint16_t *vs, uint32_t wave, uint32_t lane) {
   const uint32_t qpl = a.out_w / 6;
-  const uint32_t total_px = a.out_w * a.lines;            // out_w % 192 == 0: a chunk never leaves its row
-  const uint32_t waves_total = gridDim.x * (kLdsBlock / 64);
+  const uint32_t chunks = a.out_w * a.lines / kComposeChunk;  // out_w % 192 == 0: a chunk never leaves its row
   const float fow = (float)(int)a.out_w, foh = (float)(int)a.out_h;
-  for (uint32_t base = (blockIdx.x * (kLdsBlock / 64) + wave) * kComposeChunk; base < total_px;
-       base += waves_total * kComposeChunk) {
+  // XCD-aware order.  Neighbouring output rows sample the same source rows, and each XCD has its own L2: with chunks
+  // dealt out to workgroups in plain order, the 256 workgroups of a moment cover ~200 consecutive rows and, workgroups
+  // going to XCDs round-robin, every XCD pulls every source row of that window through its own L2 - eight fills per
+  // source row from the Infinity Cache.  Here the frame is cut into groups of 8 output rows and group g belongs to
+  // XCD g % 8 (workgroups with blockIdx % 8 == x): a source row is filled by one XCD, two at a group boundary, and the
+  // interleave keeps the XCDs' loads equal when layers cover only part of the frame (picture-in-picture).
+  const uint32_t cpg = 8u * (a.out_w / kComposeChunk);  // chunks per group
+  uint32_t v_begin = blockIdx.x * (kLdsBlock / 64) + wave, v_end = chunks, v_step = gridDim.x * (kLdsBlock / 64), xcd = 0;
+  const bool banded = (gridDim.x & 7u) == 0;
+  if (banded) {
+    xcd = blockIdx.x & 7u;
+    const uint32_t groups = (chunks + cpg - 1u) / cpg, mine = (groups + 7u - xcd) / 8u;  // groups xcd, xcd + 8, ...
+    v_begin = (blockIdx.x >> 3) * (kLdsBlock / 64) + wave, v_end = mine * cpg, v_step = (gridDim.x >> 3) * (kLdsBlock / 64);
+  }
+  for (uint32_t v = v_begin; v < v_end; v += v_step) {
+    uint32_t chunk = v;
+    if (banded) {
+      const uint32_t gi = v / cpg;
+      chunk = (gi * 8u + xcd) * cpg + (v - gi * cpg);
+      if (chunk >= chunks) continue;  // the frame's last group may be short
+    }
+    const uint32_t base = chunk * kComposeChunk;
     const uint32_t li = base / a.out_w, x_first = base - li * a.out_w;
     const uint32_t line = a.first_line + li * a.line_step;
     const float py = (float)(int)line / foh - 0.5f;
@@ -922,7 +941,7 @@ hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32
   const uint32_t want = (total + kLdsBlock - 1) / kLdsBlock;
   v210_read_lds_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, lut.bytes, s>>>(
       (const uint4 *)in, (float4 *)out, width, v210_pitch_bytes(width) / 16, total, (const float *)cm, (const float *)gm,
-      lut);
+      lut, t_stream_images);
   return hipGetLastError();
 }
 
@@ -937,7 +956,8 @@ hipError_t launch_v210_read_lds_batch(hipStream_t s, int n, const void *const *i
   uint32_t per = num_cus / (uint32_t)n ? num_cus / (uint32_t)n : 1;
   a.wg_per_frame = want < per ? want : per;
   v210_read_lds_batch_kernel<<<a.wg_per_frame * n, kLdsBlock, lut.bytes, s>>>(a, width, v210_pitch_bytes(width) / 16, total,
-                                                                              (const float *)cm, (const float *)gm, lut);
+                                                                              (const float *)cm, (const float *)gm, lut,
+                                                                              t_stream_images);
   return hipGetLastError();
 }
 

@@ -61,6 +61,7 @@ rm -rf $ROOT/gpurun_out/pmc_sq/*/  # keep the summary only
 
 # 5. per-kernel, per-config, per-instruction and staging measurements
 python $ROOT/tools/kernel_bench.py 2>/dev/null | grep '^{' > $OUT/${TAG}_kernel_bench.jsonl
+PH_BENCH_CACHED_IMAGES=1 python $ROOT/tools/kernel_bench.py 2>/dev/null | grep '^{' | grep -v '"pack_\|fused_v210\|compose_write\|v210_write' > $OUT/${TAG}_kernel_bench_cached_images.jsonl
 python $ROOT/tools/config_bench.py 2>/dev/null | grep '^{' > $OUT/${TAG}_config_bench.jsonl
 $ROOT/tools/opbench3 > $OUT/${TAG}_opbench3.jsonl 2>/dev/null
 $ROOT/tools/opbench4 > $OUT/${TAG}_opbench4.jsonl 2>/dev/null
