@@ -602,6 +602,9 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_px_kernel(Compos
 //     inset) skips its loads and its blend: its sample is the border value 0;
 //   * 1:1 layers and sampled layers take uniform branches instead of selects.
 // ------------------------------------------------------------------------------------------
+#ifndef PH_COMPOSE_GROUP_ROWS
+#define PH_COMPOSE_GROUP_ROWS 16
+#endif
 typedef uint32_t ph_u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kTapOutside = 0x80000000u;
 
@@ -644,10 +647,10 @@ __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const fl
   // XCD-aware order.  Neighbouring output rows sample the same source rows, and each XCD has its own L2: with chunks
   // dealt out to workgroups in plain order, the 256 workgroups of a moment cover ~200 consecutive rows and, workgroups
   // going to XCDs round-robin, every XCD pulls every source row of that window through its own L2 - eight fills per
-  // source row from the Infinity Cache.  Here the frame is cut into groups of 8 output rows and group g belongs to
+  // source row from the Infinity Cache.  Here the frame is cut into groups of 16 output rows and group g belongs to
   // XCD g % 8 (workgroups with blockIdx % 8 == x): a source row is filled by one XCD, two at a group boundary, and the
   // interleave keeps the XCDs' loads equal when layers cover only part of the frame (picture-in-picture).
-  const uint32_t cpg = 8u * (a.out_w / kComposeChunk);  // chunks per group
+  const uint32_t cpg = (uint32_t)PH_COMPOSE_GROUP_ROWS * (a.out_w / kComposeChunk);  // chunks per group
   uint32_t v_begin = blockIdx.x * (kLdsBlock / 64) + wave, v_end = chunks, v_step = gridDim.x * (kLdsBlock / 64), xcd = 0;
   const bool banded = (gridDim.x & 7u) == 0;
   if (banded) {

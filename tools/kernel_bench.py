@@ -29,8 +29,8 @@ def main():
         ctx.set_option("lds_lut", 0)
     # a kernel timed alone has no consumer on the device: image outputs streamed past the caches, as a caller that
     # knows this would ask for (PH_BENCH_CACHED_IMAGES=1 times the library's default, which assumes a consumer follows)
-    stream = 0 if os.environ.get("PH_BENCH_CACHED_IMAGES") else 1
-    ctx.set_option("stream_images", stream)
+    streamed = 0 if os.environ.get("PH_BENCH_CACHED_IMAGES") else 1
+    ctx.set_option("stream_images", streamed)
     words = capi.v210_pitch_bytes(w) * h // 4
     R = 6  # ring to defeat the 256 MiB Infinity Cache
     v = [torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device="cuda") & 0x3FFFFFFF for _ in range(R)]
@@ -57,7 +57,7 @@ def main():
         ctx.wait()
         ms = e0.elapsed_time(e1) / reps
         print(json.dumps({"kernel": name, "ms": round(ms, 4), "algorithmic_MB": round(bytes_ / 1e6, 1),
-                          "GBps": round(bytes_ / ms / 1e6, 1), "image_stores": "streamed" if stream else "cached"}), flush=True)
+                          "GBps": round(bytes_ / ms / 1e6, 1), "image_stores": "streamed" if streamed else "cached"}), flush=True)
 
     timeit("v210_read 2160p", lambda i: ctx.v210_read(v[i % R], out_img[i % 2], w, h, *rd), vb + ib)
     timeit("v210_write 2160p", lambda i: ctx.v210_write(img[i % R], out_v[i % 2], w, h, 0, *wr), vb + ib)
