@@ -49,16 +49,21 @@ __device__ __forceinline__ LanePick lane_pick(uint32_t x) {
   p.scr = pr == 0 ? 20u : pr == 1 ? 0u : 10u;
   return p;
 }
-template <bool STD>
-__device__ __forceinline__ Rgb unpack_row_px(const unsigned char *__restrict__ frame, uint32_t pitch_bytes, int line, const LanePick &p,
-                                             const ReadK &k, const LutK &lk) {
+// the three words of the lane's pixel, as loaded; unpacking them is a separate step so that the loads of the next
+// row can be issued BEFORE the filter of the current one and consumed after it (a frame's rows come from HBM)
+struct RawPx {
+  uint32_t wy, wcb, wcr;
+};
+__device__ __forceinline__ RawPx load_row_px(const unsigned char *__restrict__ frame, uint32_t pitch_bytes, int line, const LanePick &p) {
   const unsigned char *row = frame + (size_t)line * pitch_bytes;  // uniform
-  const uint32_t wy = *reinterpret_cast<const uint32_t *>(row + p.off_y);
-  const uint32_t wcb = *reinterpret_cast<const uint32_t *>(row + p.off_cb);
-  const uint32_t wcr = *reinterpret_cast<const uint32_t *>(row + p.off_cr);
-  const float yf = (float)((wy >> p.sy) & 0x3ff);
-  const float cbf = (float)((wcb >> p.scb) & 0x3ff);
-  const float crf = (float)((wcr >> p.scr) & 0x3ff);
+  return RawPx{*reinterpret_cast<const uint32_t *>(row + p.off_y), *reinterpret_cast<const uint32_t *>(row + p.off_cb),
+               *reinterpret_cast<const uint32_t *>(row + p.off_cr)};
+}
+template <bool STD>
+__device__ __forceinline__ Rgb unpack_px(const RawPx &r, const LanePick &p, const ReadK &k, const LutK &lk) {
+  const float yf = (float)((r.wy >> p.sy) & 0x3ff);
+  const float cbf = (float)((r.wcb >> p.scb) & 0x3ff);
+  const float crf = (float)((r.wcr >> p.scr) & 0x3ff);
   const float4 v = read_px_lds<STD>(yf, cbf, crf, k, lk);
   return Rgb{v.x, v.y, v.z};
 }
@@ -84,7 +89,8 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
     const bool emit = lane >= 3 && lane < 64 - 3 && xr < w;
     const LanePick pick = lane_pick((uint32_t)x);
     const int y0 = (int)(strip * a.rows_per_strip), y_end = (y0 + (int)a.rows_per_strip < h) ? y0 + (int)a.rows_per_strip : h;
-    auto row = [&](const unsigned char *frame, int y) { return unpack_row_px<STD>(frame, a.quads_pitch * 16u, clampi(y, 0, h - 1), pick, k, lk); };
+    auto raw = [&](const unsigned char *frame, int y) { return load_row_px(frame, a.quads_pitch * 16u, clampi(y, 0, h - 1), pick); };
+    auto row = [&](const unsigned char *frame, int y) { return unpack_px<STD>(raw(frame, y), pick, k, lk); };
     // rows y - 2 .. y + 2 of each frame live in a RING of five registers: the step with rotation R finds row y - 2 + i
     // in slot (R + i) % 5 and refills slot R % 5 (row y - 2, no longer needed) with row y + 3 - no window shifts
     // (36 v_mov per row otherwise).  Ten steps (lcm of the ring and of the even / odd row roles) make one loop body.
@@ -99,6 +105,7 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
       constexpr bool second = even ? (TFF != 0) : (TFF == 0);  // even row: parity-1 output, !(1 ^ tff); odd: !(0 ^ tff)
       float4 *__restrict__ out_interp = even ? out1 : out0, *__restrict__ out_copy = even ? out0 : out1;
 #define PH_W(A, i) A[(R + (i)) % 5]
+      const RawPx rc = raw(cur, y + 3), rp = raw(prev, y + 3), rn = raw(next, y + 3);  // in flight during the filter
       float res[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -119,7 +126,7 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
         store_image(out_copy + (size_t)y * w + xr, make_float4(PH_W(C, 2).r, PH_W(C, 2).g, PH_W(C, 2).b, 1.0f), a.nt);  // yadifCl.ts:117-121
         store_image(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], 1.0f), a.nt);                  // :164 alpha from cur
       }
-      PH_W(C, 0) = row(cur, y + 3), PH_W(P, 0) = row(prev, y + 3), PH_W(N, 0) = row(next, y + 3);
+      PH_W(C, 0) = unpack_px<STD>(rc, pick, k, lk), PH_W(P, 0) = unpack_px<STD>(rp, pick, k, lk), PH_W(N, 0) = unpack_px<STD>(rn, pick, k, lk);
 #undef PH_W
     };
     for (int y = y0; y < y_end; y += 10) {  // y0 is even
