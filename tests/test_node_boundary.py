@@ -360,3 +360,68 @@ def test_channel_compositor_on_gpu(tmp_path):
         want = orc.combine([a, b, black])
         got = np.fromfile(tmp_path / ("out_%d.bin" % f), np.float32)
         assert np.array_equal(got.view(np.uint32), want.reshape(-1).view(np.uint32)), f
+
+
+def amcp_noise(nbytes, seed, k):
+    """node/amcp.js noiseFrame, restated: a 32-bit LCG stream, three 10-bit legal-range fields per word"""
+    def imul(a, b):
+        return (a * b) & 0xFFFFFFFF
+    s = (imul(seed, 0x9E3779B1) ^ imul(k + 1, 0x85EBCA6B)) & 0xFFFFFFFF
+    out = np.empty(nbytes // 4, np.uint32)
+    for i in range(out.size):
+        w = 0
+        for f in range(3):
+            s = (imul(s, 1664525) + 1013904223) & 0xFFFFFFFF
+            w |= (64 + ((s >> 8) % 877)) << (10 * f)
+        out[i] = w
+    return out
+
+
+@needs_node
+@pytest.mark.gpu
+def test_control_plane_smoke_on_gpu(tmp_path):
+    """AMCP command lines (PLAY / LOADBG ... MIX / MIXER FILL / ROTATION / STOP / CLEAR) drive a channel of
+    synthetic v210 sources on the real addon; every output frame equals the oracle chain read -> place -> dissolve ->
+    combine -> write for the state the commands left, responses have the server's shape, nothing leaks."""
+    import frames
+    orc = orc_mod()
+    w, h = 192, 16
+    script = ["PLAY 1-10 NOISE:1", "PLAY 1-20 NOISE:2", "MIXER 1-20 FILL 0.25 0.25 0.5 0.5", dict(tick=2),
+              "LOADBG 1-20 NOISE:3 MIX 4", "PLAY 1-20", dict(tick=5), "MIXER 1-10 ROTATION 15", dict(tick=1),
+              "STOP 1-10", dict(tick=1), "CLEAR 1", dict(tick=1),
+              "SWAP 1-10 1-20", "PLAY 9-1 NOISE:1", "PLAY 1-30 NOFILE", "MIXER 1-10 FILL 1 2"]
+    (tmp_path / "job.json").write_text(json.dumps(dict(width=w, height=h, readSpec="709", writeSpec="2020", script=script)))
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "amcp_run.js"), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads((tmp_path / "result.json").read_text())
+    assert res["responses"] == ["202 PLAY OK", "202 PLAY OK", "202 MIXER OK", "202 LOADBG OK", "202 PLAY OK", "202 MIXER OK",
+                                "202 STOP OK", "202 CLEAR OK", "400 ERROR\r\nSWAP 1-10 1-20 NOT IMPLEMENTED", "404 PLAY ERROR",
+                                "404 PLAY ERROR", "400 ERROR\r\nMIXER 1-10 FILL 1 2 NOT IMPLEMENTED"]
+    assert res["frames"] == 10 and res["leaked"] == 0
+
+    nbytes = frames.v210_pitch_bytes(w) * h
+    rd = (orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
+    wr = (orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    src = lambda seed, k: orc.v210_read(amcp_noise(nbytes, seed, k), w, h, *rd)
+    place = lambda anchor=(0, 0), rot=0, fill=(0, 0, 1, 1): mixer_matrix(w, h, dict(anchor=dict(x=anchor[0], y=anchor[1]), rotation=rot,
+                                                                             fill=dict(xOffset=fill[0], yOffset=fill[1], xScale=fill[2], yScale=fill[3])))
+    full, pip, rot = place(), place(fill=(0.25, 0.25, 0.5, 0.5)), place(rot=15)
+    black = np.zeros((h, w, 4), np.float32)
+    for f in range(10):
+        if f < 2:
+            img = orc.combine([orc.transform(src(1, f), full, w, h), orc.transform(src(2, f), pip, w, h)])
+        elif f < 6:   # NOISE:2 keeps playing under a 4-frame dissolve into NOISE:3 (transitioner.ts:170)
+            k = f - 2
+            top = orc.transition_dissolve(orc.transform(src(2, f), pip, w, h), orc.transform(src(3, k), pip, w, h), float(np.float32(1.0 - k / 3)))
+            img = orc.combine([orc.transform(src(1, f), full, w, h), top])
+        elif f == 6:
+            img = orc.combine([orc.transform(src(1, f), full, w, h), orc.transform(src(3, f - 2), pip, w, h)])
+        elif f == 7:
+            img = orc.combine([orc.transform(src(1, f), rot, w, h), orc.transform(src(3, f - 2), pip, w, h)])
+        elif f == 8:  # layer 10 stopped: it contributes transparent black (combiner.ts:211-254)
+            img = orc.combine([black, orc.transform(src(3, f - 2), pip, w, h)])
+        else:         # cleared: black
+            img = black
+        want = orc.v210_write(img, w, h, 0, *wr)
+        got = np.fromfile(tmp_path / ("out_%d.bin" % f), np.uint32)
+        assert np.array_equal(got, want), f
