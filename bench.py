@@ -34,6 +34,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--ring", type=int, default=8, help="distinct frame sets cycled through (cache defeat)")
+    ap.add_argument("--content", choices=["noise", "picture"], default="noise",
+                    help="synthetic frames: independent uniform code values per sample (default; the worst case for the gamma "
+                         "tables in LDS: every lane of a wave hits a random bank) or picture-like (smooth gradients + a few "
+                         "code values of noise: neighbouring pixels look up neighbouring table entries)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--channels", type=int, default=1,
                     help="channels per GPU, composited in ONE batched launch per step (default 1: the headline)")
@@ -74,14 +78,28 @@ def launch_plan(args, argv):
     return {"mode": "spawn", "world": args.gpus, "ranks": list(range(args.gpus)), "cmd": cmd}
 
 
-def synth_v210(torch, width, height, seed, device):
-    """Legal-range random v210 frame generated on the GPU (Y 64..940, C 64..960)."""
+def synth_v210(torch, width, height, seed, device, content="noise"):
+    """Legal-range v210 frame generated on the GPU (Y 64..940, C 64..960): uniform noise, or a picture-like frame
+    (diagonal luma gradient, chroma drifting down the frame, +-6 code values of noise)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     groups = height * (width // 6)
-    y = torch.randint(64, 941, (groups, 6), generator=g, device=device, dtype=torch.int32)
-    cb = torch.randint(64, 961, (groups, 3), generator=g, device=device, dtype=torch.int32)
-    cr = torch.randint(64, 961, (groups, 3), generator=g, device=device, dtype=torch.int32)
+    if content == "picture":
+        gx = torch.arange(width // 6, device=device, dtype=torch.float32).repeat(height)          # group column
+        gy = torch.arange(height, device=device, dtype=torch.float32).repeat_interleave(width // 6)  # line
+        ph = float(seed % 97) / 97.0
+        px = gx[:, None] * 6 + torch.arange(6, device=device, dtype=torch.float32)[None, :]
+        luma = 64 + 876 * (0.5 + 0.5 * torch.sin(6.2832 * (px / width * 1.5 + gy[:, None] / height + ph)))
+        chb = 512 + 380 * torch.sin(6.2832 * (gy / height * 0.7 + ph))[:, None].expand(groups, 3)
+        chr_ = 512 + 380 * torch.cos(6.2832 * (gx / (width // 6) * 0.9 + ph))[:, None].expand(groups, 3)
+        n = lambda k: torch.randint(-6, 7, (groups, k), generator=g, device=device, dtype=torch.int32)
+        y = (luma.to(torch.int32) + n(6)).clamp(64, 940)
+        cb = (chb.to(torch.int32) + n(3)).clamp(64, 960)
+        cr = (chr_.to(torch.int32) + n(3)).clamp(64, 960)
+    else:
+        y = torch.randint(64, 941, (groups, 6), generator=g, device=device, dtype=torch.int32)
+        cb = torch.randint(64, 961, (groups, 3), generator=g, device=device, dtype=torch.int32)
+        cr = torch.randint(64, 961, (groups, 3), generator=g, device=device, dtype=torch.int32)
     w = torch.empty((groups, 4), dtype=torch.int32, device=device)
     w[:, 0] = (cr[:, 0] << 20) | (y[:, 0] << 10) | cb[:, 0]
     w[:, 1] = (y[:, 2] << 20) | (cb[:, 1] << 10) | y[:, 1]
@@ -225,7 +243,7 @@ def main():
     C = max(1, args.channels)
     ring = []  # per slot: C channels' layer lists and outputs
     for r in range(args.ring):
-        ins = [[synth_v210(torch, w, h, 0x5EED0000 + 16 * ((rank * C + c) * 64 + r) + l, device) for l in range(n)]
+        ins = [[synth_v210(torch, w, h, 0x5EED0000 + 16 * ((rank * C + c) * 64 + r) + l, device, args.content) for l in range(n)]
                for c in range(C)]
         ring.append((ins, [torch.empty(frame_words, dtype=torch.int32, device=device) for _ in range(C)]))
     torch.cuda.synchronize()
@@ -283,7 +301,8 @@ def main():
                                    "combine_%d/CSC/pack -> 1 v210 frame%s"
                                    % ("headline" if C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS) else "variant", C,
                                       "" if C == 1 else "s", n, w, h, n, "" if C == 1 else " each, one batched launch per step"),
-                       "ring_frame_sets": args.ring, "channels": world * C, "realtime_target_fps": 50},
+                       "ring_frame_sets": args.ring, "channels": world * C, "realtime_target_fps": 50,
+                       "content": args.content},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(),
                          "traffic_source": "recorded: profiles/pmc_traffic.json, rocprofv3 FETCH_SIZE / WRITE_SIZE passes "
