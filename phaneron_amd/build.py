@@ -17,7 +17,11 @@ SOURCES = ["ph_kernels.hip", "ph_kernels_lds.hip", "ph_kernels_fmt.hip", "ph_ker
 HEADERS = ["ph_device.h", "ph_kernels.h", "ph_lut.h", "ph_lut_host.h", "ph_ldslut.h", "ph_program.h", "ph_yadif.h", os.path.join("..", "..", "include", "phaneron_hip.h")]
 # -ffp-contract=off: every fused multiply-add in the kernels is explicit (parity with the
 # reference's OpenCL arithmetic); no fast-math anywhere.
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
+# -fno-slp-vectorize: the SLP vectoriser pairs independent f32 operations into v_pk_add / v_pk_fma_f32.  On gfx950 a
+# packed f32 instruction occupies the issue slot as long as its two halves would (tools/opbench3: 4.2 cycles), and the
+# register PAIRS it needs cost v_mov shuffles and spills: the de-interlacing reader lost 16 % to it.
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result",
+          "-Wno-unused-value"]
 
 
 def hipcc():

@@ -13,10 +13,17 @@ class _TorchOrdered:
     """The library launches on its OWN streams; torch fills / copies / random generators run on
     torch's.  Nothing orders the two, so a `torch.zeros` output can be zeroed AFTER the kernel under
     test wrote it.  Every call made through this proxy first drains the device (the product does not
-    need this: its callers own their ordering, e.g. bench.py synchronises once before timing)."""
+    need this: its callers own their ordering, e.g. bench.py synchronises once before timing).
+
+    The launches are asynchronous, so the tensors handed to a call must outlive it: a temporary such as
+    `k.v210_read(hh.dev(frame), ...)` would otherwise go back to torch's caching allocator the moment the call returns
+    and be handed out - and overwritten - by the next `hh.dev()` while the kernel is still reading it (seen once as
+    a flaky 1080p chain test).  The proxy therefore holds on to the arguments of a call until the device has been
+    drained again."""
 
     def __init__(self, c):
         self._c = c
+        self._alive = []
 
     def __getattr__(self, name):
         attr = getattr(self._c, name)
@@ -25,6 +32,8 @@ class _TorchOrdered:
 
         def ordered(*args, **kw):
             torch.cuda.synchronize()
+            del self._alive[:]
+            self._alive.append((args, kw))
             return attr(*args, **kw)
         return ordered
 
