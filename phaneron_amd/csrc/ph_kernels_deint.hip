@@ -54,10 +54,12 @@ __device__ __forceinline__ LanePick lane_pick(uint32_t x) {
 struct RawPx {
   uint32_t wy, wcb, wcr;
 };
-__device__ __forceinline__ RawPx load_row_px(const unsigned char *__restrict__ frame, uint32_t pitch_bytes, int line, const LanePick &p) {
-  const unsigned char *row = frame + (size_t)line * pitch_bytes;  // uniform
-  return RawPx{*reinterpret_cast<const uint32_t *>(row + p.off_y), *reinterpret_cast<const uint32_t *>(row + p.off_cb),
-               *reinterpret_cast<const uint32_t *>(row + p.off_cr)};
+// buffer loads: the line's start travels as the scalar offset, the lane's word as the vector offset - no address arithmetic
+__device__ __forceinline__ RawPx load_row_px(__amdgpu_buffer_rsrc_t frame, uint32_t pitch_bytes, int line, const LanePick &p) {
+  const int row = (int)((uint32_t)line * pitch_bytes);  // uniform
+  return RawPx{(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(frame, (int)p.off_y, row, 0),
+               (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(frame, (int)p.off_cb, row, 0),
+               (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(frame, (int)p.off_cr, row, 0)};
 }
 template <bool STD>
 __device__ __forceinline__ Rgb unpack_px(const RawPx &r, const LanePick &p, const ReadK &k, const LutK &lk) {
@@ -81,16 +83,17 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
   const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;
   for (uint32_t t = blockIdx.x * (kLdsBlock / 64) + wave; t < tasks; t += gridDim.x * (kLdsBlock / 64)) {
     const uint32_t cb = t % a.col_blocks, rest = t / a.col_blocks, strip = rest % a.strips, l = rest / a.strips;
-    const unsigned char *__restrict__ prev = reinterpret_cast<const unsigned char *>(a.prev[l]);
-    const unsigned char *__restrict__ cur = reinterpret_cast<const unsigned char *>(a.cur[l]);
-    const unsigned char *__restrict__ next = reinterpret_cast<const unsigned char *>(a.next[l]);
+    const int frame_bytes = (int)(a.quads_pitch * 16u * a.height);
+    const __amdgpu_buffer_rsrc_t prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.prev[l]), 0, frame_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.cur[l]), 0, frame_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t next = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.next[l]), 0, frame_bytes, 0x00020000);
     float4 *__restrict__ out0 = a.out0[l], *__restrict__ out1 = a.out1[l];
     const int xr = (int)(cb * kDeintCols) - 3 + (int)lane, x = clampi(xr, 0, w - 1);  // CLAMP_TO_EDGE
     const bool emit = lane >= 3 && lane < 64 - 3 && xr < w;
     const LanePick pick = lane_pick((uint32_t)x);
     const int y0 = (int)(strip * a.rows_per_strip), y_end = (y0 + (int)a.rows_per_strip < h) ? y0 + (int)a.rows_per_strip : h;
-    auto raw = [&](const unsigned char *frame, int y) { return load_row_px(frame, a.quads_pitch * 16u, clampi(y, 0, h - 1), pick); };
-    auto row = [&](const unsigned char *frame, int y) { return unpack_px<STD>(raw(frame, y), pick, k, lk); };
+    auto raw = [&](__amdgpu_buffer_rsrc_t frame, int y) { return load_row_px(frame, a.quads_pitch * 16u, clampi(y, 0, h - 1), pick); };
+    auto row = [&](__amdgpu_buffer_rsrc_t frame, int y) { return unpack_px<STD>(raw(frame, y), pick, k, lk); };
     // rows y - 2 .. y + 2 of each frame live in a RING of five registers: the step with rotation R finds row y - 2 + i
     // in slot (R + i) % 5 and refills slot R % 5 (row y - 2, no longer needed) with row y + 3 - no window shifts
     // (36 v_mov per row otherwise).  Ten steps (lcm of the ring and of the even / odd row roles) make one loop body.
