@@ -328,7 +328,10 @@ def main():
             except Exception as e:  # the headline figure must not depend on the secondary workloads
                 line["secondary"] = [{"error": "%s: %s" % (type(e).__name__, e)}]
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+            except Exception as e:  # report rather than lose the line
+                line["cpu_baseline"] = {"value": None, "unit": "frames/sec", "cores": 0, "kind": "port", "sample": "failed: %s: %s" % (type(e).__name__, e)}
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
