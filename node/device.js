@@ -121,6 +121,17 @@ class Rig {
 			params: { prev, cur, next, parity: o.parity ? 1 : 0, tff: o.tff ? 1 : 0, skipSpatial: o.skipSpatial ? 1 : 0, output }
 		})
 	}
+	// ToRGBA of n v210 frames of one size and colour recipe in one launch: stage([planes...], [images...])
+	async unpackBatch(n, width, height, spec, workSpec) {
+		const c = await this.colourIn('v210', spec, workSpec)
+		const program = await this.program(`v210_read_batch_${n}`, 'batch', { globalWorkItems: [width, height] })
+		return (sources, images) => {
+			if (sources.length !== n || images.length !== n) throw new Error(`unpackBatch: ${n} frames expected`)
+			const params = { colMatrix: c.colMatrix, gammaLut: c.gammaLut, gamutMatrix: c.gamutMatrix }
+			sources.forEach((src, i) => { params[`l${i}In`] = src; params[`l${i}Out`] = images[i] })
+			return { name: `v210_read_batch_${n}`, program, params }
+		}
+	}
 	// both send_field outputs of a frame in one pass: out[0] / out[1] are what yadif writes with parity 0 / 1
 	async yadifPair(width, height) {
 		const program = await this.program('yadif_pair', 'yadif', { globalWorkItems: [width, height] })

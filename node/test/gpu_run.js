@@ -238,6 +238,22 @@ async function main() {
 		for (let l = 0; l < windows.length; ++l)
 			for (let p = 0; p < 2; ++p) { await rig.download(windows[l].out[p]); save(`deint_l${l}_p${p}.bin`, windows[l].out[p]) }
 		windows.forEach((wn) => [wn.prev, wn.cur, wn.next, ...wn.out].forEach((b) => b.release()))
+
+		// 'v210_read_batch_<n>': the three frames of layer 0's window unpacked in one launch
+		const batch = await rig.unpackBatch(3, d.width, d.height, d.readSpec, d.writeSpec)
+		const srcs = []
+		const imgs = []
+		for (const file of d.layers[0]) {
+			const b = (await rig.planes('v210', d.width, d.height))[0]
+			await rig.upload(b, load(file))
+			srcs.push(b)
+			imgs.push(await rig.image(d.width, d.height))
+		}
+		await rig.sync(ctx.queue.load)
+		await rig.run(batch(srcs, imgs))
+		await rig.sync()
+		for (let i = 0; i < 3; ++i) { await rig.download(imgs[i]); save(`batch_read_${i}.bin`, imgs[i]) }
+		;[...srcs, ...imgs].forEach((b) => b.release())
 	}
 
 	rig.close()

@@ -919,6 +919,28 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       refresh_buf_lut(ctx, c);
       return ph_v210_yadif_pair(ctx, queue, prog->n_layers, src, width, height, (int)tff, (int)skip, b->dptr, c->dptr, d->dptr);
     }
+    case K_V210_READ_BATCH: {  // l<i>In: v210 frames; l<i>Out: RGBA images; colMatrix / gammaLut / gamutMatrix: the Loader's
+      const uint32_t width = prog->global[0], height = prog->global[1];
+      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
+      const size_t vb = (size_t)ph_v210_pitch_bytes(width) * height, img = (size_t)width * height * 16;
+      const void *ins[ph::kMaxLayers];
+      void *outs[ph::kMaxLayers];
+      for (int i = 0; i < prog->n_layers; ++i) {
+        char nm[16];
+        ph_buf *x = nullptr;
+        snprintf(nm, sizeof nm, "l%dIn", i);
+        TRY(need_buf(args, n, nm, vb, &x));
+        ins[i] = x->dptr;
+        snprintf(nm, sizeof nm, "l%dOut", i);
+        TRY(need_buf(args, n, nm, img, &x));
+        outs[i] = x->dptr;
+      }
+      TRY(need_buf(args, n, "colMatrix", 48, &b));
+      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
+      TRY(need_buf(args, n, "gamutMatrix", 36, &d));
+      refresh_buf_lut(ctx, c);
+      return ph_v210_read_batch(ctx, queue, prog->n_layers, ins, outs, width, height, b->dptr, c->dptr, d->dptr);
+    }
     case K_TRANSFORM: {
       int iw, ih;
       TRY(need_buf(args, n, "input", 0, &a));

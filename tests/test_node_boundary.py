@@ -277,6 +277,10 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
             got = np.fromfile(tmp_path / ("deint_l%d_p%d.bin" % (l, parity)), np.float32)
             assert np.array_equal(got.view(np.uint32), orc.yadif(p, c, nx, parity, True, False).reshape(-1).view(np.uint32)), (l, parity)
 
+    for i, f in enumerate(deint_src[0]):   # the batched reader under its program name
+        got = np.fromfile(tmp_path / ("batch_read_%d.bin" % i), np.float32)
+        assert np.array_equal(got.view(np.uint32), orc.v210_read(f, 384, 22, *rd).reshape(-1).view(np.uint32)), i
+
     # the other formats' round-trip scripts: same bytes back, and RGBA / output hashes equal to what the
     # reference's own kernels produced for the same pattern
     kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json")))
