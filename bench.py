@@ -55,7 +55,10 @@ def parse():
 # instruction count per launch comes from the committed SQ_INSTS_VALU pass (profiles/): it is a property of the binary.
 VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2.0
 
-FIXED_WARMUP = 200  # untimed launches before --warmup is honoured: a 20-step run must still measure settled clocks
+# untimed launches before --warmup is honoured: a 20-step run must still measure settled clocks.  The chip needs
+# ~50 ms of load to settle: after 200 launches (11 ms) the next 20 still ran 9 % slow, after 1000 they run at the
+# steady 54.6 us (profiles/r02_bench_repeat.jsonl and DESIGN.md 5).
+FIXED_WARMUP = int(os.environ.get("PH_BENCH_FIXED_WARMUP", "1000"))
 
 
 def launch_plan(args, argv):
