@@ -310,6 +310,19 @@ int ph_compose_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers,
                           uint32_t out_width, uint32_t out_height, uint32_t interlace,
                           const void *wr_col_matrix12, const void *wr_gamma_lut);
 
+/* The same compositor with wipe transitions inside: layer i's placed image is mixed with wipes[i].incoming_rgba by
+ * the red channel of wipes[i].mask_rgba (transition.ts wipe, as the Transitioner runs it: transitioner.ts:165-176)
+ * before the combine - [transform] -> transition_wipe -> combine_N -> write of a channel in mid-wipe as one kernel,
+ * bit-identical to ph_transform + ph_transition_wipe + ph_combine + ph_v210_write.  Both images have the output
+ * size; an entry with two NULLs leaves its layer alone.  Needs out_width % 192 == 0 (PH_E_INVALID otherwise). */
+typedef struct ph_layer_wipe {
+  const void *incoming_rgba; /* device, float RGBA, output size: the source the wipe reveals */
+  const void *mask_rgba;     /* device, float RGBA, output size: mix factor in .x */
+} ph_layer_wipe;
+int ph_compose_wipe_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers, const ph_layer_wipe *wipes,
+                               void *out, uint32_t out_width, uint32_t out_height, uint32_t interlace,
+                               const void *wr_col_matrix12, const void *wr_gamma_lut);
+
 /* ---- fused field pipeline (no single reference equivalent): the per-field job batch of a de-interlacing,
  *      scaling channel - Yadif per layer (yadif.ts:115-145) -> transform per layer (producer/mixer.ts:209-223)
  *      -> combine_N (combiner.ts:219-254) -> v210 write (io.ts:152-164) - as ONE kernel: de-interlaced source

@@ -52,6 +52,10 @@ class PhLayer(C.Structure):
     _fields_ = [("rgba", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("matrix9", C.c_void_p)]
 
 
+class PhLayerWipe(C.Structure):
+    _fields_ = [("incoming_rgba", C.c_void_p), ("mask_rgba", C.c_void_p)]
+
+
 class PhDeintSource(C.Structure):
     _fields_ = [("prev", C.c_void_p), ("cur", C.c_void_p), ("next", C.c_void_p), ("out_parity0", C.c_void_p), ("out_parity1", C.c_void_p)]
 
@@ -145,6 +149,7 @@ def lib():
         "ph_pack_read": (ci, [vp, ci, ci, C.POINTER(vp), vp, cu, cu, vp, vp, vp]),
         "ph_pack_write": (ci, [vp, ci, ci, vp, C.POINTER(vp), cu, cu, cu, vp, vp]),
         "ph_compose_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), vp, cu, cu, cu, vp, vp]),
+        "ph_compose_wipe_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), C.POINTER(PhLayerWipe), vp, cu, cu, cu, vp, vp]),
         "ph_fused_field_v210": (ci, [vp, ci, ci, C.POINTER(PhFieldLayer), vp, cu, cu, vp, vp]),
         "ph_route_unique_id": (ci, [vp]),
         "ph_route_init": (ci, [vp, vp, ci, ci, C.POINTER(vp)]),
@@ -380,6 +385,20 @@ class Context:
             arr[i].matrix9 = _ptr(m).value if m is not None else None
         check(lib().ph_compose_write_v210(self.h, queue, len(layers), arr, _ptr(dst), out_w, out_h, interlace,
                                           _ptr(wr_cm), _ptr(wr_lut)), self.h)
+
+    def compose_wipe_write_v210(self, layers, wipes, dst, out_w, out_h, interlace, wr_cm, wr_lut, queue=QUEUE_PROCESS):
+        """layers as compose_write_v210; wipes: per layer None or (incoming rgba tensor, mask rgba tensor)"""
+        arr = (PhLayer * len(layers))()
+        for i, (t, w, h, m) in enumerate(layers):
+            arr[i].rgba, arr[i].width, arr[i].height = _ptr(t).value, w, h
+            arr[i].matrix9 = _ptr(m).value if m is not None else None
+        wp = (PhLayerWipe * len(layers))()
+        for i, wv in enumerate(wipes):
+            if wv is not None:
+                wp[i].incoming_rgba = _ptr(wv[0]).value if wv[0] is not None else None
+                wp[i].mask_rgba = _ptr(wv[1]).value if wv[1] is not None else None
+        check(lib().ph_compose_wipe_write_v210(self.h, queue, len(layers), arr, wp, _ptr(dst), out_w, out_h, interlace,
+                                               _ptr(wr_cm), _ptr(wr_lut)), self.h)
 
     def fused_field_v210(self, layers, dst, out_w, out_h, wr_cm, wr_lut, queue=QUEUE_PROCESS):
         """layers: list of dicts {prev, cur, next (tensors; prev / next None for a progressive source), width, height,

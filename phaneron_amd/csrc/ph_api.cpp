@@ -1217,8 +1217,22 @@ int ph_pack_write(ph_ctx *ctx, int queue, int format, const void *in, void *cons
                                   lds_view(ctx, lut), (uint32_t)ctx->props.multiProcessorCount));
 }
 
+static int compose_write(ph_ctx *ctx, int queue, int n, const ph_layer *layers, const ph_layer_wipe *wipes, void *out, uint32_t out_w,
+                         uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut);
+
 int ph_compose_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers, void *out, uint32_t out_w,
                           uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut) {
+  return compose_write(ctx, queue, n, layers, nullptr, out, out_w, out_h, interlace, wr_cm, wr_lut);
+}
+
+int ph_compose_wipe_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers, const ph_layer_wipe *wipes, void *out,
+                               uint32_t out_w, uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut) {
+  if (!wipes) return fail(PH_E_INVALID, "ph_compose_wipe_write_v210: NULL argument");
+  return compose_write(ctx, queue, n, layers, wipes, out, out_w, out_h, interlace, wr_cm, wr_lut);
+}
+
+static int compose_write(ph_ctx *ctx, int queue, int n, const ph_layer *layers, const ph_layer_wipe *wipes, void *out, uint32_t out_w,
+                         uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut) {
   if (!ctx || !layers || !out || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_compose_write_v210: NULL argument");
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_compose_write_v210: 1..%d layers", ph::kMaxLayers);
   if (!out_w || out_w % 48) return fail(PH_E_INVALID, "ph_compose_write_v210: width %u is not a multiple of 48; run the separate kernels", out_w);
@@ -1235,8 +1249,15 @@ int ph_compose_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers,
                   layers[i].width, layers[i].height);
     a.layers[i] = layers[i].rgba, a.matrix[i] = (const float *)layers[i].matrix9;
     a.lw[i] = layers[i].width, a.lh[i] = layers[i].height;
+    if (wipes && (wipes[i].incoming_rgba || wipes[i].mask_rgba)) {
+      if (!wipes[i].incoming_rgba || !wipes[i].mask_rgba)
+        return fail(PH_E_INVALID, "ph_compose_wipe_write_v210: layer %d needs both the incoming image and the mask", i);
+      a.wipe_with[i] = wipes[i].incoming_rgba, a.wipe_mask[i] = wipes[i].mask_rgba;
+    }
   }
   a.out = out, a.out_w = out_w, a.out_h = out_h;
+  if (wipes && !ph::compose_can_wipe(a))
+    return fail(PH_E_INVALID, "ph_compose_wipe_write_v210: needs out_width %% 192 == 0 and source images below 2 GiB; run the separate kernels");
   a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0;
   a.lines = interlace ? out_h / 2 : out_h;
   a.wr_cm = (const float *)wr_cm, a.wr = *wv;

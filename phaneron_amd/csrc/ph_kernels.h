@@ -37,6 +37,9 @@ struct FusedLdsArgs {
 struct ComposeArgs {
   const void *layers[kMaxLayers];
   const float *matrix[kMaxLayers];  // device 3x3 (transform) or NULL = the layer is used 1:1
+  // optional wipe transition on a layer (transition.ts wipe): placed layer -> mix with `wipe_with` by `wipe_mask`.x,
+  // both output-size RGBA images; NULL = none (ph_compose_wipe_write_v210)
+  const void *wipe_with[kMaxLayers], *wipe_mask[kMaxLayers];
   int lw[kMaxLayers], lh[kMaxLayers];
   int n;
   void *out;
@@ -102,6 +105,7 @@ hipError_t launch_pack_write(hipStream_t s, int fmt, const void *in, void *const
                              uint32_t height, uint32_t interlace, const void *cm, const void *table, const LutView *lv,
                              uint32_t num_cus);
 hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32_t num_cus);
+bool compose_can_wipe(const ComposeArgs &a);  // the buffer-addressed compositor serves this job (needed for wipe layers)
 uint32_t field_index_bytes(uint32_t out_w, uint32_t out_h);  // scratch the two-stage field pipeline needs (6 bytes per pixel)
 hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t num_cus);
 hipError_t launch_field_compose_v210(hipStream_t s, const FieldArgs &a, void *index_scratch, uint32_t num_cus);

@@ -637,7 +637,10 @@ __device__ __forceinline__ float4 as_float4(const ph_u32x4 v) {
 // MIXED: some layers are taken 1:1 (selects, no branches: the loads of all layers stay in flight together).
 // SHARED: every layer is sampled through the same matrix buffer at the same source size (full-frame layers of one
 // channel): tap offsets and weights are computed once per pixel, only the resource differs per layer.
-template <int N, bool MIXED, bool ALIGNED, bool SHARED = false>
+// WIPE: a layer may carry a wipe transition (transition.ts:58-77 as the Transitioner runs it): its placed pixel t
+// becomes fma(b, m, t * (1 - m)) per component, b = the incoming source's pixel, m = the mask's red - the transform
+// -> transition_wipe -> combine chain of a channel in the middle of a wipe, without the two frames in between.
+template <int N, bool MIXED, bool ALIGNED, bool SHARED = false, bool WIPE = false>
 __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const float (&mm)[N][6], const bool (&direct)[N],
                                                   const __amdgpu_buffer_rsrc_t (&img)[N], const WriteK &wk, const LutK &lk,
                                                   uint16_t *ys, uint16_t *us, uint16_t *vs, uint32_t wave, uint32_t lane) {
@@ -683,6 +686,16 @@ __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const fl
       const uint32_t own = (line * a.out_w + x) * 16u;  // a 1:1 layer's texel
       ph_u32x4 tap[N][4];
       float wa[N], wb[N];
+      float4 wipe_b[N];
+      float wipe_m[N];
+      if (WIPE) {
+#pragma unroll
+        for (int l = 0; l < N; ++l)
+          if (a.wipe_with[l]) {  // uniform
+            wipe_b[l] = reinterpret_cast<const float4 *>(a.wipe_with[l])[(size_t)line * a.out_w + x];
+            wipe_m[l] = reinterpret_cast<const float4 *>(a.wipe_mask[l])[(size_t)line * a.out_w + x].x;
+          }
+      }
       uint32_t o00 = 0, o10 = 0, o01 = 0, o11 = 0;
       // every layer's loads are issued before any is blended: 4 N independent loads in flight
 #pragma unroll
@@ -726,6 +739,11 @@ __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const fl
         t.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
         t.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
         if (MIXED) t.x = direct[l] ? t00.x : t.x, t.y = direct[l] ? t00.y : t.y, t.z = direct[l] ? t00.z : t.z, t.w = direct[l] ? t00.w : t.w;
+        if (WIPE && a.wipe_with[l]) {  // transition.ts wipe: mix(in0, in1, mask) with the rounding of twipe_kernel
+          const float m = wipe_m[l], rm = 1.0f - m;
+          t.x = fma_rn(wipe_b[l].x, m, t.x * rm), t.y = fma_rn(wipe_b[l].y, m, t.y * rm);
+          t.z = fma_rn(wipe_b[l].z, m, t.z * rm), t.w = fma_rn(wipe_b[l].w, m, t.w * rm);
+        }
         if (l == 0) {
           r = t.x, g = t.y, b = t.z;
         } else {  // combine.ts:45-65 (alpha of the result is never used by the writer)
@@ -752,7 +770,7 @@ __device__ __forceinline__ void compose_taps_body(const ComposeArgs &a, const fl
   }
 }
 
-template <int N, bool MIXED, bool SHARED = false>
+template <int N, bool MIXED, bool SHARED = false, bool WIPE = false>
 __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_taps_kernel(ComposeArgs a, uint32_t stage_off) {
   const WriteK wk = load_write_k(a.wr_cm);
   const LutK lk = make_lut_k(a.wr);
@@ -774,18 +792,26 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_taps_kernel(Comp
   uint16_t *ys = reinterpret_cast<uint16_t *>(g_lds + stage_off + wave * kComposeChunk * 4);
   uint16_t *us = ys + kComposeChunk, *vs = us + kComposeChunk / 2;
   if (all_aligned)
-    compose_taps_body<N, MIXED, true, SHARED>(a, mm, direct, img, wk, lk, ys, us, vs, wave, lane);
+    compose_taps_body<N, MIXED, true, SHARED, WIPE>(a, mm, direct, img, wk, lk, ys, us, vs, wave, lane);
   else
-    compose_taps_body<N, MIXED, false, SHARED>(a, mm, direct, img, wk, lk, ys, us, vs, wave, lane);
+    compose_taps_body<N, MIXED, false, SHARED, WIPE>(a, mm, direct, img, wk, lk, ys, us, vs, wave, lane);
 }
 
 template <int N>
 static hipError_t launch_compose_taps_n(hipStream_t s, const ComposeArgs &a, uint32_t grid, uint32_t stage_off) {
-  bool mixed = false, shared = N > 1;
+  bool mixed = false, shared = N > 1, wipe = false;
   for (int l = 0; l < N; ++l) {
+    wipe = wipe || a.wipe_with[l] != nullptr;
     mixed = mixed || a.matrix[l] == nullptr;
     // one placement for all layers: the same matrix BUFFER (so the same nine values) and the same source size
     shared = shared && a.matrix[l] != nullptr && a.matrix[l] == a.matrix[0] && a.lw[l] == a.lw[0] && a.lh[l] == a.lh[0];
+  }
+  if (wipe) {  // one variant: 1:1 layers allowed, placements per layer
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, true, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(stage_off + kComposeStageBytes));
+    if (e != hipSuccess) return e;
+    compose_write_v210_taps_kernel<N, true, false, true><<<grid, kLdsBlock, stage_off + kComposeStageBytes, s>>>(a, stage_off);
+    return hipGetLastError();
   }
   const void *fn = shared ? reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, false, true>)
                    : mixed ? reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, true>)
@@ -810,8 +836,10 @@ static bool compose_taps_eligible(const ComposeArgs &a) {
     if (bytes + 2 * pitch > 0x80000000ull || pitch >= (1u << 23) || a.lh[l] >= (1 << 22)) return false;
     sampled = sampled || a.matrix[l] != nullptr;
   }
+  for (int l = 0; l < a.n; ++l) sampled = sampled || a.wipe_with[l] != nullptr;
   return sampled;  // all layers 1:1: the streaming kernel above is HBM-bound already
 }
+bool compose_can_wipe(const ComposeArgs &a) { return compose_taps_eligible(a); }
 
 template <int N, bool ALL_DIRECT>
 static hipError_t launch_compose_px_nd(hipStream_t s, const ComposeArgs &a, uint32_t grid, uint32_t stage_off) {

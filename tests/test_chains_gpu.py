@@ -224,6 +224,13 @@ def test_config2_chain_with_wipe_full_size():
     k.compose_write_v210([(rgba[0], w, h, dmats[0]), (rgba[1], w, h, dmats[1]), (rgba[2], w, h, dmats[2]),
                           (trans, w, h, None)], out2, w, h, 0, wcm, wlut)
     _bits_equal(hh.host(out2, np.uint32), want, "config 2, fused compositor")
+    # ---- device, the wipe inside the compositor: transform + transition_wipe + combine + write as one kernel
+    out3 = _v210_out(w, h)
+    k.compose_wipe_write_v210([(rgba[l], w, h, dmats[l]) for l in range(4)], [None, None, None, (rgba[4], dmask)],
+                              out3, w, h, 0, wcm, wlut)
+    _bits_equal(hh.host(out3, np.uint32), want, "config 2, compositor with the wipe inside")
+    with pytest.raises(Exception, match="both the incoming image and the mask"):
+        k.compose_wipe_write_v210([(rgba[0], w, h, dmats[0])], [(rgba[4], None)], out3, w, h, 0, wcm, wlut)
     # the PiP geometry really exposes every layer: each one alone changes the result
     for drop in range(4):
         layers = [xf_o[0], xf_o[1], xf_o[2], trans_o]

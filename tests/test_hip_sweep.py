@@ -177,6 +177,46 @@ def test_compose_buffer_addressed_taps():
         bits_eq(hh.host(out, np.uint32), want, "compose taps %d: %dx%d n=%d il=%d shared=%s %r" % (k, ow, oh, n, il, shared, [s[2] for s in specs]))
 
 
+def test_compose_with_wipes_inside():
+    """ph_compose_wipe_write_v210: wipes on sampled and on 1:1 layers, several per frame, interlaced outputs - against
+    transform -> transition_wipe -> combine -> write of the oracle."""
+    import hip_harness as hh
+    from phaneron_amd import capi
+    r = rng_for("compose wipes")
+    hh.ctx().set_option("lds_lut", True)
+    wcm, wlut = hh.ColourParams.writer("709")
+    for k in range(8):
+        ow, oh = 192 * int(r.integers(1, 3)), int(r.integers(2, 20))
+        n = int(r.integers(1, 6))
+        il = int(r.choice([0, 1, 3]))
+        specs, wipes = [], []
+        for l in range(n):
+            if r.integers(0, 3) == 0:
+                specs.append((ow, oh, None))
+            else:
+                specs.append((int(r.integers(2, 200)), int(r.integers(2, 60)),
+                              dict(scale_x=float(r.uniform(0.4, 2.5)), scale_y=float(r.uniform(0.4, 2.5)), offset_x=float(r.uniform(-0.4, 0.4)),
+                                   offset_y=float(r.uniform(-0.4, 0.4)), rotate=float(r.choice([0.0, 0.0, 0.1])))))
+            wipes.append(r.integers(0, 2) == 1 or (l == n - 1 and not any(wipes)))
+        imgs = [frames.rgba_random(w, h, 8800 + 10 * k + i) for i, (w, h, _) in enumerate(specs)]
+        incoming = [frames.rgba_random(ow, oh, 8900 + 10 * k + i, -0.05, 1.05) if wv else None for i, wv in enumerate(wipes)]
+        masks = [frames.rgba_random(ow, oh, 8950 + 10 * k + i) if wv else None for i, wv in enumerate(wipes)]
+        mats = [None if kw is None else capi.transform_matrix(ow, oh, **kw) for (_, _, kw) in specs]
+        dst0 = np.full(frames.v210_pitch_bytes(ow) * oh // 4, cases.POISON, np.uint32)
+        out = hh.dev(dst0)
+        layers = [(hh.dev(im), w, h, None if m is None else hh.dev(m)) for im, (w, h, _), m in zip(imgs, specs, mats)]
+        dw = [None if not wv else (hh.dev(incoming[i]), hh.dev(masks[i])) for i, wv in enumerate(wipes)]
+        hh.ctx().compose_wipe_write_v210(layers, dw, out, ow, oh, il, wcm, wlut)
+        xf = [im if m is None else orc.transform(im, m, ow, oh) for im, m in zip(imgs, mats)]
+        xf = [orc.transition_wipe(x, incoming[i], masks[i]) if wipes[i] else x for i, x in enumerate(xf)]
+        comb = xf[0] if len(xf) == 1 else orc.combine(xf)
+        want = orc.v210_write(comb, ow, oh, il, orc.rgb2ycbcr_matrix("709"), orc.linear2gamma_lut("709"), out=dst0.copy())
+        bits_eq(hh.host(out, np.uint32), want, "compose wipes %d: %dx%d n=%d il=%d wipes=%r" % (k, ow, oh, n, il, wipes))
+    with pytest.raises(Exception, match="192"):
+        t = hh.dev(frames.rgba_random(96, 4, 1))
+        hh.ctx().compose_wipe_write_v210([(t, 96, 4, None)], [(t, t)], hh.dev(np.zeros(96 * 4, np.uint32)), 96, 4, 0, wcm, wlut)
+
+
 @pytest.mark.parametrize("fmt", ["yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"])
 def test_pack_formats_random_sizes(fmt):
     import torch

@@ -101,12 +101,20 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
         ctx.compose_write_v210([(rgba[0], w, h, mats[0]), (rgba[1], w, h, mats[1]), (rgba[2], w, h, mats[2]),
                                 (trans, w, h, None)], out, w, h, 0, *wr)
 
+    def config2_wipe_inside(i):  # [read x5], then ONE compositor launch: transform x4 + transition_wipe + combine_4 + write
+        s = src[i % R]
+        ctx.v210_read_batch(s, rgba, w, h, *rd)
+        ctx.compose_wipe_write_v210([(rgba[l], w, h, mats[l]) for l in range(4)], [None, None, None, (rgba[4], mask)],
+                                    out, w, h, 0, *wr)
+
     # 4 layers + second source + the mask counted as one more v210-sized input + 1 output (38 707 200 during a transition)
     algo2 = 7 * capi.v210_pitch_bytes(w) * h
     name2 = "2: 1 channel, 4-layer 1080p50, three quarter-size insets, wipe transition on the top layer"
-    record(name2, "fused compositor, batched reads: [read x5], transform, transition_wipe, [transform x3 + combine_4 + write]", "frame",
-           timeit(lambda i: config2_fused(i, True), reps), algo2, 4)
+    record(name2, "batched reads + compositor with the wipe inside: [read x5], [transform x4 + transition_wipe + combine_4 + write]", "frame",
+           timeit(config2_wipe_inside, reps), algo2, 2)
     if routes == "all":
+        record(name2, "fused compositor, batched reads: [read x5], transform, transition_wipe, [transform x3 + combine_4 + write]", "frame",
+               timeit(lambda i: config2_fused(i, True), reps), algo2, 4)
         record(name2, "fused compositor: read x5, transform, transition_wipe, [transform x3 + combine_4 + write]", "frame",
                timeit(config2_fused, reps), algo2, 8)
         record(name2, "one kernel per operator (the reference's job batch)", "frame", timeit(config2, reps), algo2, 13)
