@@ -26,7 +26,7 @@ EXPORTS = [
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
-    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option", "ph_compose_write_v210",
+    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option", "ph_compose_write_v210", "ph_compose_wipe_write_v210",
     "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
     "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy", "ph_queue_query",
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
