@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define PH_ABI_VERSION 1
+/* 2: additive over 1 - ph_program_resolve, ph_route_*, ph_yadif_pair, ph_v210_yadif_pair, ph_v210_read_batch,
+ *    ph_fused_field_v210, ph_compose_wipe_write_v210, context option "stream_images"; no signature of 1 changed */
+#define PH_ABI_VERSION 2
 
 enum {
   PH_OK = 0,
