@@ -121,6 +121,22 @@ class Rig {
 			params: { prev, cur, next, parity: o.parity ? 1 : 0, tff: o.tff ? 1 : 0, skipSpatial: o.skipSpatial ? 1 : 0, output }
 		})
 	}
+	// the channel's tail as one launch: stage([{ image, matrix?, wipe?: { incoming, mask } }...], output v210, field)
+	// = [transform] per layer (+ transition_wipe) -> combine_n -> FromRGBA; bit-identical to the separate stages
+	async compose(n, width, height, spec) {
+		const program = await this.program(`compose_write_v210_${n}`, 'compose', { globalWorkItems: [width, height] })
+		const c = await this.colourOut('v210', spec)
+		return (layers, output, field = 0) => {
+			if (layers.length !== n) throw new Error(`compose_write_v210_${n} needs ${n} layers, got ${layers.length}`)
+			const params = { output, outColMatrix: c.colMatrix, outGammaLut: c.gammaLut, interlace: field }
+			layers.forEach((l, i) => {
+				params[`l${i}In`] = l.image
+				if (l.matrix) params[`l${i}Matrix`] = l.matrix
+				if (l.wipe) { params[`l${i}WipeIn`] = l.wipe.incoming; params[`l${i}WipeMask`] = l.wipe.mask }
+			})
+			return { name: `compose_write_v210_${n}`, program, params }
+		}
+	}
 	// ToRGBA of n v210 frames of one size and colour recipe in one launch: stage([planes...], [images...])
 	async unpackBatch(n, width, height, spec, workSpec) {
 		const c = await this.colourIn('v210', spec, workSpec)

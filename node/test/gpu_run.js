@@ -256,6 +256,40 @@ async function main() {
 		;[...srcs, ...imgs].forEach((b) => b.release())
 	}
 
+	// ---- 9. the channel of step 1 again with its tail as ONE launch: 'compose_write_v210_<n>' = transform (layer 1) ->
+	//         combine -> write; and the same with a wipe transition on the top layer inside the kernel --------------------
+	{
+		const c = job.channel
+		const n = c.layers.length
+		const read = await rig.unpack('v210', c.width, c.height, c.readSpec, c.writeSpec)
+		const xf = await rig.transform(c.width, c.height)
+		const compose = await rig.compose(n, c.width, c.height, c.writeSpec)
+		const rgba = []
+		for (let l = 0; l < n; ++l) {
+			const src = await rig.planes('v210', c.width, c.height)
+			await rig.upload(src[0], load(c.layers[l]))
+			await rig.sync(ctx.queue.load)
+			const img = await rig.image(c.width, c.height)
+			await rig.run(read(src, img))
+			src[0].release()
+			rgba.push(img)
+		}
+		const pip = await xf.matrix(c.pip)
+		const layers = rgba.map((image, l) => (l === 1 ? { image, matrix: pip } : { image }))
+		const out = await rig.planes('v210', c.width, c.height, 'writeonly')
+		await rig.run(compose(layers, out[0], 0))
+		await rig.sync()
+		await rig.download(out[0])
+		save('compose_out.bin', out[0])
+		// wipe: the top layer gives way to layer 0's picture under a mask made of layer 2's picture
+		layers[n - 1] = { image: rgba[n - 1], wipe: { incoming: rgba[0], mask: rgba[2] } }
+		await rig.run(compose(layers, out[0], 0))
+		await rig.sync()
+		await rig.download(out[0])
+		save('compose_wipe_out.bin', out[0])
+		;[...rgba, out[0]].forEach((b) => b.release())
+	}
+
 	rig.close()
 	result.liveAfter = ctx.logBuffers ? rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers : -1
 	save('result.json', JSON.stringify(result))

@@ -919,6 +919,50 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       refresh_buf_lut(ctx, c);
       return ph_v210_yadif_pair(ctx, queue, prog->n_layers, src, width, height, (int)tff, (int)skip, b->dptr, c->dptr, d->dptr);
     }
+    case K_COMPOSE_V210: {
+      // l<i>In: RGBA image; l<i>Matrix (optional): its 3x3 placement, absent = taken 1:1; l<i>WipeIn + l<i>WipeMask (optional):
+      // a wipe transition on the placed layer; output: v210; outColMatrix / outGammaLut: the Saver's; interlace as 'write'
+      const uint32_t width = prog->global[0], height = prog->global[1];
+      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
+      ph_layer layers[ph::kMaxLayers];
+      ph_layer_wipe wipes[ph::kMaxLayers];
+      bool any_wipe = false;
+      for (int i = 0; i < prog->n_layers; ++i) {
+        char nm[24];
+        ph_buf *x = nullptr;
+        int lw, lh;
+        snprintf(nm, sizeof nm, "l%dIn", i);
+        TRY(need_buf(args, n, nm, 0, &x));
+        TRY(need_image(x, nm, &lw, &lh));
+        layers[i].rgba = x->dptr, layers[i].width = lw, layers[i].height = lh, layers[i].matrix9 = nullptr;
+        snprintf(nm, sizeof nm, "l%dMatrix", i);
+        if (find_arg(args, n, nm)) {
+          TRY(need_buf(args, n, nm, 36, &x));
+          layers[i].matrix9 = x->dptr;
+        }
+        wipes[i].incoming_rgba = wipes[i].mask_rgba = nullptr;
+        snprintf(nm, sizeof nm, "l%dWipeIn", i);
+        if (find_arg(args, n, nm)) {
+          TRY(need_buf(args, n, nm, (size_t)width * height * 16, &x));
+          wipes[i].incoming_rgba = x->dptr;
+          snprintf(nm, sizeof nm, "l%dWipeMask", i);
+          TRY(need_buf(args, n, nm, (size_t)width * height * 16, &x));
+          wipes[i].mask_rgba = x->dptr;
+          any_wipe = true;
+        }
+      }
+      double interlace = 0;
+      ph_buf *wcm = nullptr, *wl = nullptr;
+      TRY(need_buf(args, n, "output", (size_t)ph_v210_pitch_bytes(width) * height, &o));
+      TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
+      TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
+      if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
+      refresh_buf_lut(ctx, wl);
+      if (any_wipe)
+        return ph_compose_wipe_write_v210(ctx, queue, prog->n_layers, layers, wipes, o->dptr, width, height, (uint32_t)interlace,
+                                          wcm->dptr, wl->dptr);
+      return ph_compose_write_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
+    }
     case K_V210_READ_BATCH: {  // l<i>In: v210 frames; l<i>Out: RGBA images; colMatrix / gammaLut / gamutMatrix: the Loader's
       const uint32_t width = prog->global[0], height = prog->global[1];
       if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());

@@ -255,6 +255,12 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
     got = np.fromfile(tmp_path / "channel_out.bin", np.uint32)
     assert np.array_equal(got, want)
 
+    # the same channel with its tail as one launch (program 'compose_write_v210_<n>'), and with a wipe inside
+    assert np.array_equal(np.fromfile(tmp_path / "compose_out.bin", np.uint32), want)
+    top = orc.transition_wipe(rgba[n - 1], orc.v210_read(layers[0], w, h, *rd), orc.v210_read(layers[2], w, h, *rd))
+    want_wipe = orc.v210_write(orc.combine(rgba[:n - 1] + [top]), w, h, 0, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    assert np.array_equal(np.fromfile(tmp_path / "compose_wipe_out.bin", np.uint32), want_wipe)
+
     # yadif send_field, tff: outputs for cur = field1 and field2, two each (yadif.ts:125-145)
     assert res["yadifTimestamps"] == [2, 3, 4, 5]
     k = 0
