@@ -120,6 +120,38 @@ def test_yadif_vs_oracle(w, h):
             assert_bits(hh.host(out), orc.yadif(p, c, n, parity, tff, False), "yadif %dx%d p%d t%d" % (w, h, parity, tff))
 
 
+def test_image_store_policy_changes_no_bit():
+    """ph_ctx_set_option("stream_images"): streamed or cached image stores, same images (read, yadif, transform, combine)"""
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    w, h = 384, 40
+    k = hh.ctx()
+    cm, lut, gm = hh.ColourParams.reader("709", "2020")
+    src = [hh.dev(frames.v210_random(w, h, 6100 + i)) for i in range(3)]
+    m = hh.dev(capi.transform_matrix(w, h, scale_x=0.75, scale_y=0.75, rotate=0.03))
+    results = []
+    try:
+        for policy in (0, 1):
+            k.set_option("stream_images", policy)
+            rgba = [torch.zeros(w * h * 4, dtype=torch.float32, device="cuda") for _ in range(3)]
+            for s_, r in zip(src, rgba):
+                k.v210_read(s_, r, w, h, cm, lut, gm)
+            de, xf, cb = (torch.zeros(w * h * 4, dtype=torch.float32, device="cuda") for _ in range(3))
+            k.yadif(rgba[0], rgba[1], rgba[2], de, w, h, 1, 1, False)
+            k.transform(de, w, h, m, xf, w, h)
+            k.combine([rgba[0], xf], cb, w, h)
+            results.append([hh.host(t).copy() for t in (rgba[0], de, xf, cb)])
+    finally:
+        k.set_option("stream_images", 0)
+    for a, b in zip(*results):
+        assert_bits(a, b, "store policy")
+    want = orc.v210_read(frames.v210_random(w, h, 6100), w, h, orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
+    assert_bits(results[1][0], want, "streamed v210 read")
+    with pytest.raises(Exception, match="unknown option"):
+        k.set_option("stream_everything", 1)
+
+
 @pytest.mark.parametrize("w,h,n", [(1920, 1080, 5), (96, 7, 3), (1282, 3, 2), (6, 1, 8), (3840, 64, 1)])
 def test_v210_read_batch_vs_oracle(w, h, n):
     """n frames in one launch == n single reads (both the LDS-table kernel and, for ragged widths, the gather kernel)"""
