@@ -360,9 +360,10 @@ int ph_lut_query(ph_ctx *ctx, const void *device_lut_f32, uint32_t *lds_bytes, u
                  uint32_t *blocks_per_octave_log2);
 /* options: "lds_lut" (default 1): 0 forces the global-gather kernels (A/B tests, profiles);
  *          "stream_images" (default 0): 1 stores f32 image outputs (ToRGBA, Yadif, Transform, Combine ...) past the
- *          caches, for a caller that knows nothing on the device reads the image soon.  By default an image is
- *          treated as what it is in a channel, an intermediate the next operator reads back; wire-format outputs
- *          always stream. */
+ *          caches, for a caller that knows nothing on the device reads the image soon; 2 does so only for images
+ *          larger than "stream_threshold_mb" MiB (default 64; measured neutral on the reference-shaped chains).  By
+ *          default an image is treated as what it is in a channel, an intermediate the next operator reads back;
+ *          wire-format outputs always stream. */
 int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value);
 
 /* ---- host colour maths (src/process/colourMaths.ts, run by Loader/Saver constructors

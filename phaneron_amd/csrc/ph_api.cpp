@@ -59,7 +59,8 @@ struct ph_ctx {
   int device = 0;
   std::map<const void *, LutEntry> luts;  // device f32 table -> compressed LDS form
   bool use_lds_lut = true;
-  bool stream_images = false;  // f32 image outputs streamed past the caches (ph_device.h store_image)
+  int stream_images = 0;        // f32 image outputs: 0 through the caches, 1 streamed past them, 2 by size (ph_device.h store_image)
+  int stream_threshold_mb = 64;  // policy 2: images larger than this stream
   hipStream_t streams[3] = {nullptr, nullptr, nullptr};
   hipDeviceProp_t props;
   std::multimap<size_t, void *> pool;  // free device blocks by exact size
@@ -100,7 +101,8 @@ namespace {
 int set_device(ph_ctx *ctx) {
   if (ctx->closed.load()) return fail(PH_E_INVALID, "the context has been destroyed");
   PH_HIP(hipSetDevice(ctx->device));
-  ph::t_stream_images = ctx->stream_images ? 1u : 0u;  // the launch that follows on this thread takes the context's store policy
+  ph::t_stream_images = (uint32_t)ctx->stream_images;  // the launch that follows on this thread takes the context's store policy
+  ph::t_stream_threshold_mb = (uint32_t)ctx->stream_threshold_mb;
   return PH_OK;
 }
 
@@ -708,7 +710,14 @@ int ph_lut_query(ph_ctx *ctx, const void *dev, uint32_t *lds_bytes, uint32_t *to
 int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
   if (!ctx || !name) return fail(PH_E_INVALID, "ph_ctx_set_option: NULL argument");
   if (0 == strcmp(name, "lds_lut")) return ctx->use_lds_lut = (value != 0), PH_OK;
-  if (0 == strcmp(name, "stream_images")) return ctx->stream_images = (value != 0), PH_OK;
+  if (0 == strcmp(name, "stream_images")) {
+    if (value < 0 || value > 2) return fail(PH_E_INVALID, "stream_images: 0 (cached), 1 (streamed) or 2 (by size)");
+    return ctx->stream_images = value, PH_OK;
+  }
+  if (0 == strcmp(name, "stream_threshold_mb")) {
+    if (value < 0) return fail(PH_E_INVALID, "stream_threshold_mb: a size in MiB");
+    return ctx->stream_threshold_mb = value, PH_OK;
+  }
   return fail(PH_E_INVALID, "unknown option '%s'", name);
 }
 

@@ -12,7 +12,12 @@ constexpr int kMaxLayers = 8;
 
 // 1 = f32 image outputs of the launches issued by this thread are streamed past the caches (ph_device.h store_image);
 // set from the context's "stream_images" option before every launch (ph_api.cpp set_device)
-extern thread_local uint32_t t_stream_images;
+extern thread_local uint32_t t_stream_images;  // 0 cached, 1 streamed, 2 by size
+extern thread_local uint32_t t_stream_threshold_mb;
+// the store policy of ONE image of `bytes` bytes written by the launch being issued
+static inline uint32_t image_nt(size_t bytes) {
+  return t_stream_images == 2 ? (bytes > ((size_t)t_stream_threshold_mb << 20) ? 1u : 0u) : t_stream_images;
+}
 
 struct FusedArgs {
   const void *layers[kMaxLayers];

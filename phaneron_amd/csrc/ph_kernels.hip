@@ -16,6 +16,7 @@
 namespace ph {
 
 thread_local uint32_t t_stream_images = 0;
+thread_local uint32_t t_stream_threshold_mb = 64;
 
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
@@ -444,7 +445,7 @@ hipError_t launch_v210_read(hipStream_t s, const void *in, void *out, uint32_t w
     const uint32_t used = width / 6, total = used * height;
     v210_read_kernel<<<div_up(total, kBlock), kBlock, 0, s>>>((const uint4 *)in, (float4 *)out, used, qpl, total,
                                                              (const float *)cm, (const float *)lut, (const float *)gm,
-                                                             t_stream_images);
+                                                             image_nt((size_t)width * height * 16));
   } else {
     const uint32_t slots = width / 6 + 1;
     v210_read_tail_kernel<<<div_up((uint64_t)slots * height, kBlock), kBlock, 0, s>>>(
@@ -490,7 +491,7 @@ hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const 
                         int tff, int skip, void *out) {
   dim3 grid(div_up(w, kYadifCols), div_up(h, kYadifRows));
   yadif_rows_kernel<<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, parity,
-                                            tff, skip, (float4 *)out, t_stream_images);
+                                            tff, skip, (float4 *)out, image_nt((size_t)w * h * 16));
   return hipGetLastError();
 }
 
@@ -499,16 +500,16 @@ hipError_t launch_yadif_pair(hipStream_t s, const void *prev, const void *cur, c
   dim3 grid(div_up(w, kYadifCols), div_up(h, kYadifRows));
   if (tff)
     yadif_pair_kernel<1><<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, skip,
-                                                 (float4 *)out0, (float4 *)out1, t_stream_images);
+                                                 (float4 *)out0, (float4 *)out1, image_nt((size_t)w * h * 16));
   else
     yadif_pair_kernel<0><<<grid, kBlock, 0, s>>>((const float4 *)prev, (const float4 *)cur, (const float4 *)next, w, h, skip,
-                                                 (float4 *)out0, (float4 *)out1, t_stream_images);
+                                                 (float4 *)out0, (float4 *)out1, image_nt((size_t)w * h * 16));
   return hipGetLastError();
 }
 
 hipError_t launch_transform(hipStream_t s, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh) {
   dim3 grid(div_up(ow, 64), div_up(oh, 4));
-  transform_kernel<<<grid, kBlock, 0, s>>>((const float4 *)in, iw, ih, (const float *)m9, (float4 *)out, ow, oh, t_stream_images);
+  transform_kernel<<<grid, kBlock, 0, s>>>((const float4 *)in, iw, ih, (const float *)m9, (float4 *)out, ow, oh, image_nt((size_t)ow * oh * 16));
   return hipGetLastError();
 }
 
@@ -516,13 +517,13 @@ hipError_t launch_resize(hipStream_t s, const void *in, int iw, int ih, float sc
                          const void *flip4, void *out, int ow, int oh) {
   dim3 grid(div_up(ow, 64), div_up(oh, 4));
   resize_kernel<<<grid, kBlock, 0, s>>>((const float4 *)in, iw, ih, scale, ox, oy, (const float *)flip4, (float4 *)out,
-                                        ow, oh, t_stream_images);
+                                        ow, oh, image_nt((size_t)ow * oh * 16));
   return hipGetLastError();
 }
 
 hipError_t launch_combine(hipStream_t s, int n, const CombineArgs &args) {
   CombineArgs a = args;
-  a.nt = t_stream_images;
+  a.nt = image_nt(a.npx * 16);
   const uint32_t grid = stream_grid(a.npx);
   switch (n) {
     case 2: combine_kernel<2><<<grid, kBlock, 0, s>>>(a); break;
@@ -539,20 +540,20 @@ hipError_t launch_combine(hipStream_t s, int n, const CombineArgs &args) {
 
 hipError_t launch_dissolve(hipStream_t s, const void *in0, const void *in1, float mix, int w, int h, void *out) {
   const size_t npx = (size_t)w * h;
-  dissolve_kernel<<<stream_grid(npx), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, mix, npx, (float4 *)out, t_stream_images);
+  dissolve_kernel<<<stream_grid(npx), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, mix, npx, (float4 *)out, image_nt(npx * 16));
   return hipGetLastError();
 }
 
 hipError_t launch_twipe(hipStream_t s, const void *in0, const void *in1, const void *mask, int w, int h, void *out) {
   const size_t npx = (size_t)w * h;
   twipe_kernel<<<stream_grid(npx), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, (const float4 *)mask, npx,
-                                                   (float4 *)out, t_stream_images);
+                                                   (float4 *)out, image_nt(npx * 16));
   return hipGetLastError();
 }
 
 hipError_t launch_wipe(hipStream_t s, const void *in0, const void *in1, float wipe, int w, int h, void *out) {
   wipe_kernel<<<stream_grid((size_t)w * h), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, wipe, w, h,
-                                                           (float4 *)out, t_stream_images);
+                                                           (float4 *)out, image_nt((size_t)w * h * 16));
   return hipGetLastError();
 }
 

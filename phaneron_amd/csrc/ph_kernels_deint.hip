@@ -171,7 +171,7 @@ hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t 
     const uint64_t cost = rounds * (r + 4);
     if (cost < best_cost) best_cost = cost, best_r = r;
   }
-  a.nt = t_stream_images;
+  a.nt = image_nt((size_t)a.width * a.height * 16);
   a.rows_per_strip = best_r;
   a.strips = (a.height + best_r - 1) / best_r;
   const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;

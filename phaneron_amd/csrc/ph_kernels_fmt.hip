@@ -271,7 +271,7 @@ hipError_t launch_pack_read(hipStream_t s, int fmt, const void *const planes[3],
                             uint32_t num_cus) {
   const bool v420 = (fmt == F_YUV420P || fmt == F_NV12);
   FmtReadArgs a{planes[0], planes[1], planes[2], (float4 *)out, width, v420 ? (height / 2) * 2 : height,
-                pack_pitch(fmt, width), (const float *)cm, (const float *)gm, t_stream_images};
+                pack_pitch(fmt, width), (const float *)cm, (const float *)gm, image_nt((size_t)width * height * 16)};
   switch (fmt) {
     case F_YUV422P10: return launch_read_fmt<F_YUV422P10>(s, a, (const float *)table, lv, num_cus);
     case F_YUV422P8: return launch_read_fmt<F_YUV422P8>(s, a, (const float *)table, lv, num_cus);

@@ -972,7 +972,7 @@ hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32
   const uint32_t want = (total + kLdsBlock - 1) / kLdsBlock;
   v210_read_lds_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, lut.bytes, s>>>(
       (const uint4 *)in, (float4 *)out, width, v210_pitch_bytes(width) / 16, total, (const float *)cm, (const float *)gm,
-      lut, t_stream_images);
+      lut, image_nt((size_t)width * height * 16));
   return hipGetLastError();
 }
 
@@ -988,7 +988,7 @@ hipError_t launch_v210_read_lds_batch(hipStream_t s, int n, const void *const *i
   a.wg_per_frame = want < per ? want : per;
   v210_read_lds_batch_kernel<<<a.wg_per_frame * n, kLdsBlock, lut.bytes, s>>>(a, width, v210_pitch_bytes(width) / 16, total,
                                                                               (const float *)cm, (const float *)gm, lut,
-                                                                              t_stream_images);
+                                                                              image_nt((size_t)width * height * 16));
   return hipGetLastError();
 }
 
