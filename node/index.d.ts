@@ -83,6 +83,8 @@ export class clContext {
 	/** ROUTE across GPUs: RCCL send / recv on a communication stream of its own, ordered on the device */
 	openRoute(id: Buffer, rank: number, world: number): RouteLink
 	static routeUniqueId(): Buffer
+	/** library options: 'lds_lut' (0 | 1), 'stream_images' (0 cached | 1 streamed | 2 by size), 'stream_threshold_mb' */
+	setOption(name: string, value: number): void
 	logBuffers(): { liveBuffers: number; liveBytes: number; pooledBytes: number }
 }
 

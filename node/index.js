@@ -158,6 +158,8 @@ class clContext {
 	}
 	static routeUniqueId() { return loadAddon().routeUniqueId() }
 
+	// library options (include/phaneron_hip.h ph_ctx_set_option): 'lds_lut', 'stream_images', 'stream_threshold_mb'
+	setOption(name, value) { this._need().setOption(this._ctx, String(name), value | 0) }
 	logBuffers() {
 		const s = this._need().bufferStats(this._ctx)
 		console.log(`phaneron HIP buffers: ${s.liveBuffers} live (${s.liveBytes} bytes), ${s.pooledBytes} bytes pooled`)

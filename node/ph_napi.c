@@ -552,6 +552,22 @@ static napi_value BufferStats(napi_env env, napi_callback_info info) {
   return out;
 }
 
+/* setOption(ctx, name, value): ph_ctx_set_option ("lds_lut", "stream_images", "stream_threshold_mb") */
+static napi_value SetOption(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  ctx_box *c;
+  char name[64];
+  int32_t value = 0;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 3 || !get_box(env, argv[0], (void **)&c)) return throw_ph(env, "setOption: bad context");
+  size_t len = 0;
+  if (napi_get_value_string_utf8(env, argv[1], name, sizeof name, &len) != napi_ok || napi_get_value_int32(env, argv[2], &value) != napi_ok)
+    return throw_ph(env, "setOption(ctx, name, value): a string and an integer");
+  if (ph_ctx_set_option(c->ctx, name, value)) return throw_ph(env, "setOption");
+  return NULL;
+}
+
 /* ---- device-free helpers: kernel selection and the host colour maths (src/process/colourMaths.ts is run
  *      by the reference's Loader / Saver; a caller that builds its own parameter buffers gets the same
  *      numbers from the library) --------------------------------------------------------------------- */
@@ -741,7 +757,7 @@ NAPI_MODULE_INIT() {
     const char *name;
     napi_callback fn;
   } fns[] = {
-      {"abiVersion", AbiVersion},   {"createContext", CreateContext}, {"contextInfo", ContextInfo},
+      {"abiVersion", AbiVersion},   {"setOption", SetOption},   {"createContext", CreateContext}, {"contextInfo", ContextInfo},
       {"createBuffer", CreateBuffer}, {"bufAddRef", BufAddRef},       {"bufRelease", BufRelease},
       {"bufRefCount", BufRefCount}, {"hostAccess", HostAccess},       {"waitFinish", WaitFinish},
       {"createProgram", CreateProgram}, {"runProgram", RunProgram},   {"bufferStats", BufferStats},

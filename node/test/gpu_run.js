@@ -172,6 +172,8 @@ async function main() {
 			await ctx.runProgram(p, { width: 1920 }, ctx.queue.process)
 		})
 		await grab('combineOne', () => rig.combine(1, 64, 64))
+		await grab('unknownOption', async () => ctx.setOption('stream_everything', 1))
+		await grab('knownOption', async () => { ctx.setOption('stream_images', 1); ctx.setOption('stream_images', 0) })
 		result.errors = errors
 	}
 

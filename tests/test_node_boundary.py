@@ -100,7 +100,7 @@ def test_job_board_keeps_the_dispatcher_contract():
 def test_napi_addon_builds_loads_and_refuses_without_gpu():
     _build_addon()
     js = ("const a=require('%s');"
-          "const want=['abiVersion','createContext','contextInfo','createBuffer','bufAddRef','bufRelease','bufRefCount',"
+          "const want=['abiVersion','setOption','createContext','contextInfo','createBuffer','bufAddRef','bufRelease','bufRefCount',"
           "'hostAccess','waitFinish','createProgram','runProgram','bufferStats','queueWaitQueue','downloadAsync',"
           "'eventRecord','eventWait','eventDone','waitFinishSpin','resolveProgram','gammaLut','colourMatrix',"
           "'transformMatrix','planeBytes','routeUniqueId','routeInit','routeOp'];"
@@ -312,6 +312,7 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
     assert "unknown kernel 'sharpen'" in e["unknownKernel"]
     assert "kernel argument 'input' (buffer) missing" in e["missingArgument"]
     assert "at least 2 layers" in e["combineOne"]
+    assert "unknown option 'stream_everything'" in e["unknownOption"] and e["knownOption"] is None
     # five flushes requested together: served in order, one drain (jobs.js)
     assert res["boardStats"] == {"flushes": 5, "drains": 1, "kernels": 7}
     assert res["liveAfter"] == 0
