@@ -128,6 +128,35 @@ def test_config3_chain_one_field_full_size(config3_sources, second_field, pip):
     _bits_equal(hh.host(out3, np.uint32), want, "config 3, fused field pipeline")
 
 
+@pytest.mark.parametrize("tff", [1, 0])
+def test_config3_deinterlacing_reader_full_size(config3_sources, tff):
+    """ph_v210_yadif_pair on config 3's four full-size windows in ONE launch (the strip height the launcher picks for
+    4 x 1080 rows, every column block, both outputs) against the oracle's read -> yadif for both parities - and the
+    whole best route of config 3: its outputs through the fused compositor equal the oracle chain's v210 frame."""
+    import hip_harness as hh
+    from phaneron_amd import capi
+    words, rgba_o, rgba_d = config3_sources
+    k = hh.ctx()
+    cm, lut, gm = hh.ColourParams.reader("709", "2020")
+    outs = [[_img(SW, SH), _img(SW, SH)] for _ in range(4)]
+    dwords = [[hh.dev(f) for f in words[l]] for l in range(4)]
+    k.v210_yadif_pair([(dwords[l][0], dwords[l][1], dwords[l][2], outs[l][0], outs[l][1]) for l in range(4)], SW, SH, tff, False, cm, lut, gm)
+    deint_o = [[orc.yadif(rgba_o[l][0], rgba_o[l][1], rgba_o[l][2], parity, tff, False) for parity in (0, 1)] for l in range(4)]
+    for l in range(4):
+        for parity in (0, 1):
+            _bits_equal(hh.host(outs[l][parity]), deint_o[l][parity], "deinterlacing reader layer %d parity %d tff %d" % (l, parity, tff))
+    # the route bench.py reports for config 3: one compositor launch per field on those outputs (one shared placement)
+    m = capi.transform_matrix(OW, OH)
+    dm = hh.dev(m)
+    wcm, wlut = hh.ColourParams.writer("2020")
+    for parity in (0, 1):
+        out = _v210_out(OW, OH)
+        k.compose_write_v210([(outs[l][parity], SW, SH, dm) for l in range(4)], out, OW, OH, 0, wcm, wlut)
+        up_o = [orc.transform(deint_o[l][parity], orc.transform_matrix(OW, OH), OW, OH) for l in range(4)]
+        want = orc.v210_write(orc.combine(up_o), OW, OH, 0, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+        _bits_equal(hh.host(out, np.uint32), want, "config 3 best route, parity %d tff %d" % (parity, tff))
+
+
 def test_fused_field_pipeline_mixed_layers_and_edges():
     """ph_fused_field_v210 beyond config 3's shape: a progressive layer next to de-interlaced ones, both parities and
     field orders, skip_spatial, a 1:1 layer, an up-scale with an offset (part of the layer off screen: border taps), an
