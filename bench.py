@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 2 and 3 (the `secondary` field)")
+    ap.add_argument("--no-route", action="store_true", help="N > 1: skip BASELINE config 5 (the `route` field)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc child runs); report the recorded figure")
     ap.add_argument("--plan", action="store_true",
                     help="print how --gpus N would be launched (one JSON line) and exit; needs no GPU")
     return ap.parse_args()
@@ -181,6 +184,51 @@ def recorded_traffic():
     return None
 
 
+# gfx950 corrections of the two counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE reports half the bytes of a wide coalesced
+# streaming read; profiles/pmc_traffic.json calibrated both on a 1 GiB copy: 1.99996 and 1.00000).  Counter unit: KiB.
+FETCH_CORRECTION, WRITE_CORRECTION = 2.0, 1.0
+
+
+def measured_traffic(kernel_substring="fused_v210_combine", timeout_s=150):
+    """HBM bytes per launch of the headline kernel measured NOW: this script is run twice more, briefly, as a child of
+    `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE cannot share a pass; --pmc goes with
+    --kernel-trace only), and the per-dispatch counter values of the kernel are averaged.  Returns (bytes, detail) or
+    (None, reason) - no rocprofv3 on PATH, a failing pass, nothing parsed."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 is not on PATH"
+    means = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="ph_bench_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "24", "--warmup", "4", "--cpu-seconds", "0", "--no-secondary", "--no-traffic"]
+        env = dict(os.environ, PH_BENCH_FIXED_WARMUP="12", TMPDIR="/tmp")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PH_BENCH_FORCE_DIST"):
+            env.pop(k, None)
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and kernel_substring in row.get("Kernel_Name", ""):
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "%s pass: no dispatch of the kernel in the counter file (exit %d)" % (counter, r.returncode)
+            means[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as e:
+            return None, "%s pass failed: %s: %s" % (counter, type(e).__name__, e)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    total = int(round((means["FETCH_SIZE"][0] * FETCH_CORRECTION + means["WRITE_SIZE"][0] * WRITE_CORRECTION) * 1024))
+    return total, {"FETCH_SIZE_KiB_mean": round(means["FETCH_SIZE"][0], 1), "WRITE_SIZE_KiB_mean": round(means["WRITE_SIZE"][0], 1),
+                   "dispatches": means["FETCH_SIZE"][1], "fetch_correction": FETCH_CORRECTION, "write_correction": WRITE_CORRECTION}
+
+
 def main():
     args = parse()
     plan = launch_plan(args, sys.argv[1:])
@@ -288,6 +336,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         frames_done = int(t.item())
 
+    # N > 1 (or the forced distributed path of the tests): BASELINE config 5 in the same command - 2 channels per rank,
+    # every channel's fourth layer routed from channel k + N (ph_route_*: RCCL on its own stream), fingerprint-checked
+    route_rec = None
+    if dist is not None and not args.no_route and C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import route_bench
+        del ring[:]
+        torch.cuda.empty_cache()
+        rh = int(os.environ.get("PH_BENCH_ROUTE_HEIGHT", HEIGHT))  # tests shrink the frame
+        r_args = route_bench.parse(["--check", "--steps", "40", "--warmup", "5", "--width", str(WIDTH), "--height", str(rh),
+                                    "--backend", "gloo" if share_gpu else "nccl"] + (["--loopback"] if world == 1 else []) +
+                                   (["--same-gpu"] if share_gpu else []))
+        try:
+            route_rec = route_bench.measure(r_args, ctx, dist, rank, world, device, log=lambda m: print(m, file=sys.stderr, flush=True))
+        except Exception as e:  # the headline figure must not depend on it; every rank takes the same path or the job hangs
+            route_rec = {"error": "%s: %s" % (type(e).__name__, e)}
+
     lds = ctx.lut_info(rd[1])["lds_bytes"] and ctx.lut_info(wr[1])["lds_bytes"] and not os.environ.get("PH_BENCH_GLOBAL_LUT")
     kernel_name = ("fused_v210_combine_lds_kernel<%d,...>" if lds else "fused_v210_combine_kernel<%d>") % n
     if rank == 0:
@@ -297,7 +362,7 @@ def main():
         line = {
             "metric": "frames/sec, 4-layer 2160p50 composite pipeline (v210 unpack->CSC->combine->CSC->v210 pack)",
             "value": round(fps, 2), "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 5),
+            "warmup": args.warmup, "fixed_warmup": FIXED_WARMUP, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%s: %d channel%s per GPU, %d x %dx%d v210 layers -> fused unpack/CSC(709->2020)/"
@@ -313,12 +378,25 @@ def main():
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": round(kernel_ms, 5)},
         }
+        if route_rec is not None:
+            line["route"] = route_rec
         insts, src = recorded_valu_instructions()
         if insts and C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS):
             rate = insts / (kernel_ms * 1e-3)
             line["roofline"]["valu"] = {"achieved": round(rate / 1e12, 4), "peak": round(VALU_PEAK_WAVE_INSTR_PER_S / 1e12, 4),
                                         "unit": "T wave64-instr/s", "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4),
                                         "instructions_per_launch": insts, "source": "recorded: profiles/" + src}
+        headline = C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS)
+        if world == 1 and headline and not args.no_traffic and os.environ.get("PH_BENCH_TRAFFIC", "1") != "0":
+            got, detail = measured_traffic()
+            if got is not None:
+                line["roofline"]["traffic"] = got
+                line["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE "
+                                                      "(separate child passes of this script), gfx950 corrections applied")
+                line["roofline"]["traffic_detail"] = detail
+                line["roofline"]["traffic_over_algorithmic"] = round(got / algo_bytes, 4)
+            else:
+                line["roofline"]["traffic_not_measured"] = detail
         if world == 1 and not args.no_secondary and C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS):
             # BASELINE configs 2 and 3 (the compositing configs: real alpha, transforms, de-interlace), fastest route of each,
             # measured after the timed region; tools/config_bench.py prints every route

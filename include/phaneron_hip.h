@@ -150,6 +150,12 @@ int ph_route_after_queue(ph_route *route, int queue);
 int ph_queue_after_route(ph_route *route, int queue);
 int ph_route_wait(ph_route *route); /* host wait for the communication stream (tests, shutdown) */
 void *ph_route_stream(ph_route *route);
+/* ranks in the route's RCCL communicator (ncclCommCount): what RCCL itself saw, not what the caller passed in */
+int ph_route_comm_count(ph_route *route, int *count);
+/* Buffer lifetime: a frame handed to ph_route_send may be RELEASED right after the call - the pool orders the three
+ * queues behind the transfers in flight before it hands a recycled block out again.  REWRITING the same buffer (a
+ * source that composes the next frame into it) needs ph_queue_after_route(route, queue) first, like any other
+ * cross-stream reuse. */
 
 /* the `logBuffers()` debug hook (src/index.ts:184): live buffers / pooled bytes */
 int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes);

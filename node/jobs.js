@@ -49,29 +49,47 @@ class JobBoard {
 	// arrives between a turn's last look at the list and its end starts the next turn
 	_kick() {
 		if (this.pump || !this.waiting.length) return
-		this.pump = Promise.resolve().then(() => this._turn()).then(() => { this.pump = null; this._kick() })
+		// whatever a turn throws, the board keeps serving: the pump is cleared in every outcome
+		this.pump = Promise.resolve()
+			.then(() => this._turn())
+			.catch((e) => this._failAll(e))
+			.then(() => { this.pump = null; this._kick() })
+	}
+
+	// a turn died outside its own error handling: nobody may be left waiting on a flush that will never settle
+	_failAll(e) {
+		for (const f of this.waiting.splice(0)) {
+			f.jobs.forEach((j) => { try { j.done() } catch (_) { /* the owner's callback is not the board's problem */ } })
+			f.fail(e)
+		}
 	}
 
 	cancel(prefix) {
 		for (const [key, jobs] of this.pending) if (key.startsWith(prefix)) jobs.forEach((j) => j.done())
 	}
 
+	// A failing job ends its flush: the jobs behind it under that key are NOT run (they consume its output), the flush
+	// rejects with the job's error, and every job's completion callback still fires - as cancel() does - so that the
+	// owners drop their buffer references.  A failing waitFinish rejects every flush of the batch the same way.
 	async _turn() {
 		while (this.waiting.length) {
 			const batch = this.coalesce ? this.waiting.splice(0) : [this.waiting.shift()]
 			const q = this.ctx.queue.process
-			let failed = null
 			for (const f of batch) {
 				try {
 					for (const j of f.jobs) { await this.ctx.runProgram(j.program, j.params, q); this.stats.kernels++ }
-				} catch (e) { failed = failed || e; f.error = e }
+				} catch (e) { f.error = e }
 			}
-			await this.ctx.waitFinish(q)
-			this.stats.drains++
+			let drainError = null
+			try {
+				await this.ctx.waitFinish(q)
+				this.stats.drains++
+			} catch (e) { drainError = e }
 			for (const f of batch) {
 				this.stats.flushes++
-				f.jobs.forEach((j) => j.done())
-				if (f.error) f.fail(f.error); else f.settle()
+				for (const j of f.jobs) { try { j.done() } catch (e) { f.error = f.error || e } }
+				const err = f.error || drainError
+				if (err) f.fail(err); else f.settle()
 			}
 		}
 	}

@@ -26,6 +26,30 @@ async function main() {
 		const device = ctx.trace.filter((e) => e.op === 'runProgram' || e.op === 'waitFinish').map((e) => e.op === 'waitFinish' ? 'wait' : e.params.mix)
 		report[coalesce ? 'coalesced' : 'oneByOne'] = { order, unknown, pendingAfterCancel: left ? left.length : 0, device, stats: board.stats }
 	}
+	// failures: a rejecting waitFinish and a failing job must settle every flush, fire every callback and leave the board serving
+	{
+		const ctx = makeMock()
+		const board = new JobBoard(ctx)
+		const prog = await ctx.createProgram('phaneron:mixer', { name: 'mixer' })
+		const fired = []
+		const mk = (src, ts, tag) => board.post({ source: src, timestamp: ts }, 'mixer', prog, { mix: ts / 10 }, () => fired.push(tag))
+		const realWait = ctx.waitFinish, realRun = ctx.runProgram
+		let waits = 0
+		ctx.waitFinish = (q) => (++waits === 1 ? Promise.reject(new Error('device lost')) : realWait.call(ctx, q))
+		mk('A', 1, 'A1'); mk('B', 2, 'B2')
+		const outcome = await Promise.all([board.flush({ source: 'A', timestamp: 1 }), board.flush({ source: 'B', timestamp: 2 })]
+			.map((p) => p.then(() => 'ok', (e) => e.message)))
+		// a job that throws: its flush rejects, the job behind it is skipped but its callback fires; the other flush of the turn runs
+		ctx.runProgram = (pr, params, q) => (params.mix === 0.3 ? Promise.reject(new Error('bad launch')) : realRun.call(ctx, pr, params, q))
+		mk('C', 3, 'C3a'); mk('C', 3, 'C3b'); mk('D', 4, 'D4')
+		const outcome2 = await Promise.all([board.flush({ source: 'C', timestamp: 3 }), board.flush({ source: 'D', timestamp: 4 })]
+			.map((p) => p.then(() => 'ok', (e) => e.message)))
+		ctx.runProgram = realRun
+		mk('E', 5, 'E5')
+		const after = await board.flush({ source: 'E', timestamp: 5 }).then(() => 'ok', (e) => e.message)
+		await new Promise((r) => setImmediate(r))
+		report.failures = { outcome, outcome2, after, fired, pumpIdle: board.pump === null }
+	}
 	report.placement = placementToTransform({ anchor: { x: 0.25, y: 0.75 }, rotation: 30, fill: { xOffset: 0.25, yOffset: -0.125, xScale: 0.5, yScale: 0.5 } })
 	report.placementDefault = placementToTransform()
 	report.dissolve = [0, 1, 2, 3].map((k) => dissolveMix(k, 4)).concat([dissolveMix(0, 1), dissolveMix(0, 0)])

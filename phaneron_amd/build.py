@@ -21,7 +21,7 @@ HEADERS = ["ph_device.h", "ph_kernels.h", "ph_lut.h", "ph_lut_host.h", "ph_ldslu
 # packed f32 instruction occupies the issue slot as long as its two halves would (tools/opbench3: 4.2 cycles), and the
 # register PAIRS it needs cost v_mov shuffles and spills: the de-interlacing reader lost 16 % to it.
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result",
-          "-Wno-unused-value"]
+          "-Wno-unused-value", "-Wno-int-to-pointer-cast"]
 
 
 def hipcc():
@@ -48,14 +48,24 @@ def build(force=False, verbose=False, extra_flags=(), variant=None):
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     cc = hipcc()
-    objs = []
+    objs, jobs = [], []
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    hdr_time = max(hdr_time, os.path.getmtime(os.path.abspath(__file__)))
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ("" if variant is None else "_" + variant) + ".o")
+        objs.append(obj)
+        # an object is rebuilt when its source, any header or this script is newer (force: always)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_time, os.path.getmtime(os.path.join(CSRC, src))):
+            continue
         cmd = [cc, "--offload-arch=" + ARCH, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + COMMON + list(extra_flags)
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
+        jobs.append((src, subprocess.Popen(cmd)))  # the sources compile side by side
+    for src, proc in jobs:
+        if proc.wait() != 0:
+            for _, other in jobs:
+                other.wait()
+            raise subprocess.CalledProcessError(proc.returncode, "hipcc " + src)
     cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-o", lib] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))

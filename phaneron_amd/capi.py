@@ -32,7 +32,7 @@ EXPORTS = [
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
     "ph_program_resolve", "ph_fused_field_v210", "ph_route_unique_id", "ph_route_init", "ph_route_destroy", "ph_route_group_begin",
     "ph_route_group_end", "ph_route_send", "ph_route_recv", "ph_route_after_queue", "ph_queue_after_route",
-    "ph_route_wait", "ph_route_stream",
+    "ph_route_wait", "ph_route_stream", "ph_route_comm_count",
 ]
 
 
@@ -162,6 +162,7 @@ def lib():
         "ph_queue_after_route": (ci, [vp, ci]),
         "ph_route_wait": (ci, [vp]),
         "ph_route_stream": (vp, [vp]),
+        "ph_route_comm_count": (ci, [vp, C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(l, name)  # AttributeError here = the header and the library disagree
@@ -586,6 +587,12 @@ class Route:
 
     def wait(self):
         check(lib().ph_route_wait(self.h))
+
+    def comm_count(self):
+        """ranks RCCL itself counts in this route's communicator (ncclCommCount)"""
+        n = C.c_int()
+        check(lib().ph_route_comm_count(self.h, C.byref(n)))
+        return n.value
 
     def destroy(self):
         if self.h:

@@ -67,6 +67,7 @@ struct ph_ctx {
   size_t pooled_bytes = 0, live_buffers = 0, live_bytes = 0;
   void *field_scratch = nullptr;  // index frame of the field pipeline (ph_fused_field_v210)
   size_t field_scratch_bytes = 0;
+  std::vector<struct ph_route *> routes;  // open ROUTEs: a recycled block must not be handed out under a transfer in flight
   std::mutex mu;
   std::atomic<int> refs{1};
   std::atomic<bool> closed{false};
@@ -80,8 +81,9 @@ struct ph_buf {
   int width, height;
   std::atomic<int> refs;
   bool owned;
-  bool host_dirty;
-  bool lut_dirty;  // host data went into a table-sized buffer since its LDS form was last built
+  // written by libuv pool threads (hostAccess) and read by the launching thread (flush_dirty_args)
+  std::atomic<bool> host_dirty;
+  std::atomic<bool> lut_dirty;  // host data went into a table-sized buffer since its LDS form was last built
   std::string owner;
 };
 
@@ -106,7 +108,18 @@ int set_device(ph_ctx *ctx) {
   return PH_OK;
 }
 
+// callers validate the index first (queue_ok): an out-of-range queue is an error, never a silent alias of PROCESS
 hipStream_t stream_of(ph_ctx *ctx, int queue) { return ctx->streams[(queue >= 0 && queue < 3) ? queue : PH_QUEUE_PROCESS]; }
+bool queue_ok(int queue) { return queue >= 0 && queue < 3; }
+int bad_queue(const char *fn, int queue) {
+  return fail(PH_E_INVALID, "%s: queue %d is not PH_QUEUE_LOAD (0), PH_QUEUE_PROCESS (1) or PH_QUEUE_UNLOAD (2)", fn, queue);
+}
+#define PH_QUEUE(fn, queue)                        \
+  do {                                             \
+    if (!queue_ok(queue)) return bad_queue(fn, queue); \
+  } while (0)
+
+void order_queues_after_routes(ph_ctx *ctx);  // below, with ph_route
 
 int pool_alloc(ph_ctx *ctx, size_t bytes, void **out) {
   {
@@ -116,6 +129,9 @@ int pool_alloc(ph_ctx *ctx, size_t bytes, void **out) {
       *out = it->second;
       ctx->pool.erase(it);
       ctx->pooled_bytes -= bytes;
+      // the block's previous owner may have released it right after ph_route_send: RCCL could still be reading it on
+      // the communication stream, which the three queues know nothing about
+      order_queues_after_routes(ctx);
       return PH_OK;
     }
   }
@@ -127,6 +143,7 @@ void pool_free(ph_ctx *ctx, size_t bytes, void *p) {
   // Recycling is stream-safe because all kernels touching a buffer were enqueued (in order)
   // before its last release, and the next user enqueues after it on the same in-order queues;
   // cross-queue users call ph_wait_finish first, exactly as the reference does (io.ts, clJobQueue.ts:131).
+  // ROUTE transfers run on a fourth stream: pool_alloc orders the queues behind them before a block is reused.
   std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->pool.emplace(bytes, p);
   ctx->pooled_bytes += bytes;
@@ -134,9 +151,28 @@ void pool_free(ph_ctx *ctx, size_t bytes, void *p) {
 
 void ctx_ref(ph_ctx *ctx) { ctx->refs.fetch_add(1); }
 
+// contexts that exist: ph_ctx_destroy on a pointer that is no longer (or never was) a context is refused instead of
+// touching freed storage (a second destroy after the last handle went)
+std::mutex g_live_mu;
+std::vector<ph_ctx *> g_live;
+bool ctx_is_live(ph_ctx *ctx) {
+  std::lock_guard<std::mutex> lock(g_live_mu);
+  for (ph_ctx *c : g_live)
+    if (c == ctx) return true;
+  return false;
+}
+
 // drops one reference; the last one frees the device state (streams, pool, LUT blobs)
 void ctx_unref(ph_ctx *ctx) {
   if (ctx->refs.fetch_sub(1) != 1) return;
+  {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    for (size_t i = 0; i < g_live.size(); ++i)
+      if (g_live[i] == ctx) {
+        g_live.erase(g_live.begin() + (long)i);
+        break;
+      }
+  }
   hipSetDevice(ctx->device);
   for (int i = 0; i < 3; ++i)
     if (ctx->streams[i]) {
@@ -203,12 +239,17 @@ int ph_ctx_create(int device_index, ph_ctx **out) {
   PH_HIP(hipSetDevice(device_index));
   PH_HIP(hipGetDeviceProperties(&ctx->props, device_index));
   for (int i = 0; i < 3; ++i) PH_HIP(hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking));
+  {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    g_live.push_back(ctx);
+  }
   *out = ctx;
   return PH_OK;
 }
 
 int ph_ctx_destroy(ph_ctx *ctx) {
   if (!ctx) return PH_OK;
+  if (!ctx_is_live(ctx)) return PH_OK;  // destroyed before and every handle gone since: the storage no longer exists
   if (ctx->closed.exchange(true)) return PH_OK;  // second destroy: the creator's reference is already gone
   hipSetDevice(ctx->device);
   for (int i = 0; i < 3; ++i)
@@ -224,11 +265,12 @@ int ph_ctx_info(ph_ctx *ctx, char *vendor, size_t vlen, char *device, size_t dle
   return PH_OK;
 }
 
-void *ph_ctx_stream(ph_ctx *ctx, int queue) { return ctx ? (void *)stream_of(ctx, queue) : nullptr; }
+void *ph_ctx_stream(ph_ctx *ctx, int queue) { return ctx && queue_ok(queue) ? (void *)stream_of(ctx, queue) : nullptr; }
 
 int ph_wait_finish(ph_ctx *ctx, int queue) {
   if (!ctx) return fail(PH_E_INVALID, "ph_wait_finish: ctx is NULL");
   if (ctx->closed.load()) return closed_error("ph_wait_finish");
+  PH_QUEUE("ph_wait_finish", queue);
   PH_HIP(hipStreamSynchronize(stream_of(ctx, queue)));
   return PH_OK;
 }
@@ -318,6 +360,7 @@ void *ph_buf_host_ptr(ph_buf *b) {
 
 int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t bytes) {
   if (!b) return fail(PH_E_INVALID, "ph_buf_host_access: NULL buffer");
+  PH_QUEUE("ph_buf_host_access", queue);
   int rc = set_device(b->ctx);
   if (rc) return rc;
   hipStream_t s = stream_of(b->ctx, queue);
@@ -354,6 +397,7 @@ int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t by
 
 int ph_queue_query(ph_ctx *ctx, int queue) {
   if (!ctx) return fail(PH_E_INVALID, "ph_queue_query: ctx is NULL");
+  PH_QUEUE("ph_queue_query", queue);
   int rc = set_device(ctx);
   if (rc) return rc;
   hipError_t e = hipStreamQuery(stream_of(ctx, queue));
@@ -380,6 +424,7 @@ int ph_queue_wait_queue(ph_ctx *ctx, int waiter_queue, int signal_queue) {
 
 int ph_buf_download_async(ph_buf *b, int queue) {
   if (!b) return fail(PH_E_INVALID, "ph_buf_download_async: NULL buffer");
+  PH_QUEUE("ph_buf_download_async", queue);
   int rc = set_device(b->ctx);
   if (rc) return rc;
   if (!ph_buf_host_ptr(b)) return PH_E_HIP;
@@ -394,6 +439,7 @@ struct ph_event {
 
 int ph_event_record(ph_ctx *ctx, int queue, ph_event **out) {
   if (!ctx || !out) return fail(PH_E_INVALID, "ph_event_record: NULL argument");
+  PH_QUEUE("ph_event_record", queue);
   int rc = set_device(ctx);
   if (rc) return rc;
   hipEvent_t ev;
@@ -441,6 +487,7 @@ struct ph_graph {
 
 int ph_graph_begin(ph_ctx *ctx, int queue) {
   if (!ctx) return fail(PH_E_INVALID, "ph_graph_begin: ctx is NULL");
+  PH_QUEUE("ph_graph_begin", queue);
   int rc = set_device(ctx);
   if (rc) return rc;
   // relaxed: other threads (the libuv pool of the node addon) may keep calling into HIP meanwhile
@@ -450,6 +497,7 @@ int ph_graph_begin(ph_ctx *ctx, int queue) {
 
 int ph_graph_end(ph_ctx *ctx, int queue, ph_graph **out) {
   if (!ctx || !out) return fail(PH_E_INVALID, "ph_graph_end: NULL argument");
+  PH_QUEUE("ph_graph_end", queue);
   int rc = set_device(ctx);
   if (rc) return rc;
   hipGraph_t g = nullptr;
@@ -468,6 +516,7 @@ int ph_graph_end(ph_ctx *ctx, int queue, ph_graph **out) {
 
 int ph_graph_launch(ph_graph *g, int queue) {
   if (!g) return fail(PH_E_INVALID, "ph_graph_launch: NULL graph");
+  PH_QUEUE("ph_graph_launch", queue);
   int rc = set_device(g->ctx);
   if (rc) return rc;
   PH_HIP(hipGraphLaunch(g->exec, stream_of(g->ctx, queue)));
@@ -500,6 +549,7 @@ struct Rccl {
   int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
+  int (*CommCount)(void *, int *) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -526,6 +576,7 @@ int load_rccl() {
   PH_SYM(Recv, "ncclRecv")
   PH_SYM(GroupStart, "ncclGroupStart")
   PH_SYM(GroupEnd, "ncclGroupEnd")
+  PH_SYM(CommCount, "ncclCommCount")
   PH_SYM(GetErrorString, "ncclGetErrorString")
 #undef PH_SYM
   g_rccl.handle = h;
@@ -543,7 +594,33 @@ struct ph_route {
   void *comm;
   hipStream_t stream;
   int rank, world;
+  hipEvent_t last = nullptr;         // recorded behind the latest transfer enqueued on `stream`
+  bool in_group = false;
+  std::atomic<bool> busy{false};     // `last` may not have completed yet
 };
+
+extern "C++" {
+namespace {
+// Buffer lifetime against ROUTE (the source rank's `send(frame); frame.release()`): the pool hands a recycled block out
+// only after the three queues have been ordered behind every transfer enqueued so far.  Device-side waits only, and
+// only while a transfer is really in flight (hipEventQuery).  Called with ctx->mu held.
+void order_queues_after_routes(ph_ctx *ctx) {
+  for (ph_route *r : ctx->routes) {
+    if (!r->busy.load() || !r->last) continue;
+    if (hipEventQuery(r->last) == hipSuccess) {
+      r->busy.store(false);
+      continue;
+    }
+    for (int q = 0; q < 3; ++q) hipStreamWaitEvent(ctx->streams[q], r->last, 0);
+  }
+}
+int route_mark(ph_route *r) {  // a transfer has just been enqueued on the communication stream
+  PH_HIP(hipEventRecord(r->last, r->stream));
+  r->busy.store(true);
+  return PH_OK;
+}
+}  // namespace
+}  // extern "C++"
 
 int ph_route_unique_id(void *id128) {
   if (!id128) return fail(PH_E_INVALID, "ph_route_unique_id: NULL argument");
@@ -571,7 +648,20 @@ int ph_route_init(ph_ctx *ctx, const void *id128, int rank, int world, ph_route 
     g_rccl.CommDestroy(comm);
     return fail(PH_E_HIP, "ph_route_init: hipStreamCreate: %s", hipGetErrorString(e));
   }
-  *out = new ph_route{ctx, comm, s, rank, world};
+  hipEvent_t ev = nullptr;
+  e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    g_rccl.CommDestroy(comm);
+    hipStreamDestroy(s);
+    return fail(PH_E_HIP, "ph_route_init: hipEventCreate: %s", hipGetErrorString(e));
+  }
+  ph_route *r = new ph_route{ctx, comm, s, rank, world};
+  r->last = ev;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->routes.push_back(r);
+  }
+  *out = r;
   ctx_ref(ctx);
   return PH_OK;
 }
@@ -580,9 +670,18 @@ int ph_route_destroy(ph_route *r) {
   if (!r) return PH_OK;
   hipSetDevice(r->ctx->device);
   hipStreamSynchronize(r->stream);
+  ph_ctx *ctx = r->ctx;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    for (size_t i = 0; i < ctx->routes.size(); ++i)
+      if (ctx->routes[i] == r) {
+        ctx->routes.erase(ctx->routes.begin() + (long)i);
+        break;
+      }
+  }
   g_rccl.CommDestroy(r->comm);
   hipStreamDestroy(r->stream);
-  ph_ctx *ctx = r->ctx;
+  if (r->last) hipEventDestroy(r->last);
   delete r;
   ctx_unref(ctx);
   return PH_OK;
@@ -591,6 +690,7 @@ int ph_route_destroy(ph_route *r) {
 int ph_route_group_begin(ph_route *r) {
   if (!r) return fail(PH_E_INVALID, "ph_route_group_begin: NULL route");
   PH_NCCL(g_rccl.GroupStart());
+  r->in_group = true;
   return PH_OK;
 }
 int ph_route_group_end(ph_route *r) {
@@ -598,7 +698,8 @@ int ph_route_group_end(ph_route *r) {
   int rc = set_device(r->ctx);
   if (rc) return rc;
   PH_NCCL(g_rccl.GroupEnd());
-  return PH_OK;
+  r->in_group = false;
+  return route_mark(r);  // the group's transfers are on the stream now
 }
 
 static int route_args(ph_route *r, const void *p, size_t bytes, int peer, const char *fn) {
@@ -611,13 +712,13 @@ int ph_route_send(ph_route *r, const void *src, size_t bytes, int peer) {
   int rc = route_args(r, src, bytes, peer, "ph_route_send");
   if (rc) return rc;
   PH_NCCL(g_rccl.Send(src, bytes / 4, kNcclUint32, peer, r->comm, r->stream));
-  return PH_OK;
+  return r->in_group ? PH_OK : route_mark(r);
 }
 int ph_route_recv(ph_route *r, void *dst, size_t bytes, int peer) {
   int rc = route_args(r, dst, bytes, peer, "ph_route_recv");
   if (rc) return rc;
   PH_NCCL(g_rccl.Recv(dst, bytes / 4, kNcclUint32, peer, r->comm, r->stream));
-  return PH_OK;
+  return r->in_group ? PH_OK : route_mark(r);
 }
 
 static int order_streams(ph_ctx *ctx, hipStream_t waiter, hipStream_t signal, const char *fn) {
@@ -647,6 +748,11 @@ int ph_route_wait(ph_route *r) {
   return PH_OK;
 }
 void *ph_route_stream(ph_route *r) { return r ? (void *)r->stream : nullptr; }
+int ph_route_comm_count(ph_route *r, int *count) {
+  if (!r || !count) return fail(PH_E_INVALID, "ph_route_comm_count: NULL argument");
+  PH_NCCL(g_rccl.CommCount(r->comm, count));
+  return PH_OK;
+}
 
 int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes) {
   if (!ctx) return fail(PH_E_INVALID, "ph_ctx_buffer_stats: ctx is NULL");
@@ -1079,6 +1185,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
 
 int ph_run_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args, int queue, ph_run_timings *t) {
   if (!ctx || !prog || (n_args > 0 && !args)) return fail(PH_E_INVALID, "ph_run_program: NULL argument");
+  PH_QUEUE("ph_run_program", queue);
   int rc = set_device(ctx);
   if (rc) return rc;
   rc = flush_dirty_args(ctx, args, n_args, queue);
@@ -1117,6 +1224,7 @@ uint32_t ph_v210_pitch_bytes(uint32_t width) { return width ? ph::v210_pitch_byt
 #define PH_LAUNCH(expr)                                                                         \
   do {                                                                                          \
     if (!ctx) return fail(PH_E_INVALID, "%s: ctx is NULL", __func__);                           \
+    PH_QUEUE(__func__, queue);                                                                  \
     int rc_ = set_device(ctx);                                                                  \
     if (rc_) return rc_;                                                                        \
     hipError_t e_ = (expr);                                                                     \
@@ -1309,8 +1417,12 @@ static int compose_write(ph_ctx *ctx, int queue, int n, const ph_layer *layers, 
     }
   }
   a.out = out, a.out_w = out_w, a.out_h = out_h;
-  if (wipes && !ph::compose_can_wipe(a))
-    return fail(PH_E_INVALID, "ph_compose_wipe_write_v210: needs out_width %% 192 == 0 and source images below 2 GiB; run the separate kernels");
+  a.wr = *wv;  // the path choice depends on the table's size
+  bool any_wipe = false;  // a wipes array without a single entry set is the plain compositor (the header: such entries leave the layer alone)
+  for (int i = 0; i < n; ++i) any_wipe = any_wipe || a.wipe_with[i] != nullptr;
+  if (any_wipe && !ph::compose_can_wipe(a))
+    return fail(PH_E_INVALID, "ph_compose_wipe_write_v210: needs out_width %% 192 == 0, source images below 2 GiB and a writer table that leaves "
+                              "the staging area free in LDS; run the separate kernels");
   a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0;
   a.lines = interlace ? out_h / 2 : out_h;
   a.wr_cm = (const float *)wr_cm, a.wr = *wv;
@@ -1353,21 +1465,25 @@ int ph_fused_field_v210(ph_ctx *ctx, int queue, int n, const ph_field_layer *lay
   // the index frame between the two stages (6 bytes per pixel): one per context, grown on demand.  Successive calls on
   // different queues would share it - the field pipeline of a channel runs on one queue.
   const size_t need_bytes = ph::field_index_bytes(out_w, out_h);
-  {
-    int rc = set_device(ctx);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (ctx->field_scratch_bytes < need_bytes) {
-      if (ctx->field_scratch) {
-        for (int q = 0; q < 3; ++q) hipStreamSynchronize(ctx->streams[q]);
-        hipFree(ctx->field_scratch);
-        ctx->field_scratch = nullptr, ctx->field_scratch_bytes = 0;
-      }
-      PH_HIP(hipMalloc(&ctx->field_scratch, need_bytes));
-      ctx->field_scratch_bytes = need_bytes;
+  PH_QUEUE("ph_fused_field_v210", queue);
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  // The scratch is grown, read and handed to the launch under the lock, so a concurrent call that grows it cannot free
+  // it between this call's check and its launch.  A growth drains all three queues first; launches on DIFFERENT queues
+  // would still share the one scratch on the device - the field pipeline of a channel runs on one queue (header).
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (ctx->field_scratch_bytes < need_bytes) {
+    if (ctx->field_scratch) {
+      for (int q = 0; q < 3; ++q) hipStreamSynchronize(ctx->streams[q]);
+      hipFree(ctx->field_scratch);
+      ctx->field_scratch = nullptr, ctx->field_scratch_bytes = 0;
     }
+    PH_HIP(hipMalloc(&ctx->field_scratch, need_bytes));
+    ctx->field_scratch_bytes = need_bytes;
   }
-  PH_LAUNCH(ph::launch_field_compose_v210(stream_of(ctx, queue), a, ctx->field_scratch, (uint32_t)ctx->props.multiProcessorCount));
+  hipError_t e = ph::launch_field_compose_v210(stream_of(ctx, queue), a, ctx->field_scratch, (uint32_t)ctx->props.multiProcessorCount);
+  if (e != hipSuccess) return fail(PH_E_HIP, "ph_fused_field_v210: launch failed: %s", hipGetErrorString(e));
+  return PH_OK;
 }
 
 int ph_yadif(ph_ctx *ctx, int queue, const void *prev, const void *cur, const void *next, int w, int h, int parity,

@@ -839,7 +839,28 @@ static bool compose_taps_eligible(const ComposeArgs &a) {
   for (int l = 0; l < a.n; ++l) sampled = sampled || a.wipe_with[l] != nullptr;
   return sampled;  // all layers 1:1: the streaming kernel above is HBM-bound already
 }
-bool compose_can_wipe(const ComposeArgs &a) { return compose_taps_eligible(a); }
+// The launcher's real path choice: the buffer-addressed kernel needs the staging area behind the writer table (a table
+// blob within kComposeStageBytes of the 160 KiB does not leave room) and can be switched off for A/B runs.
+static bool compose_stage_fits(const ComposeArgs &a) { return ((a.wr.bytes + 15u) & ~15u) + kComposeStageBytes <= 160u * 1024u; }
+static bool compose_quad_forced() {
+  static const int quad_env = [] {
+    const char *e = getenv("PH_COMPOSE_QUAD");  // 1 = the quad-per-lane kernel (A/B runs)
+    return e ? atoi(e) : 0;
+  }();
+  return quad_env != 0;
+}
+static bool compose_taps_enabled() {
+  static const int taps_env = [] {
+    const char *e = getenv("PH_COMPOSE_TAPS");  // 0 = the pointer-addressed sampler (A/B runs)
+    return e ? atoi(e) : 1;
+  }();
+  return taps_env != 0;
+}
+static bool compose_uses_taps(const ComposeArgs &a) {
+  return !compose_quad_forced() && compose_stage_fits(a) && compose_taps_enabled() && compose_taps_eligible(a);
+}
+// only the buffer-addressed kernel reads wipe_with / wipe_mask: a wipe job is served iff the launcher will pick it
+bool compose_can_wipe(const ComposeArgs &a) { return compose_uses_taps(a); }
 
 template <int N, bool ALL_DIRECT>
 static hipError_t launch_compose_px_nd(hipStream_t s, const ComposeArgs &a, uint32_t grid, uint32_t stage_off) {
@@ -918,21 +939,16 @@ hipError_t launch_fused_v210_combine_lds(hipStream_t s, int n, const FusedLdsArg
 hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32_t num_cus) {
   const uint32_t total = a.out_w / 6 * a.lines;
   if (!total) return hipSuccess;
-  static const int quad_env = [] {
-    const char *e = getenv("PH_COMPOSE_QUAD");  // 1 = the quad-per-lane kernel (A/B runs)
-    return e ? atoi(e) : 0;
-  }();
+  bool any_wipe = false;
+  for (int l = 0; l < a.n; ++l) any_wipe = any_wipe || a.wipe_with[l] != nullptr;
+  if (any_wipe && !compose_uses_taps(a)) return hipErrorInvalidValue;  // no other kernel applies the wipes: never drop them silently
   // pixel-per-lane form: needs the staging area behind the table (160 KiB of LDS per workgroup)
   const uint32_t stage_off = (a.wr.bytes + 15u) & ~15u;
-  if (!quad_env && stage_off + kComposeStageBytes <= 160u * 1024u) {
+  if (!compose_quad_forced() && compose_stage_fits(a)) {
     const uint32_t chunks = (a.out_w * a.lines + kComposeChunk - 1) / kComposeChunk;
     const uint32_t want = (chunks + kLdsBlock / 64 - 1) / (kLdsBlock / 64);
     const uint32_t grid = want < num_cus ? want : num_cus;
-    static const int taps_env = [] {
-      const char *e = getenv("PH_COMPOSE_TAPS");  // 0 = the pointer-addressed sampler (A/B runs)
-      return e ? atoi(e) : 1;
-    }();
-    if (taps_env && compose_taps_eligible(a)) {
+    if (compose_uses_taps(a)) {
       switch (a.n) {
         case 1: return launch_compose_taps_n<1>(s, a, grid, stage_off);
         case 2: return launch_compose_taps_n<2>(s, a, grid, stage_off);

@@ -169,7 +169,15 @@ int resolve_program(const char *src, const char *name, ProgramChoice &c, std::st
   }
   const int how = tagged ? PH_RESOLVED_BY_TAG : PH_RESOLVED_BY_NAME;
   auto layers = [&](const char *prefix, int lo, KernelId id) {
-    const int n = atoi(name + strlen(prefix));
+    // the whole suffix must be the layer count: "combine_4x" is not combine_4
+    const char *digits = name + strlen(prefix);
+    char *end = nullptr;
+    const long parsed = strtol(digits, &end, 10);
+    if (end == digits || *end != '\0' || digits[0] < '0' || digits[0] > '9') {
+      err = std::string("unknown kernel '") + name + "' (" + prefix + "<n> takes a plain layer count)";
+      return (int)PH_E_UNKNOWN_KERNEL;
+    }
+    const int n = parsed > 1000 ? 1000 : (int)parsed;
     if (n < lo || n > kMaxLayers) {
       char b[96];
       snprintf(b, sizeof b, "%s%d: %d..%d layers are built", prefix, n, lo, kMaxLayers);

@@ -25,6 +25,7 @@ def check_line(line, n_gpus, steps, warmup):
     assert line["n_gpus"] == n_gpus and line["steps"] == steps and line["warmup"] == warmup
     assert line["dtype"] == "f32" and line["data"] == "synthetic" and line["vs_baseline"] is None
     assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["fixed_warmup"] >= 200  # the untimed launches in front of --warmup are stated in the line
     assert abs(line["value"] - n_gpus * 1e3 / line["ms_per_step"]) < 0.02 * line["value"]
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
@@ -45,14 +46,30 @@ def test_default_line_as_the_driver_runs_it():
     cb = line["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert line["value"] > 100 * cb["value"]
+    # roofline.traffic is measured in the run when rocprofv3 is there (two --pmc child passes), and says so
+    import shutil
+    rf = line["roofline"]
+    if shutil.which("rocprofv3"):
+        assert rf["traffic_source"].startswith("measured in this run"), rf.get("traffic_not_measured")
+        assert 0.95 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.25, rf
+    else:
+        assert rf["traffic_source"].startswith("recorded")
 
 
 def test_rank_path_under_torchrun_with_rccl_on_one_gpu():
     """one rank started the way the driver starts N: the RCCL process group, barrier and all-reduce run for real"""
     line = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                 "--master-port", "29571", "bench.py", "--gpus", "1", "--steps", "30", "--warmup", "5", "--cpu-seconds", "0", "--no-secondary"],
-               {"PH_BENCH_FORCE_DIST": "1"})
+               {"PH_BENCH_FORCE_DIST": "1", "PH_BENCH_ROUTE_HEIGHT": "540"})
     check_line(line, 1, 30, 5)
+    # the distributed path carries BASELINE config 5 in the same line: 2 channels per rank, every fourth layer routed
+    # through ph_route_* (RCCL; with one rank the peer is the own rank), checked by fingerprint
+    rt = line["route"]
+    assert rt.get("error") is None, rt
+    assert rt["fingerprint_check"] == "ok" and rt["rccl_ranks_in_communicator"] == 1 and rt["ranks"] == 1
+    assert rt["channels"] == 2 and rt["routes_crossing_ranks_per_rank"] == 2
+    assert rt["bytes_per_hop"] == 3840 * 540 * 16 and rt["route_bytes_per_rank_per_step"] == 4 * rt["bytes_per_hop"]
+    assert rt["hop_ms_unoverlapped"] > 0 and rt["frames_per_sec"] > 0 and rt["path"].startswith("ph_route")
 
 
 def test_two_ranks_sum_their_frames():

@@ -267,3 +267,18 @@ def test_handles_outlive_their_context_in_any_order():
     b2 = c2.create_buffer(1 << 20)
     b2.release()
     c2.close()
+
+
+def test_out_of_range_queue_is_refused(ctx):
+    """a queue index that is not load / process / unload is an error everywhere, never a silent alias of `process`"""
+    with pytest.raises(capi.PhaneronError, match="queue 7"):
+        ctx.wait(7)
+    with pytest.raises(capi.PhaneronError, match="queue -1"):
+        ctx.queue_idle(-1)
+    assert not capi.lib().ph_ctx_stream(ctx.h, 3)
+    b = ctx.create_buffer(64)
+    with pytest.raises(capi.PhaneronError, match="queue 3"):
+        b.host_access("writeonly", 3, np.zeros(64, np.uint8))
+    with pytest.raises(capi.PhaneronError, match="queue 5"):
+        ctx.transition_dissolve(b.device_ptr(), b.device_ptr(), 0.5, b.device_ptr(), 2, 2, queue=5)
+    b.release()

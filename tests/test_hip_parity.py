@@ -465,6 +465,18 @@ def test_fused_equals_unfused_kernels_2160p():
     torch.cuda.synchronize()
     assert torch.equal(fused, unfused)
     assert torch.equal(fused, top)
+    # and against the CPU side at the full size, every word: the reference's own kernels compiled for x86 (oracle/_ref,
+    # ~1 s for 4 x 2160p on the host threads) when that build travelled with the snapshot, the oracle's restatement if not
+    hl = [frames.v210_random(w, h, frames.layer_seed(0, i)) for i in range(n)]
+    colour = (orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"),
+              orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    if orc.have_ref_fast():
+        r = orc.ref_fast()
+        r.ref_set_num_threads(orc.effective_cpus())
+        want = orc.ref_pipeline_v210_combine(r, hl, w, h, *colour)
+    else:
+        want = orc.pipeline_v210_combine(hl, w, h, *colour)
+    assert np.array_equal(hh.host(fused, np.uint32), np.asarray(want).view(np.uint32).reshape(-1)), "fused 4 x 2160p differs from the CPU side"
 
 
 @pytest.mark.parametrize("w,h,n", [(7680, 4320, 2), (7680, 1082, 3), (48, 1, 3), (96, 3, 4)])

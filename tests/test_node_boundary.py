@@ -90,6 +90,10 @@ def test_job_board_keeps_the_dispatcher_contract():
         assert r["device"][-1] == "wait" and r["stats"]["kernels"] == 4 and r["stats"]["flushes"] == 3
     assert d["oneByOne"]["device"] == [f32(0.2), "wait", f32(0.1), f32(0.1), "wait", f32(0.3), "wait"]
     assert d["coalesced"]["device"] == [f32(0.2), f32(0.1), f32(0.1), "wait", f32(0.3), "wait"]  # two flushes, one drain
+    # a rejecting waitFinish fails every flush of the drain, a failing job fails its own flush only (the job behind it is
+    # skipped); in both cases every completion callback fires and the board serves the next flush
+    assert d["failures"] == dict(outcome=["device lost", "device lost"], outcome2=["bad launch", "ok"], after="ok",
+                                 fired=["A1", "B2", "C3a", "C3b", "D4", "E5"], pumpIdle=True)
     # the channel compositor's parameter mapping (mixer.ts:209-223, transitioner.ts:170,269)
     assert d["placement"] == dict(flipH=False, flipV=False, anchorX=-0.25, anchorY=0.25, scaleX=0.5, scaleY=0.5,
                                   rotate=-30 / 360.0, offsetX=-0.25, offsetY=0.125)

@@ -62,3 +62,37 @@ def test_routes_cross_ranks_world_2():
     # each rank sends its two channels' outputs and receives two: 4 frames of 1920x270 f32 RGBA per step
     assert line["routes_crossing_ranks_per_rank"] == 2
     assert line["route_bytes_per_rank_per_step"] == 4 * 1920 * 270 * 16
+
+
+def test_release_right_after_send_keeps_the_routed_frame_intact():
+    """The source rank's `send(frame); frame.release()`: the block goes back to the pool and the very next
+    createBuffer of that size gets it - its first writer must still run AFTER RCCL has read the frame.  The pool orders
+    the queues behind the transfers in flight before it hands a recycled block out."""
+    import numpy as np
+    from phaneron_amd import capi
+    ctx = capi.Context(0)
+    route = capi.Route(ctx, capi.route_unique_id(), 0, 1)
+    assert route.comm_count() == 1
+    n = 96 << 20
+    for attempt in range(3):
+        frame = (np.arange(n // 4, dtype=np.uint32) * np.uint32(2654435761 + attempt)).view(np.uint8)
+        src = ctx.create_buffer(n)
+        dst = ctx.create_buffer(n + 4096)             # another size: never the recycled block
+        src.host_access("writeonly", capi.QUEUE_LOAD, frame)
+        route.after_queue(capi.QUEUE_LOAD)
+        with route.group():
+            route.send(src.device_ptr(), 0, n)
+            route.recv(dst.device_ptr(), 0, n)
+        block = src.device_ptr()
+        src.release()                                 # right after the send, as a channel does
+        again = ctx.create_buffer(n)
+        assert again.device_ptr() == block            # the pool handed the same block out ...
+        again.host_access("writeonly", capi.QUEUE_LOAD, np.full(n, 0xEE, np.uint8))  # ... and its new owner overwrites it at once
+        route.wait()
+        ctx.wait(capi.QUEUE_LOAD)
+        dst.host_access("readonly", capi.QUEUE_UNLOAD)
+        ctx.wait(capi.QUEUE_UNLOAD)
+        assert np.array_equal(dst.host()[:n], frame), "attempt %d: the routed frame was overwritten under the transfer" % attempt
+        again.release(), dst.release()
+    route.destroy()
+    ctx.close()

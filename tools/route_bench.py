@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--channels-per-gpu", type=int, default=2)
     ap.add_argument("--steps", type=int, default=100)
@@ -38,11 +38,12 @@ def main():
     ap.add_argument("--check", action="store_true", help="verify (bit for bit) that a routed layer is the source channel's output")
     ap.add_argument("--print-fingerprints", action="store_true", help="print a fingerprint of every channel's final v210 output")
     ap.add_argument("--loopback", action="store_true", help="send same-rank routes through RCCL too (peer = own rank)")
-    args = ap.parse_args()
-    import numpy as np
-    import torch
-    from phaneron_amd import capi, multigpu
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse()
+    import torch
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -52,11 +53,26 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.backend, **({"device_id": device} if args.backend == "nccl" else {}))
+    from phaneron_amd import capi
+    ctx = capi.Context(local)
+    rec = measure(args, ctx, dist, rank, world, device)
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def measure(args, ctx, dist, rank, world, device, log=lambda m: print(m, flush=True)):
+    """Config 5 on an existing context / process group (bench.py --gpus N calls this for its `route` entry).
+    Returns the record (meaningful on rank 0); `log` receives the check / fingerprint lines."""
+    import numpy as np
+    import torch
+    from phaneron_amd import capi, multigpu
     w, h, C = args.width, args.height, args.channels_per_gpu
     total = world * C
     mine = multigpu.channels_of_rank(rank, total, world, C)
     routes = [multigpu.Route(src=(k + total // 2) % total, dst=k) for k in range(total)]
-    ctx = capi.Context(local)
     words, npx = capi.v210_pitch_bytes(w) * h // 4, w * h
 
     def dev(a):
@@ -115,6 +131,7 @@ def main():
         ctx.wait()
         torch.cuda.synchronize()
 
+    checked = False
     if args.check:  # by hand: what arrives as channel k's routed layer is, bit for bit, channel src(k)'s output
         step(0)
         sync()
@@ -139,30 +156,46 @@ def main():
             got = multigpu.frame_fingerprint(routed[ch])
             assert got == int(prints[src]), (ch, src, got, int(prints[src]))
             assert on_device or world > 1 or routed[ch] is chan[src]["out"][0]
+        checked = True
         if rank == 0:
-            print("route check ok: %d channels on %d rank(s), %s" % (total, world, "ph_route (RCCL)" if on_device else
-                  "torch.distributed" if world > 1 else "local alias"), flush=True)
+            log("route check ok: %d channels on %d rank(s), %s" % (total, world, "ph_route (RCCL)" if on_device else
+                "torch.distributed" if world > 1 else "local alias"))
+    # one hand-off alone (nothing to overlap with): what a hop costs when the sink has to wait for it
+    hop_ms = None
+    if on_device and (ex.plan.sends or ex.plan.recvs):
+        sync()
+        for rep in range(4):
+            if rep == 1:
+                sync()
+                t0 = time.perf_counter()
+            ex.start({ch: chan[ch]["out"][0] for ch in mine})
+            ex.finish()
+        sync()
+        hop_ms = 1e3 * (time.perf_counter() - t0) / 3
     exch_s[0] = 0.0
     elapsed = multigpu.timed_steps(step, args.steps, args.warmup, sync, dist, device if args.backend == "nccl" else None)
-    if rank == 0:
-        fps = total * args.steps / elapsed
-        per_step_exch = exch_s[0] / (args.steps + args.warmup)
-        print(json.dumps({
-            "workload": "config 5: %d channels of %dx%d on %d GPU(s), 3 v210 layers + 1 routed RGBA layer each" % (total, w, h, world),
-            "frames_per_sec": round(fps, 1), "steps": args.steps, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "routes_crossing_ranks_per_rank": len(ex.plan.sends), "route_bytes_per_rank_per_step": ex.traffic_bytes(),
-            "exchange_ms_per_step_rank0": round(1e3 * per_step_exch, 3),
-            "exchange_GBps_rank0": round(ex.traffic_bytes() / per_step_exch / 1e9, 1) if per_step_exch > 0 and ex.traffic_bytes() else None,
-            "path": "ph_route: RCCL on its own stream, event-ordered, overlapped with the v210 reads" if on_device else
-                    ("torch.distributed %s, host-synchronised" % args.backend) if world > 1 else "single rank: routes alias local buffers"}), flush=True)
+    fps = total * args.steps / elapsed
+    per_step_exch = exch_s[0] / (args.steps + args.warmup)
+    rec = {
+        "workload": "config 5: %d channels of %dx%d on %d GPU(s), 3 v210 layers + 1 routed RGBA layer each" % (total, w, h, world),
+        "frames_per_sec": round(fps, 1), "steps": args.steps, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "channels": total, "channels_per_gpu": C, "ranks": world,
+        "routes_crossing_ranks_per_rank": len(ex.plan.sends), "route_bytes_per_rank_per_step": ex.traffic_bytes(),
+        "bytes_per_hop": npx * 16,
+        "hop_ms_unoverlapped": round(hop_ms, 3) if hop_ms is not None else None,
+        "hop_GBps_unoverlapped": round(ex.traffic_bytes() / (hop_ms * 1e-3) / 1e9, 1) if hop_ms else None,
+        "rccl_ranks_in_communicator": ex.route.comm_count() if on_device else None,
+        "fingerprint_check": "ok" if checked else "not run",
+        "exchange_ms_per_step_rank0": round(1e3 * per_step_exch, 3),
+        "exchange_GBps_rank0": round(ex.traffic_bytes() / per_step_exch / 1e9, 1) if per_step_exch > 0 and ex.traffic_bytes() else None,
+        "path": "ph_route: RCCL on its own stream, event-ordered, overlapped with the v210 reads" if on_device else
+                ("torch.distributed %s, host-synchronised" % args.backend) if world > 1 else "single rank: routes alias local buffers"}
     if args.print_fingerprints:
         sync()
-        print("fingerprints rank %d: %s" % (rank, " ".join("%d:%x" % (ch, multigpu.frame_fingerprint(chan[ch]["v210"]) & (2 ** 64 - 1)) for ch in mine)), flush=True)
+        log("fingerprints rank %d: %s" % (rank, " ".join("%d:%x" % (ch, multigpu.frame_fingerprint(chan[ch]["v210"]) & (2 ** 64 - 1)) for ch in mine)))
     if on_device:
         ex.close()
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return rec
 
 
 if __name__ == "__main__":
