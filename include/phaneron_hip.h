@@ -331,6 +331,39 @@ int ph_compose_wipe_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *la
                                void *out, uint32_t out_width, uint32_t out_height, uint32_t interlace,
                                const void *wr_col_matrix12, const void *wr_gamma_lut);
 
+/* ---- the channel compositor straight from the wire format (no single reference equivalent): a channel's whole
+ *      per-frame job batch - per layer ToRGBA (io.ts:79-98, v210.ts:25-111) -> Mixer transform (producer/mixer.ts:
+ *      209-223, transform.ts:36-59) -> optionally the Transitioner's dissolve / wipe against a second source
+ *      (transitioner.ts:165-176, transition.ts:54-79) -> combine_N (combiner.ts:219-254) -> FromRGBA (io.ts:152-164,
+ *      v210.ts:113-195) - as ONE kernel that samples the v210 words themselves: each bilinear tap is unpacked,
+ *      matrixed, gamma-looked-up and gamut-converted on the fly, so no f32 frame reaches HBM at all.  Bit-identical
+ *      to ph_v210_read + ph_transform (+ ph_transition_dissolve / ph_transition_wipe) + ph_combine + ph_v210_write.
+ *      A source is a v210 frame or (e.g. a routed frame, a generated mask) an f32 RGBA image; with matrix9_host ==
+ *      NULL it is taken 1:1 and must have the output size.  All v210 sources share the reader's colour recipe.
+ *      Limits (PH_E_INVALID otherwise - run the separate kernels): out_width % 192 == 0, v210 source widths % 6 == 0,
+ *      frames below 1 GiB, both gamma LUTs registered (LDS form).  interlace as ph_v210_write. ------------------ */
+#define PH_SRC_NONE 0
+#define PH_SRC_V210 1
+#define PH_SRC_RGBA_F32 2
+typedef struct ph_chan_source {
+  const void *data;          /* device: v210 words (pitch ph_v210_pitch_bytes(width)) or float RGBA, width x height */
+  int format;                /* PH_SRC_V210 | PH_SRC_RGBA_F32 (PH_SRC_NONE: absent) */
+  int width, height;
+  const float *matrix9_host; /* HOST: the nine values of ph_transform_matrix, or NULL = 1:1 */
+} ph_chan_source;
+#define PH_TRANSITION_CUT 0
+#define PH_TRANSITION_DISSOLVE 1 /* fma(src, mix, incoming * (1 - mix))            transition.ts:58-64 */
+#define PH_TRANSITION_WIPE 2     /* fma(incoming, mask.r, src * (1 - mask.r))      transition.ts:66-77 */
+typedef struct ph_chan_layer {
+  ph_chan_source src;
+  int transition;
+  float mix;                     /* dissolve */
+  ph_chan_source incoming, mask; /* the transition's second source and (wipe) its mask */
+} ph_chan_layer;
+int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, void *out, uint32_t out_width,
+                         uint32_t out_height, uint32_t interlace, const void *rd_col_matrix12, const void *rd_gamma_lut,
+                         const void *rd_gamut9, const void *wr_col_matrix12, const void *wr_gamma_lut);
+
 /* ---- fused field pipeline (no single reference equivalent): the per-field job batch of a de-interlacing,
  *      scaling channel - Yadif per layer (yadif.ts:115-145) -> transform per layer (producer/mixer.ts:209-223)
  *      -> combine_N (combiner.ts:219-254) -> v210 write (io.ts:152-164) - as ONE kernel: de-interlaced source

@@ -6,6 +6,7 @@ library or a failing call raises PhaneronError.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -32,7 +33,7 @@ EXPORTS = [
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
     "ph_program_resolve", "ph_fused_field_v210", "ph_route_unique_id", "ph_route_init", "ph_route_destroy", "ph_route_group_begin",
     "ph_route_group_end", "ph_route_send", "ph_route_recv", "ph_route_after_queue", "ph_queue_after_route",
-    "ph_route_wait", "ph_route_stream", "ph_route_comm_count",
+    "ph_route_wait", "ph_route_stream", "ph_route_comm_count", "ph_chan_compose_v210",
 ]
 
 
@@ -66,6 +67,19 @@ class PhFieldLayer(C.Structure):
                 ("parity", C.c_int), ("tff", C.c_int), ("skip_spatial", C.c_int)]
 
 
+class PhChanSource(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("format", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("matrix9_host", C.POINTER(C.c_float))]
+
+
+class PhChanLayer(C.Structure):
+    _fields_ = [("src", PhChanSource), ("transition", C.c_int), ("mix", C.c_float), ("incoming", PhChanSource), ("mask", PhChanSource)]
+
+
+SRC_V210, SRC_RGBA_F32 = 1, 2
+TRANSITION_CUT, TRANSITION_DISSOLVE, TRANSITION_WIPE = 0, 1, 2
+
+
 class RunTimings(C.Structure):
     _fields_ = [("data_to_kernel", C.c_uint32), ("kernel_exec", C.c_uint32), ("total_time", C.c_uint32)]
 
@@ -81,6 +95,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise PhaneronError("%s is missing: build it with `python -m phaneron_amd.build` "
                             "(there is no CPU fallback)" % LIB_PATH)
+    # A process that also uses PyTorch must bring torch's bundled HIP runtime in FIRST: loaded the other way round
+    # (this library's /opt/rocm libamdhip64, then torch on top of it) the second runtime finds no device
+    # ("no ROCm-capable device is detected" - seen on the GPU box with a test that called a host-maths function
+    # before importing torch).  PyTorch is only the tests' and bench's device-memory plumbing; a process without it (the
+    # node addon, a C caller) never takes this branch.  PH_NO_TORCH_PRELOAD=1 skips it.
+    if "torch" not in sys.modules and os.environ.get("PH_NO_TORCH_PRELOAD") != "1":
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     l = C.CDLL(LIB_PATH)
     vp, ci, cu, cf, cd, cs = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_double, C.c_size_t
     f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -151,6 +174,7 @@ def lib():
         "ph_compose_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), vp, cu, cu, cu, vp, vp]),
         "ph_compose_wipe_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), C.POINTER(PhLayerWipe), vp, cu, cu, cu, vp, vp]),
         "ph_fused_field_v210": (ci, [vp, ci, ci, C.POINTER(PhFieldLayer), vp, cu, cu, vp, vp]),
+        "ph_chan_compose_v210": (ci, [vp, ci, ci, C.POINTER(PhChanLayer), vp, cu, cu, cu, vp, vp, vp, vp, vp]),
         "ph_route_unique_id": (ci, [vp]),
         "ph_route_init": (ci, [vp, vp, ci, ci, C.POINTER(vp)]),
         "ph_route_destroy": (ci, [vp]),
@@ -400,6 +424,41 @@ class Context:
                 wp[i].mask_rgba = _ptr(wv[1]).value if wv[1] is not None else None
         check(lib().ph_compose_wipe_write_v210(self.h, queue, len(layers), arr, wp, _ptr(dst), out_w, out_h, interlace,
                                                _ptr(wr_cm), _ptr(wr_lut)), self.h)
+
+    def chan_compose_v210(self, layers, dst, out_w, out_h, interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut, queue=QUEUE_PROCESS,
+                          prepare_only=False):
+        """The channel compositor straight from v210 sources (ph_chan_compose_v210).  layers: list of dicts
+        {src: SOURCE, transition: "cut" | "dissolve" | "wipe", mix: float, incoming: SOURCE, mask: SOURCE}; a SOURCE is
+        (tensor, width, height, matrix) or (tensor, width, height, matrix, "rgba") - matrix: nine host floats
+        (transform_matrix) or None for 1:1; format v210 unless "rgba" (f32 RGBA image)."""
+        import numpy as np
+        arr = (PhChanLayer * len(layers))()
+        keep = []
+
+        def fill(dst_src, spec):
+            t, w, h, m = spec[:4]
+            dst_src.data, dst_src.width, dst_src.height = _ptr(t).value, w, h
+            dst_src.format = SRC_RGBA_F32 if (len(spec) > 4 and spec[4] == "rgba") else SRC_V210
+            if m is not None:
+                mh = np.ascontiguousarray(m, np.float32)
+                keep.append(mh)
+                dst_src.matrix9_host = mh.ctypes.data_as(C.POINTER(C.c_float))
+        for i, L in enumerate(layers):
+            fill(arr[i].src, L["src"])
+            arr[i].transition = {"cut": TRANSITION_CUT, "dissolve": TRANSITION_DISSOLVE, "wipe": TRANSITION_WIPE}[L.get("transition", "cut")]
+            arr[i].mix = float(L.get("mix", 0.0))
+            if L.get("incoming") is not None:
+                fill(arr[i].incoming, L["incoming"])
+            if L.get("mask") is not None:
+                fill(arr[i].mask, L["mask"])
+        args = (self.h, queue, len(layers), arr, _ptr(dst), out_w, out_h, interlace, _ptr(rd_cm), _ptr(rd_lut), _ptr(rd_gm), _ptr(wr_cm), _ptr(wr_lut))
+        if prepare_only:  # a caller that replays the same job (a bench loop) skips the marshalling: job() launches it
+            fn, h = lib().ph_chan_compose_v210, self.h
+
+            def job(_keep=(keep, layers, dst)):
+                check(fn(*args), h)
+            return job
+        check(lib().ph_chan_compose_v210(*args), self.h)
 
     def fused_field_v210(self, layers, dst, out_w, out_h, wr_cm, wr_lut, queue=QUEUE_PROCESS):
         """layers: list of dicts {prev, cur, next (tensors; prev / next None for a progressive source), width, height,

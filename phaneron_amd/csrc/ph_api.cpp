@@ -67,6 +67,8 @@ struct ph_ctx {
   size_t pooled_bytes = 0, live_buffers = 0, live_bytes = 0;
   void *field_scratch = nullptr;  // index frame of the field pipeline (ph_fused_field_v210)
   size_t field_scratch_bytes = 0;
+  void *chan_index[3] = {nullptr, nullptr, nullptr};  // index frame of the channel compositor, one per queue (ph_chan_compose_v210)
+  size_t chan_index_bytes[3] = {0, 0, 0};
   std::vector<struct ph_route *> routes;  // open ROUTEs: a recycled block must not be handed out under a transfer in flight
   std::mutex mu;
   std::atomic<int> refs{1};
@@ -183,6 +185,8 @@ void ctx_unref(ph_ctx *ctx) {
   for (auto &kv : ctx->luts)
     if (kv.second.blob_dev) hipFree(kv.second.blob_dev);
   if (ctx->field_scratch) hipFree(ctx->field_scratch);
+  for (int i = 0; i < 3; ++i)
+    if (ctx->chan_index[i]) hipFree(ctx->chan_index[i]);
   delete ctx;
 }
 
@@ -1428,6 +1432,79 @@ static int compose_write(ph_ctx *ctx, int queue, int n, const ph_layer *layers, 
   a.wr_cm = (const float *)wr_cm, a.wr = *wv;
   if (!a.lines) return PH_OK;
   PH_LAUNCH(ph::launch_compose_write_v210(stream_of(ctx, queue), a, (uint32_t)ctx->props.multiProcessorCount));
+}
+
+static int chan_source(const ph_chan_source &s, const char *what, int layer, uint32_t out_w, uint32_t out_h, ph::ChanSrc *o) {
+  if (!s.data || s.width <= 0 || s.height <= 0)
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is empty", layer, what);
+  if (s.format != PH_SRC_V210 && s.format != PH_SRC_RGBA_F32)
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has format %d (PH_SRC_V210 or PH_SRC_RGBA_F32)", layer, what, s.format);
+  if (s.format == PH_SRC_V210 && s.width % 6)
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is a v210 frame %d wide, not a multiple of 6; run the separate kernels", layer, what, s.width);
+  if (!s.matrix9_host && ((uint32_t)s.width != out_w || (uint32_t)s.height != out_h))
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has no transform but is %dx%d, not the output size", layer, what, s.width, s.height);
+  o->ptr = s.data, o->w = (uint32_t)s.width, o->h = (uint32_t)s.height;
+  o->kind = s.format == PH_SRC_V210 ? ph::kChanV210 : ph::kChanRgba;
+  o->pitch = s.format == PH_SRC_V210 ? ph_v210_pitch_bytes((uint32_t)s.width) : (uint32_t)s.width * 16u;
+  if ((uint64_t)o->pitch * o->h >= (1ull << 30))
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is 1 GiB or larger; run the separate kernels", layer, what);
+  o->sampled = s.matrix9_host ? 1u : 0u;
+  for (int i = 0; i < 6; ++i) o->m[i] = s.matrix9_host ? s.matrix9_host[i] : 0.0f;
+  return PH_OK;
+}
+
+int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
+                         uint32_t interlace, const void *rd_cm, const void *rd_lut, const void *rd_gm, const void *wr_cm,
+                         const void *wr_lut) {
+  if (!ctx || !layers || !out || !rd_cm || !rd_lut || !rd_gm || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_chan_compose_v210: NULL argument");
+  PH_QUEUE("ph_chan_compose_v210", queue);
+  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_chan_compose_v210: 1..%d layers", ph::kMaxLayers);
+  if (!out_w || out_w % 192) return fail(PH_E_INVALID, "ph_chan_compose_v210: width %u is not a multiple of 192; run the separate kernels", out_w);
+  if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_chan_compose_v210: interlace must be 0, 1 or 3");
+  const ph::LutView *rv = lds_view(ctx, rd_lut), *wv = lds_view(ctx, wr_lut);
+  if (!rv || !wv)
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: the %s gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)", rv ? "writer" : "reader");
+  ph::ChanArgs a{};
+  a.n = n;
+  for (int i = 0; i < n; ++i) {
+    const ph_chan_layer &L = layers[i];
+    int rc = chan_source(L.src, "source", i, out_w, out_h, &a.layer[i].src);
+    if (rc) return rc;
+    if (L.transition != PH_TRANSITION_CUT && L.transition != PH_TRANSITION_DISSOLVE && L.transition != PH_TRANSITION_WIPE)
+      return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: transition %d", i, L.transition);
+    a.layer[i].transition = (uint32_t)L.transition, a.layer[i].mix = L.mix;
+    if (L.transition != PH_TRANSITION_CUT) {
+      rc = chan_source(L.incoming, "transition's incoming source", i, out_w, out_h, &a.layer[i].incoming);
+      if (rc) return rc;
+    }
+    if (L.transition == PH_TRANSITION_WIPE) {
+      rc = chan_source(L.mask, "wipe's mask", i, out_w, out_h, &a.layer[i].mask);
+      if (rc) return rc;
+    }
+  }
+  a.out = out, a.out_w = out_w, a.out_h = out_h;
+  a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0;
+  a.lines = interlace ? out_h / 2 : out_h;
+  a.rd_cm = (const float *)rd_cm, a.rd_gm = (const float *)rd_gm, a.wr_cm = (const float *)wr_cm, a.rd = *rv, a.wr = *wv;
+  if (!a.lines) return PH_OK;
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  // the index frame between the phases: one per queue (launches on one queue are in order), grown on demand
+  const size_t need = ph::chan_index_bytes(out_w, a.lines);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (ctx->chan_index_bytes[queue] < need) {
+    if (ctx->chan_index[queue]) {
+      hipStreamSynchronize(ctx->streams[queue]);
+      hipFree(ctx->chan_index[queue]);
+      ctx->chan_index[queue] = nullptr, ctx->chan_index_bytes[queue] = 0;
+    }
+    PH_HIP(hipMalloc(&ctx->chan_index[queue], need));
+    ctx->chan_index_bytes[queue] = need;
+  }
+  a.index = ctx->chan_index[queue];
+  hipError_t e = ph::launch_chan_compose_v210(stream_of(ctx, queue), a, (uint32_t)ctx->props.multiProcessorCount);
+  if (e != hipSuccess) return fail(PH_E_HIP, "ph_chan_compose_v210: launch failed: %s", hipGetErrorString(e));
+  return PH_OK;
 }
 
 int ph_fused_field_v210(ph_ctx *ctx, int queue, int n, const ph_field_layer *layers, void *out, uint32_t out_w, uint32_t out_h,

@@ -53,6 +53,32 @@ struct ComposeArgs {
   LutView wr;
 };
 
+// ph_kernels_chan.hip: the compositor that samples v210 sources directly
+enum : uint32_t { kChanNone = 0, kChanV210 = 1, kChanRgba = 2 };
+enum : uint32_t { kChanCut = 0, kChanDissolve = 1, kChanWipe = 2 };
+struct ChanSrc {
+  const void *ptr;
+  uint32_t w, h, pitch;  // pixels, pixels, bytes per line
+  uint32_t kind;         // kChanV210 / kChanRgba (kChanNone: absent)
+  uint32_t sampled;      // 1 = through m (transform.ts:53-57), 0 = pixel for pixel
+  uint32_t pad;
+  float m[6];            // rows 0 and 1 of the 3x3 transform matrix
+};
+struct ChanLayer {
+  ChanSrc src, incoming, mask;
+  uint32_t transition;
+  float mix;
+};
+struct ChanArgs {
+  ChanLayer layer[kMaxLayers];
+  int n;
+  void *out;
+  void *index;  // scratch: 8 bytes per output pixel (chan_index_bytes)
+  uint32_t out_w, out_h, lines, first_line, line_step;
+  const float *rd_cm, *rd_gm, *wr_cm;
+  LutView rd, wr;
+};
+
 struct DeintArgs {  // ph_kernels_deint.hip
   const uint4 *prev[kMaxLayers], *cur[kMaxLayers], *next[kMaxLayers];  // v210 frames, width x height
   float4 *out0[kMaxLayers], *out1[kMaxLayers];                         // RGBA f32: yadif parity 0 / parity 1
@@ -110,6 +136,8 @@ hipError_t launch_pack_write(hipStream_t s, int fmt, const void *in, void *const
                              uint32_t height, uint32_t interlace, const void *cm, const void *table, const LutView *lv,
                              uint32_t num_cus);
 hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32_t num_cus);
+size_t chan_index_bytes(uint32_t out_w, uint32_t lines);
+hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t num_cus);
 bool compose_can_wipe(const ComposeArgs &a);  // the buffer-addressed compositor serves this job (needed for wipe layers)
 uint32_t field_index_bytes(uint32_t out_w, uint32_t out_h);  // scratch the two-stage field pipeline needs (6 bytes per pixel)
 hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t num_cus);

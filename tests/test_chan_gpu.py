@@ -1,0 +1,229 @@
+"""GPU tests (-m gpu) of ph_chan_compose_v210: a channel's whole frame - ToRGBA -> Mixer transform -> (Transitioner
+dissolve / wipe) -> combine_N -> FromRGBA - as one kernel that samples the v210 words directly.  Every case is compared,
+word for word, with the oracle's chain of the reference's operators (v210.ts read, transform.ts, transition.ts,
+combine.ts, v210.ts write) on the same inputs."""
+import numpy as np
+import pytest
+
+import frames
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def colour(rspec, wspec):
+    import hip_harness as hh
+    rd_o = (orc.ycbcr2rgb_matrix(rspec), orc.gamma2linear_lut(rspec), orc.rgb2rgb_matrix(rspec, wspec))
+    wr_o = (orc.rgb2ycbcr_matrix(wspec), orc.linear2gamma_lut(wspec))
+    return rd_o, wr_o, hh.ColourParams.reader(rspec, wspec), hh.ColourParams.writer(wspec)
+
+
+class Src:
+    """one source on both sides: the oracle's RGBA (read, then placed) and the tuple the binding takes"""
+
+    def __init__(self, data, w, h, matrix=None, fmt="v210"):
+        self.data, self.w, self.h, self.matrix, self.fmt = data, w, h, matrix, fmt
+
+    def oracle(self, rd_o, ow, oh):
+        img = orc.v210_read(self.data, self.w, self.h, *rd_o) if self.fmt == "v210" else self.data.reshape(self.h, self.w, 4)
+        if self.matrix is None:
+            assert (self.w, self.h) == (ow, oh)
+            return img
+        return orc.transform(img, self.matrix, ow, oh)
+
+    def device(self):
+        import hip_harness as hh
+        t = hh.dev(self.data.reshape(-1))
+        return (t, self.w, self.h, self.matrix) + (("rgba",) if self.fmt == "rgba" else ())
+
+
+def oracle_chain(layers, ow, oh, interlace, rd_o, wr_o, dst=None):
+    placed = []
+    for L in layers:
+        t = L["src"].oracle(rd_o, ow, oh)
+        kind = L.get("transition", "cut")
+        if kind == "dissolve":
+            t = orc.transition_dissolve(t, L["incoming"].oracle(rd_o, ow, oh), L["mix"])
+        elif kind == "wipe":
+            t = orc.transition_wipe(t, L["incoming"].oracle(rd_o, ow, oh), L["mask"].oracle(rd_o, ow, oh))
+        placed.append(t)
+    comb = placed[0] if len(placed) == 1 else orc.combine(placed)  # one layer: the combiner passes it through (combiner.ts:213-217)
+    return orc.v210_write(comb, ow, oh, interlace, *wr_o, out=dst)
+
+
+def run_device(layers, ow, oh, interlace, rd_d, wr_d, dst=None):
+    import torch
+    import hip_harness as hh
+    k = hh.ctx()
+    words = frames.v210_pitch_bytes(ow) * oh // 4
+    out = hh.dev(dst) if dst is not None else torch.zeros(words, dtype=torch.int32, device="cuda")
+    dl = []
+    for L in layers:
+        d = dict(src=L["src"].device(), transition=L.get("transition", "cut"), mix=L.get("mix", 0.0))
+        for role in ("incoming", "mask"):
+            if L.get(role) is not None:
+                d[role] = L[role].device()
+        dl.append(d)
+    k.chan_compose_v210(dl, out, ow, oh, interlace, *rd_d, *wr_d)
+    return hh.host(out, np.uint32)
+
+
+def check(layers, ow, oh, what, interlace=0, specs=("709", "709"), poison_dst=False):
+    rd_o, wr_o, rd_d, wr_d = colour(*specs)
+    dst = None
+    if poison_dst:  # an interlaced write touches every other line only: the rest must stay as it was
+        dst = np.full(frames.v210_pitch_bytes(ow) * oh // 4, 0x2AAAAAAA, np.uint32)
+    want = oracle_chain(layers, ow, oh, interlace, rd_o, wr_o, None if dst is None else dst.copy())
+    got = run_device(layers, ow, oh, interlace, rd_d, wr_d, dst)
+    bad = np.flatnonzero(got != np.asarray(want).reshape(-1))
+    assert bad.size == 0, "%s: %d of %d words differ, first at word %d (line %d)" % (
+        what, bad.size, got.size, bad[0], bad[0] // (frames.v210_pitch_bytes(ow) // 4))
+
+
+def m(ow, oh, **kw):
+    from phaneron_amd import capi
+    return capi.transform_matrix(ow, oh, **kw)
+
+
+PIP = [dict(), dict(scale_x=0.5, scale_y=0.5, offset_x=-0.25, offset_y=-0.25), dict(scale_x=0.5, scale_y=0.5, offset_x=0.25, offset_y=-0.25),
+       dict(scale_x=0.5, scale_y=0.5, offset_x=0.25, offset_y=0.25)]
+
+
+def pip_layers(w, h, seed, n=4):
+    srcs = [frames.v210_ramp(w, h)] + [frames.v210_random(w, h, frames.layer_seed(seed, l)) for l in range(1, n)]
+    return [dict(src=Src(srcs[l], w, h, m(w, h, **PIP[l]))) for l in range(n)]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_picture_in_picture_layers(n):
+    """the Mixer placements of BASELINE config 2: a full-frame layer through the identity fill (NOT a copy: a half-pixel
+    shift and 2 x 2 average, transform.ts:54-55) and quarter-size insets whose outside is the transparent border"""
+    w, h = 384, 108
+    check(pip_layers(w, h, 20 + n, n), w, h, "%d PiP layers %dx%d" % (n, w, h))
+
+
+def test_wipe_and_dissolve_transitions():
+    w, h = 384, 64
+    second = frames.v210_random(w, h, frames.layer_seed(30, 1), legal=False)
+    mask = frames.mask_ramp(w, h)
+    layers = pip_layers(w, h, 31)
+    # wipe on the top layer: incoming v210 taken 1:1, mask an f32 image (what tools/config_bench.py times)
+    layers[3].update(transition="wipe", incoming=Src(second, w, h), mask=Src(mask, w, h, fmt="rgba"))
+    check(layers, w, h, "wipe, 1:1 incoming, f32 mask")
+    # as the reference's graph feeds the Transitioner: incoming and mask are Mixer outputs themselves (placed sources)
+    vmask = frames.v210_ramp(w, h)
+    layers[3].update(incoming=Src(second, w, h, m(w, h)), mask=Src(vmask, w, h, m(w, h, scale_x=1.5, scale_y=1.5)))
+    check(layers, w, h, "wipe, placed v210 incoming and placed v210 mask")
+    for mix in (1.0, 0.75, 1.0 / 3.0, 0.0):
+        layers[1].update(transition="dissolve", mix=mix, incoming=Src(second, w, h, m(w, h, scale_x=0.5, scale_y=0.5)))
+        check(layers, w, h, "dissolve mix %g on layer 1 + wipe on layer 3" % mix)
+
+
+def test_one_to_one_sources_and_f32_layers():
+    """sources without a transform are taken pixel for pixel (the headline's shape), f32 RGBA sources (a routed frame) mix in"""
+    w, h = 192, 40
+    v = [frames.v210_random(w, h, frames.layer_seed(40, l), legal=(l != 2)) for l in range(4)]
+    check([dict(src=Src(x, w, h)) for x in v], w, h, "four 1:1 v210 layers")
+    rgba = frames.rgba_random(w, h, 41, -0.05, 1.05)  # real alpha: the layers below show through
+    check([dict(src=Src(v[0], w, h)), dict(src=Src(rgba, w, h, fmt="rgba"))], w, h, "v210 under a 1:1 f32 layer")
+    small = frames.rgba_random(96, 20, 42, 0.0, 1.0)
+    check([dict(src=Src(v[0], w, h, m(w, h))), dict(src=Src(small, 96, 20, m(w, h, scale_x=0.7, scale_y=0.7, offset_x=0.1), fmt="rgba")),
+           dict(src=Src(v[1], w, h, m(w, h, scale_x=0.25, scale_y=0.25, offset_x=-0.3, offset_y=0.3)))], w, h, "placed f32 layer between v210 layers")
+
+
+@pytest.mark.parametrize("kw", [dict(rotate=0.07), dict(rotate=-0.25, scale_x=0.8, scale_y=0.8), dict(flip_h=True), dict(flip_v=True, scale_x=2.0, scale_y=2.0),
+                                dict(scale_x=3.0, scale_y=0.4, offset_x=0.2), dict(anchor_x=0.25, anchor_y=-0.25, rotate=0.4, scale_x=0.6, scale_y=0.6),
+                                dict(offset_x=1.2), dict(scale_x=0.01, scale_y=0.01)],
+                         ids=lambda k: ",".join("%s=%g" % kv for kv in k.items()))
+def test_arbitrary_placements(kw):
+    """rotations, flips, zooms, a layer moved wholly off screen, a layer shrunk to a few pixels - over a 1:1 background so
+    that the placed layer's alpha edge is visible"""
+    w, h = 384, 96
+    bg, fg = frames.v210_random(w, h, frames.layer_seed(50, 0)), frames.v210_random(w, h, frames.layer_seed(50, 1), legal=False)
+    check([dict(src=Src(bg, w, h)), dict(src=Src(fg, w, h, m(w, h, **kw)))], w, h, "placement %r" % (kw,))
+
+
+def test_sources_of_other_sizes_and_colour_recipes():
+    """sources smaller and larger than the output (the Mixer scales them to the consumer format), 709 -> 2020 and a
+    non-standard reader matrix (the general dot-product path)"""
+    ow, oh = 384, 120
+    a = frames.v210_random(192, 60, frames.layer_seed(60, 0))      # up-scaled 2x
+    b = frames.v210_random(768, 240, frames.layer_seed(60, 1))     # shrunk to half
+    c = frames.v210_random(96, 36, frames.layer_seed(60, 2))       # odd aspect, placed small
+    layers = [dict(src=Src(a, 192, 60, m(ow, oh))), dict(src=Src(b, 768, 240, m(ow, oh, scale_x=0.5, scale_y=0.5, offset_x=0.2, offset_y=-0.2))),
+              dict(src=Src(c, 96, 36, m(ow, oh, scale_x=0.3, scale_y=0.3, offset_x=-0.3, offset_y=0.25)))]
+    check(layers, ow, oh, "mixed source sizes 709 -> 709")
+    check(layers, ow, oh, "mixed source sizes 709 -> 2020", specs=("709", "2020"))
+    check(layers, ow, oh, "mixed source sizes 2020 -> 709", specs=("2020", "709"))
+
+
+def test_general_reader_matrix_path():
+    """a YCbCr matrix that is not of the standard shape (Cb feeds R) takes the kernel's general dot-product path"""
+    import hip_harness as hh
+    from phaneron_amd import capi
+    w, h = 192, 24
+    cm = orc.ycbcr2rgb_matrix("709").copy()
+    cm[1] = np.float32(1.7e-5)
+    rd_o = (cm, orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
+    wr_o = (orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    _, lut, gm = hh.ColourParams.reader("709", "2020")
+    rd_d, wr_d = (hh.dev(cm), lut, gm), hh.ColourParams.writer("2020")
+    layers = pip_layers(w, h, 70, 3)
+    want = oracle_chain(layers, w, h, 0, rd_o, wr_o)
+    got = run_device(layers, w, h, 0, rd_d, wr_d)
+    assert np.array_equal(got, np.asarray(want).reshape(-1))
+
+
+@pytest.mark.parametrize("interlace", [1, 3])
+def test_field_outputs(interlace):
+    """FromRGBA's field writes (v210.ts:126-127): every other line, the rest of the destination untouched"""
+    w, h = 384, 54
+    check(pip_layers(w, h, 80 + interlace), w, h, "interlace %d" % interlace, interlace=interlace, poison_dst=True)
+
+
+def test_config2_full_size_with_wipe():
+    """BASELINE config 2 at its real size through the one kernel: ramp full frame, three quarter-size insets, a wipe on
+    the top layer against a second source by a horizontal-ramp mask"""
+    w, h = 1920, 1080
+    layers = pip_layers(w, h, 2)
+    second = frames.v210_random(w, h, frames.layer_seed(2, 4), legal=False)
+    layers[3].update(transition="wipe", incoming=Src(second, w, h), mask=Src(frames.mask_ramp(w, h), w, h, fmt="rgba"))
+    check(layers, w, h, "config 2 at 1920x1080")
+
+
+def test_frame_sizes_that_do_not_fill_the_chip():
+    """fewer chunks than waves, a single row, and a 2160p output from 1080p sources (more than one index-frame pass per lane)"""
+    for w, h in ((192, 1), (192, 5), (576, 3)):
+        check(pip_layers(w, h, 90), w, h, "%dx%d" % (w, h))
+    ow, oh = 3840, 256
+    a = frames.v210_random(1920, 128, frames.layer_seed(91, 0))
+    b = frames.v210_random(1920, 128, frames.layer_seed(91, 1))
+    check([dict(src=Src(a, 1920, 128, m(ow, oh))), dict(src=Src(b, 1920, 128, m(ow, oh, scale_x=0.5, scale_y=0.5, offset_x=0.25)))], ow, oh,
+          "1920x128 -> 3840x256", specs=("709", "2020"))
+
+
+def test_refusals():
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    k = hh.ctx()
+    rd_d, wr_d = hh.ColourParams.reader("709", "709"), hh.ColourParams.writer("709")
+    w, h = 384, 8
+    src = hh.dev(frames.v210_random(w, h, 1))
+    out = torch.zeros(frames.v210_pitch_bytes(w) * h // 4, dtype=torch.int32, device="cuda")
+    ok = dict(src=(src, w, h, None))
+    with pytest.raises(capi.PhaneronError, match="multiple of 192"):
+        k.chan_compose_v210([dict(src=(src, 336, h, None))], out, 336, h, 0, *rd_d, *wr_d)
+    with pytest.raises(capi.PhaneronError, match="not the output size"):
+        k.chan_compose_v210([dict(src=(src, 192, h, None))], out, w, h, 0, *rd_d, *wr_d)
+    with pytest.raises(capi.PhaneronError, match="incoming source is empty"):
+        k.chan_compose_v210([dict(ok, transition="dissolve", mix=0.5)], out, w, h, 0, *rd_d, *wr_d)
+    with pytest.raises(capi.PhaneronError, match="mask is empty"):
+        k.chan_compose_v210([dict(ok, transition="wipe", incoming=(src, w, h, None))], out, w, h, 0, *rd_d, *wr_d)
+    with pytest.raises(capi.PhaneronError, match="multiple of 6"):
+        k.chan_compose_v210([dict(src=(src, 100, h, capi.transform_matrix(w, h)))], out, w, h, 0, *rd_d, *wr_d)
+    with pytest.raises(capi.PhaneronError, match="1..8 layers"):
+        k.chan_compose_v210([ok] * 9, out, w, h, 0, *rd_d, *wr_d)
+    plain = hh.dev(orc.linear2gamma_lut("709"))  # never registered: no LDS form
+    with pytest.raises(capi.PhaneronError, match="writer gamma LUT has no LDS form"):
+        k.chan_compose_v210([ok], out, w, h, 0, *rd_d, wr_d[0], plain)

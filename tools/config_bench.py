@@ -107,12 +107,25 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
         ctx.compose_wipe_write_v210([(rgba[l], w, h, mats[l]) for l in range(4)], [None, None, None, (rgba[4], mask)],
                                     out, w, h, 0, *wr)
 
+    mats_h = [capi.transform_matrix(w, h)] + [capi.transform_matrix(w, h, scale_x=0.5, scale_y=0.5, offset_x=ox, offset_y=oy)
+                                              for ox, oy in ((-0.25, -0.25), (0.25, -0.25), (0.25, 0.25))]
+    # ONE launch per frame, no f32 frame at all: the compositor samples the v210 words (ph_chan_compose_v210)
+    chan_jobs = [ctx.chan_compose_v210(
+        [dict(src=(s[l], w, h, mats_h[l])) for l in range(3)] +
+        [dict(src=(s[3], w, h, mats_h[3]), transition="wipe", incoming=(s[4], w, h, None), mask=(mask, w, h, None, "rgba"))],
+        out, w, h, 0, *rd, *wr, prepare_only=True) for s in src]
+
+    def config2_chan(i):
+        chan_jobs[i % R]()
+
     # 4 layers + second source + the mask counted as one more v210-sized input + 1 output (38 707 200 during a transition)
     algo2 = 7 * capi.v210_pitch_bytes(w) * h
     name2 = "2: 1 channel, 4-layer 1080p50, three quarter-size insets, wipe transition on the top layer"
-    record(name2, "batched reads + compositor with the wipe inside: [read x5], [transform x4 + transition_wipe + combine_4 + write]", "frame",
-           timeit(config2_wipe_inside, reps), algo2, 2)
+    record(name2, "channel compositor straight from v210 (ph_chan_compose_v210): [read x5 + transform x4 + transition_wipe + combine_4 + write] "
+           "as one kernel, no f32 frame in HBM", "frame", timeit(config2_chan, reps), algo2, 1)
     if routes == "all":
+        record(name2, "batched reads + compositor with the wipe inside: [read x5], [transform x4 + transition_wipe + combine_4 + write]", "frame",
+               timeit(config2_wipe_inside, reps), algo2, 2)
         record(name2, "fused compositor, batched reads: [read x5], transform, transition_wipe, [transform x3 + combine_4 + write]", "frame",
                timeit(lambda i: config2_fused(i, True), reps), algo2, 4)
         record(name2, "fused compositor: read x5, transform, transition_wipe, [transform x3 + combine_4 + write]", "frame",
