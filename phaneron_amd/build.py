@@ -21,7 +21,11 @@ HEADERS = ["ph_device.h", "ph_kernels.h", "ph_lut.h", "ph_lut_host.h", "ph_ldslu
 # packed f32 instruction occupies the issue slot as long as its two halves would (tools/opbench3: 4.2 cycles), and the
 # register PAIRS it needs cost v_mov shuffles and spills: the de-interlacing reader lost 16 % to it.
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result",
-          "-Wno-unused-value", "-Wno-int-to-pointer-cast"]
+          "-Wno-unused-value", "-Wno-int-to-pointer-cast",
+          # A kernel's argument struct is a private copy of the kernarg segment that instcombine replaces by direct scalar
+          # loads only if it can walk all its users - at most 300 by default.  The channel compositor indexes its op list
+          # in several inlined places and crossed that line: the whole 1.7 KiB struct went to scratch (1792 B per lane, 4x slower).
+          "-mllvm", "-instcombine-max-copied-from-constant-users=8000"]
 
 
 def hipcc():

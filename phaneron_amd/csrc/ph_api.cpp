@@ -1465,23 +1465,32 @@ int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *lay
   if (!rv || !wv)
     return fail(PH_E_INVALID, "ph_chan_compose_v210: the %s gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)", rv ? "writer" : "reader");
   ph::ChanArgs a{};
-  a.n = n;
+  int k = 0;
   for (int i = 0; i < n; ++i) {
     const ph_chan_layer &L = layers[i];
-    int rc = chan_source(L.src, "source", i, out_w, out_h, &a.layer[i].src);
+    const uint32_t first = i == 0 ? ph::kChanActFirst : 0u;
+    int rc = chan_source(L.src, "source", i, out_w, out_h, &a.op[k].src);
     if (rc) return rc;
-    if (L.transition != PH_TRANSITION_CUT && L.transition != PH_TRANSITION_DISSOLVE && L.transition != PH_TRANSITION_WIPE)
+    if (L.transition == PH_TRANSITION_CUT) {
+      a.op[k++].action = ph::kChanActLayer | first;
+    } else if (L.transition == PH_TRANSITION_DISSOLVE || L.transition == PH_TRANSITION_WIPE) {
+      a.op[k++].action = ph::kChanActHold;
+      rc = chan_source(L.incoming, "transition's incoming source", i, out_w, out_h, &a.op[k].src);
+      if (rc) return rc;
+      if (L.transition == PH_TRANSITION_DISSOLVE) {
+        a.op[k].mix = L.mix;
+        a.op[k++].action = ph::kChanActDissolve | first;
+      } else {
+        a.op[k++].action = ph::kChanActIncoming;
+        rc = chan_source(L.mask, "wipe's mask", i, out_w, out_h, &a.op[k].src);
+        if (rc) return rc;
+        a.op[k++].action = ph::kChanActWipe | first;
+      }
+    } else {
       return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: transition %d", i, L.transition);
-    a.layer[i].transition = (uint32_t)L.transition, a.layer[i].mix = L.mix;
-    if (L.transition != PH_TRANSITION_CUT) {
-      rc = chan_source(L.incoming, "transition's incoming source", i, out_w, out_h, &a.layer[i].incoming);
-      if (rc) return rc;
-    }
-    if (L.transition == PH_TRANSITION_WIPE) {
-      rc = chan_source(L.mask, "wipe's mask", i, out_w, out_h, &a.layer[i].mask);
-      if (rc) return rc;
     }
   }
+  a.n_ops = k;
   a.out = out, a.out_w = out_w, a.out_h = out_h;
   a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0;
   a.lines = interlace ? out_h / 2 : out_h;

@@ -64,14 +64,20 @@ struct ChanSrc {
   uint32_t pad;
   float m[6];            // rows 0 and 1 of the 3x3 transform matrix
 };
-struct ChanLayer {
-  ChanSrc src, incoming, mask;
-  uint32_t transition;
+// The channel's frame as a flat program the kernel walks per pixel: one op per source to sample, with what to do with
+// the sample.  A layer without a transition is one op (Layer); a dissolve is Hold (the layer's own source) + Dissolve (the
+// incoming source); a wipe is Hold + Incoming + Wipe (the mask).  kChanActFirst marks the op that completes layer 0.
+enum : uint32_t { kChanActLayer = 0, kChanActHold = 1, kChanActDissolve = 2, kChanActIncoming = 3, kChanActWipe = 4, kChanActFirst = 0x100 };
+constexpr int kMaxChanOps = 3 * kMaxLayers;
+struct ChanOp {
+  ChanSrc src;
+  uint32_t action;
   float mix;
 };
 struct ChanArgs {
-  ChanLayer layer[kMaxLayers];
-  int n;
+  ChanOp op[kMaxChanOps];
+  int n_ops;
+  uint32_t magic_cpr, magic_cpg;  // ceil(2^32 / chunks per row), ceil(2^32 / chunks per row group) (launcher)
   void *out;
   void *index;  // scratch: 8 bytes per output pixel (chan_index_bytes)
   uint32_t out_w, out_h, lines, first_line, line_step;

@@ -29,6 +29,35 @@
 #define PH_CHAN_GROUP_ROWS 16
 #endif
 
+// PH_CHAN_PROBE builds (tools/chan_probe.py; never the shipped library): wave 0 of workgroup 0 stamps s_memtime at fixed
+// points of its first turns, so the share of each part of a turn can be read off the real kernel.
+#ifndef PH_CHAN_PROBE
+#define PH_CHAN_PROBE 0
+#endif
+#if PH_CHAN_PROBE
+__device__ unsigned long long g_chan_probe[8 * 64];
+__device__ unsigned long long g_chan_phase[256 * 8];  // per workgroup: s_memtime at the phase boundaries (wave 0)
+extern "C" int ph_debug_chan_phase(unsigned long long *out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chan_phase), (size_t)n_words * 8);
+}
+#define PH_CPHASE(point)                                                                                       \
+  do {                                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 256) g_chan_phase[blockIdx.x * 8 + (point)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+__device__ unsigned int g_chan_probe_n;
+extern "C" int ph_debug_chan_probe(unsigned long long *out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chan_probe), (size_t)n_words * 8);
+}
+#define PH_CSTAMP(point)                                                                    \
+  do {                                                                                      \
+    if (blockIdx.x == 0 && wave == 0 && probe_turn < 64 && lane == 0)                      \
+      g_chan_probe[probe_turn * 8 + (point)] = __builtin_amdgcn_s_memtime();                \
+  } while (0)
+#else
+#define PH_CSTAMP(point) do { } while (0)
+#define PH_CPHASE(point) do { } while (0)
+#endif
+
 namespace ph {
 
 constexpr uint32_t kChanChunk = 192;          // pixels: 3 wave steps of phase 1, 32 quads of phase 2
@@ -36,162 +65,278 @@ constexpr uint32_t kOutsideBit = 0x40000000u;  // row / column offsets of taps o
 
 // ---- a v210 column: where pixel i's Y and its pair's Cb / Cr sit inside the 16-byte quad (v210.ts:58-63) ----------
 struct V210Col {
-  uint32_t off;  // byte offset of the quad inside a line, or kOutsideBit
+  uint32_t g16;  // byte offset of the pixel's quad inside a line
   uint32_t yo, ys, cbo, cbs, cro, crs;
 };
-__device__ __forceinline__ V210Col v210_col(uint32_t i, uint32_t w) {
-  const uint32_t g = __umulhi(i, 0xAAAAAAABu) >> 2;  // i / 6
-  const uint32_t j = i - 6u * g, pr = j >> 1;
+__device__ __forceinline__ V210Col v210_col(uint32_t i) {
+  // i / 6 as a full-rate 24-bit multiply (v_mul_hi_u32 issues at a quarter of the rate): exact for i < 98304, and a column
+  // beyond any frame width is masked by the caller anyway
+  const uint32_t g = __umul24(i, 43691u) >> 18;
+  const uint32_t j = i - __umul24(g, 6u), pr = j >> 1;
   V210Col c;
-  c.off = i < w ? g << 4 : kOutsideBit;
+  c.g16 = g << 4;
   c.yo = (0xCC8440u >> (4u * j)) & 0xCu;           // Y in word {0,1,1,2,3,3}
-  c.ys = 10u * ((0x201201u >> (4u * j)) & 3u);     //   at bit {10,0,20,10,0,20}
-  c.cbo = 4u * pr, c.cbs = 10u * pr;               // Cb in word {0,1,2} at bit {0,10,20}
-  c.cro = (0xC80u >> (4u * pr)) & 0xCu;            // Cr in word {0,2,3}
-  c.crs = 10u * ((0x102u >> (4u * pr)) & 3u);      //   at bit {20,0,10}
+  c.ys = __umul24(10u, (0x201201u >> (4u * j)) & 3u);  //   at bit {10,0,20,10,0,20}
+  c.cbo = 4u * pr, c.cbs = __umul24(10u, pr);          // Cb in word {0,1,2} at bit {0,10,20}
+  c.cro = (0xC80u >> (4u * pr)) & 0xCu;                // Cr in word {0,2,3}
+  c.crs = __umul24(10u, (0x102u >> (4u * pr)) & 3u);   //   at bit {20,0,10}
   return c;
 }
 
-// one converted pixel of a v210 frame = what ToRGBA would have stored there: (r, g, b, 1); outside the frame the
-// sampler's border colour (0, 0, 0, 0)
-template <bool STD>
-__device__ __forceinline__ float4 v210_texel(__amdgpu_buffer_rsrc_t frame, uint32_t row_off, const V210Col &c, const ReadK &k,
-                                            const LutK &lut) {
-  const uint32_t base = row_off + c.off;  // >= kOutsideBit when the row or the column is outside: the loads return 0
-  const uint32_t wy = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(frame, (int)(base + c.yo), 0, 0);
-  const uint32_t wcb = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(frame, (int)(base + c.cbo), 0, 0);
-  const uint32_t wcr = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(frame, (int)(base + c.cro), 0, 0);
-  const float y = (float)__builtin_amdgcn_ubfe(wy, c.ys, 10u);
-  const float cb = (float)__builtin_amdgcn_ubfe(wcb, c.cbs, 10u);
-  const float cr = (float)__builtin_amdgcn_ubfe(wcr, c.crs, 10u);
-  float4 t = read_px_lds<STD>(y, cb, cr, k, lut);
-  const bool in = base < kOutsideBit;
-  t.x = in ? t.x : 0.0f, t.y = in ? t.y : 0.0f, t.z = in ? t.z : 0.0f, t.w = in ? 1.0f : 0.0f;
-  return t;
-}
+// ---- sampling ------------------------------------------------------------------------------------------------------------
+// A lane computes P = 2 output pixels at a time - (x, line) and (x, line + line_step), one above the other - through
+// every op together.  The table fills the LDS, so a SIMD has four waves and a wave on its own runs at the pace of its
+// dependency chains and LDS / memory round trips (measured with the in-kernel probe: 10 cycles per instruction);
+// two independent pixel streams in one wave fill each other's gaps, and the per-op scalar work (descriptor loads,
+// branches) and the per-step work are paid once per pair.
+constexpr int kChanP = 2;
 
-__device__ __forceinline__ float4 rgba_texel(__amdgpu_buffer_rsrc_t img, uint32_t row_off, uint32_t col_off) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(img, (int)(row_off + col_off), 0, 0);  // outside: 0 = the border colour
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
-// the source's sample for output pixel (x, line): 1:1, or through the transform matrix and the bilinear filter
-// (transform.ts:53-57; OpenCL 1.2 8.2 evaluated as DESIGN.md section 2 fixes it)
-template <bool STD>
-__device__ __forceinline__ float4 chan_sample(const ChanSrc &s, float px, float py, uint32_t x, uint32_t line, const ReadK &k,
-                                              const LutK &lut) {
-  const bool is_v210 = s.kind == kChanV210;  // uniform
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(s.pitch * s.h), 0x00020000);
-  if (!s.sampled) {  // uniform: the source has the output's size, pixel for pixel
-    if (is_v210) return v210_texel<STD>(rs, line * s.pitch, v210_col(x, s.w), k, lut);
-    return rgba_texel(rs, line * s.pitch, x << 4);
-  }
+struct ChanTaps {  // the `u`, `v` half of the sampler (transform.ts:53-57, OpenCL 1.2 8.2)
+  uint32_t i0, j0;
+  float a, b;
+};
+__device__ __forceinline__ ChanTaps chan_taps(const ChanSrc &s, float px, float py) {
   const float sx = dot3(s.m[0], s.m[1], s.m[2], px, py, 1.0f) + 0.5f;
   const float sy = dot3(s.m[3], s.m[4], s.m[5], px, py, 1.0f) + 0.5f;
   const float u = sx * (float)(int)s.w, v = sy * (float)(int)s.h;
   const float fu = u - 0.5f, fv = v - 0.5f;
   const float flu = __builtin_floorf(fu), flv = __builtin_floorf(fv);
-  const uint32_t i0 = (uint32_t)(int)flu, i1 = i0 + 1u, j0 = (uint32_t)(int)flv, j1 = j0 + 1u;
-  const float a = fu - flu, b = fv - flv;
-  const bool xa = i0 < s.w, xb = i1 < s.w, ya = j0 < s.h, yb = j1 < s.h;
-  float4 t00, t10, t01, t11;
-  // a wave none of whose taps touches the source (the outside of a picture-in-picture inset) gets the border value
-  // without a load: every product is w * 0
-  if (!__builtin_amdgcn_ballot_w64((xa || xb) && (ya || yb))) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  const uint32_t r0 = ya ? j0 * s.pitch : kOutsideBit, r1 = yb ? j1 * s.pitch : kOutsideBit;
-  if (is_v210) {
-    const V210Col c0 = v210_col(i0, s.w), c1 = v210_col(i1, s.w);
-    t00 = v210_texel<STD>(rs, r0, c0, k, lut), t10 = v210_texel<STD>(rs, r0, c1, k, lut);
-    t01 = v210_texel<STD>(rs, r1, c0, k, lut), t11 = v210_texel<STD>(rs, r1, c1, k, lut);
-  } else {
-    const uint32_t c0 = xa ? i0 << 4 : kOutsideBit, c1 = xb ? i1 << 4 : kOutsideBit;
-    t00 = rgba_texel(rs, r0, c0), t10 = rgba_texel(rs, r0, c1), t01 = rgba_texel(rs, r1, c0), t11 = rgba_texel(rs, r1, c1);
-  }
-  const float oma = 1.0f - a, omb = 1.0f - b;
-  const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
-  float4 t;
-  t.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
-  t.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
-  t.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
-  t.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
-  return t;
+  return ChanTaps{(uint32_t)(int)flu, (uint32_t)(int)flv, fu - flu, fv - flv};
 }
 
-// The workgroup's share of the frame: chunks of 192 pixels, dealt out XCD-aware exactly as the f32 compositor does
-// (ph_kernels_lds.hip compose_taps_body): groups of PH_CHAN_GROUP_ROWS output rows belong to one XCD (blockIdx % 8), so a
-// source row is pulled through one XCD's L2, and the chunks of a group go round the XCD's workgroups and waves so
-// that partial-frame layers load them evenly.  slot -> chunk, or ~0u past the end.
+struct V210Words {
+  uint32_t wy, wcb, wcr;
+};
+__device__ __forceinline__ V210Words v210_load(__amdgpu_buffer_rsrc_t rs, uint32_t base, const V210Col &c) {
+  return V210Words{(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(base + c.yo), 0, 0),
+                   (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(base + c.cbo), 0, 0),
+                   (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(base + c.cro), 0, 0)};
+}
+template <bool STD>
+__device__ __forceinline__ PxPending v210_issue(const V210Words &w, const V210Col &c, const ReadK &k, const LutK &lut) {
+  const float y = (float)__builtin_amdgcn_ubfe(w.wy, c.ys, 10u);
+  const float cb = (float)__builtin_amdgcn_ubfe(w.wcb, c.cbs, 10u);
+  const float cr = (float)__builtin_amdgcn_ubfe(w.wcr, c.crs, 10u);
+  return read_px_issue<STD>(y, cb, cr, k, lut);
+}
+__device__ __forceinline__ float4 rgba_load(__amdgpu_buffer_rsrc_t img, uint32_t off) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(img, (int)off, 0, 0);  // outside: 0 = the border colour
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// the source's samples for the lane's pixels (x, line[p]): 1:1, or through the transform matrix and the bilinear filter
+template <bool STD>
+__device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const float (&py)[kChanP], uint32_t x, const uint32_t (&line)[kChanP],
+                                            const ReadK &k, const LutK &lut, float4 (&out)[kChanP]) {
+  const bool is_v210 = s.kind == kChanV210;  // uniform
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(s.pitch * s.h), 0x00020000);
+  if (!s.sampled) {  // uniform: the source has the output's size, pixel for pixel
+    if (is_v210) {
+      const V210Col c = v210_col(x);
+      V210Words w[kChanP];
+#pragma unroll
+      for (int p = 0; p < kChanP; ++p) w[p] = v210_load(rs, __umul24(line[p], s.pitch) + c.g16, c);
+      PxPending pend[kChanP];
+#pragma unroll
+      for (int p = 0; p < kChanP; ++p) pend[p] = v210_issue<STD>(w[p], c, k, lut);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < kChanP; ++p) out[p] = read_px_finish(pend[p], k);
+    } else {
+#pragma unroll
+      for (int p = 0; p < kChanP; ++p) out[p] = rgba_load(rs, __umul24(line[p], s.pitch) + (x << 4));
+    }
+    return;
+  }
+  ChanTaps t[kChanP];
+  bool touches = false;
+#pragma unroll
+  for (int p = 0; p < kChanP; ++p) {
+    t[p] = chan_taps(s, px, py[p]);
+    touches = touches || (t[p].i0 + 1u <= s.w && t[p].j0 + 1u <= s.h);  // columns i0, i0 + 1 / rows j0, j0 + 1: any inside
+  }
+  // a wave none of whose taps touches the source (the outside of a picture-in-picture inset) gets the border value
+  // without a load: every product is w * 0
+  if (!__builtin_amdgcn_ballot_w64(touches)) {
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) out[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return;
+  }
+  float4 tap[kChanP][4];
+  if (is_v210) {
+    V210Words w[kChanP][4];
+    V210Col col[kChanP][2];
+    uint32_t in[kChanP];
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) {
+      col[p][0] = v210_col(t[p].i0), col[p][1] = v210_col(t[p].i0 + 1u);
+      const uint32_t c0 = t[p].i0 < s.w ? col[p][0].g16 : kOutsideBit, c1 = t[p].i0 + 1u < s.w ? col[p][1].g16 : kOutsideBit;
+      // rows inside the frame are below 2^24 and so is a pitch: the 24-bit multiply is exact where its result is used
+      const uint32_t r0 = t[p].j0 < s.h ? __umul24(t[p].j0, s.pitch) : kOutsideBit;
+      const uint32_t r1 = t[p].j0 + 1u < s.h ? __umul24(t[p].j0 + 1u, s.pitch) : kOutsideBit;
+      in[p] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t base = ((i & 2) ? r1 : r0) + ((i & 1) ? c1 : c0);  // >= kOutsideBit when the row or the column is outside: the loads return 0
+        w[p][i] = v210_load(rs, base, col[p][i & 1]);
+        in[p] |= (base < kOutsideBit ? 1u : 0u) << i;
+      }
+    }
+    // one pixel's four taps are converted together: 24 table reads in flight before the first is consumed
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) {
+      PxPending pend[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pend[i] = v210_issue<STD>(w[p][i], col[p][i & 1], k, lut);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tap[p][i] = read_px_finish(pend[i], k);
+    }
+    bool some_outside = false;
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) some_outside = some_outside || in[p] != 0xFu;
+    if (__builtin_amdgcn_ballot_w64(some_outside)) {  // the sampler's border colour (0, 0, 0, 0)
+#pragma unroll
+      for (int p = 0; p < kChanP; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool inside = (in[p] >> i) & 1u;
+          float4 &v = tap[p][i];
+          v.x = inside ? v.x : 0.0f, v.y = inside ? v.y : 0.0f, v.z = inside ? v.z : 0.0f, v.w = inside ? 1.0f : 0.0f;
+        }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) {
+      const uint32_t c0 = t[p].i0 < s.w ? t[p].i0 << 4 : kOutsideBit, c1 = t[p].i0 + 1u < s.w ? (t[p].i0 + 1u) << 4 : kOutsideBit;
+      const uint32_t r0 = t[p].j0 < s.h ? __umul24(t[p].j0, s.pitch) : kOutsideBit;
+      const uint32_t r1 = t[p].j0 + 1u < s.h ? __umul24(t[p].j0 + 1u, s.pitch) : kOutsideBit;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tap[p][i] = rgba_load(rs, ((i & 2) ? r1 : r0) + ((i & 1) ? c1 : c0));
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < kChanP; ++p) {
+    const float a = t[p].a, b = t[p].b, oma = 1.0f - a, omb = 1.0f - b;
+    const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
+    const float4(&q)[4] = tap[p];
+    out[p].x = ((w00 * q[0].x + w10 * q[1].x) + w01 * q[2].x) + w11 * q[3].x;
+    out[p].y = ((w00 * q[0].y + w10 * q[1].y) + w01 * q[2].y) + w11 * q[3].y;
+    out[p].z = ((w00 * q[0].z + w10 * q[1].z) + w01 * q[2].z) + w11 * q[3].z;
+    out[p].w = ((w00 * q[0].w + w10 * q[1].w) + w01 * q[2].w) + w11 * q[3].w;
+  }
+}
+
+// ---- the workgroup's share of the frame ----------------------------------------------------------------------------------
+// Unit of work: a CHUNK of 192 pixels x 2 rows (row pair rp: output rows 2 rp and 2 rp + 1 of the field being written; a
+// field with an odd number of rows repeats its last row as its own partner) = 3 wave steps of phase 1, 64 quads of
+// phase 2.  Chunks are dealt out XCD-aware as the f32 compositor does (ph_kernels_lds.hip compose_taps_body): groups of
+// PH_CHAN_GROUP_ROWS output rows belong to one XCD (blockIdx % 8), so a source row is pulled through one XCD's L2, and
+// the chunks of a group go round the XCD's workgroups so that partial-frame layers load them evenly.  Everything here
+// is uniform, and the divisions are multiplications by reciprocals the launcher worked out (ChanArgs::magic_*).
 struct ChanShare {
-  uint32_t chunks, cpg, xcd, v0, vstep, vend;
+  uint32_t chunks, cpg, cpr, xcd, v0, vstep, vend, slots;
   bool banded;
 };
 __device__ __forceinline__ ChanShare chan_share(const ChanArgs &a) {
   ChanShare s;
-  s.chunks = a.out_w * a.lines / kChanChunk;  // out_w % 192 == 0: a chunk never leaves its row
-  s.cpg = (uint32_t)PH_CHAN_GROUP_ROWS * (a.out_w / kChanChunk);
+  s.cpr = a.out_w / kChanChunk;  // chunks per row pair: out_w % 192 == 0, a chunk never leaves its rows
+  s.chunks = s.cpr * ((a.lines + 1u) / 2u);
+  s.cpg = (uint32_t)(PH_CHAN_GROUP_ROWS / 2) * s.cpr;
   s.banded = (gridDim.x & 7u) == 0;
-  s.xcd = 0, s.v0 = blockIdx.x * (kLdsBlock / 64), s.vstep = gridDim.x * (kLdsBlock / 64), s.vend = s.chunks;
+  s.xcd = 0, s.v0 = blockIdx.x, s.vstep = gridDim.x, s.vend = s.chunks;
   if (s.banded) {
     s.xcd = blockIdx.x & 7u;
     const uint32_t groups = (s.chunks + s.cpg - 1u) / s.cpg, mine = (groups + 7u - s.xcd) / 8u;
-    s.v0 = (blockIdx.x >> 3) * (kLdsBlock / 64), s.vstep = (gridDim.x >> 3) * (kLdsBlock / 64), s.vend = mine * s.cpg;
+    s.v0 = blockIdx.x >> 3, s.vstep = gridDim.x >> 3, s.vend = mine * s.cpg;
   }
+  s.slots = s.v0 < s.vend ? (s.vend - s.v0 + s.vstep - 1u) / s.vstep : 0u;  // chunks of this workgroup (the last may be empty)
   return s;
 }
-__device__ __forceinline__ uint32_t chan_slots(const ChanShare &s) {  // slots of this workgroup (some may be empty)
-  if (s.v0 >= s.vend) return 0;
-  return ((s.vend - s.v0 + s.vstep - 1u) / s.vstep) * (kLdsBlock / 64);
-}
-__device__ __forceinline__ uint32_t chan_chunk(const ChanShare &s, uint32_t slot) {
-  const uint32_t v = s.v0 + (slot & (kLdsBlock / 64 - 1)) + (slot / (kLdsBlock / 64)) * s.vstep;
-  if (v >= s.vend) return ~0u;
-  if (!s.banded) return v;
-  const uint32_t gi = v / s.cpg;
+__device__ __forceinline__ uint32_t chan_chunk(const ChanArgs &a, const ChanShare &s, uint32_t slot) {
+  const uint32_t v = s.v0 + slot * s.vstep;
+  if (!s.banded) return v < s.chunks ? v : ~0u;
+  const uint32_t gi = __umulhi(v, a.magic_cpg);  // v / cpg
   const uint32_t chunk = (gi * 8u + s.xcd) * s.cpg + (v - gi * s.cpg);
   return chunk < s.chunks ? chunk : ~0u;
 }
+// chunk -> its row pair and first column
+__device__ __forceinline__ void chan_place(const ChanArgs &a, const ChanShare &s, uint32_t chunk, uint32_t &rp, uint32_t &x0) {
+  rp = s.cpr == 1u ? chunk : __umulhi(chunk, a.magic_cpr);  // chunk / cpr
+  x0 = (chunk - rp * s.cpr) * kChanChunk;
+}
+
+// what a sample does to the pixel being built (transition.ts:54-79, combine.ts:45-65)
+struct ChanAcc {
+  float r, g, b;
+  float4 hold, in1;
+};
+__device__ __forceinline__ void chan_apply(const ChanOp &op, const float4 v, ChanAcc &c) {
+  const uint32_t act = op.action & 0xFFu;  // uniform
+  float4 t = v;
+  if (act == kChanActHold) {
+    c.hold = v;
+    return;
+  }
+  if (act == kChanActIncoming) {
+    c.in1 = v;
+    return;
+  }
+  if (act == kChanActDissolve) {  // fma(in0, mix, in1 * (1 - mix))
+    const float m = op.mix, rm = 1.0f - m;
+    t.x = fma_rn(c.hold.x, m, v.x * rm), t.y = fma_rn(c.hold.y, m, v.y * rm), t.z = fma_rn(c.hold.z, m, v.z * rm), t.w = fma_rn(c.hold.w, m, v.w * rm);
+  } else if (act == kChanActWipe) {  // fma(in1, mask.r, in0 * (1 - mask.r))
+    const float m = v.x, rm = 1.0f - m;
+    t.x = fma_rn(c.in1.x, m, c.hold.x * rm), t.y = fma_rn(c.in1.y, m, c.hold.y * rm), t.z = fma_rn(c.in1.z, m, c.hold.z * rm), t.w = fma_rn(c.in1.w, m, c.hold.w * rm);
+  }
+  if (op.action & kChanActFirst) {
+    c.r = t.x, c.g = t.y, c.b = t.z;
+  } else {  // the result's alpha is never used by the writer
+    const float kk = 1.0f - t.w;
+    c.r = fma_rn(c.r, kk, t.x), c.g = fma_rn(c.g, kk, t.y), c.b = fma_rn(c.b, kk, t.z);
+  }
+}
 
 template <bool STD>
-__device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &sh, uint32_t slots, const ReadK &rk, const LutK &rlut) {
+__device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &sh, const ReadK &rk, const LutK &rlut) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const float fow = (float)(int)a.out_w, foh = (float)(int)a.out_h;
   uint2 *const index = reinterpret_cast<uint2 *>(a.index);
-  for (uint32_t n = wave; n < 3u * slots; n += kLdsBlock / 64) {  // 64-pixel steps, dealt round the waves
+  const float fow = (float)(int)a.out_w, foh = (float)(int)a.out_h;
+  for (uint32_t n = wave; n < 3u * sh.slots; n += kLdsBlock / 64) {  // 64-column steps, dealt round the waves
     const uint32_t slot = n / 3u, sub = n - 3u * slot;
-    const uint32_t chunk = chan_chunk(sh, slot);
+    const uint32_t chunk = chan_chunk(a, sh, slot);
     if (chunk == ~0u) continue;  // uniform
-    const uint32_t base = chunk * kChanChunk + sub * 64u;
-    const uint32_t li = base / a.out_w, x = base - li * a.out_w + lane;
-    const uint32_t line = a.first_line + li * a.line_step;
-    const float py = (float)(int)line / foh - 0.5f;  // transform.ts:53
+    uint32_t rp, x0;
+    chan_place(a, sh, chunk, rp, x0);
+    const uint32_t x = x0 + sub * 64u + lane;
+    uint32_t li[kChanP], line[kChanP];
+    float py[kChanP];
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) {
+      li[p] = 2u * rp + (uint32_t)p < a.lines ? 2u * rp + (uint32_t)p : 2u * rp;  // an odd field's last row is its own partner
+      line[p] = a.first_line + li[p] * a.line_step;
+      py[p] = (float)(int)line[p] / foh - 0.5f;  // transform.ts:53
+    }
     const float px = (float)(int)x / fow - 0.5f;
-    float r = 0.0f, g = 0.0f, b = 0.0f;
-#pragma unroll 1  // one copy of the sampling code whatever the layer count; the layer's parameters are scalar loads from the arguments
-    for (int l = 0; l < a.n; ++l) {
-      const ChanLayer &L = a.layer[l];
-      float4 t = chan_sample<STD>(L.src, px, py, x, line, rk, rlut);
-      if (L.transition != kChanCut) {  // uniform; transition.ts:54-79 as the Transitioner runs it
-        const float4 in1 = chan_sample<STD>(L.incoming, px, py, x, line, rk, rlut);
-        if (L.transition == kChanDissolve) {  // fma(in0, mix, in1 * (1 - mix))
-          const float m = L.mix, rm = 1.0f - m;
-          t.x = fma_rn(t.x, m, in1.x * rm), t.y = fma_rn(t.y, m, in1.y * rm), t.z = fma_rn(t.z, m, in1.z * rm), t.w = fma_rn(t.w, m, in1.w * rm);
-        } else {  // wipe: fma(in1, mask.r, in0 * (1 - mask.r))
-          const float m = chan_sample<STD>(L.mask, px, py, x, line, rk, rlut).x, rm = 1.0f - m;
-          t.x = fma_rn(in1.x, m, t.x * rm), t.y = fma_rn(in1.y, m, t.y * rm), t.z = fma_rn(in1.z, m, t.z * rm), t.w = fma_rn(in1.w, m, t.w * rm);
-        }
-      }
-      if (l == 0) {
-        r = t.x, g = t.y, b = t.z;
-      } else {  // combine.ts:45-65 (the result's alpha is never used by the writer)
-        const float kk = 1.0f - t.w;
-        r = fma_rn(r, kk, t.x), g = fma_rn(g, kk, t.y), b = fma_rn(b, kk, t.z);
-      }
+    ChanAcc acc[kChanP];
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) acc[p] = ChanAcc{0.0f, 0.0f, 0.0f, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+#pragma unroll 1  // one copy of the sampling code whatever the program's length; an op's descriptor is one 64-byte scalar load
+    for (int k = 0; k < a.n_ops; ++k) {
+      const ChanOp op = a.op[k];
+      float4 v[kChanP];
+      chan_sample<STD>(op.src, px, py, x, line, rk, rlut, v);
+#pragma unroll
+      for (int p = 0; p < kChanP; ++p) chan_apply(op, v[p], acc[p]);
     }
     // the writer's first step needs no table (v210.ts:148-150): park the three 16-bit indices
-    const uint32_t ir = __float_as_uint(lds_lut_index_unit(r)) & 0xFFFFu, ig = __float_as_uint(lds_lut_index_unit(g)) & 0xFFFFu;
-    const uint32_t ib = __float_as_uint(lds_lut_index_unit(b)) & 0xFFFFu;
-    index[base + lane] = make_uint2(ir | (ig << 16), ib);
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) {
+      const uint32_t ir = __float_as_uint(lds_lut_index_unit(acc[p].r)) & 0xFFFFu, ig = __float_as_uint(lds_lut_index_unit(acc[p].g)) & 0xFFFFu;
+      const uint32_t ib = __float_as_uint(lds_lut_index_unit(acc[p].b)) & 0xFFFFu;
+      index[li[p] * a.out_w + x] = make_uint2(ir | (ig << 16), ib);
+    }
   }
 }
 
@@ -200,21 +345,29 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
   const WriteK wk = load_write_k(a.wr_cm);
   const LutK rlut = make_lut_k(a.rd), wlut = make_lut_k(a.wr);
   const ChanShare sh = chan_share(a);
-  const uint32_t slots = chan_slots(sh);
+  PH_CPHASE(0);
   lds_lut_load(a.rd);
   __syncthreads();
-  if (ycbcr_matrix_is_standard(rk)) chan_phase1<true>(a, sh, slots, rk, rlut);
-  else chan_phase1<false>(a, sh, slots, rk, rlut);
+  PH_CPHASE(1);
+  if (ycbcr_matrix_is_standard(rk)) chan_phase1<true>(a, sh, rk, rlut);
+  else chan_phase1<false>(a, sh, rk, rlut);
+  PH_CPHASE(2);
   __syncthreads();  // every index of this workgroup has been stored (the barrier drains the stores) and nobody reads the reader table any more
+  PH_CPHASE(3);
   lds_lut_load(a.wr);
   __syncthreads();
+  PH_CPHASE(4);
   // phase 2: one quad per lane.  The indices were written by other waves of THIS workgroup: read past the L1.
   const uint32_t qpl = a.out_w / 6;
   const uint4 *const index = reinterpret_cast<const uint4 *>(a.index);
-  for (uint32_t q = threadIdx.x; q < 32u * slots; q += kLdsBlock) {
-    const uint32_t chunk = chan_chunk(sh, q >> 5);
+  for (uint32_t q = threadIdx.x; q < 64u * sh.slots; q += kLdsBlock) {
+    const uint32_t chunk = chan_chunk(a, sh, q >> 6);
     if (chunk == ~0u) continue;
-    const uint32_t first_px = chunk * kChanChunk + (q & 31u) * 6u;
+    uint32_t rp, x0;
+    chan_place(a, sh, chunk, rp, x0);
+    const uint32_t li = 2u * rp + ((q >> 5) & 1u);  // quads 0..31 of a chunk: its upper row, 32..63: its lower row
+    if (li >= a.lines) continue;
+    const uint32_t first_px = li * a.out_w + x0 + (q & 31u) * 6u;
     const uint4 w0 = load_stream(index + (first_px >> 1)), w1 = load_stream(index + (first_px >> 1) + 1), w2 = load_stream(index + (first_px >> 1) + 2);
     const uint32_t pk[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
     float yi[18];
@@ -224,10 +377,10 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
       yi[3 * j + 1] = __uint_as_float((pk[2 * j] >> 16) | 0x4B400000u);
       yi[3 * j + 2] = __uint_as_float((pk[2 * j + 1] & 0xFFFFu) | 0x4B400000u);
     }
-    const uint32_t li = first_px / a.out_w, x = first_px - li * a.out_w;
     const uint32_t line = a.first_line + li * a.line_step;
-    store_stream(reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + x / 6, write_quad_idx_lds(yi, wk, wlut));
+    store_stream(reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + (x0 / 6u) + (q & 31u), write_quad_idx_lds(yi, wk, wlut));
   }
+  PH_CPHASE(5);
 }
 
 size_t chan_index_bytes(uint32_t out_w, uint32_t lines) { return (size_t)out_w * lines * 8u; }
@@ -237,9 +390,14 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
   const uint32_t lds = a.rd.bytes > a.wr.bytes ? a.rd.bytes : a.wr.bytes;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chan_compose_v210_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  const uint32_t chunks = a.out_w * a.lines / kChanChunk;
-  const uint32_t want = (chunks + kLdsBlock / 64 - 1) / (kLdsBlock / 64);
-  chan_compose_v210_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, lds, s>>>(a);
+  const uint32_t cpr = a.out_w / kChanChunk, cpg = (uint32_t)(PH_CHAN_GROUP_ROWS / 2) * cpr;
+  const uint32_t chunks = cpr * ((a.lines + 1u) / 2u);  // 192 pixels x 2 rows each
+  const uint32_t want = chunks;                         // a workgroup per chunk at most: 6 wave steps
+  ChanArgs b = a;
+  // reciprocals for the kernel's uniform divisions: umulhi(v, ceil(2^32 / d)) == v / d for every v * d < 2^32 (chunk counts are far below)
+  b.magic_cpr = cpr > 1 ? (uint32_t)(((1ull << 32) + cpr - 1) / cpr) : 0u;
+  b.magic_cpg = (uint32_t)(((1ull << 32) + cpg - 1) / cpg);
+  chan_compose_v210_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, lds, s>>>(b);
   return hipGetLastError();
 }
 

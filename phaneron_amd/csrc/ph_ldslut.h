@@ -185,6 +185,41 @@ __device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const
                      dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
 }
 
+// ---- the same two pixel stages split at the LDS reads (ph_ldslut.h lds_lut_issue / lds_lut_finish), for the
+// software-pipelined fused kernel: `issue` does everything up to and including the start of the six reads,
+// `finish` everything from their results on.
+struct PxPending {
+  LutPending r, g, b;
+};
+template <bool STD>
+__device__ __forceinline__ PxPending read_px_issue(float y, float cb, float cr, const ReadK &k, const LutK &lut) {
+  float tr, tg, tb;
+  if (STD) {
+    const float ym = y * k.r.x;
+    tr = fma_rn(1.0f, k.r.w, fma_rn(cr, k.r.z, ym));
+    tg = fma_rn(1.0f, k.g.w, fma_rn(cr, k.g.z, fma_rn(cb, k.g.y, ym)));
+    tb = fma_rn(1.0f, k.b.w, fma_rn(cb, k.b.y, ym));
+  } else {
+    tr = dot4(y, cb, cr, 1.0f, k.r), tg = dot4(y, cb, cr, 1.0f, k.g), tb = dot4(y, cb, cr, 1.0f, k.b);
+  }
+  PxPending p;
+  p.r = lds_lut_issue(lut, lds_lut_index_unit(tr));
+  p.g = lds_lut_issue(lut, lds_lut_index_unit(tg));
+  p.b = lds_lut_issue(lut, lds_lut_index_unit(tb));
+  return p;
+}
+__device__ __forceinline__ float4 read_px_finish(const PxPending &p, const ReadK &k) {
+  const float r = lds_lut_finish(p.r), g = lds_lut_finish(p.g), b = lds_lut_finish(p.b);
+  return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]),
+                     dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]), 1.0f);
+}
+// writer side, from ready-made indices (floats M + idx)
+__device__ __forceinline__ PxPending write_px_issue(float yr, float yg, float yb, const LutK &lut) {
+  PxPending p;
+  p.r = lds_lut_issue(lut, yr), p.g = lds_lut_issue(lut, yg), p.b = lds_lut_issue(lut, yb);
+  return p;
+}
+
 __device__ __forceinline__ Yuv1 write_px_lds(float r, float g, float b, const WriteK &k, const LutK &lut) {
   const float gr = lds_lut_at_unit(lut, r);
   const float gg = lds_lut_at_unit(lut, g);

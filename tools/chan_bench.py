@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""BASELINE config 2 through ph_chan_compose_v210 alone (one launch per frame): the timing loop tools/pmc_kernel.sh profiles.
+  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets]"""
+import json
+import os
+import sys
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import numpy as np
+    import torch
+    from phaneron_amd import capi
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    mask_kind = sys.argv[2] if len(sys.argv) > 2 else "rgba"
+    variant = sys.argv[3] if len(sys.argv) > 3 else "wipe"
+    ctx = capi.Context(0)
+    stream = ctx.torch_stream()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    w, h, R = 1920, 1080, 8
+    rd = [dev(capi.ycbcr2rgb_matrix("709")), dev(capi.gamma2linear_lut("709")), dev(np.concatenate([capi.rgb2rgb_matrix("709", "709"), np.zeros(3, np.float32)]))]
+    wr = [dev(capi.rgb2ycbcr_matrix("709")), dev(capi.linear2gamma_lut("709"))]
+    torch.cuda.synchronize()
+    ctx.register_lut(rd[1], capi.gamma2linear_lut("709"))
+    ctx.register_lut(wr[1], capi.linear2gamma_lut("709"))
+    words = capi.v210_pitch_bytes(w) * h // 4
+    src = [[torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device="cuda") for _ in range(6)] for _ in range(R)]
+    out = torch.empty(words, dtype=torch.int32, device="cuda")
+    mask = torch.zeros(h, w, 4, device="cuda")
+    mask[..., 0] = torch.linspace(0, 1, w, device="cuda")[None, :]
+    mask = mask.reshape(-1).contiguous()
+    mats = [capi.transform_matrix(w, h)] + [capi.transform_matrix(w, h, scale_x=0.5, scale_y=0.5, offset_x=ox, offset_y=oy)
+                                            for ox, oy in ((-0.25, -0.25), (0.25, -0.25), (0.25, 0.25))]
+    torch.cuda.synchronize()
+
+    def layers(s):
+        ls = [dict(src=(s[l], w, h, mats[l])) for l in range(4)]
+        if variant == "wipe":
+            ls[3].update(transition="wipe", incoming=(s[4], w, h, None),
+                         mask=(mask, w, h, None, "rgba") if mask_kind == "rgba" else (s[5], w, h, None))
+        elif variant == "layer0":
+            ls = ls[:1]
+        elif variant == "insets":
+            ls = ls[1:]
+        return ls
+    jobs = [ctx.chan_compose_v210(layers(s), out, w, h, 0, *rd, *wr, prepare_only=True) for s in src]
+    for i in range(8):
+        jobs[i % R]()
+    ctx.wait()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for i in range(reps):
+        jobs[i % R]()
+    e1.record(stream)
+    ctx.wait()
+    print(json.dumps({"kernel": "chan_compose_v210", "variant": variant, "mask": mask_kind, "us_per_frame": round(1e3 * e0.elapsed_time(e1) / reps, 2)}), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
