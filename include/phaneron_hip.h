@@ -242,6 +242,14 @@ typedef struct ph_deint_source {
 int ph_v210_yadif_pair(ph_ctx *ctx, int queue, int n, const ph_deint_source *sources, uint32_t width, uint32_t height,
                        int tff, int skip_spatial, const void *rd_col_matrix12, const void *rd_gamma_lut,
                        const void *rd_gamut_matrix9);
+/* the same with a choice of output layout.  PH_IMG_RGB_F32: three floats per pixel (12 bytes, rows unpadded) - what a
+ * v210 reader computes, without the alpha it sets to 1 (v210.ts:73-77, yadifCl.ts:164).  Only ph_compose_up_write_v210
+ * reads that layout: a quarter less to write here and to fetch there. */
+#define PH_IMG_RGBA_F32 0
+#define PH_IMG_RGB_F32 1
+int ph_v210_yadif_pair_fmt(ph_ctx *ctx, int queue, int n, const ph_deint_source *sources, uint32_t width, uint32_t height,
+                           int tff, int skip_spatial, int out_format, const void *rd_col_matrix12, const void *rd_gamma_lut,
+                           const void *rd_gamut_matrix9);
 
 /* transform.ts:36-59 (matrix9: device pointer to the 3x3 row-major matrix) */
 int ph_transform(ph_ctx *ctx, int queue, const void *in, int in_w, int in_h, const void *matrix9,
@@ -330,6 +338,24 @@ typedef struct ph_layer_wipe {
 int ph_compose_wipe_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *layers, const ph_layer_wipe *wipes,
                                void *out, uint32_t out_width, uint32_t out_height, uint32_t interlace,
                                const void *wr_col_matrix12, const void *wr_gamma_lut);
+
+/* ---- the compositor for magnified layers (no single reference equivalent): [transform] x N -> combine_N -> v210 write
+ *      as ph_compose_write_v210, for placements that enlarge every layer at least 2x without rotation or mirroring -
+ *      Mixer's default fill of HD sources on a UHD channel (producer/mixer.ts:209-223).  A lane produces a 2 x 2 block
+ *      of output pixels from ONE 3 x 3 patch of each source (neighbouring output pixels share their taps): 2.25 texel
+ *      loads per layer and pixel instead of 4.  Sources are f32 RGBA images or packed f32 RGB (PH_IMG_RGB_F32, alpha
+ *      == 1 implied: ph_v210_yadif_pair_fmt), all layers of a call in the same layout.  Bit-identical to ph_transform +
+ *      ph_combine + ph_v210_write.  A field write (interlace 1 / 3) needs 4x vertically: its rows are two lines apart.
+ *      PH_E_INVALID when a placement does not qualify (use ph_compose_write_v210),
+ *      out_width % 6 != 0 or the writer LUT is not registered.  interlace as ph_v210_write. -------------------- */
+typedef struct ph_image_layer {
+  const void *data;          /* device: width x height texels, rows unpadded */
+  int format;                /* PH_IMG_RGBA_F32 | PH_IMG_RGB_F32 */
+  int width, height;
+  const float *matrix9_host; /* HOST: the nine values of ph_transform_matrix */
+} ph_image_layer;
+int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer *layers, void *out, uint32_t out_width,
+                             uint32_t out_height, uint32_t interlace, const void *wr_col_matrix12, const void *wr_gamma_lut);
 
 /* ---- the channel compositor straight from the wire format (no single reference equivalent): a channel's whole
  *      per-frame job batch - per layer ToRGBA (io.ts:79-98, v210.ts:25-111) -> Mixer transform (producer/mixer.ts:

@@ -13,7 +13,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libphaneron_hip.so")
 ARCH = "gfx950"
 
-SOURCES = ["ph_kernels.hip", "ph_kernels_lds.hip", "ph_kernels_fmt.hip", "ph_kernels_field.hip", "ph_kernels_deint.hip", "ph_kernels_chan.hip", "ph_api.cpp", "ph_program.cpp", "ph_colour.cpp", "ph_lut.cpp"]
+SOURCES = ["ph_kernels.hip", "ph_kernels_lds.hip", "ph_kernels_fmt.hip", "ph_kernels_field.hip", "ph_kernels_deint.hip", "ph_kernels_chan.hip", "ph_kernels_up.hip", "ph_api.cpp", "ph_program.cpp", "ph_colour.cpp", "ph_lut.cpp"]
 HEADERS = ["ph_device.h", "ph_kernels.h", "ph_lut.h", "ph_lut_host.h", "ph_ldslut.h", "ph_program.h", "ph_yadif.h", os.path.join("..", "..", "include", "phaneron_hip.h")]
 # -ffp-contract=off: every fused multiply-add in the kernels is explicit (parity with the
 # reference's OpenCL arithmetic); no fast-math anywhere.

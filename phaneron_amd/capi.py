@@ -34,6 +34,7 @@ EXPORTS = [
     "ph_program_resolve", "ph_fused_field_v210", "ph_route_unique_id", "ph_route_init", "ph_route_destroy", "ph_route_group_begin",
     "ph_route_group_end", "ph_route_send", "ph_route_recv", "ph_route_after_queue", "ph_queue_after_route",
     "ph_route_wait", "ph_route_stream", "ph_route_comm_count", "ph_chan_compose_v210",
+    "ph_v210_yadif_pair_fmt", "ph_compose_up_write_v210",
 ]
 
 
@@ -76,6 +77,11 @@ class PhChanLayer(C.Structure):
     _fields_ = [("src", PhChanSource), ("transition", C.c_int), ("mix", C.c_float), ("incoming", PhChanSource), ("mask", PhChanSource)]
 
 
+class PhImageLayer(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("format", C.c_int), ("width", C.c_int), ("height", C.c_int), ("matrix9_host", C.POINTER(C.c_float))]
+
+
+IMG_RGBA_F32, IMG_RGB_F32 = 0, 1
 SRC_V210, SRC_RGBA_F32 = 1, 2
 TRANSITION_CUT, TRANSITION_DISSOLVE, TRANSITION_WIPE = 0, 1, 2
 
@@ -149,6 +155,7 @@ def lib():
         "ph_yadif": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
         "ph_yadif_pair": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
         "ph_v210_yadif_pair": (ci, [vp, ci, ci, vp, cu, cu, ci, ci, vp, vp, vp]),
+        "ph_v210_yadif_pair_fmt": (ci, [vp, ci, ci, vp, cu, cu, ci, ci, ci, vp, vp, vp]),
         "ph_transform": (ci, [vp, ci, vp, ci, ci, vp, vp, ci, ci]),
         "ph_resize": (ci, [vp, ci, vp, ci, ci, cf, cf, cf, vp, vp, ci, ci]),
         "ph_combine": (ci, [vp, ci, ci, C.POINTER(vp), ci, ci, vp]),
@@ -174,6 +181,7 @@ def lib():
         "ph_compose_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), vp, cu, cu, cu, vp, vp]),
         "ph_compose_wipe_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), C.POINTER(PhLayerWipe), vp, cu, cu, cu, vp, vp]),
         "ph_fused_field_v210": (ci, [vp, ci, ci, C.POINTER(PhFieldLayer), vp, cu, cu, vp, vp]),
+        "ph_compose_up_write_v210": (ci, [vp, ci, ci, C.POINTER(PhImageLayer), vp, cu, cu, cu, vp, vp]),
         "ph_chan_compose_v210": (ci, [vp, ci, ci, C.POINTER(PhChanLayer), vp, cu, cu, cu, vp, vp, vp, vp, vp]),
         "ph_route_unique_id": (ci, [vp]),
         "ph_route_init": (ci, [vp, vp, ci, ci, C.POINTER(vp)]),
@@ -358,15 +366,44 @@ class Context:
         check(lib().ph_yadif_pair(self.h, queue, _ptr(prev), _ptr(cur), _ptr(nxt), width, height, int(tff), int(skip_spatial),
                                   _ptr(dst_parity0), _ptr(dst_parity1)), self.h)
 
-    def v210_yadif_pair(self, sources, width, height, tff, skip_spatial, col_matrix, lut, gamut, queue=QUEUE_PROCESS):
-        """sources: [(prev, cur, next, dst_parity0, dst_parity1)] - v210 windows in, both de-interlaced RGBA fields out;
-        == v210_read x 3 -> yadif x 2 per source, as one kernel"""
+    def v210_yadif_pair(self, sources, width, height, tff, skip_spatial, col_matrix, lut, gamut, queue=QUEUE_PROCESS, rgb=False,
+                        prepare_only=False):
+        """sources: [(prev, cur, next, dst_parity0, dst_parity1)] - v210 windows in, both de-interlaced fields out (f32 RGBA,
+        or with rgb=True packed f32 RGB, 12 bytes per pixel); == v210_read x 3 -> yadif x 2 per source, as one kernel"""
         arr = (PhDeintSource * len(sources))()
         for i, s in enumerate(sources):
             arr[i].prev, arr[i].cur, arr[i].next = (_ptr(b).value for b in s[:3])
             arr[i].out_parity0, arr[i].out_parity1 = _ptr(s[3]).value, _ptr(s[4]).value
-        check(lib().ph_v210_yadif_pair(self.h, queue, len(sources), arr, width, height, int(tff), int(skip_spatial),
-                                       _ptr(col_matrix), _ptr(lut), _ptr(gamut)), self.h)
+        args = (self.h, queue, len(sources), arr, width, height, int(tff), int(skip_spatial), IMG_RGB_F32 if rgb else IMG_RGBA_F32,
+                _ptr(col_matrix), _ptr(lut), _ptr(gamut))
+        if prepare_only:
+            fn, h = lib().ph_v210_yadif_pair_fmt, self.h
+
+            def job(_keep=(sources,)):
+                check(fn(*args), h)
+            return job
+        check(lib().ph_v210_yadif_pair_fmt(*args), self.h)
+
+    def compose_up_write_v210(self, layers, dst, out_w, out_h, interlace, wr_cm, wr_lut, queue=QUEUE_PROCESS, rgb=False, prepare_only=False):
+        """The 2 x 2-block compositor for layers enlarged 2x or more (ph_compose_up_write_v210).  layers: [(tensor, width,
+        height, matrix)] with matrix = nine host floats (transform_matrix); rgb=True: the tensors are packed f32 RGB."""
+        import numpy as np
+        arr = (PhImageLayer * len(layers))()
+        keep = []
+        for i, (t, w, h, m) in enumerate(layers):
+            mh = np.ascontiguousarray(m, np.float32)
+            keep.append(mh)
+            arr[i].data, arr[i].width, arr[i].height = _ptr(t).value, w, h
+            arr[i].format = IMG_RGB_F32 if rgb else IMG_RGBA_F32
+            arr[i].matrix9_host = mh.ctypes.data_as(C.POINTER(C.c_float))
+        args = (self.h, queue, len(layers), arr, _ptr(dst), out_w, out_h, interlace, _ptr(wr_cm), _ptr(wr_lut))
+        if prepare_only:
+            fn, h = lib().ph_compose_up_write_v210, self.h
+
+            def job(_keep=(keep, layers, dst)):
+                check(fn(*args), h)
+            return job
+        check(lib().ph_compose_up_write_v210(*args), self.h)
 
     def transform(self, src, in_w, in_h, matrix, dst, out_w, out_h, queue=QUEUE_PROCESS):
         check(lib().ph_transform(self.h, queue, _ptr(src), in_w, in_h, _ptr(matrix), _ptr(dst), out_w, out_h), self.h)

@@ -1587,7 +1587,44 @@ int ph_yadif_pair(ph_ctx *ctx, int queue, const void *prev, const void *cur, con
 
 int ph_v210_yadif_pair(ph_ctx *ctx, int queue, int n, const ph_deint_source *src, uint32_t width, uint32_t height, int tff,
                        int skip, const void *cm, const void *lut, const void *gm) {
+  return ph_v210_yadif_pair_fmt(ctx, queue, n, src, width, height, tff, skip, PH_IMG_RGBA_F32, cm, lut, gm);
+}
+
+int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
+                             uint32_t interlace, const void *wr_cm, const void *wr_lut) {
+  if (!ctx || !layers || !out || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_compose_up_write_v210: NULL argument");
+  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_compose_up_write_v210: 1..%d layers", ph::kMaxLayers);
+  if (!out_w || out_w % 48) return fail(PH_E_INVALID, "ph_compose_up_write_v210: width %u is not a multiple of 48; run the separate kernels", out_w);
+  if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_compose_up_write_v210: interlace must be 0, 1 or 3");
+  const ph::LutView *wv = lds_view(ctx, wr_lut);
+  if (!wv) return fail(PH_E_INVALID, "ph_compose_up_write_v210: the writer gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)");
+  ph::UpArgs a{};
+  a.n = n;
+  const int fmt = layers[0].format;
+  if (fmt != PH_IMG_RGBA_F32 && fmt != PH_IMG_RGB_F32) return fail(PH_E_INVALID, "ph_compose_up_write_v210: image format %d", fmt);
+  for (int i = 0; i < n; ++i) {
+    const ph_image_layer &L = layers[i];
+    if (!L.data || L.width <= 0 || L.height <= 0 || !L.matrix9_host) return fail(PH_E_INVALID, "ph_compose_up_write_v210: layer %d is incomplete", i);
+    if (L.format != fmt) return fail(PH_E_INVALID, "ph_compose_up_write_v210: layer %d has another image format than layer 0", i);
+    a.layer[i].ptr = L.data, a.layer[i].w = (uint32_t)L.width, a.layer[i].h = (uint32_t)L.height;
+    a.layer[i].pitch = (uint32_t)L.width * (fmt == PH_IMG_RGB_F32 ? 12u : 16u);
+    for (int k = 0; k < 6; ++k) a.layer[i].m[k] = L.matrix9_host[k];
+  }
+  a.out = out, a.out_w = out_w, a.out_h = out_h;
+  a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0;
+  a.lines = interlace ? out_h / 2 : out_h;
+  a.wr_cm = (const float *)wr_cm, a.wr = *wv;
+  if (!ph::compose_up_eligible(a))
+    return fail(PH_E_INVALID, "ph_compose_up_write_v210: every layer must be enlarged 2x or more without rotation or mirroring (and be below 1 GiB); "
+                              "use ph_compose_write_v210");
+  if (!a.lines) return PH_OK;
+  PH_LAUNCH(ph::launch_compose_up_write_v210(stream_of(ctx, queue), a, fmt == PH_IMG_RGB_F32, (uint32_t)ctx->props.multiProcessorCount));
+}
+
+int ph_v210_yadif_pair_fmt(ph_ctx *ctx, int queue, int n, const ph_deint_source *src, uint32_t width, uint32_t height, int tff,
+                           int skip, int out_format, const void *cm, const void *lut, const void *gm) {
   if (!ctx || !src || !cm || !lut || !gm) return fail(PH_E_INVALID, "ph_v210_yadif_pair: NULL argument");
+  if (out_format != PH_IMG_RGBA_F32 && out_format != PH_IMG_RGB_F32) return fail(PH_E_INVALID, "ph_v210_yadif_pair: output format %d", out_format);
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_v210_yadif_pair: 1..%d sources", ph::kMaxLayers);
   if (!width || width % 6) return fail(PH_E_INVALID, "ph_v210_yadif_pair: width %u is not a multiple of 6; run the separate kernels", width);
   const ph::LutView *v = lds_view(ctx, lut);
@@ -1603,6 +1640,7 @@ int ph_v210_yadif_pair(ph_ctx *ctx, int queue, int n, const ph_deint_source *src
   }
   if (!height) return PH_OK;
   a.n = n, a.skip = skip ? 1 : 0, a.width = width, a.height = height, a.quads_pitch = ph_v210_pitch_bytes(width) / 16;
+  a.rgb12 = out_format == PH_IMG_RGB_F32 ? 1u : 0u;
   a.cm = (const float *)cm, a.gm = (const float *)gm, a.lut = *v;
   PH_LAUNCH(ph::launch_v210_yadif_pair(stream_of(ctx, queue), a, tff ? 1 : 0, (uint32_t)ctx->props.multiProcessorCount));
 }

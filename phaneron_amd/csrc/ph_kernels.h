@@ -85,12 +85,32 @@ struct ChanArgs {
   LutView rd, wr;
 };
 
+// ph_kernels_up.hip: the 2 x 2-block compositor for magnifying placements
+struct UpLayer {
+  const void *ptr;       // f32 RGBA (16 bytes per texel) or packed f32 RGB (12)
+  uint32_t w, h, pitch;  // texels, texels, bytes per row
+  uint32_t pad;
+  float m[6];            // rows 0 and 1 of the 3x3 transform matrix
+};
+struct UpArgs {
+  UpLayer layer[kMaxLayers];
+  int n;
+  void *out;
+  uint32_t out_w, out_h, lines, first_line, line_step;
+  const float *wr_cm;
+  LutView wr;
+  uint32_t magic_upr, magic_upg;  // launcher
+};
+bool compose_up_eligible(const UpArgs &a);
+hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb12, uint32_t num_cus);
+
 struct DeintArgs {  // ph_kernels_deint.hip
   const uint4 *prev[kMaxLayers], *cur[kMaxLayers], *next[kMaxLayers];  // v210 frames, width x height
   float4 *out0[kMaxLayers], *out1[kMaxLayers];                         // RGBA f32: yadif parity 0 / parity 1
   int n, skip;
   uint32_t width, height, quads_pitch;
   uint32_t rows_per_strip, strips, col_blocks, nt;  // filled in by the launcher
+  uint32_t rgb12;  // 1: the outputs are packed f32 RGB (12 bytes per pixel, the reader's alpha == 1 left out)
   const float *cm, *gm;
   LutView lut;
 };

@@ -126,8 +126,17 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
                                 PH_RGB(PH_W(N, 1), c), PH_RGB(PH_W(N, 3), c), sp, a.skip);
       }
       if (emit) {
-        store_image(out_copy + (size_t)y * w + xr, make_float4(PH_W(C, 2).r, PH_W(C, 2).g, PH_W(C, 2).b, 1.0f), a.nt);  // yadifCl.ts:117-121
-        store_image(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], 1.0f), a.nt);                  // :164 alpha from cur
+        if (a.rgb12) {  // uniform: packed RGB for the 2 x 2-block compositor (ph_kernels_up.hip); alpha == 1 is implied
+          typedef float ph_f3v __attribute__((ext_vector_type(3)));
+          ph_f3v *const pc = reinterpret_cast<ph_f3v *>(reinterpret_cast<char *>(out_copy) + ((size_t)y * w + xr) * 12);
+          ph_f3v *const pi = reinterpret_cast<ph_f3v *>(reinterpret_cast<char *>(out_interp) + ((size_t)y * w + xr) * 12);
+          const ph_f3v vc = {PH_W(C, 2).r, PH_W(C, 2).g, PH_W(C, 2).b}, vi = {res[0], res[1], res[2]};
+          if (a.nt) __builtin_nontemporal_store(vc, pc), __builtin_nontemporal_store(vi, pi);
+          else *pc = vc, *pi = vi;
+        } else {
+          store_image(out_copy + (size_t)y * w + xr, make_float4(PH_W(C, 2).r, PH_W(C, 2).g, PH_W(C, 2).b, 1.0f), a.nt);  // yadifCl.ts:117-121
+          store_image(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], 1.0f), a.nt);                  // :164 alpha from cur
+        }
       }
       PH_W(C, 0) = unpack_px<STD>(rc, pick, k, lk), PH_W(P, 0) = unpack_px<STD>(rp, pick, k, lk), PH_W(N, 0) = unpack_px<STD>(rn, pick, k, lk);
 #undef PH_W
@@ -171,7 +180,7 @@ hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t 
     const uint64_t cost = rounds * (r + 4);
     if (cost < best_cost) best_cost = cost, best_r = r;
   }
-  a.nt = image_nt((size_t)a.width * a.height * 16);
+  a.nt = image_nt((size_t)a.width * a.height * (a.rgb12 ? 12 : 16));
   a.rows_per_strip = best_r;
   a.strips = (a.height + best_r - 1) / best_r;
   const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;

@@ -1,0 +1,317 @@
+// ph_kernels_up.hip - the compositor for MAGNIFYING placements: [transform] x N -> combine_N -> v210 write as one kernel,
+// each lane producing a 2 x 2 block of output pixels.
+//
+// The pixel-per-lane compositor (ph_kernels_lds.hip) loads four 16-byte taps per layer and output pixel; for BASELINE
+// config 3 (four 1080 sources shown at 2160) that is 256 bytes through the texture addressers per output pixel, and
+// they - not HBM, not the VALU - were what the kernel waited for.  When a layer is magnified at least 2x without rotation
+// (Mixer's default fill of an HD source on a UHD channel: producer/mixer.ts:209-223, transform.ts:36-59), neighbouring
+// output pixels share their taps: the four pixels (x, x + 1) x (y, y + 1) with x, y even draw all sixteen taps from a
+// 3 x 3 patch of the source.  A lane owns such a block, loads the nine texels once per layer and picks each pixel's
+// 2 x 2 sub-patch with selects (columns, per lane) and a uniform branch (rows): 2.25 taps per pixel instead of 4, and with
+// sources stored as packed RGB (12 bytes per texel: alpha == 1 is implied for a de-interlaced v210 source,
+// ph_v210_yadif_pair_fmt) 27 bytes per layer and pixel instead of 64.  Arithmetic and its order are those of
+// transform.ts / combine.ts / v210.ts, pixel by pixel: results are bit-identical to the separate kernels.
+//
+// Shape: only the writer's table is needed (one phase); one 1024-lane workgroup per CU, persistent.  A wave step is
+// 126 columns x 2 rows: 63 lanes x (2 x 2) - 21 v210 quads per row, three lanes to a quad.  The lanes of a quad hand
+// their code values to each other with two DPP moves per row (no LDS staging): lane A (pixels 0, 1) and lane C (4, 5)
+// each store half of the packed quad, lane B (2, 3) only gives.
+#include "ph_device.h"
+#include "ph_kernels.h"
+#include "ph_ldslut.h"
+
+#pragma clang fp contract(off)
+
+#ifndef PH_UP_GROUP_ROWS
+#define PH_UP_GROUP_ROWS 16
+#endif
+
+namespace ph {
+
+constexpr uint32_t kUpCols = 126;              // output columns of a wave step
+constexpr uint32_t kUpOutside = 0x40000000u;   // offsets of texels outside the image: beyond any num_records (images < 1 GiB)
+
+typedef uint32_t ph_u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t ph_u32x4 __attribute__((ext_vector_type(4)));
+
+struct UpTexel {
+  float r, g, b, a;
+};
+template <bool RGB12>
+__device__ __forceinline__ UpTexel up_load(__amdgpu_buffer_rsrc_t img, uint32_t off) {  // outside: 0 = the border colour
+  if (RGB12) {
+    const ph_u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(img, (int)off, 0, 0);
+    UpTexel t;  // .a is not part of a packed-RGB texel (UpPend::cin / rin)
+    t.r = __uint_as_float(v.x), t.g = __uint_as_float(v.y), t.b = __uint_as_float(v.z);
+    return t;
+  }
+  const ph_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(img, (int)off, 0, 0);
+  return UpTexel{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ UpTexel up_pick(bool second, const UpTexel &t0, const UpTexel &t1) {
+  return UpTexel{second ? t1.r : t0.r, second ? t1.g : t0.g, second ? t1.b : t0.b, second ? t1.a : t0.a};
+}
+
+struct UpShare {  // as ChanShare (ph_kernels_chan.hip): units dealt XCD-aware in groups of output rows, divisions by reciprocal
+  uint32_t units, upg, upr, xcd, v0, vstep, vend, slots;
+  bool banded;
+};
+__device__ __forceinline__ UpShare up_share(const UpArgs &a) {
+  UpShare s;
+  s.upr = (a.out_w + kUpCols - 1u) / kUpCols;  // wave steps per row pair
+  s.units = s.upr * ((a.lines + 1u) / 2u);
+  s.upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * s.upr;
+  s.banded = (gridDim.x & 7u) == 0;
+  s.xcd = 0, s.v0 = blockIdx.x * (kLdsBlock / 64), s.vstep = gridDim.x * (kLdsBlock / 64), s.vend = s.units;
+  if (s.banded) {
+    s.xcd = blockIdx.x & 7u;
+    const uint32_t groups = (s.units + s.upg - 1u) / s.upg, mine = (groups + 7u - s.xcd) / 8u;
+    s.v0 = (blockIdx.x >> 3) * (kLdsBlock / 64), s.vstep = (gridDim.x >> 3) * (kLdsBlock / 64), s.vend = mine * s.upg;
+  }
+  return s;
+}
+__device__ __forceinline__ uint32_t up_unit(const UpArgs &a, const UpShare &s, uint32_t v) {
+  if (!s.banded) return v < s.units ? v : ~0u;
+  const uint32_t gi = __umulhi(v, a.magic_upg);  // v / upg
+  const uint32_t unit = (gi * 8u + s.xcd) * s.upg + (v - gi * s.upg);
+  return unit < s.units ? unit : ~0u;
+}
+
+// one output pixel of a layer: the sampler's filter on its 2 x 2 sub-patch (OpenCL 1.2 8.2 as DESIGN.md section 2 fixes it),
+// then combine.ts:45-65 into the pixel's accumulator
+struct UpAcc {
+  float r, g, b;
+};
+template <bool RGB12>
+__device__ __forceinline__ void up_blend(const UpTexel &t00, const UpTexel &t10, const UpTexel &t01, const UpTexel &t11, float wa, float wb,
+                                         bool first, bool all_inside, UpAcc &acc) {
+  const float oma = 1.0f - wa, omb = 1.0f - wb;
+  const float w00 = oma * omb, w10 = wa * omb, w01 = oma * wb, w11 = wa * wb;
+  const float r = ((w00 * t00.r + w10 * t10.r) + w01 * t01.r) + w11 * t11.r;
+  const float g = ((w00 * t00.g + w10 * t10.g) + w01 * t01.g) + w11 * t11.g;
+  const float b = ((w00 * t00.b + w10 * t10.b) + w01 * t01.b) + w11 * t11.b;
+  float al;
+  if (RGB12 && all_inside) al = ((w00 + w10) + w01) + w11;  // every texel's alpha is exactly 1: w * 1 == w
+  else al = ((w00 * t00.a + w10 * t10.a) + w01 * t01.a) + w11 * t11.a;
+  if (first) {
+    acc.r = r, acc.g = g, acc.b = b;
+  } else {  // the result's alpha is never used by the writer
+    const float kk = 1.0f - al;
+    acc.r = fma_rn(acc.r, kk, r), acc.g = fma_rn(acc.g, kk, g), acc.b = fma_rn(acc.b, kk, b);
+  }
+}
+
+// where a wave step lies: 126 columns x 2 rows; the lane's block starts at (x0, line[0])
+struct UpStep {
+  uint32_t x0, li[2], line[2];
+  float px[2], py[2];
+  bool live;
+};
+__device__ __forceinline__ bool up_step(const UpArgs &a, const UpShare &sh, uint32_t &v, uint32_t lane, UpStep &st) {
+  for (; v < sh.vend; v += sh.vstep) {
+    const uint32_t unit = up_unit(a, sh, v);
+    if (unit == ~0u) continue;  // uniform
+    const uint32_t rp = sh.upr == 1u ? unit : __umulhi(unit, a.magic_upr);  // unit / upr
+    st.x0 = (unit - rp * sh.upr) * kUpCols + 2u * lane;  // even
+    st.live = lane < 63u && st.x0 < a.out_w;               // lane 63 has no quad; the row's last step may be short
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      st.li[dy] = 2u * rp + (uint32_t)dy < a.lines ? 2u * rp + (uint32_t)dy : 2u * rp;  // an odd field's last row is its own partner
+      st.line[dy] = a.first_line + st.li[dy] * a.line_step;
+      st.py[dy] = (float)(int)st.line[dy] / (float)(int)a.out_h - 0.5f;  // transform.ts:53
+    }
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) st.px[dx] = (float)(int)(st.x0 + (uint32_t)dx) / (float)(int)a.out_w - 0.5f;
+    return true;
+  }
+  return false;
+}
+
+// A layer's 3 x 3 patch for the lane's block, in two halves (addresses + loads, then the filter) so that a caller can have
+// two layers' texels in flight together.
+template <bool RGB12>
+struct UpPend {
+  UpTexel P[3][3];
+  float wa[2], wb[2];
+  bool d1;          // per lane: the right pixel's first tap is one texel further than the left pixel's
+  bool dj;          // uniform: likewise the lower row's
+  bool all_inside;  // uniform (packed RGB): every texel of every lane's patch is inside the image
+  uint32_t cin;     // packed RGB, per lane: bit c = patch column c is inside the image
+  uint32_t rin;     // packed RGB, uniform: bit r = patch row r is inside
+};
+template <bool RGB12>
+__device__ __forceinline__ void up_issue(const UpLayer &L, const UpStep &st, bool more, UpPend<RGB12> &p) {
+  constexpr uint32_t kTexel = RGB12 ? 12u : 16u;
+  const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(L.ptr), 0, (int)(L.pitch * L.h), 0x00020000);
+  // columns (per lane): transform.ts:53-57 with m1 == 0 (host-checked): fma(py, 0, px * m0) == px * m0 for every finite py
+  uint32_t i0[2];
+#pragma unroll
+  for (int dx = 0; dx < 2; ++dx) {
+    const float sx = dot3(L.m[0], L.m[1], L.m[2], st.px[dx], st.py[0], 1.0f) + 0.5f;
+    const float fu = sx * (float)(int)L.w - 0.5f, flu = __builtin_floorf(fu);
+    i0[dx] = (uint32_t)(int)flu, p.wa[dx] = fu - flu;
+  }
+  // rows (the same for every lane: m3 == 0, host-checked; computed on the lane's own operands, read from one lane)
+  uint32_t j0[2];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    const float sy = dot3(L.m[3], L.m[4], L.m[5], st.px[0], st.py[dy], 1.0f) + 0.5f;
+    const float fv = sy * (float)(int)L.h - 0.5f, flv = __builtin_floorf(fv);
+    j0[dy] = (uint32_t)__builtin_amdgcn_readfirstlane((int)flv);
+    p.wb[dy] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(fv - flv)));
+  }
+  // the 3 x 3 patch: columns i0[0] .. + 2 (i0[1] - i0[0] is 0 or 1 for a magnification of 2 or more), rows j0[0] .. + 2
+  p.d1 = i0[1] != i0[0];
+  p.dj = j0[1] != j0[0];
+  uint32_t coff[3], roff[3];
+  bool cin[3], rin[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const uint32_t col = i0[0] + (uint32_t)c;
+    cin[c] = more && col < L.w;
+    coff[c] = cin[c] ? __umul24(col, kTexel) : kUpOutside;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const uint32_t row = j0[0] + (uint32_t)r;
+    rin[r] = row < L.h;
+    roff[r] = rin[r] ? row * L.pitch : kUpOutside;  // uniform
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p.P[r][c] = up_load<RGB12>(img, roff[r] + coff[c]);
+  p.all_inside = false, p.cin = 0, p.rin = 0;
+  if (RGB12) {  // alpha of a packed-RGB texel: 1 inside the image, 0 (the border colour) outside - made when the patch is filtered
+    const bool mine = cin[0] && cin[1] && cin[2];
+    p.all_inside = rin[0] && rin[1] && rin[2] && __builtin_amdgcn_ballot_w64(!mine) == 0;  // uniform
+    p.cin = (cin[0] ? 1u : 0u) | (cin[1] ? 2u : 0u) | (cin[2] ? 4u : 0u);
+    p.rin = (rin[0] ? 1u : 0u) | (rin[1] ? 2u : 0u) | (rin[2] ? 4u : 0u);
+  }
+}
+template <bool RGB12>
+__device__ __forceinline__ void up_finish(const UpPend<RGB12> &p, bool first, UpAcc (&acc)[2][2]) {
+  UpTexel P[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      P[r][c] = p.P[r][c];
+      if (RGB12) P[r][c].a = (!p.all_inside && ((p.rin >> r) & 1u) && ((p.cin >> c) & 1u)) ? 1.0f : 0.0f;  // unused when all are inside
+    }
+  const bool d1 = p.d1, ai = p.all_inside;
+  // upper output row: patch rows 0, 1; left pixel: columns 0, 1; right pixel: columns d1, d1 + 1
+  up_blend<RGB12>(P[0][0], P[0][1], P[1][0], P[1][1], p.wa[0], p.wb[0], first, ai, acc[0][0]);
+  up_blend<RGB12>(up_pick(d1, P[0][0], P[0][1]), up_pick(d1, P[0][1], P[0][2]), up_pick(d1, P[1][0], P[1][1]), up_pick(d1, P[1][1], P[1][2]),
+                  p.wa[1], p.wb[0], first, ai, acc[0][1]);
+  // lower output row: patch rows dj, dj + 1 (a uniform branch: no selects)
+  if (p.dj) {
+    up_blend<RGB12>(P[1][0], P[1][1], P[2][0], P[2][1], p.wa[0], p.wb[1], first, ai, acc[1][0]);
+    up_blend<RGB12>(up_pick(d1, P[1][0], P[1][1]), up_pick(d1, P[1][1], P[1][2]), up_pick(d1, P[2][0], P[2][1]), up_pick(d1, P[2][1], P[2][2]),
+                    p.wa[1], p.wb[1], first, ai, acc[1][1]);
+  } else {
+    up_blend<RGB12>(P[0][0], P[0][1], P[1][0], P[1][1], p.wa[0], p.wb[1], first, ai, acc[1][0]);
+    up_blend<RGB12>(up_pick(d1, P[0][0], P[0][1]), up_pick(d1, P[0][1], P[0][2]), up_pick(d1, P[1][0], P[1][1]), up_pick(d1, P[1][1], P[1][2]),
+                    p.wa[1], p.wb[1], first, ai, acc[1][1]);
+  }
+}
+
+// writer (v210.ts:145-162) of the lane's block: the even pixel gives Y, Cb, Cr, the odd one Y; then the quad's three lanes trade halves
+__device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, const UpAcc (&acc)[2][2], uint32_t role, const WriteK &wk, const LutK &lk) {
+  const uint32_t qpl = a.out_w / 6u;
+  // the twelve table reads of the block's four pixels are started together
+  PxPending pend[2][2];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+      pend[dy][dx] = write_px_issue(lds_lut_index_unit(acc[dy][dx].r), lds_lut_index_unit(acc[dy][dx].g), lds_lut_index_unit(acc[dy][dx].b), lk);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    const float er = lds_lut_finish(pend[dy][0].r), eg = lds_lut_finish(pend[dy][0].g), eb = lds_lut_finish(pend[dy][0].b);
+    const float orr = lds_lut_finish(pend[dy][1].r), og = lds_lut_finish(pend[dy][1].g), ob = lds_lut_finish(pend[dy][1].b);
+    const uint32_t ey = sat_u16_rte(dot4(er, eg, eb, 1.0f, wk.y)), eu = sat_u16_rte(dot4(er, eg, eb, 1.0f, wk.u)), ev = sat_u16_rte(dot4(er, eg, eb, 1.0f, wk.v));
+    const uint32_t y1 = sat_u16_rte(dot4(orr, og, ob, 1.0f, wk.y));
+    // lane B's gifts: to A (the lane before it) Cb2 << 10 | Y2 << 20, to C (the lane after it) Cr2 | Y3 << 10
+    const uint32_t to_prev = eu << 10 | ey << 20, to_next = ev | y1 << 10;
+    const uint32_t from_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)to_prev, 0x130 /* wave_shl:1: lane i reads lane i + 1 */, 0xf, 0xf, false);
+    const uint32_t from_prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)to_next, 0x138 /* wave_shr:1: lane i reads lane i - 1 */, 0xf, 0xf, false);
+    uint2 half;
+    if (role == 0u) half = make_uint2(ev << 20 | ey << 10 | eu, from_next | y1);  // w0, w1
+    else half = make_uint2(eu << 20 | from_prev, y1 << 20 | ev << 10 | ey);      // w2, w3 (lane C)
+    const bool store = st.live && role != 1u && (dy == 0 || st.li[1] != st.li[0]);
+    if (store) {
+      uint2 *dst = reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(a.out) + (size_t)st.line[dy] * qpl + st.x0 / 6u) + (role == 2u ? 1 : 0);
+      __builtin_nontemporal_store(half.x, &dst->x);
+      __builtin_nontemporal_store(half.y, &dst->y);
+    }
+  }
+}
+
+template <bool RGB12>
+__global__ __launch_bounds__(kLdsBlock) void compose_up_write_v210_kernel(UpArgs a) {
+  const WriteK wk = load_write_k(a.wr_cm);
+  const LutK lk = make_lut_k(a.wr);
+  lds_lut_load(a.wr);
+  __syncthreads();
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const UpShare sh = up_share(a);
+  const uint32_t role = lane - 3u * (lane / 3u);  // 0: pixels 0, 1 of the quad, 1: pixels 2, 3, 2: pixels 4, 5
+  UpStep st;
+  for (uint32_t v = sh.v0 + wave; up_step(a, sh, v, lane, st); v += sh.vstep) {
+    UpAcc acc[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = UpAcc{0.0f, 0.0f, 0.0f};
+    // one layer at a time.  Two variants were built and measured slower at 2160p x 4 layers (70 us): layers in pairs with both
+    // patches in flight (76 us) and a patch carried in flight across loop turns (85 us) - two patches plus the writer's
+    // temporaries do not fit 128 registers
+#pragma unroll 1
+    for (int l = 0; l < a.n; ++l) {
+      const UpLayer L = a.layer[l];  // one 48-byte scalar load
+      UpPend<RGB12> p;
+      up_issue<RGB12>(L, st, true, p);
+      up_finish<RGB12>(p, l == 0, acc);
+    }
+    up_write(a, st, acc, role, wk, lk);
+  }
+}
+
+// Does the 2 x 2 block scheme apply?  Unrotated, unmirrored, magnified by 2 or more in both directions (then neighbouring
+// output pixels' first taps are at most one texel apart, rounding noise included), images below 1 GiB.
+bool compose_up_eligible(const UpArgs &a) {
+  if (a.out_w % 6u || !a.n) return false;
+  for (int l = 0; l < a.n; ++l) {
+    const UpLayer &L = a.layer[l];
+    if (L.m[1] != 0.0f || L.m[3] != 0.0f || !(L.m[0] > 0.0f) || !(L.m[4] > 0.0f)) return false;
+    // source texels per output pixel: d(u)/dx = m0 * w / out_w; per WRITTEN row: d(v)/dy = m4 * h / out_h * line_step (a field
+    // write takes every other line).  At most half a texel: then the first taps of neighbours are 0 or 1 apart whatever
+    // the f32 noise at a texel boundary does; with a whole texel between them it could be 2.
+    if ((double)L.m[0] * L.w > 0.5 * a.out_w || (double)L.m[4] * L.h * a.line_step > 0.5 * a.out_h) return false;
+    if ((uint64_t)L.pitch * L.h >= (1ull << 30) || L.w >= (1u << 22)) return false;
+  }
+  return true;
+}
+
+hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb12, uint32_t num_cus) {
+  if (!a.lines) return hipSuccess;
+  const void *fn = rgb12 ? reinterpret_cast<const void *>(compose_up_write_v210_kernel<true>)
+                         : reinterpret_cast<const void *>(compose_up_write_v210_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.wr.bytes);
+  if (e != hipSuccess) return e;
+  UpArgs b = a;
+  const uint32_t upr = (a.out_w + kUpCols - 1u) / kUpCols, upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * upr;
+  const uint32_t units = upr * ((a.lines + 1u) / 2u);
+  // reciprocals for the kernel's uniform divisions: umulhi(v, ceil(2^32 / d)) == v / d while v * d < 2^32
+  b.magic_upr = upr > 1 ? (uint32_t)(((1ull << 32) + upr - 1) / upr) : 0u;
+  b.magic_upg = (uint32_t)(((1ull << 32) + upg - 1) / upg);
+  const uint32_t want = (units + kLdsBlock / 64 - 1) / (kLdsBlock / 64);
+  const uint32_t grid = want < num_cus ? want : num_cus;
+  if (rgb12) compose_up_write_v210_kernel<true><<<grid, kLdsBlock, a.wr.bytes, s>>>(b);
+  else compose_up_write_v210_kernel<false><<<grid, kLdsBlock, a.wr.bytes, s>>>(b);
+  return hipGetLastError();
+}
+
+}  // namespace ph

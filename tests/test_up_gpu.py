@@ -1,0 +1,157 @@
+"""GPU tests (-m gpu) of ph_compose_up_write_v210 (a 2 x 2 block of output pixels per lane from one 3 x 3 source patch per
+layer, for layers enlarged 2x or more) and of the packed-RGB output of ph_v210_yadif_pair_fmt that feeds it.  Compared word
+for word with the oracle's chain transform.ts -> combine.ts -> v210.ts write."""
+import numpy as np
+import pytest
+
+import frames
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def m(ow, oh, **kw):
+    from phaneron_amd import capi
+    return capi.transform_matrix(ow, oh, **kw)
+
+
+def run(layers, ow, oh, interlace=0, rgb=False, spec="2020", dst=None):
+    """layers: [(rgba float array h x w x 4, matrix)]; returns (device words, oracle words)"""
+    import torch
+    import hip_harness as hh
+    k = hh.ctx()
+    wcm, wlut = hh.ColourParams.writer(spec)
+    wr_o = (orc.rgb2ycbcr_matrix(spec), orc.linear2gamma_lut(spec))
+    placed = [orc.transform(img, mat, ow, oh) for img, mat in layers]
+    comb = placed[0] if len(placed) == 1 else orc.combine(placed)
+    want = orc.v210_write(comb, ow, oh, interlace, *wr_o, out=None if dst is None else dst.copy())
+    out = hh.dev(dst) if dst is not None else torch.zeros(frames.v210_pitch_bytes(ow) * oh // 4, dtype=torch.int32, device="cuda")
+    dl = []
+    for img, mat in layers:
+        h, w, _ = img.shape
+        data = np.ascontiguousarray(img[..., :3]) if rgb else img
+        dl.append((hh.dev(data.reshape(-1)), w, h, mat))
+    k.compose_up_write_v210(dl, out, ow, oh, interlace, wcm, wlut, rgb=rgb)
+    return hh.host(out, np.uint32), np.asarray(want).reshape(-1)
+
+
+def check(layers, ow, oh, what, **kw):
+    got, want = run(layers, ow, oh, **kw)
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, "%s: %d of %d words differ, first at word %d (line %d)" % (
+        what, bad.size, got.size, bad[0], bad[0] // (frames.v210_pitch_bytes(ow) // 4))
+
+
+def opaque(w, h, seed):
+    img = frames.rgba_random(w, h, seed, -0.05, 1.05)
+    img = img.reshape(h, w, 4).copy()
+    img[..., 3] = 1.0
+    return img
+
+
+@pytest.mark.parametrize("rgb", [False, True], ids=["rgba", "packed-rgb"])
+@pytest.mark.parametrize("n", [1, 2, 4])
+def test_two_times_up_scale_of_full_frame_layers(n, rgb):
+    """BASELINE config 3's compositor: 2x identity fill of every layer (transform.ts:54-55 without the half-pixel term: every
+    second output pixel's first tap sits exactly on a texel boundary, where f32 noise decides which texel it is)"""
+    sw, sh, ow, oh = 192, 54, 384, 108
+    layers = [(opaque(sw, sh, 10 + l) if rgb else frames.rgba_random(sw, sh, 10 + l, -0.05, 1.05).reshape(sh, sw, 4), m(ow, oh)) for l in range(n)]
+    check(layers, ow, oh, "%d layers 2x" % n, rgb=rgb)
+
+
+@pytest.mark.parametrize("rgb", [False, True], ids=["rgba", "packed-rgb"])
+def test_insets_with_borders_and_other_magnifications(rgb):
+    """layers that cover part of the frame (the border colour and its alpha 0 take part), 3x and 2.5x, sources of several sizes"""
+    ow, oh = 384, 120
+    mk = (lambda w, h, s: opaque(w, h, s)) if rgb else (lambda w, h, s: frames.rgba_random(w, h, s, 0.0, 1.0).reshape(h, w, 4))
+    layers = [(mk(192, 60, 1), m(ow, oh)),                                                    # 2x, full frame
+              (mk(48, 15, 2), m(ow, oh, scale_x=0.5, scale_y=0.5, offset_x=-0.25, offset_y=0.2)),  # 4x, inset
+              (mk(64, 20, 3), m(ow, oh, scale_x=0.5, scale_y=0.5, offset_x=0.3, offset_y=-0.3)),   # 3x, partly off screen
+              (mk(96, 24, 4), m(ow, oh, scale_x=0.625, scale_y=0.5, offset_x=0.05, offset_y=0.1))]  # 2.5x
+    check(layers, ow, oh, "insets", rgb=rgb)
+    check(layers[1:], ow, oh, "insets without a background", rgb=rgb)
+
+
+@pytest.mark.parametrize("interlace", [1, 3])
+def test_field_outputs(interlace):
+    """a field write takes every other line: a layer must be enlarged 4x vertically for its written rows to be half a texel apart"""
+    import hip_harness as hh
+    from phaneron_amd import capi
+    sw, sh, ow, oh = 96, 13, 192, 54
+    dst = np.full(frames.v210_pitch_bytes(ow) * oh // 4, 0x2AAAAAAA, np.uint32)
+    layers = [(opaque(sw, sh, 20), m(ow, oh)), (opaque(48, 6, 21), m(ow, oh, scale_x=0.5, scale_y=0.5, offset_x=0.2))]
+    check(layers, ow, oh, "interlace %d" % interlace, interlace=interlace, rgb=True, dst=dst)
+    with pytest.raises(capi.PhaneronError, match="enlarged 2x or more"):  # 2x vertically is not enough for a field
+        run([(opaque(96, 27, 22), m(ow, oh))], ow, oh, interlace=interlace, rgb=True)
+
+
+def test_frame_shapes():
+    """a row shorter than a wave step, rows that end in a short step, an odd number of rows (the last row has no partner),
+    a frame smaller than the chip"""
+    for ow, oh, sw, sh in ((48, 6, 24, 3), (192, 7, 96, 3), (336, 9, 100, 4), (3840, 26, 1920, 13)):
+        layers = [(opaque(sw, sh, 30), m(ow, oh)), (opaque(sw // 2, max(sh // 2, 1), 31), m(ow, oh, scale_x=0.5, scale_y=0.5, offset_x=-0.2, offset_y=0.1))]
+        check(layers, ow, oh, "%dx%d" % (ow, oh), rgb=True)
+
+
+def test_placements_that_do_not_qualify_are_refused():
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    k = hh.ctx()
+    wcm, wlut = hh.ColourParams.writer("709")
+    ow, oh = 192, 54
+    src = hh.dev(opaque(96, 27, 40).reshape(-1))
+    out = torch.zeros(frames.v210_pitch_bytes(ow) * oh // 4, dtype=torch.int32, device="cuda")
+    for kw in (dict(rotate=0.1), dict(flip_h=True), dict(scale_x=0.9, scale_y=0.9)):
+        mat = capi.transform_matrix(ow, oh, **kw)
+        src_w = 192 if "scale_x" in kw else 96  # a 192-wide source shrunk to 0.9: less than 2x
+        with pytest.raises(capi.PhaneronError, match="enlarged 2x or more"):
+            k.compose_up_write_v210([(src, src_w, 27 if src_w == 96 else 13, mat)], out, ow, oh, 0, wcm, wlut)
+
+
+def test_packed_rgb_fields_equal_the_rgba_fields():
+    """ph_v210_yadif_pair_fmt(PH_IMG_RGB_F32): the same two de-interlaced fields without their constant alpha"""
+    import torch
+    import hip_harness as hh
+    k = hh.ctx()
+    w, h = 384, 40
+    cm, lut, gm = hh.ColourParams.reader("709", "2020")
+    win = [hh.dev(frames.v210_random(w, h, frames.layer_seed(7, i), legal=(i != 1))) for i in range(3)]
+    for tff in (1, 0):
+        rgba = [torch.zeros(w * h * 4, dtype=torch.float32, device="cuda") for _ in range(2)]
+        rgb = [torch.zeros(w * h * 3, dtype=torch.float32, device="cuda") for _ in range(2)]
+        k.v210_yadif_pair([(win[0], win[1], win[2], rgba[0], rgba[1])], w, h, tff, False, cm, lut, gm)
+        k.v210_yadif_pair([(win[0], win[1], win[2], rgb[0], rgb[1])], w, h, tff, False, cm, lut, gm, rgb=True)
+        for a, b in zip(rgba, rgb):
+            a4 = hh.host(a).reshape(-1, 4)
+            assert np.all(a4[:, 3] == 1.0)
+            assert np.array_equal(a4[:, :3].view(np.uint32), hh.host(b).reshape(-1, 3).view(np.uint32))
+
+
+def test_config3_route_at_full_size():
+    """BASELINE config 3 as bench.py times it now: per frame ONE de-interlacing reader launch (packed RGB fields), per field
+    ONE 2 x 2-block compositor launch - against the route of round 2 (RGBA fields, pixel-per-lane compositor), which
+    tests/test_chains_gpu.py pins to the oracle at this size"""
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    k = hh.ctx()
+    sw, sh, ow, oh = 1920, 1080, 3840, 2160
+    cm, lut, gm = hh.ColourParams.reader("709", "2020")
+    wcm, wlut = hh.ColourParams.writer("2020")
+    mat_h = capi.transform_matrix(ow, oh)
+    mat_d = hh.dev(mat_h)
+    wins = [[hh.dev(frames.v210_random(sw, sh, frames.layer_seed(3, 4 * l + i))) for i in range(3)] for l in range(4)]
+    rgba = [[torch.zeros(sw * sh * 4, dtype=torch.float32, device="cuda") for _ in range(2)] for _ in range(4)]
+    rgb = [[torch.zeros(sw * sh * 3, dtype=torch.float32, device="cuda") for _ in range(2)] for _ in range(4)]
+    k.v210_yadif_pair([(wins[l][0], wins[l][1], wins[l][2], rgba[l][0], rgba[l][1]) for l in range(4)], sw, sh, 1, False, cm, lut, gm)
+    k.v210_yadif_pair([(wins[l][0], wins[l][1], wins[l][2], rgb[l][0], rgb[l][1]) for l in range(4)], sw, sh, 1, False, cm, lut, gm, rgb=True)
+    words = frames.v210_pitch_bytes(ow) * oh // 4
+    for parity in (0, 1):
+        want = torch.zeros(words, dtype=torch.int32, device="cuda")
+        got = torch.zeros(words, dtype=torch.int32, device="cuda")
+        k.compose_write_v210([(rgba[l][parity], sw, sh, mat_d) for l in range(4)], want, ow, oh, 0, wcm, wlut)
+        k.compose_up_write_v210([(rgb[l][parity], sw, sh, mat_h) for l in range(4)], got, ow, oh, 0, wcm, wlut, rgb=True)
+        k.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), "field of parity %d" % parity

@@ -184,11 +184,27 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
         parity = 1 ^ (0 if (i & 1) else 1)
         ctx.compose_write_v210([(deint2[l][parity], sw, sh, m) for l in range(4)], out, ow, oh, 0, *wr)
 
+    # packed-RGB fields (12 bytes per pixel) + the 2 x 2-block compositor (ph_compose_up_write_v210): 2.25 texel loads per layer and pixel
+    rgb2 = [[torch.empty(sw * sh * 3, dtype=torch.float32, device="cuda") for _ in range(2)] for _ in range(4)]
+    up_jobs = [ctx.compose_up_write_v210([(rgb2[l][p], sw, sh, mh) for l in range(4)], out, ow, oh, 0, *wr, rgb=True, prepare_only=True) for p in range(2)]
+    vwin2 = [[srcs[k % R][l] for k in range(3)] for l in range(4)]
+
+    def config3_up(i):
+        if not (i & 1):
+            s = srcs[(i // 2) % R]
+            for l in range(4):
+                vwin2[l] = [vwin2[l][1], vwin2[l][2], s[l]]
+            ctx.v210_yadif_pair([(vwin2[l][0], vwin2[l][1], vwin2[l][2], rgb2[l][0], rgb2[l][1]) for l in range(4)], sw, sh, 1, False, *rd, rgb=True)
+        up_jobs[1 ^ (0 if (i & 1) else 1)]()
+
     algo3 = 4 * 3 * capi.v210_pitch_bytes(sw) * sh + capi.v210_pitch_bytes(ow) * oh  # 88 473 600
     name3 = "3: 1 channel, 4 x 1080i50 -> yadif -> 2x up-scale -> 709->2020 -> combine_4 -> 2160p50 (per output field)"
-    record(name3, "fused de-interlacing reader + fused compositor: per frame [unpack + yadif, both fields, x4 layers] (ph_v210_yadif_pair), "
-           "per field [transform x4 + combine_4 + write]", "field", timeit(config3_deint, reps), algo3, 1.5)
+    record(name3, "fused de-interlacing reader (packed RGB fields) + 2x2-block compositor: per frame [unpack + yadif, both fields, x4 layers] "
+           "(ph_v210_yadif_pair_fmt), per field [transform x4 + combine_4 + write] (ph_compose_up_write_v210)", "field",
+           timeit(config3_up, reps), algo3, 1.5)
     if routes == "all":
+        record(name3, "fused de-interlacing reader + fused compositor: per frame [unpack + yadif, both fields, x4 layers] (ph_v210_yadif_pair), "
+               "per field [transform x4 + combine_4 + write]", "field", timeit(config3_deint, reps), algo3, 1.5)
         record(name3, "fused compositor, field pairs: per frame [read x4] + yadif_pair x4 (both fields in one pass), per field "
                "[transform x4 + combine_4 + write]", "field", timeit(config3_pair, reps), algo3, 3.5)
         record(name3, "fused compositor: read x4 every other field, yadif x4, [transform x4 + combine_4 + write]", "field",
