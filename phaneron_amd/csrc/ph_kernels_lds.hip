@@ -89,8 +89,14 @@ __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const Wr
 // P = 6 quads per lane - a whole 2160p share (5400 quads per CU) in ONE tile, so each frame costs two
 // table loads instead of four.
 // ------------------------------------------------------------------------------------------
-template <int N, int P, int BS, bool PIPE = false>
-__global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs a) {
+// PH_FUSED_SPLIT builds (tools/fused_split.py; never the shipped library): the kernel's two halves as launches of their own -
+// MODE 1 = reader half (table load, phase 1, the packed indices stored to a hand-over buffer), MODE 2 = writer half (indices
+// loaded back, table load, phase 2) - to price a split into reader CUs and writer CUs before building its cross-CU protocol.
+#ifndef PH_FUSED_SPLIT
+#define PH_FUSED_SPLIT 0
+#endif
+template <int N, int P, int BS, bool PIPE = false, int MODE = 0>
+__global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs a, uint32_t *handoff = nullptr) {
   const ReadK rk = load_read_k(a.f.rd_cm, a.f.rd_gm);
   const WriteK wk = load_write_k(a.f.wr_cm);
   const LutK rlut = make_lut_k(a.rd), wlut = make_lut_k(a.wr);
@@ -161,8 +167,10 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
       return w;
     };
     PH_STAMP(0);
-    lds_lut_load<BS>(a.rd);
-    __syncthreads();
+    if (MODE == 0 || (MODE == 1 && tile_begin == wg_begin)) {  // a half keeps its one table over all its tiles
+      lds_lut_load<BS>(a.rd);
+      __syncthreads();
+    }
     PH_STAMP(1);
     const uint32_t tile_left = wg_end - tile_begin;  // uniform; slice p holds quads iff p * BS < tile_left
     if constexpr (PIPE) {
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
         }
       }
     } else {
+    if (MODE != 2) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const uint32_t f = quad_of(p);
@@ -287,10 +296,32 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
         else w = phase1_slice(std::false_type{}, w, f, f_next, more, st[p]);
       }
     }
+    }
+    if (MODE == 1) {  // reader half: the nine packed registers of every quad go to the hand-over buffer (nine planes, coalesced)
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (p * BS < wg_end - tile_begin) {
+          const uint32_t f = quad_of(p);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) handoff[(size_t)i * a.f.total_quads + f] = st[p][i];
+        }
+      continue;
+    }
+    if (MODE == 2) {  // writer half: take them back
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (p * BS < wg_end - tile_begin) {
+          const uint32_t f = quad_of(p);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) st[p][i] = __builtin_nontemporal_load(handoff + (size_t)i * a.f.total_quads + f);
+        }
+    }
     PH_STAMP(2);
-    __syncthreads();
-    lds_lut_load<BS>(a.wr);
-    __syncthreads();
+    if (MODE == 0 || tile_begin == wg_begin) {
+      __syncthreads();
+      lds_lut_load<BS>(a.wr);
+      __syncthreads();
+    }
     PH_STAMP(3);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -851,8 +882,33 @@ static hipError_t allow_lds(K kernel, uint32_t bytes) {
                              (int)bytes);
 }
 
+#if PH_FUSED_SPLIT
+template <int N, int P, int BS, int MODE>
+static hipError_t launch_fused_half(hipStream_t s, FusedLdsArgs b, uint32_t lds) {
+  static uint32_t *handoff = nullptr;
+  static size_t handoff_quads = 0;
+  if (handoff_quads < b.f.total_quads) {
+    if (handoff) hipFree(handoff);
+    if (hipMalloc(&handoff, (size_t)b.f.total_quads * 36) != hipSuccess) return hipErrorOutOfMemory;
+    handoff_quads = b.f.total_quads;
+  }
+  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P, BS, false, MODE>, lds);
+  if (e != hipSuccess) return e;
+  fused_v210_combine_lds_kernel<N, P, BS, false, MODE><<<b.wg_per_job * b.jobs, BS, lds, s>>>(b, handoff);
+  return hipGetLastError();
+}
+#endif
+
 template <int N, int P, int BS, bool PIPE = false>
-static hipError_t launch_fused_npb(hipStream_t s, const FusedLdsArgs &a, uint32_t grid, uint32_t lds) {
+static hipError_t launch_fused_npb(hipStream_t s, const FusedLdsArgs &a, uint32_t grid_in, uint32_t lds) {
+  uint32_t grid = grid_in;
+#if PH_FUSED_SPLIT
+  static const int cus_env = [] {
+    const char *e = getenv("PH_FUSED_CUS");  // run on this many CUs (what a role would get in a split)
+    return e ? atoi(e) : 0;
+  }();
+  if (cus_env > 0 && (uint32_t)cus_env < grid) grid = (uint32_t)cus_env;
+#endif
   hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P, BS, PIPE>, lds);
   if (e != hipSuccess) return e;
   const uint32_t slices = (a.f.total_quads + BS - 1) / BS;  // never more workgroups per job than slices
@@ -860,6 +916,21 @@ static hipError_t launch_fused_npb(hipStream_t s, const FusedLdsArgs &a, uint32_
   if (b.jobs < 1) b.jobs = 1;
   b.wg_per_job = grid / b.jobs ? grid / b.jobs : 1;
   if (b.wg_per_job > slices) b.wg_per_job = slices;
+#if PH_FUSED_SPLIT
+  if (!PIPE && N == 4) {
+    static const int mode_env = [] {
+      const char *e = getenv("PH_FUSED_MODE");
+      return e ? atoi(e) : 0;
+    }();
+    // with fewer CUs a CU's share no longer fits one tile: the halves then walk several tiles, each with its table load
+    if (mode_env == 1) return launch_fused_half<N, P, BS, 1>(s, b, lds);
+    if (mode_env == 2) return launch_fused_half<N, P, BS, 2>(s, b, lds);
+    if (mode_env == 3) {  // both halves, back to back
+      hipError_t e1 = launch_fused_half<N, P, BS, 1>(s, b, lds);
+      return e1 != hipSuccess ? e1 : launch_fused_half<N, P, BS, 2>(s, b, lds);
+    }
+  }
+#endif
   fused_v210_combine_lds_kernel<N, P, BS, PIPE><<<b.wg_per_job * b.jobs, BS, lds, s>>>(b);
   return hipGetLastError();
 }
