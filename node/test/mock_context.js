@@ -37,6 +37,9 @@ function makeMock(mockOptions = {}) {
 			buf.hostAccess = async (d, q, src) => {
 				trace.push({ op: 'hostAccess', buf: buf._mockId, dir: d, queue: q === undefined ? null : q, src: src ? { bytes: src.length, sha: hash(src) } : null })
 				if (src) src.copy(buf)
+				// mapped for writing and filled by plain Buffer writes afterwards (blackSilence.ts:133-134): with
+				// options.recordMappedWrites the bytes found there when a kernel first uses the buffer are recorded
+				else if (d === 'writeonly' && mockOptions.recordMappedWrites) buf._mapped = true
 			}
 			buf.addRef = () => { buf._refs++; trace.push({ op: 'addRef', buf: buf._mockId, refs: buf._refs }) }
 			buf.release = () => {
@@ -63,6 +66,11 @@ function makeMock(mockOptions = {}) {
 			const data = {}
 			const hex = {}
 			for (const k of Object.keys(params)) {
+				const b = params[k]
+				if (Buffer.isBuffer(b) && b._mapped) {
+					b._mapped = false
+					trace.push({ op: 'hostWrite', buf: b._mockId, bytes: b.length, sha: hash(b), allZero: b.every((x) => x === 0) })
+				}
 				p[k] = describe(params[k])
 				// small read-only operands (matrices, LUTs, flip vectors): pin their contents too
 				if (Buffer.isBuffer(params[k]) && params[k].length <= 262144 && !/^(output|input|prev|cur|next|l\dIn|input\d|maskIn)$/.test(k)) {

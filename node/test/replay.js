@@ -69,6 +69,14 @@ async function main() {
 					calls++
 					break
 				}
+				case 'hostWrite': {  // the reference filled a buffer it had mapped for writing (Buffer.copy into the mirror): do the same
+					const b = bufs.get(e.buf)
+					const file = path.join(dir, `${e.sha}.bin`)
+					const bytes = e.allZero ? Buffer.alloc(e.bytes) : fs.existsSync(file) ? fs.readFileSync(file) : null
+					if (!bytes) throw new Error(`no data for the mapped write ${e.sha} (${e.bytes} bytes)`)
+					bytes.copy(b.buf)
+					break
+				}
 				case 'createProgram': {
 					let source = `phaneron:${e.name}`
 					if (e.name === 'read' || e.name === 'write') {

@@ -159,6 +159,14 @@ def main():
     with open(os.path.join(HERE, "host_trace.json"), "w") as f:
         json.dump(json.loads(tr), f, indent=0, sort_keys=True)
         f.write("\n")
+    # the reference's own video valves (mixer.ts, transitioner.ts, combiner.ts, blackSilence.ts: oracle/refbuild/ts_erase.py)
+    # driven frame by frame against the same recording mock
+    subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "refbuild", "ts_erase.py")], check=True, capture_output=True)
+    tr = subprocess.run(["node", os.path.join(ROOT, "node", "test", "valve_scenario.js"),
+                         os.path.join(ROOT, "oracle", "_ref", "work", "js")], check=True, capture_output=True, text=True).stdout
+    with open(os.path.join(HERE, "valve_trace.json"), "w") as f:
+        json.dump(json.loads(tr), f, indent=0, sort_keys=True)
+        f.write("\n")
     # which pack format each `read` / `write` program of that trace belongs to, keyed by the fingerprint the
     # mock recorded of the kernel text (a hash, so the trace can be replayed where the text cannot go)
     shas = {}

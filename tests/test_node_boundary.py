@@ -440,3 +440,117 @@ def test_control_plane_smoke_on_gpu(tmp_path):
         want = orc.v210_write(img, w, h, 0, *wr)
         got = np.fromfile(tmp_path / ("out_%d.bin" % f), np.uint32)
         assert np.array_equal(got, want), f
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's OWN video valves (mixer.ts, transitioner.ts, combiner.ts, blackSilence.ts), type-erased and run
+# against stand-ins for redioactive / beamcoder in the build container (node/test/valve_scenario.js); their trace is the
+# golden, and it is replayed call by call on the real addon
+# ---------------------------------------------------------------------------------------------------------------------
+VALVE_TRACE = os.path.join(ROOT, "tests", "golden", "valve_trace.json")
+VALVE_CLIPS = {"A": 11, "B0": 22, "B1": 33, "C": 44, "M": 55}  # node/test/valve_scenario.js CLIPS
+VALVE_PIP = dict(anchor=dict(x=0.25, y=0.75), rotation=30, fill=dict(xOffset=0.25, yOffset=-0.125, xScale=0.5, yScale=0.5), volume=1)
+VALVE_DEFAULT = dict(anchor=dict(x=0, y=0), rotation=0, fill=dict(xOffset=0, yOffset=0, xScale=1, yScale=1), volume=1)
+
+
+def valve_clip_frame(w, h, seed, k):
+    """node/test/valve_scenario.js clipFrame, restated: f32 RGBA noise in [0, 1) from a 32-bit hash of (element index, seed)"""
+    def imul(a, b):
+        return (np.asarray(a, np.uint64) * np.uint64(b)) & np.uint64(0xFFFFFFFF)
+    s = int(imul(seed, 0x9E3779B1)) ^ int(imul(k + 1, 0x85EBCA6B))
+    i = np.arange(1, w * h * 4 + 1, dtype=np.uint64)
+    x = imul(i ^ np.uint64(s), 0x9E3779B1)
+    x = x ^ (x >> np.uint64(15))
+    x = imul(x, 0x85EBCA6B)
+    x = x ^ (x >> np.uint64(13))
+    return ((x >> np.uint64(8)).astype(np.float64) / 16777216.0).astype(np.float32).reshape(h, w, 4)
+
+
+@needs_node
+@needs_ref_js
+def test_reference_valves_still_leave_the_golden_trace():
+    """Where the reference checkout exists: its Mixer / Transitioner / Combiner / Black valves, driven through the 11-frame
+    schedule, make exactly the nodencl calls of tests/golden/valve_trace.json"""
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "valve_scenario.js"), REF_JS], check=True, capture_output=True, text=True).stdout
+    trace = json.loads(out)
+    assert trace == json.load(open(VALVE_TRACE))
+    runs = [e for e in trace if e["op"] == "runProgram"]
+    assert [e["name"] for e in runs].count("transition_dissolve") == 4 and [e["name"] for e in runs].count("transition_wipe") == 4
+    f32 = lambda x: float(np.float32(x))
+    assert [e["params"]["mix"] for e in runs if e["name"] == "transition_dissolve"] == [1.0, f32(2 / 3), f32(1 / 3), 0.0]  # transitioner.ts:170
+    assert [e["timestamp"] for e in trace if e["op"] == "note" and e["what"] == "output"] == list(range(11))  # combiner.ts:211
+
+
+def valve_oracle_frames(w, h):
+    """what the 11 output frames must be: the schedule of node/test/valve_scenario.js restated on the oracle's kernels"""
+    orc = orc_mod()
+    md, mp = mixer_matrix(w, h, VALVE_DEFAULT), mixer_matrix(w, h, VALVE_PIP)
+    used = {c: 0 for c in VALVE_CLIPS}
+
+    def mixed(clip, m):
+        k = used[clip]
+        used[clip] += 1
+        return orc.transform(valve_clip_frame(w, h, VALVE_CLIPS[clip], k), m, w, h)
+    black = np.zeros((h, w, 4), np.float32)
+    out = []
+    for f in range(11):
+        l1 = mixed("A", md)
+        if f >= 7:  # transitioner.ts:165-176: inputs = srcFrames.slice(0, 2), mask = srcFrames[2]
+            l1 = orc.transition_wipe(l1, mixed("C", md), mixed("M", md))
+        if f < 2:
+            l2 = mixed("B0", mp)
+        elif f < 6:
+            l2 = orc.transition_dissolve(mixed("B0", mp), mixed("B1", md), float(np.float32(1.0 - (f - 2) / 3)))
+        else:
+            l2 = mixed("B1", md)
+        out.append(orc.combine([l1, l2, black]))
+    return out
+
+
+@needs_node
+@pytest.mark.gpu
+def test_reference_valve_trace_replays_on_the_real_addon(tmp_path):
+    """Every nodencl call the reference's valves made - buffers by owner, Transform / Transition / Combine programs from their
+    kernel names, parameters by OpenCL argument name, the black frame written through a mapped mirror, every addRef / release -
+    goes to index.js + ph_napi.c + libphaneron_hip.so; reference counts match the recorded ones at every step, nothing leaks,
+    and all 11 output frames equal the oracle's chain for the schedule."""
+    import hashlib
+    trace = json.load(open(VALVE_TRACE))
+    w, h = 192, 64
+    have = set()
+    for clip, seed in VALVE_CLIPS.items():
+        for k in range(11):
+            raw = valve_clip_frame(w, h, seed, k).tobytes()
+            name = hashlib.sha256(raw).hexdigest()[:16]
+            have.add(name)
+            (tmp_path / (name + ".bin")).write_bytes(raw)
+    big = {e["src"]["sha"] for e in trace if e["op"] == "hostAccess" and e["src"] and e["src"]["bytes"] > 64}
+    assert big <= have, "the trace loads a frame this test cannot regenerate"
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "replay.js"), VALVE_TRACE, TEXT_SHA, str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads((tmp_path / "replay.json").read_text())
+    assert res["problems"] == [], res["problems"][:5]
+    assert len(res["dumps"]) == 11
+    want = valve_oracle_frames(w, h)
+    for f, d in enumerate(res["dumps"]):
+        got = np.fromfile(tmp_path / d["file"], np.float32)
+        assert np.array_equal(got.view(np.uint32), want[f].reshape(-1).view(np.uint32)), "output frame %d" % f
+
+
+@needs_node
+@pytest.mark.gpu
+def test_channel_js_equals_the_reference_valves_frame_for_frame(tmp_path):
+    """this repository's own channel compositor (node/channel.js) on the first seven frames of the same schedule (full-frame
+    layer, PiP layer dissolving into another clip, empty layer): the frames the reference's valves produce"""
+    w, h, nf = 192, 64, 7
+    for name, seed in (("A", 11), ("B0", 22), ("B1", 33)):
+        for k in range(nf):
+            valve_clip_frame(w, h, seed, k).tofile(tmp_path / ("%s_%d.bin" % (name, k)))
+    (tmp_path / "job.json").write_text(json.dumps(dict(width=w, height=h, frames=nf, pip=VALVE_PIP, dissolveAt=2, dissolveLen=4, cutAt=6)))
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "channel_run.js"), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = valve_oracle_frames(w, h)  # == the replayed reference valves (test above)
+    for f in range(nf):
+        got = np.fromfile(tmp_path / ("out_%d.bin" % f), np.float32)
+        assert np.array_equal(got.view(np.uint32), want[f].reshape(-1).view(np.uint32)), "frame %d" % f
