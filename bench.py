@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--channels", type=int, default=1,
                     help="channels per GPU, composited in ONE batched launch per step (default 1: the headline)")
+    ap.add_argument("--frames-per-launch", type=int, default=1,
+                    help="successive frames of the ONE channel composited per launch (a play-out that decodes ahead; default 1: every "
+                         "frame its own launch).  A 1080p frame is 23 us of which launch and two table loads are ~8: K frames share them")
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
@@ -291,7 +294,10 @@ def main():
     ctx.register_lut(wr[1], capi.linear2gamma_lut("2020"))
     if os.environ.get("PH_BENCH_GLOBAL_LUT"):
         ctx.set_option("lds_lut", 0)
-    C = max(1, args.channels)
+    K = max(1, args.frames_per_launch)
+    if K > 1 and args.channels > 1:
+        raise SystemExit("bench.py: --frames-per-launch and --channels are two uses of the one batched launch; pick one")
+    C = max(1, args.channels) if K == 1 else K  # jobs of one launch: C channels' frames, or K successive frames of one channel
     ring = []  # per slot: C channels' layer lists and outputs
     for r in range(args.ring):
         ins = [[synth_v210(torch, w, h, 0x5EED0000 + 16 * ((rank * C + c) * 64 + r) + l, device, args.content) for l in range(n)]
@@ -367,9 +373,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %d channel%s per GPU, %d x %dx%d v210 layers -> fused unpack/CSC(709->2020)/"
                                    "combine_%d/CSC/pack -> 1 v210 frame%s"
-                                   % ("headline" if C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS) else "variant", C,
-                                      "" if C == 1 else "s", n, w, h, n, "" if C == 1 else " each, one batched launch per step"),
-                       "ring_frame_sets": args.ring, "channels": world * C, "realtime_target_fps": 50,
+                                   % ("headline" if C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS) else "variant", 1 if K > 1 else C,
+                                      "" if C == 1 or K > 1 else "s", n, w, h, n,
+                                      "" if C == 1 else (", %d successive frames per launch" % K if K > 1 else " each, one batched launch per step")),
+                       "ring_frame_sets": args.ring, "channels": world * (1 if K > 1 else C), "frames_per_launch": K, "realtime_target_fps": 50,
                        "content": args.content},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(),

@@ -137,6 +137,33 @@ class Rig {
 			return { name: `compose_write_v210_${n}`, program, params }
 		}
 	}
+	// the channel's whole frame as one launch, straight from the v210 sources (no f32 frame in between):
+	// stage([{ source (v210 buffer | RGBA image), width?, height?, matrix?, transition?: { type: 'dissolve' | 'wipe', mix?, incoming: {...}, mask?: {...} } }...], output v210, field)
+	// = ToRGBA -> [transform] (-> transition) per layer -> combine_n -> FromRGBA; bit-identical to the separate stages
+	async channelCompose(n, width, height, readSpec, writeSpec) {
+		const program = await this.program(`chan_compose_v210_${n}`, 'chan', { globalWorkItems: [width, height] })
+		const ci = await this.colourIn('v210', readSpec, writeSpec)
+		const co = await this.colourOut('v210', writeSpec)
+		return (layers, output, field = 0) => {
+			if (layers.length !== n) throw new Error(`chan_compose_v210_${n} needs ${n} layers, got ${layers.length}`)
+			const params = { output, colMatrix: ci.colMatrix, gammaLut: ci.gammaLut, gamutMatrix: ci.gamutMatrix, outColMatrix: co.colMatrix, outGammaLut: co.gammaLut, interlace: field }
+			const put = (prefix, s) => {
+				params[`${prefix}In`] = s.source
+				if (s.matrix) params[`${prefix}Matrix`] = s.matrix
+				if (s.width) { params[`${prefix}Width`] = s.width; params[`${prefix}Height`] = s.height }
+			}
+			layers.forEach((l, i) => {
+				put(`l${i}`, l)
+				if (l.transition) {
+					params[`l${i}Transition`] = l.transition.type === 'wipe' ? 2 : 1
+					if (l.transition.type !== 'wipe') params[`l${i}Mix`] = l.transition.mix
+					put(`l${i}Incoming`, l.transition.incoming)
+					if (l.transition.type === 'wipe') put(`l${i}Mask`, l.transition.mask)
+				}
+			})
+			return { name: `chan_compose_v210_${n}`, program, params }
+		}
+	}
 	// ToRGBA of n v210 frames of one size and colour recipe in one launch: stage([planes...], [images...])
 	async unpackBatch(n, width, height, spec, workSpec) {
 		const c = await this.colourIn('v210', spec, workSpec)

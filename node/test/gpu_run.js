@@ -292,6 +292,35 @@ async function main() {
 		;[...rgba, out[0]].forEach((b) => b.release())
 	}
 
+	// ---- 10. the same channel as ONE launch from its v210 sources: 'chan_compose_v210_<n>' = read -> transform (layer 1) ->
+	//          combine -> write, and with the wipe (incoming = layer 0's source, mask = layer 2's): the outputs of step 9 again ----
+	if (job.channel.width % 192 === 0) {
+		const c = job.channel
+		const n = c.layers.length
+		const xf = await rig.transform(c.width, c.height)
+		const chan = await rig.channelCompose(n, c.width, c.height, c.readSpec, c.writeSpec)
+		const srcs = []
+		for (let l = 0; l < n; ++l) {
+			const src = await rig.planes('v210', c.width, c.height)
+			await rig.upload(src[0], load(c.layers[l]))
+			srcs.push(src[0])
+		}
+		await rig.sync(ctx.queue.load)
+		const pip = await xf.matrix(c.pip)
+		const layers = srcs.map((source, l) => (l === 1 ? { source, matrix: pip } : { source }))
+		const out = await rig.planes('v210', c.width, c.height, 'writeonly')
+		await rig.run(chan(layers, out[0], 0))
+		await rig.sync()
+		await rig.download(out[0])
+		save('chan_out.bin', out[0])
+		layers[n - 1] = { source: srcs[n - 1], transition: { type: 'wipe', incoming: { source: srcs[0] }, mask: { source: srcs[2] } } }
+		await rig.run(chan(layers, out[0], 0))
+		await rig.sync()
+		await rig.download(out[0])
+		save('chan_wipe_out.bin', out[0])
+		;[...srcs, out[0]].forEach((b) => b.release())
+	}
+
 	rig.close()
 	result.liveAfter = ctx.logBuffers ? rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers : -1
 	save('result.json', JSON.stringify(result))

@@ -1035,8 +1035,114 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "gamutMatrix", 36, &d));
       TRY(need_num(args, n, "tff", &tff));
       TRY(need_num(args, n, "skipSpatial", &skip));
+      double rgb = 0;  // optional: 1 = the outputs are packed f32 RGB (12 bytes per pixel) for compose_up_write_v210_<n>
+      if (find_arg(args, n, "packedRgb")) TRY(need_num(args, n, "packedRgb", &rgb));
       refresh_buf_lut(ctx, c);
-      return ph_v210_yadif_pair(ctx, queue, prog->n_layers, src, width, height, (int)tff, (int)skip, b->dptr, c->dptr, d->dptr);
+      return ph_v210_yadif_pair_fmt(ctx, queue, prog->n_layers, src, width, height, (int)tff, (int)skip, rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32,
+                                    b->dptr, c->dptr, d->dptr);
+    }
+    case K_CHAN_COMPOSE: {
+      // l<i>In: a layer's source - a v210 frame (l<i>Width / l<i>Height: its size, default the output's) or an RGBA image buffer;
+      // l<i>Matrix (optional): its placement, a buffer whose host mirror holds the nine floats (Transform writes it through
+      // hostAccess: transform.ts:84-89), absent = 1:1; l<i>Transition: 0 cut / 1 dissolve / 2 wipe; l<i>Mix; l<i>Incoming(In|Matrix|
+      // Width|Height) and l<i>Mask(...): the transition's other sources; output: v210; colMatrix / gammaLut / gamutMatrix: the
+      // Loader's, outColMatrix / outGammaLut: the Saver's; interlace as 'write'
+      const uint32_t width = prog->global[0], height = prog->global[1];
+      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
+      ph_chan_layer layers[ph::kMaxLayers];
+      memset(layers, 0, sizeof layers);
+      auto source = [&](int i, const char *role, ph_chan_source *s) -> int {
+        char nm[40];
+        ph_buf *x = nullptr;
+        snprintf(nm, sizeof nm, "l%d%sIn", i, role);
+        TRY(need_buf(args, n, nm, 0, &x));
+        double sw = width, sh = height;
+        s->data = x->dptr;
+        if (x->width > 0 && x->height > 0) {  // an image buffer (createBuffer with imageDims): f32 RGBA
+          s->format = PH_SRC_RGBA_F32, sw = x->width, sh = x->height;
+        } else {
+          s->format = PH_SRC_V210;
+          snprintf(nm, sizeof nm, "l%d%sWidth", i, role);
+          if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sw));
+          snprintf(nm, sizeof nm, "l%d%sHeight", i, role);
+          if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sh));
+          if (sw > 0 && sh > 0 && x->bytes < (size_t)ph_v210_pitch_bytes((uint32_t)sw) * (size_t)sh)
+            return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than a %gx%g v210 frame", i, role, x->bytes, sw, sh);
+        }
+        s->width = (int)sw, s->height = (int)sh, s->matrix9_host = nullptr;
+        snprintf(nm, sizeof nm, "l%d%sMatrix", i, role);
+        if (find_arg(args, n, nm)) {
+          ph_buf *m = nullptr;
+          TRY(need_buf(args, n, nm, 36, &m));
+          if (!m->hptr) return fail(PH_E_INVALID, "kernel argument '%s': the matrix must have been written through hostAccess (its host copy is what the launch reads)", nm);
+          s->matrix9_host = (const float *)m->hptr;
+        }
+        return PH_OK;
+      };
+      for (int i = 0; i < prog->n_layers; ++i) {
+        char nm[40];
+        TRY(source(i, "", &layers[i].src));
+        double tr = 0, mix = 0;
+        snprintf(nm, sizeof nm, "l%dTransition", i);
+        if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &tr));
+        snprintf(nm, sizeof nm, "l%dMix", i);
+        if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &mix));
+        layers[i].transition = (int)tr, layers[i].mix = (float)mix;
+        if (layers[i].transition != PH_TRANSITION_CUT) TRY(source(i, "Incoming", &layers[i].incoming));
+        if (layers[i].transition == PH_TRANSITION_WIPE) TRY(source(i, "Mask", &layers[i].mask));
+      }
+      double interlace = 0;
+      ph_buf *wcm = nullptr, *wl = nullptr;
+      TRY(need_buf(args, n, "output", (size_t)ph_v210_pitch_bytes(width) * height, &o));
+      TRY(need_buf(args, n, "colMatrix", 48, &b));
+      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
+      TRY(need_buf(args, n, "gamutMatrix", 36, &d));
+      TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
+      TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
+      if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
+      refresh_buf_lut(ctx, c);
+      refresh_buf_lut(ctx, wl);
+      return ph_chan_compose_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, b->dptr, c->dptr, d->dptr,
+                                  wcm->dptr, wl->dptr);
+    }
+    case K_COMPOSE_UP: {
+      // l<i>In: the layer's image - an RGBA image buffer, or with packedRgb = 1 a buffer of packed f32 RGB (l<i>Width / l<i>Height:
+      // its size); l<i>Matrix: its placement (host mirror, as above); output: v210; outColMatrix / outGammaLut; interlace
+      const uint32_t width = prog->global[0], height = prog->global[1];
+      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
+      double rgb = 0, interlace = 0;
+      if (find_arg(args, n, "packedRgb")) TRY(need_num(args, n, "packedRgb", &rgb));
+      ph_image_layer layers[ph::kMaxLayers];
+      for (int i = 0; i < prog->n_layers; ++i) {
+        char nm[24];
+        ph_buf *x = nullptr, *m = nullptr;
+        double lw = 0, lh = 0;
+        snprintf(nm, sizeof nm, "l%dIn", i);
+        TRY(need_buf(args, n, nm, 0, &x));
+        if (rgb != 0) {
+          snprintf(nm, sizeof nm, "l%dWidth", i);
+          TRY(need_num(args, n, nm, &lw));
+          snprintf(nm, sizeof nm, "l%dHeight", i);
+          TRY(need_num(args, n, nm, &lh));
+          if (lw <= 0 || lh <= 0 || x->bytes < (size_t)lw * (size_t)lh * 12) return fail(PH_E_RANGE, "kernel argument 'l%dIn': smaller than its %gx%g packed-RGB image", i, lw, lh);
+        } else {
+          int iw, ih;
+          TRY(need_image(x, nm, &iw, &ih));
+          lw = iw, lh = ih;
+        }
+        snprintf(nm, sizeof nm, "l%dMatrix", i);
+        TRY(need_buf(args, n, nm, 36, &m));
+        if (!m->hptr) return fail(PH_E_INVALID, "kernel argument '%s': the matrix must have been written through hostAccess (its host copy is what the launch reads)", nm);
+        layers[i].data = x->dptr, layers[i].format = rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32;
+        layers[i].width = (int)lw, layers[i].height = (int)lh, layers[i].matrix9_host = (const float *)m->hptr;
+      }
+      ph_buf *wcm = nullptr, *wl = nullptr;
+      TRY(need_buf(args, n, "output", (size_t)ph_v210_pitch_bytes(width) * height, &o));
+      TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
+      TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
+      if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
+      refresh_buf_lut(ctx, wl);
+      return ph_compose_up_write_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
     }
     case K_COMPOSE_V210: {
       // l<i>In: RGBA image; l<i>Matrix (optional): its 3x3 placement, absent = taken 1:1; l<i>WipeIn + l<i>WipeMask (optional):

@@ -192,6 +192,8 @@ int resolve_program(const char *src, const char *name, ProgramChoice &c, std::st
   if (0 == strncmp(name, "v210_yadif_pair_", 16)) return layers("v210_yadif_pair_", 1, K_V210_YADIF_PAIR);
   if (0 == strncmp(name, "v210_read_batch_", 16)) return layers("v210_read_batch_", 1, K_V210_READ_BATCH);
   if (0 == strncmp(name, "compose_write_v210_", 19)) return layers("compose_write_v210_", 1, K_COMPOSE_V210);
+  if (0 == strncmp(name, "chan_compose_v210_", 18)) return layers("chan_compose_v210_", 1, K_CHAN_COMPOSE);
+  if (0 == strncmp(name, "compose_up_write_v210_", 22)) return layers("compose_up_write_v210_", 1, K_COMPOSE_UP);
   if (0 == strcmp(name, "transform")) return set(c, K_TRANSFORM, name, how);
   if (0 == strcmp(name, "resize")) return set(c, K_RESIZE, name, how);
   if (0 == strncmp(name, "combine_", 8)) return layers("combine_", 2, K_COMBINE);

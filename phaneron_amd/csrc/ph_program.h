@@ -13,6 +13,8 @@ enum KernelId {
   K_YADIF_PAIR,       // both send_field outputs in one pass (ph_yadif_pair)
   K_V210_YADIF_PAIR,  // ToRGBA of the window + both outputs, n layers (ph_v210_yadif_pair)
   K_V210_READ_BATCH,  // ToRGBA of n frames of one size and colour recipe in one launch (ph_v210_read_batch)
+  K_CHAN_COMPOSE,     // a channel's frame straight from its v210 sources, n layers (ph_chan_compose_v210)
+  K_COMPOSE_UP,       // [transform] x n -> combine_n -> v210 write for layers enlarged 2x or more (ph_compose_up_write_v210)
   K_COMPOSE_V210,     // [transform] x n (+ wipes) -> combine_n -> v210 write in one launch (ph_compose_wipe_write_v210)
   K_TRANSFORM,
   K_RESIZE,

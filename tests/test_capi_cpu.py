@@ -142,7 +142,10 @@ def test_program_resolution_by_tag_and_by_name_needs_no_device():
     for k in IMAGE_KERNELS:
         assert capi.resolve_program("", k) == (k, None, "name")
     assert capi.resolve_program("phaneron:x", "fused_v210_combine_4")[0] == "fused_v210_combine_4"
-    for src, name, needle in (("", "sharpen", "unknown kernel"), ("", "combine_9", "layers are built"),
+    for k in ("chan_compose_v210_4", "compose_up_write_v210_2", "compose_write_v210_3", "v210_yadif_pair_4", "v210_read_batch_5"):
+        assert capi.resolve_program("phaneron:fused", k) == (k, None, "tag") and capi.resolve_program("", k)[2] == "name"
+    for src, name, needle in (("", "sharpen", "unknown kernel"), ("", "combine_9", "layers are built"), ("", "combine_4x", "plain layer count"),
+                              ("", "chan_compose_v210_", "plain layer count"), ("", "compose_up_write_v210_9", "layers are built"),
                               ("", "combine_1", "layers are built"), ("phaneron:v211", "read", "cannot tell which pack format"),
                               ("__kernel void read(__global float* a) {}", "read", "cannot tell which pack format")):
         with pytest.raises(capi.PhaneronError, match=needle):

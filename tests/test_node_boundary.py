@@ -264,6 +264,9 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
     top = orc.transition_wipe(rgba[n - 1], orc.v210_read(layers[0], w, h, *rd), orc.v210_read(layers[2], w, h, *rd))
     want_wipe = orc.v210_write(orc.combine(rgba[:n - 1] + [top]), w, h, 0, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
     assert np.array_equal(np.fromfile(tmp_path / "compose_wipe_out.bin", np.uint32), want_wipe)
+    # and as ONE launch straight from the v210 sources (program 'chan_compose_v210_<n>': no f32 frame at all)
+    assert np.array_equal(np.fromfile(tmp_path / "chan_out.bin", np.uint32), want)
+    assert np.array_equal(np.fromfile(tmp_path / "chan_wipe_out.bin", np.uint32), want_wipe)
 
     # yadif send_field, tff: outputs for cur = field1 and field2, two each (yadif.ts:125-145)
     assert res["yadifTimestamps"] == [2, 3, 4, 5]

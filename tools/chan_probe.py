@@ -14,9 +14,7 @@ sys.path.insert(0, ROOT)
 def main():
     variant = sys.argv[1] if len(sys.argv) > 1 else "wipe"
     from phaneron_amd import build
-    lib = os.path.join(ROOT, "phaneron_amd", "lib", "libphaneron_hip_chanprobe.so")
-    if not os.path.exists(lib):
-        build.build(extra_flags=["-DPH_CHAN_PROBE=1"], variant="chanprobe")
+    lib = build.build(extra_flags=["-DPH_CHAN_PROBE=1"], variant="chanprobe")  # objects are rebuilt only when a source changed
     env = dict(os.environ, PHANERON_HIP_LIB=lib)
     if os.environ.get("PH_CHAN_PROBE_CHILD") != "1":
         env["PH_CHAN_PROBE_CHILD"] = "1"

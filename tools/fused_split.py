@@ -51,8 +51,7 @@ def main():
     if len(sys.argv) > 2:
         return child(int(sys.argv[1]), int(sys.argv[2]))
     from phaneron_amd import build
-    lib = build.build(extra_flags=["-DPH_FUSED_SPLIT=1"], variant="split") if not os.path.exists(
-        os.path.join(ROOT, "phaneron_amd", "lib", "libphaneron_hip_split.so")) else os.path.join(ROOT, "phaneron_amd", "lib", "libphaneron_hip_split.so")
+    lib = build.build(extra_flags=["-DPH_FUSED_SPLIT=1"], variant="split")  # objects are rebuilt only when a source changed
     res = {}
     runs = [(0, 0), (3, 0), (1, 0), (2, 0)] + [(1, c) for c in (224, 216, 208, 200, 192)] + [(2, c) for c in (32, 40, 48, 56, 64)]
     for mode, cus in runs:

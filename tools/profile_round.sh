@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that regenerates every measured artifact under profiles/ (written to
 # gpurun_out/profile/, copied into profiles/ afterwards).  usage: bash tools/profile_round.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profile; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -59,6 +59,45 @@ PY
 bash $ROOT/tools/pmc_sq.sh > $OUT/${TAG}_pmc_sq.txt 2>&1
 rm -rf $ROOT/gpurun_out/pmc_sq/*/  # keep the summary only
 
+# 4b. configs 2 and 3: their kernels timed alone, in-kernel phase probe, and counters incl. FETCH_SIZE / WRITE_SIZE (separate passes)
+(for v in wipe nowipe layer0; do python $ROOT/tools/chan_bench.py 300 rgba $v; done; python $ROOT/tools/chan_bench.py 300 v210 wipe) 2>/dev/null | grep '^{' > $OUT/${TAG}_chan_bench.jsonl
+python $ROOT/tools/chan_probe.py wipe 2>/dev/null | grep '^{' > $OUT/${TAG}_chan_probe.jsonl
+python $ROOT/tools/up_bench.py 100 2>/dev/null | grep '^{' > $OUT/${TAG}_up_bench.jsonl
+bash $ROOT/tools/pmc_kernel.sh chan_compose python $ROOT/tools/chan_bench.py 40 rgba wipe 2>&1 | grep -v '^{\|simple_timer\|^W2\|^find' > $OUT/${TAG}_pmc_chan.txt
+bash $ROOT/tools/pmc_kernel.sh compose_up python $ROOT/tools/up_bench.py 12 up 2>&1 | grep -v '^{\|simple_timer\|^W2\|^find' > $OUT/${TAG}_pmc_up.txt
+bash $ROOT/tools/pmc_kernel.sh v210_yadif_pair python $ROOT/tools/up_bench.py 12 deint 2>&1 | grep -v '^{\|simple_timer\|^W2\|^find' > $OUT/${TAG}_pmc_deint.txt
+rm -rf $ROOT/gpurun_out/pmc_kernel
+python3 - "$OUT" "$TAG" <<'PY'
+import json, sys
+out, tag = sys.argv[1], sys.argv[2]
+def counters(name):
+    d = {}
+    try:
+        for line in open("%s/%s_%s.txt" % (out, tag, name)):
+            f = line.split()
+            if len(f) == 3:
+                try:
+                    d[f[0]] = float(f[1])
+                except ValueError:
+                    pass
+    except OSError:
+        pass
+    return d
+doc = {"note": "per launch; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (separate --pmc passes).  MI355X_MICROARCH.md: FETCH_SIZE counts half the "
+               "bytes of a wide coalesced streaming read on gfx950 - `fetch_x2` doubles it (an upper figure: these kernels' narrow loads are uncalibrated)"}
+for name, algo, unit in (("pmc_chan", 38707200, "config 2: ph_chan_compose_v210, one launch per frame"),
+                         ("pmc_up", 4 * 1920 * 1080 * 12 + 22118400, "config 3 compositor: ph_compose_up_write_v210 on packed-RGB fields, one launch per field (its own inputs + v210 out)"),
+                         ("pmc_deint", 4 * 3 * 5529600 + 8 * 1920 * 1080 * 12, "config 3 de-interlacing reader: ph_v210_yadif_pair_fmt, one launch per frame = two fields (v210 windows in + packed-RGB fields out)")):
+    c = counters(name)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        raw = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        x2 = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        doc[name] = {"what": unit, "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"], "bytes_counter_units": int(raw), "bytes_fetch_x2": int(x2),
+                     "kernel_io_bytes": algo, "ratio_counter_units": round(raw / algo, 3), "ratio_fetch_x2": round(x2 / algo, 3)}
+json.dump(doc, open("%s/%s_config_traffic.json" % (out, tag), "w"), indent=1)
+print(json.dumps(doc))
+PY
+
 # 5. per-kernel, per-config, per-instruction and staging measurements
 python $ROOT/tools/kernel_bench.py 2>/dev/null | grep '^{' > $OUT/${TAG}_kernel_bench.jsonl
 PH_BENCH_CACHED_IMAGES=1 python $ROOT/tools/kernel_bench.py 2>/dev/null | grep '^{' | grep -v '"pack_\|fused_v210\|compose_write\|v210_write' > $OUT/${TAG}_kernel_bench_cached_images.jsonl
@@ -69,6 +108,6 @@ python $ROOT/tools/route_bench.py --loopback 2>/dev/null | grep '^{' > $OUT/${TA
 python $ROOT/tools/staging_bench.py 60 2>/dev/null | grep '^{' > $OUT/${TAG}_staging_bench.jsonl
 $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
 (node $ROOT/node/test/bench_node.js 200; node $ROOT/node/test/bench_node.js 300 1920 1080 4) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_bench.jsonl
-(for v in "--no-secondary" "--no-secondary --content picture" "--width 1920 --height 1080" "--width 1920 --height 1080 --channels 2" "--width 1920 --height 1080 --channels 4" "--channels 2 --ring 4"; do $BENCH $v --steps 1500 --cpu-seconds 0; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_bench_variants.jsonl
+(for v in "--no-secondary" "--no-secondary --content picture" "--width 1920 --height 1080" "--width 1920 --height 1080 --channels 2" "--width 1920 --height 1080 --channels 4" "--width 1920 --height 1080 --frames-per-launch 2" "--width 1920 --height 1080 --frames-per-launch 4" "--channels 2 --ring 4"; do $BENCH $v --steps 1500 --cpu-seconds 0; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_bench_variants.jsonl
 rm -rf $OUT/stats $OUT/pmc_bench_* $OUT/pmc_micro_*
 ls -la $OUT
