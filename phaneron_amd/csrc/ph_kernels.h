@@ -100,6 +100,7 @@ struct UpArgs {
   const float *wr_cm;
   LutView wr;
   uint32_t magic_upr, magic_upg;  // launcher
+  uint32_t shared;                // launcher: all layers have one size and one placement
 };
 bool compose_up_eligible(const UpArgs &a);
 hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb12, uint32_t num_cus);

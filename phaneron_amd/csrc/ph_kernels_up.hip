@@ -77,25 +77,30 @@ __device__ __forceinline__ uint32_t up_unit(const UpArgs &a, const UpShare &s, u
   return unit < s.units ? unit : ~0u;
 }
 
-// one output pixel of a layer: the sampler's filter on its 2 x 2 sub-patch (OpenCL 1.2 8.2 as DESIGN.md section 2 fixes it),
-// then combine.ts:45-65 into the pixel's accumulator
+// one output pixel of a layer: the sampler's filter on its 2 x 2 sub-patch with the four weights of OpenCL 1.2 8.2 as DESIGN.md
+// section 2 fixes them (w00 = (1 - a)(1 - b), w10 = a (1 - b), w01 = (1 - a) b, w11 = a b), then combine.ts:45-65 into the pixel's accumulator
 struct UpAcc {
   float r, g, b;
 };
-template <bool RGB12>
-__device__ __forceinline__ void up_blend(const UpTexel &t00, const UpTexel &t10, const UpTexel &t01, const UpTexel &t11, float wa, float wb,
-                                         bool first, bool all_inside, UpAcc &acc) {
+struct UpWeights {
+  float w00, w10, w01, w11;
+};
+__device__ __forceinline__ UpWeights up_weights(float wa, float wb) {
   const float oma = 1.0f - wa, omb = 1.0f - wb;
-  const float w00 = oma * omb, w10 = wa * omb, w01 = oma * wb, w11 = wa * wb;
-  const float r = ((w00 * t00.r + w10 * t10.r) + w01 * t01.r) + w11 * t11.r;
-  const float g = ((w00 * t00.g + w10 * t10.g) + w01 * t01.g) + w11 * t11.g;
-  const float b = ((w00 * t00.b + w10 * t10.b) + w01 * t01.b) + w11 * t11.b;
-  float al;
-  if (RGB12 && all_inside) al = ((w00 + w10) + w01) + w11;  // every texel's alpha is exactly 1: w * 1 == w
-  else al = ((w00 * t00.a + w10 * t10.a) + w01 * t01.a) + w11 * t11.a;
+  return UpWeights{oma * omb, wa * omb, oma * wb, wa * wb};
+}
+template <bool RGB12>
+__device__ __forceinline__ void up_blend(const UpTexel &t00, const UpTexel &t10, const UpTexel &t01, const UpTexel &t11, const UpWeights &w,
+                                         bool first, bool all_inside, UpAcc &acc) {
+  const float r = ((w.w00 * t00.r + w.w10 * t10.r) + w.w01 * t01.r) + w.w11 * t11.r;
+  const float g = ((w.w00 * t00.g + w.w10 * t10.g) + w.w01 * t01.g) + w.w11 * t11.g;
+  const float b = ((w.w00 * t00.b + w.w10 * t10.b) + w.w01 * t01.b) + w.w11 * t11.b;
   if (first) {
     acc.r = r, acc.g = g, acc.b = b;
   } else {  // the result's alpha is never used by the writer
+    float al;
+    if (RGB12 && all_inside) al = ((w.w00 + w.w10) + w.w01) + w.w11;  // every texel's alpha is exactly 1: w * 1 == w
+    else al = ((w.w00 * t00.a + w.w10 * t10.a) + w.w01 * t01.a) + w.w11 * t11.a;
     const float kk = 1.0f - al;
     acc.r = fma_rn(acc.r, kk, r), acc.g = fma_rn(acc.g, kk, g), acc.b = fma_rn(acc.b, kk, b);
   }
@@ -127,29 +132,31 @@ __device__ __forceinline__ bool up_step(const UpArgs &a, const UpShare &sh, uint
   return false;
 }
 
-// A layer's 3 x 3 patch for the lane's block, in two halves (addresses + loads, then the filter) so that a caller can have
-// two layers' texels in flight together.
-template <bool RGB12>
-struct UpPend {
-  UpTexel P[3][3];
-  float wa[2], wb[2];
-  bool d1;          // per lane: the right pixel's first tap is one texel further than the left pixel's
-  bool dj;          // uniform: likewise the lower row's
-  bool all_inside;  // uniform (packed RGB): every texel of every lane's patch is inside the image
-  uint32_t cin;     // packed RGB, per lane: bit c = patch column c is inside the image
-  uint32_t rin;     // packed RGB, uniform: bit r = patch row r is inside
+// Where a layer's 3 x 3 patch lies for the lane's block and how each of the four pixels weighs its 2 x 2 sub-patch: everything
+// that depends on the placement and the source's SIZE but not on its pixels.  Layers of one size under one placement (the
+// four full-frame HD sources of a UHD channel) share it: computed for the first, reused for the rest.
+struct UpGeo {
+  uint32_t coff[3];  // per lane: byte offsets of the patch's columns inside a row, or kUpOutside
+  uint32_t roff[3];  // uniform: byte offsets of its rows, or kUpOutside
+  UpWeights w[2][2];  // [output row][output column]
+  bool d1;           // per lane: the right pixel's first tap is one texel further than the left pixel's
+  bool dj;           // uniform: likewise the lower row's
+  bool all_inside;   // uniform (packed RGB): every texel of every lane's patch is inside the image
+  uint32_t cin;      // packed RGB, per lane: bit c = patch column c is inside the image
+  uint32_t rin;      // packed RGB, uniform: bit r = patch row r is inside
 };
 template <bool RGB12>
-__device__ __forceinline__ void up_issue(const UpLayer &L, const UpStep &st, bool more, UpPend<RGB12> &p) {
+__device__ __forceinline__ UpGeo up_geo(const UpLayer &L, const UpStep &st) {
   constexpr uint32_t kTexel = RGB12 ? 12u : 16u;
-  const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(L.ptr), 0, (int)(L.pitch * L.h), 0x00020000);
+  UpGeo g;
   // columns (per lane): transform.ts:53-57 with m1 == 0 (host-checked): fma(py, 0, px * m0) == px * m0 for every finite py
   uint32_t i0[2];
+  float wa[2], wb[2];
 #pragma unroll
   for (int dx = 0; dx < 2; ++dx) {
     const float sx = dot3(L.m[0], L.m[1], L.m[2], st.px[dx], st.py[0], 1.0f) + 0.5f;
     const float fu = sx * (float)(int)L.w - 0.5f, flu = __builtin_floorf(fu);
-    i0[dx] = (uint32_t)(int)flu, p.wa[dx] = fu - flu;
+    i0[dx] = (uint32_t)(int)flu, wa[dx] = fu - flu;
   }
   // rows (the same for every lane: m3 == 0, host-checked; computed on the lane's own operands, read from one lane)
   uint32_t j0[2];
@@ -158,61 +165,63 @@ __device__ __forceinline__ void up_issue(const UpLayer &L, const UpStep &st, boo
     const float sy = dot3(L.m[3], L.m[4], L.m[5], st.px[0], st.py[dy], 1.0f) + 0.5f;
     const float fv = sy * (float)(int)L.h - 0.5f, flv = __builtin_floorf(fv);
     j0[dy] = (uint32_t)__builtin_amdgcn_readfirstlane((int)flv);
-    p.wb[dy] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(fv - flv)));
+    wb[dy] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(fv - flv)));
   }
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) g.w[dy][dx] = up_weights(wa[dx], wb[dy]);
   // the 3 x 3 patch: columns i0[0] .. + 2 (i0[1] - i0[0] is 0 or 1 for a magnification of 2 or more), rows j0[0] .. + 2
-  p.d1 = i0[1] != i0[0];
-  p.dj = j0[1] != j0[0];
-  uint32_t coff[3], roff[3];
+  g.d1 = i0[1] != i0[0];
+  g.dj = j0[1] != j0[0];
   bool cin[3], rin[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const uint32_t col = i0[0] + (uint32_t)c;
-    cin[c] = more && col < L.w;
-    coff[c] = cin[c] ? __umul24(col, kTexel) : kUpOutside;
+    cin[c] = col < L.w;
+    g.coff[c] = cin[c] ? __umul24(col, kTexel) : kUpOutside;
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const uint32_t row = j0[0] + (uint32_t)r;
     rin[r] = row < L.h;
-    roff[r] = rin[r] ? row * L.pitch : kUpOutside;  // uniform
+    g.roff[r] = rin[r] ? row * L.pitch : kUpOutside;  // uniform
   }
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) p.P[r][c] = up_load<RGB12>(img, roff[r] + coff[c]);
-  p.all_inside = false, p.cin = 0, p.rin = 0;
+  g.all_inside = false, g.cin = 0, g.rin = 0;
   if (RGB12) {  // alpha of a packed-RGB texel: 1 inside the image, 0 (the border colour) outside - made when the patch is filtered
     const bool mine = cin[0] && cin[1] && cin[2];
-    p.all_inside = rin[0] && rin[1] && rin[2] && __builtin_amdgcn_ballot_w64(!mine) == 0;  // uniform
-    p.cin = (cin[0] ? 1u : 0u) | (cin[1] ? 2u : 0u) | (cin[2] ? 4u : 0u);
-    p.rin = (rin[0] ? 1u : 0u) | (rin[1] ? 2u : 0u) | (rin[2] ? 4u : 0u);
+    g.all_inside = rin[0] && rin[1] && rin[2] && __builtin_amdgcn_ballot_w64(!mine) == 0;  // uniform
+    g.cin = (cin[0] ? 1u : 0u) | (cin[1] ? 2u : 0u) | (cin[2] ? 4u : 0u);
+    g.rin = (rin[0] ? 1u : 0u) | (rin[1] ? 2u : 0u) | (rin[2] ? 4u : 0u);
   }
+  return g;
 }
+// one layer: its nine texels, then the four pixels' filters and combines
 template <bool RGB12>
-__device__ __forceinline__ void up_finish(const UpPend<RGB12> &p, bool first, UpAcc (&acc)[2][2]) {
+__device__ __forceinline__ void up_layer(const UpLayer &L, const UpGeo &g, bool first, UpAcc (&acc)[2][2]) {
+  const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(L.ptr), 0, (int)(L.pitch * L.h), 0x00020000);
   UpTexel P[3][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      P[r][c] = p.P[r][c];
-      if (RGB12) P[r][c].a = (!p.all_inside && ((p.rin >> r) & 1u) && ((p.cin >> c) & 1u)) ? 1.0f : 0.0f;  // unused when all are inside
+      P[r][c] = up_load<RGB12>(img, g.roff[r] + g.coff[c]);
+      if (RGB12) P[r][c].a = (!g.all_inside && ((g.rin >> r) & 1u) && ((g.cin >> c) & 1u)) ? 1.0f : 0.0f;  // unused when all are inside
     }
-  const bool d1 = p.d1, ai = p.all_inside;
+  const bool d1 = g.d1, ai = g.all_inside;
   // upper output row: patch rows 0, 1; left pixel: columns 0, 1; right pixel: columns d1, d1 + 1
-  up_blend<RGB12>(P[0][0], P[0][1], P[1][0], P[1][1], p.wa[0], p.wb[0], first, ai, acc[0][0]);
+  up_blend<RGB12>(P[0][0], P[0][1], P[1][0], P[1][1], g.w[0][0], first, ai, acc[0][0]);
   up_blend<RGB12>(up_pick(d1, P[0][0], P[0][1]), up_pick(d1, P[0][1], P[0][2]), up_pick(d1, P[1][0], P[1][1]), up_pick(d1, P[1][1], P[1][2]),
-                  p.wa[1], p.wb[0], first, ai, acc[0][1]);
+                  g.w[0][1], first, ai, acc[0][1]);
   // lower output row: patch rows dj, dj + 1 (a uniform branch: no selects)
-  if (p.dj) {
-    up_blend<RGB12>(P[1][0], P[1][1], P[2][0], P[2][1], p.wa[0], p.wb[1], first, ai, acc[1][0]);
+  if (g.dj) {
+    up_blend<RGB12>(P[1][0], P[1][1], P[2][0], P[2][1], g.w[1][0], first, ai, acc[1][0]);
     up_blend<RGB12>(up_pick(d1, P[1][0], P[1][1]), up_pick(d1, P[1][1], P[1][2]), up_pick(d1, P[2][0], P[2][1]), up_pick(d1, P[2][1], P[2][2]),
-                    p.wa[1], p.wb[1], first, ai, acc[1][1]);
+                    g.w[1][1], first, ai, acc[1][1]);
   } else {
-    up_blend<RGB12>(P[0][0], P[0][1], P[1][0], P[1][1], p.wa[0], p.wb[1], first, ai, acc[1][0]);
+    up_blend<RGB12>(P[0][0], P[0][1], P[1][0], P[1][1], g.w[1][0], first, ai, acc[1][0]);
     up_blend<RGB12>(up_pick(d1, P[0][0], P[0][1]), up_pick(d1, P[0][1], P[0][2]), up_pick(d1, P[1][0], P[1][1]), up_pick(d1, P[1][1], P[1][2]),
-                    p.wa[1], p.wb[1], first, ai, acc[1][1]);
+                    g.w[1][1], first, ai, acc[1][1]);
   }
 }
 
@@ -265,15 +274,15 @@ __global__ __launch_bounds__(kLdsBlock) void compose_up_write_v210_kernel(UpArgs
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = UpAcc{0.0f, 0.0f, 0.0f};
-    // one layer at a time.  Two variants were built and measured slower at 2160p x 4 layers (70 us): layers in pairs with both
-    // patches in flight (76 us) and a patch carried in flight across loop turns (85 us) - two patches plus the writer's
-    // temporaries do not fit 128 registers
+    // one layer at a time.  Two variants were built and measured slower at 2160p x 4 layers: layers in pairs with both
+    // patches in flight (76 against 70 us) and a patch carried in flight across loop turns (85 us) - two patches plus the
+    // writer's temporaries do not fit 128 registers
+    UpGeo geo;
 #pragma unroll 1
     for (int l = 0; l < a.n; ++l) {
       const UpLayer L = a.layer[l];  // one 48-byte scalar load
-      UpPend<RGB12> p;
-      up_issue<RGB12>(L, st, true, p);
-      up_finish<RGB12>(p, l == 0, acc);
+      if (l == 0 || !a.shared) geo = up_geo<RGB12>(L, st);  // uniform
+      up_layer<RGB12>(L, geo, l == 0, acc);
     }
     up_write(a, st, acc, role, wk, lk);
   }
@@ -302,6 +311,11 @@ hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.wr.bytes);
   if (e != hipSuccess) return e;
   UpArgs b = a;
+  b.shared = 1;  // every layer has the size and the placement of the first: the patch geometry and the weights are computed once per block
+  for (int l = 1; l < a.n; ++l) {
+    b.shared = b.shared && a.layer[l].w == a.layer[0].w && a.layer[l].h == a.layer[0].h && a.layer[l].pitch == a.layer[0].pitch;
+    for (int k = 0; k < 6; ++k) b.shared = b.shared && a.layer[l].m[k] == a.layer[0].m[k];
+  }
   const uint32_t upr = (a.out_w + kUpCols - 1u) / kUpCols, upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * upr;
   const uint32_t units = upr * ((a.lines + 1u) / 2u);
   // reciprocals for the kernel's uniform divisions: umulhi(v, ceil(2^32 / d)) == v / d while v * d < 2^32
