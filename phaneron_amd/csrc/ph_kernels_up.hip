@@ -196,16 +196,26 @@ __device__ __forceinline__ UpGeo up_geo(const UpLayer &L, const UpStep &st) {
   }
   return g;
 }
-// one layer: its nine texels, then the four pixels' filters and combines
+// one layer in two halves: its nine texels are requested, then the four pixels are filtered and combined
+struct UpPatch {
+  UpTexel P[3][3];
+};
 template <bool RGB12>
-__device__ __forceinline__ void up_layer(const UpLayer &L, const UpGeo &g, bool first, UpAcc (&acc)[2][2]) {
+__device__ __forceinline__ void up_fetch(const UpLayer &L, const UpGeo &g, UpPatch &p) {
   const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(L.ptr), 0, (int)(L.pitch * L.h), 0x00020000);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p.P[r][c] = up_load<RGB12>(img, g.roff[r] + g.coff[c]);
+}
+template <bool RGB12>
+__device__ __forceinline__ void up_filter(const UpPatch &p, const UpGeo &g, bool first, UpAcc (&acc)[2][2]) {
   UpTexel P[3][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      P[r][c] = up_load<RGB12>(img, g.roff[r] + g.coff[c]);
+      P[r][c] = p.P[r][c];
       if (RGB12) P[r][c].a = (!g.all_inside && ((g.rin >> r) & 1u) && ((g.cin >> c) & 1u)) ? 1.0f : 0.0f;  // unused when all are inside
     }
   const bool d1 = g.d1, ai = g.all_inside;
@@ -274,15 +284,18 @@ __global__ __launch_bounds__(kLdsBlock) void compose_up_write_v210_kernel(UpArgs
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = UpAcc{0.0f, 0.0f, 0.0f};
-    // one layer at a time.  Two variants were built and measured slower at 2160p x 4 layers: layers in pairs with both
-    // patches in flight (76 against 70 us) and a patch carried in flight across loop turns (85 us) - two patches plus the
-    // writer's temporaries do not fit 128 registers
+    // one layer at a time.  Variants built and measured slower at 2160p x 4 layers: layers in pairs with both patches in
+    // flight (76 against 70 us; again with the shared geometry: 84 against 68 us, 128 registers and spills) and a patch
+    // carried in flight across loop turns (85 us) - two patches plus the writer's temporaries do not fit 128 registers
     UpGeo geo;
+    int l = 0;
 #pragma unroll 1
-    for (int l = 0; l < a.n; ++l) {
+    for (; l < a.n; ++l) {
       const UpLayer L = a.layer[l];  // one 48-byte scalar load
       if (l == 0 || !a.shared) geo = up_geo<RGB12>(L, st);  // uniform
-      up_layer<RGB12>(L, geo, l == 0, acc);
+      UpPatch p;
+      up_fetch<RGB12>(L, geo, p);
+      up_filter<RGB12>(p, geo, l == 0, acc);
     }
     up_write(a, st, acc, role, wk, lk);
   }
