@@ -1008,8 +1008,9 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       // l<i>Prev / l<i>Cur / l<i>Next: v210 window; l<i>Out0 / l<i>Out1: RGBA; colMatrix / gammaLut / gamutMatrix: the Loader's
       const uint32_t width = prog->global[0], height = prog->global[1];
       if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
-      const size_t vb = (size_t)ph_v210_pitch_bytes(width) * height, img = (size_t)width * height * 16;
-      double tff, skip;
+      double tff, skip, rgb = 0;  // packedRgb (optional): 1 = the outputs are packed f32 RGB (12 bytes per pixel) for compose_up_write_v210_<n>
+      if (find_arg(args, n, "packedRgb")) TRY(need_num(args, n, "packedRgb", &rgb));
+      const size_t vb = (size_t)ph_v210_pitch_bytes(width) * height, img = (size_t)width * height * (rgb != 0 ? 12 : 16);
       ph_deint_source src[ph::kMaxLayers];
       for (int i = 0; i < prog->n_layers; ++i) {
         char nm[16];
@@ -1035,8 +1036,6 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "gamutMatrix", 36, &d));
       TRY(need_num(args, n, "tff", &tff));
       TRY(need_num(args, n, "skipSpatial", &skip));
-      double rgb = 0;  // optional: 1 = the outputs are packed f32 RGB (12 bytes per pixel) for compose_up_write_v210_<n>
-      if (find_arg(args, n, "packedRgb")) TRY(need_num(args, n, "packedRgb", &rgb));
       refresh_buf_lut(ctx, c);
       return ph_v210_yadif_pair_fmt(ctx, queue, prog->n_layers, src, width, height, (int)tff, (int)skip, rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32,
                                     b->dptr, c->dptr, d->dptr);
