@@ -25,6 +25,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef PH_CHAN_BALANCE
+#define PH_CHAN_BALANCE 1
+#endif
 #ifndef PH_CHAN_GROUP_ROWS
 #define PH_CHAN_GROUP_ROWS 16
 #endif
@@ -304,6 +307,18 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
   uint2 *const index = reinterpret_cast<uint2 *>(a.index);
   const float fow = (float)(int)a.out_w, foh = (float)(int)a.out_h;
   for (uint32_t n = wave; n < 3u * sh.slots; n += kLdsBlock / 64) {  // 64-column steps, dealt round the waves
+#if PH_CHAN_BALANCE
+    // the four waves of a SIMD are served oldest first: left alone the oldest races ahead and then idles at the phase barrier
+    // while the youngest still works alone at a wave's own pace.  A wave LOWERS its priority as it advances (priority
+    // outranks age), so whoever is behind is served first and the waves reach the barrier together (as the headline kernel does)
+    {
+      const uint32_t quarter = (4u * n) / (3u * sh.slots + 1u);
+      if (quarter == 0) __builtin_amdgcn_s_setprio(3);
+      else if (quarter == 1) __builtin_amdgcn_s_setprio(2);
+      else if (quarter == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     const uint32_t slot = n / 3u, sub = n - 3u * slot;
     const uint32_t chunk = chan_chunk(a, sh, slot);
     if (chunk == ~0u) continue;  // uniform

@@ -279,6 +279,7 @@ __global__ __launch_bounds__(kLdsBlock) void compose_up_write_v210_kernel(UpArgs
   const uint32_t role = lane - 3u * (lane / 3u);  // 0: pixels 0, 1 of the quad, 1: pixels 2, 3, 2: pixels 4, 5
   UpStep st;
   for (uint32_t v = sh.v0 + wave; up_step(a, sh, v, lane, st); v += sh.vstep) {
+    // (lowering a wave's priority as it advances, which helps the two-phase kernels reach their barrier together, measured neutral here)
     UpAcc acc[2][2];
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
