@@ -171,6 +171,11 @@ __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const fl
     V210Words w[kChanP][4];
     V210Col col[kChanP][2];
     uint32_t in[kChanP];
+    // A layer shown at its own scale (the Mixer's default fill: every full-frame layer) puts the lower pixel's upper taps on the
+    // upper pixel's lower taps - same columns, next row.  When that holds for every lane (uniform) the pair needs three source
+    // rows, not four: six conversions instead of eight.
+    static_assert(kChanP == 2, "the row sharing below is written for a pair");
+    const bool stacked = __builtin_amdgcn_ballot_w64(!(t[1].i0 == t[0].i0 && t[1].j0 == t[0].j0 + 1u)) == 0;
 #pragma unroll
     for (int p = 0; p < kChanP; ++p) {
       col[p][0] = v210_col(t[p].i0), col[p][1] = v210_col(t[p].i0 + 1u);
@@ -182,19 +187,34 @@ __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const fl
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const uint32_t base = ((i & 2) ? r1 : r0) + ((i & 1) ? c1 : c0);  // >= kOutsideBit when the row or the column is outside: the loads return 0
-        w[p][i] = v210_load(rs, base, col[p][i & 1]);
+        if (!(p == 1 && i < 2 && stacked)) w[p][i] = v210_load(rs, base, col[p][i & 1]);
         in[p] |= (base < kOutsideBit ? 1u : 0u) << i;
       }
     }
-    // one pixel's four taps are converted together: 24 table reads in flight before the first is consumed
-#pragma unroll
-    for (int p = 0; p < kChanP; ++p) {
+    // one pixel's taps are converted together: 24 table reads in flight before the first is consumed
+    {
       PxPending pend[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pend[i] = v210_issue<STD>(w[p][i], col[p][i & 1], k, lut);
+      for (int i = 0; i < 4; ++i) pend[i] = v210_issue<STD>(w[0][i], col[0][i & 1], k, lut);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) tap[p][i] = read_px_finish(pend[i], k);
+      for (int i = 0; i < 4; ++i) tap[0][i] = read_px_finish(pend[i], k);
+    }
+    if (stacked) {
+      PxPending pend[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) pend[i] = v210_issue<STD>(w[1][2 + i], col[1][i], k, lut);
+      __builtin_amdgcn_sched_barrier(0);
+      tap[1][0] = tap[0][2], tap[1][1] = tap[0][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) tap[1][2 + i] = read_px_finish(pend[i], k);
+    } else {
+      PxPending pend[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pend[i] = v210_issue<STD>(w[1][i], col[1][i & 1], k, lut);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tap[1][i] = read_px_finish(pend[i], k);
     }
     bool some_outside = false;
 #pragma unroll
