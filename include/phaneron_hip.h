@@ -340,12 +340,12 @@ int ph_compose_wipe_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *la
                                const void *wr_col_matrix12, const void *wr_gamma_lut);
 
 /* ---- the compositor for magnified layers (no single reference equivalent): [transform] x N -> combine_N -> v210 write
- *      as ph_compose_write_v210, for placements that enlarge every layer at least 2x without rotation or mirroring -
+ *      as ph_compose_write_v210, for placements that enlarge every layer (by 1 % or more) without rotation or mirroring -
  *      Mixer's default fill of HD sources on a UHD channel (producer/mixer.ts:209-223).  A lane produces a 2 x 2 block
  *      of output pixels from ONE 3 x 3 patch of each source (neighbouring output pixels share their taps): 2.25 texel
  *      loads per layer and pixel instead of 4.  Sources are f32 RGBA images or packed f32 RGB (PH_IMG_RGB_F32, alpha
  *      == 1 implied: ph_v210_yadif_pair_fmt), all layers of a call in the same layout.  Bit-identical to ph_transform +
- *      ph_combine + ph_v210_write.  A field write (interlace 1 / 3) needs 4x vertically: its rows are two lines apart.
+ *      ph_combine + ph_v210_write.  A field write (interlace 1 / 3) needs more than 2x vertically: its rows are two lines apart.
  *      PH_E_INVALID when a placement does not qualify (use ph_compose_write_v210),
  *      out_width % 6 != 0 or the writer LUT is not registered.  interlace as ph_v210_write. -------------------- */
 typedef struct ph_image_layer {

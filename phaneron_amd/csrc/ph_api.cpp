@@ -1720,8 +1720,8 @@ int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer
   a.lines = interlace ? out_h / 2 : out_h;
   a.wr_cm = (const float *)wr_cm, a.wr = *wv;
   if (!ph::compose_up_eligible(a))
-    return fail(PH_E_INVALID, "ph_compose_up_write_v210: every layer must be enlarged 2x or more without rotation or mirroring (and be below 1 GiB); "
-                              "use ph_compose_write_v210");
+    return fail(PH_E_INVALID, "ph_compose_up_write_v210: every layer must be enlarged (by 1 %% or more in both directions, per written row) without "
+                              "rotation or mirroring and be below 1 GiB; use ph_compose_write_v210");
   if (!a.lines) return PH_OK;
   PH_LAUNCH(ph::launch_compose_up_write_v210(stream_of(ctx, queue), a, fmt == PH_IMG_RGB_F32, (uint32_t)ctx->props.multiProcessorCount));
 }

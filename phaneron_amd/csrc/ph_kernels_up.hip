@@ -3,7 +3,7 @@
 //
 // The pixel-per-lane compositor (ph_kernels_lds.hip) loads four 16-byte taps per layer and output pixel; for BASELINE
 // config 3 (four 1080 sources shown at 2160) that is 256 bytes through the texture addressers per output pixel, and
-// they - not HBM, not the VALU - were what the kernel waited for.  When a layer is magnified at least 2x without rotation
+// they - not HBM, not the VALU - were what the kernel waited for.  When a layer is magnified without rotation
 // (Mixer's default fill of an HD source on a UHD channel: producer/mixer.ts:209-223, transform.ts:36-59), neighbouring
 // output pixels share their taps: the four pixels (x, x + 1) x (y, y + 1) with x, y even draw all sixteen taps from a
 // 3 x 3 patch of the source.  A lane owns such a block, loads the nine texels once per layer and picks each pixel's
@@ -302,17 +302,19 @@ __global__ __launch_bounds__(kLdsBlock) void compose_up_write_v210_kernel(UpArgs
   }
 }
 
-// Does the 2 x 2 block scheme apply?  Unrotated, unmirrored, magnified by 2 or more in both directions (then neighbouring
-// output pixels' first taps are at most one texel apart, rounding noise included), images below 1 GiB.
+// Does the 2 x 2 block scheme apply?  Unrotated, unmirrored, MAGNIFIED in both directions (then the first taps of the two
+// pixels of a block are at most one texel apart, rounding noise included, and the block's taps lie in a 3 x 3 patch), images
+// below 1 GiB.
 bool compose_up_eligible(const UpArgs &a) {
   if (a.out_w % 6u || !a.n) return false;
   for (int l = 0; l < a.n; ++l) {
     const UpLayer &L = a.layer[l];
     if (L.m[1] != 0.0f || L.m[3] != 0.0f || !(L.m[0] > 0.0f) || !(L.m[4] > 0.0f)) return false;
     // source texels per output pixel: d(u)/dx = m0 * w / out_w; per WRITTEN row: d(v)/dy = m4 * h / out_h * line_step (a field
-    // write takes every other line).  At most half a texel: then the first taps of neighbours are 0 or 1 apart whatever
-    // the f32 noise at a texel boundary does; with a whole texel between them it could be 2.
-    if ((double)L.m[0] * L.w > 0.5 * a.out_w || (double)L.m[4] * L.h * a.line_step > 0.5 * a.out_h) return false;
+    // write takes every other line).  Below one texel by a margin far above the f32 noise of the coordinates (1e-4 texels at
+    // 1920 columns): then the first taps of the block's two columns / rows are 0 or 1 apart; at a whole texel between them
+    // the noise could make it 2.
+    if ((double)L.m[0] * L.w > 0.99 * a.out_w || (double)L.m[4] * L.h * a.line_step > 0.99 * a.out_h) return false;
     if ((uint64_t)L.pitch * L.h >= (1ull << 30) || L.w >= (1u << 22)) return false;
   }
   return true;

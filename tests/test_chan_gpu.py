@@ -227,3 +227,47 @@ def test_refusals():
     plain = hh.dev(orc.linear2gamma_lut("709"))  # never registered: no LDS form
     with pytest.raises(capi.PhaneronError, match="writer gamma LUT has no LDS form"):
         k.chan_compose_v210([ok], out, w, h, 0, *rd_d, wr_d[0], plain)
+
+
+def test_random_channel_programs():
+    """seeded random channels: output sizes around the kernel's units (192-column chunks, row pairs, fewer chunks than waves),
+    1-6 layers of random source sizes and formats, random placements (scales either side of 1, rotations, flips, offsets that
+    push layers partly or wholly off screen), random transitions with placed or 1:1 partners, every interlace mode"""
+    r = np.random.default_rng(20260929)
+    sizes = [(192, 2), (192, 9), (384, 33), (576, 17), (768, 6), (960, 20)]
+    for case in range(18):
+        ow, oh = sizes[case % len(sizes)]
+        interlace = int(r.choice([0, 0, 1, 3]))
+
+        def source(must_fill=False):
+            rgba = r.random() < 0.25
+            one_to_one = r.random() < 0.3
+            if one_to_one:
+                w, h = ow, oh
+            else:
+                w, h = int(r.choice([48, 96, 192, 288, 384])), int(r.integers(2, 40))
+            seed = int(r.integers(1, 1 << 30))
+            data = frames.rgba_random(w, h, seed, -0.05, 1.05) if rgba else frames.v210_random(w, h, seed, legal=bool(r.random() < 0.7))
+            mat = None
+            if not one_to_one or r.random() < 0.5:
+                kw = dict(scale_x=float(r.choice([0.3, 0.5, 1.0, 1.0, 1.7, 2.0])), scale_y=float(r.choice([0.3, 0.5, 1.0, 1.0, 1.7, 2.0])),
+                          offset_x=float(r.uniform(-0.6, 0.6)), offset_y=float(r.uniform(-0.6, 0.6)))
+                if r.random() < 0.3:
+                    kw["rotate"] = float(r.uniform(-0.5, 0.5))
+                if r.random() < 0.2:
+                    kw["flip_h"] = True
+                if must_fill:
+                    kw = dict()
+                mat = m(ow, oh, **kw)
+            return Src(data, w, h, mat, "rgba" if rgba else "v210")
+        layers = []
+        for l in range(int(r.integers(1, 7))):
+            L = dict(src=source(must_fill=(l == 0 and r.random() < 0.5)))
+            t = r.random()
+            if t < 0.2:
+                L.update(transition="dissolve", mix=float(r.choice([0.0, 0.25, 1.0 / 3.0, 1.0])), incoming=source())
+            elif t < 0.4:
+                L.update(transition="wipe", incoming=source(), mask=source())
+            layers.append(L)
+        check(layers, ow, oh, "random channel %d: %dx%d il %d, %d layers" % (case, ow, oh, interlace, len(layers)), interlace=interlace,
+              specs=[("709", "709"), ("709", "2020"), ("2020", "709")][case % 3], poison_dst=bool(interlace))

@@ -74,14 +74,15 @@ def test_insets_with_borders_and_other_magnifications(rgb):
 
 @pytest.mark.parametrize("interlace", [1, 3])
 def test_field_outputs(interlace):
-    """a field write takes every other line: a layer must be enlarged 4x vertically for its written rows to be half a texel apart"""
+    """a field write takes every other line: a layer must be enlarged more than 2x vertically for its written rows to be less
+    than a texel apart (here 4x)"""
     import hip_harness as hh
     from phaneron_amd import capi
     sw, sh, ow, oh = 96, 13, 192, 54
     dst = np.full(frames.v210_pitch_bytes(ow) * oh // 4, 0x2AAAAAAA, np.uint32)
     layers = [(opaque(sw, sh, 20), m(ow, oh)), (opaque(48, 6, 21), m(ow, oh, scale_x=0.5, scale_y=0.5, offset_x=0.2))]
     check(layers, ow, oh, "interlace %d" % interlace, interlace=interlace, rgb=True, dst=dst)
-    with pytest.raises(capi.PhaneronError, match="enlarged 2x or more"):  # 2x vertically is not enough for a field
+    with pytest.raises(capi.PhaneronError, match="must be enlarged"):  # exactly 2x vertically: a field's rows are a whole texel apart
         run([(opaque(96, 27, 22), m(ow, oh))], ow, oh, interlace=interlace, rgb=True)
 
 
@@ -104,8 +105,8 @@ def test_placements_that_do_not_qualify_are_refused():
     out = torch.zeros(frames.v210_pitch_bytes(ow) * oh // 4, dtype=torch.int32, device="cuda")
     for kw in (dict(rotate=0.1), dict(flip_h=True), dict(scale_x=0.9, scale_y=0.9)):
         mat = capi.transform_matrix(ow, oh, **kw)
-        src_w = 192 if "scale_x" in kw else 96  # a 192-wide source shrunk to 0.9: less than 2x
-        with pytest.raises(capi.PhaneronError, match="enlarged 2x or more"):
+        src_w = 192 if "scale_x" in kw else 96  # a 192-wide source shrunk to 0.9: not enlarged
+        with pytest.raises(capi.PhaneronError, match="must be enlarged"):
             k.compose_up_write_v210([(src, src_w, 27 if src_w == 96 else 13, mat)], out, ow, oh, 0, wcm, wlut)
 
 
@@ -155,3 +156,27 @@ def test_config3_route_at_full_size():
         k.wait()
         torch.cuda.synchronize()
         assert torch.equal(got, want), "field of parity %d" % parity
+
+
+def test_random_magnified_layers():
+    """seeded random jobs: 1-5 layers of random sizes enlarged 1.1x-6x with random offsets (partly off screen included), both
+    layouts, output sizes around the 126-column wave step and odd row counts"""
+    r = np.random.default_rng(29092026)
+    outs = [(48, 4), (96, 7), (144, 12), (240, 9), (288, 31), (384, 16), (768, 5)]
+    for case in range(16):
+        ow, oh = outs[case % len(outs)]
+        rgb = bool(case & 1)
+        layers = []
+        for l in range(int(r.integers(1, 6))):
+            fx, fy = float(r.choice([1.1, 1.5, 2.0, 2.0, 2.5, 3.0, 4.0, 6.0])), float(r.choice([1.2, 1.5, 2.0, 2.0, 2.5, 3.0, 4.0]))
+            shown_w, shown_h = float(r.choice([1.0, 1.0, 0.5, 0.75])), float(r.choice([1.0, 1.0, 0.5]))
+            sw, sh = max(int(ow * shown_w / fx), 1), max(int(oh * shown_h / fy), 1)
+            img = opaque(sw, sh, int(r.integers(1, 1 << 30))) if rgb else frames.rgba_random(sw, sh, int(r.integers(1, 1 << 30)), -0.05, 1.05).reshape(sh, sw, 4)
+            kw = dict(scale_x=shown_w, scale_y=shown_h, offset_x=float(r.uniform(-0.4, 0.4)) if shown_w < 1 or r.random() < 0.3 else 0.0,
+                      offset_y=float(r.uniform(-0.4, 0.4)) if shown_h < 1 or r.random() < 0.3 else 0.0)
+            mat = m(ow, oh, **kw)
+            assert float(mat[0]) * sw <= 0.99 * ow and float(mat[4]) * sh <= 0.99 * oh
+            layers.append((img, mat))
+        if not layers:
+            continue
+        check(layers, ow, oh, "random magnified job %d: %dx%d, %d layers, %s" % (case, ow, oh, len(layers), "rgb" if rgb else "rgba"), rgb=rgb)
