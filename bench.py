@@ -342,6 +342,74 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         frames_done = int(t.item())
 
+    lds = ctx.lut_info(rd[1])["lds_bytes"] and ctx.lut_info(wr[1])["lds_bytes"] and not os.environ.get("PH_BENCH_GLOBAL_LUT")
+    kernel_name = ("fused_v210_combine_lds_kernel<%d,...>" if lds else "fused_v210_combine_kernel<%d>") % n
+
+    def report(route_rec, minimal=False):
+        """rank 0 prints the one JSON line; `minimal` (the route watchdog's call) leaves out everything that takes time"""
+        if rank == 0:
+            fps = frames_done / elapsed
+            algo_bytes = C * (n + 1) * frame_words * 4  # each input byte once + each output byte once
+            achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+            line = {
+                "metric": "frames/sec, 4-layer 2160p50 composite pipeline (v210 unpack->CSC->combine->CSC->v210 pack)",
+                "value": round(fps, 2), "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "fixed_warmup": FIXED_WARMUP, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 5),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": "%s: %d channel%s per GPU, %d x %dx%d v210 layers -> fused unpack/CSC(709->2020)/"
+                                       "combine_%d/CSC/pack -> 1 v210 frame%s"
+                                       % ("headline" if C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS) else "variant", 1 if K > 1 else C,
+                                          "" if C == 1 or K > 1 else "s", n, w, h, n,
+                                          "" if C == 1 else (", %d successive frames per launch" % K if K > 1 else " each, one batched launch per step")),
+                           "ring_frame_sets": args.ring, "channels": world * (1 if K > 1 else C), "frames_per_launch": K, "realtime_target_fps": 50,
+                           "content": args.content},
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(),
+                             "traffic_source": "recorded: profiles/pmc_traffic.json, rocprofv3 FETCH_SIZE / WRITE_SIZE passes "
+                                               "of this command (tools/profile_round.sh), not measured in this run",
+                             "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,
+                             "avg_launch_ms": round(kernel_ms, 5)},
+            }
+            if route_rec is not None:
+                line["route"] = route_rec
+            insts, src = recorded_valu_instructions()
+            if insts and C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS):
+                rate = insts / (kernel_ms * 1e-3)
+                line["roofline"]["valu"] = {"achieved": round(rate / 1e12, 4), "peak": round(VALU_PEAK_WAVE_INSTR_PER_S / 1e12, 4),
+                                            "unit": "T wave64-instr/s", "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4),
+                                            "instructions_per_launch": insts, "source": "recorded: profiles/" + src}
+            headline = C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS)
+            if not minimal and world == 1 and headline and not args.no_traffic and os.environ.get("PH_BENCH_TRAFFIC", "1") != "0":
+                got, detail = measured_traffic()
+                if got is not None:
+                    line["roofline"]["traffic"] = got
+                    line["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE "
+                                                          "(separate child passes of this script), gfx950 corrections applied")
+                    line["roofline"]["traffic_detail"] = detail
+                    line["roofline"]["traffic_over_algorithmic"] = round(got / algo_bytes, 4)
+                else:
+                    line["roofline"]["traffic_not_measured"] = detail
+            if not minimal and world == 1 and not args.no_secondary and C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS):
+                # BASELINE configs 2 and 3 (the compositing configs: real alpha, transforms, de-interlace), fastest route of each,
+                # measured after the timed region; tools/config_bench.py prints every route
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import config_bench
+                del ring[:]
+                torch.cuda.empty_cache()
+                try:
+                    line["secondary"] = config_bench.measure(ctx, torch, np, capi, "best", reps=150)
+                except Exception as e:  # the headline figure must not depend on the secondary workloads
+                    line["secondary"] = [{"error": "%s: %s" % (type(e).__name__, e)}]
+            if not minimal and world == 1 and args.cpu_seconds > 0:
+                try:
+                    line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+                except Exception as e:  # report rather than lose the line
+                    line["cpu_baseline"] = {"value": None, "unit": "frames/sec", "cores": 0, "kind": "port", "sample": "failed: %s: %s" % (type(e).__name__, e)}
+            else:
+                line["cpu_baseline"] = None
+            print(json.dumps(line), flush=True)
+
     # N > 1 (or the forced distributed path of the tests): BASELINE config 5 in the same command - 2 channels per rank,
     # every channel's fourth layer routed from channel k + N (ph_route_*: RCCL on its own stream), fingerprint-checked
     route_rec = None
@@ -354,75 +422,26 @@ def main():
         r_args = route_bench.parse(["--check", "--steps", "40", "--warmup", "5", "--width", str(WIDTH), "--height", str(rh),
                                     "--backend", "gloo" if share_gpu else "nccl"] + (["--loopback"] if world == 1 else []) +
                                    (["--same-gpu"] if share_gpu else []))
+        # The hand-off between processes on different GPUs cannot be rehearsed on the one-GPU boxes this is developed on: a
+        # watchdog keeps the headline figure if it stalls - rank 0 prints the line with the failure recorded, every rank leaves
+        import threading
+        limit = float(os.environ.get("PH_BENCH_ROUTE_TIMEOUT", "240"))
+
+        def gave_up():
+            report({"error": "config 5 did not finish within %.0f s; abandoned by the watchdog" % limit}, minimal=True)
+            sys.stdout.flush()
+            os._exit(0)
+        watchdog = threading.Timer(limit, gave_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             route_rec = route_bench.measure(r_args, ctx, dist, rank, world, device, log=lambda m: print(m, file=sys.stderr, flush=True))
         except Exception as e:  # the headline figure must not depend on it; every rank takes the same path or the job hangs
             route_rec = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            watchdog.cancel()
 
-    lds = ctx.lut_info(rd[1])["lds_bytes"] and ctx.lut_info(wr[1])["lds_bytes"] and not os.environ.get("PH_BENCH_GLOBAL_LUT")
-    kernel_name = ("fused_v210_combine_lds_kernel<%d,...>" if lds else "fused_v210_combine_kernel<%d>") % n
-    if rank == 0:
-        fps = frames_done / elapsed
-        algo_bytes = C * (n + 1) * frame_words * 4  # each input byte once + each output byte once
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        line = {
-            "metric": "frames/sec, 4-layer 2160p50 composite pipeline (v210 unpack->CSC->combine->CSC->v210 pack)",
-            "value": round(fps, 2), "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "fixed_warmup": FIXED_WARMUP, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "%s: %d channel%s per GPU, %d x %dx%d v210 layers -> fused unpack/CSC(709->2020)/"
-                                   "combine_%d/CSC/pack -> 1 v210 frame%s"
-                                   % ("headline" if C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS) else "variant", 1 if K > 1 else C,
-                                      "" if C == 1 or K > 1 else "s", n, w, h, n,
-                                      "" if C == 1 else (", %d successive frames per launch" % K if K > 1 else " each, one batched launch per step")),
-                       "ring_frame_sets": args.ring, "channels": world * (1 if K > 1 else C), "frames_per_launch": K, "realtime_target_fps": 50,
-                       "content": args.content},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(),
-                         "traffic_source": "recorded: profiles/pmc_traffic.json, rocprofv3 FETCH_SIZE / WRITE_SIZE passes "
-                                           "of this command (tools/profile_round.sh), not measured in this run",
-                         "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,
-                         "avg_launch_ms": round(kernel_ms, 5)},
-        }
-        if route_rec is not None:
-            line["route"] = route_rec
-        insts, src = recorded_valu_instructions()
-        if insts and C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS):
-            rate = insts / (kernel_ms * 1e-3)
-            line["roofline"]["valu"] = {"achieved": round(rate / 1e12, 4), "peak": round(VALU_PEAK_WAVE_INSTR_PER_S / 1e12, 4),
-                                        "unit": "T wave64-instr/s", "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4),
-                                        "instructions_per_launch": insts, "source": "recorded: profiles/" + src}
-        headline = C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS)
-        if world == 1 and headline and not args.no_traffic and os.environ.get("PH_BENCH_TRAFFIC", "1") != "0":
-            got, detail = measured_traffic()
-            if got is not None:
-                line["roofline"]["traffic"] = got
-                line["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE "
-                                                      "(separate child passes of this script), gfx950 corrections applied")
-                line["roofline"]["traffic_detail"] = detail
-                line["roofline"]["traffic_over_algorithmic"] = round(got / algo_bytes, 4)
-            else:
-                line["roofline"]["traffic_not_measured"] = detail
-        if world == 1 and not args.no_secondary and C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS):
-            # BASELINE configs 2 and 3 (the compositing configs: real alpha, transforms, de-interlace), fastest route of each,
-            # measured after the timed region; tools/config_bench.py prints every route
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import config_bench
-            del ring[:]
-            torch.cuda.empty_cache()
-            try:
-                line["secondary"] = config_bench.measure(ctx, torch, np, capi, "best", reps=150)
-            except Exception as e:  # the headline figure must not depend on the secondary workloads
-                line["secondary"] = [{"error": "%s: %s" % (type(e).__name__, e)}]
-        if world == 1 and args.cpu_seconds > 0:
-            try:
-                line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-            except Exception as e:  # report rather than lose the line
-                line["cpu_baseline"] = {"value": None, "unit": "frames/sec", "cores": 0, "kind": "port", "sample": "failed: %s: %s" % (type(e).__name__, e)}
-        else:
-            line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+    report(route_rec)
     ctx.close()
     if dist:
         dist.destroy_process_group()

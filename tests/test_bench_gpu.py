@@ -80,3 +80,12 @@ def test_two_ranks_sum_their_frames():
     check_line(line, 2, 30, 5)
     assert line["cpu_baseline"] is None and "secondary" not in line
     assert line["config"]["channels"] == 2
+
+
+def test_a_stalled_route_does_not_cost_the_line():
+    """config 5 abandoned by the watchdog (limit set to nothing): rank 0 still prints the headline line, the failure recorded in it"""
+    line = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29573", "bench.py", "--gpus", "1", "--steps", "30", "--warmup", "5", "--cpu-seconds", "0", "--no-secondary"],
+               {"PH_BENCH_FORCE_DIST": "1", "PH_BENCH_ROUTE_HEIGHT": "540", "PH_BENCH_ROUTE_TIMEOUT": "0.001"})
+    check_line(line, 1, 30, 5)
+    assert "abandoned by the watchdog" in line["route"]["error"]
