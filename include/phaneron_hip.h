@@ -428,7 +428,9 @@ int ph_lut_query(ph_ctx *ctx, const void *device_lut_f32, uint32_t *lds_bytes, u
  *          caches, for a caller that knows nothing on the device reads the image soon; 2 does so only for images
  *          larger than "stream_threshold_mb" MiB (default 64; measured neutral on the reference-shaped chains).  By
  *          default an image is treated as what it is in a channel, an intermediate the next operator reads back;
- *          wire-format outputs always stream. */
+ *          wire-format outputs always stream;
+ *          "host_pool_mb" (default 4096): how much pinned host memory released buffers' mirrors may keep for the next
+ *          buffer of the same size (the reference creates its destinations per job and frame: io.ts:64-72). */
 int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value);
 
 /* ---- host colour maths (src/process/colourMaths.ts, run by Loader/Saver constructors

@@ -1,0 +1,323 @@
+'use strict'
+// defer.js - runProgram as a RECORDING, so that the reference's per-frame job stream reaches the MI355X as the fused
+// kernels instead of one launch and one f32 frame per operator.
+//
+// The reference (and anything written against nodencl) asks for a channel's frame operator by operator, from
+// different valves and at different times: ToRGBA `read` in the producer (io.ts:100-118), `transform` in the Mixer
+// (producer/mixer.ts:209-223), `transition_*` in the Transitioner (transitioner.ts:165-176), `combine_N` in the
+// Combiner (combiner.ts:219-254), `write` in the consumer (io.ts:150-164) - every arrow a full-size f32 RGBA frame
+// through HBM (SURVEY 3.3).  The library has kernels that do the whole chain in one pass straight from the v210 words
+// (ph_chan_compose_v210, ph_fused_v210_combine), but nobody who speaks nodencl calls them.  With
+// `new clContext({ deferred: true })` (or PHANERON_DEFERRED=1) this layer makes the connection:
+//
+//   * runProgram does not launch.  It records a node - program, arguments, the buffers it reads and writes - and
+//     resolves at once.  Every buffer knows the pending node that will produce it and the pending nodes that read it.
+//     A node keeps a reference of its own on each of its buffers, so the owners' release() calls (the job callbacks of
+//     clJobQueue.ts:133-137) cannot free what a recorded job still needs.
+//   * The recording is forced only where a result becomes observable or an operand is about to change: hostAccess
+//     'readonly' / downloadAsync / a route send of a buffer with a pending producer (the consumer mapping its output
+//     frame, io.ts:166-174); hostAccess 'writeonly' of a buffer pending nodes still read (a new frame or a new
+//     placement matrix into an old buffer: transform.ts:84-89); a new job writing into such a buffer.  waitFinish does
+//     not force: nothing can tell a frame that sits in HBM from one that was never made.
+//   * Forcing a v210 `write` looks at what produces its input: [combine_N of] per layer [transition_* of]
+//     [transform of] (`read` of a v210 frame | an image that exists).  That shape is ONE launch of chan_compose_v210_N
+//     (or fused_v210_combine_N when every layer is a plain read of the output's size) on the ORIGINAL v210 sources.
+//     Anything else runs as recorded, producers first.  Both kernels are bit-identical to the chain of separate
+//     operators (tests/test_chan_gpu.py, tests/test_hip_parity.py), so deferring changes no result.
+//   * Intermediate images are never made unless somebody asks for them: their nodes stay pending as recipes.  When the
+//     owner's last reference goes (release() finds only recorded jobs holding the buffer) and nobody pending reads it,
+//     the recipe is dropped and its own operands are let go - the v210 source of a frame is recycled as soon as the
+//     last thing that could still need it is gone.
+//
+// What changes for the caller: RunTimings of a deferred job are zeros, and an argument error of a recorded job
+// surfaces where the job is forced (as a rejected hostAccess) instead of at runProgram.  Own design; nothing of
+// this exists in the reference, whose OpenCL queue runs every job as posted.
+
+const OUTPUT_ARG = /^(output|l\d+Out)/
+const ZERO_TIMINGS = () => ({ dataToKernel: 0, kernelExec: 0, totalTime: 0 })
+
+class Deferral {
+	constructor(ctx) {
+		this.ctx = ctx // the clContext: _native, _ctx, queue, createProgram
+		this.programs = new Map() // fused programs by `${name}|${w}|${h}`
+		this.pending = new Set() // recorded nodes that have neither run nor been dropped
+		this.launchedOn = new Map() // queue -> number of launches made on it
+		this.orderedAt = new Map() // `${waiter}<${signal}` -> the signal queue's launch count the waiter is ordered behind
+		this.stats = { recorded: 0, launched: 0, fused: 0, fusedNodes: 0, plain: 0, dropped: 0, fallbacks: 0, lastFallback: null }
+	}
+
+	// ---- bookkeeping on buffers -----------------------------------------------------------------------------
+	static adopt(buf) {
+		if (buf._readers) return
+		Object.defineProperty(buf, '_readers', { value: new Set(), enumerable: false })
+		Object.defineProperty(buf, '_producer', { value: null, enumerable: false, writable: true })
+		Object.defineProperty(buf, '_held', { value: 0, enumerable: false, writable: true })
+	}
+	_hold(buf) { this.ctx._native.bufAddRef(buf._handle); buf._held++ }
+	_unhold(buf) { buf._held--; this.ctx._native.bufRelease(buf._handle) }
+	_appRefs(buf) { return this.ctx._native.bufRefCount(buf._handle) - buf._held }
+
+	// ---- recording --------------------------------------------------------------------------------------------
+	record(program, params, queue) {
+		const ins = new Set()
+		const outs = new Set()
+		for (const name of Object.keys(params)) {
+			const v = params[name]
+			if (!Buffer.isBuffer(v)) continue
+			if (!v._handle) throw new Error(`runProgram: parameter '${name}' is a plain Buffer, not an OpenCLBuffer`)
+			Deferral.adopt(v)
+			if (OUTPUT_ARG.test(name)) outs.add(v); else ins.add(v)
+		}
+		const node = { program, params: Object.assign({}, params), queue, ins: Array.from(ins), outs: Array.from(outs), state: 'pending' }
+		for (const b of new Set([...ins, ...outs])) this._hold(b)
+		for (const i of node.ins) i._readers.add(node)
+		// a buffer this job overwrites: whoever still wants its present (or pending) contents goes first.  A pending
+		// producer is run too when the new job fills only part of the buffer (an interlaced `write`: every other line)
+		const whole = !(program.name === 'write' && params.interlace) // a field write leaves the other field's lines as they are
+		for (const o of node.outs) {
+			for (const r of Array.from(o._readers)) if (r !== node) this._run(r)
+			const p = o._producer
+			if (p && whole && p.outs.length === 1) { this.stats.dropped++; this._retire(p, 'dropped') } // its result would be overwritten unseen
+			else if (p) this._run(p)
+			o._producer = node
+		}
+		this.pending.add(node)
+		this.stats.recorded++
+		return ZERO_TIMINGS()
+	}
+
+	// the node has run, or will never have to: take it out of the graph and let go of its buffers
+	_retire(node, state) {
+		node.state = state
+		this.pending.delete(node)
+		for (const o of node.outs) if (o._producer === node) o._producer = null
+		for (const i of node.ins) i._readers.delete(node)
+		// operands that are recipes themselves go with it if nobody else can ask for them (we still hold them here)
+		for (const i of node.ins) this._reap(i)
+		for (const b of new Set([...node.ins, ...node.outs])) this._unhold(b)
+	}
+	// a recipe nobody can ask for any more: none of its outputs has a pending reader or a reference outside the recording
+	_reap(buf) {
+		const p = buf._producer
+		if (!p || p.state !== 'pending') return
+		for (const o of p.outs) if (o._readers.size || this._appRefs(o) > 0) return
+		this.stats.dropped++
+		this._retire(p, 'dropped')
+	}
+	// the owner called release(): index.js tells us after the native count went down
+	released(buf) {
+		if (buf._held > 0) this._reap(buf)
+	}
+
+	// ---- where the recording meets the host -------------------------------------------------------------------
+	// hostAccess / downloadAsync / route traffic on `queue`: 'readonly' needs the buffer's contents, 'writeonly' and
+	// 'none' replace them.  Launches made here (and earlier ones the caller's waitFinish could not have covered,
+	// because they had not been made yet) are ordered in front of the access ON THE DEVICE.
+	touch(buf, dir, queue) {
+		Deferral.adopt(buf)
+		if (dir === 'readonly') this.force(buf)
+		else {
+			this.beforeWrite(buf)
+			if (buf._producer) this.force(buf) // (a recorded result the host overwrites: run it rather than reason about partial writes)
+		}
+		for (const [q, epoch] of this.launchedOn) {
+			if (q === queue) continue
+			const key = `${queue}<${q}`
+			if (this.orderedAt.get(key) === epoch) continue
+			this.ctx._native.queueWaitQueue(this.ctx._ctx, queue, q)
+			this.orderedAt.set(key, epoch)
+		}
+	}
+
+	// ---- forcing ------------------------------------------------------------------------------------------------
+	// the buffer's contents are about to be replaced: every pending job that reads them runs now
+	beforeWrite(buf) {
+		if (!buf._readers || !buf._readers.size) return
+		for (const r of Array.from(buf._readers)) this._run(r)
+	}
+	// make the buffer's contents real
+	force(buf) {
+		if (buf._producer) this._run(buf._producer)
+	}
+	// whatever is still recorded runs (clContext.flushDeferred; recipes whose images nobody holds were dropped already)
+	forceAll() {
+		for (const n of Array.from(this.pending)) this._run(n)
+	}
+	_run(node) {
+		if (node.state !== 'pending') return
+		if (!this._fused(node)) this._plain(node)
+	}
+
+	_launch(program, params, queue) {
+		const names = []
+		const values = []
+		for (const name of Object.keys(params)) {
+			const v = params[name]
+			if (v === undefined || v === null) continue
+			names.push(name)
+			values.push(Buffer.isBuffer(v) ? v._handle : typeof v === 'boolean' ? (v ? 1 : 0) : v)
+		}
+		this.stats.launched++
+		this.launchedOn.set(queue, (this.launchedOn.get(queue) || 0) + 1)
+		return this.ctx._native.runProgram(this.ctx._ctx, program._handle, names, values, queue, false)
+	}
+	_plain(node) {
+		for (const i of node.ins) if (i._producer) this.force(i)
+		try {
+			this._launch(node.program, node.params, node.queue)
+		} finally {
+			this.stats.plain++
+			this._retire(node, 'done')
+		}
+	}
+
+	// ---- the fused shapes -------------------------------------------------------------------------------------
+	_program(name, width, height) {
+		const key = `${name}|${width}|${height}`
+		let p = this.programs.get(key)
+		if (!p) {
+			const handle = this.ctx._native.createProgram(this.ctx._ctx, 'phaneron:deferred', name, [width, height], 0)
+			this.programs.set(key, (p = { name, globalWorkItems: [width, height], workItemsPerGroup: 0, _handle: handle }))
+		}
+		return p
+	}
+	static _isV210(program, which) { return program.name === which && program.format === 'v210' }
+	static _frameOf(node) { // a v210 `read` / `write` job's frame: packer.ts:58-66 geometry
+		const wipg = node.program.workItemsPerGroup
+		const lines = wipg ? node.program.globalWorkItems[0] / wipg : 0
+		return { width: node.params.width, lines }
+	}
+
+	// node: a pending v210 `write`.  true = the frame has been produced by one fused launch
+	_fused(node) {
+		if (!Deferral._isV210(node.program, 'write')) return false
+		const image = node.params.input
+		const dims = image && image.imageDims
+		const top = image && image._producer
+		if (!dims || !top || top.state !== 'pending') return false
+		const width = dims.width
+		const height = dims.height
+		const interlace = node.params.interlace || 0
+		const geo = Deferral._frameOf(node)
+		if (geo.width !== width || geo.lines !== (interlace ? height / 2 : height)) return false
+		const output = node.params.output
+		if (!output || !node.params.colMatrix || !node.params.gammaLut) return false
+
+		let layerImages = [image]
+		const m = /^combine_(\d+)$/.exec(top.program.name)
+		if (m) {
+			layerImages = []
+			for (let i = 0; i < Number(m[1]); ++i) {
+				const l = top.params[`l${i}In`]
+				if (!l) return false
+				layerImages.push(l)
+			}
+		}
+		if (layerImages.length > 8) return false
+
+		// what each layer is made of; `reader` = the one Loader recipe the fused kernel can apply to v210 sources
+		let reader = null
+		const used = new Set() // pending nodes the fused launch stands in for
+		const sameSize = (img) => img.imageDims && img.imageDims.width === width && img.imageDims.height === height
+		const materialised = (img) => { this.force(img); return img.imageDims ? { source: img } : null }
+		const plainSource = (img) => { // an image as a sampled source: a pending v210 read, or the image itself
+			const p = img._producer
+			if (p && p.state === 'pending' && Deferral._isV210(p.program, 'read')) {
+				const r = { colMatrix: p.params.colMatrix, gammaLut: p.params.gammaLut, gamutMatrix: p.params.gamutMatrix }
+				const f = Deferral._frameOf(p)
+				const ok = r.colMatrix && r.gammaLut && r.gamutMatrix && p.params.input && img.imageDims &&
+					f.width === img.imageDims.width && f.lines === img.imageDims.height && f.width % 6 === 0 &&
+					(!reader || (reader.colMatrix === r.colMatrix && reader.gammaLut === r.gammaLut && reader.gamutMatrix === r.gamutMatrix))
+				if (ok) {
+					reader = reader || r
+					used.add(p)
+					return { source: p.params.input, width: f.width, height: f.lines, v210: true }
+				}
+			}
+			return materialised(img)
+		}
+		const placed = (img) => { // [transform of] a plain source, shown at the output's size
+			const p = img._producer
+			if (p && p.state === 'pending' && p.program.name === 'transform' && p.params.input && p.params.transformMatrix &&
+				p.program.globalWorkItems[0] === width && p.program.globalWorkItems[1] === height) {
+				const s = plainSource(p.params.input)
+				if (!s) return null
+				used.add(p)
+				return Object.assign(s, { matrix: p.params.transformMatrix })
+			}
+			if (!sameSize(img)) return null
+			const s = plainSource(img)
+			return s && (s.v210 ? (s.width === width && s.height === height ? s : null) : s)
+		}
+		const layers = []
+		for (const img of layerImages) {
+			const p = img._producer
+			const kind = p && p.state === 'pending' ? p.program.name : ''
+			if (kind === 'transition_dissolve' || kind === 'transition_wipe') {
+				const wipe = kind === 'transition_wipe'
+				if (!p.params.input0 || !p.params.input1 || (wipe && !p.params.maskIn) || !sameSize(img)) return false
+				const l = placed(p.params.input0)
+				const incoming = l && placed(p.params.input1)
+				const mask = incoming && wipe ? placed(p.params.maskIn) : null
+				if (!l || !incoming || (wipe && !mask)) return false
+				used.add(p)
+				l.transition = { wipe, mix: wipe ? 0 : Number(p.params.mix), incoming, mask }
+				layers.push(l)
+			} else {
+				const l = placed(img)
+				if (!l) return false
+				layers.push(l)
+			}
+		}
+		if (m) used.add(top)
+		if (!reader) return false // nothing but finished images: the recorded jobs are as good
+		// making a layer real may have run a producer another layer was going to stand in for: look again, with that image real
+		for (const u of used) if (u.state !== 'pending') return this._fused(node)
+
+		const n = layers.length
+		const headline = !interlace && layers.every((l) => l.v210 && !l.matrix && !l.transition)
+		const params = { output, colMatrix: reader.colMatrix, gammaLut: reader.gammaLut, gamutMatrix: reader.gamutMatrix,
+			outColMatrix: node.params.colMatrix, outGammaLut: node.params.gammaLut }
+		let program
+		if (headline) {
+			program = this._program(`fused_v210_combine_${n}`, width, height)
+			layers.forEach((l, i) => { params[`l${i}In`] = l.source })
+		} else {
+			program = this._program(`chan_compose_v210_${n}`, width, height)
+			params.interlace = interlace
+			const put = (prefix, s) => {
+				params[`${prefix}In`] = s.source
+				if (s.matrix) params[`${prefix}Matrix`] = s.matrix
+				if (s.v210) { params[`${prefix}Width`] = s.width; params[`${prefix}Height`] = s.height }
+			}
+			layers.forEach((l, i) => {
+				put(`l${i}`, l)
+				if (l.transition) {
+					params[`l${i}Transition`] = l.transition.wipe ? 2 : 1
+					if (!l.transition.wipe) params[`l${i}Mix`] = l.transition.mix
+					put(`l${i}Incoming`, l.transition.incoming)
+					if (l.transition.wipe) put(`l${i}Mask`, l.transition.mask)
+				}
+			})
+		}
+		if (process.env.PHANERON_DEFER_DEBUG) {
+			const show = {}
+			for (const k of Object.keys(params)) show[k] = Buffer.isBuffer(params[k]) ? `buf#${params[k]._handle && params[k].owner}:${params[k].length}` + (/Matrix$/.test(k) ? ' ' + Array.from(new Float32Array(params[k].buffer, params[k].byteOffset, 9)).map((v) => v.toFixed(4)).join(',') : '') : params[k]
+			process.stderr.write(`deferred launch ${program.name} ${JSON.stringify(show)}\n`)
+		}
+		try {
+			this._launch(program, params, node.queue)
+		} catch (e) { // a shape the fused kernels do not take after all: the recorded jobs still can
+			this.stats.launched--
+			this.stats.fallbacks++
+			this.stats.lastFallback = String(e && e.message || e)
+			return false
+		}
+		this.stats.fused++
+		this.stats.fusedNodes += used.size + 1
+		this._retire(node, 'done') // the producers it stood in for stay recipes until nobody can ask for their images
+		return true
+	}
+}
+
+module.exports = { Deferral }

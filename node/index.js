@@ -5,6 +5,7 @@
 // queue / logBuffers, and OpenCLBuffer objects that ARE node Buffers with hostAccess /
 // addRef / release and free-form timestamp fields.  Call sites: SURVEY.md 8(b).
 const path = require('path')
+const { Deferral } = require('./defer.js')
 
 let addon = null
 function loadAddon() {
@@ -24,7 +25,7 @@ const HOSTDIR = { readonly: 0, writeonly: 1, none: 2 }
 
 // Decorate the node Buffer the addon returned (pinned host mirror of the device buffer) with
 // the OpenCLBuffer members the reference uses.
-function makeOpenCLBuffer(native, created, numBytes, imageDims, owner) {
+function makeOpenCLBuffer(native, created, numBytes, imageDims, owner, deferral) {
 	const buf = created.buffer
 	const handle = created.handle
 	Object.defineProperty(buf, '_handle', { value: handle, enumerable: false })
@@ -37,14 +38,23 @@ function makeOpenCLBuffer(native, created, numBytes, imageDims, owner) {
 	buf.hostAccess = (dir, queue, src) => {
 		if (!(dir in HOSTDIR)) return Promise.reject(new Error(`hostAccess: unknown direction '${dir}'`))
 		if (Buffer.isBuffer(queue)) { src = queue; queue = 0 } // hostAccess(dir, src)
+		if (deferral) {
+			try {
+				deferral.touch(buf, dir, queue || 0)
+			} catch (e) { return Promise.reject(e) }
+		}
 		return native.hostAccess(handle, HOSTDIR[dir], queue || 0, src)
 	}
 	buf.addRef = () => { native.bufAddRef(handle) }
-	buf.release = () => { native.bufRelease(handle) }
-	buf.refCount = () => native.bufRefCount(handle)
+	// deferred contexts: recorded jobs hold references of their own (buf._held); the owner sees only its own
+	buf.release = () => { native.bufRelease(handle); if (deferral && buf._held) deferral.released(buf) }
+	buf.refCount = () => native.bufRefCount(handle) - (buf._held || 0)
 	// staging extension (not nodencl): device -> mirror on `queue` without a host wait; the bytes are
 	// valid after waitFinish(queue) or after an event recorded behind it has been awaited
-	buf.downloadAsync = (queue) => native.downloadAsync(handle, queue === undefined ? 2 : queue)
+	buf.downloadAsync = (queue) => {
+		if (deferral) deferral.touch(buf, 'readonly', queue === undefined ? 2 : queue)
+		return native.downloadAsync(handle, queue === undefined ? 2 : queue)
+	}
 	return buf
 }
 
@@ -58,6 +68,11 @@ class clContext {
 		// extension: waitFinish first polls the queue on the JS thread for up to this many microseconds
 		// before handing the wait to the libuv pool (a hand-off costs ~30 us; 0 = always hand off)
 		this.spinWaitMicros = params.spinWaitMicros || 0
+		// extension (node/defer.js): runProgram records instead of launching, and a frame's recorded operator chain
+		// reaches the device as one fused kernel when its result is asked for.  PHANERON_DEFERRED=1 turns it on for
+		// code that constructs the context itself (src/index.ts:94-107)
+		this.deferred = params.deferred === undefined ? process.env.PHANERON_DEFERRED === '1' : !!params.deferred
+		this._deferral = null
 		this.queue = this.overlapping ? { load: 0, process: 1, unload: 2 } : { load: 1, process: 1, unload: 1 }
 		this._ctx = null
 		this._native = null
@@ -66,6 +81,7 @@ class clContext {
 	async initialise() {
 		this._native = loadAddon()
 		this._ctx = this._native.createContext(this.deviceIndex)
+		if (this.deferred) this._deferral = new Deferral(this)
 	}
 
 	_need() {
@@ -87,7 +103,7 @@ class clContext {
 		const w = imageDims ? imageDims.width : 0
 		const h = imageDims ? imageDims.height : 0
 		const created = native.createBuffer(this._ctx, numBytes, ACCESS[bufDir], SVM[bufType], w, h, owner || '')
-		return makeOpenCLBuffer(native, created, numBytes, imageDims, owner)
+		return makeOpenCLBuffer(native, created, numBytes, imageDims, owner, this._deferral)
 	}
 
 	async createProgram(kernel, options) {
@@ -96,11 +112,15 @@ class clContext {
 		const gwi = options.globalWorkItems === undefined ? [] :
 			typeof options.globalWorkItems === 'number' ? [options.globalWorkItems] : Array.from(options.globalWorkItems)
 		const handle = native.createProgram(this._ctx, String(kernel), options.name, gwi, options.workItemsPerGroup || 0)
-		return { name: options.name, globalWorkItems: gwi, workItemsPerGroup: options.workItemsPerGroup || 0, _handle: handle }
+		const program = { name: options.name, globalWorkItems: gwi, workItemsPerGroup: options.workItemsPerGroup || 0, _handle: handle }
+		// which wire format a `read` / `write` is for: the recording layer recognises the v210 ends of a channel's chain
+		if (this._deferral && (options.name === 'read' || options.name === 'write')) program.format = native.resolveProgram(String(kernel), options.name).format
+		return program
 	}
 
 	async runProgram(program, params, queue) {
 		const native = this._need()
+		if (this._deferral) return this._deferral.record(program, params, queue === undefined ? this.queue.process : queue)
 		const names = []
 		const values = []
 		for (const name of Object.keys(params)) {
@@ -124,6 +144,15 @@ class clContext {
 		if (this.spinWaitMicros > 0 && native.waitFinishSpin(this._ctx, q, this.spinWaitMicros)) return
 		return native.waitFinish(this._ctx, q)
 	}
+
+	// deferred contexts: run whatever is still recorded (results nobody has asked for yet); returns the recording's counters
+	flushDeferred() {
+		if (this._deferral) this._deferral.forceAll()
+		return this._deferral ? Object.assign({ pending: this._deferral.pending.size }, this._deferral.stats) : null
+	}
+	// deferred contexts: make these buffers' contents real now, as a consumer on the device would need them (a no-op otherwise)
+	realise(...bufs) { if (this._deferral) for (const b of bufs) this._deferral.touch(b, 'readonly', this.queue.process) }
+	deferredStats() { return this._deferral ? Object.assign({ pending: this._deferral.pending.size }, this._deferral.stats) : null }
 
 	// ---- staging extensions (not nodencl; SURVEY 8f-3, node/staging.js) -----------------------------
 	// later work on `waiter` starts only after everything enqueued so far on `signal` has finished
@@ -152,13 +181,13 @@ class clContext {
 			afterQueue: (queue) => native.routeOp(h, 2, q(queue)),
 			queueAfter: (queue) => native.routeOp(h, 3, q(queue)),
 			wait: () => native.routeOp(h, 4),
-			send: (buf, peer) => native.routeOp(h, 5, buf._handle, peer),
-			recv: (buf, peer) => native.routeOp(h, 6, buf._handle, peer)
+			send: (buf, peer) => { if (this._deferral) this._deferral.touch(buf, 'readonly', this.queue.process); return native.routeOp(h, 5, buf._handle, peer) },
+			recv: (buf, peer) => { if (this._deferral) this._deferral.touch(buf, 'writeonly', this.queue.process); return native.routeOp(h, 6, buf._handle, peer) }
 		}
 	}
 	static routeUniqueId() { return loadAddon().routeUniqueId() }
 
-	// library options (include/phaneron_hip.h ph_ctx_set_option): 'lds_lut', 'stream_images', 'stream_threshold_mb'
+	// library options (include/phaneron_hip.h ph_ctx_set_option): 'lds_lut', 'stream_images', 'stream_threshold_mb', 'host_pool_mb'
 	setOption(name, value) { this._need().setOption(this._ctx, String(name), value | 0) }
 	logBuffers() {
 		const s = this._need().bufferStats(this._ctx)

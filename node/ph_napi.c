@@ -470,7 +470,9 @@ static napi_value CreateProgram(napi_env env, napi_callback_info info) {
 
 /* runProgram(ctx, prog, names[], values[], queue, timed) -> RunTimings | Promise<RunTimings>
  * values[i] is a buffer handle (external) or a number; float-valued kernel arguments are the
- * ones named in FLOAT_ARGS, everything else numeric is passed as a 32-bit integer. */
+ * ones named in FLOAT_ARGS and any value that is not a whole number (per-layer arguments such as l<i>Mix of
+ * chan_compose_v210_<n>); everything else numeric is passed as a 32-bit integer.  The library reads a
+ * numeric argument of either kind as a number (ph_api.cpp need_num). */
 static const char *FLOAT_ARGS[] = {"scale", "offsetX", "offsetY", "mix", "wipe", NULL};
 
 static napi_value RunProgram(napi_env env, napi_callback_info info) {
@@ -511,7 +513,7 @@ static napi_value RunProgram(napi_env env, napi_callback_info info) {
       double d = 0;
       napi_coerce_to_number(env, val, &val);
       napi_get_value_double(env, val, &d);
-      int is_float = 0;
+      int is_float = !(d >= -2147483648.0 && d <= 2147483647.0 && d == (double)(int32_t)d);
       for (const char **f = FLOAT_ARGS; *f; ++f) is_float |= (0 == strcmp(*f, args[i].name));
       if (is_float)
         args[i].kind = PH_ARG_F32, args[i].v.f32 = (float)d;

@@ -3,7 +3,10 @@
 //   (a) one kernel per operator (read x N, combine_N, write), every producer / combiner / consumer flushing its own
 //       key as the reference's graph does - the JobBoard drains once per turn;
 //   (b) the same with coalescing off: one waitFinish per key (the reference dispatcher's behaviour);
-//   (c) the fused channel program, one launch per frame.
+//   (c) the fused channel program, one launch per frame;
+//   (d) the job stream of (a) posted to a RECORDING context (node/defer.js) the way the reference's valves post it - a
+//       fresh destination image per job, released in the job's callback - and the packed frame asked for by a consumer
+//       on the device (ctx.realise): the recording folds each frame's six jobs into the one fused launch of (c).
 // usage: node bench_node.js [frames=200] [width=3840] [height=2160] [layers=4]; prints one JSON line per mode.
 const { Rig } = require('../device.js')
 
@@ -12,8 +15,8 @@ async function main() {
 	const w = parseInt(process.argv[3] || '3840')
 	const h = parseInt(process.argv[4] || '2160')
 	const n = parseInt(process.argv[5] || '4')
-	for (const mode of ['coalesced', 'per-key', 'fused']) {
-		const rig = await Rig.open({ deviceIndex: 0, coalesce: mode !== 'per-key', spinWaitMicros: 200 })
+	for (const mode of ['coalesced', 'per-key', 'fused', 'deferred']) {
+		const rig = await Rig.open({ deviceIndex: 0, coalesce: mode !== 'per-key', spinWaitMicros: 200, deferred: mode === 'deferred' })
 		const read = await rig.unpack('v210', w, h, '709', '2020')
 		const write = await rig.pack('v210', w, h, '2020', false)
 		const combine = n > 1 ? await rig.combine(n, w, h) : null
@@ -30,8 +33,29 @@ async function main() {
 		for (let l = 0; l < n; ++l) rgba.push(await rig.image(w, h))
 		const comb = await rig.image(w, h)
 		const out = await rig.planes('v210', w, h, 'writeonly')
+		const ring = [out, await rig.planes('v210', w, h, 'writeonly'), await rig.planes('v210', w, h, 'writeonly')]
 		const one = async (f) => {
 			if (mode === 'fused') { await rig.run(fused(src.map((p) => p[0]), out[0])); return rig.sync() }
+			if (mode === 'deferred') {
+				const ids = []
+				const fresh = []
+				for (let l = 0; l < n; ++l) {
+					const im = await rig.image(w, h)
+					const id = { source: `L${l}`, timestamp: f }
+					rig.post(id, read(src[l], im))
+					fresh.push(im)
+					ids.push(id)
+				}
+				const c = { source: 'combine', timestamp: f }
+				const cm = combine ? await rig.image(w, h) : fresh[0]
+				if (combine) rig.post(c, combine(fresh, cm), () => fresh.forEach((b) => b.release()))
+				const o = ring[f % ring.length] // three output frames in flight: the host prepares frame f + 1 while the device makes frame f
+				rig.post(c, write(cm, o, 0), () => cm.release())
+				ids.push(c)
+				await Promise.all(ids.map((id) => rig.board.flush(id)))
+				rig.ctx.realise(o[0])
+				return f % ring.length === ring.length - 1 ? rig.sync() : undefined
+			}
 			const ids = []
 			for (let l = 0; l < n; ++l) { const id = { source: `L${l}`, timestamp: f }; rig.post(id, read(src[l], rgba[l])); ids.push(id) }
 			const c = { source: 'combine', timestamp: f }
@@ -43,9 +67,10 @@ async function main() {
 		for (let f = 0; f < 10; ++f) await one(f)
 		const t0 = process.hrtime.bigint()
 		for (let f = 0; f < frames; ++f) await one(10 + f)
+		await rig.sync()
 		const sec = Number(process.hrtime.bigint() - t0) / 1e9
-		console.log(JSON.stringify({ bench: 'node', mode, width: w, height: h, layers: n, frames, frames_per_sec: +(frames / sec).toFixed(1), us_per_frame: +(1e6 * sec / frames).toFixed(1), drains: rig.board.stats.drains }))
-		;[...src.flat(), ...rgba, comb, ...out].forEach((b) => b.release())
+		console.log(JSON.stringify({ bench: 'node', mode, width: w, height: h, layers: n, frames, frames_per_sec: +(frames / sec).toFixed(1), us_per_frame: +(1e6 * sec / frames).toFixed(1), drains: rig.board.stats.drains, deferred: rig.ctx.deferredStats() || undefined }))
+		;[...src.flat(), ...rgba, comb, ...ring.flat()].forEach((b) => b.release())
 		rig.close()
 	}
 }

@@ -1,0 +1,297 @@
+'use strict'
+// The recording context (node/defer.js) against the plain one, on the GPU: the same operator-by-operator job streams -
+// shaped like the reference's valves post them (fresh destination per frame, released in the job callback, the
+// consumer mapping the packed frame) - go to `new clContext({deferred: false})` and `({deferred: true})`; every
+// frame a consumer would see must be the same bytes, and the counters must show that the deferred side made its
+// frames with ONE launch each where the chain has a fused form.
+// usage: node defer_run.js [width=384] [height=108]; prints one JSON object { scenarios: [...], problems: [...] }
+const { Rig } = require('../device.js')
+
+const W = parseInt(process.argv[2] || '384')
+const H = parseInt(process.argv[3] || '108')
+const problems = []
+const scenarios = []
+
+function lcg(seed) { let s = seed >>> 0; return () => (s = (Math.imul(s, 1664525) + 1013904223) >>> 0) }
+function v210Frame(bytes, seed, legal = true) {
+	const r = lcg(seed)
+	const b = Buffer.alloc(bytes)
+	const code = () => (legal ? 64 + (r() >>> 8) % 877 : (r() >>> 8) % 1024)
+	for (let i = 0; i + 4 <= bytes; i += 4) b.writeUInt32LE((code() | (code() << 10) | (code() << 20)) >>> 0, i)
+	return b
+}
+function rgbaFrame(w, h, seed, lo = 0, hi = 1) {
+	const r = lcg(seed)
+	const f = new Float32Array(w * h * 4)
+	for (let i = 0; i < f.length; ++i) f[i] = lo + (hi - lo) * ((r() >>> 8) / 16777216)
+	return Buffer.from(f.buffer)
+}
+const PIP = [{}, { scaleX: 0.5, scaleY: 0.5, offsetX: -0.25, offsetY: -0.25 }, { scaleX: 0.5, scaleY: 0.5, offsetX: 0.25, offsetY: -0.25 },
+	{ scaleX: 0.5, scaleY: 0.5, offsetX: 0.25, offsetY: 0.25 }]
+
+// one side (plain or deferred): the stages a channel needs and the helpers to drive them the way the valves do
+async function side(deferred) {
+	const rig = await Rig.open({ deviceIndex: 0, deferred, spinWaitMicros: 100 })
+	const s = { rig, deferred }
+	s.read = await rig.unpack('v210', W, H, '709', '709')
+	s.readHalf = await rig.unpack('v210', W / 2, H / 2, '709', '709')
+	s.write = await rig.pack('v210', W, H, '709', false)
+	s.writeField = await rig.pack('v210', W, H, '709', true)
+	s.combine = {}
+	for (const n of [2, 3, 4]) s.combine[n] = await rig.combine(n, W, H)
+	s.transform = await rig.transform(W, H)
+	s.dissolve = await rig.two('transition_dissolve', W, H)
+	s.wipe = await rig.two('transition_wipe', W, H)
+	s.yadif = await rig.yadif(W, H)
+	s.frame = 0
+	// a v210 source on the device
+	s.source = async (bytes, w = W, h = H) => {
+		const p = await rig.planes('v210', w, h)
+		await rig.upload(p[0], bytes)
+		return p[0]
+	}
+	s.image = async (bytes) => {
+		const im = await rig.image(W, H)
+		await rig.upload(im, bytes)
+		return im
+	}
+	// post a job as a valve does: destination released by the poster once the job's callback has fired
+	s.id = (name) => ({ source: name, timestamp: s.frame })
+	s.flush = (id) => rig.board.flush(id)
+	s.consume = async (out) => { await rig.download(out); return Buffer.from(out) } // the consumer's saveFrame
+	return s
+}
+
+// a scenario: fn(side) -> array of Buffers a consumer saw; run on both sides and compared
+async function scenario(name, fn, expect) {
+	const got = []
+	const stats = []
+	for (const deferred of [false, true]) {
+		const s = await side(deferred)
+		try {
+			got.push(await fn(s))
+			const st = s.rig.ctx.flushDeferred ? s.rig.ctx.deferredStats() : null
+			stats.push(st)
+			s.rig.close()
+			const left = s.rig.ctx.flushDeferred()
+			const live = s.rig.ctx._native.bufferStats(s.rig.ctx._ctx)
+			if (deferred && left && left.pending) problems.push({ scenario: name, what: `${left.pending} recorded jobs are still pending after everything was released` })
+			if (live.liveBuffers !== 0) problems.push({ scenario: name, what: `${live.liveBuffers} buffers still alive on the ${deferred ? 'deferred' : 'plain'} side` })
+		} catch (e) {
+			problems.push({ scenario: name, what: `${deferred ? 'deferred' : 'plain'} side: ${e && e.stack || e}` })
+			got.push([])
+			stats.push(null)
+		}
+	}
+	const [plain, lazy] = got
+	if (process.env.PHANERON_DEFER_DUMP) {
+		const fs = require('fs')
+		plain.forEach((b, i) => fs.writeFileSync(`${process.env.PHANERON_DEFER_DUMP}/s${scenarios.length}_plain_${i}.bin`, b))
+		lazy.forEach((b, i) => fs.writeFileSync(`${process.env.PHANERON_DEFER_DUMP}/s${scenarios.length}_deferred_${i}.bin`, b))
+	}
+	if (plain.length !== lazy.length || !plain.length) problems.push({ scenario: name, what: `frames seen: plain ${plain.length}, deferred ${lazy.length}` })
+	for (let i = 0; i < Math.min(plain.length, lazy.length); ++i)
+		if (Buffer.compare(plain[i], lazy[i]) !== 0) {
+			let at = 0
+			while (at < plain[i].length && plain[i][at] === lazy[i][at]) ++at
+			problems.push({ scenario: name, what: `frame ${i} differs from byte ${at} of ${plain[i].length}` })
+		}
+	const st = stats[1]
+	if (st && expect) for (const k of Object.keys(expect)) if (st[k] !== expect[k]) problems.push({ scenario: name, what: `deferred counter ${k} = ${st[k]}, expected ${expect[k]}`, stats: st })
+	scenarios.push({ name, frames: plain.length, deferred: st })
+}
+
+const v210Bytes = (w, h) => (Math.ceil(w / 48) * 128) * h
+
+async function main() {
+	const full = v210Bytes(W, H)
+	const half = v210Bytes(W / 2, H / 2)
+
+	// the headline's chain, as the producers / combiner / consumer post it: read x4 | combine_4 + write, three frames in flight
+	await scenario('read x4 -> combine_4 -> write, three frames in flight', async (s) => {
+		const seen = []
+		const outs = []
+		for (let f = 0; f < 3; ++f) {
+			s.frame = f
+			const srcs = []
+			for (let l = 0; l < 4; ++l) srcs.push(await s.source(v210Frame(full, 100 + 10 * f + l, l !== 2)))
+			const rgba = []
+			const ids = []
+			for (let l = 0; l < 4; ++l) {
+				const im = await s.rig.image(W, H)
+				const id = s.id(`L${l}`)
+				s.rig.post(id, s.read([srcs[l]], im), () => srcs[l].release()) // io.ts: the source goes once its frame is unpacked
+				rgba.push(im)
+				ids.push(id)
+			}
+			const comb = await s.rig.image(W, H)
+			const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+			const c = s.id('combine')
+			s.rig.post(c, s.combine[4](rgba, comb), () => rgba.forEach((b) => b.release()))
+			s.rig.post(c, s.write(comb, [out], 0), () => comb.release())
+			ids.push(c)
+			await Promise.all(ids.map((id) => s.flush(id)))
+			outs.push(out)
+		}
+		for (const out of outs) { seen.push(await s.consume(out)); out.release() }
+		return seen
+	}, { fused: 3, plain: 0, launched: 3 })
+
+	// BASELINE config 2's shape: placed layers, a wipe against a placed second source with an image mask
+	await scenario('PiP transforms + wipe on the top layer -> combine_4 -> write', async (s) => {
+		s.frame = 1
+		const srcs = []
+		for (let l = 0; l < 5; ++l) srcs.push(await s.source(v210Frame(full, 200 + l)))
+		const mask = await s.image(rgbaFrame(W, H, 77))
+		const unpacked = []
+		for (let l = 0; l < 5; ++l) {
+			const im = await s.rig.image(W, H)
+			s.rig.post(s.id('read'), s.read([srcs[l]], im), () => srcs[l].release())
+			unpacked.push(im)
+		}
+		const placed = []
+		for (let l = 0; l < 5; ++l) {
+			const im = await s.rig.image(W, H)
+			s.rig.post(s.id('mix'), s.transform(unpacked[l], im, await s.transform.matrix(PIP[Math.min(l, 3)])), () => unpacked[l].release())
+			placed.push(im)
+		}
+		const wiped = await s.rig.image(W, H)
+		s.rig.post(s.id('mix'), s.wipe(placed[3], placed[4], mask, wiped), () => { placed[3].release(); placed[4].release(); mask.release() })
+		const comb = await s.rig.image(W, H)
+		const layers = [placed[0], placed[1], placed[2], wiped]
+		s.rig.post(s.id('mix'), s.combine[4](layers, comb), () => layers.slice(0, 3).forEach((b) => b.release()))
+		s.rig.post(s.id('mix'), s.combine[4](layers, comb), () => wiped.release()) // (posted twice on purpose: the second supersedes the first)
+		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		s.rig.post(s.id('mix'), s.write(comb, [out], 0), () => comb.release())
+		await s.flush(s.id('read'))
+		await s.flush(s.id('mix'))
+		const seen = [await s.consume(out)]
+		out.release()
+		return seen
+	}, { fused: 1, plain: 0, launched: 1 })
+
+	// a dissolve against a half-size, rotated incoming source, over a plain read
+	await scenario('dissolve layer over a plain read', async (s) => {
+		s.frame = 2
+		const a = await s.source(v210Frame(full, 300))
+		const b = await s.source(v210Frame(half, 301), W / 2, H / 2)
+		const ua = await s.rig.image(W, H)
+		const ub = await s.rig.image(W / 2, H / 2)
+		await s.rig.run(s.read([a], ua))
+		await s.rig.run(s.readHalf([b], ub))
+		const pa = await s.rig.image(W, H)
+		const pb = await s.rig.image(W, H)
+		await s.rig.run(s.transform(ua, pa, await s.transform.matrix({})))
+		await s.rig.run(s.transform(ub, pb, await s.transform.matrix({ scaleX: 0.8, scaleY: 0.8, rotate: 0.05 })))
+		const d = await s.rig.image(W, H)
+		await s.rig.run(s.dissolve(pa, pb, 0.75, d))
+		const comb = await s.rig.image(W, H)
+		await s.rig.run(s.combine[2]([ua, d], comb))
+		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		await s.rig.run(s.write(comb, [out], 0))
+		await s.rig.sync()
+		const seen = [await s.consume(out)]
+		// intermediates somebody asks for after all: made then, from their recipes
+		seen.push(await s.consume(d), await s.consume(ub))
+		;[a, b, ua, ub, pa, pb, d, comb, out].forEach((x) => x.release())
+		return seen
+	}, { fused: 1 })
+
+	// a finished image (a routed frame, real alpha) as a layer over a plain read and under a placed one
+	await scenario('a finished image as a layer', async (s) => {
+		s.frame = 2
+		const a = await s.source(v210Frame(full, 310))
+		const b = await s.source(v210Frame(full, 311))
+		const routed = await s.image(rgbaFrame(W, H, 302, -0.05, 1.05))
+		const ua = await s.rig.image(W, H)
+		const ub = await s.rig.image(W, H)
+		await s.rig.run(s.read([a], ua))
+		await s.rig.run(s.read([b], ub))
+		const pb = await s.rig.image(W, H)
+		await s.rig.run(s.transform(ub, pb, await s.transform.matrix(PIP[2])))
+		const comb = await s.rig.image(W, H)
+		await s.rig.run(s.combine[3]([ua, routed, pb], comb))
+		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		await s.rig.run(s.write(comb, [out], 0))
+		const seen = [await s.consume(out)]
+		;[a, b, routed, ua, ub, pb, comb, out].forEach((x) => x.release())
+		return seen
+	}, { fused: 1, plain: 0 })
+
+	// one layer: the combiner passes it through (combiner.ts:213-217) - read -> write and read -> transform -> write
+	await scenario('single-layer channels', async (s) => {
+		s.frame = 2
+		const a = await s.source(v210Frame(full, 320, false))
+		const ua = await s.rig.image(W, H)
+		await s.rig.run(s.read([a], ua))
+		const pa = await s.rig.image(W, H)
+		await s.rig.run(s.transform(ua, pa, await s.transform.matrix({ scaleX: 1.5, scaleY: 1.5, rotate: -0.1 })))
+		const out1 = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		const out2 = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		await s.rig.run(s.write(ua, [out1], 0))
+		await s.rig.run(s.write(pa, [out2], 0))
+		const seen = [await s.consume(out1), await s.consume(out2)]
+		;[a, ua, pa, out1, out2].forEach((x) => x.release())
+		return seen
+	}, { fused: 2, plain: 0 })
+
+	// operands that change under a recording: a source frame and a placement matrix overwritten before the result is asked for
+	await scenario('source and matrix overwritten while recorded', async (s) => {
+		s.frame = 3
+		const a = await s.source(v210Frame(full, 400))
+		const b = await s.source(v210Frame(full, 401))
+		const ua = await s.rig.image(W, H)
+		const ub = await s.rig.image(W, H)
+		await s.rig.run(s.read([a], ua))
+		await s.rig.run(s.read([b], ub))
+		const m = await s.rig.ctx.createBuffer(48, 'readonly', 'none', undefined, 'matrix')
+		const set = async (placement) => {
+			const f = new Float32Array(12)
+			f.set(require('../index.js').colour.transformMatrix(W, H, placement))
+			await m.hostAccess('writeonly', s.rig.ctx.queue.load, Buffer.from(f.buffer))
+		}
+		await set({ scaleX: 0.5, scaleY: 0.5 })
+		const pb = await s.rig.image(W, H)
+		await s.rig.run(s.transform(ub, pb, m))
+		const comb = await s.rig.image(W, H)
+		await s.rig.run(s.combine[2]([ua, pb], comb))
+		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		await s.rig.run(s.write(comb, [out], 0))
+		await s.rig.sync()
+		await s.rig.upload(a, v210Frame(full, 402)) // the next frame into the same source buffer
+		await set({ scaleX: 0.25, scaleY: 0.25, rotate: 0.1 }) // the next placement into the same matrix buffer
+		const seen = [await s.consume(out)] // must show frame 400 / 401 at half size
+		;[a, b, ua, ub, m, pb, comb, out].forEach((x) => x.release())
+		return seen
+	})
+
+	// interlaced output: two field writes into one frame from two different composites; a de-interlaced layer
+	await scenario('field writes into one frame; a yadif layer', async (s) => {
+		s.frame = 4
+		const win = []
+		for (let i = 0; i < 3; ++i) win.push(await s.source(v210Frame(full, 500 + i)))
+		const bg = await s.source(v210Frame(full, 510))
+		const u = []
+		for (let i = 0; i < 3; ++i) { const im = await s.rig.image(W, H); await s.rig.run(s.read([win[i]], im)); u.push(im) }
+		const ubg = await s.rig.image(W, H)
+		await s.rig.run(s.read([bg], ubg))
+		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		await s.rig.upload(out, Buffer.alloc(full, 0x2a))
+		for (const field of [1, 3]) {
+			const y = await s.rig.image(W, H)
+			await s.rig.run(s.yadif(u[0], u[1], u[2], y, { parity: field === 1 ? 0 : 1, tff: 1, skipSpatial: 0 }))
+			const py = await s.rig.image(W, H)
+			await s.rig.run(s.transform(y, py, await s.transform.matrix({ scaleX: 0.6, scaleY: 0.6, offsetX: field === 1 ? 0.1 : -0.1 })))
+			const comb = await s.rig.image(W, H)
+			await s.rig.run(s.combine[2]([ubg, py], comb))
+			await s.rig.run(s.writeField(comb, [out], field))
+			;[y, py, comb].forEach((x) => x.release())
+		}
+		const seen = [await s.consume(out)]
+		;[...win, bg, ...u, ubg, out].forEach((x) => x.release())
+		return seen
+	}, { fused: 2 })
+
+	process.stdout.write(JSON.stringify({ width: W, height: H, scenarios, problems }) + '\n')
+}
+main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })

@@ -65,6 +65,12 @@ struct ph_ctx {
   hipDeviceProp_t props;
   std::multimap<size_t, void *> pool;  // free device blocks by exact size
   size_t pooled_bytes = 0, live_buffers = 0, live_bytes = 0;
+  // Pinned host mirrors by exact size.  The reference makes a fresh destination per job and frame (io.ts:64-72, mixer.ts:196,
+  // combiner.ts:230) and the node binding gives every buffer its mirror at once (an OpenCLBuffer IS a node Buffer): a
+  // hipHostMalloc / hipHostFree pair of a 2160p image is ~40 ms, a pool hit nothing
+  std::multimap<size_t, void *> host_pool;
+  size_t host_pooled_bytes = 0;
+  int host_pool_mb = 4096;  // what the pool may keep pinned
   void *field_scratch = nullptr;  // index frame of the field pipeline (ph_fused_field_v210)
   size_t field_scratch_bytes = 0;
   void *chan_index[3] = {nullptr, nullptr, nullptr};  // index frame of the channel compositor, one per queue (ph_chan_compose_v210)
@@ -182,6 +188,7 @@ void ctx_unref(ph_ctx *ctx) {
       hipStreamDestroy(ctx->streams[i]);
     }
   for (auto &kv : ctx->pool) hipFree(kv.second);
+  for (auto &kv : ctx->host_pool) hipHostFree(kv.second);
   for (auto &kv : ctx->luts)
     if (kv.second.blob_dev) hipFree(kv.second.blob_dev);
   if (ctx->field_scratch) hipFree(ctx->field_scratch);
@@ -329,7 +336,16 @@ int ph_buf_release(ph_buf *b) {
   hipSetDevice(ctx->device);
   ph_lut_unregister(ctx, b->dptr);  // the storage goes back to the pool: forget any LUT form of it
   if (b->owned) pool_free(ctx, b->bytes, b->dptr);
-  if (b->hptr) hipHostFree(b->hptr);
+  if (b->hptr) {
+    // as with device blocks: whoever releases a buffer has waited for the copies it started on it
+    bool keep = false;
+    {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      keep = ctx->host_pooled_bytes + b->bytes <= (size_t)ctx->host_pool_mb << 20;
+      if (keep) ctx->host_pool.emplace(b->bytes, b->hptr), ctx->host_pooled_bytes += b->bytes;
+    }
+    if (!keep) hipHostFree(b->hptr);
+  }
   {
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (b->owned) ctx->live_bytes -= b->bytes;
@@ -353,6 +369,16 @@ int ph_buf_dims(const ph_buf *b, int *w, int *h) {
 void *ph_buf_host_ptr(ph_buf *b) {
   if (!b) return nullptr;
   if (!b->hptr) {
+    {
+      std::lock_guard<std::mutex> lock(b->ctx->mu);
+      auto it = b->ctx->host_pool.find(b->bytes);
+      if (it != b->ctx->host_pool.end()) {
+        b->hptr = it->second;
+        b->ctx->host_pool.erase(it);
+        b->ctx->host_pooled_bytes -= b->bytes;
+        return b->hptr;
+      }
+    }
     hipSetDevice(b->ctx->device);
     if (hipHostMalloc(&b->hptr, b->bytes ? b->bytes : 1, hipHostMallocDefault) != hipSuccess) {
       fail(PH_E_HIP, "hipHostMalloc(%zu) failed", b->bytes);
@@ -827,6 +853,22 @@ int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
   if (0 == strcmp(name, "stream_threshold_mb")) {
     if (value < 0) return fail(PH_E_INVALID, "stream_threshold_mb: a size in MiB");
     return ctx->stream_threshold_mb = value, PH_OK;
+  }
+  if (0 == strcmp(name, "host_pool_mb")) {
+    if (value < 0) return fail(PH_E_INVALID, "host_pool_mb: a size in MiB");
+    std::vector<void *> drop;
+    {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      ctx->host_pool_mb = value;
+      while (ctx->host_pooled_bytes > (size_t)value << 20 && !ctx->host_pool.empty()) {
+        auto it = std::prev(ctx->host_pool.end());
+        ctx->host_pooled_bytes -= it->first;
+        drop.push_back(it->second);
+        ctx->host_pool.erase(it);
+      }
+    }
+    for (void *p : drop) hipHostFree(p);
+    return PH_OK;
   }
   return fail(PH_E_INVALID, "unknown option '%s'", name);
 }

@@ -282,3 +282,37 @@ def test_out_of_range_queue_is_refused(ctx):
     with pytest.raises(capi.PhaneronError, match="queue 5"):
         ctx.transition_dissolve(b.device_ptr(), b.device_ptr(), 0.5, b.device_ptr(), 2, 2, queue=5)
     b.release()
+
+
+def test_channel_program_by_name_with_a_dissolve(ctx):
+    """'chan_compose_v210_<n>' through runProgram's argument names (what node/defer.js folds a recorded chain into): a plain
+    layer under a placed one that dissolves against a smaller, rotated source - against the oracle's chain of operators"""
+    import frames
+    ow, oh = 384, 108
+    a = frames.v210_random(ow, oh, frames.layer_seed(96, 0))
+    b = frames.v210_random(192, 54, frames.layer_seed(96, 1))
+    col = Colour(ctx, "709", "709")
+    va, vb = upload(ctx, a, svm="coarse"), upload(ctx, b, svm="coarse")
+    m_id = np.zeros(12, np.float32)
+    m_id[:9] = capi.transform_matrix(ow, oh)
+    m_in = np.zeros(12, np.float32)
+    m_in[:9] = capi.transform_matrix(ow, oh, scale_x=0.8, scale_y=0.8, rotate=0.05)
+    bm_id, bm_in = upload(ctx, m_id), upload(ctx, m_in)
+    vout = ctx.create_buffer(capi.v210_pitch_bytes(ow) * oh, "writeonly", "coarse")
+    ctx.wait(capi.QUEUE_LOAD)
+    prog = ctx.create_program("phaneron:chan", "chan_compose_v210_2", [ow, oh])
+    ctx.run_program(prog, {"output": vout, "colMatrix": col.rd_cm, "gammaLut": col.rd_lut, "gamutMatrix": col.rd_gm, "outColMatrix": col.wr_cm,
+                           "outGammaLut": col.wr_lut, "interlace": 0, "l0In": va, "l0Width": ow, "l0Height": oh, "l1In": va, "l1Matrix": bm_id,
+                           "l1Width": ow, "l1Height": oh, "l1Transition": 1, "l1Mix": 0.75, "l1IncomingIn": vb, "l1IncomingMatrix": bm_in,
+                           "l1IncomingWidth": 192, "l1IncomingHeight": 54})
+    ctx.wait()
+    vout.host_access("readonly", capi.QUEUE_UNLOAD)
+    got = vout.host(np.uint32).copy()
+    ra = orc.v210_read(a, ow, oh, *col.oracle_rd)
+    rb = orc.v210_read(b, 192, 54, *col.oracle_rd)
+    d = orc.transition_dissolve(orc.transform(ra, m_id[:9], ow, oh), orc.transform(rb, m_in[:9], ow, oh), 0.75)
+    want = orc.v210_write(orc.combine([ra, d]), ow, oh, 0, *col.oracle_wr)
+    assert np.array_equal(got, np.asarray(want).reshape(-1))
+    for x in (va, vb, bm_id, bm_in, vout):
+        x.release()
+    col.release()

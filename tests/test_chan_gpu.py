@@ -271,3 +271,15 @@ def test_random_channel_programs():
             layers.append(L)
         check(layers, ow, oh, "random channel %d: %dx%d il %d, %d layers" % (case, ow, oh, interlace, len(layers)), interlace=interlace,
               specs=[("709", "709"), ("709", "2020"), ("2020", "709")][case % 3], poison_dst=bool(interlace))
+
+
+def test_dissolve_against_a_smaller_rotated_source_over_the_same_frame_taken_plain():
+    """one v210 frame used twice - pixel for pixel as the bottom layer and, through the identity fill, as the outgoing side
+    of a dissolve whose incoming side is a half-size source, rotated (the chain node/defer.js folds into this kernel)"""
+    ow, oh = 384, 108
+    a = frames.v210_random(ow, oh, frames.layer_seed(95, 0))
+    b = frames.v210_random(192, 54, frames.layer_seed(95, 1))
+    for mix in (0.75, 0.2):
+        layers = [dict(src=Src(a, ow, oh)),
+                  dict(src=Src(a, ow, oh, m(ow, oh)), transition="dissolve", mix=mix, incoming=Src(b, 192, 54, m(ow, oh, scale_x=0.8, scale_y=0.8, rotate=0.05)))]
+        check(layers, ow, oh, "dissolve %g, half-size rotated incoming" % mix)

@@ -152,9 +152,11 @@ def test_addon_host_maths_equals_the_reference_goldens():
 
 @needs_node
 @pytest.mark.gpu
-def test_golden_trace_replays_on_the_real_addon(tmp_path):
+@pytest.mark.parametrize("deferred", [False, True], ids=["launch_as_posted", "deferred"])
+def test_golden_trace_replays_on_the_real_addon(tmp_path, deferred):
     """tests/golden/host_trace.json - every nodencl call the reference's own operators and dispatcher made in the
-    scenario - executed call by call on index.js + ph_napi.c + libphaneron_hip.so (node/test/replay.js)."""
+    scenario - executed call by call on index.js + ph_napi.c + libphaneron_hip.so (node/test/replay.js); a second time
+    through the recording context (node/defer.js, PHANERON_DEFERRED=1): same counts, same frames, fewer launches."""
     import hashlib
     import frames
     trace = json.load(open(TRACE))
@@ -171,11 +173,16 @@ def test_golden_trace_replays_on_the_real_addon(tmp_path):
     big = {e["src"]["sha"] for e in trace if e["op"] == "hostAccess" and e["src"] and e["src"]["bytes"] > 64}
     assert big <= have, "the trace loads a frame this test cannot regenerate"
     r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "replay.js"), TRACE, TEXT_SHA, str(tmp_path)],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, PHANERON_DEFERRED="1" if deferred else "0"))
     assert r.returncode == 0, r.stdout + r.stderr
     res = json.loads((tmp_path / "replay.json").read_text())
     assert "gfx950" in res["device"]
     assert res["problems"] == [], res["problems"][:5]
+    if deferred:  # the v210 round trip (read -> write, io.ts) is one fused launch (images the scenario never maps stay recipes)
+        d = res["deferred"]
+        assert d["fused"] >= 1 and d["launched"] < d["recorded"] and d["fallbacks"] == 0, d
+    else:
+        assert res["deferred"] is None
     n_calls = sum(1 for e in trace if e["op"] in ("createBuffer", "hostAccess", "createProgram", "runProgram", "waitFinish", "addRef", "release"))
     assert res["calls"] == n_calls and n_calls > 480
     # what the reference mapped for reading (saveFrame): the v210 round trip gives the ramp back ("Compare returned
@@ -512,7 +519,8 @@ def valve_oracle_frames(w, h):
 
 @needs_node
 @pytest.mark.gpu
-def test_reference_valve_trace_replays_on_the_real_addon(tmp_path):
+@pytest.mark.parametrize("deferred", [False, True], ids=["launch_as_posted", "deferred"])
+def test_reference_valve_trace_replays_on_the_real_addon(tmp_path, deferred):
     """Every nodencl call the reference's valves made - buffers by owner, Transform / Transition / Combine programs from their
     kernel names, parameters by OpenCL argument name, the black frame written through a mapped mirror, every addRef / release -
     goes to index.js + ph_napi.c + libphaneron_hip.so; reference counts match the recorded ones at every step, nothing leaks,
@@ -530,10 +538,12 @@ def test_reference_valve_trace_replays_on_the_real_addon(tmp_path):
     big = {e["src"]["sha"] for e in trace if e["op"] == "hostAccess" and e["src"] and e["src"]["bytes"] > 64}
     assert big <= have, "the trace loads a frame this test cannot regenerate"
     r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "replay.js"), VALVE_TRACE, TEXT_SHA, str(tmp_path)],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, PHANERON_DEFERRED="1" if deferred else "0"))
     assert r.returncode == 0, r.stdout + r.stderr
     res = json.loads((tmp_path / "replay.json").read_text())
     assert res["problems"] == [], res["problems"][:5]
+    if deferred:  # (the valves' outputs are f32 images mapped by the test, so every job runs as recorded, when its image is asked for)
+        assert res["deferred"]["recorded"] > 0 and res["deferred"]["fallbacks"] == 0, res["deferred"]
     assert len(res["dumps"]) == 11
     want = valve_oracle_frames(w, h)
     for f, d in enumerate(res["dumps"]):
@@ -557,3 +567,21 @@ def test_channel_js_equals_the_reference_valves_frame_for_frame(tmp_path):
     for f in range(nf):
         got = np.fromfile(tmp_path / ("out_%d.bin" % f), np.float32)
         assert np.array_equal(got.view(np.uint32), want[f].reshape(-1).view(np.uint32)), "frame %d" % f
+
+
+@needs_node
+@pytest.mark.gpu
+def test_recording_context_gives_the_same_frames_with_one_launch_per_frame():
+    """node/defer.js (new clContext({deferred: true})): operator-by-operator job streams shaped like the valves' - fresh
+    destinations released in the job callbacks, several frames in flight, sources and placement matrices overwritten while
+    recorded, field writes, a de-interlaced layer, intermediates asked for afterwards - give byte for byte the frames of the
+    launch-as-posted context, the chains with a fused form as ONE launch per frame, and leave no buffer behind."""
+    _build_addon()
+    for size in (("384", "108"), ("1920", "64")):
+        r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "defer_run.js"), *size], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        assert res["problems"] == [], res["problems"][:3]
+        assert len(res["scenarios"]) >= 7 and all(s["frames"] >= 1 for s in res["scenarios"])
+        first = res["scenarios"][0]["deferred"]
+        assert first["recorded"] == 18 and first["launched"] == 3 and first["fused"] == 3, first

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 struct Stamp { unsigned long long cyc, real, r0, r1; };
@@ -71,6 +72,10 @@ ASMK(k_fma_then_cvt, "v_fma_f32 %0, %0, %1, %2\n\tv_cvt_f32_u32 %0, %0")
 ASMK(k_fma_then_lshl_add, "v_fma_f32 %0, %0, %1, %2\n\tv_lshl_add_u32 %0, %0, 2, %1")
 ASMK(k_fma_then_fma, "v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2")
 ASMK(k_fma_dpp, "v_fma_f32 %0, %0, %1, %2\n\tv_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+// neighbour moves: inside a row of 16 lanes against across the whole wave (s_nop: the VALU-write -> DPP-read hazard)
+ASMK(k_fma_rowshr, "v_fma_f32 %0, %0, %1, %2\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
+ASMK(k_fma_waveshr, "v_fma_f32 %0, %0, %1, %2\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf")
+ASMK(k_fma_nop, "v_fma_f32 %0, %0, %1, %2\n\ts_nop 1")
 
 // packed f32
 __global__ __launch_bounds__(1024) void k_pk(Stamp* st, unsigned* out, unsigned a, unsigned b, int iters) {
@@ -168,6 +173,13 @@ static void run(const char* name, K kern, int instr_per_slot, int waves_per_simd
 }
 
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "dpp")) {  // only the neighbour-move rows
+    run("pair fma+mov_dpp quad_perm", k_fma_dpp, 2, 4, 256);
+    run("pair fma+s_nop", k_fma_nop, 1, 4, 256);
+    run("pair fma+s_nop+mov_dpp row_shr:1", k_fma_rowshr, 2, 4, 256);
+    run("pair fma+s_nop+mov_dpp wave_shr:1", k_fma_waveshr, 2, 4, 256);
+    return 0;
+  }
   const bool quick = argc > 1;
   const int wlist[] = {1, 2, 4, 8};
 #define R(n, k, ips) for (int w : wlist) { run(n, k, ips, w, 256); } if (!quick) run(n, k, ips, 4, 1);
