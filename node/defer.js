@@ -41,6 +41,7 @@ class Deferral {
 		this.ctx = ctx // the clContext: _native, _ctx, queue, createProgram
 		this.programs = new Map() // fused programs by `${name}|${w}|${h}`
 		this.pending = new Set() // recorded nodes that have neither run nor been dropped
+		this.lastReader = null // the Loader recipe of the newest v210 `read` (colMatrix / gammaLut / gamutMatrix buffers)
 		this.launchedOn = new Map() // queue -> number of launches made on it
 		this.orderedAt = new Map() // `${waiter}<${signal}` -> the signal queue's launch count the waiter is ordered behind
 		this.stats = { recorded: 0, launched: 0, fused: 0, fusedNodes: 0, plain: 0, dropped: 0, fallbacks: 0, lastFallback: null }
@@ -81,6 +82,8 @@ class Deferral {
 			else if (p) this._run(p)
 			o._producer = node
 		}
+		if (Deferral._isV210(program, 'read') && params.colMatrix && params.gammaLut && params.gamutMatrix)
+			this.lastReader = { colMatrix: params.colMatrix, gammaLut: params.gammaLut, gamutMatrix: params.gamutMatrix }
 		this.pending.add(node)
 		this.stats.recorded++
 		return ZERO_TIMINGS()
@@ -161,6 +164,24 @@ class Deferral {
 		this.launchedOn.set(queue, (this.launchedOn.get(queue) || 0) + 1)
 		return this.ctx._native.runProgram(this.ctx._ctx, program._handle, names, values, queue, false)
 	}
+	// a fused launch that may be refused (a shape the kernel does not take): false = nothing was launched
+	_try(program, params, queue) {
+		if (process.env.PHANERON_DEFER_DEBUG) {
+			const show = {}
+			for (const k of Object.keys(params)) show[k] = Buffer.isBuffer(params[k]) ? `${params[k].owner}:${params[k].length}` : params[k]
+			process.stderr.write(`deferred launch ${program.name} ${JSON.stringify(show)}\n`)
+		}
+		try {
+			this._launch(program, params, queue)
+			return true
+		} catch (e) {
+			this.stats.launched--
+			this.launchedOn.set(queue, this.launchedOn.get(queue) - 1)
+			this.stats.fallbacks++
+			this.stats.lastFallback = `${program.name}: ${e && e.message || e}`
+			return false
+		}
+	}
 	_plain(node) {
 		for (const i of node.ins) if (i._producer) this.force(i)
 		try {
@@ -186,6 +207,65 @@ class Deferral {
 		const wipg = node.program.workItemsPerGroup
 		const lines = wipg ? node.program.globalWorkItems[0] / wipg : 0
 		return { width: node.params.width, lines }
+	}
+
+	// Layers that are de-interlaced sources: [transform of] `yadif` of three images that are pending v210 reads.  The Yadif
+	// valve posts both fields of a frame (yadif.ts:100-145, send_field: parity 1 ^ tff, then parity tff); the pair over one
+	// window, for every such layer of the channel, is ONE launch of v210_yadif_pair_<k> on the v210 frames themselves
+	// (unpack + filter, both fields: ph_kernels_deint.hip), bit-identical to read x 3 -> yadif x 2.  Anything that does not
+	// fit (one field only, an image of the window already real, mixed sizes) is left to run as recorded.
+	_deinterlace(layerImages) {
+		const found = new Map() // cur image -> { windows of v210 sources, the two yadif nodes }
+		const v210Of = (img, w, h, reader) => {
+			const p = img && img._producer
+			if (!p || p.state !== 'pending' || !Deferral._isV210(p.program, 'read') || !p.params.input) return null
+			const f = Deferral._frameOf(p)
+			if (f.width !== w || f.lines !== h || !img.imageDims || img.imageDims.width !== w || img.imageDims.height !== h) return null
+			if (reader.colMatrix !== p.params.colMatrix || reader.gammaLut !== p.params.gammaLut || reader.gamutMatrix !== p.params.gamutMatrix) return null
+			return p.params.input
+		}
+		for (let img of layerImages) {
+			let p = img._producer
+			if (p && p.state === 'pending' && p.program.name === 'transform') { img = p.params.input; p = img && img._producer }
+			if (!p || p.state !== 'pending' || p.program.name !== 'yadif' || found.has(p.params.cur)) continue
+			const { prev, cur, next } = p.params
+			const rd = cur && cur._producer
+			if (!prev || !cur || !next || !rd || !p.params.output) continue
+			const [w, h] = p.program.globalWorkItems
+			const reader = { colMatrix: rd.params.colMatrix, gammaLut: rd.params.gammaLut, gamutMatrix: rd.params.gamutMatrix }
+			if (!reader.colMatrix || !reader.gammaLut || !reader.gamutMatrix) continue
+			const src = [v210Of(prev, w, h, reader), v210Of(cur, w, h, reader), v210Of(next, w, h, reader)]
+			if (src.includes(null)) continue
+			// the other field of the same window
+			let twin = null
+			for (const r of cur._readers)
+				if (r !== p && r.state === 'pending' && r.program.name === 'yadif' && r.params.prev === prev && r.params.cur === cur && r.params.next === next &&
+					!!r.params.tff === !!p.params.tff && !!r.params.skipSpatial === !!p.params.skipSpatial && !!r.params.parity !== !!p.params.parity &&
+					r.params.output && r.params.output !== p.params.output) twin = r
+			if (!twin) continue
+			const out = p.params.parity ? [twin.params.output, p.params.output] : [p.params.output, twin.params.output]
+			found.set(cur, { src, out, nodes: [p, twin], w, h, reader, tff: p.params.tff ? 1 : 0, skip: p.params.skipSpatial ? 1 : 0 })
+		}
+		// one launch per group of windows that share size, field order and Loader recipe
+		const groups = []
+		for (const e of found.values()) {
+			let g = groups.find((v) => v.length < 8 && v[0].w === e.w && v[0].h === e.h && v[0].tff === e.tff && v[0].skip === e.skip &&
+				v[0].reader.colMatrix === e.reader.colMatrix && v[0].reader.gammaLut === e.reader.gammaLut && v[0].reader.gamutMatrix === e.reader.gamutMatrix)
+			if (!g) groups.push((g = []))
+			g.push(e)
+		}
+		for (const g of groups) {
+			const e0 = g[0]
+			const params = Object.assign({ tff: e0.tff, skipSpatial: e0.skip }, e0.reader)
+			g.forEach((e, i) => {
+				params[`l${i}Prev`] = e.src[0]; params[`l${i}Cur`] = e.src[1]; params[`l${i}Next`] = e.src[2]
+				params[`l${i}Out0`] = e.out[0]; params[`l${i}Out1`] = e.out[1]
+			})
+			if (!this._try(this._program(`v210_yadif_pair_${g.length}`, e0.w, e0.h), params, e0.nodes[0].queue)) continue
+			this.stats.fused++
+			this.stats.fusedNodes += 2 * g.length
+			for (const e of g) for (const y of e.nodes) this._retire(y, 'done')
+		}
 	}
 
 	// node: a pending v210 `write`.  true = the frame has been produced by one fused launch
@@ -214,6 +294,7 @@ class Deferral {
 			}
 		}
 		if (layerImages.length > 8) return false
+		this._deinterlace(layerImages)
 
 		// what each layer is made of; `reader` = the one Loader recipe the fused kernel can apply to v210 sources
 		let reader = null
@@ -270,21 +351,27 @@ class Deferral {
 			}
 		}
 		if (m) used.add(top)
-		if (!reader) return false // nothing but finished images: the recorded jobs are as good
 		// making a layer real may have run a producer another layer was going to stand in for: look again, with that image real
 		for (const u of used) if (u.state !== 'pending') return this._fused(node)
 
 		const n = layers.length
-		const headline = !interlace && layers.every((l) => l.v210 && !l.matrix && !l.transition)
-		const params = { output, colMatrix: reader.colMatrix, gammaLut: reader.gammaLut, gamutMatrix: reader.gamutMatrix,
-			outColMatrix: node.params.colMatrix, outGammaLut: node.params.gammaLut }
-		let program
-		if (headline) {
-			program = this._program(`fused_v210_combine_${n}`, width, height)
+		const anyV210 = layers.some((l) => l.v210 || (l.transition && (l.transition.incoming.v210 || (l.transition.mask && l.transition.mask.v210))))
+		if (!used.size) return false // every layer is a finished image taken as it is: the recorded write is as good
+		const saver = { outColMatrix: node.params.colMatrix, outGammaLut: node.params.gammaLut }
+		const candidates = [] // [program name, params], best first; the library refuses the shapes a kernel does not take
+		if (!interlace && layers.every((l) => l.v210 && !l.matrix && !l.transition)) {
+			const params = Object.assign({ output }, reader, saver)
 			layers.forEach((l, i) => { params[`l${i}In`] = l.source })
-		} else {
-			program = this._program(`chan_compose_v210_${n}`, width, height)
-			params.interlace = interlace
+			candidates.push([`fused_v210_combine_${n}`, params])
+		}
+		if (!anyV210 && layers.every((l) => l.matrix && !l.transition)) { // finished images, placed: enlarged ones share their taps
+			const params = Object.assign({ output, interlace }, saver)
+			layers.forEach((l, i) => { params[`l${i}In`] = l.source; params[`l${i}Matrix`] = l.matrix })
+			candidates.push([`compose_up_write_v210_${n}`, params])
+		}
+		const loader = reader || this.lastReader // the channel kernel wants a Loader recipe even if no layer turns out to need it
+		if (loader) {
+			const params = Object.assign({ output, interlace }, loader, saver)
 			const put = (prefix, s) => {
 				params[`${prefix}In`] = s.source
 				if (s.matrix) params[`${prefix}Matrix`] = s.matrix
@@ -299,20 +386,13 @@ class Deferral {
 					if (l.transition.wipe) put(`l${i}Mask`, l.transition.mask)
 				}
 			})
+			candidates.push([`chan_compose_v210_${n}`, params])
 		}
-		if (process.env.PHANERON_DEFER_DEBUG) {
-			const show = {}
-			for (const k of Object.keys(params)) show[k] = Buffer.isBuffer(params[k]) ? `buf#${params[k]._handle && params[k].owner}:${params[k].length}` + (/Matrix$/.test(k) ? ' ' + Array.from(new Float32Array(params[k].buffer, params[k].byteOffset, 9)).map((v) => v.toFixed(4)).join(',') : '') : params[k]
-			process.stderr.write(`deferred launch ${program.name} ${JSON.stringify(show)}\n`)
+		let done = false
+		for (const [name, params] of candidates) {
+			if (this._try(this._program(name, width, height), params, node.queue)) { done = true; break }
 		}
-		try {
-			this._launch(program, params, node.queue)
-		} catch (e) { // a shape the fused kernels do not take after all: the recorded jobs still can
-			this.stats.launched--
-			this.stats.fallbacks++
-			this.stats.lastFallback = String(e && e.message || e)
-			return false
-		}
+		if (!done) return false
 		this.stats.fused++
 		this.stats.fusedNodes += used.size + 1
 		this._retire(node, 'done') // the producers it stood in for stay recipes until nobody can ask for their images

@@ -67,8 +67,14 @@ export interface PlatformInfo {
 	devices: Array<{ type: string; name: string; vendor: string }>
 }
 
+export interface DeferredStats {
+	pending: number; recorded: number; launched: number; fused: number; fusedNodes: number; plain: number; dropped: number; fallbacks: number; lastFallback: string | null
+}
+
 export class clContext {
-	constructor(params?: { platformIndex?: number; deviceIndex?: number; overlapping?: boolean; profile?: boolean; spinWaitMicros?: number })
+	/** `deferred` (default: PHANERON_DEFERRED === '1'): runProgram records instead of launching; a packed frame's recorded operator chain
+	 * reaches the device as one fused kernel when the frame is asked for (node/defer.js) */
+	constructor(params?: { platformIndex?: number; deviceIndex?: number; overlapping?: boolean; profile?: boolean; spinWaitMicros?: number; deferred?: boolean })
 	readonly queue: { load: number; process: number; unload: number }
 	initialise(): Promise<void>
 	getPlatformInfo(): PlatformInfo
@@ -76,6 +82,11 @@ export class clContext {
 	createProgram(kernel: string, options: { name: string; globalWorkItems?: number | Uint32Array | number[]; workItemsPerGroup?: number }): Promise<OpenCLProgram>
 	runProgram(program: OpenCLProgram, params: KernelParams, queue?: number): Promise<RunTimings>
 	waitFinish(queue?: number): Promise<void>
+	/** deferred contexts: make these buffers' contents real now, as a consumer on the device would need them */
+	realise(...bufs: OpenCLBuffer[]): void
+	/** deferred contexts: run everything still recorded; returns the recording's counters (null on a plain context) */
+	flushDeferred(): DeferredStats | null
+	deferredStats(): DeferredStats | null
 	/** staging extension: later work on `waiter` starts after everything enqueued so far on `signal` */
 	queueWaitQueue(waiter: number, signal: number): void
 	/** staging extension */
@@ -83,7 +94,7 @@ export class clContext {
 	/** ROUTE across GPUs: RCCL send / recv on a communication stream of its own, ordered on the device */
 	openRoute(id: Buffer, rank: number, world: number): RouteLink
 	static routeUniqueId(): Buffer
-	/** library options: 'lds_lut' (0 | 1), 'stream_images' (0 cached | 1 streamed | 2 by size), 'stream_threshold_mb' */
+	/** library options: 'lds_lut' (0 | 1), 'stream_images' (0 cached | 1 streamed | 2 by size), 'stream_threshold_mb', 'host_pool_mb' (pinned mirrors kept for reuse) */
 	setOption(name: string, value: number): void
 	logBuffers(): { liveBuffers: number; liveBytes: number; pooledBytes: number }
 }

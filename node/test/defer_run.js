@@ -43,6 +43,7 @@ async function side(deferred) {
 	s.dissolve = await rig.two('transition_dissolve', W, H)
 	s.wipe = await rig.two('transition_wipe', W, H)
 	s.yadif = await rig.yadif(W, H)
+	s.yadifHalf = await rig.yadif(W / 2, H / 2)
 	s.frame = 0
 	// a v210 source on the device
 	s.source = async (bytes, w = W, h = H) => {
@@ -290,7 +291,74 @@ async function main() {
 		const seen = [await s.consume(out)]
 		;[...win, bg, ...u, ubg, out].forEach((x) => x.release())
 		return seen
-	}, { fused: 2 })
+	}, { fused: 3, plain: 0, launched: 3 }) // the yadif pair in one launch (both fields are recorded before the first is asked for), one compositor launch per field
+
+	// BASELINE config 3's shape: interlaced half-size sources, both fields of every layer de-interlaced (the Yadif valve posts
+	// the pair), each enlarged to the channel's size by the default fill, combine, one packed frame per field
+	await scenario('de-interlaced layers enlarged 2x, both fields', async (s) => {
+		s.frame = 5
+		const L = 2
+		const u = []
+		const srcs = []
+		for (let l = 0; l < L; ++l) {
+			u.push([])
+			for (let i = 0; i < 3; ++i) {
+				const src = await s.source(v210Frame(half, 600 + 10 * l + i), W / 2, H / 2)
+				const im = await s.rig.image(W / 2, H / 2)
+				await s.rig.run(s.readHalf([src], im))
+				srcs.push(src)
+				u[l].push(im)
+			}
+		}
+		const fields = [[], []]
+		for (let l = 0; l < L; ++l)
+			for (const second of [0, 1]) { // yadif.ts:104 parity = tff ^ !isSecond, tff = 1
+				const y = await s.rig.image(W / 2, H / 2)
+				await s.rig.run(s.yadifHalf(u[l][0], u[l][1], u[l][2], y, { parity: second ? 1 : 0, tff: 1, skipSpatial: 0 }))
+				fields[second].push(y)
+			}
+		const seen = []
+		const fill = await s.transform.matrix({})
+		for (const second of [0, 1]) {
+			const placed = []
+			for (let l = 0; l < L; ++l) {
+				const im = await s.rig.image(W, H)
+				await s.rig.run(s.transform(fields[second][l], im, fill))
+				fields[second][l].release()
+				placed.push(im)
+			}
+			const comb = await s.rig.image(W, H)
+			await s.rig.run(s.combine[2](placed, comb))
+			const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+			await s.rig.run(s.write(comb, [out], 0))
+			;[...placed, comb].forEach((x) => x.release())
+			seen.push(await s.consume(out))
+			out.release()
+		}
+		;[...srcs, ...u.flat()].forEach((x) => x.release())
+		return seen
+	}, { fused: 3, plain: 0, launched: 3, fallbacks: 0 })
+
+	// finished images only, one of them rotated: the tap-sharing compositor declines, the channel kernel takes them
+	await scenario('finished images, placed and rotated', async (s) => {
+		s.frame = 6
+		const warm = await s.source(v210Frame(full, 700)) // (a Loader recipe has been seen on this context)
+		const uw = await s.rig.image(W, H)
+		await s.rig.run(s.read([warm], uw))
+		const a = await s.image(rgbaFrame(W, H, 701, 0, 1))
+		const b = await s.image(rgbaFrame(W, H, 702, -0.1, 1.1))
+		const pa = await s.rig.image(W, H)
+		const pb = await s.rig.image(W, H)
+		await s.rig.run(s.transform(a, pa, await s.transform.matrix({ scaleX: 1.5, scaleY: 1.5 })))
+		await s.rig.run(s.transform(b, pb, await s.transform.matrix({ scaleX: 0.7, scaleY: 0.7, rotate: 0.125 })))
+		const comb = await s.rig.image(W, H)
+		await s.rig.run(s.combine[2]([pa, pb], comb))
+		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		await s.rig.run(s.write(comb, [out], 0))
+		const seen = [await s.consume(out)]
+		;[warm, uw, a, b, pa, pb, comb, out].forEach((x) => x.release())
+		return seen
+	}, { fused: 1, plain: 0, fallbacks: 1 })
 
 	process.stdout.write(JSON.stringify({ width: W, height: H, scenarios, problems }) + '\n')
 }
