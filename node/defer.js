@@ -54,6 +54,16 @@ class Deferral {
 		Object.defineProperty(buf, '_producer', { value: null, enumerable: false, writable: true })
 		Object.defineProperty(buf, '_held', { value: 0, enumerable: false, writable: true })
 	}
+	// two parameter buffers that hold the same bytes (every producer's Loader makes its own LUT and matrices: loadSave.ts:50-99);
+	// the host mirror is what hostAccess wrote, its digest is dropped when the buffer is written again (touch)
+	static same(a, b) {
+		if (a === b) return true
+		if (!a || !b || a.length !== b.length) return false
+		for (const x of [a, b])
+			if (!x._digest) Object.defineProperty(x, '_digest', { value: require('crypto').createHash('sha1').update(x).digest('hex'), enumerable: false, configurable: true, writable: true })
+		return a._digest === b._digest
+	}
+	static sameRecipe(r, q) { return Deferral.same(r.colMatrix, q.colMatrix) && Deferral.same(r.gammaLut, q.gammaLut) && Deferral.same(r.gamutMatrix, q.gamutMatrix) }
 	_hold(buf) { this.ctx._native.bufAddRef(buf._handle); buf._held++ }
 	_unhold(buf) { buf._held--; this.ctx._native.bufRelease(buf._handle) }
 	_appRefs(buf) { return this.ctx._native.bufRefCount(buf._handle) - buf._held }
@@ -120,6 +130,7 @@ class Deferral {
 		Deferral.adopt(buf)
 		if (dir === 'readonly') this.force(buf)
 		else {
+			if (buf._digest) buf._digest = null
 			this.beforeWrite(buf)
 			if (buf._producer) this.force(buf) // (a recorded result the host overwrites: run it rather than reason about partial writes)
 		}
@@ -221,7 +232,7 @@ class Deferral {
 			if (!p || p.state !== 'pending' || !Deferral._isV210(p.program, 'read') || !p.params.input) return null
 			const f = Deferral._frameOf(p)
 			if (f.width !== w || f.lines !== h || !img.imageDims || img.imageDims.width !== w || img.imageDims.height !== h) return null
-			if (reader.colMatrix !== p.params.colMatrix || reader.gammaLut !== p.params.gammaLut || reader.gamutMatrix !== p.params.gamutMatrix) return null
+			if (!Deferral.sameRecipe(reader, p.params)) return null
 			return p.params.input
 		}
 		for (let img of layerImages) {
@@ -250,7 +261,7 @@ class Deferral {
 		const groups = []
 		for (const e of found.values()) {
 			let g = groups.find((v) => v.length < 8 && v[0].w === e.w && v[0].h === e.h && v[0].tff === e.tff && v[0].skip === e.skip &&
-				v[0].reader.colMatrix === e.reader.colMatrix && v[0].reader.gammaLut === e.reader.gammaLut && v[0].reader.gamutMatrix === e.reader.gamutMatrix)
+				Deferral.sameRecipe(v[0].reader, e.reader))
 			if (!g) groups.push((g = []))
 			g.push(e)
 		}
@@ -308,7 +319,7 @@ class Deferral {
 				const f = Deferral._frameOf(p)
 				const ok = r.colMatrix && r.gammaLut && r.gamutMatrix && p.params.input && img.imageDims &&
 					f.width === img.imageDims.width && f.lines === img.imageDims.height && f.width % 6 === 0 &&
-					(!reader || (reader.colMatrix === r.colMatrix && reader.gammaLut === r.gammaLut && reader.gamutMatrix === r.gamutMatrix))
+					(!reader || Deferral.sameRecipe(reader, r))
 				if (ok) {
 					reader = reader || r
 					used.add(p)

@@ -69,7 +69,9 @@ function makeMock(mockOptions = {}) {
 				const b = params[k]
 				if (Buffer.isBuffer(b) && b._mapped) {
 					b._mapped = false
-					trace.push({ op: 'hostWrite', buf: b._mockId, bytes: b.length, sha: hash(b), allZero: b.every((x) => x === 0) })
+					const w = { op: 'hostWrite', buf: b._mockId, bytes: b.length, sha: hash(b), allZero: b.every((x) => x === 0) }
+					if (b.length <= 64) w.hex = b.toString('hex') // matrices (loadSave.ts:76-99 fills them through the mapped mirror)
+					trace.push(w)
 				}
 				p[k] = describe(params[k])
 				// small read-only operands (matrices, LUTs, flip vectors): pin their contents too

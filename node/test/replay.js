@@ -72,9 +72,11 @@ async function main() {
 				case 'hostWrite': {  // the reference filled a buffer it had mapped for writing (Buffer.copy into the mirror): do the same
 					const b = bufs.get(e.buf)
 					const file = path.join(dir, `${e.sha}.bin`)
-					const bytes = e.allZero ? Buffer.alloc(e.bytes) : fs.existsSync(file) ? fs.readFileSync(file) : null
+					// frames come from files, matrices are in the trace, tables are recognised among the library's own
+					const bytes = e.allZero ? Buffer.alloc(e.bytes) : fs.existsSync(file) ? fs.readFileSync(file) : e.hex ? Buffer.from(e.hex, 'hex') : luts.get(e.sha) || null
 					if (!bytes) throw new Error(`no data for the mapped write ${e.sha} (${e.bytes} bytes)`)
 					bytes.copy(b.buf)
+					b.content = e.sha
 					break
 				}
 				case 'createProgram': {

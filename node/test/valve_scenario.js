@@ -12,7 +12,12 @@
 //   layer 1: clip A full frame; frames 7..10: wipe to clip C through mask clip M (the mask is a Mixer output like any source)
 //   layer 2: clip B0 picture-in-picture; frames 2..5: dissolve into clip B1 (full frame); from frame 6: B1
 //   layer 3: nothing loaded (the Transitioner passes its black frame through)
-// usage: node valve_scenario.js <root>
+// With --v210 the ends of the path are the reference's too: every source frame is a v210 frame that goes through ToRGBA
+// (io.ts:61-118: createSources / loadFrame / createDest / processFrame, as ffmpegProducer.ts:501-538 calls them, one Loader
+// per producer) and every output frame through FromRGBA (io.ts:141-174: createDests / processFrame / saveFrame, as
+// macadamConsumer.ts:221-256 calls them) - the whole per-frame video path of a channel, v210 in, v210 out
+// (tests/golden/channel_trace.json).
+// usage: node valve_scenario.js <root> [--v210]
 const path = require('path')
 const { EventEmitter } = require('events')
 const { makeMock } = require('./mock_context')
@@ -24,6 +29,9 @@ const { Mixer } = req('producer/mixer.js')
 const { Transitioner } = req('transitioner.js')
 const { Combiner, CombineLayer } = req('combiner.js')
 const redio = require('./redioactive_mock.js')
+const V210 = process.argv.includes('--v210')
+const { ToRGBA, FromRGBA } = V210 ? req('process/io.js') : {}
+const v210 = V210 ? req('process/v210.js') : null
 
 const W = 192
 const H = 64
@@ -45,6 +53,21 @@ function clipFrame(seed, k) {
 	return Buffer.from(f.buffer)
 }
 const CLIPS = { A: 11, B0: 22, B1: 33, C: 44, M: 55 }
+// the same clip as v210: word i of the frame packs three legal-range codes taken from the hash of elements 3i .. 3i + 2
+function clipFrameV210(seed, k) {
+	const words = (Math.ceil(W / 48) * 128 * H) / 4
+	const b = Buffer.alloc(words * 4)
+	const s = (Math.imul(seed, 0x9E3779B1) ^ Math.imul(k + 1, 0x85EBCA6B)) >>> 0
+	const code = (i) => {
+		let h = Math.imul((i + 1) ^ s, 0x9E3779B1) >>> 0
+		h = (h ^ (h >>> 15)) >>> 0
+		h = Math.imul(h, 0x85EBCA6B) >>> 0
+		h = (h ^ (h >>> 13)) >>> 0
+		return 64 + (h >>> 8) % 877
+	}
+	for (let i = 0; i < words; ++i) b.writeUInt32LE((code(3 * i) | (code(3 * i + 1) << 10) | (code(3 * i + 2) << 20)) >>> 0, 4 * i)
+	return b
+}
 
 async function main() {
 	const ctx = makeMock({ recordMappedWrites: true })
@@ -56,8 +79,27 @@ async function main() {
 
 	// a producer's output: an f32 RGBA frame on the device, stamped like ffmpegProducer does; then its Mixer
 	const counters = {}
+	const loaders = {}
 	async function sourceFrame(clip) {
 		const k = counters[clip] = (counters[clip] === undefined ? 0 : counters[clip] + 1)
+		if (V210) { // ffmpegProducer.ts:501-538 vidLoader + vidProcess
+			const sourceID = `P${CLIPS[clip]} ${clip}`
+			if (!loaders[clip]) {
+				loaders[clip] = new ToRGBA(ctx, '709', '709', new v210.Reader(W, H), jobs)
+				await loaders[clip].init()
+			}
+			const convert = loaders[clip]
+			const ts = 1000 * CLIPS[clip] + k
+			const clSources = await convert.createSources(`${sourceID} ${ts}`)
+			clSources.forEach((s) => { s.timestamp = ts })
+			await convert.loadFrame(clipFrameV210(CLIPS[clip], k), clSources, ctx.queue.load)
+			await ctx.waitFinish(ctx.queue.load)
+			const clDest = await convert.createDest(dims, `${sourceID} ${clSources[0].timestamp}`)
+			clDest.timestamp = clSources[0].timestamp
+			convert.processFrame(sourceID, clSources, clDest)
+			note('source frame', { clip, k, buf: clDest._mockId })
+			return clDest
+		}
 		const buf = await ctx.createBuffer(W * H * 16, 'readwrite', 'coarse', dims, `P ${clip}`)
 		await buf.hostAccess('writeonly', ctx.queue.load, clipFrame(CLIPS[clip], k))
 		buf.timestamp = 1000 * CLIPS[clip] + k
@@ -76,8 +118,13 @@ async function main() {
 	for (const [clip, params] of [['A', null], ['B0', PIP], ['B1', null], ['C', null], ['M', null]]) await mixerOf(clip, params)
 	const mixed = async (clip) => {
 		const f = await sourceFrame(clip)
-		await ctx.waitFinish(ctx.queue.load)
+		if (!V210) await ctx.waitFinish(ctx.queue.load)
 		return mixers[clip].getVideoPipe().fn(f)
+	}
+	let fromRGBA = null
+	if (V210) {
+		fromRGBA = new FromRGBA(ctx, '709', new v210.Writer(W, H, false), jobs)
+		await fromRGBA.init()
 	}
 	const vid = (clip) => mixers[clip].getVideoPipe()
 
@@ -115,6 +162,17 @@ async function main() {
 		const zipped = await endValve([await black(combiner.videoPipe)].concat(outs))
 		const out = await combineValve(zipped)
 		note('output', { f, buf: out._mockId, timestamp: out.timestamp })
+		if (V210) { // macadamConsumer.ts:221-256 vidProcess + vidSaver (progressive format); the spout lets the frame go
+			const clDests = await fromRGBA.createDests(`chan1 ${out.timestamp}`)
+			clDests.forEach((d) => { d.timestamp = out.timestamp })
+			const ts = out.timestamp
+			fromRGBA.processFrame('chan1', out, clDests, 0)
+			await jobs.runQueue({ source: 'chan1', timestamp: ts })
+			await fromRGBA.saveFrame(clDests[0], ctx.queue.unload)
+			await ctx.waitFinish(ctx.queue.unload)
+			clDests.forEach((d) => d.release())
+			continue
+		}
 		await out.hostAccess('readonly', ctx.queue.unload)  // what a consumer's saveFrame does after FromRGBA; here the f32 frame itself
 		out.release()
 	}

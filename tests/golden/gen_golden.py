@@ -167,6 +167,13 @@ def main():
     with open(os.path.join(HERE, "valve_trace.json"), "w") as f:
         json.dump(json.loads(tr), f, indent=0, sort_keys=True)
         f.write("\n")
+    # the same schedule with the reference's ToRGBA in front (v210 sources, one Loader per producer) and its FromRGBA + saveFrame
+    # behind: the whole per-frame video path of a channel, v210 in, v210 out
+    tr = subprocess.run(["node", os.path.join(ROOT, "node", "test", "valve_scenario.js"),
+                         os.path.join(ROOT, "oracle", "_ref", "work", "js"), "--v210"], check=True, capture_output=True, text=True).stdout
+    with open(os.path.join(HERE, "channel_trace.json"), "w") as f:
+        json.dump(json.loads(tr), f, indent=0, sort_keys=True)
+        f.write("\n")
     # which pack format each `read` / `write` program of that trace belongs to, keyed by the fingerprint the
     # mock recorded of the kernel text (a hash, so the trace can be replayed where the text cannot go)
     shas = {}

@@ -491,15 +491,35 @@ def test_reference_valves_still_leave_the_golden_trace():
     assert [e["timestamp"] for e in trace if e["op"] == "note" and e["what"] == "output"] == list(range(11))  # combiner.ts:211
 
 
-def valve_oracle_frames(w, h):
-    """what the 11 output frames must be: the schedule of node/test/valve_scenario.js restated on the oracle's kernels"""
+def valve_clip_frame_v210(w, h, seed, k):
+    """node/test/valve_scenario.js clipFrameV210, restated: word i packs three legal-range codes from the hash of elements 3i .. 3i + 2"""
+    def imul(a, b):
+        return (np.asarray(a, np.uint64) * np.uint64(b)) & np.uint64(0xFFFFFFFF)
+    words = (w + 47) // 48 * 128 * h // 4
+    s = int(imul(seed, 0x9E3779B1)) ^ int(imul(k + 1, 0x85EBCA6B))
+    i = np.arange(1, 3 * words + 1, dtype=np.uint64)
+    x = imul(i ^ np.uint64(s), 0x9E3779B1)
+    x = x ^ (x >> np.uint64(15))
+    x = imul(x, 0x85EBCA6B)
+    x = x ^ (x >> np.uint64(13))
+    code = (np.uint64(64) + (x >> np.uint64(8)) % np.uint64(877)).reshape(words, 3)
+    return (code[:, 0] | (code[:, 1] << np.uint64(10)) | (code[:, 2] << np.uint64(20))).astype(np.uint32)
+
+
+def valve_oracle_frames(w, h, v210=False):
+    """what the 11 output frames must be: the schedule of node/test/valve_scenario.js restated on the oracle's kernels
+    (v210: the clips are v210 frames read 709 -> 709, the outputs packed v210 frames)"""
     orc = orc_mod()
     md, mp = mixer_matrix(w, h, VALVE_DEFAULT), mixer_matrix(w, h, VALVE_PIP)
     used = {c: 0 for c in VALVE_CLIPS}
+    rd = (orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "709"))
+    wr = (orc.rgb2ycbcr_matrix("709"), orc.linear2gamma_lut("709"))
 
     def mixed(clip, m):
         k = used[clip]
         used[clip] += 1
+        if v210:
+            return orc.transform(orc.v210_read(valve_clip_frame_v210(w, h, VALVE_CLIPS[clip], k), w, h, *rd), m, w, h)
         return orc.transform(valve_clip_frame(w, h, VALVE_CLIPS[clip], k), m, w, h)
     black = np.zeros((h, w, 4), np.float32)
     out = []
@@ -514,6 +534,8 @@ def valve_oracle_frames(w, h):
         else:
             l2 = mixed("B1", md)
         out.append(orc.combine([l1, l2, black]))
+    if v210:
+        return [np.asarray(orc.v210_write(o, w, h, 0, *wr)).reshape(-1) for o in out]
     return out
 
 
@@ -585,3 +607,55 @@ def test_recording_context_gives_the_same_frames_with_one_launch_per_frame():
         assert len(res["scenarios"]) >= 9 and all(s["frames"] >= 1 for s in res["scenarios"])
         first = res["scenarios"][0]["deferred"]
         assert first["recorded"] == 18 and first["launched"] == 3 and first["fused"] == 3, first
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The whole per-frame video path with the reference's code at BOTH ends: ToRGBA (one Loader per producer) -> Mixer ->
+# Transitioner -> Combiner -> FromRGBA -> saveFrame (node/test/valve_scenario.js --v210), v210 in, v210 out
+# ---------------------------------------------------------------------------------------------------------------------
+CHANNEL_TRACE = os.path.join(ROOT, "tests", "golden", "channel_trace.json")
+
+
+@needs_node
+@needs_ref_js
+def test_reference_channel_path_still_leaves_the_golden_trace():
+    out = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "valve_scenario.js"), REF_JS, "--v210"], check=True, capture_output=True, text=True).stdout
+    trace = json.loads(out)
+    assert trace == json.load(open(CHANNEL_TRACE))
+    names = [e["name"] for e in trace if e["op"] == "runProgram"]
+    assert names.count("read") == 34 and names.count("transform") == 34 and names.count("write") == 11 and names.count("combine_3") == 11
+
+
+@needs_node
+@pytest.mark.gpu
+@pytest.mark.parametrize("deferred", [False, True], ids=["launch_as_posted", "deferred"])
+def test_reference_channel_trace_replays_on_the_real_addon(tmp_path, deferred):
+    """The nodencl calls of the reference's complete video path (98 kernel jobs for 11 frames) on the real addon: reference
+    counts as recorded, nothing leaks, every packed output frame equals the oracle's chain.  Through the recording context
+    (PHANERON_DEFERRED=1) the same calls give the same frames with ONE launch per output frame: the Loaders of the five
+    producers are different buffers with the same contents, the third layer is the Transitioner's black frame."""
+    import hashlib
+    trace = json.load(open(CHANNEL_TRACE))
+    w, h = 192, 64
+    have = set()
+    for clip, seed in VALVE_CLIPS.items():
+        for k in range(11):
+            raw = valve_clip_frame_v210(w, h, seed, k).tobytes()
+            name = hashlib.sha256(raw).hexdigest()[:16]
+            have.add(name)
+            (tmp_path / (name + ".bin")).write_bytes(raw)
+    big = {e["src"]["sha"] for e in trace if e["op"] == "hostAccess" and e["src"] and e["src"]["bytes"] > 64}
+    assert big <= have, "the trace loads a frame this test cannot regenerate"
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "replay.js"), CHANNEL_TRACE, TEXT_SHA, str(tmp_path)],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, PHANERON_DEFERRED="1" if deferred else "0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads((tmp_path / "replay.json").read_text())
+    assert res["problems"] == [], res["problems"][:5]
+    assert len(res["dumps"]) == 11
+    want = valve_oracle_frames(w, h, v210=True)
+    for f, d in enumerate(res["dumps"]):
+        got = np.fromfile(tmp_path / d["file"], np.uint32)
+        assert np.array_equal(got, want[f]), "output frame %d" % f
+    if deferred:
+        d = res["deferred"]
+        assert d["recorded"] == 98 and d["fused"] == 11 and d["launched"] == 11 and d["plain"] == 0 and d["fallbacks"] == 0 and d["pending"] == 0, d
