@@ -87,6 +87,8 @@ export class clContext {
 	/** deferred contexts: run everything still recorded; returns the recording's counters (null on a plain context) */
 	flushDeferred(): DeferredStats | null
 	deferredStats(): DeferredStats | null
+	/** wait until everything launched so far on `queue` has finished (on a deferred context waitFinish(queue.process) returns at once) */
+	drain(queue?: number): Promise<void>
 	/** staging extension: later work on `waiter` starts after everything enqueued so far on `signal` */
 	queueWaitQueue(waiter: number, signal: number): void
 	/** staging extension */

@@ -141,6 +141,11 @@ class clContext {
 	async waitFinish(queue) {
 		const native = this._need()
 		const q = queue === undefined ? this.queue.process : queue
+		// A recording context has nothing to wait for on the queue its jobs are recorded for: what was asked of it has not been
+		// launched, and what has been launched (when a result was asked for) is ordered in front of whoever reads the result
+		// on the device (defer.js touch) - waiting here would only stall the host behind the previous frame's kernel.
+		// Uploads and downloads (the other queues) are waited for as ever.
+		if (this._deferral && q === this.queue.process && this.queue.process !== this.queue.load) return
 		if (this.spinWaitMicros > 0 && native.waitFinishSpin(this._ctx, q, this.spinWaitMicros)) return
 		return native.waitFinish(this._ctx, q)
 	}
@@ -152,6 +157,11 @@ class clContext {
 	}
 	// deferred contexts: make these buffers' contents real now, as a consumer on the device would need them (a no-op otherwise)
 	realise(...bufs) { if (this._deferral) for (const b of bufs) this._deferral.touch(b, 'readonly', this.queue.process) }
+	// deferred contexts: wait until everything launched so far on `queue` has finished (what waitFinish does on a plain context)
+	async drain(queue) {
+		const native = this._need()
+		return native.waitFinish(this._ctx, queue === undefined ? this.queue.process : queue)
+	}
 	deferredStats() { return this._deferral ? Object.assign({ pending: this._deferral.pending.size }, this._deferral.stats) : null }
 
 	// ---- staging extensions (not nodencl; SURVEY 8f-3, node/staging.js) -----------------------------

@@ -54,7 +54,7 @@ async function main() {
 				ids.push(c)
 				await Promise.all(ids.map((id) => rig.board.flush(id)))
 				rig.ctx.realise(o[0])
-				return f % ring.length === ring.length - 1 ? rig.sync() : undefined
+				return f % ring.length === ring.length - 1 ? rig.ctx.drain() : undefined
 			}
 			const ids = []
 			for (let l = 0; l < n; ++l) { const id = { source: `L${l}`, timestamp: f }; rig.post(id, read(src[l], rgba[l])); ids.push(id) }
@@ -67,7 +67,7 @@ async function main() {
 		for (let f = 0; f < 10; ++f) await one(f)
 		const t0 = process.hrtime.bigint()
 		for (let f = 0; f < frames; ++f) await one(10 + f)
-		await rig.sync()
+		await rig.ctx.drain()
 		const sec = Number(process.hrtime.bigint() - t0) / 1e9
 		console.log(JSON.stringify({ bench: 'node', mode, width: w, height: h, layers: n, frames, frames_per_sec: +(frames / sec).toFixed(1), us_per_frame: +(1e6 * sec / frames).toFixed(1), drains: rig.board.stats.drains, deferred: rig.ctx.deferredStats() || undefined }))
 		;[...src.flat(), ...rgba, comb, ...ring.flat()].forEach((b) => b.release())
