@@ -88,7 +88,7 @@ class Deferral {
 		for (const o of node.outs) {
 			for (const r of Array.from(o._readers)) if (r !== node) this._run(r)
 			const p = o._producer
-			if (p && whole && p.outs.length === 1) { this.stats.dropped++; this._retire(p, 'dropped') } // its result would be overwritten unseen
+			if (p && whole && p.outs.length === 1 && !node.ins.includes(o)) { this.stats.dropped++; this._retire(p, 'dropped') } // its result would be overwritten unseen
 			else if (p) this._run(p)
 			o._producer = node
 		}
@@ -194,7 +194,7 @@ class Deferral {
 		}
 	}
 	_plain(node) {
-		for (const i of node.ins) if (i._producer) this.force(i)
+		for (const i of node.ins) if (i._producer && i._producer !== node) this.force(i) // (an in-place job is its own operand's producer)
 		try {
 			this._launch(node.program, node.params, node.queue)
 		} finally {

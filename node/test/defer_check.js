@@ -1,0 +1,185 @@
+'use strict'
+// node/defer.js without a device: the recording's graph logic (what is launched, in which order, what is dropped, who
+// holds which buffer) against a stand-in for the addon that only counts.  Prints one JSON object { checks, problems }.
+const { Deferral } = require('../defer.js')
+
+const problems = []
+let checks = 0
+const expect = (what, got, want) => {
+	++checks
+	if (JSON.stringify(got) !== JSON.stringify(want)) problems.push({ what, got, want })
+}
+
+function rig() {
+	const launches = [] // [program name, queue]
+	const orders = [] // [waiter, signal]
+	let nextId = 1
+	const refs = new Map() // handle -> count (0 = freed)
+	const native = {
+		bufAddRef: (h) => { if (!refs.get(h)) throw new Error(`addRef on freed buffer ${h}`); refs.set(h, refs.get(h) + 1) },
+		bufRelease: (h) => { if (!refs.get(h)) throw new Error(`release on freed buffer ${h}`); refs.set(h, refs.get(h) - 1) },
+		bufRefCount: (h) => refs.get(h) || 0,
+		createProgram: (_ctx, _src, name) => ({ name }),
+		runProgram: (_ctx, prog, names, values, queue) => {
+			if (native.refuse && native.refuse(prog.name)) throw new Error(`${prog.name}: refused`)
+			for (const v of values) if (v && typeof v === 'object' && !refs.get(v)) throw new Error(`${prog.name} launched on a freed buffer`)
+			launches.push([prog.name, queue, names.join(',')])
+			return { dataToKernel: 0, kernelExec: 0, totalTime: 0 }
+		},
+		queueWaitQueue: (_ctx, waiter, signal) => orders.push([waiter, signal])
+	}
+	const ctx = { _native: native, _ctx: {}, queue: { load: 0, process: 1, unload: 2 } }
+	const d = new Deferral(ctx)
+	const buffer = (bytes, dims, owner) => {
+		const b = Buffer.alloc(bytes)
+		const h = { id: nextId++ }
+		refs.set(h, 1)
+		Object.defineProperty(b, '_handle', { value: h })
+		b.imageDims = dims
+		b.owner = owner || ''
+		b.release = () => { native.bufRelease(h); if (b._held) d.released(b) }
+		b.alive = () => refs.get(h) > 0
+		b.appRefs = () => refs.get(h) - (b._held || 0)
+		return b
+	}
+	const W = 96
+	const H = 4
+	const program = (name, extra) => Object.assign({ name, globalWorkItems: [W, H], workItemsPerGroup: 0, _handle: { name } }, extra || {})
+	const P = {
+		read: program('read', { format: 'v210', globalWorkItems: [2 * H], workItemsPerGroup: 2 }),
+		write: program('write', { format: 'v210', globalWorkItems: [2 * H], workItemsPerGroup: 2 }),
+		writeField: program('write', { format: 'v210', globalWorkItems: [H], workItemsPerGroup: 2 }),
+		transform: program('transform'), combine2: program('combine_2'), dissolve: program('transition_dissolve'), yadif: program('yadif'),
+		other: program('resize')
+	}
+	const param = (tag, bytes, fill) => { const b = buffer(bytes, undefined, tag); b.fill(fill); return b }
+	const loader = (fill = 1) => ({ colMatrix: param('cm', 48, fill), gammaLut: param('lut', 64, fill + 1), gamutMatrix: param('gm', 36, fill + 2) })
+	const saver = { colMatrix: param('wcm', 48, 7), gammaLut: param('wlut', 64, 8) }
+	const image = (owner) => buffer(W * H * 16, { width: W, height: H }, owner)
+	const v210 = (owner) => buffer(256 * H, undefined, owner)
+	return { d, native, launches, orders, buffer, image, v210, P, loader, saver, W, H, names: () => launches.map((l) => l[0]) }
+}
+
+// 1. read x2 -> combine_2 -> write: one fused launch, intermediates never made, everything let go when the owners release
+{
+	const r = rig()
+	const L = r.loader()
+	const src = [r.v210('s0'), r.v210('s1')]
+	const img = [r.image('u0'), r.image('u1')]
+	const comb = r.image('comb')
+	const out = r.v210('out')
+	src.forEach((s, i) => r.d.record(r.P.read, Object.assign({ input: s, output: img[i], width: r.W }, L), 1))
+	r.d.record(r.P.combine2, { l0In: img[0], l1In: img[1], output: comb }, 1)
+	r.d.record(r.P.write, Object.assign({ input: comb, output: out, width: r.W, interlace: 0 }, r.saver), 1)
+	src.forEach((s) => s.release()) // the read jobs' callbacks
+	img.forEach((s) => s.release()) // the combine job's callback
+	comb.release() // the write job's callback
+	expect('sources survive their owners while recorded', src.map((s) => s.alive()), [true, true])
+	expect('nothing launched before the frame is asked for', r.names(), [])
+	r.d.touch(out, 'readonly', 2)
+	expect('one fused launch', r.names(), ['fused_v210_combine_2'])
+	expect('the unload queue is ordered behind the process queue', r.orders, [[2, 1]])
+	expect('recording empty', r.d.pending.size, 0)
+	expect('sources and intermediates freed', [...src, ...img, comb].map((b) => b.alive()), [false, false, false, false, false])
+	expect('counters', [r.d.stats.recorded, r.d.stats.launched, r.d.stats.fused, r.d.stats.plain, r.d.stats.dropped], [4, 1, 1, 0, 3])
+}
+
+// 2. Loaders with equal contents are one recipe; a Loader with other contents makes its layer a finished image first
+{
+	const r = rig()
+	const out = r.v210('out')
+	const build = (loaders) => {
+		const img = loaders.map((L, i) => { const im = r.image(`u${i}`); r.d.record(r.P.read, Object.assign({ input: r.v210(`s${i}`), output: im, width: r.W }, L), 1); return im })
+		const comb = r.image('comb')
+		r.d.record(r.P.combine2, { l0In: img[0], l1In: img[1], output: comb }, 1)
+		r.d.record(r.P.write, Object.assign({ input: comb, output: out, width: r.W, interlace: 0 }, r.saver), 1)
+	}
+	build([r.loader(1), r.loader(1)])
+	r.d.touch(out, 'readonly', 2)
+	expect('equal Loader contents: one fused launch', r.names(), ['fused_v210_combine_2'])
+	build([r.loader(1), r.loader(5)])
+	r.d.touch(out, 'readonly', 2)
+	expect('another Loader: its layer is unpacked as recorded, the rest goes to the channel kernel', r.names().slice(1), ['read', 'chan_compose_v210_2'])
+}
+
+// 3. hazards: a source overwritten while recorded; a destination reused for the next frame; a field write over a field write
+{
+	const r = rig()
+	const L = r.loader()
+	const s = r.v210('s')
+	const u = r.image('u')
+	const out = r.v210('out')
+	r.d.record(r.P.read, Object.assign({ input: s, output: u, width: r.W }, L), 1)
+	r.d.record(r.P.write, Object.assign({ input: u, output: out, width: r.W, interlace: 0 }, r.saver), 1)
+	r.d.touch(s, 'writeonly', 0) // the next frame into the same source buffer
+	expect('the reader of an overwritten source runs first, as recorded', r.names(), ['read'])
+	expect('the upload is ordered behind it', r.orders, [[0, 1]])
+	r.d.touch(out, 'readonly', 2)
+	expect('then the write has only a finished image in front of it: as recorded', r.names(), ['read', 'write'])
+
+	const r2 = rig()
+	const u2 = r2.image('u')
+	const L2 = r2.loader()
+	for (let f = 0; f < 3; ++f) r2.d.record(r2.P.read, Object.assign({ input: r2.v210(`s${f}`), output: u2, width: r2.W }, L2), 1)
+	expect('a result overwritten unseen is dropped, not run', [r2.names(), r2.d.stats.dropped, r2.d.pending.size], [[], 2, 1])
+
+	const r3 = rig()
+	const out3 = r3.v210('out')
+	const L3 = r3.loader()
+	for (const field of [1, 3]) {
+		const im = r3.image(`u${field}`)
+		r3.d.record(r3.P.read, Object.assign({ input: r3.v210(`s${field}`), output: im, width: r3.W }, L3), 1)
+		r3.d.record(r3.P.writeField, Object.assign({ input: im, output: out3, width: r3.W, interlace: field }, r3.saver), 1)
+	}
+	expect('the first field is made when the second is posted (it fills every other line of the same frame)', r3.names(), ['chan_compose_v210_1'])
+	r3.d.touch(out3, 'readonly', 2)
+	expect('then the second', r3.names(), ['chan_compose_v210_1', 'chan_compose_v210_1'])
+}
+
+// 4. an intermediate somebody holds is made when asked for; an in-place job keeps its operand's producer
+{
+	const r = rig()
+	const L = r.loader()
+	const u = r.image('u')
+	const t = r.image('t')
+	const m = r.buffer(48, undefined, 'matrix')
+	const out = r.v210('out')
+	r.d.record(r.P.read, Object.assign({ input: r.v210('s'), output: u, width: r.W }, L), 1)
+	r.d.record(r.P.transform, { input: u, transformMatrix: m, output: t }, 1)
+	r.d.record(r.P.write, Object.assign({ input: t, output: out, width: r.W, interlace: 0 }, r.saver), 1)
+	r.d.touch(out, 'readonly', 2)
+	expect('fused frame', r.names(), ['chan_compose_v210_1'])
+	expect('the images in between stay recipes while their owner holds them', r.d.pending.size, 2)
+	r.d.touch(t, 'readonly', 2)
+	expect('asked for after all: producers first', r.names(), ['chan_compose_v210_1', 'read', 'transform'])
+	r.d.record(r.P.other, { input: t, output: t }, 1)
+	r.d.record(r.P.other, { input: t, output: t }, 1)
+	r.d.touch(t, 'readonly', 2)
+	expect('in-place jobs run in order', r.names().slice(3), ['resize', 'resize'])
+}
+
+// 5. both fields of a de-interlaced layer: one pair launch; a refused fused launch falls back to the recorded jobs
+{
+	const r = rig()
+	const L = r.loader()
+	const win = [0, 1, 2].map((i) => { const im = r.image(`w${i}`); r.d.record(r.P.read, Object.assign({ input: r.v210(`s${i}`), output: im, width: r.W }, L), 1); return im })
+	const m = r.buffer(48, undefined, 'matrix')
+	const outs = []
+	for (const parity of [0, 1]) {
+		const y = r.image(`y${parity}`)
+		r.d.record(r.P.yadif, { prev: win[0], cur: win[1], next: win[2], parity, tff: 1, skipSpatial: 0, output: y }, 1)
+		const t = r.image(`t${parity}`)
+		r.d.record(r.P.transform, { input: y, transformMatrix: m, output: t }, 1)
+		const out = r.v210(`out${parity}`)
+		r.d.record(r.P.write, Object.assign({ input: t, output: out, width: r.W, interlace: 0 }, r.saver), 1)
+		outs.push(out)
+	}
+	r.d.touch(outs[0], 'readonly', 2)
+	expect('pair launch, then the tap-sharing compositor for the finished image', r.names(), ['v210_yadif_pair_1', 'compose_up_write_v210_1'])
+	r.native.refuse = (name) => name !== 'write' && name !== 'transform'
+	r.d.touch(outs[1], 'readonly', 2)
+	expect('refused fused launches: the jobs as recorded', r.names().slice(2), ['transform', 'write'])
+	expect('fallbacks counted', r.d.stats.fallbacks, 2)
+}
+
+process.stdout.write(JSON.stringify({ checks, problems }) + '\n')

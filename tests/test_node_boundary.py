@@ -659,3 +659,14 @@ def test_reference_channel_trace_replays_on_the_real_addon(tmp_path, deferred):
     if deferred:
         d = res["deferred"]
         assert d["recorded"] == 98 and d["fused"] == 11 and d["launched"] == 11 and d["plain"] == 0 and d["fallbacks"] == 0 and d["pending"] == 0, d
+
+
+@needs_node
+def test_recording_graph_logic_without_a_device():
+    """node/defer.js against a counting stand-in for the addon (node/test/defer_check.js): what is launched and in which order,
+    what is dropped, who keeps which buffer alive, hazards (a source overwritten while recorded, a destination reused, field
+    writes, in-place jobs), Loaders matched by content, refused fused launches falling back to the recorded jobs"""
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "defer_check.js")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads(r.stdout)
+    assert res["problems"] == [] and res["checks"] >= 22, res["problems"]
