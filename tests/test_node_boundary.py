@@ -346,7 +346,8 @@ def orc_mod():
 
 @needs_node
 @pytest.mark.gpu
-def test_channel_compositor_on_gpu(tmp_path):
+@pytest.mark.parametrize("deferred", [False, True], ids=["launch_as_posted", "deferred"])
+def test_channel_compositor_on_gpu(tmp_path, deferred):
     """node/channel.js on the real addon - a full-frame layer, a PiP layer that dissolves into another clip, an
     empty layer: every output frame equals the oracle's chain for that frame under the reference's valve rules
     (mixer.ts:209-223, transitioner.ts:143-176, combiner.ts:211-254), and no buffer leaks."""
@@ -363,7 +364,7 @@ def test_channel_compositor_on_gpu(tmp_path):
     job = dict(width=w, height=h, frames=nf, pip=pip, dissolveAt=2, dissolveLen=4, cutAt=6)
     (tmp_path / "job.json").write_text(json.dumps(job))
     r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "channel_run.js"), str(tmp_path)], capture_output=True,
-                       text=True, timeout=300)
+                       text=True, timeout=300, env=dict(os.environ, PHANERON_DEFERRED="1" if deferred else "0"))
     assert r.returncode == 0, r.stdout + r.stderr
     res = json.loads((tmp_path / "result.json").read_text())
     assert res["stamps"] == list(range(nf))     # the combiner renumbers its output 0, 1, 2 ...
@@ -404,7 +405,8 @@ def amcp_noise(nbytes, seed, k):
 
 @needs_node
 @pytest.mark.gpu
-def test_control_plane_smoke_on_gpu(tmp_path):
+@pytest.mark.parametrize("deferred", [False, True], ids=["launch_as_posted", "deferred"])
+def test_control_plane_smoke_on_gpu(tmp_path, deferred):
     """AMCP command lines (PLAY / LOADBG ... MIX / MIXER FILL / ROTATION / STOP / CLEAR) drive a channel of
     synthetic v210 sources on the real addon; every output frame equals the oracle chain read -> place -> dissolve ->
     combine -> write for the state the commands left, responses have the server's shape, nothing leaks."""
@@ -416,7 +418,9 @@ def test_control_plane_smoke_on_gpu(tmp_path):
               "STOP 1-10", dict(tick=1), "CLEAR 1", dict(tick=1),
               "SWAP 1-10 1-20", "PLAY 9-1 NOISE:1", "PLAY 1-30 NOFILE", "MIXER 1-10 FILL 1 2"]
     (tmp_path / "job.json").write_text(json.dumps(dict(width=w, height=h, readSpec="709", writeSpec="2020", script=script)))
-    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "amcp_run.js"), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    # (deferred: the same script on a recording context - every frame it packs must still be the oracle's)
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "amcp_run.js"), str(tmp_path)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PHANERON_DEFERRED="1" if deferred else "0"))
     assert r.returncode == 0, r.stdout + r.stderr
     res = json.loads((tmp_path / "result.json").read_text())
     assert res["responses"] == ["202 PLAY OK", "202 PLAY OK", "202 MIXER OK", "202 LOADBG OK", "202 PLAY OK", "202 MIXER OK",
