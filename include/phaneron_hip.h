@@ -204,6 +204,11 @@ typedef struct ph_run_timings {
  * returns after the kernel has finished (hipEvent pair on the queue's stream). */
 int ph_run_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args, int queue,
                    ph_run_timings *timings);
+/* Everything ph_run_program checks before it launches - argument names and kinds, buffer sizes against the frame geometry,
+ * image-ness - with nothing enqueued and no buffer touched: the same return codes and ph_last_error() texts.  For a binding
+ * that records jobs and launches them later (node/defer.js): a bad job is reported where the reference posts it
+ * (clJobQueue.ts:126 awaits runProgram), not where it is finally run. */
+int ph_check_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args, int queue);
 
 /* ---- typed entry points: the same kernels on raw device pointers, launched on `queue`.
  *      Images are row-major float RGBA (16 B/pixel); v210 is LE 32-bit words with line pitch

@@ -29,9 +29,9 @@
 //     the recipe is dropped and its own operands are let go - the v210 source of a frame is recycled as soon as the
 //     last thing that could still need it is gone.
 //
-// What changes for the caller: RunTimings of a deferred job are zeros, and an argument error of a recorded job
-// surfaces where the job is forced (as a rejected hostAccess) instead of at runProgram.  Own design; nothing of
-// this exists in the reference, whose OpenCL queue runs every job as posted.
+// What changes for the caller: RunTimings of a deferred job are zeros.  A job's arguments are checked when it is recorded
+// (ph_check_program: the checks of a launch without the launch), so a bad job is refused by runProgram as on a plain
+// context.  Own design; nothing of this exists in the reference, whose OpenCL queue runs every job as posted.
 
 const OUTPUT_ARG = /^(output|l\d+Out)/
 const ZERO_TIMINGS = () => ({ dataToKernel: 0, kernelExec: 0, totalTime: 0 })
@@ -79,6 +79,9 @@ class Deferral {
 			Deferral.adopt(v)
 			if (OUTPUT_ARG.test(name)) outs.add(v); else ins.add(v)
 		}
+		// what runProgram would refuse - a missing argument, a buffer too small for the frame - is refused here, with the same
+		// message, where the reference awaits it (clJobQueue.ts:126); nothing is enqueued (ph_check_program)
+		this._launch(program, params, queue, true)
 		const node = { program, params: Object.assign({}, params), queue, ins: Array.from(ins), outs: Array.from(outs), state: 'pending' }
 		for (const b of new Set([...ins, ...outs])) this._hold(b)
 		for (const i of node.ins) i._readers.add(node)
@@ -162,7 +165,7 @@ class Deferral {
 		if (!this._fused(node)) this._plain(node)
 	}
 
-	_launch(program, params, queue) {
+	_launch(program, params, queue, checkOnly = false) {
 		const names = []
 		const values = []
 		for (const name of Object.keys(params)) {
@@ -171,6 +174,7 @@ class Deferral {
 			names.push(name)
 			values.push(Buffer.isBuffer(v) ? v._handle : typeof v === 'boolean' ? (v ? 1 : 0) : v)
 		}
+		if (checkOnly) return this.ctx._native.runProgram(this.ctx._ctx, program._handle, names, values, queue, false, true)
 		this.stats.launched++
 		this.launchedOn.set(queue, (this.launchedOn.get(queue) || 0) + 1)
 		return this.ctx._native.runProgram(this.ctx._ctx, program._handle, names, values, queue, false)

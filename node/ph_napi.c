@@ -468,7 +468,7 @@ static napi_value CreateProgram(napi_env env, napi_callback_info info) {
   return out;
 }
 
-/* runProgram(ctx, prog, names[], values[], queue, timed) -> RunTimings | Promise<RunTimings>
+/* runProgram(ctx, prog, names[], values[], queue, timed[, checkOnly]) -> RunTimings | Promise<RunTimings>
  * values[i] is a buffer handle (external) or a number; float-valued kernel arguments are the
  * ones named in FLOAT_ARGS and any value that is not a whole number (per-layer arguments such as l<i>Mix of
  * chan_compose_v210_<n>); everything else numeric is passed as a 32-bit integer.  The library reads a
@@ -476,16 +476,17 @@ static napi_value CreateProgram(napi_env env, napi_callback_info info) {
 static const char *FLOAT_ARGS[] = {"scale", "offsetX", "offsetY", "mix", "wipe", NULL};
 
 static napi_value RunProgram(napi_env env, napi_callback_info info) {
-  size_t argc = 6;
-  napi_value argv[6];
+  size_t argc = 7;
+  napi_value argv[7];
   ctx_box *c;
   prog_box *p;
   uint32_t n = 0;
   int32_t q = PH_QUEUE_PROCESS;
-  bool timed = false;
+  bool timed = false, check_only = false; /* check_only: ph_check_program - the job's arguments are examined, nothing is launched */
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   if (argc < 4 || !get_box(env, argv[0], (void **)&c) || !get_box(env, argv[1], (void **)&p))
     return throw_ph(env, "runProgram: bad context/program");
+  if (argc > 6) napi_get_value_bool(env, argv[6], &check_only);
   napi_get_array_length(env, argv[2], &n);
   if (argc > 4) get_i32(env, argv[4], &q);
   if (argc > 5) napi_get_value_bool(env, argv[5], &timed);
@@ -521,7 +522,7 @@ static napi_value RunProgram(napi_env env, napi_callback_info info) {
         args[i].kind = PH_ARG_I32, args[i].v.i32 = (int32_t)d;
     }
   }
-  if (timed) {
+  if (timed && !check_only) {
     job *j = (job *)calloc(1, sizeof *j);
     j->kind = JOB_RUN_TIMED, j->ctx = c->ctx, j->prog = p->prog, j->args = args, j->names = names;
     j->n_args = (int)n, j->queue = q;
@@ -532,7 +533,7 @@ static napi_value RunProgram(napi_env env, napi_callback_info info) {
       if (args[i].kind == PH_ARG_BUF) ph_buf_addref(j->held[j->n_held++] = args[i].v.buf);
     return start_job(env, j, "phaneron.runProgram");
   }
-  int rc = ph_run_program(c->ctx, p->prog, args, (int)n, q, NULL);
+  int rc = check_only ? ph_check_program(c->ctx, p->prog, args, (int)n, q) : ph_run_program(c->ctx, p->prog, args, (int)n, q, NULL);
   free(args), free(names);
   if (rc != PH_OK) return throw_ph(env, "runProgram");
   ph_run_timings zero = {0, 0, 0};

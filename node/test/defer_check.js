@@ -20,7 +20,8 @@ function rig() {
 		bufRelease: (h) => { if (!refs.get(h)) throw new Error(`release on freed buffer ${h}`); refs.set(h, refs.get(h) - 1) },
 		bufRefCount: (h) => refs.get(h) || 0,
 		createProgram: (_ctx, _src, name) => ({ name }),
-		runProgram: (_ctx, prog, names, values, queue) => {
+		runProgram: (_ctx, prog, names, values, queue, _timed, checkOnly) => {
+			if (checkOnly) return null
 			if (native.refuse && native.refuse(prog.name)) throw new Error(`${prog.name}: refused`)
 			for (const v of values) if (v && typeof v === 'object' && !refs.get(v)) throw new Error(`${prog.name} launched on a freed buffer`)
 			launches.push([prog.name, queue, names.join(',')])

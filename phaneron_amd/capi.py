@@ -22,7 +22,7 @@ EXPORTS = [
     "ph_abi_version", "ph_last_error", "ph_ctx_create", "ph_ctx_destroy", "ph_ctx_info", "ph_ctx_stream",
     "ph_wait_finish", "ph_buf_create", "ph_buf_wrap", "ph_buf_addref", "ph_buf_release", "ph_buf_refcount",
     "ph_buf_bytes", "ph_buf_device_ptr", "ph_buf_dims", "ph_buf_host_access", "ph_buf_host_ptr",
-    "ph_ctx_buffer_stats", "ph_program_create", "ph_program_destroy", "ph_program_kernel", "ph_run_program",
+    "ph_ctx_buffer_stats", "ph_program_create", "ph_program_destroy", "ph_program_kernel", "ph_run_program", "ph_check_program",
     "ph_v210_pitch_bytes", "ph_v210_read", "ph_v210_read_batch", "ph_v210_write", "ph_yadif", "ph_yadif_pair", "ph_v210_yadif_pair", "ph_transform", "ph_resize", "ph_combine",
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
@@ -148,6 +148,7 @@ def lib():
         "ph_program_destroy": (ci, [vp]),
         "ph_program_kernel": (C.c_char_p, [vp]),
         "ph_run_program": (ci, [vp, vp, C.POINTER(PhArg), ci, ci, C.POINTER(RunTimings)]),
+        "ph_check_program": (ci, [vp, vp, C.POINTER(PhArg), ci, ci]),
         "ph_v210_pitch_bytes": (cu, [cu]),
         "ph_v210_read": (ci, [vp, ci, vp, vp, cu, cu, vp, vp, vp]),
         "ph_v210_read_batch": (ci, [vp, ci, ci, vp, vp, cu, cu, vp, vp, vp]),
@@ -538,9 +539,10 @@ class Context:
         """`clContext.createProgram(kernelSrc, {name, globalWorkItems, workItemsPerGroup})`"""
         return Program(self, source, name, global_work_items, work_items_per_group)
 
-    def run_program(self, program, params, queue=QUEUE_PROCESS):
+    def run_program(self, program, params, queue=QUEUE_PROCESS, check_only=False):
         """`clContext.runProgram(program, params, queue)`: params maps kernel argument NAMES to a
-        Buffer, an int or a float (floats must be Python floats).  Returns the RunTimings in us."""
+        Buffer, an int or a float (floats must be Python floats).  Returns the RunTimings in us.
+        check_only: examine the job as a launch would and enqueue nothing (ph_check_program)."""
         n = len(params)
         arr = (PhArg * n)()
         keep = []
@@ -561,6 +563,9 @@ class Context:
                 arr[i].kind, arr[i].v.f32 = ARG_F32, v
             else:
                 raise TypeError("kernel parameter %r: unsupported value %r" % (k, type(v)))
+        if check_only:  # ph_check_program: the checks of a launch, nothing enqueued
+            check(lib().ph_check_program(self.h, program.h, arr, n, queue), self.h)
+            return None
         t = RunTimings()
         check(lib().ph_run_program(self.h, program.h, arr, n, queue, C.byref(t)), self.h)
         return {"dataToKernel": t.data_to_kernel, "kernelExec": t.kernel_exec, "totalTime": t.total_time}

@@ -949,7 +949,9 @@ static int flush_dirty_args(ph_ctx *ctx, const ph_arg *args, int n, int queue) {
   return PH_OK;
 }
 
-static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue) {
+// check_only: everything up to the launch - argument names, kinds, buffer sizes, geometry - and nothing on the device
+// (ph_check_program: a recording binding reports a bad job where it is posted, not where it is run)
+static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue, bool check_only = false) {
   ph_buf *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr, *o = nullptr;
   double num = 0;
   int rc, w, h;
@@ -983,12 +985,12 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, rd ? "output" : "input", (size_t)width * height * 16, &o));
       if (!rgb) TRY(need_buf(args, n, "colMatrix", 48, &b));
       TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
-      refresh_buf_lut(ctx, c);
+      if (!check_only) refresh_buf_lut(ctx, c);
       if (rd) {
         TRY(need_buf(args, n, "gamutMatrix", 36, &d));
-        return ph_pack_read(ctx, queue, fmt, planes, o->dptr, width, height, rgb ? nullptr : b->dptr, c->dptr, d->dptr);
+        return check_only ? PH_OK : ph_pack_read(ctx, queue, fmt, planes, o->dptr, width, height, rgb ? nullptr : b->dptr, c->dptr, d->dptr);
       }
-      return ph_pack_write(ctx, queue, fmt, o->dptr, const_cast<void *const *>(planes), width, height, interlace,
+      return check_only ? PH_OK : ph_pack_write(ctx, queue, fmt, o->dptr, const_cast<void *const *>(planes), width, height, interlace,
                            rgb ? nullptr : b->dptr, c->dptr);
     }
     case K_V210_READ: {
@@ -1001,8 +1003,8 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "colMatrix", 48, &b));
       TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
       TRY(need_buf(args, n, "gamutMatrix", 36, &d));
-      refresh_buf_lut(ctx, c);
-      return ph_v210_read(ctx, queue, a->dptr, o->dptr, width, height, b->dptr, c->dptr, d->dptr);
+      if (!check_only) refresh_buf_lut(ctx, c);
+      return check_only ? PH_OK : ph_v210_read(ctx, queue, a->dptr, o->dptr, width, height, b->dptr, c->dptr, d->dptr);
     }
     case K_V210_WRITE: {
       double il = 0;
@@ -1016,8 +1018,8 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "output", (size_t)ph_v210_pitch_bytes(width) * height, &o));
       TRY(need_buf(args, n, "colMatrix", 48, &b));
       TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
-      refresh_buf_lut(ctx, c);
-      return ph_v210_write(ctx, queue, a->dptr, o->dptr, width, height, interlace, b->dptr, c->dptr);
+      if (!check_only) refresh_buf_lut(ctx, c);
+      return check_only ? PH_OK : ph_v210_write(ctx, queue, a->dptr, o->dptr, width, height, interlace, b->dptr, c->dptr);
     }
     case K_YADIF: {
       double parity, tff, skip;
@@ -1030,7 +1032,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_num(args, n, "parity", &parity));
       TRY(need_num(args, n, "tff", &tff));
       TRY(need_num(args, n, "skipSpatial", &skip));
-      return ph_yadif(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, (int)parity, (int)tff, (int)skip, o->dptr);
+      return check_only ? PH_OK : ph_yadif(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, (int)parity, (int)tff, (int)skip, o->dptr);
     }
     case K_YADIF_PAIR: {  // output0 / output1: what 'yadif' writes with parity 0 / 1
       double tff, skip;
@@ -1044,7 +1046,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "next", img, &c));
       TRY(need_num(args, n, "tff", &tff));
       TRY(need_num(args, n, "skipSpatial", &skip));
-      return ph_yadif_pair(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, (int)tff, (int)skip, o->dptr, o1->dptr);
+      return check_only ? PH_OK : ph_yadif_pair(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, (int)tff, (int)skip, o->dptr, o1->dptr);
     }
     case K_V210_YADIF_PAIR: {
       // l<i>Prev / l<i>Cur / l<i>Next: v210 window; l<i>Out0 / l<i>Out1: RGBA; colMatrix / gammaLut / gamutMatrix: the Loader's
@@ -1078,8 +1080,8 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "gamutMatrix", 36, &d));
       TRY(need_num(args, n, "tff", &tff));
       TRY(need_num(args, n, "skipSpatial", &skip));
-      refresh_buf_lut(ctx, c);
-      return ph_v210_yadif_pair_fmt(ctx, queue, prog->n_layers, src, width, height, (int)tff, (int)skip, rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32,
+      if (!check_only) refresh_buf_lut(ctx, c);
+      return check_only ? PH_OK : ph_v210_yadif_pair_fmt(ctx, queue, prog->n_layers, src, width, height, (int)tff, (int)skip, rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32,
                                     b->dptr, c->dptr, d->dptr);
     }
     case K_CHAN_COMPOSE: {
@@ -1141,9 +1143,9 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
       TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
       if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
-      refresh_buf_lut(ctx, c);
-      refresh_buf_lut(ctx, wl);
-      return ph_chan_compose_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, b->dptr, c->dptr, d->dptr,
+      if (!check_only) refresh_buf_lut(ctx, c);
+      if (!check_only) refresh_buf_lut(ctx, wl);
+      return check_only ? PH_OK : ph_chan_compose_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, b->dptr, c->dptr, d->dptr,
                                   wcm->dptr, wl->dptr);
     }
     case K_COMPOSE_UP: {
@@ -1182,8 +1184,8 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
       TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
       if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
-      refresh_buf_lut(ctx, wl);
-      return ph_compose_up_write_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
+      if (!check_only) refresh_buf_lut(ctx, wl);
+      return check_only ? PH_OK : ph_compose_up_write_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
     }
     case K_COMPOSE_V210: {
       // l<i>In: RGBA image; l<i>Matrix (optional): its 3x3 placement, absent = taken 1:1; l<i>WipeIn + l<i>WipeMask (optional):
@@ -1223,11 +1225,11 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
       TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
       if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
-      refresh_buf_lut(ctx, wl);
+      if (!check_only) refresh_buf_lut(ctx, wl);
       if (any_wipe)
-        return ph_compose_wipe_write_v210(ctx, queue, prog->n_layers, layers, wipes, o->dptr, width, height, (uint32_t)interlace,
+        return check_only ? PH_OK : ph_compose_wipe_write_v210(ctx, queue, prog->n_layers, layers, wipes, o->dptr, width, height, (uint32_t)interlace,
                                           wcm->dptr, wl->dptr);
-      return ph_compose_write_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
+      return check_only ? PH_OK : ph_compose_write_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
     }
     case K_V210_READ_BATCH: {  // l<i>In: v210 frames; l<i>Out: RGBA images; colMatrix / gammaLut / gamutMatrix: the Loader's
       const uint32_t width = prog->global[0], height = prog->global[1];
@@ -1248,8 +1250,8 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "colMatrix", 48, &b));
       TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
       TRY(need_buf(args, n, "gamutMatrix", 36, &d));
-      refresh_buf_lut(ctx, c);
-      return ph_v210_read_batch(ctx, queue, prog->n_layers, ins, outs, width, height, b->dptr, c->dptr, d->dptr);
+      if (!check_only) refresh_buf_lut(ctx, c);
+      return check_only ? PH_OK : ph_v210_read_batch(ctx, queue, prog->n_layers, ins, outs, width, height, b->dptr, c->dptr, d->dptr);
     }
     case K_TRANSFORM: {
       int iw, ih;
@@ -1258,7 +1260,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "output", 0, &o));
       TRY(need_image(o, "output", &w, &h));
       TRY(need_buf(args, n, "transformMatrix", 32, &b));
-      return ph_transform(ctx, queue, a->dptr, iw, ih, b->dptr, o->dptr, w, h);
+      return check_only ? PH_OK : ph_transform(ctx, queue, a->dptr, iw, ih, b->dptr, o->dptr, w, h);
     }
     case K_RESIZE: {
       int iw, ih;
@@ -1271,7 +1273,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_num(args, n, "scale", &scale));
       TRY(need_num(args, n, "offsetX", &ox));
       TRY(need_num(args, n, "offsetY", &oy));
-      return ph_resize(ctx, queue, a->dptr, iw, ih, (float)scale, (float)ox, (float)oy, b->dptr, o->dptr, w, h);
+      return check_only ? PH_OK : ph_resize(ctx, queue, a->dptr, iw, ih, (float)scale, (float)ox, (float)oy, b->dptr, o->dptr, w, h);
     }
     case K_COMBINE: {
       const void *layers[ph::kMaxLayers];
@@ -1283,7 +1285,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
         TRY(need_buf(args, n, nm, (size_t)w * h * 16, &a));
         layers[i] = a->dptr;
       }
-      return ph_combine(ctx, queue, prog->n_layers, layers, w, h, o->dptr);
+      return check_only ? PH_OK : ph_combine(ctx, queue, prog->n_layers, layers, w, h, o->dptr);
     }
     case K_FUSED_V210: {
       // l<i>In: v210 sources; colMatrix / gammaLut / gamutMatrix: the Loader's; outColMatrix / outGammaLut: the Saver's
@@ -1304,9 +1306,9 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "gamutMatrix", 36, &d));
       TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
       TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
-      refresh_buf_lut(ctx, c);
-      refresh_buf_lut(ctx, wl);
-      return ph_fused_v210_combine(ctx, queue, prog->n_layers, layers, o->dptr, width, height, b->dptr, c->dptr, d->dptr,
+      if (!check_only) refresh_buf_lut(ctx, c);
+      if (!check_only) refresh_buf_lut(ctx, wl);
+      return check_only ? PH_OK : ph_fused_v210_combine(ctx, queue, prog->n_layers, layers, o->dptr, width, height, b->dptr, c->dptr, d->dptr,
                                    wcm->dptr, wl->dptr);
     }
     case K_DISSOLVE:
@@ -1317,9 +1319,9 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "input0", (size_t)w * h * 16, &a));
       TRY(need_buf(args, n, "input1", (size_t)w * h * 16, &b));
       TRY(need_num(args, n, prog->id == K_WIPE ? "wipe" : "mix", &num));
-      if (prog->id == K_WIPE) return ph_wipe(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
-      if (prog->id == K_MIXER) return ph_mixer(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
-      return ph_transition_dissolve(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
+      if (prog->id == K_WIPE) return check_only ? PH_OK : ph_wipe(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
+      if (prog->id == K_MIXER) return check_only ? PH_OK : ph_mixer(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
+      return check_only ? PH_OK : ph_transition_dissolve(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
     }
     case K_TWIPE: {
       TRY(need_buf(args, n, "output", 0, &o));
@@ -1327,7 +1329,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "input0", (size_t)w * h * 16, &a));
       TRY(need_buf(args, n, "input1", (size_t)w * h * 16, &b));
       TRY(need_buf(args, n, "maskIn", (size_t)w * h * 16, &c));
-      return ph_transition_wipe(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, o->dptr);
+      return check_only ? PH_OK : ph_transition_wipe(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, o->dptr);
     }
   }
 #undef TRY
@@ -1367,6 +1369,12 @@ int ph_run_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args
   t->kernel_exec = (uint32_t)(ms * 1000.0f + 0.5f);
   t->total_time = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
   return PH_OK;
+}
+
+int ph_check_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args, int queue) {
+  if (!ctx || !prog || (n_args > 0 && !args)) return fail(PH_E_INVALID, "ph_check_program: NULL argument");
+  PH_QUEUE("ph_check_program", queue);
+  return dispatch(ctx, prog, args, n_args, queue, true);
 }
 
 // ---- typed entry points ------------------------------------------------------------------------

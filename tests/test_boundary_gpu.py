@@ -109,6 +109,16 @@ def test_run_program_by_argument_name_matches_oracle(ctx):
     assert np.array_equal(rgba.host(np.uint32), want_rgba.reshape(-1).view(np.uint32))
     vout.host_access("readonly", capi.QUEUE_UNLOAD)
     assert np.array_equal(vout.host(np.uint32), orc.v210_write(want_rgba, w, h, 0, *col.oracle_wr))
+    # ph_check_program: the same job examined without a launch - accepted, and the output is not touched
+    vout.host_access("writeonly", capi.QUEUE_LOAD, np.zeros(src.size, np.uint32))
+    ctx.wait(capi.QUEUE_LOAD)
+    assert ctx.run_program(wr, {"gammaLut": col.wr_lut, "colMatrix": col.wr_cm, "interlace": 0, "width": w, "output": vout, "input": rgba},
+                           check_only=True) is None
+    ctx.wait()
+    vout.host_access("readonly", capi.QUEUE_UNLOAD)
+    assert not vout.host(np.uint32).any()
+    with pytest.raises(capi.PhaneronError, match="'gammaLut'"):  # and refused with the launch's own words when an argument is missing
+        ctx.run_program(wr, {"colMatrix": col.wr_cm, "interlace": 0, "width": w, "output": vout, "input": rgba}, check_only=True)
     # errors: a missing argument and an unknown kernel are reported, not ignored
     with pytest.raises(capi.PhaneronError, match="colMatrix"):
         ctx.run_program(rd, {"input": vin, "output": rgba, "width": w, "gammaLut": col.rd_lut, "gamutMatrix": col.rd_gm})

@@ -218,7 +218,8 @@ FORMAT_KATS = [("yuv422p10", 1920, 1080, "709"), ("yuv420p", 1920, 1080, "709"),
 
 @needs_node
 @pytest.mark.gpu
-def test_node_layer_end_to_end_on_gpu(tmp_path):
+@pytest.mark.parametrize("deferred", [False, True], ids=["launch_as_posted", "deferred"])
+def test_node_layer_end_to_end_on_gpu(tmp_path, deferred):
     import frames
     from oracle import orc
     w, h, n = 1920, 96, 4
@@ -251,8 +252,9 @@ def test_node_layer_end_to_end_on_gpu(tmp_path):
         for l, words in enumerate(ls):
             words.tofile(tmp_path / ("staged_f%d_l%d.bin" % (f, l)))
     (tmp_path / "job.json").write_text(json.dumps(job))
+    # (deferred: the whole script on a recording context - same frames, same hashes, the same errors where they are raised)
     r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "gpu_run.js"), str(tmp_path)], capture_output=True,
-                       text=True, timeout=300)
+                       text=True, timeout=300, env=dict(os.environ, PHANERON_DEFERRED="1" if deferred else "0"))
     assert r.returncode == 0, r.stdout + r.stderr
     res = json.loads((tmp_path / "result.json").read_text())
     assert res["rampCompare"] == 0  # the reference scripts' "Compare returned 0"
