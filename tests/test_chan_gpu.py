@@ -283,3 +283,41 @@ def test_dissolve_against_a_smaller_rotated_source_over_the_same_frame_taken_pla
         layers = [dict(src=Src(a, ow, oh)),
                   dict(src=Src(a, ow, oh, m(ow, oh)), transition="dissolve", mix=mix, incoming=Src(b, 192, 54, m(ow, oh, scale_x=0.8, scale_y=0.8, rotate=0.05)))]
         check(layers, ow, oh, "dissolve %g, half-size rotated incoming" % mix)
+
+
+def test_8k_channel_equals_the_separate_kernels():
+    """Beyond UHD (7680 x 4320: 88 MB v210 frames, 530 MB images, a 265 MB index frame): the one-kernel channel against the
+    separate HIP kernels - read, transform, combine_3, write, each pinned to the oracle at sizes it finishes in seconds - word
+    for word.  Layers: an 8K frame taken pixel for pixel, a 2160p frame enlarged by the default fill, an 8K frame shrunk and rotated."""
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    ow, oh = 7680, 4320
+    k = hh.ctx()
+    a = frames.v210_random(ow, oh, frames.layer_seed(97, 0))
+    b = frames.v210_random(3840, 2160, frames.layer_seed(97, 1))
+    c = frames.v210_random(ow, oh, frames.layer_seed(97, 2), legal=False)
+    _, _, rd_d, wr_d = colour("709", "2020")
+    mats = [None, m(ow, oh), m(ow, oh, scale_x=0.4, scale_y=0.4, rotate=0.07, offset_x=0.2, offset_y=-0.15)]
+    srcs = [(a, ow, oh), (b, 3840, 2160), (c, ow, oh)]
+    dev = [hh.dev(s[0]) for s in srcs]
+    words = frames.v210_pitch_bytes(ow) * oh // 4
+    got = torch.zeros(words, dtype=torch.int32, device="cuda")
+    k.chan_compose_v210([dict(src=(d, s[1], s[2], mt)) for d, s, mt in zip(dev, srcs, mats)], got, ow, oh, 0, *rd_d, *wr_d)
+    placed = []
+    for d, s, mt in zip(dev, srcs, mats):
+        img = torch.empty(s[1] * s[2] * 4, dtype=torch.float32, device="cuda")
+        k.v210_read(d, img, s[1], s[2], *rd_d)
+        if mt is not None:
+            out = torch.empty(ow * oh * 4, dtype=torch.float32, device="cuda")
+            k.transform(img, s[1], s[2], hh.dev(np.asarray(mt, np.float32)), out, ow, oh)
+            k.wait()
+            img = out
+        placed.append(img)
+    comb = torch.empty(ow * oh * 4, dtype=torch.float32, device="cuda")
+    k.combine(placed, comb, ow, oh)
+    want = torch.zeros_like(got)
+    k.v210_write(comb, want, ow, oh, 0, *wr_d)
+    k.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

@@ -180,3 +180,28 @@ def test_random_magnified_layers():
         if not layers:
             continue
         check(layers, ow, oh, "random magnified job %d: %dx%d, %d layers, %s" % (case, ow, oh, len(layers), "rgb" if rgb else "rgba"), rgb=rgb)
+
+
+def test_8k_from_four_uhd_layers_equals_the_pixel_per_lane_compositor():
+    """7680 x 4320 from four 2160p images (2x): the 2 x 2-block compositor against ph_compose_write_v210 (pixel per lane, pinned to
+    the oracle's chain at small sizes), word for word, both image layouts"""
+    import torch
+    import hip_harness as hh
+    ow, oh, sw, sh = 7680, 4320, 3840, 2160
+    k = hh.ctx()
+    wcm, wlut = hh.ColourParams.writer("2020")
+    mats = [m(ow, oh), m(ow, oh, scale_x=0.75, scale_y=0.75, offset_x=0.1), m(ow, oh, scale_x=0.6, scale_y=0.55, offset_x=-0.25, offset_y=0.25), m(ow, oh)]
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    imgs = [torch.rand(sw * sh * 4, device="cuda", generator=gen) * 1.1 - 0.05 for _ in range(4)]
+    for im in imgs:
+        im.view(-1, 4)[:, 3] = 1.0  # (the packed-RGB layout implies alpha 1)
+    words = frames.v210_pitch_bytes(ow) * oh // 4
+    want = torch.zeros(words, dtype=torch.int32, device="cuda")
+    k.compose_write_v210([(im, sw, sh, hh.dev(np.asarray(mt, np.float32))) for im, mt in zip(imgs, mats)], want, ow, oh, 0, wcm, wlut)
+    for rgb in (False, True):
+        got = torch.zeros_like(want)
+        data = [im.view(-1, 4)[:, :3].contiguous().view(-1) if rgb else im for im in imgs]
+        k.compose_up_write_v210([(d, sw, sh, mt) for d, mt in zip(data, mats)], got, ow, oh, 0, wcm, wlut, rgb=rgb)
+        k.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), "packed RGB" if rgb else "RGBA"
