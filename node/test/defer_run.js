@@ -59,7 +59,7 @@ async function side(deferred) {
 	// post a job as a valve does: destination released by the poster once the job's callback has fired
 	s.id = (name) => ({ source: name, timestamp: s.frame })
 	s.flush = (id) => rig.board.flush(id)
-	s.consume = async (out) => { await rig.download(out); return Buffer.from(out) } // the consumer's saveFrame
+	s.consume = async (out) => { await rig.sync(); await rig.download(out); return Buffer.from(out) } // the consumer's saveFrame, after its jobs' waitFinish (clJobQueue.ts:131)
 	return s
 }
 

@@ -676,3 +676,18 @@ def test_recording_graph_logic_without_a_device():
     assert r.returncode == 0, r.stdout + r.stderr
     res = json.loads(r.stdout)
     assert res["problems"] == [] and res["checks"] >= 22, res["problems"]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_random_job_streams_give_the_same_bytes_through_the_recording_context():
+    """node/test/defer_fuzz.js: seeded random streams of reads, transforms, transitions, combines, de-interlaces, frame and
+    field writes, source and matrix overwrites, early releases and host reads in the middle of chains - nothing shaped like a
+    channel - through the plain context and through the recording one: every host read sees the same bytes, nothing is left
+    alive or recorded at the end, and fused launches did take part"""
+    _build_addon()
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "defer_fuzz.js"), "7000", "80", "120"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["problems"] == [], res["problems"][:2]
+    assert res["fusedLaunches"] > 100 and res["launchesSaved"] > 1000, res

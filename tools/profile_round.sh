@@ -110,6 +110,7 @@ $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
 (node $ROOT/node/test/bench_node.js 200; node $ROOT/node/test/bench_node.js 300 1920 1080 4) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_bench.jsonl
 # the recording context (node/defer.js) against the launch-as-posted one: scenarios, frames compared byte for byte, launch counters
 (node $ROOT/node/test/defer_run.js; node $ROOT/node/test/defer_run.js 1920 64) 2>/dev/null | grep '^{' > $OUT/${TAG}_defer_run.jsonl
+node $ROOT/node/test/defer_fuzz.js 100 400 120 2>/dev/null | grep '^{' > $OUT/${TAG}_defer_fuzz.jsonl
 (for v in "--no-secondary" "--no-secondary --content picture" "--width 1920 --height 1080" "--width 1920 --height 1080 --channels 2" "--width 1920 --height 1080 --channels 4" "--width 1920 --height 1080 --frames-per-launch 2" "--width 1920 --height 1080 --frames-per-launch 4" "--channels 2 --ring 4"; do $BENCH $v --steps 1500 --cpu-seconds 0; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_bench_variants.jsonl
 rm -rf $OUT/stats $OUT/pmc_bench_* $OUT/pmc_micro_*
 ls -la $OUT
