@@ -376,11 +376,15 @@ int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer
 #define PH_SRC_NONE 0
 #define PH_SRC_V210 1
 #define PH_SRC_RGBA_F32 2
+#define PH_SRC_YUV422P10 3 /* planar 4:2:2, 16-bit little-endian samples (yuv422p10.ts): data = the Y plane, data_u / data_v the chroma
+                            * planes, plane sizes as ph_pack_plane_bytes(PH_FMT_YUV422P10, ...); unpacked with the SAME Loader recipe as
+                            * the v210 sources of the call (a 10-bit 4:2:2 Loader's matrix does not depend on the packing) */
 typedef struct ph_chan_source {
-  const void *data;          /* device: v210 words (pitch ph_v210_pitch_bytes(width)) or float RGBA, width x height */
-  int format;                /* PH_SRC_V210 | PH_SRC_RGBA_F32 (PH_SRC_NONE: absent) */
+  const void *data;          /* device: v210 words (pitch ph_v210_pitch_bytes(width)), float RGBA, or the Y plane; width x height */
+  int format;                /* PH_SRC_V210 | PH_SRC_RGBA_F32 | PH_SRC_YUV422P10 (PH_SRC_NONE: absent) */
   int width, height;
   const float *matrix9_host; /* HOST: the nine values of ph_transform_matrix, or NULL = 1:1 */
+  const void *data_u, *data_v; /* PH_SRC_YUV422P10: the Cb and Cr planes (ignored otherwise) */
 } ph_chan_source;
 #define PH_TRANSITION_CUT 0
 #define PH_TRANSITION_DISSOLVE 1 /* fma(src, mix, incoming * (1 - mix))            transition.ts:58-64 */

@@ -20,7 +20,7 @@
 //     placement matrix into an old buffer: transform.ts:84-89); a new job writing into such a buffer.  waitFinish does
 //     not force: nothing can tell a frame that sits in HBM from one that was never made.
 //   * Forcing a v210 `write` looks at what produces its input: [combine_N of] per layer [transition_* of]
-//     [transform of] (`read` of a v210 frame | an image that exists).  That shape is ONE launch of chan_compose_v210_N
+//     [transform of] (`read` of a v210 or yuv422p10 frame | an image that exists).  That shape is ONE launch of chan_compose_v210_N
 //     (or fused_v210_combine_N when every layer is a plain read of the output's size) on the ORIGINAL v210 sources.
 //     Anything else runs as recorded, producers first.  Both kernels are bit-identical to the chain of separate
 //     operators (tests/test_chan_gpu.py, tests/test_hip_parity.py), so deferring changes no result.
@@ -318,16 +318,20 @@ class Deferral {
 		const materialised = (img) => { this.force(img); return img.imageDims ? { source: img } : null }
 		const plainSource = (img) => { // an image as a sampled source: a pending v210 read, or the image itself
 			const p = img._producer
-			if (p && p.state === 'pending' && Deferral._isV210(p.program, 'read')) {
+			// a pending ToRGBA of a v210 frame, or of a planar 10-bit 4:2:2 one (yuv422p10le: what file decoders hand over,
+			// ffmpegProducer.ts:410-412; its Loader recipe is the v210 one, the packing does not enter the matrix)
+			const planar = p && p.state === 'pending' && p.program.name === 'read' && p.program.format === 'yuv422p10'
+			if (p && p.state === 'pending' && (planar || Deferral._isV210(p.program, 'read'))) {
 				const r = { colMatrix: p.params.colMatrix, gammaLut: p.params.gammaLut, gamutMatrix: p.params.gamutMatrix }
 				const f = Deferral._frameOf(p)
-				const ok = r.colMatrix && r.gammaLut && r.gamutMatrix && p.params.input && img.imageDims &&
-					f.width === img.imageDims.width && f.lines === img.imageDims.height && f.width % 6 === 0 &&
-					(!reader || Deferral.sameRecipe(reader, r))
+				const planes = planar ? p.params.inputY && p.params.inputU && p.params.inputV && f.width % 2 === 0 : p.params.input && f.width % 6 === 0
+				const ok = r.colMatrix && r.gammaLut && r.gamutMatrix && planes && img.imageDims &&
+					f.width === img.imageDims.width && f.lines === img.imageDims.height && (!reader || Deferral.sameRecipe(reader, r))
 				if (ok) {
 					reader = reader || r
 					used.add(p)
-					return { source: p.params.input, width: f.width, height: f.lines, v210: true }
+					return planar ? { source: p.params.inputY, u: p.params.inputU, v: p.params.inputV, width: f.width, height: f.lines, v210: true, planar: true }
+						: { source: p.params.input, width: f.width, height: f.lines, v210: true }
 				}
 			}
 			return materialised(img)
@@ -374,7 +378,7 @@ class Deferral {
 		if (!used.size) return false // every layer is a finished image taken as it is: the recorded write is as good
 		const saver = { outColMatrix: node.params.colMatrix, outGammaLut: node.params.gammaLut }
 		const candidates = [] // [program name, params], best first; the library refuses the shapes a kernel does not take
-		if (!interlace && layers.every((l) => l.v210 && !l.matrix && !l.transition)) {
+		if (!interlace && layers.every((l) => l.v210 && !l.planar && !l.matrix && !l.transition)) {
 			const params = Object.assign({ output }, reader, saver)
 			layers.forEach((l, i) => { params[`l${i}In`] = l.source })
 			candidates.push([`fused_v210_combine_${n}`, params])
@@ -389,6 +393,7 @@ class Deferral {
 			const params = Object.assign({ output, interlace }, loader, saver)
 			const put = (prefix, s) => {
 				params[`${prefix}In`] = s.source
+				if (s.planar) { params[`${prefix}InU`] = s.u; params[`${prefix}InV`] = s.v }
 				if (s.matrix) params[`${prefix}Matrix`] = s.matrix
 				if (s.v210) { params[`${prefix}Width`] = s.width; params[`${prefix}Height`] = s.height }
 			}

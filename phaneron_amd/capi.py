@@ -70,7 +70,7 @@ class PhFieldLayer(C.Structure):
 
 class PhChanSource(C.Structure):
     _fields_ = [("data", C.c_void_p), ("format", C.c_int), ("width", C.c_int), ("height", C.c_int),
-                ("matrix9_host", C.POINTER(C.c_float))]
+                ("matrix9_host", C.POINTER(C.c_float)), ("data_u", C.c_void_p), ("data_v", C.c_void_p)]
 
 
 class PhChanLayer(C.Structure):
@@ -82,7 +82,7 @@ class PhImageLayer(C.Structure):
 
 
 IMG_RGBA_F32, IMG_RGB_F32 = 0, 1
-SRC_V210, SRC_RGBA_F32 = 1, 2
+SRC_V210, SRC_RGBA_F32, SRC_YUV422P10 = 1, 2, 3
 TRANSITION_CUT, TRANSITION_DISSOLVE, TRANSITION_WIPE = 0, 1, 2
 
 
@@ -467,16 +467,22 @@ class Context:
                           prepare_only=False):
         """The channel compositor straight from v210 sources (ph_chan_compose_v210).  layers: list of dicts
         {src: SOURCE, transition: "cut" | "dissolve" | "wipe", mix: float, incoming: SOURCE, mask: SOURCE}; a SOURCE is
-        (tensor, width, height, matrix) or (tensor, width, height, matrix, "rgba") - matrix: nine host floats
-        (transform_matrix) or None for 1:1; format v210 unless "rgba" (f32 RGBA image)."""
+        (tensor, width, height, matrix) or (tensor, width, height, matrix, "rgba") or ((y, u, v) plane tensors, width, height,
+        matrix, "yuv422p10") - matrix: nine host floats (transform_matrix) or None for 1:1; format v210 unless "rgba" (f32 RGBA
+        image) or "yuv422p10" (planar 4:2:2, 16-bit samples)."""
         import numpy as np
         arr = (PhChanLayer * len(layers))()
         keep = []
 
         def fill(dst_src, spec):
             t, w, h, m = spec[:4]
-            dst_src.data, dst_src.width, dst_src.height = _ptr(t).value, w, h
-            dst_src.format = SRC_RGBA_F32 if (len(spec) > 4 and spec[4] == "rgba") else SRC_V210
+            kind = spec[4] if len(spec) > 4 else "v210"
+            if kind == "yuv422p10":
+                dst_src.data, dst_src.data_u, dst_src.data_v = (_ptr(p).value for p in t)
+            else:
+                dst_src.data = _ptr(t).value
+            dst_src.width, dst_src.height = w, h
+            dst_src.format = {"rgba": SRC_RGBA_F32, "yuv422p10": SRC_YUV422P10}.get(kind, SRC_V210)
             if m is not None:
                 mh = np.ascontiguousarray(m, np.float32)
                 keep.append(mh)

@@ -1105,11 +1105,29 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
           s->format = PH_SRC_RGBA_F32, sw = x->width, sh = x->height;
         } else {
           s->format = PH_SRC_V210;
+          s->data_u = s->data_v = nullptr;
+          snprintf(nm, sizeof nm, "l%d%sInU", i, role);
+          if (find_arg(args, n, nm)) {  // a planar 4:2:2 source of 16-bit samples: l<i>In is its Y plane, l<i>InU / l<i>InV its chroma planes
+            ph_buf *pu = nullptr, *pv = nullptr;
+            TRY(need_buf(args, n, nm, 0, &pu));
+            snprintf(nm, sizeof nm, "l%d%sInV", i, role);
+            TRY(need_buf(args, n, nm, 0, &pv));
+            s->format = PH_SRC_YUV422P10, s->data_u = pu->dptr, s->data_v = pv->dptr;
+          }
           snprintf(nm, sizeof nm, "l%d%sWidth", i, role);
           if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sw));
           snprintf(nm, sizeof nm, "l%d%sHeight", i, role);
           if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sh));
-          if (sw > 0 && sh > 0 && x->bytes < (size_t)ph_v210_pitch_bytes((uint32_t)sw) * (size_t)sh)
+          if (s->format == PH_SRC_YUV422P10) {
+            size_t pb[3] = {0, 0, 0};
+            if (sw > 0 && sh > 0) ph_pack_plane_bytes(PH_FMT_YUV422P10, (uint32_t)sw, (uint32_t)sh, pb);
+            char nu[40], nv[40];
+            snprintf(nu, sizeof nu, "l%d%sInU", i, role), snprintf(nv, sizeof nv, "l%d%sInV", i, role);
+            ph_buf *pu = nullptr, *pv = nullptr;
+            TRY(need_buf(args, n, nu, pb[1], &pu));
+            TRY(need_buf(args, n, nv, pb[2], &pv));
+            if (x->bytes < pb[0]) return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than the Y plane of a %gx%g yuv422p10 frame", i, role, x->bytes, sw, sh);
+          } else if (sw > 0 && sh > 0 && x->bytes < (size_t)ph_v210_pitch_bytes((uint32_t)sw) * (size_t)sh)
             return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than a %gx%g v210 frame", i, role, x->bytes, sw, sh);
         }
         s->width = (int)sw, s->height = (int)sh, s->matrix9_host = nullptr;
@@ -1589,18 +1607,27 @@ static int compose_write(ph_ctx *ctx, int queue, int n, const ph_layer *layers, 
   PH_LAUNCH(ph::launch_compose_write_v210(stream_of(ctx, queue), a, (uint32_t)ctx->props.multiProcessorCount));
 }
 
-static int chan_source(const ph_chan_source &s, const char *what, int layer, uint32_t out_w, uint32_t out_h, ph::ChanSrc *o) {
+static int chan_source(const ph_chan_source &s, const char *what, int layer, uint32_t out_w, uint32_t out_h, ph::ChanSrc *o, const void **pu,
+                       const void **pv, uint32_t *planar) {
   if (!s.data || s.width <= 0 || s.height <= 0)
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is empty", layer, what);
-  if (s.format != PH_SRC_V210 && s.format != PH_SRC_RGBA_F32)
-    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has format %d (PH_SRC_V210 or PH_SRC_RGBA_F32)", layer, what, s.format);
+  if (s.format != PH_SRC_V210 && s.format != PH_SRC_RGBA_F32 && s.format != PH_SRC_YUV422P10)
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has format %d (PH_SRC_V210, PH_SRC_RGBA_F32 or PH_SRC_YUV422P10)", layer, what, s.format);
+  *pu = *pv = nullptr;
+  if (s.format == PH_SRC_YUV422P10) {
+    if (!s.data_u || !s.data_v || (s.width & 1))
+      return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is planar 4:2:2 and needs its two chroma planes and an even width", layer, what);
+    *pu = s.data_u, *pv = s.data_v, *planar = 1;
+  }
   if (s.format == PH_SRC_V210 && s.width % 6)
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is a v210 frame %d wide, not a multiple of 6; run the separate kernels", layer, what, s.width);
   if (!s.matrix9_host && ((uint32_t)s.width != out_w || (uint32_t)s.height != out_h))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has no transform but is %dx%d, not the output size", layer, what, s.width, s.height);
   o->ptr = s.data, o->w = (uint32_t)s.width, o->h = (uint32_t)s.height;
-  o->kind = s.format == PH_SRC_V210 ? ph::kChanV210 : ph::kChanRgba;
-  o->pitch = s.format == PH_SRC_V210 ? ph_v210_pitch_bytes((uint32_t)s.width) : (uint32_t)s.width * 16u;
+  o->kind = s.format == PH_SRC_V210 ? ph::kChanV210 : s.format == PH_SRC_YUV422P10 ? ph::kChanP10 : ph::kChanRgba;
+  // planar 4:2:2: the luma line pitch in samples is the width rounded up to 8 (yuv422p10.ts:221), two bytes each
+  o->pitch = s.format == PH_SRC_V210 ? ph_v210_pitch_bytes((uint32_t)s.width)
+             : s.format == PH_SRC_YUV422P10 ? (((uint32_t)s.width + 7u) & ~7u) * 2u : (uint32_t)s.width * 16u;
   if ((uint64_t)o->pitch * o->h >= (1ull << 30))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is 1 GiB or larger; run the separate kernels", layer, what);
   o->sampled = s.matrix9_host ? 1u : 0u;
@@ -1624,20 +1651,20 @@ int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *lay
   for (int i = 0; i < n; ++i) {
     const ph_chan_layer &L = layers[i];
     const uint32_t first = i == 0 ? ph::kChanActFirst : 0u;
-    int rc = chan_source(L.src, "source", i, out_w, out_h, &a.op[k].src);
+    int rc = chan_source(L.src, "source", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.planar);
     if (rc) return rc;
     if (L.transition == PH_TRANSITION_CUT) {
       a.op[k++].action = ph::kChanActLayer | first;
     } else if (L.transition == PH_TRANSITION_DISSOLVE || L.transition == PH_TRANSITION_WIPE) {
       a.op[k++].action = ph::kChanActHold;
-      rc = chan_source(L.incoming, "transition's incoming source", i, out_w, out_h, &a.op[k].src);
+      rc = chan_source(L.incoming, "transition's incoming source", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.planar);
       if (rc) return rc;
       if (L.transition == PH_TRANSITION_DISSOLVE) {
         a.op[k].mix = L.mix;
         a.op[k++].action = ph::kChanActDissolve | first;
       } else {
         a.op[k++].action = ph::kChanActIncoming;
-        rc = chan_source(L.mask, "wipe's mask", i, out_w, out_h, &a.op[k].src);
+        rc = chan_source(L.mask, "wipe's mask", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.planar);
         if (rc) return rc;
         a.op[k++].action = ph::kChanActWipe | first;
       }

@@ -54,12 +54,12 @@ struct ComposeArgs {
 };
 
 // ph_kernels_chan.hip: the compositor that samples v210 sources directly
-enum : uint32_t { kChanNone = 0, kChanV210 = 1, kChanRgba = 2 };
+enum : uint32_t { kChanNone = 0, kChanV210 = 1, kChanRgba = 2, kChanP10 = 3 };
 enum : uint32_t { kChanCut = 0, kChanDissolve = 1, kChanWipe = 2 };
 struct ChanSrc {
   const void *ptr;
   uint32_t w, h, pitch;  // pixels, pixels, bytes per line
-  uint32_t kind;         // kChanV210 / kChanRgba (kChanNone: absent)
+  uint32_t kind;         // kChanV210 / kChanRgba / kChanP10 (planar 4:2:2, 16-bit samples: ptr = the Y plane, ChanArgs::plane_u / plane_v) (kChanNone: absent)
   uint32_t sampled;      // 1 = through m (transform.ts:53-57), 0 = pixel for pixel
   uint32_t pad;
   float m[6];            // rows 0 and 1 of the 3x3 transform matrix
@@ -83,6 +83,9 @@ struct ChanArgs {
   uint32_t out_w, out_h, lines, first_line, line_step;
   const float *rd_cm, *rd_gm, *wr_cm;
   LutView rd, wr;
+  // kChanP10 sources: the chroma planes of op k (read by the planar instantiation of the kernel only)
+  const void *plane_u[kMaxChanOps], *plane_v[kMaxChanOps];
+  uint32_t planar;  // launcher: some op is kChanP10
 };
 
 // ph_kernels_up.hip: the 2 x 2-block compositor for magnifying placements

@@ -128,6 +128,82 @@ __device__ __forceinline__ float4 rgba_load(__amdgpu_buffer_rsrc_t img, uint32_t
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// ---- a planar 4:2:2 source with 16-bit samples (yuv422p10le: yuv422p10.ts:60-72) ------------------------------------------
+// Y at plane 0 [row][x], Cb / Cr at planes 1 / 2 [row][x / 2]; the reader's arithmetic from there on is ToRGBA's own
+// (read_px_issue), with the sample taken as it is (the reference converts the whole 16-bit word, yuv422p10.ts:66-68).
+// A tap is three 2-byte buffer loads; taps outside the frame get offsets beyond every plane and load 0.
+struct P10Planes {
+  __amdgpu_buffer_rsrc_t y, u, v;
+};
+__device__ __forceinline__ V210Words p10_load(const P10Planes &pl, uint32_t row_y, uint32_t row_c, uint32_t col) {  // col: the pixel's column, or kOutsideBit
+  const uint32_t oy = row_y + (col << 1), oc = row_c + (col & ~1u);  // 2 bytes per sample; the pair's chroma sample
+  return V210Words{(uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(pl.y, (int)oy, 0, 0),
+                   (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(pl.u, (int)oc, 0, 0),
+                   (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(pl.v, (int)oc, 0, 0)};
+}
+template <bool STD>
+__device__ __forceinline__ PxPending p10_issue(const V210Words &w, const ReadK &k, const LutK &lut) {
+  return read_px_issue<STD>((float)w.wy, (float)w.wcb, (float)w.wcr, k, lut);
+}
+template <bool STD>
+__device__ __forceinline__ void chan_sample_p10(const ChanSrc &s, const void *pu, const void *pv, float px, const float (&py)[kChanP], uint32_t x,
+                                                const uint32_t (&line)[kChanP], const ReadK &k, const LutK &lut, float4 (&out)[kChanP]) {
+  const uint32_t pitch_c = s.pitch >> 1;
+  P10Planes pl;
+  pl.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(s.pitch * s.h), 0x00020000);
+  pl.u = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(pu), 0, (int)(pitch_c * s.h), 0x00020000);
+  pl.v = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(pv), 0, (int)(pitch_c * s.h), 0x00020000);
+  if (!s.sampled) {
+    PxPending pend[kChanP];
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) pend[p] = p10_issue<STD>(p10_load(pl, __umul24(line[p], s.pitch), __umul24(line[p], pitch_c), x), k, lut);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) out[p] = read_px_finish(pend[p], k);
+    return;
+  }
+  ChanTaps t[kChanP];
+  bool touches = false;
+#pragma unroll
+  for (int p = 0; p < kChanP; ++p) {
+    t[p] = chan_taps(s, px, py[p]);
+    touches = touches || (t[p].i0 + 1u <= s.w && t[p].j0 + 1u <= s.h);
+  }
+  if (!__builtin_amdgcn_ballot_w64(touches)) {
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) out[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < kChanP; ++p) {
+    const bool ci[2] = {t[p].i0 < s.w, t[p].i0 + 1u < s.w}, ri[2] = {t[p].j0 < s.h, t[p].j0 + 1u < s.h};
+    V210Words w[4];
+    bool in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t row = t[p].j0 + (uint32_t)(i >> 1), col = t[p].i0 + (uint32_t)(i & 1);
+      in[i] = ci[i & 1] && ri[i >> 1];
+      w[i] = p10_load(pl, __umul24(row, s.pitch), __umul24(row, pitch_c), in[i] ? col : kOutsideBit);  // rows inside are below 2^24: the 24-bit product is exact where it is used
+    }
+    PxPending pend[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pend[i] = p10_issue<STD>(w[i], k, lut);
+    __builtin_amdgcn_sched_barrier(0);
+    float4 q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      q[i] = read_px_finish(pend[i], k);
+      q[i].x = in[i] ? q[i].x : 0.0f, q[i].y = in[i] ? q[i].y : 0.0f, q[i].z = in[i] ? q[i].z : 0.0f, q[i].w = in[i] ? 1.0f : 0.0f;  // the border colour
+    }
+    const float a = t[p].a, b = t[p].b, oma = 1.0f - a, omb = 1.0f - b;
+    const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
+    out[p].x = ((w00 * q[0].x + w10 * q[1].x) + w01 * q[2].x) + w11 * q[3].x;
+    out[p].y = ((w00 * q[0].y + w10 * q[1].y) + w01 * q[2].y) + w11 * q[3].y;
+    out[p].z = ((w00 * q[0].z + w10 * q[1].z) + w01 * q[2].z) + w11 * q[3].z;
+    out[p].w = ((w00 * q[0].w + w10 * q[1].w) + w01 * q[2].w) + w11 * q[3].w;
+  }
+}
+
 // the source's samples for the lane's pixels (x, line[p]): 1:1, or through the transform matrix and the bilinear filter
 template <bool STD>
 __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const float (&py)[kChanP], uint32_t x, const uint32_t (&line)[kChanP],
@@ -321,7 +397,7 @@ __device__ __forceinline__ void chan_apply(const ChanOp &op, const float4 v, Cha
   }
 }
 
-template <bool STD>
+template <bool STD, bool PLANAR>
 __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &sh, const ReadK &rk, const LutK &rlut) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   uint2 *const index = reinterpret_cast<uint2 *>(a.index);
@@ -361,7 +437,8 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
     for (int k = 0; k < a.n_ops; ++k) {
       const ChanOp op = a.op[k];
       float4 v[kChanP];
-      chan_sample<STD>(op.src, px, py, x, line, rk, rlut, v);
+      if (PLANAR && op.src.kind == kChanP10) chan_sample_p10<STD>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, rk, rlut, v);  // uniform
+      else chan_sample<STD>(op.src, px, py, x, line, rk, rlut, v);
 #pragma unroll
       for (int p = 0; p < kChanP; ++p) chan_apply(op, v[p], acc[p]);
     }
@@ -375,6 +452,8 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
   }
 }
 
+// PLANAR: the program has planar sources (an instantiation of its own: the v210 / image kernel is not touched by them)
+template <bool PLANAR>
 __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a) {
   const ReadK rk = load_read_k(a.rd_cm, a.rd_gm);
   const WriteK wk = load_write_k(a.wr_cm);
@@ -384,8 +463,8 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
   lds_lut_load(a.rd);
   __syncthreads();
   PH_CPHASE(1);
-  if (ycbcr_matrix_is_standard(rk)) chan_phase1<true>(a, sh, rk, rlut);
-  else chan_phase1<false>(a, sh, rk, rlut);
+  if (ycbcr_matrix_is_standard(rk)) chan_phase1<true, PLANAR>(a, sh, rk, rlut);
+  else chan_phase1<false, PLANAR>(a, sh, rk, rlut);
   PH_CPHASE(2);
   __syncthreads();  // every index of this workgroup has been stored (the barrier drains the stores) and nobody reads the reader table any more
   PH_CPHASE(3);
@@ -423,7 +502,8 @@ size_t chan_index_bytes(uint32_t out_w, uint32_t lines) { return (size_t)out_w *
 hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t num_cus) {
   if (!a.lines) return hipSuccess;
   const uint32_t lds = a.rd.bytes > a.wr.bytes ? a.rd.bytes : a.wr.bytes;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chan_compose_v210_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const void *fn = a.planar ? reinterpret_cast<const void *>(chan_compose_v210_kernel<true>) : reinterpret_cast<const void *>(chan_compose_v210_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint32_t cpr = a.out_w / kChanChunk, cpg = (uint32_t)(PH_CHAN_GROUP_ROWS / 2) * cpr;
   const uint32_t chunks = cpr * ((a.lines + 1u) / 2u);  // 192 pixels x 2 rows each
@@ -432,7 +512,8 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
   // reciprocals for the kernel's uniform divisions: umulhi(v, ceil(2^32 / d)) == v / d for every v * d < 2^32 (chunk counts are far below)
   b.magic_cpr = cpr > 1 ? (uint32_t)(((1ull << 32) + cpr - 1) / cpr) : 0u;
   b.magic_cpg = (uint32_t)(((1ull << 32) + cpg - 1) / cpg);
-  chan_compose_v210_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, lds, s>>>(b);
+  if (a.planar) chan_compose_v210_kernel<true><<<want < num_cus ? want : num_cus, kLdsBlock, lds, s>>>(b);
+  else chan_compose_v210_kernel<false><<<want < num_cus ? want : num_cus, kLdsBlock, lds, s>>>(b);
   return hipGetLastError();
 }
 

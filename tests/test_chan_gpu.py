@@ -25,7 +25,10 @@ class Src:
         self.data, self.w, self.h, self.matrix, self.fmt = data, w, h, matrix, fmt
 
     def oracle(self, rd_o, ow, oh):
-        img = orc.v210_read(self.data, self.w, self.h, *rd_o) if self.fmt == "v210" else self.data.reshape(self.h, self.w, 4)
+        if self.fmt == "yuv422p10":  # data: the three planes; the Loader recipe of a 10-bit 4:2:2 source is the v210 one
+            img = orc.pack_read("yuv422p10", [np.ascontiguousarray(p).view(np.uint8) for p in self.data], self.w, self.h, *rd_o)
+        else:
+            img = orc.v210_read(self.data, self.w, self.h, *rd_o) if self.fmt == "v210" else self.data.reshape(self.h, self.w, 4)
         if self.matrix is None:
             assert (self.w, self.h) == (ow, oh)
             return img
@@ -33,6 +36,8 @@ class Src:
 
     def device(self):
         import hip_harness as hh
+        if self.fmt == "yuv422p10":
+            return (tuple(hh.dev(np.ascontiguousarray(p).reshape(-1)) for p in self.data), self.w, self.h, self.matrix, "yuv422p10")
         t = hh.dev(self.data.reshape(-1))
         return (t, self.w, self.h, self.matrix) + (("rgba",) if self.fmt == "rgba" else ())
 
@@ -321,3 +326,24 @@ def test_8k_channel_equals_the_separate_kernels():
     k.wait()
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+def test_planar_ten_bit_sources():
+    """yuv422p10le frames (what a ProRes / DNxHD decoder hands over: ffmpegProducer.ts:410-412) as sources of the channel kernel:
+    pixel for pixel, placed, enlarged from a smaller frame, as the incoming side of a dissolve and as a wipe's mask, beside v210
+    and image layers - against the oracle's yuv422p10 reader (every 16-bit code, legal or not) followed by the chain of operators"""
+    w, h = 384, 54
+    p = [frames.pack_random("yuv422p10", w, h, 300 + i) for i in range(4)]
+    small = frames.pack_random("yuv422p10", 200, 30, 310)  # (a width that is not a multiple of 8: the planes' lines are padded)
+    small = [(frames.splitmix64(311 + i, x.size // 2) % np.uint64(65536)).astype(np.uint16).view(np.uint8) for i, x in enumerate(small)]  # every 16-bit word
+    v = frames.v210_random(w, h, frames.layer_seed(98, 0))
+    check([dict(src=Src(p[0], w, h, fmt="yuv422p10"))], w, h, "one planar layer, pixel for pixel")
+    check([dict(src=Src(p[0], w, h, fmt="yuv422p10")), dict(src=Src(p[1], w, h, m(w, h, **PIP[1]), fmt="yuv422p10")),
+           dict(src=Src(v, w, h, m(w, h, **PIP[2]))), dict(src=Src(small, 200, 30, m(w, h, scale_x=0.6, scale_y=0.6, rotate=0.05, offset_x=0.2), fmt="yuv422p10"))],
+          w, h, "planar and v210 layers, placed", specs=("709", "2020"))
+    rgba = frames.rgba_random(w, h, 320, -0.05, 1.05)
+    layers = [dict(src=Src(v, w, h)),
+              dict(src=Src(p[2], w, h, m(w, h), fmt="yuv422p10"), transition="dissolve", mix=0.4, incoming=Src(small, 200, 30, m(w, h, scale_x=1.5, scale_y=1.5), fmt="yuv422p10")),
+              dict(src=Src(rgba, w, h, fmt="rgba"), transition="wipe", incoming=Src(p[3], w, h, fmt="yuv422p10"), mask=Src(p[0], w, h, m(w, h, scale_x=2.0, scale_y=2.0), fmt="yuv422p10"))]
+    check(layers, w, h, "planar sources inside transitions")
+    check(layers, w, h, "planar sources inside transitions, field 3", interlace=3, poison_dst=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 2 through ph_chan_compose_v210 alone (one launch per frame): the timing loop tools/pmc_kernel.sh profiles.
-  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets]"""
+  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets] [sources: v210|yuv422p10]"""
 import json
 import os
 import sys
@@ -16,6 +16,7 @@ def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     mask_kind = sys.argv[2] if len(sys.argv) > 2 else "rgba"
     variant = sys.argv[3] if len(sys.argv) > 3 else "wipe"
+    packing = sys.argv[4] if len(sys.argv) > 4 else "v210"  # yuv422p10: the sources are planar 10-bit frames (file decoders' format)
     ctx = capi.Context(0)
     stream = ctx.torch_stream()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -28,6 +29,11 @@ def main():
     words = capi.v210_pitch_bytes(w) * h // 4
     src = [[torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device="cuda") for _ in range(6)] for _ in range(R)]
     out = torch.empty(words, dtype=torch.int32, device="cuda")
+    if packing == "yuv422p10":
+        pitch = (w + 7) // 8 * 8
+        plane = lambda n: torch.randint(0, 1024, (n,), dtype=torch.int16, device="cuda")
+        src = [[(plane(pitch * h), plane(pitch // 2 * h), plane(pitch // 2 * h)) for _ in range(6)] for _ in range(R)]
+    kind = ("yuv422p10",) if packing == "yuv422p10" else ()
     mask = torch.zeros(h, w, 4, device="cuda")
     mask[..., 0] = torch.linspace(0, 1, w, device="cuda")[None, :]
     mask = mask.reshape(-1).contiguous()
@@ -36,10 +42,10 @@ def main():
     torch.cuda.synchronize()
 
     def layers(s):
-        ls = [dict(src=(s[l], w, h, mats[l])) for l in range(4)]
+        ls = [dict(src=(s[l], w, h, mats[l]) + kind) for l in range(4)]
         if variant == "wipe":
-            ls[3].update(transition="wipe", incoming=(s[4], w, h, None),
-                         mask=(mask, w, h, None, "rgba") if mask_kind == "rgba" else (s[5], w, h, None))
+            ls[3].update(transition="wipe", incoming=(s[4], w, h, None) + kind,
+                         mask=(mask, w, h, None, "rgba") if mask_kind == "rgba" else (s[5], w, h, None) + kind)
         elif variant == "layer0":
             ls = ls[:1]
         elif variant == "insets":
@@ -55,7 +61,7 @@ def main():
         jobs[i % R]()
     e1.record(stream)
     ctx.wait()
-    print(json.dumps({"kernel": "chan_compose_v210", "variant": variant, "mask": mask_kind, "us_per_frame": round(1e3 * e0.elapsed_time(e1) / reps, 2)}), flush=True)
+    print(json.dumps({"kernel": "chan_compose_v210", "variant": variant, "mask": mask_kind, "sources": packing, "us_per_frame": round(1e3 * e0.elapsed_time(e1) / reps, 2)}), flush=True)
     ctx.close()
 
 
