@@ -376,15 +376,22 @@ int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer
 #define PH_SRC_NONE 0
 #define PH_SRC_V210 1
 #define PH_SRC_RGBA_F32 2
-#define PH_SRC_YUV422P10 3 /* planar 4:2:2, 16-bit little-endian samples (yuv422p10.ts): data = the Y plane, data_u / data_v the chroma
-                            * planes, plane sizes as ph_pack_plane_bytes(PH_FMT_YUV422P10, ...); unpacked with the SAME Loader recipe as
-                            * the v210 sources of the call (a 10-bit 4:2:2 Loader's matrix does not depend on the packing) */
+/* planar YCbCr frames, as file decoders hand them over (ffmpegProducer.ts:398-412): data = the Y plane, data_u / data_v the chroma
+ * planes (nv12: data_u = the interleaved CbCr plane, data_v unused), plane sizes as ph_pack_plane_bytes(PH_FMT_*, ...).  A 10-bit 4:2:2
+ * Loader's matrix does not depend on the packing, so PH_SRC_YUV422P10 sources are unpacked with the call's Loader recipe like the
+ * v210 ones; the 8-bit formats have code ranges of their own: col_matrix12 = that source's Loader matrix (its LUT and gamut
+ * matrix are the call's: one colour space per call) */
+#define PH_SRC_YUV422P10 3 /* yuv422p10.ts: 4:2:2, 16-bit little-endian samples */
+#define PH_SRC_YUV422P8 4  /* yuv422p8.ts:  4:2:2, 8-bit */
+#define PH_SRC_YUV420P 5   /* yuv420p.ts:   4:2:0, 8-bit */
+#define PH_SRC_NV12 6      /* nv12.ts:      4:2:0, 8-bit, Cb and Cr interleaved */
 typedef struct ph_chan_source {
   const void *data;          /* device: v210 words (pitch ph_v210_pitch_bytes(width)), float RGBA, or the Y plane; width x height */
-  int format;                /* PH_SRC_V210 | PH_SRC_RGBA_F32 | PH_SRC_YUV422P10 (PH_SRC_NONE: absent) */
+  int format;                /* PH_SRC_V210 | PH_SRC_RGBA_F32 | a planar PH_SRC_* (PH_SRC_NONE: absent) */
   int width, height;
   const float *matrix9_host; /* HOST: the nine values of ph_transform_matrix, or NULL = 1:1 */
-  const void *data_u, *data_v; /* PH_SRC_YUV422P10: the Cb and Cr planes (ignored otherwise) */
+  const void *data_u, *data_v; /* planar formats: the chroma plane(s) (ignored otherwise) */
+  const void *col_matrix12;  /* planar formats: DEVICE, this source's YCbCr -> RGB matrix, or NULL = the call's */
 } ph_chan_source;
 #define PH_TRANSITION_CUT 0
 #define PH_TRANSITION_DISSOLVE 1 /* fma(src, mix, incoming * (1 - mix))            transition.ts:58-64 */

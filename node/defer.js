@@ -20,7 +20,7 @@
 //     placement matrix into an old buffer: transform.ts:84-89); a new job writing into such a buffer.  waitFinish does
 //     not force: nothing can tell a frame that sits in HBM from one that was never made.
 //   * Forcing a v210 `write` looks at what produces its input: [combine_N of] per layer [transition_* of]
-//     [transform of] (`read` of a v210 or yuv422p10 frame | an image that exists).  That shape is ONE launch of chan_compose_v210_N
+//     [transform of] (`read` of a v210 or planar YCbCr frame | an image that exists).  That shape is ONE launch of chan_compose_v210_N
 //     (or fused_v210_combine_N when every layer is a plain read of the output's size) on the ORIGINAL v210 sources.
 //     Anything else runs as recorded, producers first.  Both kernels are bit-identical to the chain of separate
 //     operators (tests/test_chan_gpu.py, tests/test_hip_parity.py), so deferring changes no result.
@@ -218,9 +218,10 @@ class Deferral {
 		return p
 	}
 	static _isV210(program, which) { return program.name === which && program.format === 'v210' }
-	static _frameOf(node) { // a v210 `read` / `write` job's frame: packer.ts:58-66 geometry
+	static _frameOf(node) { // a `read` / `write` job's frame: packer.ts:58-66 geometry (a 4:2:0 work group handles a line pair: yuv420p.ts:381)
 		const wipg = node.program.workItemsPerGroup
-		const lines = wipg ? node.program.globalWorkItems[0] / wipg : 0
+		const pairs = node.program.format === 'yuv420p' || node.program.format === 'nv12' ? 2 : 1
+		const lines = wipg ? pairs * node.program.globalWorkItems[0] / wipg : 0
 		return { width: node.params.width, lines }
 	}
 
@@ -311,27 +312,34 @@ class Deferral {
 		if (layerImages.length > 8) return false
 		this._deinterlace(layerImages)
 
-		// what each layer is made of; `reader` = the one Loader recipe the fused kernel can apply to v210 sources
+		// what each layer is made of.  The fused kernel applies ONE gamma table and gamut matrix (`reader`: a call is one colour
+		// space) and one YCbCr matrix to its v210 sources (`packedCm`); a planar source may bring a matrix of its own (the 8-bit
+		// formats' code ranges: `cm` on the source, compared with the call's when the launch is put together)
 		let reader = null
+		let packedCm = null
+		const PLANAR = { yuv422p10: 1, yuv422p8: 2, yuv420p: 3, nv12: 4 } // PH_FMT_*
 		const used = new Set() // pending nodes the fused launch stands in for
 		const sameSize = (img) => img.imageDims && img.imageDims.width === width && img.imageDims.height === height
 		const materialised = (img) => { this.force(img); return img.imageDims ? { source: img } : null }
-		const plainSource = (img) => { // an image as a sampled source: a pending v210 read, or the image itself
+		const plainSource = (img) => { // an image as a sampled source: a pending ToRGBA of a wire-format frame, or the image itself
 			const p = img._producer
-			// a pending ToRGBA of a v210 frame, or of a planar 10-bit 4:2:2 one (yuv422p10le: what file decoders hand over,
-			// ffmpegProducer.ts:410-412; its Loader recipe is the v210 one, the packing does not enter the matrix)
-			const planar = p && p.state === 'pending' && p.program.name === 'read' && p.program.format === 'yuv422p10'
-			if (p && p.state === 'pending' && (planar || Deferral._isV210(p.program, 'read'))) {
+			// v210 (SDI), or a planar frame as file decoders hand them over (ffmpegProducer.ts:398-412)
+			const fmt = p && p.state === 'pending' && p.program.name === 'read' ? p.program.format : null
+			if (fmt === 'v210' || PLANAR[fmt]) {
 				const r = { colMatrix: p.params.colMatrix, gammaLut: p.params.gammaLut, gamutMatrix: p.params.gamutMatrix }
 				const f = Deferral._frameOf(p)
-				const planes = planar ? p.params.inputY && p.params.inputU && p.params.inputV && f.width % 2 === 0 : p.params.input && f.width % 6 === 0
-				const ok = r.colMatrix && r.gammaLut && r.gamutMatrix && planes && img.imageDims &&
-					f.width === img.imageDims.width && f.lines === img.imageDims.height && (!reader || Deferral.sameRecipe(reader, r))
+				const q = p.params
+				const planes = fmt === 'v210' ? q.input && f.width % 6 === 0
+					: q.inputY && (fmt === 'nv12' ? q.inputC : q.inputU && q.inputV) && f.width % 2 === 0 && (fmt === 'yuv422p10' || fmt === 'yuv422p8' || f.lines % 2 === 0)
+				const ok = r.colMatrix && r.gammaLut && r.gamutMatrix && planes && img.imageDims && f.width === img.imageDims.width && f.lines === img.imageDims.height &&
+					(!reader || (Deferral.same(reader.gammaLut, r.gammaLut) && Deferral.same(reader.gamutMatrix, r.gamutMatrix))) &&
+					(fmt !== 'v210' || !packedCm || Deferral.same(packedCm, r.colMatrix))
 				if (ok) {
 					reader = reader || r
+					if (fmt === 'v210') packedCm = packedCm || r.colMatrix
 					used.add(p)
-					return planar ? { source: p.params.inputY, u: p.params.inputU, v: p.params.inputV, width: f.width, height: f.lines, v210: true, planar: true }
-						: { source: p.params.input, width: f.width, height: f.lines, v210: true }
+					return fmt === 'v210' ? { source: q.input, width: f.width, height: f.lines, v210: true }
+						: { source: q.inputY, u: fmt === 'nv12' ? q.inputC : q.inputU, v: fmt === 'nv12' ? null : q.inputV, cm: r.colMatrix, packing: PLANAR[fmt], width: f.width, height: f.lines, v210: true, planar: true }
 				}
 			}
 			return materialised(img)
@@ -388,12 +396,17 @@ class Deferral {
 			layers.forEach((l, i) => { params[`l${i}In`] = l.source; params[`l${i}Matrix`] = l.matrix })
 			candidates.push([`compose_up_write_v210_${n}`, params])
 		}
-		const loader = reader || this.lastReader // the channel kernel wants a Loader recipe even if no layer turns out to need it
+		const loader = reader ? { colMatrix: packedCm || reader.colMatrix, gammaLut: reader.gammaLut, gamutMatrix: reader.gamutMatrix } : this.lastReader // the channel kernel wants a Loader recipe even if no layer turns out to need it
 		if (loader) {
 			const params = Object.assign({ output, interlace }, loader, saver)
 			const put = (prefix, s) => {
 				params[`${prefix}In`] = s.source
-				if (s.planar) { params[`${prefix}InU`] = s.u; params[`${prefix}InV`] = s.v }
+				if (s.planar) {
+					params[`${prefix}Packing`] = s.packing
+					params[`${prefix}InU`] = s.u
+					if (s.v) params[`${prefix}InV`] = s.v
+					if (!Deferral.same(s.cm, loader.colMatrix)) params[`${prefix}ColMatrix`] = s.cm
+				}
 				if (s.matrix) params[`${prefix}Matrix`] = s.matrix
 				if (s.v210) { params[`${prefix}Width`] = s.width; params[`${prefix}Height`] = s.height }
 			}

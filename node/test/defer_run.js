@@ -35,7 +35,8 @@ async function side(deferred) {
 	const s = { rig, deferred }
 	s.read = await rig.unpack('v210', W, H, '709', '709')
 	s.readHalf = await rig.unpack('v210', W / 2, H / 2, '709', '709')
-	s.readP10 = await rig.unpack('yuv422p10', W, H, '709', '709')
+	s.readAs = {}
+	for (const fmt of ['yuv422p10', 'yuv422p8', 'yuv420p', 'nv12']) s.readAs[fmt] = await rig.unpack(fmt, W, H, '709', '709')
 	s.write = await rig.pack('v210', W, H, '709', false)
 	s.writeField = await rig.pack('v210', W, H, '709', true)
 	s.combine = {}
@@ -52,13 +53,14 @@ async function side(deferred) {
 		await rig.upload(p[0], bytes)
 		return p[0]
 	}
-	// a planar 10-bit 4:2:2 frame (three planes) on the device, every 10-bit code
-	s.sourceP10 = async (seed) => {
-		const planes = await rig.planes('yuv422p10', W, H)
+	// a planar frame on the device: every 10-bit code in 16-bit samples, or every byte
+	s.sourcePlanar = async (fmt, seed) => {
+		const planes = await rig.planes(fmt, W, H)
 		const r = lcg(seed)
 		for (const p of planes) {
 			const b = Buffer.alloc(p.length)
-			for (let i = 0; i + 2 <= b.length; i += 2) b.writeUInt16LE((r() >>> 8) % 1024, i)
+			if (fmt === 'yuv422p10') for (let i = 0; i + 2 <= b.length; i += 2) b.writeUInt16LE((r() >>> 8) % 1024, i)
+			else for (let i = 0; i < b.length; ++i) b[i] = (r() >>> 8) & 255
 			await rig.upload(p, b)
 		}
 		return planes
@@ -372,31 +374,36 @@ async function main() {
 		return seen
 	}, { fused: 1, plain: 0, fallbacks: 1 })
 
-	// file sources: yuv422p10le frames (what a ProRes / DNxHD decoder hands over) beside a v210 one, placed, combined, packed
-	await scenario('planar 10-bit sources', async (s) => {
+	// file sources: planar frames as decoders hand them over - 10-bit 4:2:2 (the v210 Loader recipe) and the 8-bit formats (a Loader
+	// matrix of their own) - beside a v210 one, placed, combined, packed
+	await scenario('planar sources of every format', async (s) => {
 		s.frame = 7
-		const a = await s.sourceP10(800)
-		const b = await s.sourceP10(801)
-		const c = await s.source(v210Frame(full, 802))
-		const ua = await s.rig.image(W, H)
-		const ub = await s.rig.image(W, H)
-		const uc = await s.rig.image(W, H)
-		s.rig.post(s.id('A'), s.readP10(a, ua), () => a.forEach((p) => p.release()))
-		s.rig.post(s.id('B'), s.readP10(b, ub), () => b.forEach((p) => p.release()))
-		s.rig.post(s.id('C'), s.read([c], uc), () => c.release())
-		const pb = await s.rig.image(W, H)
-		const pc = await s.rig.image(W, H)
-		s.rig.post(s.id('B'), s.transform(ub, pb, await s.transform.matrix(PIP[1])), () => ub.release())
-		s.rig.post(s.id('C'), s.transform(uc, pc, await s.transform.matrix({ scaleX: 0.6, scaleY: 0.6, rotate: -0.08, offsetX: 0.15 })), () => uc.release())
-		const comb = await s.rig.image(W, H)
-		s.rig.post(s.id('mix'), s.combine[3]([ua, pb, pc], comb), () => [ua, pb, pc].forEach((x) => x.release()))
-		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
-		s.rig.post(s.id('mix'), s.write(comb, [out], 0), () => comb.release())
-		for (const k of ['A', 'B', 'C', 'mix']) await s.flush(s.id(k))
-		const seen = [await s.consume(out)]
-		out.release()
+		const seen = []
+		for (const [fa, fb] of [['yuv422p10', 'yuv420p'], ['nv12', 'yuv422p8']]) {
+			const a = await s.sourcePlanar(fa, 800)
+			const b = await s.sourcePlanar(fb, 801)
+			const c = await s.source(v210Frame(full, 802))
+			const ua = await s.rig.image(W, H)
+			const ub = await s.rig.image(W, H)
+			const uc = await s.rig.image(W, H)
+			s.rig.post(s.id('A'), s.readAs[fa](a, ua), () => a.forEach((p) => p.release()))
+			s.rig.post(s.id('B'), s.readAs[fb](b, ub), () => b.forEach((p) => p.release()))
+			s.rig.post(s.id('C'), s.read([c], uc), () => c.release())
+			const pb = await s.rig.image(W, H)
+			const pc = await s.rig.image(W, H)
+			s.rig.post(s.id('B'), s.transform(ub, pb, await s.transform.matrix(PIP[1])), () => ub.release())
+			s.rig.post(s.id('C'), s.transform(uc, pc, await s.transform.matrix({ scaleX: 0.6, scaleY: 0.6, rotate: -0.08, offsetX: 0.15 })), () => uc.release())
+			const comb = await s.rig.image(W, H)
+			s.rig.post(s.id('mix'), s.combine[3]([ua, pb, pc], comb), () => [ua, pb, pc].forEach((x) => x.release()))
+			const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+			s.rig.post(s.id('mix'), s.write(comb, [out], 0), () => comb.release())
+			for (const k of ['A', 'B', 'C', 'mix']) await s.flush(s.id(k))
+			seen.push(await s.consume(out))
+			out.release()
+			s.frame++
+		}
 		return seen
-	}, { fused: 1, plain: 0, launched: 1, fallbacks: 0 })
+	}, { fused: 2, plain: 0, launched: 2, fallbacks: 0 })
 
 	process.stdout.write(JSON.stringify({ width: W, height: H, scenarios, problems }) + '\n')
 }

@@ -70,7 +70,7 @@ class PhFieldLayer(C.Structure):
 
 class PhChanSource(C.Structure):
     _fields_ = [("data", C.c_void_p), ("format", C.c_int), ("width", C.c_int), ("height", C.c_int),
-                ("matrix9_host", C.POINTER(C.c_float)), ("data_u", C.c_void_p), ("data_v", C.c_void_p)]
+                ("matrix9_host", C.POINTER(C.c_float)), ("data_u", C.c_void_p), ("data_v", C.c_void_p), ("col_matrix12", C.c_void_p)]
 
 
 class PhChanLayer(C.Structure):
@@ -82,7 +82,8 @@ class PhImageLayer(C.Structure):
 
 
 IMG_RGBA_F32, IMG_RGB_F32 = 0, 1
-SRC_V210, SRC_RGBA_F32, SRC_YUV422P10 = 1, 2, 3
+SRC_V210, SRC_RGBA_F32, SRC_YUV422P10, SRC_YUV422P8, SRC_YUV420P, SRC_NV12 = 1, 2, 3, 4, 5, 6
+SRC_PLANAR = {"yuv422p10": SRC_YUV422P10, "yuv422p8": SRC_YUV422P8, "yuv420p": SRC_YUV420P, "nv12": SRC_NV12}
 TRANSITION_CUT, TRANSITION_DISSOLVE, TRANSITION_WIPE = 0, 1, 2
 
 
@@ -468,8 +469,8 @@ class Context:
         """The channel compositor straight from v210 sources (ph_chan_compose_v210).  layers: list of dicts
         {src: SOURCE, transition: "cut" | "dissolve" | "wipe", mix: float, incoming: SOURCE, mask: SOURCE}; a SOURCE is
         (tensor, width, height, matrix) or (tensor, width, height, matrix, "rgba") or ((y, u, v) plane tensors, width, height,
-        matrix, "yuv422p10") - matrix: nine host floats (transform_matrix) or None for 1:1; format v210 unless "rgba" (f32 RGBA
-        image) or "yuv422p10" (planar 4:2:2, 16-bit samples)."""
+        matrix, "yuv422p10" | "yuv422p8" | "yuv420p" | "nv12"[, own Loader matrix tensor]) - matrix: nine host floats
+        (transform_matrix) or None for 1:1; format v210 unless "rgba" (f32 RGBA image) or a planar pack format."""
         import numpy as np
         arr = (PhChanLayer * len(layers))()
         keep = []
@@ -477,12 +478,16 @@ class Context:
         def fill(dst_src, spec):
             t, w, h, m = spec[:4]
             kind = spec[4] if len(spec) > 4 else "v210"
-            if kind == "yuv422p10":
-                dst_src.data, dst_src.data_u, dst_src.data_v = (_ptr(p).value for p in t)
+            if kind in SRC_PLANAR:  # t: the planes (nv12: two); an optional sixth element: the source's own Loader matrix (device)
+                planes = [_ptr(p).value for p in t]
+                dst_src.data, dst_src.data_u = planes[0], planes[1]
+                dst_src.data_v = planes[2] if len(planes) > 2 else None
+                if len(spec) > 5 and spec[5] is not None:
+                    dst_src.col_matrix12 = _ptr(spec[5]).value
             else:
                 dst_src.data = _ptr(t).value
             dst_src.width, dst_src.height = w, h
-            dst_src.format = {"rgba": SRC_RGBA_F32, "yuv422p10": SRC_YUV422P10}.get(kind, SRC_V210)
+            dst_src.format = SRC_PLANAR.get(kind, SRC_RGBA_F32 if kind == "rgba" else SRC_V210)
             if m is not None:
                 mh = np.ascontiguousarray(m, np.float32)
                 keep.append(mh)

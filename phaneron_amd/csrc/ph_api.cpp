@@ -1105,28 +1105,40 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
           s->format = PH_SRC_RGBA_F32, sw = x->width, sh = x->height;
         } else {
           s->format = PH_SRC_V210;
-          s->data_u = s->data_v = nullptr;
-          snprintf(nm, sizeof nm, "l%d%sInU", i, role);
-          if (find_arg(args, n, nm)) {  // a planar 4:2:2 source of 16-bit samples: l<i>In is its Y plane, l<i>InU / l<i>InV its chroma planes
-            ph_buf *pu = nullptr, *pv = nullptr;
-            TRY(need_buf(args, n, nm, 0, &pu));
-            snprintf(nm, sizeof nm, "l%d%sInV", i, role);
-            TRY(need_buf(args, n, nm, 0, &pv));
-            s->format = PH_SRC_YUV422P10, s->data_u = pu->dptr, s->data_v = pv->dptr;
+          s->data_u = s->data_v = nullptr, s->col_matrix12 = nullptr;
+          // a planar source: l<i>Packing = its PH_FMT_* (1 yuv422p10, 2 yuv422p8, 3 yuv420p, 4 nv12), l<i>In its Y plane, l<i>InU /
+          // l<i>InV its chroma planes (nv12: l<i>InU the CbCr plane), l<i>ColMatrix (optional) its own Loader matrix
+          double packing = 0;
+          snprintf(nm, sizeof nm, "l%d%sPacking", i, role);
+          if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &packing));
+          if (packing != 0) {
+            if (packing < PH_FMT_YUV422P10 || packing > PH_FMT_NV12) return fail(PH_E_INVALID, "kernel argument '%s': %g is not a planar pack format", nm, packing);
+            s->format = PH_SRC_YUV422P10 + ((int)packing - PH_FMT_YUV422P10);
           }
           snprintf(nm, sizeof nm, "l%d%sWidth", i, role);
           if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sw));
           snprintf(nm, sizeof nm, "l%d%sHeight", i, role);
           if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sh));
-          if (s->format == PH_SRC_YUV422P10) {
+          if (s->format != PH_SRC_V210) {
+            const int fmt = PH_FMT_YUV422P10 + (s->format - PH_SRC_YUV422P10);
             size_t pb[3] = {0, 0, 0};
-            if (sw > 0 && sh > 0) ph_pack_plane_bytes(PH_FMT_YUV422P10, (uint32_t)sw, (uint32_t)sh, pb);
-            char nu[40], nv[40];
-            snprintf(nu, sizeof nu, "l%d%sInU", i, role), snprintf(nv, sizeof nv, "l%d%sInV", i, role);
-            ph_buf *pu = nullptr, *pv = nullptr;
+            if (sw > 0 && sh > 0) ph_pack_plane_bytes(fmt, (uint32_t)sw, (uint32_t)sh, pb);
+            char nu[40];
+            ph_buf *pu = nullptr, *pv = nullptr, *pm = nullptr;
+            snprintf(nu, sizeof nu, "l%d%sInU", i, role);
             TRY(need_buf(args, n, nu, pb[1], &pu));
-            TRY(need_buf(args, n, nv, pb[2], &pv));
-            if (x->bytes < pb[0]) return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than the Y plane of a %gx%g yuv422p10 frame", i, role, x->bytes, sw, sh);
+            s->data_u = pu->dptr;
+            if (fmt != PH_FMT_NV12) {
+              snprintf(nu, sizeof nu, "l%d%sInV", i, role);
+              TRY(need_buf(args, n, nu, pb[2], &pv));
+              s->data_v = pv->dptr;
+            }
+            snprintf(nu, sizeof nu, "l%d%sColMatrix", i, role);
+            if (find_arg(args, n, nu)) {
+              TRY(need_buf(args, n, nu, 48, &pm));
+              s->col_matrix12 = pm->dptr;
+            }
+            if (x->bytes < pb[0]) return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than the Y plane of a %gx%g frame", i, role, x->bytes, sw, sh);
           } else if (sw > 0 && sh > 0 && x->bytes < (size_t)ph_v210_pitch_bytes((uint32_t)sw) * (size_t)sh)
             return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than a %gx%g v210 frame", i, role, x->bytes, sw, sh);
         }
@@ -1608,26 +1620,28 @@ static int compose_write(ph_ctx *ctx, int queue, int n, const ph_layer *layers, 
 }
 
 static int chan_source(const ph_chan_source &s, const char *what, int layer, uint32_t out_w, uint32_t out_h, ph::ChanSrc *o, const void **pu,
-                       const void **pv, uint32_t *planar) {
+                       const void **pv, const float **cm, uint32_t *planar) {
   if (!s.data || s.width <= 0 || s.height <= 0)
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is empty", layer, what);
-  if (s.format != PH_SRC_V210 && s.format != PH_SRC_RGBA_F32 && s.format != PH_SRC_YUV422P10)
-    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has format %d (PH_SRC_V210, PH_SRC_RGBA_F32 or PH_SRC_YUV422P10)", layer, what, s.format);
-  *pu = *pv = nullptr;
-  if (s.format == PH_SRC_YUV422P10) {
-    if (!s.data_u || !s.data_v || (s.width & 1))
-      return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is planar 4:2:2 and needs its two chroma planes and an even width", layer, what);
-    *pu = s.data_u, *pv = s.data_v, *planar = 1;
+  const bool is_planar = s.format >= PH_SRC_YUV422P10 && s.format <= PH_SRC_NV12;
+  if (s.format != PH_SRC_V210 && s.format != PH_SRC_RGBA_F32 && !is_planar)
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has format %d (PH_SRC_V210, PH_SRC_RGBA_F32 or a planar PH_SRC_*)", layer, what, s.format);
+  *pu = *pv = nullptr, *cm = nullptr;
+  if (is_planar) {
+    if (!s.data_u || (s.format != PH_SRC_NV12 && !s.data_v) || (s.width & 1) || ((s.format == PH_SRC_YUV420P || s.format == PH_SRC_NV12) && (s.height & 1)))
+      return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is planar: it needs its chroma plane(s), an even width and, for 4:2:0, an even height", layer, what);
+    *pu = s.data_u, *pv = s.data_v, *cm = (const float *)s.col_matrix12, *planar = 1;
   }
   if (s.format == PH_SRC_V210 && s.width % 6)
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is a v210 frame %d wide, not a multiple of 6; run the separate kernels", layer, what, s.width);
   if (!s.matrix9_host && ((uint32_t)s.width != out_w || (uint32_t)s.height != out_h))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has no transform but is %dx%d, not the output size", layer, what, s.width, s.height);
   o->ptr = s.data, o->w = (uint32_t)s.width, o->h = (uint32_t)s.height;
-  o->kind = s.format == PH_SRC_V210 ? ph::kChanV210 : s.format == PH_SRC_YUV422P10 ? ph::kChanP10 : ph::kChanRgba;
-  // planar 4:2:2: the luma line pitch in samples is the width rounded up to 8 (yuv422p10.ts:221), two bytes each
+  static const uint32_t kinds[] = {ph::kChanNone, ph::kChanV210, ph::kChanRgba, ph::kChanP10, ph::kChanP8x422, ph::kChanP8x420, ph::kChanNv12};
+  o->kind = kinds[s.format];
+  // planar: the luma line pitch in samples is the width rounded up to 8 (yuv422p10.ts:221), one or two bytes each
   o->pitch = s.format == PH_SRC_V210 ? ph_v210_pitch_bytes((uint32_t)s.width)
-             : s.format == PH_SRC_YUV422P10 ? (((uint32_t)s.width + 7u) & ~7u) * 2u : (uint32_t)s.width * 16u;
+             : is_planar ? (((uint32_t)s.width + 7u) & ~7u) * (s.format == PH_SRC_YUV422P10 ? 2u : 1u) : (uint32_t)s.width * 16u;
   if ((uint64_t)o->pitch * o->h >= (1ull << 30))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is 1 GiB or larger; run the separate kernels", layer, what);
   o->sampled = s.matrix9_host ? 1u : 0u;
@@ -1651,20 +1665,20 @@ int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *lay
   for (int i = 0; i < n; ++i) {
     const ph_chan_layer &L = layers[i];
     const uint32_t first = i == 0 ? ph::kChanActFirst : 0u;
-    int rc = chan_source(L.src, "source", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.planar);
+    int rc = chan_source(L.src, "source", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.cm_op[k], &a.planar);
     if (rc) return rc;
     if (L.transition == PH_TRANSITION_CUT) {
       a.op[k++].action = ph::kChanActLayer | first;
     } else if (L.transition == PH_TRANSITION_DISSOLVE || L.transition == PH_TRANSITION_WIPE) {
       a.op[k++].action = ph::kChanActHold;
-      rc = chan_source(L.incoming, "transition's incoming source", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.planar);
+      rc = chan_source(L.incoming, "transition's incoming source", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.cm_op[k], &a.planar);
       if (rc) return rc;
       if (L.transition == PH_TRANSITION_DISSOLVE) {
         a.op[k].mix = L.mix;
         a.op[k++].action = ph::kChanActDissolve | first;
       } else {
         a.op[k++].action = ph::kChanActIncoming;
-        rc = chan_source(L.mask, "wipe's mask", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.planar);
+        rc = chan_source(L.mask, "wipe's mask", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.cm_op[k], &a.planar);
         if (rc) return rc;
         a.op[k++].action = ph::kChanActWipe | first;
       }

@@ -54,12 +54,14 @@ struct ComposeArgs {
 };
 
 // ph_kernels_chan.hip: the compositor that samples v210 sources directly
-enum : uint32_t { kChanNone = 0, kChanV210 = 1, kChanRgba = 2, kChanP10 = 3 };
+// planar YCbCr sources: 4:2:2 with 16-bit samples (yuv422p10le), 4:2:2 and 4:2:0 with 8-bit samples (yuv422p8, yuv420p), 4:2:0 with
+// interleaved chroma (nv12); ptr = the Y plane, ChanArgs::plane_u / plane_v the chroma planes (nv12: plane_u holds CbCr pairs)
+enum : uint32_t { kChanNone = 0, kChanV210 = 1, kChanRgba = 2, kChanP10 = 3, kChanP8x422 = 4, kChanP8x420 = 5, kChanNv12 = 6 };
 enum : uint32_t { kChanCut = 0, kChanDissolve = 1, kChanWipe = 2 };
 struct ChanSrc {
   const void *ptr;
   uint32_t w, h, pitch;  // pixels, pixels, bytes per line
-  uint32_t kind;         // kChanV210 / kChanRgba / kChanP10 (planar 4:2:2, 16-bit samples: ptr = the Y plane, ChanArgs::plane_u / plane_v) (kChanNone: absent)
+  uint32_t kind;         // kChanV210 / kChanRgba / a planar kind (kChanNone: absent)
   uint32_t sampled;      // 1 = through m (transform.ts:53-57), 0 = pixel for pixel
   uint32_t pad;
   float m[6];            // rows 0 and 1 of the 3x3 transform matrix
@@ -83,9 +85,11 @@ struct ChanArgs {
   uint32_t out_w, out_h, lines, first_line, line_step;
   const float *rd_cm, *rd_gm, *wr_cm;
   LutView rd, wr;
-  // kChanP10 sources: the chroma planes of op k (read by the planar instantiation of the kernel only)
+  // planar sources: the chroma planes of op k and, where the source has a Loader matrix of its own (8-bit code ranges), that
+  // matrix (12 floats, device; NULL = rd_cm) - read by the planar instantiation of the kernel only
   const void *plane_u[kMaxChanOps], *plane_v[kMaxChanOps];
-  uint32_t planar;  // launcher: some op is kChanP10
+  const float *cm_op[kMaxChanOps];
+  uint32_t planar;  // launcher: some op is planar
 };
 
 // ph_kernels_up.hip: the 2 x 2-block compositor for magnifying placements

@@ -128,35 +128,55 @@ __device__ __forceinline__ float4 rgba_load(__amdgpu_buffer_rsrc_t img, uint32_t
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// ---- a planar 4:2:2 source with 16-bit samples (yuv422p10le: yuv422p10.ts:60-72) ------------------------------------------
-// Y at plane 0 [row][x], Cb / Cr at planes 1 / 2 [row][x / 2]; the reader's arithmetic from there on is ToRGBA's own
-// (read_px_issue), with the sample taken as it is (the reference converts the whole 16-bit word, yuv422p10.ts:66-68).
-// A tap is three 2-byte buffer loads; taps outside the frame get offsets beyond every plane and load 0.
-struct P10Planes {
+// ---- planar YCbCr sources (what file decoders hand over: ffmpegProducer.ts:398-412) -----------------------------------------------
+//   kChanP10    yuv422p10le  Y [row][x], Cb / Cr [row][x / 2], 16-bit samples        yuv422p10.ts:60-72
+//   kChanP8x422 yuv422p8     the same with 8-bit samples                             yuv422p8.ts
+//   kChanP8x420 yuv420p      Cb / Cr [row / 2][x / 2], 8-bit                          yuv420p.ts
+//   kChanNv12   nv12         Cb, Cr interleaved in one plane [row / 2][x / 2]         nv12.ts:61-74
+// The reader's arithmetic from the three samples on is ToRGBA's own (read_px_issue), the sample taken as it is (the reference
+// converts the whole 8- or 16-bit word).  A tap is three 1- or 2-byte buffer loads; taps outside the frame get offsets beyond
+// every plane and load 0.  Everything that depends on the kind is uniform.
+struct Planes {
   __amdgpu_buffer_rsrc_t y, u, v;
+  uint32_t pitch_y, pitch_c;  // bytes per line of the Y plane / of a chroma plane
+  uint32_t wide;              // 1: 16-bit samples
+  uint32_t vshift;            // 1: a chroma line serves two luma lines
+  uint32_t nv12;              // 1: u holds CbCr pairs (v is u)
 };
-__device__ __forceinline__ V210Words p10_load(const P10Planes &pl, uint32_t row_y, uint32_t row_c, uint32_t col) {  // col: the pixel's column, or kOutsideBit
-  const uint32_t oy = row_y + (col << 1), oc = row_c + (col & ~1u);  // 2 bytes per sample; the pair's chroma sample
-  return V210Words{(uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(pl.y, (int)oy, 0, 0),
-                   (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(pl.u, (int)oc, 0, 0),
-                   (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(pl.v, (int)oc, 0, 0)};
+__device__ __forceinline__ Planes planes_of(const ChanSrc &s, const void *pu, const void *pv) {
+  Planes pl;
+  pl.wide = s.kind == kChanP10 ? 1u : 0u, pl.vshift = (s.kind == kChanP8x420 || s.kind == kChanNv12) ? 1u : 0u, pl.nv12 = s.kind == kChanNv12 ? 1u : 0u;
+  pl.pitch_y = s.pitch, pl.pitch_c = pl.nv12 ? s.pitch : s.pitch >> 1;
+  const uint32_t crows = (s.h + pl.vshift) >> pl.vshift;
+  pl.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(pl.pitch_y * s.h), 0x00020000);
+  pl.u = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(pu), 0, (int)(pl.pitch_c * crows), 0x00020000);
+  pl.v = pl.nv12 ? pl.u : __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(pv), 0, (int)(pl.pitch_c * crows), 0x00020000);
+  return pl;
+}
+__device__ __forceinline__ V210Words planar_load(const Planes &pl, uint32_t row, uint32_t col) {  // row inside the frame; col: the pixel's column, or kOutsideBit
+  const uint32_t oy = __umul24(row, pl.pitch_y) + (col << pl.wide);
+  // the pair's chroma sample: planar [x / 2] samples of 1 or 2 bytes, nv12 [x / 2] pairs of bytes (Cb first)
+  const uint32_t ocb = __umul24(row >> pl.vshift, pl.pitch_c) + (pl.nv12 ? (col & ~1u) : ((col >> 1) << pl.wide)), ocr = ocb + pl.nv12;
+  if (pl.wide)
+    return V210Words{(uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(pl.y, (int)oy, 0, 0),
+                     (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(pl.u, (int)ocb, 0, 0),
+                     (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(pl.v, (int)ocr, 0, 0)};
+  return V210Words{(uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(pl.y, (int)oy, 0, 0),
+                   (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(pl.u, (int)ocb, 0, 0),
+                   (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(pl.v, (int)ocr, 0, 0)};
 }
 template <bool STD>
-__device__ __forceinline__ PxPending p10_issue(const V210Words &w, const ReadK &k, const LutK &lut) {
+__device__ __forceinline__ PxPending planar_issue(const V210Words &w, const ReadK &k, const LutK &lut) {
   return read_px_issue<STD>((float)w.wy, (float)w.wcb, (float)w.wcr, k, lut);
 }
 template <bool STD>
-__device__ __forceinline__ void chan_sample_p10(const ChanSrc &s, const void *pu, const void *pv, float px, const float (&py)[kChanP], uint32_t x,
-                                                const uint32_t (&line)[kChanP], const ReadK &k, const LutK &lut, float4 (&out)[kChanP]) {
-  const uint32_t pitch_c = s.pitch >> 1;
-  P10Planes pl;
-  pl.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(s.pitch * s.h), 0x00020000);
-  pl.u = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(pu), 0, (int)(pitch_c * s.h), 0x00020000);
-  pl.v = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(pv), 0, (int)(pitch_c * s.h), 0x00020000);
+__device__ __forceinline__ void chan_sample_planar(const ChanSrc &s, const void *pu, const void *pv, float px, const float (&py)[kChanP], uint32_t x,
+                                                   const uint32_t (&line)[kChanP], const ReadK &k, const LutK &lut, float4 (&out)[kChanP]) {
+  const Planes pl = planes_of(s, pu, pv);
   if (!s.sampled) {
     PxPending pend[kChanP];
 #pragma unroll
-    for (int p = 0; p < kChanP; ++p) pend[p] = p10_issue<STD>(p10_load(pl, __umul24(line[p], s.pitch), __umul24(line[p], pitch_c), x), k, lut);
+    for (int p = 0; p < kChanP; ++p) pend[p] = planar_issue<STD>(planar_load(pl, line[p], x), k, lut);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < kChanP; ++p) out[p] = read_px_finish(pend[p], k);
@@ -183,11 +203,11 @@ __device__ __forceinline__ void chan_sample_p10(const ChanSrc &s, const void *pu
     for (int i = 0; i < 4; ++i) {
       const uint32_t row = t[p].j0 + (uint32_t)(i >> 1), col = t[p].i0 + (uint32_t)(i & 1);
       in[i] = ci[i & 1] && ri[i >> 1];
-      w[i] = p10_load(pl, __umul24(row, s.pitch), __umul24(row, pitch_c), in[i] ? col : kOutsideBit);  // rows inside are below 2^24: the 24-bit product is exact where it is used
+      w[i] = planar_load(pl, in[i] ? row : 0u, in[i] ? col : kOutsideBit);  // (rows inside are below 2^24: the 24-bit products are exact)
     }
     PxPending pend[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pend[i] = p10_issue<STD>(w[i], k, lut);
+    for (int i = 0; i < 4; ++i) pend[i] = planar_issue<STD>(w[i], k, lut);
     __builtin_amdgcn_sched_barrier(0);
     float4 q[4];
 #pragma unroll
@@ -437,8 +457,15 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
     for (int k = 0; k < a.n_ops; ++k) {
       const ChanOp op = a.op[k];
       float4 v[kChanP];
-      if (PLANAR && op.src.kind == kChanP10) chan_sample_p10<STD>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, rk, rlut, v);  // uniform
-      else chan_sample<STD>(op.src, px, py, x, line, rk, rlut, v);
+      if (PLANAR && op.src.kind >= kChanP10) {  // uniform
+        // a source with code ranges of its own (8-bit) brings its Loader matrix: the general dot products serve any matrix and give
+        // the same bits as the short form where that applies (its missing terms are exact zeros)
+        const float *cm = a.cm_op[k];
+        if (cm) chan_sample_planar<false>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, load_read_k(cm, a.rd_gm), rlut, v);
+        else chan_sample_planar<STD>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, rk, rlut, v);
+      } else {
+        chan_sample<STD>(op.src, px, py, x, line, rk, rlut, v);
+      }
 #pragma unroll
       for (int p = 0; p < kChanP; ++p) chan_apply(op, v[p], acc[p]);
     }

@@ -21,12 +21,13 @@ def colour(rspec, wspec):
 class Src:
     """one source on both sides: the oracle's RGBA (read, then placed) and the tuple the binding takes"""
 
-    def __init__(self, data, w, h, matrix=None, fmt="v210"):
-        self.data, self.w, self.h, self.matrix, self.fmt = data, w, h, matrix, fmt
+    def __init__(self, data, w, h, matrix=None, fmt="v210", spec="709"):
+        self.data, self.w, self.h, self.matrix, self.fmt, self.spec = data, w, h, matrix, fmt, spec  # spec: the reader's colour space (8-bit planar sources make their own matrix for it)
 
     def oracle(self, rd_o, ow, oh):
-        if self.fmt == "yuv422p10":  # data: the three planes; the Loader recipe of a 10-bit 4:2:2 source is the v210 one
-            img = orc.pack_read("yuv422p10", [np.ascontiguousarray(p).view(np.uint8) for p in self.data], self.w, self.h, *rd_o)
+        if self.fmt in orc.FORMATS and self.fmt != "v210":  # data: the planes; a 10-bit 4:2:2 source shares the v210 Loader matrix, 8-bit ones have their own
+            cm = rd_o[0] if self.fmt == "yuv422p10" else orc.ycbcr2rgb_matrix(self.spec, *orc.FORMAT_RANGE[self.fmt])
+            img = orc.pack_read(self.fmt, [np.ascontiguousarray(p).view(np.uint8) for p in self.data], self.w, self.h, cm, rd_o[1], rd_o[2])
         else:
             img = orc.v210_read(self.data, self.w, self.h, *rd_o) if self.fmt == "v210" else self.data.reshape(self.h, self.w, 4)
         if self.matrix is None:
@@ -36,8 +37,10 @@ class Src:
 
     def device(self):
         import hip_harness as hh
-        if self.fmt == "yuv422p10":
-            return (tuple(hh.dev(np.ascontiguousarray(p).reshape(-1)) for p in self.data), self.w, self.h, self.matrix, "yuv422p10")
+        if self.fmt in orc.FORMATS and self.fmt != "v210":
+            from phaneron_amd import capi
+            own = None if self.fmt == "yuv422p10" else hh.dev(capi.ycbcr2rgb_matrix(self.spec, *orc.FORMAT_RANGE[self.fmt]))
+            return (tuple(hh.dev(np.ascontiguousarray(p).reshape(-1)) for p in self.data), self.w, self.h, self.matrix, self.fmt, own)
         t = hh.dev(self.data.reshape(-1))
         return (t, self.w, self.h, self.matrix) + (("rgba",) if self.fmt == "rgba" else ())
 
@@ -347,3 +350,22 @@ def test_planar_ten_bit_sources():
               dict(src=Src(rgba, w, h, fmt="rgba"), transition="wipe", incoming=Src(p[3], w, h, fmt="yuv422p10"), mask=Src(p[0], w, h, m(w, h, scale_x=2.0, scale_y=2.0), fmt="yuv422p10"))]
     check(layers, w, h, "planar sources inside transitions")
     check(layers, w, h, "planar sources inside transitions, field 3", interlace=3, poison_dst=True)
+
+
+@pytest.mark.parametrize("fmt", ["yuv422p8", "yuv420p", "nv12"])
+def test_planar_eight_bit_sources(fmt):
+    """the 8-bit planar formats of file decoders (ffmpegProducer.ts:398-408) as sources: their code ranges are not the 10-bit ones, so
+    each brings its own Loader matrix (col_matrix12) while the gamma table and the gamut matrix are the call's - pixel for pixel,
+    placed (4:2:0: a chroma line serves two luma lines, also across the bilinear taps), odd sizes' padded lines, beside v210 and
+    planar 10-bit layers, inside a dissolve; against the oracle's reader of that format followed by the chain"""
+    w, h = 384, 54
+    a = frames.pack_random(fmt, w, h, 400)
+    b = frames.pack_random(fmt, 204, 38, 401)  # lines padded to a multiple of 8 samples
+    v = frames.v210_random(w, h, frames.layer_seed(99, 0))
+    p10 = frames.pack_random("yuv422p10", w, h, 402)
+    check([dict(src=Src(a, w, h, fmt=fmt))], w, h, "%s pixel for pixel" % fmt)
+    check([dict(src=Src(a, w, h, fmt=fmt, spec="709")), dict(src=Src(b, 204, 38, m(w, h, scale_x=0.5, scale_y=0.7, offset_x=-0.2, rotate=0.03), fmt=fmt)),
+           dict(src=Src(v, w, h, m(w, h, **PIP[2]))), dict(src=Src(p10, w, h, m(w, h, **PIP[3]), fmt="yuv422p10"))], w, h, "%s beside v210 and yuv422p10" % fmt)
+    layers = [dict(src=Src(v, w, h)), dict(src=Src(a, w, h, m(w, h), fmt=fmt), transition="dissolve", mix=0.3, incoming=Src(b, 204, 38, m(w, h, scale_x=1.7, scale_y=1.7), fmt=fmt))]
+    check(layers, w, h, "%s inside a dissolve" % fmt)
+    check(layers, w, h, "%s inside a dissolve, 709 -> 2020, field 1" % fmt, interlace=1, poison_dst=True, specs=("709", "2020"))

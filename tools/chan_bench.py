@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 2 through ph_chan_compose_v210 alone (one launch per frame): the timing loop tools/pmc_kernel.sh profiles.
-  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets] [sources: v210|yuv422p10]"""
+  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets] [sources: v210|yuv422p10|yuv422p8|yuv420p|nv12]"""
 import json
 import os
 import sys
@@ -29,11 +29,16 @@ def main():
     words = capi.v210_pitch_bytes(w) * h // 4
     src = [[torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device="cuda") for _ in range(6)] for _ in range(R)]
     out = torch.empty(words, dtype=torch.int32, device="cuda")
-    if packing == "yuv422p10":
+    kind = ()
+    if packing != "v210":  # planar sources (file decoders' formats); the 8-bit ones bring a Loader matrix of their own
         pitch = (w + 7) // 8 * 8
-        plane = lambda n: torch.randint(0, 1024, (n,), dtype=torch.int16, device="cuda")
-        src = [[(plane(pitch * h), plane(pitch // 2 * h), plane(pitch // 2 * h)) for _ in range(6)] for _ in range(R)]
-    kind = ("yuv422p10",) if packing == "yuv422p10" else ()
+        wide = packing == "yuv422p10"
+        plane = lambda n: torch.randint(0, 1024, (n,), dtype=torch.int16, device="cuda") if wide else torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")
+        sizes = {"yuv422p10": (pitch * h, pitch // 2 * h, pitch // 2 * h), "yuv422p8": (pitch * h, pitch // 2 * h, pitch // 2 * h),
+                 "yuv420p": (pitch * h, pitch * h // 4, pitch * h // 4), "nv12": (pitch * h, pitch * h // 2)}[packing]
+        src = [[tuple(plane(n) for n in sizes) for _ in range(6)] for _ in range(R)]
+        own = None if wide else dev(capi.ycbcr2rgb_matrix("709", 8, 16, 235, 224))
+        kind = (packing, own)
     mask = torch.zeros(h, w, 4, device="cuda")
     mask[..., 0] = torch.linspace(0, 1, w, device="cuda")[None, :]
     mask = mask.reshape(-1).contiguous()

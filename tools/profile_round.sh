@@ -60,7 +60,7 @@ bash $ROOT/tools/pmc_sq.sh > $OUT/${TAG}_pmc_sq.txt 2>&1
 rm -rf $ROOT/gpurun_out/pmc_sq/*/  # keep the summary only
 
 # 4b. configs 2 and 3: their kernels timed alone, in-kernel phase probe, and counters incl. FETCH_SIZE / WRITE_SIZE (separate passes)
-(for v in wipe nowipe layer0; do python $ROOT/tools/chan_bench.py 300 rgba $v; done; python $ROOT/tools/chan_bench.py 300 v210 wipe; python $ROOT/tools/chan_bench.py 300 rgba wipe yuv422p10; python $ROOT/tools/chan_bench.py 300 rgba nowipe yuv422p10) 2>/dev/null | grep '^{' > $OUT/${TAG}_chan_bench.jsonl
+(for v in wipe nowipe layer0; do python $ROOT/tools/chan_bench.py 300 rgba $v; done; python $ROOT/tools/chan_bench.py 300 v210 wipe; python $ROOT/tools/chan_bench.py 300 rgba wipe yuv422p10; python $ROOT/tools/chan_bench.py 300 rgba nowipe yuv422p10; python $ROOT/tools/chan_bench.py 300 rgba wipe yuv420p; python $ROOT/tools/chan_bench.py 300 rgba wipe nv12) 2>/dev/null | grep '^{' > $OUT/${TAG}_chan_bench.jsonl
 python $ROOT/tools/chan_probe.py wipe 2>/dev/null | grep '^{' > $OUT/${TAG}_chan_probe.jsonl
 python $ROOT/tools/up_bench.py 100 2>/dev/null | grep '^{' > $OUT/${TAG}_up_bench.jsonl
 bash $ROOT/tools/pmc_kernel.sh chan_compose python $ROOT/tools/chan_bench.py 40 rgba wipe 2>&1 | grep -v '^{\|simple_timer\|^W2\|^find' > $OUT/${TAG}_pmc_chan.txt
