@@ -385,9 +385,13 @@ int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer
 #define PH_SRC_YUV422P8 4  /* yuv422p8.ts:  4:2:2, 8-bit */
 #define PH_SRC_YUV420P 5   /* yuv420p.ts:   4:2:0, 8-bit */
 #define PH_SRC_NV12 6      /* nv12.ts:      4:2:0, 8-bit, Cb and Cr interleaved */
+/* packed 8-bit RGB (stills, graphics with alpha): four bytes per pixel, every byte - alpha too - through the call's gamma table,
+ * r g b through its gamut matrix (rgba8.ts:49-62); no YCbCr matrix, no planes */
+#define PH_SRC_RGBA8 7
+#define PH_SRC_BGRA8 8
 typedef struct ph_chan_source {
   const void *data;          /* device: v210 words (pitch ph_v210_pitch_bytes(width)), float RGBA, or the Y plane; width x height */
-  int format;                /* PH_SRC_V210 | PH_SRC_RGBA_F32 | a planar PH_SRC_* (PH_SRC_NONE: absent) */
+  int format;                /* PH_SRC_V210 | PH_SRC_RGBA_F32 | a planar PH_SRC_* | PH_SRC_RGBA8 | PH_SRC_BGRA8 (PH_SRC_NONE: absent) */
   int width, height;
   const float *matrix9_host; /* HOST: the nine values of ph_transform_matrix, or NULL = 1:1 */
   const void *data_u, *data_v; /* planar formats: the chroma plane(s) (ignored otherwise) */

@@ -318,6 +318,7 @@ class Deferral {
 		let reader = null
 		let packedCm = null
 		const PLANAR = { yuv422p10: 1, yuv422p8: 2, yuv420p: 3, nv12: 4 } // PH_FMT_*
+		const RGB8 = { rgba8: 5, bgra8: 6 } // stills and graphics: no YCbCr matrix, alpha in the data
 		const used = new Set() // pending nodes the fused launch stands in for
 		const sameSize = (img) => img.imageDims && img.imageDims.width === width && img.imageDims.height === height
 		const materialised = (img) => { this.force(img); return img.imageDims ? { source: img } : null }
@@ -325,6 +326,17 @@ class Deferral {
 			const p = img._producer
 			// v210 (SDI), or a planar frame as file decoders hand them over (ffmpegProducer.ts:398-412)
 			const fmt = p && p.state === 'pending' && p.program.name === 'read' ? p.program.format : null
+			if (RGB8[fmt]) {
+				const q = p.params
+				const f = Deferral._frameOf(p)
+				const ok = q.input && q.gammaLut && q.gamutMatrix && img.imageDims && f.width === img.imageDims.width && f.lines === img.imageDims.height &&
+					(!reader || (Deferral.same(reader.gammaLut, q.gammaLut) && Deferral.same(reader.gamutMatrix, q.gamutMatrix)))
+				if (ok) {
+					reader = reader || { colMatrix: null, gammaLut: q.gammaLut, gamutMatrix: q.gamutMatrix }
+					used.add(p)
+					return { source: q.input, packing: RGB8[fmt], width: f.width, height: f.lines, v210: true, planar: true, rgb8: true }
+				}
+			}
 			if (fmt === 'v210' || PLANAR[fmt]) {
 				const r = { colMatrix: p.params.colMatrix, gammaLut: p.params.gammaLut, gamutMatrix: p.params.gamutMatrix }
 				const f = Deferral._frameOf(p)
@@ -335,7 +347,8 @@ class Deferral {
 					(!reader || (Deferral.same(reader.gammaLut, r.gammaLut) && Deferral.same(reader.gamutMatrix, r.gamutMatrix))) &&
 					(fmt !== 'v210' || !packedCm || Deferral.same(packedCm, r.colMatrix))
 				if (ok) {
-					reader = reader || r
+					if (!reader) reader = r
+					else if (!reader.colMatrix) reader.colMatrix = r.colMatrix
 					if (fmt === 'v210') packedCm = packedCm || r.colMatrix
 					used.add(p)
 					return fmt === 'v210' ? { source: q.input, width: f.width, height: f.lines, v210: true }
@@ -396,13 +409,15 @@ class Deferral {
 			layers.forEach((l, i) => { params[`l${i}In`] = l.source; params[`l${i}Matrix`] = l.matrix })
 			candidates.push([`compose_up_write_v210_${n}`, params])
 		}
-		const loader = reader ? { colMatrix: packedCm || reader.colMatrix, gammaLut: reader.gammaLut, gamutMatrix: reader.gamutMatrix } : this.lastReader // the channel kernel wants a Loader recipe even if no layer turns out to need it
+		// the channel kernel wants a whole Loader recipe even if no layer turns out to need its YCbCr matrix (packed RGB and image layers only)
+		const anyCm = packedCm || (reader && reader.colMatrix) || (this.lastReader && this.lastReader.colMatrix)
+		const loader = reader ? (anyCm ? { colMatrix: anyCm, gammaLut: reader.gammaLut, gamutMatrix: reader.gamutMatrix } : null) : this.lastReader
 		if (loader) {
 			const params = Object.assign({ output, interlace }, loader, saver)
 			const put = (prefix, s) => {
 				params[`${prefix}In`] = s.source
-				if (s.planar) {
-					params[`${prefix}Packing`] = s.packing
+				if (s.planar) params[`${prefix}Packing`] = s.packing
+				if (s.planar && !s.rgb8) {
 					params[`${prefix}InU`] = s.u
 					if (s.v) params[`${prefix}InV`] = s.v
 					if (!Deferral.same(s.cm, loader.colMatrix)) params[`${prefix}ColMatrix`] = s.cm

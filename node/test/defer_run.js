@@ -36,7 +36,7 @@ async function side(deferred) {
 	s.read = await rig.unpack('v210', W, H, '709', '709')
 	s.readHalf = await rig.unpack('v210', W / 2, H / 2, '709', '709')
 	s.readAs = {}
-	for (const fmt of ['yuv422p10', 'yuv422p8', 'yuv420p', 'nv12']) s.readAs[fmt] = await rig.unpack(fmt, W, H, '709', '709')
+	for (const fmt of ['yuv422p10', 'yuv422p8', 'yuv420p', 'nv12', 'rgba8', 'bgra8']) s.readAs[fmt] = await rig.unpack(fmt, W, H, '709', '709')
 	s.write = await rig.pack('v210', W, H, '709', false)
 	s.writeField = await rig.pack('v210', W, H, '709', true)
 	s.combine = {}
@@ -404,6 +404,29 @@ async function main() {
 		}
 		return seen
 	}, { fused: 2, plain: 0, launched: 2, fallbacks: 0 })
+
+	// graphics: packed 8-bit RGB frames with real alpha (a logo, a lower third) over a v210 frame, one placed small
+	await scenario('packed RGB graphics with alpha over v210', async (s) => {
+		s.frame = 9
+		const bg = await s.source(v210Frame(full, 900))
+		const ga = await s.sourcePlanar('bgra8', 901)
+		const gb = await s.sourcePlanar('rgba8', 902)
+		const ubg = await s.rig.image(W, H)
+		const ua = await s.rig.image(W, H)
+		const ub = await s.rig.image(W, H)
+		await s.rig.run(s.read([bg], ubg))
+		await s.rig.run(s.readAs.bgra8(ga, ua))
+		await s.rig.run(s.readAs.rgba8(gb, ub))
+		const pb = await s.rig.image(W, H)
+		await s.rig.run(s.transform(ub, pb, await s.transform.matrix({ scaleX: 0.25, scaleY: 0.25, offsetX: 0.35, offsetY: -0.35 })))
+		const comb = await s.rig.image(W, H)
+		await s.rig.run(s.combine[3]([ubg, ua, pb], comb))
+		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		await s.rig.run(s.write(comb, [out], 0))
+		const seen = [await s.consume(out)]
+		;[bg, ...ga, ...gb, ubg, ua, ub, pb, comb, out].forEach((x) => x.release())
+		return seen
+	}, { fused: 1, plain: 0, launched: 1, fallbacks: 0 })
 
 	process.stdout.write(JSON.stringify({ width: W, height: H, scenarios, problems }) + '\n')
 }

@@ -82,7 +82,7 @@ class PhImageLayer(C.Structure):
 
 
 IMG_RGBA_F32, IMG_RGB_F32 = 0, 1
-SRC_V210, SRC_RGBA_F32, SRC_YUV422P10, SRC_YUV422P8, SRC_YUV420P, SRC_NV12 = 1, 2, 3, 4, 5, 6
+SRC_V210, SRC_RGBA_F32, SRC_YUV422P10, SRC_YUV422P8, SRC_YUV420P, SRC_NV12, SRC_RGBA8, SRC_BGRA8 = 1, 2, 3, 4, 5, 6, 7, 8
 SRC_PLANAR = {"yuv422p10": SRC_YUV422P10, "yuv422p8": SRC_YUV422P8, "yuv420p": SRC_YUV420P, "nv12": SRC_NV12}
 TRANSITION_CUT, TRANSITION_DISSOLVE, TRANSITION_WIPE = 0, 1, 2
 
@@ -470,7 +470,8 @@ class Context:
         {src: SOURCE, transition: "cut" | "dissolve" | "wipe", mix: float, incoming: SOURCE, mask: SOURCE}; a SOURCE is
         (tensor, width, height, matrix) or (tensor, width, height, matrix, "rgba") or ((y, u, v) plane tensors, width, height,
         matrix, "yuv422p10" | "yuv422p8" | "yuv420p" | "nv12"[, own Loader matrix tensor]) - matrix: nine host floats
-        (transform_matrix) or None for 1:1; format v210 unless "rgba" (f32 RGBA image) or a planar pack format."""
+        (transform_matrix) or None for 1:1; format v210 unless "rgba" (f32 RGBA image), a planar pack format, or "rgba8" / "bgra8"
+        (tensor of packed 8-bit pixels)."""
         import numpy as np
         arr = (PhChanLayer * len(layers))()
         keep = []
@@ -487,7 +488,7 @@ class Context:
             else:
                 dst_src.data = _ptr(t).value
             dst_src.width, dst_src.height = w, h
-            dst_src.format = SRC_PLANAR.get(kind, SRC_RGBA_F32 if kind == "rgba" else SRC_V210)
+            dst_src.format = SRC_PLANAR.get(kind, {"rgba": SRC_RGBA_F32, "rgba8": SRC_RGBA8, "bgra8": SRC_BGRA8}.get(kind, SRC_V210))
             if m is not None:
                 mh = np.ascontiguousarray(m, np.float32)
                 keep.append(mh)

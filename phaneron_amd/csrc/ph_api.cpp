@@ -1106,20 +1106,22 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
         } else {
           s->format = PH_SRC_V210;
           s->data_u = s->data_v = nullptr, s->col_matrix12 = nullptr;
-          // a planar source: l<i>Packing = its PH_FMT_* (1 yuv422p10, 2 yuv422p8, 3 yuv420p, 4 nv12), l<i>In its Y plane, l<i>InU /
-          // l<i>InV its chroma planes (nv12: l<i>InU the CbCr plane), l<i>ColMatrix (optional) its own Loader matrix
+          // another wire format: l<i>Packing = its PH_FMT_* (1 yuv422p10, 2 yuv422p8, 3 yuv420p, 4 nv12: l<i>In the Y plane, l<i>InU /
+          // l<i>InV the chroma planes (nv12: l<i>InU the CbCr plane), l<i>ColMatrix (optional) its own Loader matrix; 5 rgba8, 6 bgra8: l<i>In the frame)
           double packing = 0;
           snprintf(nm, sizeof nm, "l%d%sPacking", i, role);
           if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &packing));
           if (packing != 0) {
-            if (packing < PH_FMT_YUV422P10 || packing > PH_FMT_NV12) return fail(PH_E_INVALID, "kernel argument '%s': %g is not a planar pack format", nm, packing);
-            s->format = PH_SRC_YUV422P10 + ((int)packing - PH_FMT_YUV422P10);
+            if (packing < PH_FMT_YUV422P10 || packing > PH_FMT_BGRA8) return fail(PH_E_INVALID, "kernel argument '%s': %g is not a pack format other than v210", nm, packing);
+            s->format = PH_SRC_YUV422P10 + ((int)packing - PH_FMT_YUV422P10);  // PH_SRC_* follow PH_FMT_* from here on
           }
           snprintf(nm, sizeof nm, "l%d%sWidth", i, role);
           if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sw));
           snprintf(nm, sizeof nm, "l%d%sHeight", i, role);
           if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sh));
-          if (s->format != PH_SRC_V210) {
+          if (s->format == PH_SRC_RGBA8 || s->format == PH_SRC_BGRA8) {
+            if (sw > 0 && sh > 0 && x->bytes < (size_t)sw * (size_t)sh * 4) return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than a %gx%g frame of 4 bytes per pixel", i, role, x->bytes, sw, sh);
+          } else if (s->format != PH_SRC_V210) {
             const int fmt = PH_FMT_YUV422P10 + (s->format - PH_SRC_YUV422P10);
             size_t pb[3] = {0, 0, 0};
             if (sw > 0 && sh > 0) ph_pack_plane_bytes(fmt, (uint32_t)sw, (uint32_t)sh, pb);
@@ -1623,10 +1625,11 @@ static int chan_source(const ph_chan_source &s, const char *what, int layer, uin
                        const void **pv, const float **cm, uint32_t *planar) {
   if (!s.data || s.width <= 0 || s.height <= 0)
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is empty", layer, what);
-  const bool is_planar = s.format >= PH_SRC_YUV422P10 && s.format <= PH_SRC_NV12;
-  if (s.format != PH_SRC_V210 && s.format != PH_SRC_RGBA_F32 && !is_planar)
-    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has format %d (PH_SRC_V210, PH_SRC_RGBA_F32 or a planar PH_SRC_*)", layer, what, s.format);
+  const bool is_planar = s.format >= PH_SRC_YUV422P10 && s.format <= PH_SRC_NV12, is_rgb8 = s.format == PH_SRC_RGBA8 || s.format == PH_SRC_BGRA8;
+  if (s.format != PH_SRC_V210 && s.format != PH_SRC_RGBA_F32 && !is_planar && !is_rgb8)
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has format %d (not a PH_SRC_*)", layer, what, s.format);
   *pu = *pv = nullptr, *cm = nullptr;
+  if (is_rgb8) *planar = 1;  // (served by the kernel's wire-format instantiation)
   if (is_planar) {
     if (!s.data_u || (s.format != PH_SRC_NV12 && !s.data_v) || (s.width & 1) || ((s.format == PH_SRC_YUV420P || s.format == PH_SRC_NV12) && (s.height & 1)))
       return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is planar: it needs its chroma plane(s), an even width and, for 4:2:0, an even height", layer, what);
@@ -1637,11 +1640,12 @@ static int chan_source(const ph_chan_source &s, const char *what, int layer, uin
   if (!s.matrix9_host && ((uint32_t)s.width != out_w || (uint32_t)s.height != out_h))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has no transform but is %dx%d, not the output size", layer, what, s.width, s.height);
   o->ptr = s.data, o->w = (uint32_t)s.width, o->h = (uint32_t)s.height;
-  static const uint32_t kinds[] = {ph::kChanNone, ph::kChanV210, ph::kChanRgba, ph::kChanP10, ph::kChanP8x422, ph::kChanP8x420, ph::kChanNv12};
+  static const uint32_t kinds[] = {ph::kChanNone, ph::kChanV210, ph::kChanRgba, ph::kChanP10, ph::kChanP8x422, ph::kChanP8x420, ph::kChanNv12, ph::kChanRgba8, ph::kChanBgra8};
   o->kind = kinds[s.format];
   // planar: the luma line pitch in samples is the width rounded up to 8 (yuv422p10.ts:221), one or two bytes each
   o->pitch = s.format == PH_SRC_V210 ? ph_v210_pitch_bytes((uint32_t)s.width)
-             : is_planar ? (((uint32_t)s.width + 7u) & ~7u) * (s.format == PH_SRC_YUV422P10 ? 2u : 1u) : (uint32_t)s.width * 16u;
+             : is_planar ? (((uint32_t)s.width + 7u) & ~7u) * (s.format == PH_SRC_YUV422P10 ? 2u : 1u)
+             : is_rgb8 ? (uint32_t)s.width * 4u : (uint32_t)s.width * 16u;  // rgba8.ts:103-105: no line padding
   if ((uint64_t)o->pitch * o->h >= (1ull << 30))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is 1 GiB or larger; run the separate kernels", layer, what);
   o->sampled = s.matrix9_host ? 1u : 0u;

@@ -56,7 +56,8 @@ struct ComposeArgs {
 // ph_kernels_chan.hip: the compositor that samples v210 sources directly
 // planar YCbCr sources: 4:2:2 with 16-bit samples (yuv422p10le), 4:2:2 and 4:2:0 with 8-bit samples (yuv422p8, yuv420p), 4:2:0 with
 // interleaved chroma (nv12); ptr = the Y plane, ChanArgs::plane_u / plane_v the chroma planes (nv12: plane_u holds CbCr pairs)
-enum : uint32_t { kChanNone = 0, kChanV210 = 1, kChanRgba = 2, kChanP10 = 3, kChanP8x422 = 4, kChanP8x420 = 5, kChanNv12 = 6 };
+// and the packed 8-bit RGB formats of stills and graphics (rgba8, bgra8: four bytes per pixel, alpha included)
+enum : uint32_t { kChanNone = 0, kChanV210 = 1, kChanRgba = 2, kChanP10 = 3, kChanP8x422 = 4, kChanP8x420 = 5, kChanNv12 = 6, kChanRgba8 = 7, kChanBgra8 = 8 };
 enum : uint32_t { kChanCut = 0, kChanDissolve = 1, kChanWipe = 2 };
 struct ChanSrc {
   const void *ptr;

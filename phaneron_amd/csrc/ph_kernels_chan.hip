@@ -224,6 +224,79 @@ __device__ __forceinline__ void chan_sample_planar(const ChanSrc &s, const void 
   }
 }
 
+// ---- packed 8-bit RGB sources: rgba8 / bgra8 (rgba8.ts:49-62, bgra8.ts) ------------------------------------------------------------------
+// One dword per pixel.  Every byte b - alpha too - goes through the gamma table at index b * 65535 / 255 (= b * 257, exactly),
+// then the gamut matrix on r, g, b; no YCbCr matrix.  A tap outside the frame is the border colour.
+struct Rgb8Pending {
+  LutPending r, g, b, a;
+};
+__device__ __forceinline__ Rgb8Pending rgb8_issue(uint32_t word, bool bgra, const LutK &lut) {
+  const float b0 = (float)(word & 0xFFu), b1 = (float)((word >> 8) & 0xFFu), b2 = (float)((word >> 16) & 0xFFu), b3 = (float)(word >> 24);
+  Rgb8Pending p;
+  p.r = lds_lut_issue(lut, (bgra ? b2 : b0) * 257.0f + kRoundMagic);
+  p.g = lds_lut_issue(lut, b1 * 257.0f + kRoundMagic);
+  p.b = lds_lut_issue(lut, (bgra ? b0 : b2) * 257.0f + kRoundMagic);
+  p.a = lds_lut_issue(lut, b3 * 257.0f + kRoundMagic);
+  return p;
+}
+__device__ __forceinline__ float4 rgb8_finish(const Rgb8Pending &p, const ReadK &k) {
+  const float r = lds_lut_finish(p.r), g = lds_lut_finish(p.g), b = lds_lut_finish(p.b);
+  return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]), dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]),
+                     lds_lut_finish(p.a));
+}
+__device__ __forceinline__ void chan_sample_rgb8(const ChanSrc &s, float px, const float (&py)[kChanP], uint32_t x, const uint32_t (&line)[kChanP],
+                                                 const ReadK &k, const LutK &lut, float4 (&out)[kChanP]) {
+  const bool bgra = s.kind == kChanBgra8;  // uniform
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(s.pitch * s.h), 0x00020000);
+  if (!s.sampled) {
+    Rgb8Pending pend[kChanP];
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p)
+      pend[p] = rgb8_issue((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(__umul24(line[p], s.pitch) + (x << 2)), 0, 0), bgra, lut);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) out[p] = rgb8_finish(pend[p], k);
+    return;
+  }
+  ChanTaps t[kChanP];
+  bool touches = false;
+#pragma unroll
+  for (int p = 0; p < kChanP; ++p) {
+    t[p] = chan_taps(s, px, py[p]);
+    touches = touches || (t[p].i0 + 1u <= s.w && t[p].j0 + 1u <= s.h);
+  }
+  if (!__builtin_amdgcn_ballot_w64(touches)) {
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) out[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < kChanP; ++p) {
+    const bool ci[2] = {t[p].i0 < s.w, t[p].i0 + 1u < s.w}, ri[2] = {t[p].j0 < s.h, t[p].j0 + 1u < s.h};
+    Rgb8Pending pend[4];
+    bool in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      in[i] = ci[i & 1] && ri[i >> 1];
+      const uint32_t off = in[i] ? __umul24(t[p].j0 + (uint32_t)(i >> 1), s.pitch) + ((t[p].i0 + (uint32_t)(i & 1)) << 2) : kOutsideBit;
+      pend[i] = rgb8_issue((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0), bgra, lut);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float4 q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      q[i] = rgb8_finish(pend[i], k);
+      q[i].x = in[i] ? q[i].x : 0.0f, q[i].y = in[i] ? q[i].y : 0.0f, q[i].z = in[i] ? q[i].z : 0.0f, q[i].w = in[i] ? q[i].w : 0.0f;  // the border colour
+    }
+    const float a = t[p].a, b = t[p].b, oma = 1.0f - a, omb = 1.0f - b;
+    const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
+    out[p].x = ((w00 * q[0].x + w10 * q[1].x) + w01 * q[2].x) + w11 * q[3].x;
+    out[p].y = ((w00 * q[0].y + w10 * q[1].y) + w01 * q[2].y) + w11 * q[3].y;
+    out[p].z = ((w00 * q[0].z + w10 * q[1].z) + w01 * q[2].z) + w11 * q[3].z;
+    out[p].w = ((w00 * q[0].w + w10 * q[1].w) + w01 * q[2].w) + w11 * q[3].w;
+  }
+}
+
 // the source's samples for the lane's pixels (x, line[p]): 1:1, or through the transform matrix and the bilinear filter
 template <bool STD>
 __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const float (&py)[kChanP], uint32_t x, const uint32_t (&line)[kChanP],
@@ -457,7 +530,9 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
     for (int k = 0; k < a.n_ops; ++k) {
       const ChanOp op = a.op[k];
       float4 v[kChanP];
-      if (PLANAR && op.src.kind >= kChanP10) {  // uniform
+      if (PLANAR && op.src.kind >= kChanRgba8) {  // uniform
+        chan_sample_rgb8(op.src, px, py, x, line, rk, rlut, v);
+      } else if (PLANAR && op.src.kind >= kChanP10) {
         // a source with code ranges of its own (8-bit) brings its Loader matrix: the general dot products serve any matrix and give
         // the same bits as the short form where that applies (its missing terms are exact zeros)
         const float *cm = a.cm_op[k];

@@ -25,8 +25,9 @@ class Src:
         self.data, self.w, self.h, self.matrix, self.fmt, self.spec = data, w, h, matrix, fmt, spec  # spec: the reader's colour space (8-bit planar sources make their own matrix for it)
 
     def oracle(self, rd_o, ow, oh):
-        if self.fmt in orc.FORMATS and self.fmt != "v210":  # data: the planes; a 10-bit 4:2:2 source shares the v210 Loader matrix, 8-bit ones have their own
-            cm = rd_o[0] if self.fmt == "yuv422p10" else orc.ycbcr2rgb_matrix(self.spec, *orc.FORMAT_RANGE[self.fmt])
+        if self.fmt in orc.FORMATS and self.fmt != "v210":  # data: the planes; a 10-bit 4:2:2 source shares the v210 Loader matrix, 8-bit ones have their own, RGB ones none
+            rng = orc.FORMAT_RANGE[self.fmt]
+            cm = rd_o[0] if self.fmt == "yuv422p10" else None if rng is None else orc.ycbcr2rgb_matrix(self.spec, *rng)
             img = orc.pack_read(self.fmt, [np.ascontiguousarray(p).view(np.uint8) for p in self.data], self.w, self.h, cm, rd_o[1], rd_o[2])
         else:
             img = orc.v210_read(self.data, self.w, self.h, *rd_o) if self.fmt == "v210" else self.data.reshape(self.h, self.w, 4)
@@ -39,6 +40,8 @@ class Src:
         import hip_harness as hh
         if self.fmt in orc.FORMATS and self.fmt != "v210":
             from phaneron_amd import capi
+            if orc.FORMAT_RANGE[self.fmt] is None:  # rgba8 / bgra8: one packed plane
+                return (hh.dev(np.ascontiguousarray(self.data[0]).reshape(-1)), self.w, self.h, self.matrix, self.fmt)
             own = None if self.fmt == "yuv422p10" else hh.dev(capi.ycbcr2rgb_matrix(self.spec, *orc.FORMAT_RANGE[self.fmt]))
             return (tuple(hh.dev(np.ascontiguousarray(p).reshape(-1)) for p in self.data), self.w, self.h, self.matrix, self.fmt, own)
         t = hh.dev(self.data.reshape(-1))
@@ -369,3 +372,21 @@ def test_planar_eight_bit_sources(fmt):
     layers = [dict(src=Src(v, w, h)), dict(src=Src(a, w, h, m(w, h), fmt=fmt), transition="dissolve", mix=0.3, incoming=Src(b, 204, 38, m(w, h, scale_x=1.7, scale_y=1.7), fmt=fmt))]
     check(layers, w, h, "%s inside a dissolve" % fmt)
     check(layers, w, h, "%s inside a dissolve, 709 -> 2020, field 1" % fmt, interlace=1, poison_dst=True, specs=("709", "2020"))
+
+
+@pytest.mark.parametrize("fmt", ["rgba8", "bgra8"])
+def test_packed_rgb_sources_with_alpha(fmt):
+    """stills and graphics (rgba8 / bgra8: every byte, alpha too, through the gamma table - rgba8.ts:49-62): a logo with real alpha
+    over v210 and planar layers, pixel for pixel and placed, as the incoming side of a dissolve and as a wipe's mask"""
+    w, h = 384, 54
+    g = frames.pack_random(fmt, w, h, 500)
+    small = frames.pack_random(fmt, 100, 30, 501)
+    v = frames.v210_random(w, h, frames.layer_seed(100, 0))
+    p10 = frames.pack_random("yuv422p10", w, h, 502)
+    check([dict(src=Src(g, w, h, fmt=fmt))], w, h, "%s pixel for pixel" % fmt)
+    check([dict(src=Src(v, w, h)), dict(src=Src(p10, w, h, m(w, h, **PIP[1]), fmt="yuv422p10")), dict(src=Src(g, w, h, fmt=fmt)),
+           dict(src=Src(small, 100, 30, m(w, h, scale_x=0.3, scale_y=0.5, offset_x=0.3, offset_y=-0.2, rotate=-0.04), fmt=fmt))], w, h, "%s over v210 and yuv422p10" % fmt,
+          specs=("709", "2020"))
+    layers = [dict(src=Src(v, w, h)), dict(src=Src(g, w, h, m(w, h), fmt=fmt), transition="dissolve", mix=0.6, incoming=Src(small, 100, 30, m(w, h, scale_x=2.0, scale_y=2.0), fmt=fmt)),
+              dict(src=Src(p10, w, h, fmt="yuv422p10"), transition="wipe", incoming=Src(v, w, h, m(w, h, **PIP[3])), mask=Src(g, w, h, fmt=fmt))]
+    check(layers, w, h, "%s inside transitions" % fmt)
