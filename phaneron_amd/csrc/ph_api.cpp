@@ -1659,7 +1659,8 @@ int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *lay
   if (!ctx || !layers || !out || !rd_cm || !rd_lut || !rd_gm || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_chan_compose_v210: NULL argument");
   PH_QUEUE("ph_chan_compose_v210", queue);
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_chan_compose_v210: 1..%d layers", ph::kMaxLayers);
-  if (!out_w || out_w % 192) return fail(PH_E_INVALID, "ph_chan_compose_v210: width %u is not a multiple of 192; run the separate kernels", out_w);
+  // (a v210 line of a width that is not a multiple of 48 ends in a padded block the reference's writer addresses by width: DESIGN.md section 2)
+  if (!out_w || out_w % 48) return fail(PH_E_INVALID, "ph_chan_compose_v210: width %u is not a multiple of 48; run the separate kernels", out_w);
   if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_chan_compose_v210: interlace must be 0, 1 or 3");
   const ph::LutView *rv = lds_view(ctx, rd_lut), *wv = lds_view(ctx, wr_lut);
   if (!rv || !wv)

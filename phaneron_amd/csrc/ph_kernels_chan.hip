@@ -421,7 +421,7 @@ __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const fl
 }
 
 // ---- the workgroup's share of the frame ----------------------------------------------------------------------------------
-// Unit of work: a CHUNK of 192 pixels x 2 rows (row pair rp: output rows 2 rp and 2 rp + 1 of the field being written; a
+// Unit of work: a CHUNK of 192 pixels x 2 rows (the last chunk of a row may be short: widths are multiples of 48; row pair rp: output rows 2 rp and 2 rp + 1 of the field being written; a
 // field with an odd number of rows repeats its last row as its own partner) = 3 wave steps of phase 1, 64 quads of
 // phase 2.  Chunks are dealt out XCD-aware as the f32 compositor does (ph_kernels_lds.hip compose_taps_body): groups of
 // PH_CHAN_GROUP_ROWS output rows belong to one XCD (blockIdx % 8), so a source row is pulled through one XCD's L2, and
@@ -433,7 +433,7 @@ struct ChanShare {
 };
 __device__ __forceinline__ ChanShare chan_share(const ChanArgs &a) {
   ChanShare s;
-  s.cpr = a.out_w / kChanChunk;  // chunks per row pair: out_w % 192 == 0, a chunk never leaves its rows
+  s.cpr = (a.out_w + kChanChunk - 1u) / kChanChunk;  // chunks per row pair: a chunk never leaves its rows; a row's last chunk may be short (out_w % 48 == 0)
   s.chunks = s.cpr * ((a.lines + 1u) / 2u);
   s.cpg = (uint32_t)(PH_CHAN_GROUP_ROWS / 2) * s.cpr;
   s.banded = (gridDim.x & 7u) == 0;
@@ -549,7 +549,7 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
     for (int p = 0; p < kChanP; ++p) {
       const uint32_t ir = __float_as_uint(lds_lut_index_unit(acc[p].r)) & 0xFFFFu, ig = __float_as_uint(lds_lut_index_unit(acc[p].g)) & 0xFFFFu;
       const uint32_t ib = __float_as_uint(lds_lut_index_unit(acc[p].b)) & 0xFFFFu;
-      index[li[p] * a.out_w + x] = make_uint2(ir | (ig << 16), ib);
+      if (x < a.out_w) index[li[p] * a.out_w + x] = make_uint2(ir | (ig << 16), ib);  // (lanes beyond a short last chunk have nothing to park)
     }
   }
 }
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
     uint32_t rp, x0;
     chan_place(a, sh, chunk, rp, x0);
     const uint32_t li = 2u * rp + ((q >> 5) & 1u);  // quads 0..31 of a chunk: its upper row, 32..63: its lower row
-    if (li >= a.lines) continue;
+    if (li >= a.lines || x0 + (q & 31u) * 6u >= a.out_w) continue;
     const uint32_t first_px = li * a.out_w + x0 + (q & 31u) * 6u;
     const uint4 w0 = load_stream(index + (first_px >> 1)), w1 = load_stream(index + (first_px >> 1) + 1), w2 = load_stream(index + (first_px >> 1) + 2);
     const uint32_t pk[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
@@ -607,8 +607,8 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
   const void *fn = a.planar ? reinterpret_cast<const void *>(chan_compose_v210_kernel<true>) : reinterpret_cast<const void *>(chan_compose_v210_kernel<false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  const uint32_t cpr = a.out_w / kChanChunk, cpg = (uint32_t)(PH_CHAN_GROUP_ROWS / 2) * cpr;
-  const uint32_t chunks = cpr * ((a.lines + 1u) / 2u);  // 192 pixels x 2 rows each
+  const uint32_t cpr = (a.out_w + kChanChunk - 1u) / kChanChunk, cpg = (uint32_t)(PH_CHAN_GROUP_ROWS / 2) * cpr;
+  const uint32_t chunks = cpr * ((a.lines + 1u) / 2u);  // 192 pixels x 2 rows each (a row's last chunk may be short)
   const uint32_t want = chunks;                         // a workgroup per chunk at most: 6 wave steps
   ChanArgs b = a;
   // reciprocals for the kernel's uniform divisions: umulhi(v, ceil(2^32 / d)) == v / d for every v * d < 2^32 (chunk counts are far below)

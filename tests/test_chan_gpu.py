@@ -223,8 +223,8 @@ def test_refusals():
     src = hh.dev(frames.v210_random(w, h, 1))
     out = torch.zeros(frames.v210_pitch_bytes(w) * h // 4, dtype=torch.int32, device="cuda")
     ok = dict(src=(src, w, h, None))
-    with pytest.raises(capi.PhaneronError, match="multiple of 192"):
-        k.chan_compose_v210([dict(src=(src, 336, h, None))], out, 336, h, 0, *rd_d, *wr_d)
+    with pytest.raises(capi.PhaneronError, match="multiple of 48"):
+        k.chan_compose_v210([dict(src=(src, 330, h, None))], out, 330, h, 0, *rd_d, *wr_d)
     with pytest.raises(capi.PhaneronError, match="not the output size"):
         k.chan_compose_v210([dict(src=(src, 192, h, None))], out, w, h, 0, *rd_d, *wr_d)
     with pytest.raises(capi.PhaneronError, match="incoming source is empty"):
@@ -390,3 +390,12 @@ def test_packed_rgb_sources_with_alpha(fmt):
     layers = [dict(src=Src(v, w, h)), dict(src=Src(g, w, h, m(w, h), fmt=fmt), transition="dissolve", mix=0.6, incoming=Src(small, 100, 30, m(w, h, scale_x=2.0, scale_y=2.0), fmt=fmt)),
               dict(src=Src(p10, w, h, fmt="yuv422p10"), transition="wipe", incoming=Src(v, w, h, m(w, h, **PIP[3])), mask=Src(g, w, h, fmt=fmt))]
     check(layers, w, h, "%s inside transitions" % fmt)
+
+
+@pytest.mark.parametrize("w,h,interlace", [(720, 576, 0), (720, 576, 1), (720, 486, 3), (48, 4, 0), (240, 7, 0), (1440, 30, 0), (336, 9, 3)])
+def test_widths_that_are_not_whole_chunks(w, h, interlace):
+    """SD frames (720 x 576 / 486, field writes) and other widths that are multiples of 48 but not of the kernel's 192-pixel chunk: a
+    row's last chunk is short - its spare lanes park nothing, its spare quads write nothing, the lines' ends are what the oracle wrote"""
+    layers = pip_layers(w, h, 600 + w + interlace, 3)
+    layers.append(dict(src=Src(frames.pack_random("yuv420p", w, h + (h & 1), 601), w, h + (h & 1), m(w, h, scale_x=0.6, scale_y=0.6, offset_x=0.2, offset_y=0.2), fmt="yuv420p")))
+    check(layers, w, h, "%dx%d interlace %d" % (w, h, interlace), interlace=interlace, poison_dst=interlace != 0)
