@@ -191,8 +191,16 @@ class clContext {
 			afterQueue: (queue) => native.routeOp(h, 2, q(queue)),
 			queueAfter: (queue) => native.routeOp(h, 3, q(queue)),
 			wait: () => native.routeOp(h, 4),
-			send: (buf, peer) => { if (this._deferral) this._deferral.touch(buf, 'readonly', this.queue.process); return native.routeOp(h, 5, buf._handle, peer) },
-			recv: (buf, peer) => { if (this._deferral) this._deferral.touch(buf, 'writeonly', this.queue.process); return native.routeOp(h, 6, buf._handle, peer) }
+			// (recording context: the frame's producer may be launched only now - after the caller's afterQueue() - so the
+			// communication stream is ordered behind the process queue once more before the transfer is enqueued)
+			send: (buf, peer) => {
+				if (this._deferral) { this._deferral.touch(buf, 'readonly', this.queue.process); native.routeOp(h, 2, this.queue.process) }
+				return native.routeOp(h, 5, buf._handle, peer)
+			},
+			recv: (buf, peer) => {
+				if (this._deferral) { this._deferral.touch(buf, 'writeonly', this.queue.process); native.routeOp(h, 2, this.queue.process) } // (readers of the old contents were launched just now)
+				return native.routeOp(h, 6, buf._handle, peer)
+			}
 		}
 	}
 	static routeUniqueId() { return loadAddon().routeUniqueId() }
