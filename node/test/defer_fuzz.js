@@ -29,10 +29,12 @@ const PLACEMENTS = [{}, { scaleX: 0.5, scaleY: 0.5, offsetX: 0.25, offsetY: -0.2
 async function play(seed, deferred) {
 	const rig = await Rig.open({ deviceIndex: 0, deferred, spinWaitMicros: 100 })
 	const S = {
-		read: await rig.unpack('v210', W, H, '709', '2020'), write: await rig.pack('v210', W, H, '2020', false), writeField: await rig.pack('v210', W, H, '2020', true),
+		read: await rig.unpack('v210', W, H, '709', '2020'), readAs: {}, write: await rig.pack('v210', W, H, '2020', false), writeField: await rig.pack('v210', W, H, '2020', true),
 		transform: await rig.transform(W, H), dissolve: await rig.two('transition_dissolve', W, H), wipe: await rig.two('transition_wipe', W, H), yadif: await rig.yadif(W, H),
 		combine: { 2: await rig.combine(2, W, H), 3: await rig.combine(3, W, H), 4: await rig.combine(4, W, H) }
 	}
+	const FORMATS = ['v210', 'v210', 'yuv422p10', 'yuv422p8', 'yuv420p', 'nv12', 'rgba8', 'bgra8'] // sources come in every pack format (v210 twice as often)
+	for (const f of FORMATS.slice(2)) S.readAs[f] = await rig.unpack(f, W, H, '709', '2020')
 	const r = rng(seed)
 	const pick = (list) => list[r() % list.length]
 	const seen = []
@@ -47,8 +49,17 @@ async function play(seed, deferred) {
 	const up = async (buf, bytes) => { await rig.upload(buf, bytes); await rig.sync(rig.ctx.queue.load) }
 	const setLive = async (i) => { const f = new Float32Array(12); f.set(colour.transformMatrix(W, H, PLACEMENTS[i % PLACEMENTS.length])); await up(live, Buffer.from(f.buffer)) }
 	await setLive(1)
-	const newSource = async () => { const p = (await rig.planes('v210', W, H))[0]; await up(p, v210Frame(r())); sources.push(p); return p }
-	for (let i = 0; i < 3; ++i) await newSource()
+	const fill = (fmt, bytes, seed) => {
+		if (fmt === 'v210') return v210Frame(seed)
+		const q = rng(seed)
+		const b = Buffer.alloc(bytes)
+		if (fmt === 'yuv422p10') for (let i = 0; i + 2 <= bytes; i += 2) b.writeUInt16LE((q() >>> 8) % 1024, i)
+		else for (let i = 0; i < bytes; ++i) b[i] = (q() >>> 8) & 255
+		return b
+	}
+	const refill = async (src) => { for (const p of src.planes) await up(p, fill(src.fmt, p.length, r())) }
+	const newSource = async () => { const fmt = pick(FORMATS); const src = { fmt, planes: await rig.planes(fmt, W, H) }; await refill(src); sources.push(src); return src }
+	for (let i = 0; i < 4; ++i) await newSource()
 	const newImage = async () => rig.image(W, H)
 	const log = []
 	// (a consumer maps a frame after its jobs' waitFinish: clJobQueue.ts:131, macadamConsumer.ts:233-254)
@@ -58,7 +69,8 @@ async function play(seed, deferred) {
 		if (process.env.PHANERON_DEFER_DEBUG && deferred) process.stderr.write(`step ${step} op ${op} after: ${log[log.length - 1]}\n`)
 		if (op < 3 || images.length < 2) { // read
 			const im = await newImage()
-			await rig.run(S.read([pick(sources)], im))
+			const src = pick(sources)
+			await rig.run(src.fmt === 'v210' ? S.read(src.planes, im) : S.readAs[src.fmt](src.planes, im))
 			images.push(im); log.push('read')
 		} else if (op < 5) { // transform, through a constant matrix or the live one
 			const im = await newImage()
@@ -100,7 +112,7 @@ async function play(seed, deferred) {
 				outs.push({ buf }); log.push('write')
 			}
 		} else if (op === 12) { // the next frame into an old source, or a new placement into the live matrix
-			if (r() % 2) await up(pick(sources), v210Frame(r())); else await setLive(r())
+			if (r() % 2) await refill(pick(sources)); else await setLive(r())
 			log.push('overwrite')
 		} else if (op === 13 && images.length > 2) { // the owner lets an image go (jobs recorded on it may still need it)
 			const i = r() % images.length
@@ -114,7 +126,7 @@ async function play(seed, deferred) {
 		if (r() % 7 === 0) await rig.sync()
 	}
 	for (const o of outs) await consume(o.buf)
-	;[...images, ...sources, ...outs.map((o) => o.buf), live].forEach((b) => b.release())
+	;[...images, ...sources.map((x) => x.planes).flat(), ...outs.map((o) => o.buf), live].forEach((b) => b.release())
 	rig.close()
 	const stats = rig.ctx.deferredStats()
 	const left = rig.ctx.flushDeferred()
