@@ -27,7 +27,9 @@ extern "C" {
 
 /* 2: additive over 1 - ph_program_resolve, ph_route_*, ph_yadif_pair, ph_v210_yadif_pair, ph_v210_read_batch,
  *    ph_fused_field_v210, ph_compose_wipe_write_v210, context option "stream_images"; no signature of 1 changed */
-#define PH_ABI_VERSION 2
+/* 3: additive over 2 - ph_chan_compose_v210 (ph_chan_source / ph_chan_layer), ph_compose_up_write_v210, ph_v210_yadif_pair_fmt,
+ *    ph_check_program, ph_route_comm_count, context option "host_pool_mb"; no signature of 2 changed */
+#define PH_ABI_VERSION 3
 
 enum {
   PH_OK = 0,
