@@ -67,8 +67,8 @@ __device__ __forceinline__ void fmt_read_body(const FmtReadArgs &a, const LUT &l
         v = (float)reinterpret_cast<const uint16_t *>(a.p2)[(size_t)cl * (a.pitch >> 1) + (x >> 1)];
       } else if (FMT == F_NV12) {  // nv12.ts:61-74
         y = (float)reinterpret_cast<const uint8_t *>(a.p0)[(size_t)line * a.pitch + x];
-        const uchar2 c = reinterpret_cast<const uchar2 *>(a.p1)[((size_t)cl * a.pitch >> 1) + (x >> 1)];
-        u = (float)c.x, v = (float)c.y;
+        const uint8_t *c = reinterpret_cast<const uint8_t *>(a.p1) + (size_t)cl * a.pitch + (x & ~1u);  // the pair's Cb, Cr bytes (two byte loads: a 2-byte vector load measured twice as slow here)
+        u = (float)c[0], v = (float)c[1];
       } else {
         y = (float)reinterpret_cast<const uint8_t *>(a.p0)[(size_t)line * a.pitch + x];
         u = (float)reinterpret_cast<const uint8_t *>(a.p1)[(size_t)cl * (a.pitch >> 1) + (x >> 1)];
