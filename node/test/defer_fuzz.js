@@ -9,8 +9,9 @@
 const { Rig } = require('../device.js')
 const { colour } = require('../index.js')
 
-const W = 192 // (the channel kernel takes widths that are multiples of 192)
-const H = 12
+// frame size: small by default (many streams per second); PHANERON_FUZZ_SIZE=1920x270 makes the kernels long enough for an ordering
+// mistake between queues, or a block recycled too early, to show
+const [W, H] = (process.env.PHANERON_FUZZ_SIZE || '192x12').split('x').map((v) => parseInt(v)) // (widths: multiples of 48)
 const first = parseInt(process.argv[2] || '1')
 const streams = parseInt(process.argv[3] || '20')
 const steps = parseInt(process.argv[4] || '60')
