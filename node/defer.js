@@ -286,7 +286,11 @@ class Deferral {
 
 	// node: a pending v210 `write`.  true = the frame has been produced by one fused launch
 	_fused(node) {
-		if (!Deferral._isV210(node.program, 'write')) return false
+		// FromRGBA with a Writer whose frame the channel kernel can make: v210 (SDI), yuv422p8 / yuv422p10 (an encoder), rgba8 / bgra8 (the screen)
+		const OUT = { v210: 0, yuv422p10: 1, yuv422p8: 2, rgba8: 5, bgra8: 6 }
+		if (node.program.name !== 'write' || OUT[node.program.format] === undefined) return false
+		const outFmt = OUT[node.program.format]
+		const outRgb8 = outFmt >= 5
 		const image = node.params.input
 		const dims = image && image.imageDims
 		const top = image && image._producer
@@ -296,8 +300,9 @@ class Deferral {
 		const interlace = node.params.interlace || 0
 		const geo = Deferral._frameOf(node)
 		if (geo.width !== width || geo.lines !== (interlace ? height / 2 : height)) return false
-		const output = node.params.output
-		if (!output || !node.params.colMatrix || !node.params.gammaLut) return false
+		const output = outFmt === 1 || outFmt === 2 ? node.params.outputY : node.params.output
+		if (!output || (!outRgb8 && !node.params.colMatrix) || !node.params.gammaLut) return false
+		if ((outFmt === 1 || outFmt === 2) && (!node.params.outputU || !node.params.outputV)) return false
 
 		let layerImages = [image]
 		const m = /^combine_(\d+)$/.exec(top.program.name)
@@ -397,14 +402,16 @@ class Deferral {
 		const n = layers.length
 		const anyV210 = layers.some((l) => l.v210 || (l.transition && (l.transition.incoming.v210 || (l.transition.mask && l.transition.mask.v210))))
 		if (!used.size) return false // every layer is a finished image taken as it is: the recorded write is as good
-		const saver = { outColMatrix: node.params.colMatrix, outGammaLut: node.params.gammaLut }
+		const saver = { outGammaLut: node.params.gammaLut }
+		if (!outRgb8) saver.outColMatrix = node.params.colMatrix
+		if (outFmt) Object.assign(saver, { outPacking: outFmt }, outFmt < 5 ? { outputU: node.params.outputU, outputV: node.params.outputV } : {})
 		const candidates = [] // [program name, params], best first; the library refuses the shapes a kernel does not take
-		if (!interlace && layers.every((l) => l.v210 && !l.planar && !l.matrix && !l.transition)) {
+		if (!outFmt && !interlace && layers.every((l) => l.v210 && !l.planar && !l.matrix && !l.transition)) {
 			const params = Object.assign({ output }, reader, saver)
 			layers.forEach((l, i) => { params[`l${i}In`] = l.source })
 			candidates.push([`fused_v210_combine_${n}`, params])
 		}
-		if (!anyV210 && layers.every((l) => l.matrix && !l.transition)) { // finished images, placed: enlarged ones share their taps
+		if (!outFmt && !anyV210 && layers.every((l) => l.matrix && !l.transition)) { // finished images, placed: enlarged ones share their taps
 			const params = Object.assign({ output, interlace }, saver)
 			layers.forEach((l, i) => { params[`l${i}In`] = l.source; params[`l${i}Matrix`] = l.matrix })
 			candidates.push([`compose_up_write_v210_${n}`, params])

@@ -39,6 +39,8 @@ async function side(deferred) {
 	for (const fmt of ['yuv422p10', 'yuv422p8', 'yuv420p', 'nv12', 'rgba8', 'bgra8']) s.readAs[fmt] = await rig.unpack(fmt, W, H, '709', '709')
 	s.write = await rig.pack('v210', W, H, '709', false)
 	s.writeField = await rig.pack('v210', W, H, '709', true)
+	s.writeAs = {}
+	for (const fmt of ['rgba8', 'bgra8', 'yuv422p8', 'yuv422p10']) s.writeAs[fmt] = await rig.pack(fmt, W, H, '709', false)
 	s.combine = {}
 	for (const n of [2, 3, 4]) s.combine[n] = await rig.combine(n, W, H)
 	s.transform = await rig.transform(W, H)
@@ -427,6 +429,30 @@ async function main() {
 		;[bg, ...ga, ...gb, ubg, ua, ub, pb, comb, out].forEach((x) => x.release())
 		return seen
 	}, { fused: 1, plain: 0, launched: 1, fallbacks: 0 })
+
+	// the reference's other consumers: the screen maps an rgba8 frame (screenConsumer.ts:131), an encoder yuv422p8 planes (ffmpegConsumer.ts:144)
+	await scenario('frames for the screen and for an encoder', async (s) => {
+		s.frame = 10
+		const seen = []
+		for (const fmt of ['rgba8', 'yuv422p8', 'bgra8', 'yuv422p10']) {
+			const a = await s.source(v210Frame(full, 1000))
+			const b = await s.sourcePlanar('yuv420p', 1001)
+			const ua = await s.rig.image(W, H)
+			const ub = await s.rig.image(W, H)
+			s.rig.post(s.id('A'), s.read([a], ua), () => a.release())
+			s.rig.post(s.id('B'), s.readAs.yuv420p(b, ub), () => b.forEach((p) => p.release()))
+			const pb = await s.rig.image(W, H)
+			s.rig.post(s.id('B'), s.transform(ub, pb, await s.transform.matrix(PIP[2])), () => ub.release())
+			const comb = await s.rig.image(W, H)
+			s.rig.post(s.id('mix'), s.combine[2]([ua, pb], comb), () => [ua, pb].forEach((x) => x.release()))
+			const out = await s.rig.planes(fmt, W, H, 'writeonly')
+			s.rig.post(s.id('mix'), s.writeAs[fmt](comb, out, 0), () => comb.release())
+			for (const k of ['A', 'B', 'mix']) await s.flush(s.id(k))
+			for (const p of out) { seen.push(await s.consume(p)); p.release() }
+			s.frame++
+		}
+		return seen
+	}, { fused: 4, plain: 0, launched: 4, fallbacks: 0 })
 
 	process.stdout.write(JSON.stringify({ width: W, height: H, scenarios, problems }) + '\n')
 }

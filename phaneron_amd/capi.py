@@ -22,7 +22,7 @@ EXPORTS = [
     "ph_abi_version", "ph_last_error", "ph_ctx_create", "ph_ctx_destroy", "ph_ctx_info", "ph_ctx_stream",
     "ph_wait_finish", "ph_buf_create", "ph_buf_wrap", "ph_buf_addref", "ph_buf_release", "ph_buf_refcount",
     "ph_buf_bytes", "ph_buf_device_ptr", "ph_buf_dims", "ph_buf_host_access", "ph_buf_host_ptr",
-    "ph_ctx_buffer_stats", "ph_program_create", "ph_program_destroy", "ph_program_kernel", "ph_run_program", "ph_check_program",
+    "ph_ctx_buffer_stats", "ph_program_create", "ph_program_destroy", "ph_program_kernel", "ph_run_program", "ph_check_program", "ph_chan_compose",
     "ph_v210_pitch_bytes", "ph_v210_read", "ph_v210_read_batch", "ph_v210_write", "ph_yadif", "ph_yadif_pair", "ph_v210_yadif_pair", "ph_transform", "ph_resize", "ph_combine",
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
@@ -185,6 +185,7 @@ def lib():
         "ph_fused_field_v210": (ci, [vp, ci, ci, C.POINTER(PhFieldLayer), vp, cu, cu, vp, vp]),
         "ph_compose_up_write_v210": (ci, [vp, ci, ci, C.POINTER(PhImageLayer), vp, cu, cu, cu, vp, vp]),
         "ph_chan_compose_v210": (ci, [vp, ci, ci, C.POINTER(PhChanLayer), vp, cu, cu, cu, vp, vp, vp, vp, vp]),
+        "ph_chan_compose": (ci, [vp, ci, ci, C.POINTER(PhChanLayer), ci, C.POINTER(C.c_void_p), cu, cu, cu, vp, vp, vp, vp, vp]),
         "ph_route_unique_id": (ci, [vp]),
         "ph_route_init": (ci, [vp, vp, ci, ci, C.POINTER(vp)]),
         "ph_route_destroy": (ci, [vp]),
@@ -465,7 +466,7 @@ class Context:
                                                _ptr(wr_cm), _ptr(wr_lut)), self.h)
 
     def chan_compose_v210(self, layers, dst, out_w, out_h, interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut, queue=QUEUE_PROCESS,
-                          prepare_only=False):
+                          prepare_only=False, out_fmt="v210"):
         """The channel compositor straight from v210 sources (ph_chan_compose_v210).  layers: list of dicts
         {src: SOURCE, transition: "cut" | "dissolve" | "wipe", mix: float, incoming: SOURCE, mask: SOURCE}; a SOURCE is
         (tensor, width, height, matrix) or (tensor, width, height, matrix, "rgba") or ((y, u, v) plane tensors, width, height,
@@ -501,14 +502,22 @@ class Context:
                 fill(arr[i].incoming, L["incoming"])
             if L.get("mask") is not None:
                 fill(arr[i].mask, L["mask"])
-        args = (self.h, queue, len(layers), arr, _ptr(dst), out_w, out_h, interlace, _ptr(rd_cm), _ptr(rd_lut), _ptr(rd_gm), _ptr(wr_cm), _ptr(wr_lut))
+        if out_fmt != "v210":  # dst: the planes of the packed frame (ph_chan_compose); wr_cm None for rgba8 / bgra8
+            planes = (C.c_void_p * 3)(*([_ptr(p).value for p in dst] + [None] * (3 - len(dst))))
+            keep.append(planes)
+            args = (self.h, queue, len(layers), arr, FORMATS[out_fmt], planes, out_w, out_h, interlace, _ptr(rd_cm), _ptr(rd_lut), _ptr(rd_gm),
+                    None if wr_cm is None else _ptr(wr_cm), _ptr(wr_lut))
+            fn = lib().ph_chan_compose
+        else:
+            args = (self.h, queue, len(layers), arr, _ptr(dst), out_w, out_h, interlace, _ptr(rd_cm), _ptr(rd_lut), _ptr(rd_gm), _ptr(wr_cm), _ptr(wr_lut))
+            fn = lib().ph_chan_compose_v210
         if prepare_only:  # a caller that replays the same job (a bench loop) skips the marshalling: job() launches it
-            fn, h = lib().ph_chan_compose_v210, self.h
+            h = self.h
 
             def job(_keep=(keep, layers, dst)):
                 check(fn(*args), h)
             return job
-        check(lib().ph_chan_compose_v210(*args), self.h)
+        check(fn(*args), self.h)
 
     def fused_field_v210(self, layers, dst, out_w, out_h, wr_cm, wr_lut, queue=QUEUE_PROCESS):
         """layers: list of dicts {prev, cur, next (tensors; prev / next None for a progressive source), width, height,

@@ -1166,19 +1166,30 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
         if (layers[i].transition != PH_TRANSITION_CUT) TRY(source(i, "Incoming", &layers[i].incoming));
         if (layers[i].transition == PH_TRANSITION_WIPE) TRY(source(i, "Mask", &layers[i].mask));
       }
-      double interlace = 0;
-      ph_buf *wcm = nullptr, *wl = nullptr;
-      TRY(need_buf(args, n, "output", (size_t)ph_v210_pitch_bytes(width) * height, &o));
+      // output: the packed frame - v210, or with outPacking = PH_FMT_* another wire format: 1 yuv422p10 / 2 yuv422p8 (output = the Y plane,
+      // outputU, outputV), 5 rgba8 / 6 bgra8 (no outColMatrix)
+      double interlace = 0, out_packing = 0;
+      ph_buf *wcm = nullptr, *wl = nullptr, *ou = nullptr, *ov = nullptr;
+      if (find_arg(args, n, "outPacking")) TRY(need_num(args, n, "outPacking", &out_packing));
+      const int ofmt = (int)out_packing;
+      size_t opb[3] = {0, 0, 0};
+      if (ph_pack_plane_bytes(ofmt, width, height, opb) < 0) return fail(PH_E_INVALID, "kernel argument 'outPacking': %g is not a pack format", out_packing);
+      TRY(need_buf(args, n, "output", opb[0], &o));
+      if (ofmt == PH_FMT_YUV422P10 || ofmt == PH_FMT_YUV422P8) {
+        TRY(need_buf(args, n, "outputU", opb[1], &ou));
+        TRY(need_buf(args, n, "outputV", opb[2], &ov));
+      }
       TRY(need_buf(args, n, "colMatrix", 48, &b));
       TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
       TRY(need_buf(args, n, "gamutMatrix", 36, &d));
-      TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
+      if (ofmt != PH_FMT_RGBA8 && ofmt != PH_FMT_BGRA8) TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
       TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
       if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
       if (!check_only) refresh_buf_lut(ctx, c);
       if (!check_only) refresh_buf_lut(ctx, wl);
-      return check_only ? PH_OK : ph_chan_compose_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, b->dptr, c->dptr, d->dptr,
-                                  wcm->dptr, wl->dptr);
+      void *oplanes[3] = {o->dptr, ou ? ou->dptr : nullptr, ov ? ov->dptr : nullptr};
+      return check_only ? PH_OK : ph_chan_compose(ctx, queue, prog->n_layers, layers, ofmt, oplanes, width, height, (uint32_t)interlace, b->dptr, c->dptr, d->dptr,
+                                  wcm ? wcm->dptr : nullptr, wl->dptr);
     }
     case K_COMPOSE_UP: {
       // l<i>In: the layer's image - an RGBA image buffer, or with packedRgb = 1 a buffer of packed f32 RGB (l<i>Width / l<i>Height:
@@ -1656,7 +1667,20 @@ static int chan_source(const ph_chan_source &s, const char *what, int layer, uin
 int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
                          uint32_t interlace, const void *rd_cm, const void *rd_lut, const void *rd_gm, const void *wr_cm,
                          const void *wr_lut) {
-  if (!ctx || !layers || !out || !rd_cm || !rd_lut || !rd_gm || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_chan_compose_v210: NULL argument");
+  void *planes[3] = {out, nullptr, nullptr};
+  return ph_chan_compose(ctx, queue, n, layers, PH_FMT_V210, planes, out_w, out_h, interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut);
+}
+
+int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, int out_format, void *const out_planes[3], uint32_t out_w,
+                    uint32_t out_h, uint32_t interlace, const void *rd_cm, const void *rd_lut, const void *rd_gm, const void *wr_cm,
+                    const void *wr_lut) {
+  if (!ctx || !layers || !out_planes || !out_planes[0] || !rd_cm || !rd_lut || !rd_gm || !wr_lut) return fail(PH_E_INVALID, "ph_chan_compose_v210: NULL argument");
+  void *const out = out_planes[0];
+  const bool out_rgb8 = out_format == PH_FMT_RGBA8 || out_format == PH_FMT_BGRA8, out_planar = out_format == PH_FMT_YUV422P10 || out_format == PH_FMT_YUV422P8;
+  if (out_format != PH_FMT_V210 && !out_rgb8 && !out_planar)
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: output format %d (v210, yuv422p10, yuv422p8, rgba8 or bgra8; run the separate kernels for the others)", out_format);
+  if (!out_rgb8 && !wr_cm) return fail(PH_E_INVALID, "ph_chan_compose_v210: the writer's RGB -> YCbCr matrix is missing");
+  if (out_planar && (!out_planes[1] || !out_planes[2])) return fail(PH_E_INVALID, "ph_chan_compose_v210: a planar output needs its three planes");
   PH_QUEUE("ph_chan_compose_v210", queue);
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_chan_compose_v210: 1..%d layers", ph::kMaxLayers);
   // (a v210 line of a width that is not a multiple of 48 ends in a padded block the reference's writer addresses by width: DESIGN.md section 2)
@@ -1695,7 +1719,9 @@ int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *lay
   a.out = out, a.out_w = out_w, a.out_h = out_h;
   a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0;
   a.lines = interlace ? out_h / 2 : out_h;
-  a.rd_cm = (const float *)rd_cm, a.rd_gm = (const float *)rd_gm, a.wr_cm = (const float *)wr_cm, a.rd = *rv, a.wr = *wv;
+  a.rd_cm = (const float *)rd_cm, a.rd_gm = (const float *)rd_gm, a.wr_cm = (const float *)(wr_cm ? wr_cm : rd_cm), a.rd = *rv, a.wr = *wv;
+  a.out_fmt = (uint32_t)out_format, a.out_u = out_planes[1], a.out_v = out_planes[2];
+  a.out_pitch = out_w;  // planar: width rounded up to 8 samples (yuv422p10.ts:221) - widths here are multiples of 48; rgba8: no padding
   if (!a.lines) return PH_OK;
   int rc = set_device(ctx);
   if (rc) return rc;

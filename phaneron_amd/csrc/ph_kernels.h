@@ -91,6 +91,10 @@ struct ChanArgs {
   const void *plane_u[kMaxChanOps], *plane_v[kMaxChanOps];
   const float *cm_op[kMaxChanOps];
   uint32_t planar;  // launcher: some op is planar
+  // the packed frame the writer makes: 0 v210 (out), 1 yuv422p10 / 2 yuv422p8 (out = the Y plane, out_u, out_v; out_pitch = luma
+  // samples per line), 5 rgba8 / 6 bgra8 (out; out_pitch = pixels per line) - PH_FMT_* numbering
+  uint32_t out_fmt, out_pitch;
+  void *out_u, *out_v;
 };
 
 // ph_kernels_up.hip: the 2 x 2-block compositor for magnifying placements

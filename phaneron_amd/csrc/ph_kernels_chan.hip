@@ -555,7 +555,84 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
 }
 
 // PLANAR: the program has planar sources (an instantiation of its own: the v210 / image kernel is not touched by them)
-template <bool PLANAR>
+// the writer's phase for frames that are not v210 (FromRGBA with the Writers of the reference's other consumers: rgba8 for the screen,
+// screenConsumer.ts:131; yuv422p8 for an encoder, ffmpegConsumer.ts:144; yuv422p10).  Same indices, same table; what differs is the packing.
+template <int OUT>
+__device__ __forceinline__ void chan_phase2_other(const ChanArgs &a, const ChanShare &sh, const WriteK &wk, const LutK &wlut) {
+  const uint2 *const index = reinterpret_cast<const uint2 *>(a.index);
+  auto idx = [](uint32_t bits) __attribute__((always_inline)) { return __uint_as_float((bits & 0xFFFFu) | 0x4B400000u); };  // M + idx (ph_ldslut.h)
+  if (OUT == 5 || OUT == 6) {  // rgba8.ts:69-101: one pixel per lane, alpha 255
+    for (uint32_t t = threadIdx.x; t < 2u * kChanChunk * sh.slots; t += kLdsBlock) {
+      const uint32_t slot = t / (2u * kChanChunk), within = t - slot * (2u * kChanChunk);
+      const uint32_t chunk = chan_chunk(a, sh, slot);
+      if (chunk == ~0u) continue;
+      uint32_t rp, x0;
+      chan_place(a, sh, chunk, rp, x0);
+      const uint32_t li = 2u * rp + (within >= kChanChunk ? 1u : 0u), x = x0 + (within >= kChanChunk ? within - kChanChunk : within);
+      if (li >= a.lines || x >= a.out_w) continue;
+      const uint2 e = index[li * a.out_w + x];
+      const PxPending pend = write_px_issue(idx(e.x), idx(e.x >> 16), idx(e.y), wlut);
+      const float r = lds_lut_finish(pend.r), g = lds_lut_finish(pend.g), b = lds_lut_finish(pend.b);
+      const uint32_t r8 = sat_u8_rte(r * 255.0f), g8 = sat_u8_rte(g * 255.0f), b8 = sat_u8_rte(b * 255.0f);
+      const uint32_t line = a.first_line + li * a.line_step;
+      reinterpret_cast<uint32_t *>(a.out)[(size_t)line * a.out_pitch + x] = OUT == 5 ? (r8 | g8 << 8 | b8 << 16 | 0xff000000u) : (b8 | g8 << 8 | r8 << 16 | 0xff000000u);
+    }
+    return;
+  }
+  // planar 4:2:2 (yuv422p10.ts:140-189, yuv422p8.ts): eight pixels per lane - chroma from the even pixels, codes rounded to 16 bits and
+  // cut to the sample width on store (widths are multiples of 8 here: no tail group)
+  constexpr bool WIDE = OUT == 1;
+  constexpr uint32_t kGroups = kChanChunk / 8u;  // per chunk row
+  for (uint32_t t = threadIdx.x; t < 2u * kGroups * sh.slots; t += kLdsBlock) {
+    const uint32_t slot = t / (2u * kGroups), within = t - slot * (2u * kGroups);
+    const uint32_t chunk = chan_chunk(a, sh, slot);
+    if (chunk == ~0u) continue;
+    uint32_t rp, x0;
+    chan_place(a, sh, chunk, rp, x0);
+    const uint32_t li = 2u * rp + (within >= kGroups ? 1u : 0u), x = x0 + 8u * (within >= kGroups ? within - kGroups : within);
+    if (li >= a.lines || x >= a.out_w) continue;
+    const uint4 *const e4 = reinterpret_cast<const uint4 *>(index + li * a.out_w + x);
+    const uint4 w0 = load_stream(e4), w1 = load_stream(e4 + 1), w2 = load_stream(e4 + 2), w3 = load_stream(e4 + 3);
+    const uint32_t pk[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+    uint32_t y[8], u[4], v[4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // four pixels' twelve table reads in flight at a time
+      PxPending pend[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pend[j] = write_px_issue(idx(pk[2 * (4 * half + j)]), idx(pk[2 * (4 * half + j)] >> 16), idx(pk[2 * (4 * half + j) + 1]), wlut);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int p = 4 * half + j;
+        const float gr = lds_lut_finish(pend[j].r), gg = lds_lut_finish(pend[j].g), gb = lds_lut_finish(pend[j].b);
+        y[p] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.y));
+        if (!(p & 1)) u[p >> 1] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.u)), v[p >> 1] = sat_u16_rte(dot4(gr, gg, gb, 1.0f, wk.v));
+      }
+    }
+    const uint32_t line = a.first_line + li * a.line_step;
+    const size_t o8 = ((size_t)line * a.out_pitch + x) >> 3;
+    if (WIDE) {
+      uint4 wy;
+      wy.x = (y[0] & 0xffff) | y[1] << 16, wy.y = (y[2] & 0xffff) | y[3] << 16, wy.z = (y[4] & 0xffff) | y[5] << 16, wy.w = (y[6] & 0xffff) | y[7] << 16;
+      store_stream(reinterpret_cast<uint4 *>(a.out) + o8, wy);
+      uint2 wu, wv;
+      wu.x = (u[0] & 0xffff) | u[1] << 16, wu.y = (u[2] & 0xffff) | u[3] << 16;
+      wv.x = (v[0] & 0xffff) | v[1] << 16, wv.y = (v[2] & 0xffff) | v[3] << 16;
+      reinterpret_cast<uint2 *>(a.out_u)[o8] = wu;
+      reinterpret_cast<uint2 *>(a.out_v)[o8] = wv;
+    } else {  // uchar = (uchar)ushort keeps the low 8 bits (yuv422p8.ts:166-168)
+      uint2 wy;
+      wy.x = (y[0] & 0xff) | (y[1] & 0xff) << 8 | (y[2] & 0xff) << 16 | y[3] << 24;
+      wy.y = (y[4] & 0xff) | (y[5] & 0xff) << 8 | (y[6] & 0xff) << 16 | y[7] << 24;
+      reinterpret_cast<uint2 *>(a.out)[o8] = wy;
+      reinterpret_cast<uint32_t *>(a.out_u)[o8] = (u[0] & 0xff) | (u[1] & 0xff) << 8 | (u[2] & 0xff) << 16 | u[3] << 24;
+      reinterpret_cast<uint32_t *>(a.out_v)[o8] = (v[0] & 0xff) | (v[1] & 0xff) << 8 | (v[2] & 0xff) << 16 | v[3] << 24;
+    }
+  }
+}
+
+// OUT: the packed frame's format (0 v210; the others only with the wire-format instantiation PLANAR = true)
+template <bool PLANAR, int OUT = 0>
 __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a) {
   const ReadK rk = load_read_k(a.rd_cm, a.rd_gm);
   const WriteK wk = load_write_k(a.wr_cm);
@@ -573,6 +650,10 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
   lds_lut_load(a.wr);
   __syncthreads();
   PH_CPHASE(4);
+  if (OUT != 0) {
+    chan_phase2_other<OUT>(a, sh, wk, wlut);
+    return;
+  }
   // phase 2: one quad per lane.  The indices were written by other waves of THIS workgroup: read past the L1.
   const uint32_t qpl = a.out_w / 6;
   const uint4 *const index = reinterpret_cast<const uint4 *>(a.index);
@@ -604,9 +685,6 @@ size_t chan_index_bytes(uint32_t out_w, uint32_t lines) { return (size_t)out_w *
 hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t num_cus) {
   if (!a.lines) return hipSuccess;
   const uint32_t lds = a.rd.bytes > a.wr.bytes ? a.rd.bytes : a.wr.bytes;
-  const void *fn = a.planar ? reinterpret_cast<const void *>(chan_compose_v210_kernel<true>) : reinterpret_cast<const void *>(chan_compose_v210_kernel<false>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
   const uint32_t cpr = (a.out_w + kChanChunk - 1u) / kChanChunk, cpg = (uint32_t)(PH_CHAN_GROUP_ROWS / 2) * cpr;
   const uint32_t chunks = cpr * ((a.lines + 1u) / 2u);  // 192 pixels x 2 rows each (a row's last chunk may be short)
   const uint32_t want = chunks;                         // a workgroup per chunk at most: 6 wave steps
@@ -614,9 +692,21 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
   // reciprocals for the kernel's uniform divisions: umulhi(v, ceil(2^32 / d)) == v / d for every v * d < 2^32 (chunk counts are far below)
   b.magic_cpr = cpr > 1 ? (uint32_t)(((1ull << 32) + cpr - 1) / cpr) : 0u;
   b.magic_cpg = (uint32_t)(((1ull << 32) + cpg - 1) / cpg);
-  if (a.planar) chan_compose_v210_kernel<true><<<want < num_cus ? want : num_cus, kLdsBlock, lds, s>>>(b);
-  else chan_compose_v210_kernel<false><<<want < num_cus ? want : num_cus, kLdsBlock, lds, s>>>(b);
-  return hipGetLastError();
+  const uint32_t grid = want < num_cus ? want : num_cus;
+  auto go = [&](auto kernel) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    kernel<<<grid, kLdsBlock, lds, s>>>(b);
+    return hipGetLastError();
+  };
+  switch (a.out_fmt) {  // frames other than v210 are made by the wire-format instantiation, whatever the sources
+    case 0: return a.planar ? go(chan_compose_v210_kernel<true, 0>) : go(chan_compose_v210_kernel<false, 0>);
+    case 1: return go(chan_compose_v210_kernel<true, 1>);
+    case 2: return go(chan_compose_v210_kernel<true, 2>);
+    case 5: return go(chan_compose_v210_kernel<true, 5>);
+    case 6: return go(chan_compose_v210_kernel<true, 6>);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace ph

@@ -399,3 +399,42 @@ def test_widths_that_are_not_whole_chunks(w, h, interlace):
     layers = pip_layers(w, h, 600 + w + interlace, 3)
     layers.append(dict(src=Src(frames.pack_random("yuv420p", w, h + (h & 1), 601), w, h + (h & 1), m(w, h, scale_x=0.6, scale_y=0.6, offset_x=0.2, offset_y=0.2), fmt="yuv420p")))
     check(layers, w, h, "%dx%d interlace %d" % (w, h, interlace), interlace=interlace, poison_dst=interlace != 0)
+
+
+def placed_and_combined(layers, ow, oh, rd_o):
+    """the oracle's composite of a layer list (no transitions) as an RGBA image"""
+    placed = [L["src"].oracle(rd_o, ow, oh) for L in layers]
+    return placed[0] if len(placed) == 1 else orc.combine(placed)
+
+
+@pytest.mark.parametrize("fmt", ["rgba8", "bgra8", "yuv422p8", "yuv422p10"])
+@pytest.mark.parametrize("interlace", [0, 1, 3])
+def test_other_output_formats(fmt, interlace):
+    """the channel's packed frame in the formats of the reference's other consumers - rgba8 / bgra8 for the screen
+    (screenConsumer.ts:131), yuv422p8 for an encoder (ffmpegConsumer.ts:144), yuv422p10 - whole frames and single fields (the other
+    field's lines stay as they were), from v210, planar and graphics sources: against the oracle's chain ending in that format's writer"""
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    w, h = 384, 54
+    rd_o, _, rd_d, _ = colour("709", "709")
+    layers = pip_layers(w, h, 700 + interlace, 3)
+    layers.append(dict(src=Src(frames.pack_random("bgra8", 100, 30, 701), 100, 30, m(w, h, scale_x=0.3, scale_y=0.5, offset_x=0.3, offset_y=-0.2), fmt="bgra8")))
+    layers.append(dict(src=Src(frames.pack_random("yuv420p", w, h, 702), w, h, m(w, h, **PIP[3]), fmt="yuv420p")))
+    rng = orc.FORMAT_RANGE[fmt]
+    wcm_o = None if rng is None else orc.rgb2ycbcr_matrix("709", *rng)
+    wlut_o = orc.linear2gamma_lut("709")
+    before = [np.full(n, 0x5A, np.uint8) for n in frames.pack_plane_bytes(fmt, w, h)]
+    want = orc.pack_write(fmt, placed_and_combined(layers, w, h, rd_o), w, h, interlace, wcm_o, wlut_o, planes=before)
+    k = hh.ctx()
+    dst = [hh.dev(b.copy()) for b in before]
+    wlut_d = hh.ColourParams.writer("709")[1]
+    wcm_d = None if rng is None else hh.dev(capi.rgb2ycbcr_matrix("709", *rng))
+    dl = [dict(src=L["src"].device()) for L in layers]
+    k.chan_compose_v210(dl, dst, w, h, interlace, *rd_d, wcm_d, wlut_d, out_fmt=fmt)
+    k.wait()
+    torch.cuda.synchronize()
+    for i, (g, wnt) in enumerate(zip(dst, want)):
+        got = hh.host(g, np.uint8)
+        bad = np.flatnonzero(got != wnt)
+        assert bad.size == 0, "%s interlace %d plane %d: %d of %d bytes differ, first at %d" % (fmt, interlace, i, bad.size, got.size, bad[0])
