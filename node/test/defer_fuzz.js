@@ -36,6 +36,9 @@ async function play(seed, deferred) {
 	}
 	const FORMATS = ['v210', 'v210', 'yuv422p10', 'yuv422p8', 'yuv420p', 'nv12', 'rgba8', 'bgra8'] // sources come in every pack format (v210 twice as often)
 	for (const f of FORMATS.slice(2)) S.readAs[f] = await rig.unpack(f, W, H, '709', '2020')
+	const OUT_FORMATS = ['v210', 'v210', 'v210', 'rgba8', 'bgra8', 'yuv422p8', 'yuv422p10'] // packed frames for every consumer of the reference (v210 most often)
+	S.writeAs = { v210: [S.write, S.writeField] }
+	for (const f of OUT_FORMATS.slice(3)) S.writeAs[f] = [await rig.pack(f, W, H, '2020', false), await rig.pack(f, W, H, '2020', true)]
 	const r = rng(seed)
 	const pick = (list) => list[r() % list.length]
 	const seen = []
@@ -104,13 +107,14 @@ async function play(seed, deferred) {
 			if (outs.length && r() % 3 === 0) {
 				const o = pick(outs)
 				const field = r() % 2 ? 1 : 3
-				await rig.run(S.writeField(pick(images), [o.buf], field))
+				await rig.run(S.writeAs[o.fmt][1](pick(images), o.planes, field))
 				log.push(`write field ${field}`)
 			} else {
-				const buf = (await rig.planes('v210', W, H, 'writeonly'))[0]
-				await up(buf, Buffer.alloc(v210Bytes, 0x15))
-				await rig.run(S.write(pick(images), [buf], 0))
-				outs.push({ buf }); log.push('write')
+				const fmt = pick(OUT_FORMATS)
+				const planes = await rig.planes(fmt, W, H, 'writeonly')
+				for (const p of planes) await up(p, Buffer.alloc(p.length, 0x15))
+				await rig.run(S.writeAs[fmt][0](pick(images), planes, 0))
+				outs.push({ fmt, planes }); log.push(`write ${fmt}`)
 			}
 		} else if (op === 12) { // the next frame into an old source, or a new placement into the live matrix
 			if (r() % 2) await refill(pick(sources)); else await setLive(r())
@@ -120,14 +124,15 @@ async function play(seed, deferred) {
 			images[i].release()
 			images.splice(i, 1); log.push('release')
 		} else if (op === 14 && outs.length) { // a consumer maps a packed frame
-			await consume(pick(outs).buf); log.push('consume out')
+			for (const p of pick(outs).planes) await consume(p)
+			log.push('consume out')
 		} else if (op === 15) { // somebody maps an image in the middle of everything
 			await consume(pick(images)); log.push('consume image')
 		}
 		if (r() % 7 === 0) await rig.sync()
 	}
-	for (const o of outs) await consume(o.buf)
-	;[...images, ...sources.map((x) => x.planes).flat(), ...outs.map((o) => o.buf), live].forEach((b) => b.release())
+	for (const o of outs) for (const p of o.planes) await consume(p)
+	;[...images, ...sources.map((x) => x.planes).flat(), ...outs.map((o) => o.planes).flat(), live].forEach((b) => b.release())
 	rig.close()
 	const stats = rig.ctx.deferredStats()
 	const left = rig.ctx.flushDeferred()
