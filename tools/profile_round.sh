@@ -7,6 +7,11 @@ OUT=$ROOT/gpurun_out/profile; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py"
 
+# 0. the stand-alone microbenchmarks (binaries are not tracked: built here when the snapshot did not bring them)
+for t in microbench opbench3 opbench4; do
+  [ -x $ROOT/tools/$t ] || hipcc --offload-arch=gfx950 -O2 -o $ROOT/tools/$t $ROOT/tools/$t.hip > /dev/null 2>&1
+done
+
 # 1. the bench line exactly as the driver runs it
 $BENCH > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 tail -1 $OUT/${TAG}_bench.json
