@@ -28,7 +28,8 @@ extern "C" {
 /* 2: additive over 1 - ph_program_resolve, ph_route_*, ph_yadif_pair, ph_v210_yadif_pair, ph_v210_read_batch,
  *    ph_fused_field_v210, ph_compose_wipe_write_v210, context option "stream_images"; no signature of 1 changed */
 /* 3: additive over 2 - ph_chan_compose_v210 (ph_chan_source / ph_chan_layer), ph_compose_up_write_v210, ph_v210_yadif_pair_fmt,
- *    ph_check_program, ph_route_comm_count, context option "host_pool_mb"; no signature of 2 changed */
+ *    ph_chan_compose, ph_yadif_pair_packed (ph_deint_source grew), ph_check_program, ph_route_comm_count, context option
+ *    "host_pool_mb"; no signature of 2 changed */
 #define PH_ABI_VERSION 3
 
 enum {
@@ -243,8 +244,9 @@ int ph_yadif_pair(ph_ctx *ctx, int queue, const void *prev, const void *cur, con
  *      followed by ph_yadif with parity 0 / 1.  n sources of one size and one colour recipe per call (the layers of a
  *      channel).  Needs width % 6 == 0 and the reader LUT registered (PH_E_INVALID otherwise - run the separate kernels). */
 typedef struct ph_deint_source {
-  const void *prev, *cur, *next;      /* device, v210, width x height */
+  const void *prev, *cur, *next;      /* device, v210, width x height (ph_yadif_pair_packed: or the Y planes of planar frames) */
   void *out_parity0, *out_parity1;    /* device, float RGBA, width x height */
+  const void *prev_u, *prev_v, *cur_u, *cur_v, *next_u, *next_v; /* ph_yadif_pair_packed with a planar packing: the chroma planes */
 } ph_deint_source;
 int ph_v210_yadif_pair(ph_ctx *ctx, int queue, int n, const ph_deint_source *sources, uint32_t width, uint32_t height,
                        int tff, int skip_spatial, const void *rd_col_matrix12, const void *rd_gamma_lut,
@@ -257,6 +259,12 @@ int ph_v210_yadif_pair(ph_ctx *ctx, int queue, int n, const ph_deint_source *sou
 int ph_v210_yadif_pair_fmt(ph_ctx *ctx, int queue, int n, const ph_deint_source *sources, uint32_t width, uint32_t height,
                            int tff, int skip_spatial, int out_format, const void *rd_col_matrix12, const void *rd_gamma_lut,
                            const void *rd_gamut_matrix9);
+/* the same over windows of interlaced FILE frames: packing = PH_FMT_YUV422P10 or PH_FMT_YUV422P8 (planar 4:2:2, what decoders of
+ * XDCAM / ProRes / DNxHD material hand over; every source of the call in that packing, unpacked with the call's Loader recipe - for
+ * the 8-bit packing the 8-bit Loader's matrix), or PH_FMT_V210 (= the call above) */
+int ph_yadif_pair_packed(ph_ctx *ctx, int queue, int n, const ph_deint_source *sources, int packing, uint32_t width, uint32_t height,
+                         int tff, int skip_spatial, int out_format, const void *rd_col_matrix12, const void *rd_gamma_lut,
+                         const void *rd_gamut_matrix9);
 
 /* transform.ts:36-59 (matrix9: device pointer to the 3x3 row-major matrix) */
 int ph_transform(ph_ctx *ctx, int queue, const void *in, int in_w, int in_h, const void *matrix9,

@@ -225,20 +225,26 @@ class Deferral {
 		return { width: node.params.width, lines }
 	}
 
-	// Layers that are de-interlaced sources: [transform of] `yadif` of three images that are pending v210 reads.  The Yadif
+	// Layers that are de-interlaced sources: [transform of] `yadif` of three images that are pending reads of v210 frames (SDI) or of
+	// planar 4:2:2 frames (yuv422p10 / yuv422p8: interlaced files).  The Yadif
 	// valve posts both fields of a frame (yadif.ts:100-145, send_field: parity 1 ^ tff, then parity tff); the pair over one
 	// window, for every such layer of the channel, is ONE launch of v210_yadif_pair_<k> on the v210 frames themselves
 	// (unpack + filter, both fields: ph_kernels_deint.hip), bit-identical to read x 3 -> yadif x 2.  Anything that does not
 	// fit (one field only, an image of the window already real, mixed sizes) is left to run as recorded.
 	_deinterlace(layerImages) {
-		const found = new Map() // cur image -> { windows of v210 sources, the two yadif nodes }
-		const v210Of = (img, w, h, reader) => {
+		const found = new Map() // cur image -> { windows of wire-format sources, the two yadif nodes }
+		const PACKING = { v210: 0, yuv422p10: 1, yuv422p8: 2 } // SDI frames, or planar 4:2:2 frames of interlaced files
+		// the wire-format frame behind an image of the window: [planes], if it is a pending ToRGBA of `fmt` with the window's Loader recipe
+		const framesOf = (img, w, h, reader, fmt) => {
 			const p = img && img._producer
-			if (!p || p.state !== 'pending' || !Deferral._isV210(p.program, 'read') || !p.params.input) return null
+			if (!p || p.state !== 'pending' || p.program.name !== 'read' || p.program.format !== fmt) return null
+			const q = p.params
+			const planes = fmt === 'v210' ? [q.input] : [q.inputY, q.inputU, q.inputV]
+			if (planes.some((b) => !b)) return null
 			const f = Deferral._frameOf(p)
 			if (f.width !== w || f.lines !== h || !img.imageDims || img.imageDims.width !== w || img.imageDims.height !== h) return null
-			if (!Deferral.sameRecipe(reader, p.params)) return null
-			return p.params.input
+			if (!Deferral.sameRecipe(reader, q)) return null
+			return planes
 		}
 		for (let img of layerImages) {
 			let p = img._producer
@@ -246,11 +252,12 @@ class Deferral {
 			if (!p || p.state !== 'pending' || p.program.name !== 'yadif' || found.has(p.params.cur)) continue
 			const { prev, cur, next } = p.params
 			const rd = cur && cur._producer
-			if (!prev || !cur || !next || !rd || !p.params.output) continue
+			if (!prev || !cur || !next || !rd || !p.params.output || rd.program.name !== 'read' || PACKING[rd.program.format] === undefined) continue
+			const fmt = rd.program.format
 			const [w, h] = p.program.globalWorkItems
 			const reader = { colMatrix: rd.params.colMatrix, gammaLut: rd.params.gammaLut, gamutMatrix: rd.params.gamutMatrix }
-			if (!reader.colMatrix || !reader.gammaLut || !reader.gamutMatrix) continue
-			const src = [v210Of(prev, w, h, reader), v210Of(cur, w, h, reader), v210Of(next, w, h, reader)]
+			if (!reader.colMatrix || !reader.gammaLut || !reader.gamutMatrix || w % (fmt === 'v210' ? 6 : 2)) continue
+			const src = [framesOf(prev, w, h, reader, fmt), framesOf(cur, w, h, reader, fmt), framesOf(next, w, h, reader, fmt)]
 			if (src.includes(null)) continue
 			// the other field of the same window
 			let twin = null
@@ -260,12 +267,12 @@ class Deferral {
 					r.params.output && r.params.output !== p.params.output) twin = r
 			if (!twin) continue
 			const out = p.params.parity ? [twin.params.output, p.params.output] : [p.params.output, twin.params.output]
-			found.set(cur, { src, out, nodes: [p, twin], w, h, reader, tff: p.params.tff ? 1 : 0, skip: p.params.skipSpatial ? 1 : 0 })
+			found.set(cur, { src, out, nodes: [p, twin], w, h, reader, fmt, tff: p.params.tff ? 1 : 0, skip: p.params.skipSpatial ? 1 : 0 })
 		}
 		// one launch per group of windows that share size, field order and Loader recipe
 		const groups = []
 		for (const e of found.values()) {
-			let g = groups.find((v) => v.length < 8 && v[0].w === e.w && v[0].h === e.h && v[0].tff === e.tff && v[0].skip === e.skip &&
+			let g = groups.find((v) => v.length < 8 && v[0].w === e.w && v[0].h === e.h && v[0].tff === e.tff && v[0].skip === e.skip && v[0].fmt === e.fmt &&
 				Deferral.sameRecipe(v[0].reader, e.reader))
 			if (!g) groups.push((g = []))
 			g.push(e)
@@ -273,8 +280,12 @@ class Deferral {
 		for (const g of groups) {
 			const e0 = g[0]
 			const params = Object.assign({ tff: e0.tff, skipSpatial: e0.skip }, e0.reader)
+			if (PACKING[e0.fmt]) params.packing = PACKING[e0.fmt]
 			g.forEach((e, i) => {
-				params[`l${i}Prev`] = e.src[0]; params[`l${i}Cur`] = e.src[1]; params[`l${i}Next`] = e.src[2]
+				;['Prev', 'Cur', 'Next'].forEach((which, f) => {
+					params[`l${i}${which}`] = e.src[f][0]
+					if (e.src[f].length === 3) { params[`l${i}${which}U`] = e.src[f][1]; params[`l${i}${which}V`] = e.src[f][2] }
+				})
 				params[`l${i}Out0`] = e.out[0]; params[`l${i}Out1`] = e.out[1]
 			})
 			if (!this._try(this._program(`v210_yadif_pair_${g.length}`, e0.w, e0.h), params, e0.nodes[0].queue)) continue

@@ -454,6 +454,45 @@ async function main() {
 		return seen
 	}, { fused: 4, plain: 0, launched: 4, fallbacks: 0 })
 
+	// interlaced file sources: windows of planar 4:2:2 frames (yuv422p10, yuv422p8), both fields de-interlaced, placed, packed
+	await scenario('interlaced file sources: planar windows de-interlaced', async (s) => {
+		s.frame = 20
+		const seen = []
+		for (const fmt of ['yuv422p10', 'yuv422p8']) {
+			const win = []
+			const u = []
+			for (let i = 0; i < 3; ++i) {
+				const planes = await s.sourcePlanar(fmt, 1100 + i)
+				const im = await s.rig.image(W, H)
+				await s.rig.run(s.readAs[fmt](planes, im))
+				win.push(planes)
+				u.push(im)
+			}
+			const bg = await s.source(v210Frame(full, 1110))
+			const ubg = await s.rig.image(W, H)
+			await s.rig.run(s.read([bg], ubg))
+			const fields = []
+			for (const parity of [0, 1]) {
+				const y = await s.rig.image(W, H)
+				await s.rig.run(s.yadif(u[0], u[1], u[2], y, { parity, tff: 1, skipSpatial: 0 }))
+				fields.push(y)
+			}
+			for (const y of fields) {
+				const py = await s.rig.image(W, H)
+				await s.rig.run(s.transform(y, py, await s.transform.matrix({ scaleX: 0.6, scaleY: 0.6, offsetX: 0.1 })))
+				const comb = await s.rig.image(W, H)
+				await s.rig.run(s.combine[2]([ubg, py], comb))
+				const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+				await s.rig.run(s.write(comb, [out], 0))
+				;[y, py, comb].forEach((x) => x.release())
+				seen.push(await s.consume(out))
+				out.release()
+			}
+			;[...win.flat(), ...u, bg, ubg].forEach((x) => x.release())
+		}
+		return seen
+	}, { fused: 6, plain: 0, launched: 6, fallbacks: 0 })
+
 	process.stdout.write(JSON.stringify({ width: W, height: H, scenarios, problems }) + '\n')
 }
 main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })

@@ -22,7 +22,7 @@ EXPORTS = [
     "ph_abi_version", "ph_last_error", "ph_ctx_create", "ph_ctx_destroy", "ph_ctx_info", "ph_ctx_stream",
     "ph_wait_finish", "ph_buf_create", "ph_buf_wrap", "ph_buf_addref", "ph_buf_release", "ph_buf_refcount",
     "ph_buf_bytes", "ph_buf_device_ptr", "ph_buf_dims", "ph_buf_host_access", "ph_buf_host_ptr",
-    "ph_ctx_buffer_stats", "ph_program_create", "ph_program_destroy", "ph_program_kernel", "ph_run_program", "ph_check_program", "ph_chan_compose",
+    "ph_ctx_buffer_stats", "ph_program_create", "ph_program_destroy", "ph_program_kernel", "ph_run_program", "ph_check_program", "ph_chan_compose", "ph_yadif_pair_packed",
     "ph_v210_pitch_bytes", "ph_v210_read", "ph_v210_read_batch", "ph_v210_write", "ph_yadif", "ph_yadif_pair", "ph_v210_yadif_pair", "ph_transform", "ph_resize", "ph_combine",
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
@@ -59,7 +59,8 @@ class PhLayerWipe(C.Structure):
 
 
 class PhDeintSource(C.Structure):
-    _fields_ = [("prev", C.c_void_p), ("cur", C.c_void_p), ("next", C.c_void_p), ("out_parity0", C.c_void_p), ("out_parity1", C.c_void_p)]
+    _fields_ = [("prev", C.c_void_p), ("cur", C.c_void_p), ("next", C.c_void_p), ("out_parity0", C.c_void_p), ("out_parity1", C.c_void_p),
+                ("prev_u", C.c_void_p), ("prev_v", C.c_void_p), ("cur_u", C.c_void_p), ("cur_v", C.c_void_p), ("next_u", C.c_void_p), ("next_v", C.c_void_p)]
 
 
 class PhFieldLayer(C.Structure):
@@ -158,6 +159,7 @@ def lib():
         "ph_yadif_pair": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
         "ph_v210_yadif_pair": (ci, [vp, ci, ci, vp, cu, cu, ci, ci, vp, vp, vp]),
         "ph_v210_yadif_pair_fmt": (ci, [vp, ci, ci, vp, cu, cu, ci, ci, ci, vp, vp, vp]),
+        "ph_yadif_pair_packed": (ci, [vp, ci, ci, vp, ci, cu, cu, ci, ci, ci, vp, vp, vp]),
         "ph_transform": (ci, [vp, ci, vp, ci, ci, vp, vp, ci, ci]),
         "ph_resize": (ci, [vp, ci, vp, ci, ci, cf, cf, cf, vp, vp, ci, ci]),
         "ph_combine": (ci, [vp, ci, ci, C.POINTER(vp), ci, ci, vp]),
@@ -370,22 +372,27 @@ class Context:
                                   _ptr(dst_parity0), _ptr(dst_parity1)), self.h)
 
     def v210_yadif_pair(self, sources, width, height, tff, skip_spatial, col_matrix, lut, gamut, queue=QUEUE_PROCESS, rgb=False,
-                        prepare_only=False):
+                        prepare_only=False, packing="v210"):
         """sources: [(prev, cur, next, dst_parity0, dst_parity1)] - v210 windows in, both de-interlaced fields out (f32 RGBA,
-        or with rgb=True packed f32 RGB, 12 bytes per pixel); == v210_read x 3 -> yadif x 2 per source, as one kernel"""
+        or with rgb=True packed f32 RGB, 12 bytes per pixel); == v210_read x 3 -> yadif x 2 per source, as one kernel.
+        packing "yuv422p10" / "yuv422p8": prev, cur, next are (y, u, v) plane triples (ph_yadif_pair_packed)"""
         arr = (PhDeintSource * len(sources))()
         for i, s in enumerate(sources):
-            arr[i].prev, arr[i].cur, arr[i].next = (_ptr(b).value for b in s[:3])
+            if packing == "v210":
+                arr[i].prev, arr[i].cur, arr[i].next = (_ptr(b).value for b in s[:3])
+            else:
+                (arr[i].prev, arr[i].prev_u, arr[i].prev_v), (arr[i].cur, arr[i].cur_u, arr[i].cur_v), (arr[i].next, arr[i].next_u, arr[i].next_v) = (
+                    tuple(_ptr(p).value for p in frame) for frame in s[:3])
             arr[i].out_parity0, arr[i].out_parity1 = _ptr(s[3]).value, _ptr(s[4]).value
-        args = (self.h, queue, len(sources), arr, width, height, int(tff), int(skip_spatial), IMG_RGB_F32 if rgb else IMG_RGBA_F32,
+        args = (self.h, queue, len(sources), arr, FORMATS[packing], width, height, int(tff), int(skip_spatial), IMG_RGB_F32 if rgb else IMG_RGBA_F32,
                 _ptr(col_matrix), _ptr(lut), _ptr(gamut))
         if prepare_only:
-            fn, h = lib().ph_v210_yadif_pair_fmt, self.h
+            fn, h = lib().ph_yadif_pair_packed, self.h
 
             def job(_keep=(sources,)):
                 check(fn(*args), h)
             return job
-        check(lib().ph_v210_yadif_pair_fmt(*args), self.h)
+        check(lib().ph_yadif_pair_packed(*args), self.h)
 
     def compose_up_write_v210(self, layers, dst, out_w, out_h, interlace, wr_cm, wr_lut, queue=QUEUE_PROCESS, rgb=False, prepare_only=False):
         """The 2 x 2-block compositor for layers enlarged 2x or more (ph_compose_up_write_v210).  layers: [(tensor, width,

@@ -1052,13 +1052,31 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       // l<i>Prev / l<i>Cur / l<i>Next: v210 window; l<i>Out0 / l<i>Out1: RGBA; colMatrix / gammaLut / gamutMatrix: the Loader's
       const uint32_t width = prog->global[0], height = prog->global[1];
       if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
-      double tff, skip, rgb = 0;  // packedRgb (optional): 1 = the outputs are packed f32 RGB (12 bytes per pixel) for compose_up_write_v210_<n>
+      double tff, skip, rgb = 0, packing = 0;  // packedRgb (optional): 1 = the outputs are packed f32 RGB (12 bytes per pixel) for compose_up_write_v210_<n>
       if (find_arg(args, n, "packedRgb")) TRY(need_num(args, n, "packedRgb", &rgb));
-      const size_t vb = (size_t)ph_v210_pitch_bytes(width) * height, img = (size_t)width * height * (rgb != 0 ? 12 : 16);
+      // packing (optional): 1 yuv422p10 / 2 yuv422p8 - the windows are planar 4:2:2 frames: l<i>Prev / Cur / Next their Y planes,
+      // l<i>PrevU, l<i>PrevV, l<i>CurU ... their chroma planes
+      if (find_arg(args, n, "packing")) TRY(need_num(args, n, "packing", &packing));
+      const int pfmt = (int)packing;
+      size_t pb[3] = {0, 0, 0};
+      if (pfmt != PH_FMT_V210 && pfmt != PH_FMT_YUV422P10 && pfmt != PH_FMT_YUV422P8) return fail(PH_E_INVALID, "kernel argument 'packing': %g (0 v210, 1 yuv422p10, 2 yuv422p8)", packing);
+      ph_pack_plane_bytes(pfmt, width, height, pb);
+      const size_t vb = pb[0], img = (size_t)width * height * (rgb != 0 ? 12 : 16);
       ph_deint_source src[ph::kMaxLayers];
+      memset(src, 0, sizeof src);
       for (int i = 0; i < prog->n_layers; ++i) {
         char nm[16];
         ph_buf *x = nullptr;
+        if (pfmt != PH_FMT_V210) {
+          static const char *const which[3] = {"Prev", "Cur", "Next"};
+          const void **slots[3][2] = {{&src[i].prev_u, &src[i].prev_v}, {&src[i].cur_u, &src[i].cur_v}, {&src[i].next_u, &src[i].next_v}};
+          for (int f = 0; f < 3; ++f)
+            for (int c = 0; c < 2; ++c) {
+              snprintf(nm, sizeof nm, "l%d%s%c", i, which[f], c ? 'V' : 'U');
+              TRY(need_buf(args, n, nm, pb[1 + c], &x));
+              *slots[f][c] = x->dptr;
+            }
+        }
         snprintf(nm, sizeof nm, "l%dPrev", i);
         TRY(need_buf(args, n, nm, vb, &x));
         src[i].prev = x->dptr;
@@ -1081,7 +1099,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_num(args, n, "tff", &tff));
       TRY(need_num(args, n, "skipSpatial", &skip));
       if (!check_only) refresh_buf_lut(ctx, c);
-      return check_only ? PH_OK : ph_v210_yadif_pair_fmt(ctx, queue, prog->n_layers, src, width, height, (int)tff, (int)skip, rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32,
+      return check_only ? PH_OK : ph_yadif_pair_packed(ctx, queue, prog->n_layers, src, pfmt, width, height, (int)tff, (int)skip, rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32,
                                     b->dptr, c->dptr, d->dptr);
     }
     case K_CHAN_COMPOSE: {
@@ -1850,10 +1868,19 @@ int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer
 
 int ph_v210_yadif_pair_fmt(ph_ctx *ctx, int queue, int n, const ph_deint_source *src, uint32_t width, uint32_t height, int tff,
                            int skip, int out_format, const void *cm, const void *lut, const void *gm) {
+  return ph_yadif_pair_packed(ctx, queue, n, src, PH_FMT_V210, width, height, tff, skip, out_format, cm, lut, gm);
+}
+
+int ph_yadif_pair_packed(ph_ctx *ctx, int queue, int n, const ph_deint_source *src, int packing, uint32_t width, uint32_t height, int tff,
+                         int skip, int out_format, const void *cm, const void *lut, const void *gm) {
   if (!ctx || !src || !cm || !lut || !gm) return fail(PH_E_INVALID, "ph_v210_yadif_pair: NULL argument");
+  if (packing != PH_FMT_V210 && packing != PH_FMT_YUV422P10 && packing != PH_FMT_YUV422P8)
+    return fail(PH_E_INVALID, "ph_v210_yadif_pair: packing %d (v210, yuv422p10 or yuv422p8; run the separate kernels for the others)", packing);
+  const bool planar = packing != PH_FMT_V210;
   if (out_format != PH_IMG_RGBA_F32 && out_format != PH_IMG_RGB_F32) return fail(PH_E_INVALID, "ph_v210_yadif_pair: output format %d", out_format);
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_v210_yadif_pair: 1..%d sources", ph::kMaxLayers);
-  if (!width || width % 6) return fail(PH_E_INVALID, "ph_v210_yadif_pair: width %u is not a multiple of 6; run the separate kernels", width);
+  if (!width || (planar ? width % 2 : width % 6))
+    return fail(PH_E_INVALID, "ph_v210_yadif_pair: width %u is not a multiple of %d; run the separate kernels", width, planar ? 2 : 6);
   const ph::LutView *v = lds_view(ctx, lut);
   if (!v) return fail(PH_E_INVALID, "ph_v210_yadif_pair: the reader gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)");
   ph::DeintArgs a{};
@@ -1864,9 +1891,15 @@ int ph_v210_yadif_pair_fmt(ph_ctx *ctx, int queue, int n, const ph_deint_source 
     if (s.out_parity0 == s.out_parity1) return fail(PH_E_INVALID, "ph_v210_yadif_pair: source %d: the two outputs are the same buffer", i);
     a.prev[i] = (const uint4 *)s.prev, a.cur[i] = (const uint4 *)s.cur, a.next[i] = (const uint4 *)s.next;
     a.out0[i] = (float4 *)s.out_parity0, a.out1[i] = (float4 *)s.out_parity1;
+    if (planar) {
+      if (!s.prev_u || !s.prev_v || !s.cur_u || !s.cur_v || !s.next_u || !s.next_v) return fail(PH_E_INVALID, "ph_v210_yadif_pair: source %d: a planar window needs its chroma planes", i);
+      a.prev_u[i] = s.prev_u, a.prev_v[i] = s.prev_v, a.cur_u[i] = s.cur_u, a.cur_v[i] = s.cur_v, a.next_u[i] = s.next_u, a.next_v[i] = s.next_v;
+    }
   }
   if (!height) return PH_OK;
-  a.n = n, a.skip = skip ? 1 : 0, a.width = width, a.height = height, a.quads_pitch = ph_v210_pitch_bytes(width) / 16;
+  a.pack = packing == PH_FMT_V210 ? 0u : packing == PH_FMT_YUV422P10 ? 1u : 2u;
+  // quads_pitch: a v210 line in 16-byte quads, or (planar) the luma samples per line: the width rounded up to 8 (yuv422p10.ts:221)
+  a.n = n, a.skip = skip ? 1 : 0, a.width = width, a.height = height, a.quads_pitch = planar ? ((width + 7u) & ~7u) : ph_v210_pitch_bytes(width) / 16;
   a.rgb12 = out_format == PH_IMG_RGB_F32 ? 1u : 0u;
   a.cm = (const float *)cm, a.gm = (const float *)gm, a.lut = *v;
   PH_LAUNCH(ph::launch_v210_yadif_pair(stream_of(ctx, queue), a, tff ? 1 : 0, (uint32_t)ctx->props.multiProcessorCount));

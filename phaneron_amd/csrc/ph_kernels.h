@@ -126,6 +126,10 @@ struct DeintArgs {  // ph_kernels_deint.hip
   uint32_t rgb12;  // 1: the outputs are packed f32 RGB (12 bytes per pixel, the reader's alpha == 1 left out)
   const float *cm, *gm;
   LutView lut;
+  // windows of planar 4:2:2 frames (pack 1: yuv422p10le, 2: yuv422p8; 0: v210): prev / cur / next are the Y planes, these the
+  // chroma planes; read by the planar instantiations only
+  uint32_t pack;
+  const void *prev_u[kMaxLayers], *prev_v[kMaxLayers], *cur_u[kMaxLayers], *cur_v[kMaxLayers], *next_u[kMaxLayers], *next_v[kMaxLayers];
 };
 
 struct FieldArgs {  // ph_kernels_field.hip

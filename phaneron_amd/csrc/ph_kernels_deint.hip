@@ -49,6 +49,18 @@ __device__ __forceinline__ LanePick lane_pick(uint32_t x) {
   p.scr = pr == 0 ? 20u : pr == 1 ? 0u : 10u;
   return p;
 }
+// a planar 4:2:2 frame (yuv422p10.ts:60-72, yuv422p8.ts): Y at [line][x], Cb / Cr at [line][x / 2] of their planes, samples of
+// BPS bytes taken whole; the three "words" of a pixel are its three samples
+template <int BPS>
+__device__ __forceinline__ LanePick lane_pick_planar(uint32_t x) {
+  LanePick p;
+  p.off_y = x * BPS, p.off_cb = p.off_cr = (x >> 1) * BPS;
+  p.sy = p.scb = p.scr = 0;
+  return p;
+}
+struct FramePlanes {  // a frame of the window as buffer resources: v210 uses y only
+  __amdgpu_buffer_rsrc_t y, u, v;
+};
 // the three words of the lane's pixel, as loaded; unpacking them is a separate step so that the loads of the next
 // row can be issued BEFORE the filter of the current one and consumed after it (a frame's rows come from HBM)
 struct RawPx {
@@ -61,11 +73,23 @@ __device__ __forceinline__ RawPx load_row_px(__amdgpu_buffer_rsrc_t frame, uint3
                (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(frame, (int)p.off_cb, row, 0),
                (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(frame, (int)p.off_cr, row, 0)};
 }
-template <bool STD>
+template <int PACK>
+__device__ __forceinline__ RawPx load_row_planar(const FramePlanes &f, uint32_t pitch_y, int line, const LanePick &p) {
+  const int row_y = (int)((uint32_t)line * pitch_y), row_c = (int)((uint32_t)line * (pitch_y >> 1));  // uniform
+  if (PACK == 1)
+    return RawPx{(uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(f.y, (int)p.off_y, row_y, 0),
+                 (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(f.u, (int)p.off_cb, row_c, 0),
+                 (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(f.v, (int)p.off_cr, row_c, 0)};
+  return RawPx{(uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(f.y, (int)p.off_y, row_y, 0),
+               (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(f.u, (int)p.off_cb, row_c, 0),
+               (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(f.v, (int)p.off_cr, row_c, 0)};
+}
+template <bool STD, int PACK = 0>
 __device__ __forceinline__ Rgb unpack_px(const RawPx &r, const LanePick &p, const ReadK &k, const LutK &lk) {
-  const float yf = (float)((r.wy >> p.sy) & 0x3ff);
-  const float cbf = (float)((r.wcb >> p.scb) & 0x3ff);
-  const float crf = (float)((r.wcr >> p.scr) & 0x3ff);
+  // (a planar sample is converted whole, as the reference does: yuv422p10.ts:66-68)
+  const float yf = PACK ? (float)r.wy : (float)((r.wy >> p.sy) & 0x3ff);
+  const float cbf = PACK ? (float)r.wcb : (float)((r.wcb >> p.scb) & 0x3ff);
+  const float crf = PACK ? (float)r.wcr : (float)((r.wcr >> p.scr) & 0x3ff);
   const float4 v = read_px_lds<STD>(yf, cbf, crf, k, lk);
   return Rgb{v.x, v.y, v.z};
 }
@@ -76,24 +100,39 @@ __device__ __forceinline__ float lane_tap(float v, uint32_t lane, int d) {
 
 #define PH_RGB(v, c) ((c) == 0 ? (v).r : (c) == 1 ? (v).g : (v).b)
 
-template <int TFF, bool STD>
+template <int TFF, bool STD, int PACK = 0>
 __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const ReadK &k, const LutK &lk) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = (int)a.width, h = (int)a.height;
   const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;
   for (uint32_t t = blockIdx.x * (kLdsBlock / 64) + wave; t < tasks; t += gridDim.x * (kLdsBlock / 64)) {
     const uint32_t cb = t % a.col_blocks, rest = t / a.col_blocks, strip = rest % a.strips, l = rest / a.strips;
-    const int frame_bytes = (int)(a.quads_pitch * 16u * a.height);
-    const __amdgpu_buffer_rsrc_t prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.prev[l]), 0, frame_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.cur[l]), 0, frame_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t next = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.next[l]), 0, frame_bytes, 0x00020000);
+    // bytes per line: a v210 line of quads_pitch quads, or (planar) quads_pitch luma samples of 1 or 2 bytes
+    const uint32_t line_bytes = PACK == 0 ? a.quads_pitch * 16u : a.quads_pitch * (PACK == 1 ? 2u : 1u);
+    const int frame_bytes = (int)(line_bytes * a.height);
+    auto planes = [&](const uint4 *y, const void *u, const void *v) __attribute__((always_inline)) {
+      FramePlanes f;
+      f.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(y), 0, frame_bytes, 0x00020000);
+      if (PACK) {
+        f.u = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(u), 0, frame_bytes / 2, 0x00020000);
+        f.v = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(v), 0, frame_bytes / 2, 0x00020000);
+      } else {
+        f.u = f.v = f.y;
+      }
+      return f;
+    };
+    const FramePlanes prev = planes(a.prev[l], PACK ? a.prev_u[l] : nullptr, PACK ? a.prev_v[l] : nullptr);
+    const FramePlanes cur = planes(a.cur[l], PACK ? a.cur_u[l] : nullptr, PACK ? a.cur_v[l] : nullptr);
+    const FramePlanes next = planes(a.next[l], PACK ? a.next_u[l] : nullptr, PACK ? a.next_v[l] : nullptr);
     float4 *__restrict__ out0 = a.out0[l], *__restrict__ out1 = a.out1[l];
     const int xr = (int)(cb * kDeintCols) - 3 + (int)lane, x = clampi(xr, 0, w - 1);  // CLAMP_TO_EDGE
     const bool emit = lane >= 3 && lane < 64 - 3 && xr < w;
-    const LanePick pick = lane_pick((uint32_t)x);
+    const LanePick pick = PACK == 0 ? lane_pick((uint32_t)x) : PACK == 1 ? lane_pick_planar<2>((uint32_t)x) : lane_pick_planar<1>((uint32_t)x);
     const int y0 = (int)(strip * a.rows_per_strip), y_end = (y0 + (int)a.rows_per_strip < h) ? y0 + (int)a.rows_per_strip : h;
-    auto raw = [&](__amdgpu_buffer_rsrc_t frame, int y) { return load_row_px(frame, a.quads_pitch * 16u, clampi(y, 0, h - 1), pick); };
-    auto row = [&](__amdgpu_buffer_rsrc_t frame, int y) { return unpack_px<STD>(raw(frame, y), pick, k, lk); };
+    auto raw = [&](const FramePlanes &frame, int y) {
+      return PACK == 0 ? load_row_px(frame.y, line_bytes, clampi(y, 0, h - 1), pick) : load_row_planar<PACK>(frame, line_bytes, clampi(y, 0, h - 1), pick);
+    };
+    auto row = [&](const FramePlanes &frame, int y) { return unpack_px<STD, PACK>(raw(frame, y), pick, k, lk); };
     // rows y - 2 .. y + 2 of each frame live in a RING of five registers: the step with rotation R finds row y - 2 + i
     // in slot (R + i) % 5 and refills slot R % 5 (row y - 2, no longer needed) with row y + 3 - no window shifts
     // (36 v_mov per row otherwise).  Ten steps (lcm of the ring and of the even / odd row roles) make one loop body.
@@ -138,7 +177,7 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
           store_image(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], 1.0f), a.nt);                  // :164 alpha from cur
         }
       }
-      PH_W(C, 0) = unpack_px<STD>(rc, pick, k, lk), PH_W(P, 0) = unpack_px<STD>(rp, pick, k, lk), PH_W(N, 0) = unpack_px<STD>(rn, pick, k, lk);
+      PH_W(C, 0) = unpack_px<STD, PACK>(rc, pick, k, lk), PH_W(P, 0) = unpack_px<STD, PACK>(rp, pick, k, lk), PH_W(N, 0) = unpack_px<STD, PACK>(rn, pick, k, lk);
 #undef PH_W
     };
     for (int y = y0; y < y_end; y += 10) {  // y0 is even
@@ -156,16 +195,16 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
   }
 }
 
-template <int TFF>
+template <int TFF, int PACK = 0>
 __global__ __launch_bounds__(kLdsBlock) void v210_yadif_pair_kernel(DeintArgs a) {
   const ReadK k = load_read_k(a.cm, a.gm);
   const LutK lk = make_lut_k(a.lut);
   lds_lut_load(a.lut);
   __syncthreads();
   if (ycbcr_matrix_is_standard(k))  // every matrix colourMaths produces (ph_ldslut.h): 8 operations per pixel instead of 12
-    v210_yadif_pair_body<TFF, true>(a, k, lk);
+    v210_yadif_pair_body<TFF, true, PACK>(a, k, lk);
   else
-    v210_yadif_pair_body<TFF, false>(a, k, lk);
+    v210_yadif_pair_body<TFF, false, PACK>(a, k, lk);
 }
 
 hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t num_cus) {
@@ -186,14 +225,18 @@ hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t 
   const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;
   const uint32_t want = (tasks + kLdsBlock / 64 - 1) / (kLdsBlock / 64);
   const uint32_t grid = want < num_cus ? want : num_cus;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tff ? v210_yadif_pair_kernel<1> : v210_yadif_pair_kernel<0>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lut.bytes);
-  if (e != hipSuccess) return e;
-  if (tff)
-    v210_yadif_pair_kernel<1><<<grid, kLdsBlock, a.lut.bytes, s>>>(a);
-  else
-    v210_yadif_pair_kernel<0><<<grid, kLdsBlock, a.lut.bytes, s>>>(a);
-  return hipGetLastError();
+  auto go = [&](auto kernel) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lut.bytes);
+    if (e != hipSuccess) return e;
+    kernel<<<grid, kLdsBlock, a.lut.bytes, s>>>(a);
+    return hipGetLastError();
+  };
+  switch (a.pack) {
+    case 0: return tff ? go(v210_yadif_pair_kernel<1, 0>) : go(v210_yadif_pair_kernel<0, 0>);
+    case 1: return tff ? go(v210_yadif_pair_kernel<1, 1>) : go(v210_yadif_pair_kernel<0, 1>);
+    case 2: return tff ? go(v210_yadif_pair_kernel<1, 2>) : go(v210_yadif_pair_kernel<0, 2>);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace ph

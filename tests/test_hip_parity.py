@@ -212,6 +212,39 @@ def test_v210_yadif_pair_vs_oracle(w, h, n, lut_path):
         hh.ctx().v210_yadif_pair([(hh.dev(wins[0][0]), hh.dev(wins[0][1]), hh.dev(wins[0][2]), outs[0][0], outs[0][0])], w, h, 1, False, rcm, rlut, rgm)
 
 
+@pytest.mark.parametrize("fmt", ["yuv422p10", "yuv422p8"])
+@pytest.mark.parametrize("w,h,n", [(1920, 64, 2), (100, 33, 3), (346, 17, 1), (2, 2, 1)])
+def test_planar_yadif_pair_vs_oracle(fmt, w, h, n, lut_path):
+    """windows of interlaced FILE frames (planar 4:2:2, what decoders of XDCAM / ProRes material hand over): the fused de-interlacing
+    reader == that format's ToRGBA on the three window frames (the 8-bit format with its own Loader matrix), then Yadif per parity"""
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    if lut_path == "global_lut":  # the fused de-interlacing reader exists in the LDS-table form only (its refusal is checked with v210 above)
+        return
+    _, rlut, rgm = hh.ColourParams.reader("709", "2020")
+    rng = orc.FORMAT_RANGE[fmt]
+    rcm = hh.dev(capi.ycbcr2rgb_matrix("709", *rng))
+    o_args = (orc.ycbcr2rgb_matrix("709", *rng), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
+    for tff, skip, rgb in ((1, False, False), (0, False, False), (1, True, True)):
+        wins = [[frames.pack_random(fmt, w, h, 9100 + 31 * l + 7 * i + w + tff) for i in range(3)] for l in range(n)]
+        px = 3 if rgb else 4
+        outs = [[torch.full((w * h * px,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(2)] for _ in range(n)]
+        dev = lambda frame: tuple(hh.dev(np.ascontiguousarray(p)) for p in frame)
+        hh.ctx().v210_yadif_pair([(dev(wins[l][0]), dev(wins[l][1]), dev(wins[l][2]), outs[l][0], outs[l][1]) for l in range(n)],
+                                 w, h, tff, skip, rcm, rlut, rgm, rgb=rgb, packing=fmt)
+        for l in range(n):
+            p, c, nx = (orc.pack_read(fmt, f, w, h, *o_args) for f in wins[l])
+            for parity in (0, 1):
+                want = orc.yadif(p, c, nx, parity, tff, skip)
+                got = hh.host(outs[l][parity])
+                if rgb:
+                    want = np.ascontiguousarray(want[..., :3])
+                assert_bits(got, want, "%s yadif pair %dx%d layer %d p%d t%d s%d" % (fmt, w, h, l, parity, tff, skip))
+    with pytest.raises(Exception, match="multiple of 2"):
+        hh.ctx().v210_yadif_pair([(dev(wins[0][0]), dev(wins[0][1]), dev(wins[0][2]), outs[0][0], outs[0][1])], 101, 4, 1, False, rcm, rlut, rgm, packing=fmt)
+
+
 @pytest.mark.parametrize("iw,ih,ow,oh,kw", [
     (1920, 1080, 3840, 2160, {}),
     (960, 540, 960, 540, dict(scale_x=0.5, scale_y=0.5, offset_x=0.25, offset_y=-0.25)),
