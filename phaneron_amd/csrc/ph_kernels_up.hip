@@ -20,6 +20,8 @@
 #include "ph_kernels.h"
 #include "ph_ldslut.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 #ifndef PH_UP_GROUP_ROWS
@@ -89,20 +91,35 @@ __device__ __forceinline__ UpWeights up_weights(float wa, float wb) {
   const float oma = 1.0f - wa, omb = 1.0f - wb;
   return UpWeights{oma * omb, wa * omb, oma * wb, wa * wb};
 }
-template <bool RGB12>
-__device__ __forceinline__ void up_blend(const UpTexel &t00, const UpTexel &t10, const UpTexel &t01, const UpTexel &t11, const UpWeights &w,
-                                         bool first, bool all_inside, UpAcc &acc) {
-  const float r = ((w.w00 * t00.r + w.w10 * t10.r) + w.w01 * t01.r) + w.w11 * t11.r;
-  const float g = ((w.w00 * t00.g + w.w10 * t10.g) + w.w01 * t01.g) + w.w11 * t11.g;
-  const float b = ((w.w00 * t00.b + w.w10 * t10.b) + w.w01 * t01.b) + w.w11 * t11.b;
-  if (first) {
-    acc.r = r, acc.g = g, acc.b = b;
-  } else {  // the result's alpha is never used by the writer
-    float al;
-    if (RGB12 && all_inside) al = ((w.w00 + w.w10) + w.w01) + w.w11;  // every texel's alpha is exactly 1: w * 1 == w
-    else al = ((w.w00 * t00.a + w.w10 * t10.a) + w.w01 * t01.a) + w.w11 * t11.a;
-    const float kk = 1.0f - al;
-    acc.r = fma_rn(acc.r, kk, r), acc.g = fma_rn(acc.g, kk, g), acc.b = fma_rn(acc.b, kk, b);
+// `INSIDE` (packed RGB, every texel of every lane's patch inside the image): each texel's alpha is exactly 1, so the filtered alpha
+// is the sum of the four weights and 1 - alpha depends on the block's geometry only (UpGeo::kk, computed with it).
+// A pixel of a layer in two steps: its filtered colour with what it leaves of the layers below (kk = 1 - alpha) ...
+struct UpColour {
+  float r, g, b, kk;
+};
+template <bool RGB12, bool INSIDE, bool FIRST>
+__device__ __forceinline__ UpColour up_blend(const UpTexel &t00, const UpTexel &t10, const UpTexel &t01, const UpTexel &t11, const UpWeights &w,
+                                             float kk_inside) {
+  UpColour c;
+  c.r = ((w.w00 * t00.r + w.w10 * t10.r) + w.w01 * t01.r) + w.w11 * t11.r;
+  c.g = ((w.w00 * t00.g + w.w10 * t10.g) + w.w01 * t01.g) + w.w11 * t11.g;
+  c.b = ((w.w00 * t00.b + w.w10 * t10.b) + w.w01 * t01.b) + w.w11 * t11.b;
+  c.kk = kk_inside;  // (the result's alpha is never used by the writer)
+  if (!FIRST && !INSIDE) c.kk = 1.0f - (((w.w00 * t00.a + w.w10 * t10.a) + w.w01 * t01.a) + w.w11 * t11.a);
+  return c;
+}
+// ... then combine.ts:45-65 into the pixel's accumulator.  The bottom layer is taken as it is (the kernel peels it off the layer loop);
+// above it acc = fma(acc, kk, colour) is the three-operand v_fma_f32 with the accumulator as destination, issued once per pixel
+// outside any branch: the accumulators stay in their registers over the layer loop (LLVM's v_fmac into the fresh colour costs a
+// v_mov per accumulator and layer, an accumulator merged from two paths another one)
+template <bool FIRST>
+__device__ __forceinline__ void up_over(const UpColour &c, UpAcc &acc) {
+  if (FIRST) {
+    acc.r = c.r, acc.g = c.g, acc.b = c.b;
+  } else {
+    asm volatile("v_fma_f32 %0, %0, %3, %4\n\tv_fma_f32 %1, %1, %3, %5\n\tv_fma_f32 %2, %2, %3, %6"
+                 : "+v"(acc.r), "+v"(acc.g), "+v"(acc.b)
+                 : "v"(c.kk), "v"(c.r), "v"(c.g), "v"(c.b));
   }
 }
 
@@ -139,6 +156,7 @@ struct UpGeo {
   uint32_t coff[3];  // per lane: byte offsets of the patch's columns inside a row, or kUpOutside
   uint32_t roff[3];  // uniform: byte offsets of its rows, or kUpOutside
   UpWeights w[2][2];  // [output row][output column]
+  float kk[2][2];    // packed RGB with every texel inside: 1 - (the filtered alpha = the sum of the weights, each times exactly 1)
   bool d1;           // per lane: the right pixel's first tap is one texel further than the left pixel's
   bool dj;           // uniform: likewise the lower row's
   bool all_inside;   // uniform (packed RGB): every texel of every lane's patch is inside the image
@@ -170,7 +188,11 @@ __device__ __forceinline__ UpGeo up_geo(const UpLayer &L, const UpStep &st) {
 #pragma unroll
   for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-    for (int dx = 0; dx < 2; ++dx) g.w[dy][dx] = up_weights(wa[dx], wb[dy]);
+    for (int dx = 0; dx < 2; ++dx) {
+      g.w[dy][dx] = up_weights(wa[dx], wb[dy]);
+      const UpWeights &q = g.w[dy][dx];
+      g.kk[dy][dx] = RGB12 ? 1.0f - (((q.w00 + q.w10) + q.w01) + q.w11) : 0.0f;
+    }
   // the 3 x 3 patch: columns i0[0] .. + 2 (i0[1] - i0[0] is 0 or 1 for a magnification of 2 or more), rows j0[0] .. + 2
   g.d1 = i0[1] != i0[0];
   g.dj = j0[1] != j0[0];
@@ -208,31 +230,34 @@ __device__ __forceinline__ void up_fetch(const UpLayer &L, const UpGeo &g, UpPat
 #pragma unroll
     for (int c = 0; c < 3; ++c) p.P[r][c] = up_load<RGB12>(img, g.roff[r] + g.coff[c]);
 }
-template <bool RGB12>
-__device__ __forceinline__ void up_filter(const UpPatch &p, const UpGeo &g, bool first, UpAcc (&acc)[2][2]) {
+template <bool RGB12, bool INSIDE, bool FIRST>
+__device__ __forceinline__ void up_filter(const UpPatch &p, const UpGeo &g, UpAcc (&acc)[2][2]) {
   UpTexel P[3][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       P[r][c] = p.P[r][c];
-      if (RGB12) P[r][c].a = (!g.all_inside && ((g.rin >> r) & 1u) && ((g.cin >> c) & 1u)) ? 1.0f : 0.0f;  // unused when all are inside
+      if (RGB12) P[r][c].a = (!INSIDE && ((g.rin >> r) & 1u) && ((g.cin >> c) & 1u)) ? 1.0f : 0.0f;  // unused when all are inside
     }
-  const bool d1 = g.d1, ai = g.all_inside;
+  const bool d1 = g.d1;
   // upper output row: patch rows 0, 1; left pixel: columns 0, 1; right pixel: columns d1, d1 + 1
-  up_blend<RGB12>(P[0][0], P[0][1], P[1][0], P[1][1], g.w[0][0], first, ai, acc[0][0]);
-  up_blend<RGB12>(up_pick(d1, P[0][0], P[0][1]), up_pick(d1, P[0][1], P[0][2]), up_pick(d1, P[1][0], P[1][1]), up_pick(d1, P[1][1], P[1][2]),
-                  g.w[0][1], first, ai, acc[0][1]);
+  up_over<FIRST>(up_blend<RGB12, INSIDE, FIRST>(P[0][0], P[0][1], P[1][0], P[1][1], g.w[0][0], g.kk[0][0]), acc[0][0]);
+  up_over<FIRST>(up_blend<RGB12, INSIDE, FIRST>(up_pick(d1, P[0][0], P[0][1]), up_pick(d1, P[0][1], P[0][2]), up_pick(d1, P[1][0], P[1][1]),
+                                                up_pick(d1, P[1][1], P[1][2]), g.w[0][1], g.kk[0][1]), acc[0][1]);
   // lower output row: patch rows dj, dj + 1 (a uniform branch: no selects)
+  UpColour lo0, lo1;
   if (g.dj) {
-    up_blend<RGB12>(P[1][0], P[1][1], P[2][0], P[2][1], g.w[1][0], first, ai, acc[1][0]);
-    up_blend<RGB12>(up_pick(d1, P[1][0], P[1][1]), up_pick(d1, P[1][1], P[1][2]), up_pick(d1, P[2][0], P[2][1]), up_pick(d1, P[2][1], P[2][2]),
-                    g.w[1][1], first, ai, acc[1][1]);
+    lo0 = up_blend<RGB12, INSIDE, FIRST>(P[1][0], P[1][1], P[2][0], P[2][1], g.w[1][0], g.kk[1][0]);
+    lo1 = up_blend<RGB12, INSIDE, FIRST>(up_pick(d1, P[1][0], P[1][1]), up_pick(d1, P[1][1], P[1][2]), up_pick(d1, P[2][0], P[2][1]),
+                                         up_pick(d1, P[2][1], P[2][2]), g.w[1][1], g.kk[1][1]);
   } else {
-    up_blend<RGB12>(P[0][0], P[0][1], P[1][0], P[1][1], g.w[1][0], first, ai, acc[1][0]);
-    up_blend<RGB12>(up_pick(d1, P[0][0], P[0][1]), up_pick(d1, P[0][1], P[0][2]), up_pick(d1, P[1][0], P[1][1]), up_pick(d1, P[1][1], P[1][2]),
-                    g.w[1][1], first, ai, acc[1][1]);
+    lo0 = up_blend<RGB12, INSIDE, FIRST>(P[0][0], P[0][1], P[1][0], P[1][1], g.w[1][0], g.kk[1][0]);
+    lo1 = up_blend<RGB12, INSIDE, FIRST>(up_pick(d1, P[0][0], P[0][1]), up_pick(d1, P[0][1], P[0][2]), up_pick(d1, P[1][0], P[1][1]),
+                                         up_pick(d1, P[1][1], P[1][2]), g.w[1][1], g.kk[1][1]);
   }
+  up_over<FIRST>(lo0, acc[1][0]);
+  up_over<FIRST>(lo1, acc[1][1]);
 }
 
 // writer (v210.ts:145-162) of the lane's block: the even pixel gives Y, Cb, Cr, the odd one Y; then the quad's three lanes trade halves
@@ -288,15 +313,34 @@ __global__ __launch_bounds__(kLdsBlock) void compose_up_write_v210_kernel(UpArgs
     // one layer at a time.  Variants built and measured slower at 2160p x 4 layers: layers in pairs with both patches in
     // flight (76 against 70 us; again with the shared geometry: 84 against 68 us, 128 registers and spills) and a patch
     // carried in flight across loop turns (85 us) - two patches plus the writer's temporaries do not fit 128 registers
+    // The bottom layer is peeled off the loop (it is taken as it is; above it the accumulators are updated in place), and the loop
+    // exists three times - shared geometry with every texel inside (packed RGB: no alpha arithmetic at all), shared geometry, a
+    // geometry per layer - so that inside a loop nothing about an accumulator is decided by a branch
     UpGeo geo;
-    int l = 0;
+    auto layers = [&](auto inside_tag, auto shared_tag) __attribute__((always_inline)) {
+      constexpr bool INSIDE = decltype(inside_tag)::value, SHARED = decltype(shared_tag)::value;
+      {
+        const UpLayer L = a.layer[0];  // one 48-byte scalar load
+        if (!SHARED) geo = up_geo<RGB12>(L, st);
+        UpPatch p;
+        up_fetch<RGB12>(L, geo, p);
+        up_filter<RGB12, INSIDE, true>(p, geo, acc);
+      }
 #pragma unroll 1
-    for (; l < a.n; ++l) {
-      const UpLayer L = a.layer[l];  // one 48-byte scalar load
-      if (l == 0 || !a.shared) geo = up_geo<RGB12>(L, st);  // uniform
-      UpPatch p;
-      up_fetch<RGB12>(L, geo, p);
-      up_filter<RGB12>(p, geo, l == 0, acc);
+      for (int l = 1; l < a.n; ++l) {
+        const UpLayer L = a.layer[l];
+        if (!SHARED) geo = up_geo<RGB12>(L, st);
+        UpPatch p;
+        up_fetch<RGB12>(L, geo, p);
+        up_filter<RGB12, INSIDE, false>(p, geo, acc);
+      }
+    };
+    if (a.shared) {  // uniform
+      geo = up_geo<RGB12>(a.layer[0], st);
+      if (RGB12 && geo.all_inside) layers(std::true_type{}, std::true_type{});  // uniform
+      else layers(std::false_type{}, std::true_type{});
+    } else {
+      layers(std::false_type{}, std::false_type{});
     }
     up_write(a, st, acc, role, wk, lk);
   }
