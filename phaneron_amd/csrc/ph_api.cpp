@@ -45,7 +45,7 @@ int fail(int code, const char *fmt, ...) {
 }  // namespace
 
 struct LutEntry {
-  ph::LutView view{nullptr, 0, 0.f, 0, 0, 0.f, 0.f};
+  ph::LutView view{};  // bytes == 0: a plain table
   void *blob_dev = nullptr;
 };
 
@@ -79,6 +79,7 @@ struct ph_ctx {
   std::mutex mu;
   std::atomic<int> refs{1};
   std::atomic<bool> closed{false};
+  std::atomic<bool> lds_base_checked{false};  // ph_lut_register: the kernels' dynamic shared array starts at LDS address 0
 };
 
 struct ph_buf {
@@ -821,8 +822,20 @@ int ph_lut_register(ph_ctx *ctx, const void *dev, const float *host) {
   ph::LutHostInfo info;
   LutEntry e;
   if (ph::lut_compress(host, ph::kLutMaxLdsBytes, blob, info)) {
-    PH_HIP(hipMalloc(&e.blob_dev, info.bytes));
-    PH_HIP(hipMemcpy(e.blob_dev, blob.data(), info.bytes, hipMemcpyHostToDevice));
+    if (!ctx->lds_base_checked.load()) {  // the lookups address the table absolutely: the kernels' dynamic shared array must start at LDS 0
+      uint32_t *probe = nullptr, base = ~0u;
+      PH_HIP(hipMalloc(&probe, 4));
+      hipError_t pe = ph::launch_lds_base_probe(ctx->streams[0], probe);
+      if (pe == hipSuccess) pe = hipStreamSynchronize(ctx->streams[0]);
+      if (pe == hipSuccess) pe = hipMemcpy(&base, probe, 4, hipMemcpyDeviceToHost);
+      hipFree(probe);
+      if (pe != hipSuccess) return fail(PH_E_HIP, "ph_lut_register: LDS base probe: %s", hipGetErrorString(pe));
+      if (base != 0) return fail(PH_E_HIP, "ph_lut_register: dynamic shared memory starts at LDS address %u, not 0: the table kernels cannot run", base);
+      ctx->lds_base_checked.store(true);
+    }
+    const size_t blob_bytes = blob.size() * sizeof(uint32_t);  // info.bytes is the LDS footprint: the hole in front of the blob included
+    PH_HIP(hipMalloc(&e.blob_dev, blob_bytes));
+    PH_HIP(hipMemcpy(e.blob_dev, blob.data(), blob_bytes, hipMemcpyHostToDevice));
     e.view = ph::lut_view(info, e.blob_dev);
   }
   {

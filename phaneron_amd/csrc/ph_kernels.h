@@ -163,6 +163,7 @@ hipError_t launch_v210_write(hipStream_t s, const void *in, void *out, uint32_t 
 hipError_t launch_fused_v210_combine(hipStream_t s, int n, const FusedArgs &a);
 // LDS-LUT variants (ph_kernels_lds.hip): one 1024-lane workgroup per CU
 hipError_t launch_fused_v210_combine_lds(hipStream_t s, int n, const FusedLdsArgs &a, uint32_t num_cus);
+hipError_t launch_lds_base_probe(hipStream_t s, uint32_t *out_dev);  // writes the LDS address of g_lds (expected: 0)
 hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
                                 const void *cm, const void *gm, const LutView &lut, uint32_t num_cus);
 hipError_t launch_v210_read_lds_batch(hipStream_t s, int n, const void *const *ins, void *const *outs, uint32_t width,

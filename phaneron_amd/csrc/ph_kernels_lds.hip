@@ -1016,6 +1016,16 @@ hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32
   return hipGetLastError();
 }
 
+// The LDS address of the dynamic shared array of a kernel that declares no other shared memory: the table lookups
+// (ph_ldslut.h) take it to be 0.  ph_lut_register checks it once per context.
+__global__ void lds_base_probe_kernel(uint32_t *out) {
+  *out = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)g_lds;
+}
+hipError_t launch_lds_base_probe(hipStream_t s, uint32_t *out_dev) {
+  lds_base_probe_kernel<<<1, 64, 16, s>>>(out_dev);
+  return hipGetLastError();
+}
+
 hipError_t launch_v210_read_lds(hipStream_t s, const void *in, void *out, uint32_t width, uint32_t height,
                                 const void *cm, const void *gm, const LutView &lut, uint32_t num_cus) {
   hipError_t e = allow_lds(v210_read_lds_kernel, lut.bytes);

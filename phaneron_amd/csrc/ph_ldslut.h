@@ -26,7 +26,8 @@ __device__ __forceinline__ void lds_lut_load(const LutView &v) {
 #if PH_ABLATE & 2  // timing experiment only: no table loads
   return;
 #endif
-  const uint32_t n = v.bytes / 16;
+  const uint32_t n = (v.bytes - v.hole) / 16;
+  unsigned char *const dst = g_lds + v.hole;
   // LDS-DMA: each wave instruction moves 1 KiB global -> LDS (wave-uniform LDS base + lane*16)
   // without touching VGPRs; all of a wave's pieces are in flight before the single wait.
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -35,45 +36,51 @@ __device__ __forceinline__ void lds_lut_load(const LutView &v) {
     const uint32_t i = base + lane;
     if (i < n)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i),
-                                       (__attribute__((address_space(3))) void *)(g_lds + 16 * base), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void *)(dst + 16 * base), 16, 0, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // table[clamp(rint(x), 0, 65535)] for x = (gamma- or linear-domain value) * 65535, see ph_lut.h:
-// 4 float ops, 3 integer ops, 2 LDS reads.
+// 4 float ops, 3 integer ops - every one of them of the 2-cycle class - and 2 LDS reads.
 //   * round FIRST, then + bias (exact on integers).  Adding the bias before rounding would round
 //     twice: x + bias has a coarser ulp than x just above a power of two and can manufacture a tie;
-//   * the float's own exponent/mantissa bits are the logarithmic block number: one shift;
+//   * rounding is the magic-number add of ph_device.h: y = x + 1.5*2^23 is M + idx exactly;
+//   * the float (idx + bias) * a_scale = fma(y, a_scale, -(M - bias) * a_scale) (exact: a power-of-two multiple of a
+//     24-bit integer) carries the logarithmic block number in its exponent / top mantissa bits, and a_scale is chosen so
+//     that (bits >> (shift - 2)) & ~3 IS the anchor's byte address in the LDS: no base to add, no left shift
+//     (v_lshl_add_u32 issues at half the rate of v_lshrrev / v_and on gfx950).
+//     This needs the table at a fixed place - the blob is loaded at LutView::hole = 4 * 2^m, g_lds at LDS address 0
+//     (checked once per kernel; these kernels declare no other shared memory);
 //   * the delta address is produced by an fma whose result is a DENORMAL: (2*(i+bias) + base)
 //     * 2^-149 has exactly that integer as its bit pattern, so no int multiply/add is needed
-//     (f32 denormals are enabled in HIP kernels and cost nothing extra on gfx950);
-//   * both addresses are ABSOLUTE LDS addresses (the position of g_lds inside the workgroup's LDS is
-//     folded into anchor_off / delta_base once per kernel) and are dereferenced as address-space-3
-//     pointers made from integers: going through `g_lds + offset` costs one v_add_u32 per read,
-//     because the symbol's address is only known at link time.
-//   * rounding is the magic-number add of ph_device.h (y = x + 1.5*2^23 is M + idx exactly), the
-//     delta address comes straight from y (the -M is folded into the fma's addend) and only the
-//     anchor's logarithmic block needs (float)(idx + bias) = y - (M - bias).
+//     (f32 denormals are enabled in HIP kernels and cost nothing extra on gfx950); it comes straight from y
+//     (the -M is folded into the fma's addend);
+//   * both addresses are ABSOLUTE LDS addresses dereferenced as address-space-3 pointers made from integers: going
+//     through `g_lds + offset` costs one v_add_u32 per read, because the symbol's address is only known at link time.
 struct LutK {
-  float magic_minus_bias, delta_scale, delta_base;  // delta_base already holds -M*scale, +2*bias and the LDS base
-  uint32_t shift, anchor_off;
+  float a_scale, a_base;            // (idx + bias) * a_scale = fma(y, a_scale, a_base)
+  float delta_scale, delta_base;    // delta_base already holds -M*scale, +2*bias and the LDS base
+  uint32_t a_shift;                 // shift - 2
 };
 typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
 typedef const __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
 __device__ __forceinline__ LutK make_lut_k(const LutView &v) {
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)g_lds;
+  // (lds0 is 0: these kernels declare no other shared memory, and the anchor address has no base to add - ph_api.cpp checks it once per context)
   // d_addr = 2*(idx + bias) + base + lds0 = bits(fma(M + idx, 2^-148, B)) with
   // B = (base + lds0 + 2*bias) * 2^-149 - M * 2^-148.  Every term is a multiple of 2^-148 below 2^24
   // of them (base, lds0 are even), so each float operation here is exact.
   const float small = (v.delta_base + __uint_as_float(lds0)) + v.bias * v.delta_scale;  // denormal sums
   const float b = small - kRoundMagic * v.delta_scale;
-  return LutK{kRoundMagic - v.bias, v.delta_scale, b, v.shift, v.anchor_off + lds0};
+  return LutK{v.a_scale, -((kRoundMagic - v.bias) * v.a_scale), v.delta_scale, b, v.shift - 2u};
+}
+__device__ __forceinline__ uint32_t lds_lut_anchor_addr(const LutK &k, float y) {
+  return (__float_as_uint(fma_rn(y, k.a_scale, k.a_base)) >> k.a_shift) & ~3u;
 }
 // y = M + idx (idx already clamped and rounded by the add that produced y)
 __device__ __forceinline__ float lds_lut_fetch(const LutK &k, float y) {
-  const float fb = y - k.magic_minus_bias;  // (float)(idx + bias), exact
-  const uint32_t a_addr = ((__float_as_uint(fb) >> k.shift) << 2) + k.anchor_off;
+  const uint32_t a_addr = lds_lut_anchor_addr(k, y);
   const uint32_t d_addr = __float_as_uint(fma_rn(y, k.delta_scale, k.delta_base));
 #if PH_ABLATE & 8  // timing experiment only (wrong results): both reads issued, but conflict-free
   const uint32_t a = *(lds_u32_ptr)(a_addr & 4u);
@@ -98,8 +105,7 @@ struct LutPending {
   uint32_t a, d;
 };
 __device__ __forceinline__ LutPending lds_lut_issue(const LutK &k, float y) {
-  const float fb = y - k.magic_minus_bias;  // (float)(idx + bias), exact
-  const uint32_t a_addr = ((__float_as_uint(fb) >> k.shift) << 2) + k.anchor_off;
+  const uint32_t a_addr = lds_lut_anchor_addr(k, y);
   const uint32_t d_addr = __float_as_uint(fma_rn(y, k.delta_scale, k.delta_base));
 #if PH_ABLATE & 8
   return LutPending{*(lds_u32_ptr)(a_addr & 4u), *(lds_u16_ptr)(d_addr & 2u)};

@@ -24,9 +24,10 @@ LutView lut_view(const LutHostInfo &info, const void *blob_dev) {
   LutView v;
   v.blob = static_cast<const uint32_t *>(blob_dev);
   v.bytes = info.bytes;
+  v.hole = info.hole;
   v.bias = info.bias;
   v.shift = info.shift;
-  v.anchor_off = 0u - 4u * info.first;
+  v.a_scale = std::ldexp(1.0f, 1 - (int)(f2u(info.bias) >> 23));  // 2^(1 - E): a denormal constant (2^-132 for a bias of 64)
   v.delta_scale = u2f(2u);  // 2 * 2^-149
   // (delta_off - 2*bias) * 2^-149: a denormal whose bit pattern is that integer
   v.delta_base = u2f(info.delta_off - 2u * (uint32_t)info.bias);
@@ -44,7 +45,8 @@ bool lut_compress(const float *lut, uint32_t max_bytes, std::vector<uint32_t> &b
       const uint32_t first = f2u(bias) >> shift;
       const uint32_t n_blocks = (f2u(65535.0f + bias) >> shift) - first + 1;
       const uint32_t n_anchors = (n_blocks + 3) & ~3u;  // keep delta[] 16-byte aligned
-      const uint32_t bytes = n_anchors * 4 + 65536 * 2;
+      const uint32_t hole = 4u << m;  // the anchors' LDS address is made without an add (ph_lut.h a_scale): they start at 4 * 2^m
+      const uint32_t bytes = hole + n_anchors * 4 + 65536 * 2;
       if (bytes > max_bytes || (found && bytes >= info.bytes)) continue;
       std::vector<uint32_t> lo(n_blocks, 0xffffffffu), hi(n_blocks, 0);
       for (uint32_t i = 0; i < 65536; ++i) {
@@ -58,8 +60,8 @@ bool lut_compress(const float *lut, uint32_t max_bytes, std::vector<uint32_t> &b
       if (!ok) continue;
       found = true;
       info.bytes = bytes, info.shift = shift, info.first = first, info.n_anchors = n_anchors;
-      info.delta_off = n_anchors * 4, info.bias = bias;
-      blob.assign(bytes / 4, 0);
+      info.hole = hole, info.delta_off = hole + n_anchors * 4, info.bias = bias;
+      blob.assign((bytes - hole) / 4, 0);
       for (uint32_t b = 0; b < n_blocks; ++b) blob[b] = lo[b] == 0xffffffffu ? 0 : lo[b];
       uint16_t *delta = reinterpret_cast<uint16_t *>(blob.data() + n_anchors);
       for (uint32_t i = 0; i < 65536; ++i) delta[i] = (uint16_t)(p[i] - lo[blk[i]]);
@@ -67,24 +69,27 @@ bool lut_compress(const float *lut, uint32_t max_bytes, std::vector<uint32_t> &b
   }
   if (!found) return false;
   // Exhaustive self-check with the very operations the kernels use (ph_ldslut.h make_lut_k /
-  // lds_lut_fetch): the magic-number add that rounds, the subtraction that gives (float)(i + bias),
-  // the shift, and the fma whose denormal result is the delta byte address.
+  // lds_lut_fetch): the magic-number add that rounds, the fma that gives (i + bias) * a_scale, the
+  // shift and the mask, and the fma whose denormal result is the delta byte address - on an image of
+  // the LDS as the kernels fill it (the blob at `hole`).
   const LutView v = lut_view(info, nullptr);
   const float magic = 12582912.0f;  // kRoundMagic
-  const float mmb = magic - v.bias;
+  const float abase = -((magic - v.bias) * v.a_scale);
   const float dbase = (v.delta_base + v.bias * v.delta_scale) - magic * v.delta_scale;
-  const uint8_t *bytes = reinterpret_cast<const uint8_t *>(blob.data());
+  std::vector<uint8_t> lds(info.bytes, 0);
+  std::memcpy(lds.data() + info.hole, blob.data(), info.bytes - info.hole);
   for (uint32_t i = 0; i < 65536; ++i) {
     const float y = (float)i + magic;
-    const float fb = y - mmb;
-    if (fb != (float)i + v.bias) return false;
-    const uint32_t a_addr = ((f2u(fb) >> v.shift) << 2) + v.anchor_off;
+    const float fs = std::fmaf(y, v.a_scale, abase);
+    if (fs != ((float)i + v.bias) * v.a_scale) return false;
+    const uint32_t a_addr = (f2u(fs) >> (v.shift - 2u)) & ~3u;
     const uint32_t d_addr = f2u(std::fmaf(y, v.delta_scale, dbase));
-    if (a_addr + 4 > info.delta_off || d_addr != info.delta_off + 2 * i) return false;
+    if (a_addr < info.hole || a_addr + 4 > info.delta_off || d_addr != info.delta_off + 2 * i) return false;
+    if (a_addr != info.hole + 4u * ((f2u((float)i + v.bias) >> v.shift) - info.first)) return false;
     uint32_t a;
     uint16_t d;
-    std::memcpy(&a, bytes + a_addr, 4);
-    std::memcpy(&d, bytes + d_addr, 2);
+    std::memcpy(&a, lds.data() + a_addr, 4);
+    std::memcpy(&d, lds.data() + d_addr, 2);
     if (a + d != p[i]) return false;
   }
   return true;

@@ -8,7 +8,7 @@
 //     anchor[b]  (u32)  minimum bit pattern of block b
 //     delta[i]   (u16)  p[i] - anchor[block(i)]
 // with p[i] = anchor[block(i)] + delta[i].  Blocks are LOGARITHMIC in the index:
-//     block(i) = (bits((float)(i + bias)) >> (23 - m)) - first
+//     block(i) = (bits((float)(i + bias)) >> (23 - m)) - first      (first = the block number of i = 0)
 // i.e. 2^m blocks per octave of (i + bias): single entries in the steep toe near 0, ~128
 // entries per block at the top.  One float add and one shift give the block, which is what
 // makes the lookup cheap (the LUT curves are power laws, so equal *relative* block widths
@@ -22,12 +22,16 @@ namespace ph {
 
 struct LutView {          // passed by value to kernels
   const uint32_t *blob;   // device: [anchors u32 x n_anchors][delta u16 x 65536], size % 16 == 0
-  uint32_t bytes;         // 0 = not compressible
+  uint32_t bytes;         // LDS footprint: `hole` + the blob; 0 = not compressible
+  uint32_t hole;          // the blob is loaded at this LDS byte address (4 * 2^m, see a_scale); [0, hole) stays unused
   float bias;             // even integer >= 2 (keeps round-to-nearest-even parity of the index)
   uint32_t shift;         // 23 - m
-  uint32_t anchor_off;    // 0 - 4 * first  (mod 2^32): byte address of anchor[b] = ((bits >> shift) << 2) + anchor_off
+  // The anchor's LDS byte address comes out of the float (i + bias) * a_scale with NO offset to add: a_scale = 2^(1 - E),
+  // E the exponent field of the bias, puts the smallest value at the exponent field 1, so (bits >> (shift - 2)) & ~3 runs
+  // from 4 * 2^m = `hole` upwards in steps of 4 per block - the absolute address when the table is loaded at `hole`.
+  float a_scale;
   float delta_scale;      // 2^-148 as a float (denormal): delta byte address = bits(fma(i + bias, delta_scale, delta_base))
-  float delta_base;       // (delta_off - 2 * bias) * 2^-149 (denormal)
+  float delta_base;       // (delta_off - 2 * bias) * 2^-149 (denormal), delta_off counted from LDS address 0
 };
 
 }  // namespace ph

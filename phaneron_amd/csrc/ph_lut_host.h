@@ -8,7 +8,7 @@
 namespace ph {
 
 struct LutHostInfo {
-  uint32_t bytes = 0, shift = 0, first = 0, n_anchors = 0, delta_off = 0;
+  uint32_t bytes = 0, shift = 0, first = 0, n_anchors = 0, delta_off = 0, hole = 0;  // bytes / delta_off: LDS footprint / address (hole included)
   float bias = 0;
 };
 
