@@ -30,7 +30,7 @@ extern "C" {
 /* 3: additive over 2 - ph_chan_compose_v210 (ph_chan_source / ph_chan_layer), ph_compose_up_write_v210, ph_v210_yadif_pair_fmt,
  *    ph_chan_compose, ph_yadif_pair_packed (ph_deint_source grew), ph_check_program, ph_route_comm_count, context option
  *    "host_pool_mb"; no signature of 2 changed */
-#define PH_ABI_VERSION 3
+#define PH_ABI_VERSION 4
 
 enum {
   PH_OK = 0,
@@ -459,6 +459,20 @@ int ph_lut_unregister(ph_ctx *ctx, const void *device_lut_f32);
  * describe the logarithmic block layout chosen for the table (ph_lut.h) */
 int ph_lut_query(ph_ctx *ctx, const void *device_lut_f32, uint32_t *lds_bytes, uint32_t *index_bias,
                  uint32_t *blocks_per_octave_log2);
+/* Device-free: compress a table exactly as ph_lut_register would and hand back the IMAGE of the LDS the table kernels
+ * see - [0, hole) unused, then the anchors (u32 per logarithmic block), then the deltas (u16 per entry) - with the constants
+ * of the lookup (phaneron_amd/csrc/ph_ldslut.h): for y = (float)idx + 1.5 * 2^23
+ *     anchor byte address = (bits(fma(y, a_scale, -(1.5 * 2^23 - index_bias) * a_scale)) >> (shift - 2)) & ~3
+ *     delta  byte address = delta_off + 2 * idx            (on the device: the bit pattern of a denormal fma)
+ *     table[idx]          = the float whose bits are  u32 at the anchor address + u16 at the delta address.
+ * `lds_image` may be NULL (layout only) or hold `capacity` >= lds_bytes bytes.  Returns the LDS footprint in bytes,
+ * 0 when the table is not exactly compressible into 160 KiB (it stays plain: global-gather kernels), negative on error.
+ * Replaces nothing in the reference: its kernels read the 256 KiB f32 table from global memory (v210.ts:68-70). */
+typedef struct ph_lut_layout {
+  uint32_t lds_bytes, hole, delta_off, shift, index_bias;
+  float a_scale;
+} ph_lut_layout;
+int ph_lut_layout_of(const float *host_lut65536, ph_lut_layout *layout, void *lds_image, size_t capacity);
 /* options: "lds_lut" (default 1): 0 forces the global-gather kernels (A/B tests, profiles);
  *          "stream_images" (default 0): 1 stores f32 image outputs (ToRGBA, Yadif, Transform, Combine ...) past the
  *          caches, for a caller that knows nothing on the device reads the image soon; 2 does so only for images

@@ -27,7 +27,7 @@ EXPORTS = [
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
-    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_ctx_set_option", "ph_compose_write_v210", "ph_compose_wipe_write_v210",
+    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_lut_layout_of", "ph_ctx_set_option", "ph_compose_write_v210", "ph_compose_wipe_write_v210",
     "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
     "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy", "ph_queue_query",
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
@@ -86,6 +86,11 @@ IMG_RGBA_F32, IMG_RGB_F32 = 0, 1
 SRC_V210, SRC_RGBA_F32, SRC_YUV422P10, SRC_YUV422P8, SRC_YUV420P, SRC_NV12, SRC_RGBA8, SRC_BGRA8 = 1, 2, 3, 4, 5, 6, 7, 8
 SRC_PLANAR = {"yuv422p10": SRC_YUV422P10, "yuv422p8": SRC_YUV422P8, "yuv420p": SRC_YUV420P, "nv12": SRC_NV12}
 TRANSITION_CUT, TRANSITION_DISSOLVE, TRANSITION_WIPE = 0, 1, 2
+
+
+class LutLayout(C.Structure):  # ph_lut_layout
+    _fields_ = [("lds_bytes", C.c_uint32), ("hole", C.c_uint32), ("delta_off", C.c_uint32), ("shift", C.c_uint32), ("index_bias", C.c_uint32),
+                ("a_scale", C.c_float)]
 
 
 class RunTimings(C.Structure):
@@ -178,6 +183,7 @@ def lib():
         "ph_lut_register": (ci, [vp, vp, f32p]),
         "ph_lut_unregister": (ci, [vp, vp]),
         "ph_lut_query": (ci, [vp, vp, C.POINTER(cu), C.POINTER(cu), C.POINTER(cu)]),
+        "ph_lut_layout_of": (ci, [f32p, C.POINTER(LutLayout), vp, C.c_size_t]),
         "ph_ctx_set_option": (ci, [vp, C.c_char_p, ci]),
         "ph_pack_plane_bytes": (ci, [ci, cu, cu, C.POINTER(cs)]),
         "ph_pack_read": (ci, [vp, ci, ci, C.POINTER(vp), vp, cu, cu, vp, vp, vp]),
@@ -215,6 +221,23 @@ def check(rc, ctx=None):
 
 
 # ---- host colour maths (pure host code in the library; no device needed) ---------------------
+def lut_layout(lut):
+    """(layout dict, LDS image as uint8 array) of a 65536-entry f32 table as the table kernels hold it; (None, None) when the
+    table does not compress exactly (ph_lut_layout_of; needs no device)."""
+    lut = np.ascontiguousarray(lut, np.float32)
+    assert lut.shape == (65536,)
+    lay = LutLayout()
+    n = lib().ph_lut_layout_of(lut, C.byref(lay), None, 0)
+    if n < 0:
+        check(n)
+    if n == 0:
+        return None, None
+    image = np.zeros(n, np.uint8)
+    if lib().ph_lut_layout_of(lut, C.byref(lay), image.ctypes.data_as(C.c_void_p), n) != n:
+        check(-1)
+    return {k: getattr(lay, k) for k, _ in LutLayout._fields_}, image
+
+
 def gamma2linear_lut(colspec):
     out = np.empty(65536, np.float32)
     check(lib().ph_colour_gamma2linear_lut(colspec.encode(), out))

@@ -845,6 +845,23 @@ int ph_lut_register(ph_ctx *ctx, const void *dev, const float *host) {
   return e.view.bytes ? 1 : 0;
 }
 
+int ph_lut_layout_of(const float *host, ph_lut_layout *layout, void *lds_image, size_t capacity) {
+  if (!host || !layout) return fail(PH_E_INVALID, "ph_lut_layout_of: NULL argument");
+  std::vector<uint32_t> blob;
+  ph::LutHostInfo info;
+  memset(layout, 0, sizeof(*layout));
+  if (!ph::lut_compress(host, ph::kLutMaxLdsBytes, blob, info)) return 0;
+  const ph::LutView v = ph::lut_view(info, nullptr);
+  layout->lds_bytes = info.bytes, layout->hole = info.hole, layout->delta_off = info.delta_off, layout->shift = info.shift;
+  layout->index_bias = (uint32_t)info.bias, layout->a_scale = v.a_scale;
+  if (lds_image) {
+    if (capacity < info.bytes) return fail(PH_E_INVALID, "ph_lut_layout_of: the image needs %u bytes, %zu given", info.bytes, capacity);
+    memset(lds_image, 0, info.hole);
+    memcpy(static_cast<char *>(lds_image) + info.hole, blob.data(), info.bytes - info.hole);
+  }
+  return (int)info.bytes;
+}
+
 int ph_lut_query(ph_ctx *ctx, const void *dev, uint32_t *lds_bytes, uint32_t *toe, uint32_t *shift) {
   if (!ctx) return fail(PH_E_INVALID, "ph_lut_query: ctx is NULL");
   std::lock_guard<std::mutex> lock(ctx->mu);

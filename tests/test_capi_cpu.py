@@ -38,7 +38,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 
 def test_abi_version():
-    assert capi.lib().ph_abi_version() == 3
+    assert capi.lib().ph_abi_version() == 4
 
 
 @pytest.mark.parametrize("spec", ["601-625", "601_525", "709", "2020", "sRGB", "bogus"])
@@ -183,3 +183,41 @@ def test_edited_kernel_text_is_still_told_apart_by_signature_and_body():
         src = decoys + open(os.path.join(REF_CL, fmt + ".cl")).read() + "\n// edited\n"
         for name in ("read", "write"):
             assert capi.resolve_program(src, name) == (_want_kernel(fmt, name), fmt, "signature"), (fmt, name)
+
+
+# ---- the LDS form of a gamma table (ph_lut_layout_of: host code of the product, no device) --------------------------------
+def _lds_lookup(layout, image, idx):
+    """The table kernels' lookup (phaneron_amd/csrc/ph_ldslut.h) restated with numpy on the LDS image: every float operation of it
+    is exact, so float64 arithmetic narrowed to float32 reproduces it."""
+    magic = np.float64(12582912.0)  # 1.5 * 2^23: y = idx + magic is what the rounding add leaves
+    y = idx.astype(np.float64) + magic
+    a_scale = np.float64(layout["a_scale"])
+    fs = (y * a_scale - (magic - layout["index_bias"]) * a_scale).astype(np.float32)
+    assert np.array_equal(fs.astype(np.float64), (idx.astype(np.float64) + layout["index_bias"]) * a_scale)  # exact
+    a_addr = (fs.view(np.uint32) >> np.uint32(layout["shift"] - 2)) & np.uint32(0xFFFFFFFC)
+    d_addr = np.uint32(layout["delta_off"]) + 2 * idx.astype(np.uint32)
+    assert a_addr.min() >= layout["hole"] and a_addr.max() + 4 <= layout["delta_off"] and d_addr.max() + 2 <= layout["lds_bytes"]
+    anchors = image[: layout["delta_off"]].view(np.uint32)
+    deltas = image[layout["delta_off"]:].view(np.uint16)
+    return anchors[a_addr >> 2] + deltas[idx].astype(np.uint32)
+
+
+@pytest.mark.parametrize("spec", ["709", "2020", "601-625", "601-525", "sRGB"])
+@pytest.mark.parametrize("direction", ["gamma2linear", "linear2gamma"])
+def test_lds_form_of_the_gamma_tables_is_exact(spec, direction):
+    lut = capi.gamma2linear_lut(spec) if direction == "gamma2linear" else capi.linear2gamma_lut(spec)
+    layout, image = capi.lut_layout(lut)
+    assert layout is not None, "the %s %s table must fit the LDS" % (spec, direction)
+    assert layout["lds_bytes"] == image.size <= 160 * 1024 and layout["hole"] == 4 << (23 - layout["shift"])
+    assert not image[: layout["hole"]].any()
+    idx = np.arange(65536, dtype=np.uint32)
+    assert np.array_equal(_lds_lookup(layout, image, idx), lut.view(np.uint32))
+
+
+def test_a_table_that_does_not_compress_stays_plain():
+    rng = np.random.default_rng(7)
+    layout, image = capi.lut_layout(rng.random(65536, dtype=np.float32))  # neighbouring entries orders of magnitude apart
+    assert layout is None and image is None
+    ramp = (np.arange(65536, dtype=np.float32) / np.float32(65535.0)).astype(np.float32)  # a linear ramp does compress
+    layout, image = capi.lut_layout(ramp)
+    assert layout is not None and np.array_equal(_lds_lookup(layout, image, np.arange(65536, dtype=np.uint32)), ramp.view(np.uint32))
