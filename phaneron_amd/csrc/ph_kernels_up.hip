@@ -129,8 +129,17 @@ struct UpStep {
   float px[2], py[2];
   bool live;
 };
-__device__ __forceinline__ bool up_step(const UpArgs &a, const UpShare &sh, uint32_t &v, uint32_t lane, UpStep &st) {
-  for (; v < sh.vend; v += sh.vstep) {
+// A wave's steps: round k of the share's units is [k * vstep, (k + 1) * vstep), the wave's place in a round v0 + wave.  The LAST round is
+// usually partial (2160p: 8.2 rounds) and its units are dealt one per SIMD instead - workgroup first, wave second (the waves of a
+// workgroup go round its four SIMDs) - so that the tail runs as single waves on otherwise idle SIMDs all over the chip, not as a few
+// CUs with sixteen waves each doing a ninth step.
+__device__ __forceinline__ bool up_step(const UpArgs &a, const UpShare &sh, uint32_t &base, uint32_t wave, uint32_t lane, UpStep &st) {
+  while (base < sh.vend) {
+    const uint32_t left = sh.vend - base, nwg = sh.vstep / (kLdsBlock / 64), wg = sh.v0 / (kLdsBlock / 64);
+    const uint32_t pos = left >= sh.vstep ? sh.v0 + wave : wg + nwg * wave;
+    const uint32_t v = base + pos;
+    base += sh.vstep;
+    if (pos >= left) continue;  // uniform
     const uint32_t unit = up_unit(a, sh, v);
     if (unit == ~0u) continue;  // uniform
     const uint32_t rp = sh.upr == 1u ? unit : __umulhi(unit, a.magic_upr);  // unit / upr
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(kLdsBlock) void compose_up_write_v210_kernel(UpArgs
   const UpShare sh = up_share(a);
   const uint32_t role = lane - 3u * (lane / 3u);  // 0: pixels 0, 1 of the quad, 1: pixels 2, 3, 2: pixels 4, 5
   UpStep st;
-  for (uint32_t v = sh.v0 + wave; up_step(a, sh, v, lane, st); v += sh.vstep) {
+  for (uint32_t base = 0; up_step(a, sh, base, wave, lane, st);) {
     // (lowering a wave's priority as it advances, which helps the two-phase kernels reach their barrier together, measured neutral here)
     UpAcc acc[2][2];
 #pragma unroll
