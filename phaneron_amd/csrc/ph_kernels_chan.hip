@@ -28,8 +28,10 @@
 #ifndef PH_CHAN_BALANCE
 #define PH_CHAN_BALANCE 1
 #endif
+// output rows per XCD band.  8, not 16: at 1080p sixteen-row bands give four XCDs 9 bands and four XCDs 8 (22.5 against 20 chunks per
+// workgroup: a fifth round of wave steps on half the chip); with eight rows it is 17 against 16 (53.2 -> 51.3 us on config 2's frame)
 #ifndef PH_CHAN_GROUP_ROWS
-#define PH_CHAN_GROUP_ROWS 16
+#define PH_CHAN_GROUP_ROWS 8
 #endif
 
 // PH_CHAN_PROBE builds (tools/chan_probe.py; never the shipped library): wave 0 of workgroup 0 stamps s_memtime at fixed
@@ -495,6 +497,7 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   uint2 *const index = reinterpret_cast<uint2 *>(a.index);
   const float fow = (float)(int)a.out_w, foh = (float)(int)a.out_h;
+  // (taking the steps from an LDS counter as the waves come free, instead of dealing them in turn, measured the same: 51.9 against 51.3 us)
   for (uint32_t n = wave; n < 3u * sh.slots; n += kLdsBlock / 64) {  // 64-column steps, dealt round the waves
 #if PH_CHAN_BALANCE
     // the four waves of a SIMD are served oldest first: left alone the oldest races ahead and then idles at the phase barrier
