@@ -30,6 +30,13 @@
 
 namespace ph {
 
+#ifndef PH_UP_BLOCK
+#define PH_UP_BLOCK 1024
+#endif
+// lanes per workgroup (one workgroup per CU: the table fills the LDS).  Measured at 2160p x 4 layers: 1024 lanes 64.7 us, 768 lanes
+// (three waves per SIMD, 168 registers each) 65.7 us, 512 lanes 78 us; with the next layer's patch requested before this layer's is
+// filtered (two patches in flight) 768 lanes 69 us, 512 lanes 72.5 us, 1024 lanes 92 us (31 spilled registers): not a kernel that waits for its loads
+constexpr int kUpBlock = PH_UP_BLOCK;
 constexpr uint32_t kUpCols = 126;              // output columns of a wave step
 constexpr uint32_t kUpOutside = 0x40000000u;   // offsets of texels outside the image: beyond any num_records (images < 1 GiB)
 
@@ -64,11 +71,11 @@ __device__ __forceinline__ UpShare up_share(const UpArgs &a) {
   s.units = s.upr * ((a.lines + 1u) / 2u);
   s.upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * s.upr;
   s.banded = (gridDim.x & 7u) == 0;
-  s.xcd = 0, s.v0 = blockIdx.x * (kLdsBlock / 64), s.vstep = gridDim.x * (kLdsBlock / 64), s.vend = s.units;
+  s.xcd = 0, s.v0 = blockIdx.x * (kUpBlock / 64), s.vstep = gridDim.x * (kUpBlock / 64), s.vend = s.units;
   if (s.banded) {
     s.xcd = blockIdx.x & 7u;
     const uint32_t groups = (s.units + s.upg - 1u) / s.upg, mine = (groups + 7u - s.xcd) / 8u;
-    s.v0 = (blockIdx.x >> 3) * (kLdsBlock / 64), s.vstep = (gridDim.x >> 3) * (kLdsBlock / 64), s.vend = mine * s.upg;
+    s.v0 = (blockIdx.x >> 3) * (kUpBlock / 64), s.vstep = (gridDim.x >> 3) * (kUpBlock / 64), s.vend = mine * s.upg;
   }
   return s;
 }
@@ -135,7 +142,7 @@ struct UpStep {
 // CUs with sixteen waves each doing a ninth step.
 __device__ __forceinline__ bool up_step(const UpArgs &a, const UpShare &sh, uint32_t &base, uint32_t wave, uint32_t lane, UpStep &st) {
   while (base < sh.vend) {
-    const uint32_t left = sh.vend - base, nwg = sh.vstep / (kLdsBlock / 64), wg = sh.v0 / (kLdsBlock / 64);
+    const uint32_t left = sh.vend - base, nwg = sh.vstep / (kUpBlock / 64), wg = sh.v0 / (kUpBlock / 64);
     const uint32_t pos = left >= sh.vstep ? sh.v0 + wave : wg + nwg * wave;
     const uint32_t v = base + pos;
     base += sh.vstep;
@@ -303,10 +310,10 @@ __device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, cons
 }
 
 template <bool RGB12>
-__global__ __launch_bounds__(kLdsBlock) void compose_up_write_v210_kernel(UpArgs a) {
+__global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs a) {
   const WriteK wk = load_write_k(a.wr_cm);
   const LutK lk = make_lut_k(a.wr);
-  lds_lut_load(a.wr);
+  lds_lut_load<kUpBlock>(a.wr);
   __syncthreads();
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const UpShare sh = up_share(a);
@@ -390,10 +397,10 @@ hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb
   // reciprocals for the kernel's uniform divisions: umulhi(v, ceil(2^32 / d)) == v / d while v * d < 2^32
   b.magic_upr = upr > 1 ? (uint32_t)(((1ull << 32) + upr - 1) / upr) : 0u;
   b.magic_upg = (uint32_t)(((1ull << 32) + upg - 1) / upg);
-  const uint32_t want = (units + kLdsBlock / 64 - 1) / (kLdsBlock / 64);
+  const uint32_t want = (units + kUpBlock / 64 - 1) / (kUpBlock / 64);
   const uint32_t grid = want < num_cus ? want : num_cus;
-  if (rgb12) compose_up_write_v210_kernel<true><<<grid, kLdsBlock, a.wr.bytes, s>>>(b);
-  else compose_up_write_v210_kernel<false><<<grid, kLdsBlock, a.wr.bytes, s>>>(b);
+  if (rgb12) compose_up_write_v210_kernel<true><<<grid, kUpBlock, a.wr.bytes, s>>>(b);
+  else compose_up_write_v210_kernel<false><<<grid, kUpBlock, a.wr.bytes, s>>>(b);
   return hipGetLastError();
 }
 
