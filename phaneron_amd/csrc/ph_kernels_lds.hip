@@ -951,6 +951,14 @@ static hipError_t launch_fused_n(hipStream_t s, const FusedLdsArgs &a, uint32_t 
     const char *e = getenv("PH_FUSED_PIPE");  // 1 = the software-pipelined phases (measured 3 % SLOWER: DESIGN.md 4)
     return e ? atoi(e) : 0;
   }();
+#ifdef PH_FUSED_EXPERIMENT  // timing builds only: smaller workgroups (more registers per wave) for N = 4
+  static const int bs_env = [] {
+    const char *e = getenv("PH_FUSED_BS");
+    return e ? atoi(e) : 0;
+  }();
+  if (N == 4 && bs_env == 768) return pipe_env ? launch_fused_npb<4, 8, 768, true>(s, a, grid, lds) : launch_fused_npb<4, 8, 768>(s, a, grid, lds);
+  if (N == 4 && bs_env == 512) return pipe_env ? launch_fused_npb<4, 11, 512, true>(s, a, grid, lds) : launch_fused_npb<4, 11, 512>(s, a, grid, lds);
+#endif
   if (pipe_env && geom == 6) return launch_fused_npb<N, 6, 1024, true>(s, a, grid, lds);
   if (geom == 4) return launch_fused_npb<N, 4, 1024>(s, a, grid, lds);
   if (geom == 8) return launch_fused_npb<N, 8, 1024>(s, a, grid, lds);
