@@ -26,6 +26,12 @@
 namespace ph {
 
 constexpr int kDeintCols = 64 - 6;  // columns a wave produces
+#ifndef PH_DEINT_BLOCK
+#define PH_DEINT_BLOCK 1024
+#endif
+// lanes per workgroup.  Four 1080i layers, packed-RGB fields: 1024 lanes 113 us per frame, 768 lanes (131 registers, no spill) 119 us,
+// 512 lanes 128 us - half the waves cost 13 %: the kernel sits on VALU issue and the LDS pipe, not on latency
+constexpr int kDeintBlock = PH_DEINT_BLOCK;
 
 struct Rgb {
   float r, g, b;
@@ -105,7 +111,7 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int w = (int)a.width, h = (int)a.height;
   const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;
-  for (uint32_t t = blockIdx.x * (kLdsBlock / 64) + wave; t < tasks; t += gridDim.x * (kLdsBlock / 64)) {
+  for (uint32_t t = blockIdx.x * (kDeintBlock / 64) + wave; t < tasks; t += gridDim.x * (kDeintBlock / 64)) {
     const uint32_t cb = t % a.col_blocks, rest = t / a.col_blocks, strip = rest % a.strips, l = rest / a.strips;
     // bytes per line: a v210 line of quads_pitch quads, or (planar) quads_pitch luma samples of 1 or 2 bytes
     const uint32_t line_bytes = PACK == 0 ? a.quads_pitch * 16u : a.quads_pitch * (PACK == 1 ? 2u : 1u);
@@ -196,10 +202,10 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
 }
 
 template <int TFF, int PACK = 0>
-__global__ __launch_bounds__(kLdsBlock) void v210_yadif_pair_kernel(DeintArgs a) {
+__global__ __launch_bounds__(kDeintBlock) void v210_yadif_pair_kernel(DeintArgs a) {
   const ReadK k = load_read_k(a.cm, a.gm);
   const LutK lk = make_lut_k(a.lut);
-  lds_lut_load(a.lut);
+  lds_lut_load<kDeintBlock>(a.lut);
   __syncthreads();
   if (ycbcr_matrix_is_standard(k))  // every matrix colourMaths produces (ph_ldslut.h): 8 operations per pixel instead of 12
     v210_yadif_pair_body<TFF, true, PACK>(a, k, lk);
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_yadif_pair_kernel(DeintArgs a)
 
 hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t num_cus) {
   // strip height: even, and such that the waves of the chip are filled in whole rounds - cost ~ rounds x (R + 4 halo rows)
-  const uint32_t slots = num_cus * (kLdsBlock / 64);
+  const uint32_t slots = num_cus * (kDeintBlock / 64);
   a.col_blocks = (a.width + kDeintCols - 1) / kDeintCols;
   uint32_t best_r = 16;
   uint64_t best_cost = ~0ull;
@@ -223,12 +229,12 @@ hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t 
   a.rows_per_strip = best_r;
   a.strips = (a.height + best_r - 1) / best_r;
   const uint32_t tasks = (uint32_t)a.n * a.strips * a.col_blocks;
-  const uint32_t want = (tasks + kLdsBlock / 64 - 1) / (kLdsBlock / 64);
+  const uint32_t want = (tasks + kDeintBlock / 64 - 1) / (kDeintBlock / 64);
   const uint32_t grid = want < num_cus ? want : num_cus;
   auto go = [&](auto kernel) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lut.bytes);
     if (e != hipSuccess) return e;
-    kernel<<<grid, kLdsBlock, a.lut.bytes, s>>>(a);
+    kernel<<<grid, kDeintBlock, a.lut.bytes, s>>>(a);
     return hipGetLastError();
   };
   switch (a.pack) {
