@@ -20,7 +20,7 @@ def main():
     ctx = capi.Context(0)
     stream = ctx.torch_stream()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    w, h, R = 1920, 1080, 8
+    w, h, R = 1920, int(os.environ.get("PH_CHAN_BENCH_H", "1080")), 8  # (another height: how much of a frame's time is the last, partial round of chunks)
     rd = [dev(capi.ycbcr2rgb_matrix("709")), dev(capi.gamma2linear_lut("709")), dev(np.concatenate([capi.rgb2rgb_matrix("709", "709"), np.zeros(3, np.float32)]))]
     wr = [dev(capi.rgb2ycbcr_matrix("709")), dev(capi.linear2gamma_lut("709"))]
     torch.cuda.synchronize()
@@ -66,7 +66,7 @@ def main():
         jobs[i % R]()
     e1.record(stream)
     ctx.wait()
-    print(json.dumps({"kernel": "chan_compose_v210", "variant": variant, "mask": mask_kind, "sources": packing, "us_per_frame": round(1e3 * e0.elapsed_time(e1) / reps, 2)}), flush=True)
+    print(json.dumps({"kernel": "chan_compose_v210", "height": h, "variant": variant, "mask": mask_kind, "sources": packing, "us_per_frame": round(1e3 * e0.elapsed_time(e1) / reps, 2)}), flush=True)
     ctx.close()
 
 
