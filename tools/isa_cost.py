@@ -27,7 +27,7 @@ import tempfile
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-HEADLINE = "fused_v210_combine_lds_kernelILi4ELi6ELi1024ELb0EEE"
+HEADLINE = "fused_v210_combine_lds_kernelILi4ELi6ELi1024ELb0ELi0EEE"
 
 # mnemonics opbench3 did not time, priced as the measured instruction of the same hardware class
 SAME_AS = {
