@@ -30,7 +30,7 @@ extern "C" {
 /* 3: additive over 2 - ph_chan_compose_v210 (ph_chan_source / ph_chan_layer), ph_compose_up_write_v210, ph_v210_yadif_pair_fmt,
  *    ph_chan_compose, ph_yadif_pair_packed (ph_deint_source grew), ph_check_program, ph_route_comm_count, context option
  *    "host_pool_mb"; no signature of 2 changed */
-#define PH_ABI_VERSION 4
+#define PH_ABI_VERSION 5
 
 enum {
   PH_OK = 0,
@@ -371,6 +371,13 @@ typedef struct ph_image_layer {
 } ph_image_layer;
 int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer *layers, void *out, uint32_t out_width,
                              uint32_t out_height, uint32_t interlace, const void *wr_col_matrix12, const void *wr_gamma_lut);
+/* Both fields of a de-interlaced frame in ONE launch: exactly ph_compose_up_write_v210(layers_a -> out_a) followed by
+ * ph_compose_up_write_v210(layers_b -> out_b), for two sets of layers that differ in their data only (same count, formats, sizes and
+ * placements: the parity-0 and parity-1 outputs of ph_v210_yadif_pair_fmt under one Mixer setting).  One launch, one table load and one
+ * partly filled last round of wave steps instead of two. */
+int ph_compose_up_write_v210_pair(ph_ctx *ctx, int queue, int n, const ph_image_layer *layers_a, const ph_image_layer *layers_b, void *out_a,
+                                  void *out_b, uint32_t out_width, uint32_t out_height, uint32_t interlace, const void *wr_col_matrix12,
+                                  const void *wr_gamma_lut);
 
 /* ---- the channel compositor straight from the wire format (no single reference equivalent): a channel's whole
  *      per-frame job batch - per layer ToRGBA (io.ts:79-98, v210.ts:25-111) -> Mixer transform (producer/mixer.ts:

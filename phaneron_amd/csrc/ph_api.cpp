@@ -1865,35 +1865,56 @@ int ph_v210_yadif_pair(ph_ctx *ctx, int queue, int n, const ph_deint_source *src
   return ph_v210_yadif_pair_fmt(ctx, queue, n, src, width, height, tff, skip, PH_IMG_RGBA_F32, cm, lut, gm);
 }
 
-int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
-                             uint32_t interlace, const void *wr_cm, const void *wr_lut) {
-  if (!ctx || !layers || !out || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_compose_up_write_v210: NULL argument");
-  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_compose_up_write_v210: 1..%d layers", ph::kMaxLayers);
-  if (!out_w || out_w % 48) return fail(PH_E_INVALID, "ph_compose_up_write_v210: width %u is not a multiple of 48; run the separate kernels", out_w);
-  if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_compose_up_write_v210: interlace must be 0, 1 or 3");
+static int compose_up_common(const char *fn, ph_ctx *ctx, int queue, int n, const ph_image_layer *layers, const ph_image_layer *layers_b, void *out, void *out_b,
+                             uint32_t out_w, uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut) {
+  const bool pair = layers_b != nullptr;
+  if (!ctx || !layers || !out || !wr_cm || !wr_lut || (pair && !out_b)) return fail(PH_E_INVALID, "%s: NULL argument", fn);
+  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "%s: 1..%d layers", fn, ph::kMaxLayers);
+  if (!out_w || out_w % 48) return fail(PH_E_INVALID, "%s: width %u is not a multiple of 48; run the separate kernels", fn, out_w);
+  if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "%s: interlace must be 0, 1 or 3", fn);
+  if (pair && out == out_b) return fail(PH_E_INVALID, "%s: the two outputs are the same buffer", fn);
   const ph::LutView *wv = lds_view(ctx, wr_lut);
-  if (!wv) return fail(PH_E_INVALID, "ph_compose_up_write_v210: the writer gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)");
+  if (!wv) return fail(PH_E_INVALID, "%s: the writer gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)", fn);
   ph::UpArgs a{};
   a.n = n;
   const int fmt = layers[0].format;
-  if (fmt != PH_IMG_RGBA_F32 && fmt != PH_IMG_RGB_F32) return fail(PH_E_INVALID, "ph_compose_up_write_v210: image format %d", fmt);
+  if (fmt != PH_IMG_RGBA_F32 && fmt != PH_IMG_RGB_F32) return fail(PH_E_INVALID, "%s: image format %d", fn, fmt);
   for (int i = 0; i < n; ++i) {
     const ph_image_layer &L = layers[i];
-    if (!L.data || L.width <= 0 || L.height <= 0 || !L.matrix9_host) return fail(PH_E_INVALID, "ph_compose_up_write_v210: layer %d is incomplete", i);
-    if (L.format != fmt) return fail(PH_E_INVALID, "ph_compose_up_write_v210: layer %d has another image format than layer 0", i);
+    if (!L.data || L.width <= 0 || L.height <= 0 || !L.matrix9_host) return fail(PH_E_INVALID, "%s: layer %d is incomplete", fn, i);
+    if (L.format != fmt) return fail(PH_E_INVALID, "%s: layer %d has another image format than layer 0", fn, i);
     a.layer[i].ptr = L.data, a.layer[i].w = (uint32_t)L.width, a.layer[i].h = (uint32_t)L.height;
     a.layer[i].pitch = (uint32_t)L.width * (fmt == PH_IMG_RGB_F32 ? 12u : 16u);
     for (int k = 0; k < 6; ++k) a.layer[i].m[k] = L.matrix9_host[k];
+    if (pair) {
+      const ph_image_layer &B = layers_b[i];
+      if (!B.data || !B.matrix9_host || B.format != L.format || B.width != L.width || B.height != L.height)
+        return fail(PH_E_INVALID, "%s: layer %d of the second set differs from the first in more than its data", fn, i);
+      for (int k = 0; k < 9; ++k)
+        if (B.matrix9_host[k] != L.matrix9_host[k]) return fail(PH_E_INVALID, "%s: layer %d of the second set is placed differently", fn, i);
+      a.ptr2[i] = B.data;
+    }
   }
-  a.out = out, a.out_w = out_w, a.out_h = out_h;
+  a.out = out, a.out2 = out_b, a.jobs = pair ? 2u : 1u, a.out_w = out_w, a.out_h = out_h;
   a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0;
   a.lines = interlace ? out_h / 2 : out_h;
   a.wr_cm = (const float *)wr_cm, a.wr = *wv;
   if (!ph::compose_up_eligible(a))
-    return fail(PH_E_INVALID, "ph_compose_up_write_v210: every layer must be enlarged (by 1 %% or more in both directions, per written row) without "
-                              "rotation or mirroring and be below 1 GiB; use ph_compose_write_v210");
+    return fail(PH_E_INVALID, "%s: every layer must be enlarged (by 1 %% or more in both directions, per written row) without "
+                              "rotation or mirroring and be below 1 GiB; use ph_compose_write_v210", fn);
   if (!a.lines) return PH_OK;
   PH_LAUNCH(ph::launch_compose_up_write_v210(stream_of(ctx, queue), a, fmt == PH_IMG_RGB_F32, (uint32_t)ctx->props.multiProcessorCount));
+}
+
+int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
+                             uint32_t interlace, const void *wr_cm, const void *wr_lut) {
+  return compose_up_common("ph_compose_up_write_v210", ctx, queue, n, layers, nullptr, out, nullptr, out_w, out_h, interlace, wr_cm, wr_lut);
+}
+
+int ph_compose_up_write_v210_pair(ph_ctx *ctx, int queue, int n, const ph_image_layer *layers_a, const ph_image_layer *layers_b, void *out_a, void *out_b,
+                                  uint32_t out_w, uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut) {
+  if (!layers_b) return fail(PH_E_INVALID, "ph_compose_up_write_v210_pair: NULL argument");
+  return compose_up_common("ph_compose_up_write_v210_pair", ctx, queue, n, layers_a, layers_b, out_a, out_b, out_w, out_h, interlace, wr_cm, wr_lut);
 }
 
 int ph_v210_yadif_pair_fmt(ph_ctx *ctx, int queue, int n, const ph_deint_source *src, uint32_t width, uint32_t height, int tff,

@@ -113,6 +113,10 @@ struct UpArgs {
   LutView wr;
   uint32_t magic_upr, magic_upg;  // launcher
   uint32_t shared;                // launcher: all layers have one size and one placement
+  // a second job of the same shape in the same launch (both fields of a frame): its layers' data and its output; jobs = 1 | 2
+  const void *ptr2[kMaxLayers];
+  void *out2;
+  uint32_t jobs;
 };
 bool compose_up_eligible(const UpArgs &a);
 hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb12, uint32_t num_cus);

@@ -68,7 +68,7 @@ struct UpShare {  // as ChanShare (ph_kernels_chan.hip): units dealt XCD-aware i
 __device__ __forceinline__ UpShare up_share(const UpArgs &a) {
   UpShare s;
   s.upr = (a.out_w + kUpCols - 1u) / kUpCols;  // wave steps per row pair
-  s.units = s.upr * ((a.lines + 1u) / 2u);
+  s.units = s.upr * ((a.lines + 1u) / 2u) * (a.jobs > 1u ? 2u : 1u);  // a second job's row pairs follow the first's
   s.upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * s.upr;
   s.banded = (gridDim.x & 7u) == 0;
   s.xcd = 0, s.v0 = blockIdx.x * (kUpBlock / 64), s.vstep = gridDim.x * (kUpBlock / 64), s.vend = s.units;
@@ -132,6 +132,7 @@ __device__ __forceinline__ void up_over(const UpColour &c, UpAcc &acc) {
 
 // where a wave step lies: 126 columns x 2 rows; the lane's block starts at (x0, line[0])
 struct UpStep {
+  uint32_t job;  // uniform: 0, or 1 for a row pair of the launch's second job
   uint32_t x0, li[2], line[2];
   float px[2], py[2];
   bool live;
@@ -149,8 +150,11 @@ __device__ __forceinline__ bool up_step(const UpArgs &a, const UpShare &sh, uint
     if (pos >= left) continue;  // uniform
     const uint32_t unit = up_unit(a, sh, v);
     if (unit == ~0u) continue;  // uniform
-    const uint32_t rp = sh.upr == 1u ? unit : __umulhi(unit, a.magic_upr);  // unit / upr
-    st.x0 = (unit - rp * sh.upr) * kUpCols + 2u * lane;  // even
+    uint32_t rp = sh.upr == 1u ? unit : __umulhi(unit, a.magic_upr);  // unit / upr
+    const uint32_t col_unit = unit - rp * sh.upr, rp_per_job = (a.lines + 1u) / 2u;
+    st.job = rp >= rp_per_job ? 1u : 0u;
+    rp -= st.job * rp_per_job;
+    st.x0 = col_unit * kUpCols + 2u * lane;  // even
     st.live = lane < 63u && st.x0 < a.out_w;               // lane 63 has no quad; the row's last step may be short
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
@@ -302,7 +306,7 @@ __device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, cons
     else half = make_uint2(eu << 20 | from_prev, y1 << 20 | ev << 10 | ey);      // w2, w3 (lane C)
     const bool store = st.live && role != 1u && (dy == 0 || st.li[1] != st.li[0]);
     if (store) {
-      uint2 *dst = reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(a.out) + (size_t)st.line[dy] * qpl + st.x0 / 6u) + (role == 2u ? 1 : 0);
+      uint2 *dst = reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(st.job ? a.out2 : a.out) + (size_t)st.line[dy] * qpl + st.x0 / 6u) + (role == 2u ? 1 : 0);
       __builtin_nontemporal_store(half.x, &dst->x);
       __builtin_nontemporal_store(half.y, &dst->y);
     }
@@ -336,7 +340,8 @@ __global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs 
     auto layers = [&](auto inside_tag, auto shared_tag) __attribute__((always_inline)) {
       constexpr bool INSIDE = decltype(inside_tag)::value, SHARED = decltype(shared_tag)::value;
       {
-        const UpLayer L = a.layer[0];  // one 48-byte scalar load
+        UpLayer L = a.layer[0];  // one 48-byte scalar load
+        if (st.job) L.ptr = a.ptr2[0];
         if (!SHARED) geo = up_geo<RGB12>(L, st);
         UpPatch p;
         up_fetch<RGB12>(L, geo, p);
@@ -344,7 +349,8 @@ __global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs 
       }
 #pragma unroll 1
       for (int l = 1; l < a.n; ++l) {
-        const UpLayer L = a.layer[l];
+        UpLayer L = a.layer[l];
+        if (st.job) L.ptr = a.ptr2[l];
         if (!SHARED) geo = up_geo<RGB12>(L, st);
         UpPatch p;
         up_fetch<RGB12>(L, geo, p);
@@ -393,7 +399,7 @@ hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb
     for (int k = 0; k < 6; ++k) b.shared = b.shared && a.layer[l].m[k] == a.layer[0].m[k];
   }
   const uint32_t upr = (a.out_w + kUpCols - 1u) / kUpCols, upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * upr;
-  const uint32_t units = upr * ((a.lines + 1u) / 2u);
+  const uint32_t units = upr * ((a.lines + 1u) / 2u) * (a.jobs > 1u ? 2u : 1u);
   // reciprocals for the kernel's uniform divisions: umulhi(v, ceil(2^32 / d)) == v / d while v * d < 2^32
   b.magic_upr = upr > 1 ? (uint32_t)(((1ull << 32) + upr - 1) / upr) : 0u;
   b.magic_upg = (uint32_t)(((1ull << 32) + upg - 1) / upg);

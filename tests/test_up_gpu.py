@@ -86,6 +86,50 @@ def test_field_outputs(interlace):
         run([(opaque(96, 27, 22), m(ow, oh))], ow, oh, interlace=interlace, rgb=True)
 
 
+@pytest.mark.parametrize("rgb", [False, True], ids=["rgba", "packed-rgb"])
+@pytest.mark.parametrize("interlace", [0, 1, 3])
+@pytest.mark.parametrize("shape", [(192, 54, 384, 108, 3), (96, 31, 288, 124, 2), (1920, 1080, 3840, 2160, 4)])
+def test_both_fields_in_one_launch_equal_two_launches(shape, interlace, rgb):
+    """ph_compose_up_write_v210_pair == ph_compose_up_write_v210 twice (and, at the small sizes, == the oracle's chain for each set)"""
+    import torch
+    import hip_harness as hh
+    sw, sh, ow, oh, n = shape
+    if interlace and oh * 0.99 <= 2 * sh:  # a field write needs more than 2x vertically (rows two lines apart)
+        pytest.skip("not eligible as a field write")
+    k = hh.ctx()
+    wcm, wlut = hh.ColourParams.writer("2020")
+    mat = m(ow, oh)
+    words = frames.v210_pitch_bytes(ow) * oh // 4
+    rng = np.random.default_rng(sw + interlace)
+    sets = []
+    for f in range(2):
+        imgs = [opaque(sw, sh, 300 + 10 * f + l) if rgb else frames.rgba_random(sw, sh, 300 + 10 * f + l, -0.05, 1.05).reshape(sh, sw, 4) for l in range(n)]
+        sets.append(imgs)
+    dev = [[(hh.dev((np.ascontiguousarray(img[..., :3]) if rgb else img).reshape(-1)), sw, sh, mat) for img in imgs] for imgs in sets]
+    fill = rng.integers(0, 2 ** 30, words, dtype=np.int64).astype(np.uint32)  # a field write leaves the other field's lines alone
+    single = [hh.dev(fill.copy()) for _ in range(2)]
+    pair = [hh.dev(fill.copy()) for _ in range(2)]
+    for f in range(2):
+        k.compose_up_write_v210(dev[f], single[f], ow, oh, interlace, wcm, wlut, rgb=rgb)
+    k.compose_up_write_v210_pair(dev[0], dev[1], pair[0], pair[1], ow, oh, interlace, wcm, wlut, rgb=rgb)
+    k.wait()
+    for f in range(2):
+        a, b = hh.host(single[f], np.uint32), hh.host(pair[f], np.uint32)
+        bad = np.flatnonzero(a != b)
+        assert bad.size == 0, "set %d: %d words differ from the single launch, first at %d" % (f, bad.size, bad[0])
+    if ow <= 384:
+        wr_o = (orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+        for f in range(2):
+            placed = [orc.transform(img, mat, ow, oh) for img in sets[f]]
+            want = orc.v210_write(placed[0] if n == 1 else orc.combine(placed), ow, oh, interlace, *wr_o, out=fill.copy())
+            assert np.array_equal(hh.host(pair[f], np.uint32), np.asarray(want).reshape(-1)), "set %d differs from the oracle" % f
+    with pytest.raises(Exception, match="same buffer"):
+        k.compose_up_write_v210_pair(dev[0], dev[1], pair[0], pair[0], ow, oh, interlace, wcm, wlut, rgb=rgb)
+    with pytest.raises(Exception, match="placed differently"):
+        other = [(t, w, h, m(ow, oh, offset_x=0.01)) for t, w, h, _ in dev[1]]
+        k.compose_up_write_v210_pair(dev[0], other, pair[0], pair[1], ow, oh, interlace, wcm, wlut, rgb=rgb)
+
+
 def test_frame_shapes():
     """a row shorter than a wave step, rows that end in a short step, an odd number of rows (the last row has no partner),
     a frame smaller than the chip"""

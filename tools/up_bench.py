@@ -27,6 +27,7 @@ def main():
     words = capi.v210_pitch_bytes(sw) * sh // 4
     src = [[torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device="cuda") for _ in range(4)] for _ in range(R)]
     out = torch.empty(capi.v210_pitch_bytes(ow) * oh // 4, dtype=torch.int32, device="cuda")
+    out2 = torch.empty_like(out)
     rgba = [[[torch.rand(sw * sh * 4, device="cuda") for _ in range(2)] for _ in range(4)] for _ in range(2)]  # two sets: defeat the caches a little
     rgb = [[[torch.rand(sw * sh * 3, device="cuda") for _ in range(2)] for _ in range(4)] for _ in range(2)]
     mh = capi.transform_matrix(ow, oh)
@@ -58,6 +59,9 @@ def main():
     if which in ("all", "compose", "up"):
         jobs_b = [ctx.compose_up_write_v210([(rgb[s][l][p], sw, sh, mh) for l in range(4)], out, ow, oh, 0, *wr, rgb=True, prepare_only=True) for s in range(2) for p in range(2)]
         res["compose_up_rgb_us_per_field"] = timeit(lambda i: jobs_b[i & 3]())
+        pair_jobs = [ctx.compose_up_write_v210_pair([(rgb[s][l][0], sw, sh, mh) for l in range(4)], [(rgb[s][l][1], sw, sh, mh) for l in range(4)], out, out2,
+                                                    ow, oh, 0, *wr, rgb=True, prepare_only=True) for s in range(2)]
+        res["compose_up_rgb_pair_us_per_field"] = round(timeit(lambda i: pair_jobs[i & 1]()) / 2, 2)
     print(json.dumps(res), flush=True)
     ctx.close()
 
