@@ -64,6 +64,8 @@ VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2.0
 # untimed launches before --warmup is honoured: a 20-step run must still measure settled clocks.  The chip needs
 # ~50 ms of load to settle: after 200 launches (11 ms) the next 20 still ran 9 % slow, after 1000 they run at the
 # steady 54.6 us (profiles/r02_bench_repeat.jsonl and DESIGN.md 5).
+WATCHDOG_EXIT = 3  # exit code of a job whose config-5 leg was abandoned (the partial line is still printed)
+
 FIXED_WARMUP = int(os.environ.get("PH_BENCH_FIXED_WARMUP", "1000"))
 
 
@@ -333,14 +335,22 @@ def main():
     for i in range(FIXED_WARMUP):  # clocks, caches and the allocator settle before the contract's own warm-up
         step(i)
     sync()
-    elapsed = multigpu.timed_steps(timed_step, args.steps, args.warmup, sync, dist, reduce_device)
+    timed_local = {}
+    elapsed = multigpu.timed_steps(timed_step, args.steps, args.warmup, sync, dist, reduce_device, local=timed_local)
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # average launch duration on the kernel's stream
     # frames every rank really composited in the timed region, summed over ranks (not assumed equal)
     frames_done = C * args.steps
+    per_rank = None
     if dist is not None:
         t = torch.tensor([frames_done], dtype=torch.int64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         frames_done = int(t.item())
+        # every rank's own figures, so that the first run on N devices says which rank was slow and why: its own wall
+        # clock over the timed steps (timed_steps keeps it), its frames, its kernel's average launch time
+        mine = torch.tensor([C * args.steps, timed_local["elapsed"], kernel_ms], dtype=torch.float64, device=reduce_device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [[float(x) for x in e.tolist()] for e in every]
 
     lds = ctx.lut_info(rd[1])["lds_bytes"] and ctx.lut_info(wr[1])["lds_bytes"] and not os.environ.get("PH_BENCH_GLOBAL_LUT")
     kernel_name = ("fused_v210_combine_lds_kernel<%d,...>" if lds else "fused_v210_combine_kernel<%d>") % n
@@ -371,6 +381,25 @@ def main():
                              "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,
                              "avg_launch_ms": round(kernel_ms, 5)},
             }
+            # the same fraction on the OTHER clock (SURVEY 8d's formula): algorithmic bytes x the frames/s of `value` per GPU.
+            # `frac` is the kernel's own time (HIP events on its stream); `value` is wall clock over the K steps including the
+            # closing ctx.wait() + device sync, which a short run does not amortise - the difference is stated, not hidden
+            by_value = algo_bytes / C * (fps / world) / 1e9
+            line["roofline"]["frac_by_value"] = round(by_value / HBM_PEAK_GBS, 4)
+            line["roofline"]["clocks"] = ("frac: HIP events around the timed launches on the kernel's stream (avg_launch_ms); "
+                                          "frac_by_value: algorithmic bytes x value / n_gpus (host wall clock, barrier + sync on both sides)")
+            line["roofline"]["sync_overhead_us_per_step"] = round(1e3 * (1e3 * elapsed / max(args.steps, 1) - kernel_ms), 3)
+            if args.steps < 200:
+                line["roofline"]["sync_overhead_note"] = ("%d timed steps: the closing sync (a few hundred microseconds of host time, once) is "
+                                                          "spread over few steps; with the default 2000 steps both fractions agree" % args.steps)
+            if per_rank is not None:
+                rates = [f / e for f, e, _ in per_rank]
+                slow = min(range(len(rates)), key=lambda i: rates[i])
+                line["per_rank"] = {"frames_per_sec": [round(x, 2) for x in rates], "min": round(min(rates), 2), "max": round(max(rates), 2),
+                                    "elapsed_s": [round(e, 6) for _, e, _ in per_rank],
+                                    "avg_launch_ms": [round(k, 5) for _, _, k in per_rank],
+                                    "slowest_rank": slow, "slowest_rank_avg_launch_ms": round(per_rank[slow][2], 5),
+                                    "roofline_frac": [round(algo_bytes / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k > 0 else None for _, _, k in per_rank]}
             if route_rec is not None:
                 line["route"] = route_rec
             insts, src = recorded_valu_instructions()
@@ -430,7 +459,7 @@ def main():
         def gave_up():
             report({"error": "config 5 did not finish within %.0f s; abandoned by the watchdog" % limit}, minimal=True)
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(WATCHDOG_EXIT)  # the line is out; the exit code still tells the launcher that a rank hung
         watchdog = threading.Timer(limit, gave_up)
         watchdog.daemon = True
         watchdog.start()

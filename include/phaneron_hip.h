@@ -25,12 +25,17 @@
 extern "C" {
 #endif
 
-/* 2: additive over 1 - ph_program_resolve, ph_route_*, ph_yadif_pair, ph_v210_yadif_pair, ph_v210_read_batch,
- *    ph_fused_field_v210, ph_compose_wipe_write_v210, context option "stream_images"; no signature of 1 changed */
-/* 3: additive over 2 - ph_chan_compose_v210 (ph_chan_source / ph_chan_layer), ph_compose_up_write_v210, ph_v210_yadif_pair_fmt,
- *    ph_chan_compose, ph_yadif_pair_packed (ph_deint_source grew), ph_check_program, ph_route_comm_count, context option
- *    "host_pool_mb"; no signature of 2 changed */
-#define PH_ABI_VERSION 5
+/* ABI history (ph_abi_version() returns PH_ABI_VERSION; a binding compiled against another value must not load the library)
+ * 2: additive over 1 - ph_program_resolve, ph_route_*, ph_yadif_pair, ph_v210_yadif_pair, ph_v210_read_batch,
+ *    ph_compose_wipe_write_v210, context option "stream_images"; no signature of 1 changed
+ * 3: ph_chan_compose_v210 (ph_chan_source / ph_chan_layer), ph_compose_up_write_v210, ph_v210_yadif_pair_fmt, ph_check_program,
+ *    ph_route_comm_count, context option "host_pool_mb"
+ * 4: BREAKING for callers of ph_v210_yadif_pair: ph_deint_source grew from 40 to 88 bytes (six chroma-plane pointers for
+ *    ph_yadif_pair_packed), so an array of sources built against 2 / 3 has the wrong stride.  ph_chan_compose added
+ * 5: ph_compose_up_write_v210_pair, ph_lut_layout_of
+ * 6: ph_fused_field_v210 / ph_field_layer REMOVED (the slowest route of its workload by 2.7x, no caller).  The fused entry
+ *    points take widths that are not a multiple of 48 (1280 x 720: the reference's third format, src/config.ts:43-54) */
+#define PH_ABI_VERSION 6
 
 enum {
   PH_OK = 0,
@@ -432,25 +437,6 @@ int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *lay
 int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, int out_format, void *const out_planes[3],
                     uint32_t out_width, uint32_t out_height, uint32_t interlace, const void *rd_col_matrix12, const void *rd_gamma_lut,
                     const void *rd_gamut9, const void *wr_col_matrix12, const void *wr_gamma_lut);
-
-/* ---- fused field pipeline (no single reference equivalent): the per-field job batch of a de-interlacing,
- *      scaling channel - Yadif per layer (yadif.ts:115-145) -> transform per layer (producer/mixer.ts:209-223)
- *      -> combine_N (combiner.ts:219-254) -> v210 write (io.ts:152-164) - as ONE kernel: de-interlaced source
- *      windows are staged in LDS and sampled from there, so neither the de-interlaced nor the placed nor the
- *      combined f32 frames reach HBM.  Bit-identical to ph_yadif + ph_transform + ph_combine + ph_v210_write.
- *      Limits (PH_E_INVALID otherwise - run the separate kernels): every transform axis-aligned and not mirrored
- *      (matrix[1] == matrix[3] == 0, matrix[0] > 0, matrix[4] > 0), the source window of a 192 x 16 output slice
- *      within the LDS (up-scales and 1:1), out_width % 192 == 0, progressive output, the writer LUT registered. */
-typedef struct ph_field_layer {
-  const void *prev, *cur, *next; /* device, float RGBA, width x height (prev / next unused when deinterlace == 0) */
-  int width, height;
-  const void *matrix9;           /* device 3x3 transform matrix (ph_transform_matrix) */
-  const float *matrix9_host;     /* the same nine values on the host */
-  int deinterlace;               /* 0 = progressive source (cur as it is), 1 = yadif */
-  int parity, tff, skip_spatial; /* as ph_yadif */
-} ph_field_layer;
-int ph_fused_field_v210(ph_ctx *ctx, int queue, int n, const ph_field_layer *layers, void *out, uint32_t out_width,
-                        uint32_t out_height, const void *wr_col_matrix12, const void *wr_gamma_lut);
 
 /* ---- gamma LUT placement.  The reference hands its kernels a 65536-entry f32 `gammaLut` buffer
  *      (loadSave.ts:65-73,152-160) and gathers from it 3x per pixel.  Registering the table's

@@ -11,9 +11,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libphaneron_hip.so")
+# experiment builds (PH_PROBE, PH_FUSED_SPLIT ...: tools/*_probe.py) live outside the package: lib/ holds the product only
+VARIANT_DIR = os.path.normpath(os.path.join(HERE, "..", "tools", "_variants"))
 ARCH = "gfx950"
 
-SOURCES = ["ph_kernels.hip", "ph_kernels_lds.hip", "ph_kernels_fmt.hip", "ph_kernels_field.hip", "ph_kernels_deint.hip", "ph_kernels_chan.hip", "ph_kernels_up.hip", "ph_api.cpp", "ph_program.cpp", "ph_colour.cpp", "ph_lut.cpp"]
+SOURCES = ["ph_kernels.hip", "ph_kernels_lds.hip", "ph_kernels_fmt.hip", "ph_kernels_deint.hip", "ph_kernels_chan.hip", "ph_kernels_up.hip", "ph_api.cpp", "ph_program.cpp", "ph_colour.cpp", "ph_lut.cpp"]
 HEADERS = ["ph_device.h", "ph_kernels.h", "ph_lut.h", "ph_lut_host.h", "ph_ldslut.h", "ph_program.h", "ph_yadif.h", os.path.join("..", "..", "include", "phaneron_hip.h")]
 # -ffp-contract=off: every fused multiply-add in the kernels is explicit (parity with the
 # reference's OpenCL arithmetic); no fast-math anywhere.
@@ -43,20 +45,24 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def variant_path(variant):
+    return os.path.join(VARIANT_DIR, "libphaneron_hip_%s.so" % variant)
+
+
 def build(force=False, verbose=False, extra_flags=(), variant=None):
     """Compile every HIP source for gfx950 and link libphaneron_hip.so.  Returns its path.
-    variant: build lib/libphaneron_hip_<variant>.so with extra_flags (A/B experiments)."""
-    global LIB
-    lib = LIB if variant is None else os.path.join(LIB_DIR, "libphaneron_hip_%s.so" % variant)
+    variant: build tools/_variants/libphaneron_hip_<variant>.so with extra_flags (A/B experiments)."""
+    out_dir = LIB_DIR if variant is None else VARIANT_DIR
+    lib = LIB if variant is None else variant_path(variant)
     if variant is None and not force and not _stale():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(out_dir, exist_ok=True)
     cc = hipcc()
     objs, jobs = [], []
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     hdr_time = max(hdr_time, os.path.getmtime(os.path.abspath(__file__)))
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ("" if variant is None else "_" + variant) + ".o")
+        obj = os.path.join(out_dir, os.path.splitext(src)[0] + ("" if variant is None else "_" + variant) + ".o")
         objs.append(obj)
         # an object is rebuilt when its source, any header or this script is newer (force: always)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_time, os.path.getmtime(os.path.join(CSRC, src))):

@@ -31,7 +31,7 @@ EXPORTS = [
     "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
     "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy", "ph_queue_query",
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
-    "ph_program_resolve", "ph_fused_field_v210", "ph_route_unique_id", "ph_route_init", "ph_route_destroy", "ph_route_group_begin",
+    "ph_program_resolve", "ph_route_unique_id", "ph_route_init", "ph_route_destroy", "ph_route_group_begin",
     "ph_route_group_end", "ph_route_send", "ph_route_recv", "ph_route_after_queue", "ph_queue_after_route",
     "ph_route_wait", "ph_route_stream", "ph_route_comm_count", "ph_chan_compose_v210",
     "ph_v210_yadif_pair_fmt", "ph_compose_up_write_v210",
@@ -61,12 +61,6 @@ class PhLayerWipe(C.Structure):
 class PhDeintSource(C.Structure):
     _fields_ = [("prev", C.c_void_p), ("cur", C.c_void_p), ("next", C.c_void_p), ("out_parity0", C.c_void_p), ("out_parity1", C.c_void_p),
                 ("prev_u", C.c_void_p), ("prev_v", C.c_void_p), ("cur_u", C.c_void_p), ("cur_v", C.c_void_p), ("next_u", C.c_void_p), ("next_v", C.c_void_p)]
-
-
-class PhFieldLayer(C.Structure):
-    _fields_ = [("prev", C.c_void_p), ("cur", C.c_void_p), ("next", C.c_void_p), ("width", C.c_int), ("height", C.c_int),
-                ("matrix9", C.c_void_p), ("matrix9_host", C.POINTER(C.c_float)), ("deinterlace", C.c_int),
-                ("parity", C.c_int), ("tff", C.c_int), ("skip_spatial", C.c_int)]
 
 
 class PhChanSource(C.Structure):
@@ -191,7 +185,6 @@ def lib():
         "ph_pack_write": (ci, [vp, ci, ci, vp, C.POINTER(vp), cu, cu, cu, vp, vp]),
         "ph_compose_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), vp, cu, cu, cu, vp, vp]),
         "ph_compose_wipe_write_v210": (ci, [vp, ci, ci, C.POINTER(PhLayer), C.POINTER(PhLayerWipe), vp, cu, cu, cu, vp, vp]),
-        "ph_fused_field_v210": (ci, [vp, ci, ci, C.POINTER(PhFieldLayer), vp, cu, cu, vp, vp]),
         "ph_compose_up_write_v210": (ci, [vp, ci, ci, C.POINTER(PhImageLayer), vp, cu, cu, cu, vp, vp]),
         "ph_chan_compose_v210": (ci, [vp, ci, ci, C.POINTER(PhChanLayer), vp, cu, cu, cu, vp, vp, vp, vp, vp]),
         "ph_chan_compose": (ci, [vp, ci, ci, C.POINTER(PhChanLayer), ci, C.POINTER(C.c_void_p), cu, cu, cu, vp, vp, vp, vp, vp]),
@@ -576,23 +569,6 @@ class Context:
                 check(fn(*args), h)
             return job
         check(fn(*args), self.h)
-
-    def fused_field_v210(self, layers, dst, out_w, out_h, wr_cm, wr_lut, queue=QUEUE_PROCESS):
-        """layers: list of dicts {prev, cur, next (tensors; prev / next None for a progressive source), width, height,
-        matrix (device tensor), matrix_host (9 floats), deinterlace, parity, tff, skip_spatial}"""
-        arr = (PhFieldLayer * len(layers))()
-        keep = []
-        for i, L in enumerate(layers):
-            mh = (C.c_float * 9)(*[float(x) for x in L["matrix_host"]])
-            keep.append(mh)
-            arr[i].prev = _ptr(L["prev"]).value if L.get("prev") is not None else None
-            arr[i].cur = _ptr(L["cur"]).value
-            arr[i].next = _ptr(L["next"]).value if L.get("next") is not None else None
-            arr[i].width, arr[i].height = L["width"], L["height"]
-            arr[i].matrix9, arr[i].matrix9_host = _ptr(L["matrix"]).value, mh
-            arr[i].deinterlace = int(bool(L.get("deinterlace", True)))
-            arr[i].parity, arr[i].tff, arr[i].skip_spatial = int(L.get("parity", 0)), int(L.get("tff", 1)), int(bool(L.get("skip_spatial", False)))
-        check(lib().ph_fused_field_v210(self.h, queue, len(layers), arr, _ptr(dst), out_w, out_h, _ptr(wr_cm), _ptr(wr_lut)), self.h)
 
     def fused_v210_combine(self, layers, dst, width, height, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut,
                            queue=QUEUE_PROCESS):

@@ -71,8 +71,6 @@ struct ph_ctx {
   std::multimap<size_t, void *> host_pool;
   size_t host_pooled_bytes = 0;
   int host_pool_mb = 4096;  // what the pool may keep pinned
-  void *field_scratch = nullptr;  // index frame of the field pipeline (ph_fused_field_v210)
-  size_t field_scratch_bytes = 0;
   void *chan_index[3] = {nullptr, nullptr, nullptr};  // index frame of the channel compositor, one per queue (ph_chan_compose_v210)
   size_t chan_index_bytes[3] = {0, 0, 0};
   std::vector<struct ph_route *> routes;  // open ROUTEs: a recycled block must not be handed out under a transfer in flight
@@ -117,12 +115,18 @@ int set_device(ph_ctx *ctx) {
   return PH_OK;
 }
 
-// callers validate the index first (queue_ok): an out-of-range queue is an error, never a silent alias of PROCESS
-hipStream_t stream_of(ph_ctx *ctx, int queue) { return ctx->streams[(queue >= 0 && queue < 3) ? queue : PH_QUEUE_PROCESS]; }
 bool queue_ok(int queue) { return queue >= 0 && queue < 3; }
 int bad_queue(const char *fn, int queue) {
   return fail(PH_E_INVALID, "%s: queue %d is not PH_QUEUE_LOAD (0), PH_QUEUE_PROCESS (1) or PH_QUEUE_UNLOAD (2)", fn, queue);
 }
+// The stream behind a queue index.  There is no unchecked accessor: an out-of-range index makes the ENCLOSING entry point
+// return PH_E_INVALID here, whether or not it remembered PH_QUEUE() at its top - never a silent alias of the process queue.
+#define stream_of(ctx, queue)                                  \
+  ({                                                           \
+    const int ph_q_ = (queue);                                 \
+    if (!queue_ok(ph_q_)) return bad_queue(__func__, ph_q_);   \
+    (ctx)->streams[ph_q_];                                     \
+  })
 #define PH_QUEUE(fn, queue)                        \
   do {                                             \
     if (!queue_ok(queue)) return bad_queue(fn, queue); \
@@ -192,7 +196,6 @@ void ctx_unref(ph_ctx *ctx) {
   for (auto &kv : ctx->host_pool) hipHostFree(kv.second);
   for (auto &kv : ctx->luts)
     if (kv.second.blob_dev) hipFree(kv.second.blob_dev);
-  if (ctx->field_scratch) hipFree(ctx->field_scratch);
   for (int i = 0; i < 3; ++i)
     if (ctx->chan_index[i]) hipFree(ctx->chan_index[i]);
   delete ctx;
@@ -277,7 +280,7 @@ int ph_ctx_info(ph_ctx *ctx, char *vendor, size_t vlen, char *device, size_t dle
   return PH_OK;
 }
 
-void *ph_ctx_stream(ph_ctx *ctx, int queue) { return ctx && queue_ok(queue) ? (void *)stream_of(ctx, queue) : nullptr; }
+void *ph_ctx_stream(ph_ctx *ctx, int queue) { return ctx && queue_ok(queue) ? (void *)ctx->streams[queue] : nullptr; }
 
 int ph_wait_finish(ph_ctx *ctx, int queue) {
   if (!ctx) return fail(PH_E_INVALID, "ph_wait_finish: ctx is NULL");
@@ -921,7 +924,7 @@ static const ph::LutView *lds_view(ph_ctx *ctx, const void *dev) {
 // a ph_buf used as `gammaLut`: (re)compress from its host mirror if new data went in
 static void refresh_buf_lut(ph_ctx *ctx, ph_buf *b) {
   if (b->lut_dirty && b->hptr && b->bytes >= 65536 * 4) {
-    hipStreamSynchronize(stream_of(ctx, PH_QUEUE_LOAD));  // the mirror must be stable
+    hipStreamSynchronize(ctx->streams[PH_QUEUE_LOAD]);  // the mirror must be stable
     ph_lut_register(ctx, b->dptr, (const float *)b->hptr);
     b->lut_dirty = false;
   }
@@ -1788,62 +1791,6 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
   a.index = ctx->chan_index[queue];
   hipError_t e = ph::launch_chan_compose_v210(stream_of(ctx, queue), a, (uint32_t)ctx->props.multiProcessorCount);
   if (e != hipSuccess) return fail(PH_E_HIP, "ph_chan_compose_v210: launch failed: %s", hipGetErrorString(e));
-  return PH_OK;
-}
-
-int ph_fused_field_v210(ph_ctx *ctx, int queue, int n, const ph_field_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
-                        const void *wr_cm, const void *wr_lut) {
-  if (!ctx || !layers || !out || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_fused_field_v210: NULL argument");
-  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_fused_field_v210: 1..%d layers", ph::kMaxLayers);
-  if (!out_w || out_w % 192) return fail(PH_E_INVALID, "ph_fused_field_v210: width %u is not a multiple of 192; run the separate kernels", out_w);
-  const ph::LutView *wv = lds_view(ctx, wr_lut);
-  if (!wv) return fail(PH_E_INVALID, "ph_fused_field_v210: the writer gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)");
-  ph::FieldArgs a{};
-  a.n = n;
-  uint32_t need = 1, widest = 1;
-  for (int i = 0; i < n; ++i) {
-    const ph_field_layer &L = layers[i];
-    if (!L.cur || !L.matrix9 || !L.matrix9_host || L.width <= 0 || L.height <= 0)
-      return fail(PH_E_INVALID, "ph_fused_field_v210: layer %d is incomplete", i);
-    if (L.deinterlace && (!L.prev || !L.next)) return fail(PH_E_INVALID, "ph_fused_field_v210: layer %d de-interlaces but has no prev / next frame", i);
-    const float *m = L.matrix9_host;
-    if (m[1] != 0.0f || m[3] != 0.0f || !(m[0] > 0.0f) || !(m[4] > 0.0f))
-      return fail(PH_E_INVALID, "ph_fused_field_v210: layer %d is rotated or mirrored; run the separate kernels", i);
-    uint32_t wc = 0, wr = 0;
-    ph::field_window_extent(m, L.width, L.height, out_w, out_h, &wc, &wr);
-    const uint32_t px = wc * wr;
-    widest = wc > widest ? wc : widest;
-    if (px > 160u * 1024u / 16u)
-      return fail(PH_E_INVALID, "ph_fused_field_v210: layer %d is shrunk too far for the LDS window (%u pixels per slice); run the separate kernels", i, px);
-    need = px > need ? px : need;
-    a.prev[i] = L.prev, a.cur[i] = L.cur, a.next[i] = L.next, a.matrix[i] = (const float *)L.matrix9;
-    a.lw[i] = L.width, a.lh[i] = L.height, a.mode[i] = L.deinterlace ? 1 : 0;
-    a.parity[i] = L.parity ? 1 : 0, a.tff[i] = L.tff ? 1 : 0, a.skip[i] = L.skip_spatial ? 1 : 0;
-  }
-  a.out = out, a.out_w = out_w, a.out_h = out_h, a.window_capacity = need, a.window_max_width = widest;
-  a.wr_cm = (const float *)wr_cm, a.wr = *wv;
-  if (!out_h) return PH_OK;
-  // the index frame between the two stages (6 bytes per pixel): one per context, grown on demand.  Successive calls on
-  // different queues would share it - the field pipeline of a channel runs on one queue.
-  const size_t need_bytes = ph::field_index_bytes(out_w, out_h);
-  PH_QUEUE("ph_fused_field_v210", queue);
-  int rc = set_device(ctx);
-  if (rc) return rc;
-  // The scratch is grown, read and handed to the launch under the lock, so a concurrent call that grows it cannot free
-  // it between this call's check and its launch.  A growth drains all three queues first; launches on DIFFERENT queues
-  // would still share the one scratch on the device - the field pipeline of a channel runs on one queue (header).
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  if (ctx->field_scratch_bytes < need_bytes) {
-    if (ctx->field_scratch) {
-      for (int q = 0; q < 3; ++q) hipStreamSynchronize(ctx->streams[q]);
-      hipFree(ctx->field_scratch);
-      ctx->field_scratch = nullptr, ctx->field_scratch_bytes = 0;
-    }
-    PH_HIP(hipMalloc(&ctx->field_scratch, need_bytes));
-    ctx->field_scratch_bytes = need_bytes;
-  }
-  hipError_t e = ph::launch_field_compose_v210(stream_of(ctx, queue), a, ctx->field_scratch, (uint32_t)ctx->props.multiProcessorCount);
-  if (e != hipSuccess) return fail(PH_E_HIP, "ph_fused_field_v210: launch failed: %s", hipGetErrorString(e));
   return PH_OK;
 }
 

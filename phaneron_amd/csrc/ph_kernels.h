@@ -136,21 +136,6 @@ struct DeintArgs {  // ph_kernels_deint.hip
   const void *prev_u[kMaxLayers], *prev_v[kMaxLayers], *cur_u[kMaxLayers], *cur_v[kMaxLayers], *next_u[kMaxLayers], *next_v[kMaxLayers];
 };
 
-struct FieldArgs {  // ph_kernels_field.hip
-  const void *prev[kMaxLayers], *cur[kMaxLayers], *next[kMaxLayers];  // RGBA f32, lw x lh
-  const float *matrix[kMaxLayers];                                    // device 3x3 transform matrix
-  int lw[kMaxLayers], lh[kMaxLayers];
-  int mode[kMaxLayers];  // 0 = progressive (cur as it is), 1 = yadif
-  int parity[kMaxLayers], tff[kMaxLayers], skip[kMaxLayers];
-  int n;
-  void *out;
-  uint32_t out_w, out_h;
-  uint32_t window_capacity;   // pixels of LDS window per layer (>= every slice's need, host-checked)
-  uint32_t window_max_width;  // widest window of any layer, pixels
-  const float *wr_cm;
-  LutView wr;
-};
-
 struct CombineArgs {
   const void *layers[kMaxLayers];
   void *out;
@@ -187,10 +172,7 @@ hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32
 size_t chan_index_bytes(uint32_t out_w, uint32_t lines);
 hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t num_cus);
 bool compose_can_wipe(const ComposeArgs &a);  // the buffer-addressed compositor serves this job (needed for wipe layers)
-uint32_t field_index_bytes(uint32_t out_w, uint32_t out_h);  // scratch the two-stage field pipeline needs (6 bytes per pixel)
 hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t num_cus);
-hipError_t launch_field_compose_v210(hipStream_t s, const FieldArgs &a, void *index_scratch, uint32_t num_cus);
-void field_window_extent(const float m[6], int lw, int lh, uint32_t out_w, uint32_t out_h, uint32_t *cols, uint32_t *rows);
 hipError_t launch_yadif(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int parity,
                         int tff, int skip, void *out);
 hipError_t launch_yadif_pair(hipStream_t s, const void *prev, const void *cur, const void *next, int w, int h, int tff,

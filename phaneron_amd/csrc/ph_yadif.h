@@ -1,5 +1,5 @@
 // ph_yadif.h - the per-component yadif predictors, shared by the stand-alone yadif kernel (ph_kernels.hip), the fused
-// de-interlacing reader (ph_kernels_deint.hip) and the field pipeline (ph_kernels_field.hip).
+// de-interlacing reader (ph_kernels_deint.hip).
 //
 // yadif is FFmpeg's libavfilter/vf_yadif.c (filter_line_c): an edge-directed spatial interpolation between the lines
 // above and below, limited to a band around the temporal average whose width comes from how much the neighbouring

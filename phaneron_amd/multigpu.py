@@ -168,9 +168,10 @@ def frame_fingerprint(t):
     return int(((v * k).sum()).item())
 
 
-def timed_steps(step, steps: int, warmup: int, sync, dist=None, device=None) -> float:
+def timed_steps(step, steps: int, warmup: int, sync, dist=None, device=None, local: dict = None) -> float:
     """The bench timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by
-    barrier + device sync on both sides; returns the MAX elapsed seconds over ranks."""
+    barrier + device sync on both sides; returns the MAX elapsed seconds over ranks.  `local`, if given,
+    receives this rank's own elapsed seconds under "elapsed" (per-rank diagnostics)."""
     for i in range(warmup):
         step(i)
     sync()
@@ -182,6 +183,8 @@ def timed_steps(step, steps: int, warmup: int, sync, dist=None, device=None) -> 
         step(warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
+    if local is not None:
+        local["elapsed"] = elapsed
     if dist is not None:
         import torch
         dist.barrier()

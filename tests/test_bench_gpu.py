@@ -11,10 +11,10 @@ ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 pytestmark = pytest.mark.gpu
 
 
-def run(cmd, extra_env=None, timeout=600):
+def run(cmd, extra_env=None, timeout=600, rc=0):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **(extra_env or {}))
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert (r.returncode == 0) == (rc == 0), r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout   # exactly ONE JSON line, from rank 0
     return json.loads(lines[0])
@@ -33,6 +33,26 @@ def check_line(line, n_gpus, steps, warmup):
     # the kernel's own time (HIP events on its stream) can never exceed the wall clock per step
     assert rf["avg_launch_ms"] <= line["ms_per_step"] * 1.02
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / rf["avg_launch_ms"] / 1e6) < 0.01 * rf["achieved"]
+    # both clocks are in the line: SURVEY 8d's formula on `value`, and what separates the two
+    per_gpu_fps = line["value"] / n_gpus
+    frames_per_launch = max(line["config"].get("frames_per_launch", 1), 1)
+    assert abs(rf["frac_by_value"] - rf["algorithmic_bytes_per_launch"] / frames_per_launch * per_gpu_fps / 1e9 / rf["peak"]) < 2e-3
+    assert rf["frac_by_value"] <= rf["frac"] * 1.02
+    assert abs(rf["sync_overhead_us_per_step"] - 1e3 * (line["ms_per_step"] - rf["avg_launch_ms"])) < 0.5
+    assert ("sync_overhead_note" in rf) == (steps < 200)
+
+
+def check_per_rank(line, n_ranks):
+    """the N > 1 line says what every rank did"""
+    pr = line["per_rank"]
+    assert len(pr["frames_per_sec"]) == len(pr["avg_launch_ms"]) == len(pr["roofline_frac"]) == len(pr["elapsed_s"]) == n_ranks
+    assert pr["min"] == min(pr["frames_per_sec"]) and pr["max"] == max(pr["frames_per_sec"])
+    assert 0 <= pr["slowest_rank"] < n_ranks and pr["frames_per_sec"][pr["slowest_rank"]] == pr["min"]
+    assert pr["slowest_rank_avg_launch_ms"] == pr["avg_launch_ms"][pr["slowest_rank"]] > 0
+    assert all(0 < f < 1 for f in pr["roofline_frac"])
+    # value = all frames over the slowest rank's time: never more than the sum of the ranks' own rates
+    assert line["value"] <= sum(pr["frames_per_sec"]) * 1.001
+    assert abs(max(pr["elapsed_s"]) * 1e3 / line["steps"] - line["ms_per_step"]) < 0.02 * line["ms_per_step"]
 
 
 def test_default_line_as_the_driver_runs_it():
@@ -62,6 +82,7 @@ def test_rank_path_under_torchrun_with_rccl_on_one_gpu():
                 "--master-port", "29571", "bench.py", "--gpus", "1", "--steps", "30", "--warmup", "5", "--cpu-seconds", "0", "--no-secondary"],
                {"PH_BENCH_FORCE_DIST": "1", "PH_BENCH_ROUTE_HEIGHT": "540"})
     check_line(line, 1, 30, 5)
+    check_per_rank(line, 1)
     # the distributed path carries BASELINE config 5 in the same line: 2 channels per rank, every fourth layer routed
     # through ph_route_* (RCCL; with one rank the peer is the own rank), checked by fingerprint
     rt = line["route"]
@@ -78,14 +99,16 @@ def test_two_ranks_sum_their_frames():
                 "--master-port", "29572", "bench.py", "--gpus", "2", "--steps", "30", "--warmup", "5", "--width", "1920", "--height", "1080"],
                {"PH_BENCH_SHARE_GPU": "1"})
     check_line(line, 2, 30, 5)
+    check_per_rank(line, 2)
     assert line["cpu_baseline"] is None and "secondary" not in line
     assert line["config"]["channels"] == 2
 
 
 def test_a_stalled_route_does_not_cost_the_line():
-    """config 5 abandoned by the watchdog (limit set to nothing): rank 0 still prints the headline line, the failure recorded in it"""
+    """config 5 abandoned by the watchdog (limit set to nothing): rank 0 still prints the headline line, the failure recorded in
+    it - and the job ends with a non-zero exit code, so a hung RCCL group is not mistaken for a clean run"""
     line = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                 "--master-port", "29573", "bench.py", "--gpus", "1", "--steps", "30", "--warmup", "5", "--cpu-seconds", "0", "--no-secondary"],
-               {"PH_BENCH_FORCE_DIST": "1", "PH_BENCH_ROUTE_HEIGHT": "540", "PH_BENCH_ROUTE_TIMEOUT": "0.001"})
+               {"PH_BENCH_FORCE_DIST": "1", "PH_BENCH_ROUTE_HEIGHT": "540", "PH_BENCH_ROUTE_TIMEOUT": "0.001"}, rc=3)
     check_line(line, 1, 30, 5)
     assert "abandoned by the watchdog" in line["route"]["error"]

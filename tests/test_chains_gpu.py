@@ -120,12 +120,6 @@ def test_config3_chain_one_field_full_size(config3_sources, second_field, pip):
     out2 = _v210_out(OW, OH)
     k.compose_write_v210([(deint[l], SW, SH, dmats[l]) for l in range(4)], out2, OW, OH, 0, wcm, wlut)
     _bits_equal(hh.host(out2, np.uint32), want, "config 3, fused compositor")
-    # ---- device, fused field pipeline: yadif + transform + combine + write as ONE kernel (ph_fused_field_v210)
-    fl = [dict(prev=rgba_d[l][0], cur=rgba_d[l][1], next=rgba_d[l][2], width=SW, height=SH, matrix=dmats[l],
-               matrix_host=mats[l], deinterlace=True, parity=parity, tff=tff, skip_spatial=False) for l in range(4)]
-    out3 = _v210_out(OW, OH)
-    k.fused_field_v210(fl, out3, OW, OH, wcm, wlut)  # (a half-size inset of a 2x up-scale is a 1:1 window: still fits)
-    _bits_equal(hh.host(out3, np.uint32), want, "config 3, fused field pipeline")
 
 
 @pytest.mark.parametrize("tff", [1, 0])
@@ -155,58 +149,6 @@ def test_config3_deinterlacing_reader_full_size(config3_sources, tff):
         up_o = [orc.transform(deint_o[l][parity], orc.transform_matrix(OW, OH), OW, OH) for l in range(4)]
         want = orc.v210_write(orc.combine(up_o), OW, OH, 0, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
         _bits_equal(hh.host(out, np.uint32), want, "config 3 best route, parity %d tff %d" % (parity, tff))
-
-
-def test_fused_field_pipeline_mixed_layers_and_edges():
-    """ph_fused_field_v210 beyond config 3's shape: a progressive layer next to de-interlaced ones, both parities and
-    field orders, skip_spatial, a 1:1 layer, an up-scale with an offset (part of the layer off screen: border taps), an
-    output height that is not a multiple of the slice height - against ph_yadif + ph_transform + ph_combine +
-    ph_v210_write, which are pinned to the oracle."""
-    import torch
-    import hip_harness as hh
-    from phaneron_amd import capi
-    k = hh.ctx()
-    ow, oh = 768, 200
-    wcm, wlut = hh.ColourParams.writer("709")
-    specs = [  # (source w, h, transform kwargs, deinterlace, parity, tff, skip)
-        (768, 200, dict(), False, 0, 1, False),
-        (384, 100, dict(), True, 1, 1, False),
-        (384, 100, dict(scale_x=1.5, scale_y=1.5, offset_x=0.2, offset_y=-0.1), True, 0, 0, True),
-        (768, 200, dict(offset_x=-0.3, offset_y=0.25), True, 0, 1, False),
-    ]
-    layers, refs = [], []
-    for i, (w, h, kw, deint, parity, tff, skip) in enumerate(specs):
-        fr = [hh.dev(frames.rgba_random(w, h, 4100 + 10 * i + t)) for t in range(3)]
-        m = capi.transform_matrix(ow, oh, **kw)
-        dm = hh.dev(m)
-        layers.append(dict(prev=fr[0], cur=fr[1], next=fr[2], width=w, height=h, matrix=dm, matrix_host=m,
-                           deinterlace=deint, parity=parity, tff=tff, skip_spatial=skip))
-        src = fr[1]
-        if deint:
-            src = _img(w, h)
-            k.yadif(fr[0], fr[1], fr[2], src, w, h, parity, tff, skip)
-        placed = _img(ow, oh)
-        k.transform(src, w, h, dm, placed, ow, oh)
-        refs.append(placed)
-    for n in (1, 2, 4):
-        comb = refs[0]
-        if n > 1:
-            comb = _img(ow, oh)
-            k.combine(refs[:n], comb, ow, oh)
-        want = _v210_out(ow, oh)
-        k.v210_write(comb, want, ow, oh, 0, wcm, wlut)
-        got = _v210_out(ow, oh)
-        k.fused_field_v210(layers[:n], got, ow, oh, wcm, wlut)
-        _bits_equal(hh.host(got, np.uint32), hh.host(want, np.uint32), "fused field pipeline, %d layer(s)" % n)
-    tiny = capi.transform_matrix(ow, oh, scale_x=0.2, scale_y=0.2)  # a 768-wide source shown 154 wide: 5 source pixels per output pixel
-    with pytest.raises(capi.PhaneronError, match="shrunk too far"):
-        k.fused_field_v210([dict(layers[0], matrix=hh.dev(tiny), matrix_host=tiny)], _v210_out(ow, oh), ow, oh, wcm, wlut)
-    rot = dict(layers[1], matrix_host=capi.transform_matrix(ow, oh, rotate=0.1))
-    with pytest.raises(capi.PhaneronError, match="rotated or mirrored"):
-        k.fused_field_v210([rot], _v210_out(ow, oh), ow, oh, wcm, wlut)
-    with pytest.raises(capi.PhaneronError, match="multiple of 192"):
-        k.fused_field_v210(layers[:1], _v210_out(624, oh), 624, oh, wcm, wlut)
-    del torch
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -157,3 +157,28 @@ def test_bench_gpus_flag_plans_one_rank_per_gpu():
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3"], env=env, capture_output=True, text=True)
         assert r.returncode != 0 and "only 0 GPU(s) are visible" in r.stderr
+
+
+def test_bench_plan_carries_every_flag_into_the_spawned_command():
+    """`python bench.py --gpus N --plan` (no GPU needed): the self-spawned torch.distributed.run command is one process per
+    GPU on one node, rendezvous on 127.0.0.1, and hands --steps / --warmup (and every other flag) through to the ranks"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "37", "--warmup", "9", "--no-route", "--plan"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    assert plan["mode"] == "spawn" and plan["world"] == 8 and plan["ranks"] == list(range(8))
+    cmd = plan["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(os.path.join(root, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "37", "--warmup", "9", "--no-route"]  # --plan itself is not passed on
+    # started by a launcher (WORLD_SIZE set) the same script is a rank and must agree with --gpus
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--plan"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="8", RANK="3"), timeout=120)
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    assert plan == {"mode": "rank", "world": 8, "rank": 3, "gpus_flag_matches": False}

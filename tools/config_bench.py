@@ -248,21 +248,6 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
             ctx.combine(up, comb3, ow, oh)
             ctx.v210_write(comb3, out, ow, oh, 0, *wr)
 
-        def config3_field(i):  # yadif + upscale + combine_4 over LDS-staged scanline windows as ONE kernel, then index -> v210
-            parity = new_frames(i)
-            ctx.fused_field_v210([dict(prev=win[l][0], cur=win[l][1], next=win[l][2], width=sw, height=sh, matrix=m, matrix_host=mh,
-                                       deinterlace=True, parity=parity, tff=1) for l in range(4)], out, ow, oh, *wr)
-
-        def config3_windows(i):  # yadif per layer, then the windowed upscale + combine kernel on the de-interlaced frames
-            parity = new_frames(i)
-            for l in range(4):
-                ctx.yadif(win[l][0], win[l][1], win[l][2], deint[l], sw, sh, parity, 1, False)
-            ctx.fused_field_v210([dict(cur=deint[l], width=sw, height=sh, matrix=m, matrix_host=mh, deinterlace=False) for l in range(4)],
-                                 out, ow, oh, *wr)
-
-        record(name3, "field pipeline (ph_fused_field_v210): read x4 every other field, [yadif x4 + transform x4 + combine_4] over LDS "
-               "windows, [index -> v210]", "field", timeit(config3_field, reps), algo3, 4)
-        record(name3, "yadif x4, then ph_fused_field_v210 on the de-interlaced frames", "field", timeit(config3_windows, reps), algo3, 8)
         record(name3, "one kernel per operator (the reference's job batch)", "field", timeit(config3, reps), algo3, 12)
     return out_records
 

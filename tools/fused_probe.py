@@ -16,7 +16,7 @@ from phaneron_amd import build  # noqa: E402
 # WRONG results, timing only) to see what the VALU stream costs on its own
 ablate = os.environ.get("PH_PROBE_ABLATE", "")
 variant = "probe" + ablate
-lib_path = os.path.join(ROOT, "phaneron_amd", "lib", "libphaneron_hip_%s.so" % variant)
+lib_path = build.variant_path(variant)
 if not os.path.exists(lib_path) or "--build" in sys.argv:
     build.build(variant=variant, extra_flags=["-DPH_PROBE=1"] + (["-DPH_ABLATE=" + ablate] if ablate else []))
 if "--build-only" in sys.argv:
