@@ -34,7 +34,24 @@
 // context.  Own design; nothing of this exists in the reference, whose OpenCL queue runs every job as posted.
 
 const OUTPUT_ARG = /^(output|l\d+Out)/
+const isOutputArg = (name) => { const c = name.charCodeAt(0); return (c === 111 || c === 108) && OUTPUT_ARG.test(name) } // 'o' | 'l'
 const ZERO_TIMINGS = () => ({ dataToKernel: 0, kernelExec: 0, totalTime: 0 })
+// Jobs that write EVERY byte of their output (a frame-sized operator, a progressive `write`): a pending producer of that buffer
+// can be dropped unseen.  Anything else - a field `write`, a program this layer does not know - may fill only part of it: the
+// producer runs first (ADVICE r3).
+const WHOLE_OUTPUT = /^(read|write|yadif|transform|resize|combine_\d+|transition_dissolve|transition_wipe|mixer|wipe)$/
+// parameter names of the fused programs, made once: `${prefix}${suffix}` per source (l0, l0Incoming, l0Mask ...)
+const SOURCE_KEYS = new Map()
+const sourceKeys = (prefix) => {
+	let k = SOURCE_KEYS.get(prefix)
+	if (!k) SOURCE_KEYS.set(prefix, (k = { In: `${prefix}In`, Packing: `${prefix}Packing`, InU: `${prefix}InU`, InV: `${prefix}InV`, ColMatrix: `${prefix}ColMatrix`,
+		Matrix: `${prefix}Matrix`, Width: `${prefix}Width`, Height: `${prefix}Height`, Transition: `${prefix}Transition`, Mix: `${prefix}Mix` }))
+	return k
+}
+const LAYER_PREFIX = [0, 1, 2, 3, 4, 5, 6, 7].map((i) => `l${i}`)
+const LAYER_INCOMING = LAYER_PREFIX.map((p) => `${p}Incoming`)
+const LAYER_MASK = LAYER_PREFIX.map((p) => `${p}Mask`)
+const pushNew = (list, v) => { if (!list.includes(v)) list.push(v) }
 
 class Deferral {
 	constructor(ctx) {
@@ -48,11 +65,13 @@ class Deferral {
 	}
 
 	// ---- bookkeeping on buffers -----------------------------------------------------------------------------
+	// (plain assignments: Object.defineProperty is a runtime call per field and buffer - a fifth of the recording's host time was here)
 	static adopt(buf) {
-		if (buf._readers) return
-		Object.defineProperty(buf, '_readers', { value: new Set(), enumerable: false })
-		Object.defineProperty(buf, '_producer', { value: null, enumerable: false, writable: true })
-		Object.defineProperty(buf, '_held', { value: 0, enumerable: false, writable: true })
+		if (buf._readers !== undefined) return
+		buf._readers = new Set() // pending nodes that read the buffer
+		buf._producer = null // the pending node that will write it
+		buf._held = 0 // recorded nodes that hold it (ONE native reference stands for all of them: _hold)
+		buf._failed = null // the error of the job that should have produced it (ADVICE r3: every later consumer sees it, not only the first)
 	}
 	// two parameter buffers that hold the same bytes (every producer's Loader makes its own LUT and matrices: loadSave.ts:50-99);
 	// the host mirror is what hostAccess wrote, its digest is dropped when the buffer is written again (touch)
@@ -60,40 +79,50 @@ class Deferral {
 		if (a === b) return true
 		if (!a || !b || a.length !== b.length) return false
 		for (const x of [a, b])
-			if (!x._digest) Object.defineProperty(x, '_digest', { value: require('crypto').createHash('sha1').update(x).digest('hex'), enumerable: false, configurable: true, writable: true })
+			if (!x._digest) x._digest = require('crypto').createHash('sha1').update(x).digest('hex')
 		return a._digest === b._digest
 	}
 	static sameRecipe(r, q) { return Deferral.same(r.colMatrix, q.colMatrix) && Deferral.same(r.gammaLut, q.gammaLut) && Deferral.same(r.gamutMatrix, q.gamutMatrix) }
-	_hold(buf) { this.ctx._native.bufAddRef(buf._handle); buf._held++ }
-	_unhold(buf) { buf._held--; this.ctx._native.bufRelease(buf._handle) }
-	_appRefs(buf) { return this.ctx._native.bufRefCount(buf._handle) - buf._held }
+	// The recorded nodes' hold on a buffer is ONE native reference however many nodes hold it (29 addRef + 34 release calls into the
+	// addon per 4-layer frame before; now one pair per buffer)
+	_hold(buf) { if (buf._held++ === 0) this.ctx._native.bufAddRef(buf._handle) }
+	_unhold(buf) { if (--buf._held === 0) this.ctx._native.bufRelease(buf._handle) }
+	_appRefs(buf) { return this.ctx._native.bufRefCount(buf._handle) - (buf._held > 0 ? 1 : 0) }
 
 	// ---- recording --------------------------------------------------------------------------------------------
 	record(program, params, queue) {
-		const ins = new Set()
-		const outs = new Set()
-		for (const name of Object.keys(params)) {
-			const v = params[name]
+		const ins = []
+		const outs = []
+		const names = Object.keys(params)
+		for (let k = 0; k < names.length; ++k) {
+			const v = params[names[k]]
 			if (!Buffer.isBuffer(v)) continue
-			if (!v._handle) throw new Error(`runProgram: parameter '${name}' is a plain Buffer, not an OpenCLBuffer`)
+			if (!v._handle) throw new Error(`runProgram: parameter '${names[k]}' is a plain Buffer, not an OpenCLBuffer`)
 			Deferral.adopt(v)
-			if (OUTPUT_ARG.test(name)) outs.add(v); else ins.add(v)
+			pushNew(isOutputArg(names[k]) ? outs : ins, v)
 		}
 		// what runProgram would refuse - a missing argument, a buffer too small for the frame - is refused here, with the same
-		// message, where the reference awaits it (clJobQueue.ts:126); nothing is enqueued (ph_check_program)
-		this._launch(program, params, queue, true)
-		const node = { program, params: Object.assign({}, params), queue, ins: Array.from(ins), outs: Array.from(outs), state: 'pending' }
-		for (const b of new Set([...ins, ...outs])) this._hold(b)
-		for (const i of node.ins) i._readers.add(node)
-		// a buffer this job overwrites: whoever still wants its present (or pending) contents goes first.  A pending
-		// producer is run too when the new job fills only part of the buffer (an interlaced `write`: every other line)
-		const whole = !(program.name === 'write' && params.interlace) // a field write leaves the other field's lines as they are
-		for (const o of node.outs) {
-			for (const r of Array.from(o._readers)) if (r !== node) this._run(r)
+		// message, where the reference awaits it (clJobQueue.ts:126); nothing is enqueued (ph_check_program).  A job that looks
+		// exactly like the last one this program accepted (names, buffer sizes and image dimensions, scalars, queue) is not asked again.
+		if (!this._sameAsChecked(program, names, params, queue)) {
+			this._launch(program, params, queue, true)
+			program._checked = this._signature(names, params, queue)
+		}
+		const node = { program, params: Object.assign({}, params), queue, ins, outs, state: 'pending' }
+		for (let k = 0; k < ins.length; ++k) { this._hold(ins[k]); ins[k]._readers.add(node) }
+		for (let k = 0; k < outs.length; ++k) if (!ins.includes(outs[k])) this._hold(outs[k])
+		// a buffer this job overwrites: whoever still wants its present (or pending) contents goes first.  A pending producer is
+		// dropped unseen only if this job is known to write the WHOLE buffer; a job that fills part of it (an interlaced `write`:
+		// every other line) or a program this layer does not know runs the producer first
+		const whole = WHOLE_OUTPUT.test(program.name) && !params.interlace
+		for (let k = 0; k < outs.length; ++k) {
+			const o = outs[k]
+			if (o._readers.size) for (const r of Array.from(o._readers)) if (r !== node) this._run(r)
 			const p = o._producer
-			if (p && whole && p.outs.length === 1 && !node.ins.includes(o)) { this.stats.dropped++; this._retire(p, 'dropped') } // its result would be overwritten unseen
+			if (p && whole && p.outs.length === 1 && !ins.includes(o)) { this.stats.dropped++; this._retire(p, 'dropped') } // its result would be overwritten unseen
 			else if (p) this._run(p)
 			o._producer = node
+			o._failed = null
 		}
 		if (Deferral._isV210(program, 'read') && params.colMatrix && params.gammaLut && params.gamutMatrix)
 			this.lastReader = { colMatrix: params.colMatrix, gammaLut: params.gammaLut, gamutMatrix: params.gamutMatrix }
@@ -101,16 +130,41 @@ class Deferral {
 		this.stats.recorded++
 		return ZERO_TIMINGS()
 	}
+	// what ph_check_program looks at, as a flat list: the names in order, per buffer its size and image dimensions, the scalars
+	_signature(names, params, queue) {
+		const sig = [queue, names.length]
+		for (let k = 0; k < names.length; ++k) {
+			const v = params[names[k]]
+			sig.push(names[k])
+			if (Buffer.isBuffer(v)) sig.push(v.length, v.imageDims ? v.imageDims.width : 0, v.imageDims ? v.imageDims.height : 0)
+			else sig.push(v === undefined || v === null ? null : typeof v === 'boolean' ? (v ? 1 : 0) : v, -1, -1)
+		}
+		return sig
+	}
+	_sameAsChecked(program, names, params, queue) {
+		const sig = program._checked
+		if (!sig || sig[0] !== queue || sig[1] !== names.length) return false
+		for (let k = 0, j = 2; k < names.length; ++k, j += 4) {
+			const v = params[names[k]]
+			if (sig[j] !== names[k]) return false
+			if (Buffer.isBuffer(v)) {
+				if (sig[j + 1] !== v.length || sig[j + 2] !== (v.imageDims ? v.imageDims.width : 0) || sig[j + 3] !== (v.imageDims ? v.imageDims.height : 0)) return false
+			} else if (sig[j + 2] !== -1 || sig[j + 1] !== (v === undefined || v === null ? null : typeof v === 'boolean' ? (v ? 1 : 0) : v)) return false
+		}
+		return true
+	}
 
 	// the node has run, or will never have to: take it out of the graph and let go of its buffers
 	_retire(node, state) {
 		node.state = state
 		this.pending.delete(node)
-		for (const o of node.outs) if (o._producer === node) o._producer = null
-		for (const i of node.ins) i._readers.delete(node)
+		const { ins, outs } = node
+		for (let k = 0; k < outs.length; ++k) if (outs[k]._producer === node) outs[k]._producer = null
+		for (let k = 0; k < ins.length; ++k) ins[k]._readers.delete(node)
 		// operands that are recipes themselves go with it if nobody else can ask for them (we still hold them here)
-		for (const i of node.ins) this._reap(i)
-		for (const b of new Set([...node.ins, ...node.outs])) this._unhold(b)
+		for (let k = 0; k < ins.length; ++k) this._reap(ins[k])
+		for (let k = 0; k < ins.length; ++k) this._unhold(ins[k])
+		for (let k = 0; k < outs.length; ++k) if (!ins.includes(outs[k])) this._unhold(outs[k])
 	}
 	// a recipe nobody can ask for any more: none of its outputs has a pending reader or a reference outside the recording
 	_reap(buf) {
@@ -136,6 +190,7 @@ class Deferral {
 			if (buf._digest) buf._digest = null
 			this.beforeWrite(buf)
 			if (buf._producer) this.force(buf) // (a recorded result the host overwrites: run it rather than reason about partial writes)
+			buf._failed = null
 		}
 		for (const [q, epoch] of this.launchedOn) {
 			if (q === queue) continue
@@ -153,8 +208,11 @@ class Deferral {
 		for (const r of Array.from(buf._readers)) this._run(r)
 	}
 	// make the buffer's contents real
+	// (a buffer whose producer FAILED stays failed until somebody writes it again: every consumer gets the error, not only
+	// the one whose request happened to run the job)
 	force(buf) {
 		if (buf._producer) this._run(buf._producer)
+		if (buf._failed) throw buf._failed
 	}
 	// whatever is still recorded runs (clContext.flushDeferred; recipes whose images nobody holds were dropped already)
 	forceAll() {
@@ -198,13 +256,18 @@ class Deferral {
 		}
 	}
 	_plain(node) {
-		for (const i of node.ins) if (i._producer && i._producer !== node) this.force(i) // (an in-place job is its own operand's producer)
+		let failure = null
 		try {
+			for (const i of node.ins) {
+				if (i._producer && i._producer !== node) this.force(i) // (an in-place job is its own operand's producer)
+				else if (i._failed) throw i._failed
+			}
 			this._launch(node.program, node.params, node.queue)
-		} finally {
-			this.stats.plain++
-			this._retire(node, 'done')
-		}
+		} catch (e) { failure = e }
+		this.stats.plain++
+		if (failure) for (const o of node.outs) o._failed = failure // whoever asks for them later is told, too
+		this._retire(node, failure ? 'error' : 'done')
+		if (failure) throw failure
 	}
 
 	// ---- the fused shapes -------------------------------------------------------------------------------------
@@ -241,6 +304,10 @@ class Deferral {
 			const q = p.params
 			const planes = fmt === 'v210' ? [q.input] : [q.inputY, q.inputU, q.inputV]
 			if (planes.some((b) => !b)) return null
+			// a frame that is itself the pending result of a recorded job (a packed frame made on the device and read back) is made
+			// real first: the fused launch reads the planes, not the images (ADVICE r3)
+			for (const b of planes) if (b._producer || b._failed) this.force(b)
+			if (p.state !== 'pending') return null
 			const f = Deferral._frameOf(p)
 			if (f.width !== w || f.lines !== h || !img.imageDims || img.imageDims.width !== w || img.imageDims.height !== h) return null
 			if (!Deferral.sameRecipe(reader, q)) return null
@@ -259,6 +326,7 @@ class Deferral {
 			if (!reader.colMatrix || !reader.gammaLut || !reader.gamutMatrix || w % (fmt === 'v210' ? 6 : 2)) continue
 			const src = [framesOf(prev, w, h, reader, fmt), framesOf(cur, w, h, reader, fmt), framesOf(next, w, h, reader, fmt)]
 			if (src.includes(null)) continue
+			if (p.state !== 'pending' || [prev, cur, next].some((im) => !im._producer || im._producer.state !== 'pending')) continue // (forcing a plane ran one of them)
 			// the other field of the same window
 			let twin = null
 			for (const r of cur._readers)
@@ -338,6 +406,10 @@ class Deferral {
 		const used = new Set() // pending nodes the fused launch stands in for
 		const sameSize = (img) => img.imageDims && img.imageDims.width === width && img.imageDims.height === height
 		const materialised = (img) => { this.force(img); return img.imageDims ? { source: img } : null }
+		// a wire-format plane the fused launch will read directly: if it is itself the pending result of a recorded job (a packed frame
+		// made on the device and read back: write -> read), that job runs first - the launch reads the plane, not the image (ADVICE r3).
+		// Whatever that ran is caught by the `used` re-check below.
+		const realPlanes = (...planes) => { for (const b of planes) if (b && (b._producer || b._failed)) this.force(b) }
 		const plainSource = (img) => { // an image as a sampled source: a pending ToRGBA of a wire-format frame, or the image itself
 			const p = img._producer
 			// v210 (SDI), or a planar frame as file decoders hand them over (ffmpegProducer.ts:398-412)
@@ -348,6 +420,7 @@ class Deferral {
 				const ok = q.input && q.gammaLut && q.gamutMatrix && img.imageDims && f.width === img.imageDims.width && f.lines === img.imageDims.height &&
 					(!reader || (Deferral.same(reader.gammaLut, q.gammaLut) && Deferral.same(reader.gamutMatrix, q.gamutMatrix)))
 				if (ok) {
+					realPlanes(q.input)
 					reader = reader || { colMatrix: null, gammaLut: q.gammaLut, gamutMatrix: q.gamutMatrix }
 					used.add(p)
 					return { source: q.input, packing: RGB8[fmt], width: f.width, height: f.lines, v210: true, planar: true, rgb8: true }
@@ -357,12 +430,13 @@ class Deferral {
 				const r = { colMatrix: p.params.colMatrix, gammaLut: p.params.gammaLut, gamutMatrix: p.params.gamutMatrix }
 				const f = Deferral._frameOf(p)
 				const q = p.params
-				const planes = fmt === 'v210' ? q.input && f.width % 6 === 0
+				const planes = fmt === 'v210' ? q.input && f.width % 2 === 0 // (a line with a tail - 1280 - is the channel kernel's general instantiation)
 					: q.inputY && (fmt === 'nv12' ? q.inputC : q.inputU && q.inputV) && f.width % 2 === 0 && (fmt === 'yuv422p10' || fmt === 'yuv422p8' || f.lines % 2 === 0)
 				const ok = r.colMatrix && r.gammaLut && r.gamutMatrix && planes && img.imageDims && f.width === img.imageDims.width && f.lines === img.imageDims.height &&
 					(!reader || (Deferral.same(reader.gammaLut, r.gammaLut) && Deferral.same(reader.gamutMatrix, r.gamutMatrix))) &&
 					(fmt !== 'v210' || !packedCm || Deferral.same(packedCm, r.colMatrix))
 				if (ok) {
+					realPlanes(q.input, q.inputY, q.inputU, q.inputV, q.inputC)
 					if (!reader) reader = r
 					else if (!reader.colMatrix) reader.colMatrix = r.colMatrix
 					if (fmt === 'v210') packedCm = packedCm || r.colMatrix
@@ -433,23 +507,26 @@ class Deferral {
 		if (loader) {
 			const params = Object.assign({ output, interlace }, loader, saver)
 			const put = (prefix, s) => {
-				params[`${prefix}In`] = s.source
-				if (s.planar) params[`${prefix}Packing`] = s.packing
+				const key = sourceKeys(prefix)
+				params[key.In] = s.source
+				if (s.planar) params[key.Packing] = s.packing
 				if (s.planar && !s.rgb8) {
-					params[`${prefix}InU`] = s.u
-					if (s.v) params[`${prefix}InV`] = s.v
-					if (!Deferral.same(s.cm, loader.colMatrix)) params[`${prefix}ColMatrix`] = s.cm
+					params[key.InU] = s.u
+					if (s.v) params[key.InV] = s.v
+					if (!Deferral.same(s.cm, loader.colMatrix)) params[key.ColMatrix] = s.cm
 				}
-				if (s.matrix) params[`${prefix}Matrix`] = s.matrix
-				if (s.v210) { params[`${prefix}Width`] = s.width; params[`${prefix}Height`] = s.height }
+				if (s.matrix) params[key.Matrix] = s.matrix
+				if (s.v210) { params[key.Width] = s.width; params[key.Height] = s.height }
 			}
 			layers.forEach((l, i) => {
-				put(`l${i}`, l)
+				const li = LAYER_PREFIX[i]
+				put(li, l)
 				if (l.transition) {
-					params[`l${i}Transition`] = l.transition.wipe ? 2 : 1
-					if (!l.transition.wipe) params[`l${i}Mix`] = l.transition.mix
-					put(`l${i}Incoming`, l.transition.incoming)
-					if (l.transition.wipe) put(`l${i}Mask`, l.transition.mask)
+					const key = sourceKeys(li)
+					params[key.Transition] = l.transition.wipe ? 2 : 1
+					if (!l.transition.wipe) params[key.Mix] = l.transition.mix
+					put(LAYER_INCOMING[i], l.transition.incoming)
+					if (l.transition.wipe) put(LAYER_MASK[i], l.transition.mask)
 				}
 			})
 			candidates.push([`chan_compose_v210_${n}`, params])

@@ -23,38 +23,48 @@ const ACCESS = { readonly: 0, writeonly: 1, readwrite: 2 }
 const SVM = { none: 0, coarse: 1, fine: 2 }
 const HOSTDIR = { readonly: 0, writeonly: 1, none: 2 }
 
-// Decorate the node Buffer the addon returned (pinned host mirror of the device buffer) with
-// the OpenCLBuffer members the reference uses.
+// Decorate the node Buffer the addon returned (pinned host mirror of the device buffer) with the OpenCLBuffer members the
+// reference uses.  The methods are shared functions on `this` and the fields plain assignments: the reference makes a fresh
+// destination per job and frame (io.ts:64-72), and five closures plus an Object.defineProperty per buffer showed in the profile
+// of the recording context (node/test/defer_host_bench.js).
+function hostAccess(dir, queue, src) {
+	if (!(dir in HOSTDIR)) return Promise.reject(new Error(`hostAccess: unknown direction '${dir}'`))
+	if (Buffer.isBuffer(queue)) { src = queue; queue = 0 } // hostAccess(dir, src)
+	if (this._deferral) {
+		try {
+			this._deferral.touch(this, dir, queue || 0)
+		} catch (e) { return Promise.reject(e) }
+	}
+	return this._native.hostAccess(this._handle, HOSTDIR[dir], queue || 0, src)
+}
+function addRef() { this._native.bufAddRef(this._handle) }
+// deferred contexts: recorded jobs hold ONE reference of their own while any of them needs the buffer (buf._held counts the jobs);
+// the owner sees only its own
+function release() { this._native.bufRelease(this._handle); if (this._deferral && this._held) this._deferral.released(this) }
+function refCount() { return this._native.bufRefCount(this._handle) - (this._held > 0 ? 1 : 0) }
+// staging extension (not nodencl): device -> mirror on `queue` without a host wait; the bytes are
+// valid after waitFinish(queue) or after an event recorded behind it has been awaited
+function downloadAsync(queue) {
+	if (this._deferral) this._deferral.touch(this, 'readonly', queue === undefined ? 2 : queue)
+	return this._native.downloadAsync(this._handle, queue === undefined ? 2 : queue)
+}
 function makeOpenCLBuffer(native, created, numBytes, imageDims, owner, deferral) {
 	const buf = created.buffer
-	const handle = created.handle
-	Object.defineProperty(buf, '_handle', { value: handle, enumerable: false })
+	buf._handle = created.handle
+	buf._native = native
+	buf._deferral = deferral
 	buf.numBytes = numBytes
 	buf.owner = owner || ''
 	buf.imageDims = imageDims
 	buf.timestamp = 0
 	buf.loadstamp = 0
 	buf.creationTime = process.hrtime()
-	buf.hostAccess = (dir, queue, src) => {
-		if (!(dir in HOSTDIR)) return Promise.reject(new Error(`hostAccess: unknown direction '${dir}'`))
-		if (Buffer.isBuffer(queue)) { src = queue; queue = 0 } // hostAccess(dir, src)
-		if (deferral) {
-			try {
-				deferral.touch(buf, dir, queue || 0)
-			} catch (e) { return Promise.reject(e) }
-		}
-		return native.hostAccess(handle, HOSTDIR[dir], queue || 0, src)
-	}
-	buf.addRef = () => { native.bufAddRef(handle) }
-	// deferred contexts: recorded jobs hold references of their own (buf._held); the owner sees only its own
-	buf.release = () => { native.bufRelease(handle); if (deferral && buf._held) deferral.released(buf) }
-	buf.refCount = () => native.bufRefCount(handle) - (buf._held || 0)
-	// staging extension (not nodencl): device -> mirror on `queue` without a host wait; the bytes are
-	// valid after waitFinish(queue) or after an event recorded behind it has been awaited
-	buf.downloadAsync = (queue) => {
-		if (deferral) deferral.touch(buf, 'readonly', queue === undefined ? 2 : queue)
-		return native.downloadAsync(handle, queue === undefined ? 2 : queue)
-	}
+	buf.hostAccess = hostAccess
+	buf.addRef = addRef
+	buf.release = release
+	buf.refCount = refCount
+	buf.downloadAsync = downloadAsync
+	if (deferral) Deferral.adopt(buf)
 	return buf
 }
 
@@ -73,13 +83,14 @@ class clContext {
 		// code that constructs the context itself (src/index.ts:94-107)
 		this.deferred = params.deferred === undefined ? process.env.PHANERON_DEFERRED === '1' : !!params.deferred
 		this._deferral = null
+		this._addon = params.addon || null // tests: a stand-in for the N-API addon (node/test/defer_host_bench.js counts the calls the JS layer makes)
 		this.queue = this.overlapping ? { load: 0, process: 1, unload: 2 } : { load: 1, process: 1, unload: 1 }
 		this._ctx = null
 		this._native = null
 	}
 
 	async initialise() {
-		this._native = loadAddon()
+		this._native = this._addon || loadAddon()
 		this._ctx = this._native.createContext(this.deviceIndex)
 		if (this.deferred) this._deferral = new Deferral(this)
 	}

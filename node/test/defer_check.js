@@ -40,7 +40,7 @@ function rig() {
 		b.owner = owner || ''
 		b.release = () => { native.bufRelease(h); if (b._held) d.released(b) }
 		b.alive = () => refs.get(h) > 0
-		b.appRefs = () => refs.get(h) - (b._held || 0)
+		b.appRefs = () => refs.get(h) - (b._held > 0 ? 1 : 0)
 		return b
 	}
 	const W = 96
@@ -181,6 +181,81 @@ function rig() {
 	r.d.touch(outs[1], 'readonly', 2)
 	expect('refused fused launches: the jobs as recorded', r.names().slice(2), ['transform', 'write'])
 	expect('fallbacks counted', r.d.stats.fallbacks, 2)
+}
+
+// 6. a packed frame made on the device and read back (write -> read -> write): the fused launch reads `mid` itself, so the job
+//    that makes `mid` runs first (ADVICE r3: it used to stay pending, and `out` was computed from an unwritten buffer)
+{
+	const r = rig()
+	const L = r.loader()
+	const s0 = r.v210('s0')
+	const a = r.image('a')
+	const mid = r.v210('mid')
+	const b = r.image('b')
+	const out = r.v210('out')
+	r.d.record(r.P.read, Object.assign({ input: s0, output: a, width: r.W }, L), 1)
+	r.d.record(r.P.write, Object.assign({ input: a, output: mid, width: r.W, interlace: 0 }, r.saver), 1)
+	r.d.record(r.P.read, Object.assign({ input: mid, output: b, width: r.W }, L), 1)
+	r.d.record(r.P.write, Object.assign({ input: b, output: out, width: r.W, interlace: 0 }, r.saver), 1)
+	r.d.touch(out, 'readonly', 2)
+	expect('the frame in the middle is made first, then read back', r.launches.map((l) => [l[0], /l0In/.test(l[2])]), [['fused_v210_combine_1', true], ['fused_v210_combine_1', true]])
+	expect('nothing is left pending but the recipes of images their owners still hold', r.d.pending.size, 2)
+	;[s0, a, mid, b, out].forEach((x) => x.release())
+	expect('and those go with their owners', r.d.pending.size, 0)
+	// the same through the de-interlacing reader: a window frame that is a pending packed result
+	const r2 = rig()
+	const L2 = r2.loader()
+	const pre = r2.image('pre')
+	const packed = r2.v210('packed')
+	r2.d.record(r2.P.read, Object.assign({ input: r2.v210('s'), output: pre, width: r2.W }, L2), 1)
+	r2.d.record(r2.P.write, Object.assign({ input: pre, output: packed, width: r2.W, interlace: 0 }, r2.saver), 1)
+	const win = [r2.v210('w0'), packed, r2.v210('w2')].map((src, i) => { const im = r2.image(`u${i}`); r2.d.record(r2.P.read, Object.assign({ input: src, output: im, width: r2.W }, L2), 1); return im })
+	const m = r2.buffer(48, undefined, 'matrix')
+	const outs = []
+	for (const parity of [0, 1]) {
+		const y = r2.image(`y${parity}`)
+		r2.d.record(r2.P.yadif, { prev: win[0], cur: win[1], next: win[2], parity, tff: 1, skipSpatial: 0, output: y }, 1)
+		const t = r2.image(`t${parity}`)
+		r2.d.record(r2.P.transform, { input: y, transformMatrix: m, output: t }, 1)
+		const o = r2.v210(`o${parity}`)
+		r2.d.record(r2.P.write, Object.assign({ input: t, output: o, width: r2.W, interlace: 0 }, r2.saver), 1)
+		outs.push(o)
+	}
+	r2.d.touch(outs[0], 'readonly', 2)
+	expect('a window frame that is a pending result is made before the pair launch reads it', r2.names(), ['fused_v210_combine_1', 'v210_yadif_pair_1', 'compose_up_write_v210_1'])
+}
+
+// 7. a job that fails is not forgotten: every later consumer of its output is told, until somebody writes the buffer again;
+//    a job that may fill only PART of a buffer never drops the pending producer of the rest
+{
+	const r = rig()
+	const L = r.loader()
+	const u = r.image('u')
+	const t1 = r.image('t1')
+	const t2 = r.image('t2')
+	const m = r.buffer(48, undefined, 'matrix')
+	r.d.record(r.P.read, Object.assign({ input: r.v210('s'), output: u, width: r.W }, L), 1)
+	r.d.record(r.P.transform, { input: u, transformMatrix: m, output: t1 }, 1)
+	r.d.record(r.P.other, { input: u, output: t2 }, 1)
+	r.native.refuse = (name) => name === 'read'
+	const caught = []
+	for (const b of [t1, t2, u]) { try { r.d.touch(b, 'readonly', 2); caught.push(null) } catch (e) { caught.push(String(e.message)) } }
+	expect('the failed read is reported to each of its consumers, and to whoever asks for its own output', caught, ['read: refused', 'read: refused', 'read: refused'])
+	expect('and nothing of it was launched', r.names(), [])
+	r.native.refuse = null
+	r.d.record(r.P.read, Object.assign({ input: r.v210('s2'), output: u, width: r.W }, L), 1)
+	r.d.touch(u, 'readonly', 2)
+	expect('a new job into the buffer clears the failure', r.names(), ['read'])
+
+	const r2 = rig()
+	const L2 = r2.loader()
+	const frame = r2.image('frame')
+	const partial = Object.assign({}, r2.P.other, { name: 'paint_region' }) // a program this layer does not know: it may write part of its output
+	r2.d.record(r2.P.read, Object.assign({ input: r2.v210('s'), output: frame, width: r2.W }, L2), 1)
+	r2.d.record(partial, { input: r2.image('logo'), output: frame }, 1)
+	expect('an unknown program over a pending result: the producer runs first, it is not dropped', [r2.names(), r2.d.stats.dropped], [['read'], 0])
+	r2.d.record(r2.P.read, Object.assign({ input: r2.v210('s3'), output: frame, width: r2.W }, L2), 1)
+	expect('a whole-frame operator over it: the superseded job is dropped unseen', [r2.names(), r2.d.stats.dropped], [['read'], 1])
 }
 
 process.stdout.write(JSON.stringify({ checks, problems }) + '\n')

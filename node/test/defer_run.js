@@ -493,6 +493,72 @@ async function main() {
 		return seen
 	}, { fused: 6, plain: 0, launched: 6, fallbacks: 0 })
 
+	// a packed frame made on the device and unpacked again (a channel whose consumer's frame feeds another channel's producer):
+	// write -> read -> write.  The second frame's fused launch reads `mid` itself, so the job that makes `mid` must run first
+	await scenario('a packed frame made on the device and read back: write -> read -> write', async (s) => {
+		s.frame = 12
+		const a = await s.source(v210Frame(full, 1200))
+		const b = await s.source(v210Frame(full, 1201))
+		const ua = await s.rig.image(W, H)
+		const ub = await s.rig.image(W, H)
+		await s.rig.run(s.read([a], ua))
+		await s.rig.run(s.read([b], ub))
+		const comb = await s.rig.image(W, H)
+		await s.rig.run(s.combine[2]([ua, ub], comb))
+		const mid = (await s.rig.planes('v210', W, H, 'readwrite'))[0]
+		await s.rig.run(s.write(comb, [mid], 0))
+		const um = await s.rig.image(W, H)
+		await s.rig.run(s.read([mid], um))
+		const pm = await s.rig.image(W, H)
+		await s.rig.run(s.transform(um, pm, await s.transform.matrix(PIP[1])))
+		const comb2 = await s.rig.image(W, H)
+		await s.rig.run(s.combine[2]([ua, pm], comb2))
+		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		await s.rig.run(s.write(comb2, [out], 0))
+		const seen = [await s.consume(out), await s.consume(mid)]
+		;[a, b, ua, ub, comb, mid, um, pm, comb2, out].forEach((x) => x.release())
+		return seen
+	}, { fused: 2, plain: 0, launched: 2, fallbacks: 0 })
+
+	// 720p50, the reference's third format (src/config.ts:43-54): 1280 % 48 = 32 - every line ends in a tail quad and cleared slots
+	if (W === 384) {
+		const w7 = 1280
+		const h7 = 24
+		await scenario('a 1280-wide channel: tails in every read and in the write', async (s) => {
+			s.frame = 13
+			const read7 = await s.rig.unpack('v210', w7, h7, '709', '709')
+			const write7 = await s.rig.pack('v210', w7, h7, '709', false)
+			const combine7 = await s.rig.combine(3, w7, h7)
+			const transform7 = await s.rig.transform(w7, h7)
+			const srcs = []
+			for (let l = 0; l < 3; ++l) srcs.push(await s.source(v210Frame(v210Bytes(w7, h7), 1300 + l, l !== 1), w7, h7))
+			const placed = []
+			for (let l = 0; l < 3; ++l) {
+				const u = await s.rig.image(w7, h7)
+				await s.rig.run(read7([srcs[l]], u))
+				const p = await s.rig.image(w7, h7)
+				await s.rig.run(transform7(u, p, await transform7.matrix(PIP[l])))
+				u.release()
+				placed.push(p)
+			}
+			const comb = await s.rig.image(w7, h7)
+			await s.rig.run(combine7(placed, comb))
+			const out = (await s.rig.planes('v210', w7, h7, 'writeonly'))[0]
+			await s.rig.run(write7(comb, [out], 0))
+			const seen = [await s.consume(out)]
+			// and the headline's shape at that width: plain reads, no placement
+			const plain = []
+			for (let l = 0; l < 3; ++l) { const u = await s.rig.image(w7, h7); await s.rig.run(read7([srcs[l]], u)); plain.push(u) }
+			const comb2 = await s.rig.image(w7, h7)
+			await s.rig.run(combine7(plain, comb2))
+			const out2 = (await s.rig.planes('v210', w7, h7, 'writeonly'))[0]
+			await s.rig.run(write7(comb2, [out2], 0))
+			seen.push(await s.consume(out2))
+			;[...srcs, ...placed, comb, out, ...plain, comb2, out2].forEach((x) => x.release())
+			return seen
+		}, { fused: 2, plain: 0, launched: 2, fallbacks: 0 })
+	}
+
 	process.stdout.write(JSON.stringify({ width: W, height: H, scenarios, problems }) + '\n')
 }
 main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })

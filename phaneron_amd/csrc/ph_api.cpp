@@ -1532,7 +1532,10 @@ int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *laye
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_fused_v210_combine: 1..%d layers", ph::kMaxLayers);
   if (!layers || !out || !rd_cm || !rd_lut || !rd_gm || !wr_cm || !wr_lut || !width)
     return fail(PH_E_INVALID, "ph_fused_v210_combine: NULL/zero argument");
-  if (width % 48) return fail(PH_E_INVALID, "ph_fused_v210_combine: width %u is not a multiple of 48; run the separate kernels", width);
+  // (a width that is not a multiple of 48 - 1280 x 720, src/config.ts:43-54 - has lines that end in a tail quad and cleared slots:
+  // the LDS kernel's TAIL instantiation; the reference's kernels serve tails of 2 or 4 pixels, v210.ts:84-110,166-193)
+  const bool ragged = width % 48 != 0;
+  if (width & 1) return fail(PH_E_INVALID, "ph_fused_v210_combine: width %u is odd; run the separate kernels", width);
   if (!height) return PH_OK;
   ph::FusedArgs a{};
   for (int i = 0; i < n; ++i) {
@@ -1542,7 +1545,10 @@ int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *laye
   a.out = out;
   a.quads_per_line_used = width / 6;
   a.quads_per_line_pitch = ph::v210_pitch_bytes(width) / 16;
-  a.total_quads = a.quads_per_line_used * height;
+  a.total_quads = (ragged ? a.quads_per_line_pitch : a.quads_per_line_used) * height;
+  a.tail_px = width % 6, a.magic_qpp = (uint32_t)(((1ull << 32) + a.quads_per_line_pitch - 1) / a.quads_per_line_pitch);
+  if (ragged && (uint64_t)a.total_quads * a.quads_per_line_pitch >= (1ull << 32))  // the kernel's slot -> column division by reciprocal
+    return fail(PH_E_INVALID, "ph_fused_v210_combine: a %u x %u frame with ragged lines is too large; run the separate kernels", width, height);
   a.rd_cm = (const float *)rd_cm, a.rd_lut = (const float *)rd_lut, a.rd_gm = (const float *)rd_gm;
   a.wr_cm = (const float *)wr_cm, a.wr_lut = (const float *)wr_lut;
   if (ctx) {
@@ -1697,8 +1703,10 @@ static int chan_source(const ph_chan_source &s, const char *what, int layer, uin
       return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is planar: it needs its chroma plane(s), an even width and, for 4:2:0, an even height", layer, what);
     *pu = s.data_u, *pv = s.data_v, *cm = (const float *)s.col_matrix12, *planar = 1;
   }
-  if (s.format == PH_SRC_V210 && s.width % 6)
-    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is a v210 frame %d wide, not a multiple of 6; run the separate kernels", layer, what, s.width);
+  // (the reference's v210 reader serves tails of 2 or 4 pixels: v210.ts:84-110)
+  if (s.format == PH_SRC_V210 && (s.width & 1))
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is a v210 frame %d wide, an odd width; run the separate kernels", layer, what, s.width);
+  if (s.format == PH_SRC_V210 && s.width % 6) *planar = 1;  // a line with a tail: the kernel's general instantiation
   if (!s.matrix9_host && ((uint32_t)s.width != out_w || (uint32_t)s.height != out_h))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has no transform but is %dx%d, not the output size", layer, what, s.width, s.height);
   o->ptr = s.data, o->w = (uint32_t)s.width, o->h = (uint32_t)s.height;
@@ -1711,6 +1719,7 @@ static int chan_source(const ph_chan_source &s, const char *what, int layer, uin
   if ((uint64_t)o->pitch * o->h >= (1ull << 30))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is 1 GiB or larger; run the separate kernels", layer, what);
   o->sampled = s.matrix9_host ? 1u : 0u;
+  o->tail_from = (uint32_t)s.width - (uint32_t)s.width % 6u;
   for (int i = 0; i < 6; ++i) o->m[i] = s.matrix9_host ? s.matrix9_host[i] : 0.0f;
   return PH_OK;
 }
@@ -1734,8 +1743,11 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
   if (out_planar && (!out_planes[1] || !out_planes[2])) return fail(PH_E_INVALID, "ph_chan_compose_v210: a planar output needs its three planes");
   PH_QUEUE("ph_chan_compose_v210", queue);
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_chan_compose_v210: 1..%d layers", ph::kMaxLayers);
-  // (a v210 line of a width that is not a multiple of 48 ends in a padded block the reference's writer addresses by width: DESIGN.md section 2)
-  if (!out_w || out_w % 48) return fail(PH_E_INVALID, "ph_chan_compose_v210: width %u is not a multiple of 48; run the separate kernels", out_w);
+  // A v210 line of a width that is not a multiple of 48 (1280 x 720, src/config.ts:43-54) ends in a padded block: whole quads, the
+  // tail quad with the reference's tail arithmetic (v210.ts:166-193), cleared slots - lines addressed by pitch.
+  // The planar writers here take whole groups of eight pixels; rgba8 / bgra8 any width.
+  if (!out_w || (out_format == PH_FMT_V210 && (out_w & 1)) || (out_planar && out_w % 8))
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: width %u (a v210 frame needs an even width, a planar one a multiple of 8); run the separate kernels", out_w);
   if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_chan_compose_v210: interlace must be 0, 1 or 3");
   const ph::LutView *rv = lds_view(ctx, rd_lut), *wv = lds_view(ctx, wr_lut);
   if (!rv || !wv)
@@ -1772,7 +1784,13 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
   a.lines = interlace ? out_h / 2 : out_h;
   a.rd_cm = (const float *)rd_cm, a.rd_gm = (const float *)rd_gm, a.wr_cm = (const float *)(wr_cm ? wr_cm : rd_cm), a.rd = *rv, a.wr = *wv;
   a.out_fmt = (uint32_t)out_format, a.out_u = out_planes[1], a.out_v = out_planes[2];
-  a.out_pitch = out_w;  // planar: width rounded up to 8 samples (yuv422p10.ts:221) - widths here are multiples of 48; rgba8: no padding
+  a.out_pitch = out_w;  // planar: width rounded up to 8 samples (yuv422p10.ts:221) - widths here are multiples of 8; rgba8: no padding
+  a.out_qpitch = ph_v210_pitch_bytes(out_w) / 16u;
+  a.out_tail_from = 0xFFFFFFFFu;
+  if (out_format == PH_FMT_V210 && out_w % 48) {
+    a.planar = 1;  // the general instantiation writes lines that end in a tail / cleared slots
+    if (out_w % 6) a.out_tail_from = out_w - out_w % 6u;
+  }
   if (!a.lines) return PH_OK;
   int rc = set_device(ctx);
   if (rc) return rc;

@@ -26,6 +26,9 @@ struct FusedArgs {
   uint32_t quads_per_line_pitch;  // pitch bytes / 16
   uint32_t total_quads;           // quads_per_line_used * height
   const float *rd_cm, *rd_lut, *rd_gm, *wr_cm, *wr_lut;
+  // widths that are not a multiple of 48 (the LDS kernel's TAIL instantiation only): total_quads counts the quad SLOTS of the
+  // pitch, a line is quads_per_line_used whole quads, then - if tail_px (2 or 4) - the tail quad, then cleared slots
+  uint32_t tail_px, magic_qpp;  // width % 6; ceil(2^32 / quads_per_line_pitch)
 };
 
 constexpr int kMaxBatch = 8;
@@ -64,7 +67,7 @@ struct ChanSrc {
   uint32_t w, h, pitch;  // pixels, pixels, bytes per line
   uint32_t kind;         // kChanV210 / kChanRgba / a planar kind (kChanNone: absent)
   uint32_t sampled;      // 1 = through m (transform.ts:53-57), 0 = pixel for pixel
-  uint32_t pad;
+  uint32_t tail_from;    // v210: the first column of the line's tail, 6 * (w / 6) (== w when the width is a multiple of 6: no tail)
   float m[6];            // rows 0 and 1 of the 3x3 transform matrix
 };
 // The channel's frame as a flat program the kernel walks per pixel: one op per source to sample, with what to do with
@@ -95,6 +98,9 @@ struct ChanArgs {
   // samples per line), 5 rgba8 / 6 bgra8 (out; out_pitch = pixels per line) - PH_FMT_* numbering
   uint32_t out_fmt, out_pitch;
   void *out_u, *out_v;
+  // v210 frames of any even width (1280: src/config.ts:43-54): quad slots per line by pitch, and the first column of the line's
+  // tail (v210.ts:166-193; 0xFFFFFFFF when the width is a multiple of 6 or the frame is not v210)
+  uint32_t out_qpitch, out_tail_from;
 };
 
 // ph_kernels_up.hip: the 2 x 2-block compositor for magnifying placements

@@ -170,8 +170,18 @@ __global__ __launch_bounds__(kBlock) void fused_v210_combine_kernel(FusedArgs a)
   const WriteK wk = load_write_k(a.wr_cm);
   const uint32_t f = blockIdx.x * kBlock + threadIdx.x;
   if (f >= a.total_quads) return;
-  const uint32_t line = f / a.quads_per_line_used, g = f - line * a.quads_per_line_used;
+  // Lines that do not end on a 48-pixel block (total_quads then counts the slots of the pitch): whole quads, the tail quad
+  // (read with the fourth vector component 0, v210.ts:88-93; written with the tail arithmetic, :169-194), cleared slots (:131-136)
+  const bool ragged = a.quads_per_line_used != a.quads_per_line_pitch;  // uniform
+  const uint32_t per_line = ragged ? a.quads_per_line_pitch : a.quads_per_line_used;
+  const uint32_t line = f / per_line, g = f - line * per_line;
   const size_t off = (size_t)line * a.quads_per_line_pitch + g;
+  const bool in_tail = ragged && g == a.quads_per_line_used && a.tail_px;
+  if (ragged && g >= a.quads_per_line_used && !in_tail) {
+    store_stream(reinterpret_cast<uint4 *>(a.out) + off, make_uint4(0u, 0u, 0u, 0u));
+    return;
+  }
+  const float last = in_tail ? 0.0f : 1.0f;
 
   uint4 w[N];
 #pragma unroll
@@ -181,20 +191,34 @@ __global__ __launch_bounds__(kBlock) void fused_v210_combine_kernel(FusedArgs a)
   {
     const Yuv6 q = unpack_quad(w[0]);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) acc[j] = read_px(q.y[j], q.cb[j >> 1], q.cr[j >> 1], 1.0f, rk, a.rd_lut);
+    for (int j = 0; j < 6; ++j) acc[j] = read_px(q.y[j], q.cb[j >> 1], q.cr[j >> 1], last, rk, a.rd_lut);
   }
 #pragma unroll
   for (int l = 1; l < N; ++l) {  // combine.ts:45-65: premultiplied "over", alpha = top layer's
     const Yuv6 q = unpack_quad(w[l]);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const float4 t = read_px(q.y[j], q.cb[j >> 1], q.cr[j >> 1], 1.0f, rk, a.rd_lut);
+      const float4 t = read_px(q.y[j], q.cb[j >> 1], q.cr[j >> 1], last, rk, a.rd_lut);
       const float kk = 1.0f - t.w;
       acc[j].x = fma_rn(acc[j].x, kk, t.x);
       acc[j].y = fma_rn(acc[j].y, kk, t.y);
       acc[j].z = fma_rn(acc[j].z, kk, t.z);
       acc[j].w = fma_rn(acc[j].w, 0.0f, t.w);
     }
+  }
+  if (in_tail) {
+    Yuv1 c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = write_px_tail(acc[j].x, acc[j].y, acc[j].z, wk, a.wr_lut);
+    uint4 o = make_uint4(c[0].v << 20 | c[0].y << 10 | c[0].u, 0u, 0u, 0u);
+    if (a.tail_px == 2u) {
+      o.y = c[1].y;
+    } else if (a.tail_px == 4u) {
+      o.y = c[2].y << 20 | c[2].u << 10 | c[1].y;
+      o.z = c[3].y << 10 | c[2].v;
+    }
+    store_stream(reinterpret_cast<uint4 *>(a.out) + off, o);
+    return;
   }
   uint32_t y[6], u[3], v[3];
 #pragma unroll

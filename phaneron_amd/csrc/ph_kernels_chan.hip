@@ -118,11 +118,11 @@ __device__ __forceinline__ V210Words v210_load(__amdgpu_buffer_rsrc_t rs, uint32
                    (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(base + c.cro), 0, 0)};
 }
 template <bool STD>
-__device__ __forceinline__ PxPending v210_issue(const V210Words &w, const V210Col &c, const ReadK &k, const LutK &lut) {
+__device__ __forceinline__ PxPending v210_issue(const V210Words &w, const V210Col &c, const ReadK &k, const LutK &lut, float last = 1.0f) {
   const float y = (float)__builtin_amdgcn_ubfe(w.wy, c.ys, 10u);
   const float cb = (float)__builtin_amdgcn_ubfe(w.wcb, c.cbs, 10u);
   const float cr = (float)__builtin_amdgcn_ubfe(w.wcr, c.crs, 10u);
-  return read_px_issue<STD>(y, cb, cr, k, lut);
+  return read_px_issue<STD>(y, cb, cr, k, lut, last);
 }
 __device__ __forceinline__ float4 rgba_load(__amdgpu_buffer_rsrc_t img, uint32_t off) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -300,10 +300,14 @@ __device__ __forceinline__ void chan_sample_rgb8(const ChanSrc &s, float px, con
 }
 
 // the source's samples for the lane's pixels (x, line[p]): 1:1, or through the transform matrix and the bilinear filter
-template <bool STD>
+// TAILS: v210 sources may have a width that is not a multiple of 6 (1280 x 720).  The pixels of such a line's tail are unpacked from
+// the same bit positions, but the reference's reader converts them without the matrix's offset column (v210.ts:88-93, `last` of
+// read_px_issue): a tap in a column >= tail_from passes 0.  (The other instantiation has no such sources: the launcher sees to it.)
+template <bool STD, bool TAILS>
 __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const float (&py)[kChanP], uint32_t x, const uint32_t (&line)[kChanP],
                                             const ReadK &k, const LutK &lut, float4 (&out)[kChanP]) {
   const bool is_v210 = s.kind == kChanV210;  // uniform
+  auto last_of = [&](uint32_t column) __attribute__((always_inline)) { return TAILS ? (column < s.tail_from ? 1.0f : 0.0f) : 1.0f; };
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(s.pitch * s.h), 0x00020000);
   if (!s.sampled) {  // uniform: the source has the output's size, pixel for pixel
     if (is_v210) {
@@ -313,7 +317,7 @@ __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const fl
       for (int p = 0; p < kChanP; ++p) w[p] = v210_load(rs, __umul24(line[p], s.pitch) + c.g16, c);
       PxPending pend[kChanP];
 #pragma unroll
-      for (int p = 0; p < kChanP; ++p) pend[p] = v210_issue<STD>(w[p], c, k, lut);
+      for (int p = 0; p < kChanP; ++p) pend[p] = v210_issue<STD>(w[p], c, k, lut, last_of(x));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < kChanP; ++p) out[p] = read_px_finish(pend[p], k);
@@ -362,11 +366,14 @@ __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const fl
         in[p] |= (base < kOutsideBit ? 1u : 0u) << i;
       }
     }
+    float last[kChanP][2];
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) last[p][0] = last_of(t[p].i0), last[p][1] = last_of(t[p].i0 + 1u);
     // one pixel's taps are converted together: 24 table reads in flight before the first is consumed
     {
       PxPending pend[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pend[i] = v210_issue<STD>(w[0][i], col[0][i & 1], k, lut);
+      for (int i = 0; i < 4; ++i) pend[i] = v210_issue<STD>(w[0][i], col[0][i & 1], k, lut, last[0][i & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) tap[0][i] = read_px_finish(pend[i], k);
@@ -374,7 +381,7 @@ __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const fl
     if (stacked) {
       PxPending pend[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) pend[i] = v210_issue<STD>(w[1][2 + i], col[1][i], k, lut);
+      for (int i = 0; i < 2; ++i) pend[i] = v210_issue<STD>(w[1][2 + i], col[1][i], k, lut, last[1][i]);
       __builtin_amdgcn_sched_barrier(0);
       tap[1][0] = tap[0][2], tap[1][1] = tap[0][3];
 #pragma unroll
@@ -382,7 +389,7 @@ __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const fl
     } else {
       PxPending pend[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pend[i] = v210_issue<STD>(w[1][i], col[1][i & 1], k, lut);
+      for (int i = 0; i < 4; ++i) pend[i] = v210_issue<STD>(w[1][i], col[1][i & 1], k, lut, last[1][i & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) tap[1][i] = read_px_finish(pend[i], k);
@@ -542,16 +549,20 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
         if (cm) chan_sample_planar<false>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, load_read_k(cm, a.rd_gm), rlut, v);
         else chan_sample_planar<STD>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, rk, rlut, v);
       } else {
-        chan_sample<STD>(op.src, px, py, x, line, rk, rlut, v);
+        chan_sample<STD, PLANAR>(op.src, px, py, x, line, rk, rlut, v);
       }
 #pragma unroll
       for (int p = 0; p < kChanP; ++p) chan_apply(op, v[p], acc[p]);
     }
     // the writer's first step needs no table (v210.ts:148-150): park the three 16-bit indices
+    // (in the tail of a v210 line whose width is not a multiple of 6 the writer truncates its index: v210.ts:176-178)
+    const bool trunc_idx = PLANAR && x >= a.out_tail_from;
 #pragma unroll
     for (int p = 0; p < kChanP; ++p) {
-      const uint32_t ir = __float_as_uint(lds_lut_index_unit(acc[p].r)) & 0xFFFFu, ig = __float_as_uint(lds_lut_index_unit(acc[p].g)) & 0xFFFFu;
-      const uint32_t ib = __float_as_uint(lds_lut_index_unit(acc[p].b)) & 0xFFFFu;
+      auto index_of = [&](float t) __attribute__((always_inline)) {
+        return __float_as_uint(PLANAR ? lds_lut_index_unit_tail(t, trunc_idx) : lds_lut_index_unit(t)) & 0xFFFFu;
+      };
+      const uint32_t ir = index_of(acc[p].r), ig = index_of(acc[p].g), ib = index_of(acc[p].b);
       if (x < a.out_w) index[li[p] * a.out_w + x] = make_uint2(ir | (ig << 16), ib);  // (lanes beyond a short last chunk have nothing to park)
     }
   }
@@ -658,7 +669,9 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
     return;
   }
   // phase 2: one quad per lane.  The indices were written by other waves of THIS workgroup: read past the L1.
-  const uint32_t qpl = a.out_w / 6;
+  // A line has out_qpitch quad slots.  Widths that are multiples of 48 fill them all; otherwise (the wire-format instantiation
+  // only) `full` whole quads are followed by the tail quad (v210.ts:169-194) and by slots the reference's writer clears (:131-136).
+  const uint32_t qpl = a.out_qpitch, full = a.out_w / 6u, remain = a.out_w - 6u * full;
   const uint4 *const index = reinterpret_cast<const uint4 *>(a.index);
   for (uint32_t q = threadIdx.x; q < 64u * sh.slots; q += kLdsBlock) {
     const uint32_t chunk = chan_chunk(a, sh, q >> 6);
@@ -666,7 +679,14 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
     uint32_t rp, x0;
     chan_place(a, sh, chunk, rp, x0);
     const uint32_t li = 2u * rp + ((q >> 5) & 1u);  // quads 0..31 of a chunk: its upper row, 32..63: its lower row
-    if (li >= a.lines || x0 + (q & 31u) * 6u >= a.out_w) continue;
+    const uint32_t g = x0 / 6u + (q & 31u);
+    if (li >= a.lines || g >= qpl) continue;
+    const uint32_t line = a.first_line + li * a.line_step;
+    uint4 *const dst = reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + g;
+    if (PLANAR && g > full - (remain ? 0u : 1u)) {  // past the line's pixels
+      store_stream(dst, make_uint4(0u, 0u, 0u, 0u));
+      continue;
+    }
     const uint32_t first_px = li * a.out_w + x0 + (q & 31u) * 6u;
     const uint4 w0 = load_stream(index + (first_px >> 1)), w1 = load_stream(index + (first_px >> 1) + 1), w2 = load_stream(index + (first_px >> 1) + 2);
     const uint32_t pk[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
@@ -677,13 +697,13 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
       yi[3 * j + 1] = __uint_as_float((pk[2 * j] >> 16) | 0x4B400000u);
       yi[3 * j + 2] = __uint_as_float((pk[2 * j + 1] & 0xFFFFu) | 0x4B400000u);
     }
-    const uint32_t line = a.first_line + li * a.line_step;
-    store_stream(reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + (x0 / 6u) + (q & 31u), write_quad_idx_lds(yi, wk, wlut));
+    if (PLANAR && g == full) store_stream(dst, write_quad_idx_lds_tail(yi, wk, wlut, remain));  // (the index frame is padded: the tail's loads stay inside)
+    else store_stream(dst, write_quad_idx_lds(yi, wk, wlut));
   }
   PH_CPHASE(5);
 }
 
-size_t chan_index_bytes(uint32_t out_w, uint32_t lines) { return (size_t)out_w * lines * 8u; }
+size_t chan_index_bytes(uint32_t out_w, uint32_t lines) { return (size_t)out_w * lines * 8u + 64u; }  // + a tail quad's reach past the last line
 
 hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t num_cus) {
   if (!a.lines) return hipSuccess;

@@ -95,8 +95,13 @@ __device__ __forceinline__ uint4 write_quad_lds(const float (&rgb)[18], const Wr
 #ifndef PH_FUSED_SPLIT
 #define PH_FUSED_SPLIT 0
 #endif
-template <int N, int P, int BS, bool PIPE = false, int MODE = 0>
+// TAIL: lines that do not end on a 48-pixel block (1280 x 720, src/config.ts:43-54).  The flat index then runs over the quad SLOTS
+// of the pitch - the layers' words and the output's are at the same offsets - and a lane's slot is a whole quad, the line's tail
+// quad (its 2 or 4 pixels read without the matrix's offset column, v210.ts:88-93, written from truncated indices with round(),
+// :169-194) or a slot the reference's writer clears (:131-136).  The other instantiation is the same code as before.
+template <int N, int P, int BS, bool PIPE = false, int MODE = 0, bool TAIL = false>
 __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs a, uint32_t *handoff = nullptr) {
+  static_assert(!TAIL || (!PIPE && MODE == 0), "the tail instantiation exists for the shipped form only");
   const ReadK rk = load_read_k(a.f.rd_cm, a.f.rd_gm);
   const WriteK wk = load_write_k(a.f.wr_cm);
   const LutK rlut = make_lut_k(a.rd), wlut = make_lut_k(a.wr);
@@ -127,7 +132,14 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
     // packed.  Takes the slice's layer-0 word and returns the next slice's (prefetch chain).  A
     // generic lambda instantiated for both matrix shapes; everything it touches stays in registers
     // (a by-reference `w` or argument struct ends up in scratch).
+    // slot f of a TAIL frame: 0 = a whole quad, 1 = the line's tail quad, 2 = past the line's pixels
+    auto slot_kind = [&](uint32_t f) -> uint32_t {
+      const uint32_t g = f - __umulhi(f, a.f.magic_qpp) * a.f.quads_per_line_pitch;
+      return g < a.f.quads_per_line_used ? 0u : (g == a.f.quads_per_line_used && a.f.tail_px) ? 1u : 2u;
+    };
     auto phase1_slice = [&](auto tag, uint4 w, uint32_t f, uint32_t f_next, bool more, uint32_t(&st)[9]) -> uint4 {
+      const bool in_tail = TAIL && slot_kind(f) == 1u;
+      const float last = TAIL ? (in_tail ? 0.0f : 1.0f) : 1.0f;
       float acc[18];
 #pragma unroll
       for (int i = 0; i < 18; ++i) acc[i] = 0.0f;
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
         const Yuv6 q = unpack_quad(w);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-          const float4 t = read_px_lds<decltype(tag)::value>(q.y[j], q.cb[j >> 1], q.cr[j >> 1], rk, rlut);
+          const float4 t = read_px_lds<decltype(tag)::value>(q.y[j], q.cb[j >> 1], q.cr[j >> 1], rk, rlut, last);
           // acc starts at 0, so layer 0 goes through the same fma: fma(0, k, t) == t, and the
           // sign of a zero can never reach the packed output (combine.ts:45-65 for l >= 1)
           const float kk = 1.0f - t.w;
@@ -156,8 +168,8 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
       // here and keep only the 16-bit indices, two per register (v_perm_b32)
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
-        const uint32_t lo = __float_as_uint(lds_lut_index_unit(acc[2 * i]));
-        const uint32_t hi = __float_as_uint(lds_lut_index_unit(acc[2 * i + 1]));
+        const uint32_t lo = __float_as_uint(TAIL ? lds_lut_index_unit_tail(acc[2 * i], in_tail) : lds_lut_index_unit(acc[2 * i]));
+        const uint32_t hi = __float_as_uint(TAIL ? lds_lut_index_unit_tail(acc[2 * i + 1], in_tail) : lds_lut_index_unit(acc[2 * i + 1]));
         st[i] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
         // Pin the packed state here.  Without a pin LLVM sinks the whole decode / gamut / combine
         // arithmetic to its first use in phase 2 (past the barrier and the table swap) and keeps
@@ -339,7 +351,15 @@ __global__ __launch_bounds__(BS) void fused_v210_combine_lds_kernel(FusedLdsArgs
           yi[2 * i] = __uint_as_float((st[p][i] & 0xFFFFu) | 0x4B400000u);
           yi[2 * i + 1] = __uint_as_float((st[p][i] >> 16) | 0x4B400000u);
         }
-        const uint4 packed = write_quad_idx_lds(yi, wk, wlut);
+        uint4 packed;
+        if (TAIL) {
+          const uint32_t kind = slot_kind(f < wg_end ? f : wg_end - 1);
+          if (kind == 0u) packed = write_quad_idx_lds(yi, wk, wlut);
+          else if (kind == 1u) packed = write_quad_idx_lds_tail(yi, wk, wlut, a.f.tail_px);
+          else packed = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+          packed = write_quad_idx_lds(yi, wk, wlut);
+        }
         if (f < wg_end) store_stream(out_ptr + f, packed);
       }
     }
@@ -904,7 +924,7 @@ static hipError_t launch_fused_half(hipStream_t s, FusedLdsArgs b, uint32_t lds)
 }
 #endif
 
-template <int N, int P, int BS, bool PIPE = false>
+template <int N, int P, int BS, bool PIPE = false, bool TAIL = false>
 static hipError_t launch_fused_npb(hipStream_t s, const FusedLdsArgs &a, uint32_t grid_in, uint32_t lds) {
   uint32_t grid = grid_in;
 #if PH_FUSED_SPLIT
@@ -914,7 +934,7 @@ static hipError_t launch_fused_npb(hipStream_t s, const FusedLdsArgs &a, uint32_
   }();
   if (cus_env > 0 && (uint32_t)cus_env < grid) grid = (uint32_t)cus_env;
 #endif
-  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P, BS, PIPE>, lds);
+  hipError_t e = allow_lds(fused_v210_combine_lds_kernel<N, P, BS, PIPE, 0, TAIL>, lds);
   if (e != hipSuccess) return e;
   const uint32_t slices = (a.f.total_quads + BS - 1) / BS;  // never more workgroups per job than slices
   FusedLdsArgs b = a;
@@ -936,7 +956,7 @@ static hipError_t launch_fused_npb(hipStream_t s, const FusedLdsArgs &a, uint32_
     }
   }
 #endif
-  fused_v210_combine_lds_kernel<N, P, BS, PIPE><<<b.wg_per_job * b.jobs, BS, lds, s>>>(b);
+  fused_v210_combine_lds_kernel<N, P, BS, PIPE, 0, TAIL><<<b.wg_per_job * b.jobs, BS, lds, s>>>(b);
   return hipGetLastError();
 }
 
@@ -949,8 +969,7 @@ static hipError_t launch_fused_n(hipStream_t s, const FusedLdsArgs &a, uint32_t 
     const char *e = getenv("PH_FUSED_GEOM");
     return e ? atoi(e) : 0;
   }();
-  const uint32_t per_wg = (a.f.total_quads + grid - 1) / grid;
-  (void)per_wg;
+  if (a.f.quads_per_line_used != a.f.quads_per_line_pitch) return launch_fused_npb<N, 6, 1024, false, true>(s, a, grid, lds);  // ragged lines
   int geom = geom_env ? geom_env : 6;
   static const int pipe_env = [] {
     const char *e = getenv("PH_FUSED_PIPE");  // 1 = the software-pipelined phases (measured 3 % SLOWER: DESIGN.md 4)

@@ -122,6 +122,13 @@ __device__ __forceinline__ float lds_lut_index_unit(float t) {
   t = __builtin_fminf(__builtin_fmaxf(t, 0.0f), 1.0f);
   return t * 65535.0f + kRoundMagic;
 }
+// The same with the TAIL's index (v210.ts:176-178 convert_ushort_sat_rtz): truncated instead of rounded where `trunc` is set
+// (per lane).  The clamped product is not negative, so floor is the truncation, and M + an integer is exact.
+__device__ __forceinline__ float lds_lut_index_unit_tail(float t, bool trunc) {
+  t = __builtin_fminf(__builtin_fmaxf(t, 0.0f), 1.0f);
+  const float x = t * 65535.0f;
+  return (trunc ? __builtin_floorf(x) : x) + kRoundMagic;
+}
 // table[sat_rte(x)], x in table-index units
 __device__ __forceinline__ float lds_lut_at(const LutK &k, float x) {
   x = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 65535.0f);  // v_med3_f32; NaN -> 0 like the reference
@@ -151,6 +158,31 @@ __device__ __forceinline__ uint4 write_quad_idx_lds(const float (&yi)[18], const
   return pack_quad(y, u, v);
 }
 
+// The tail quad of a line whose width is not a multiple of 6 (v210.ts:169-194): `remain` = 2 or 4 pixels from indices that were
+// TRUNCATED (lds_lut_index_unit_tail), code values rounded half away from zero (round(), then the truncating convert_ushort_sat),
+// the words the reference does not set left 0.  Chroma comes from the even pixels as everywhere.
+__device__ __forceinline__ uint4 write_quad_idx_lds_tail(const float (&yi)[18], const WriteK &wk, const LutK &lut, uint32_t remain) {
+  uint32_t y[4], u[2], v[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gr = lds_lut_fetch(lut, yi[3 * j]), gg = lds_lut_fetch(lut, yi[3 * j + 1]);
+    const float gb = lds_lut_fetch(lut, yi[3 * j + 2]);
+    y[j] = sat_u16_trunc(__builtin_roundf(dot4(gr, gg, gb, 1.0f, wk.y)));
+    if ((j & 1) == 0) {
+      u[j >> 1] = sat_u16_trunc(__builtin_roundf(dot4(gr, gg, gb, 1.0f, wk.u)));
+      v[j >> 1] = sat_u16_trunc(__builtin_roundf(dot4(gr, gg, gb, 1.0f, wk.v)));
+    }
+  }
+  uint4 w = make_uint4(v[0] << 20 | y[0] << 10 | u[0], 0u, 0u, 0u);
+  if (remain == 2u) {
+    w.y = y[1];
+  } else if (remain == 4u) {
+    w.y = y[2] << 20 | u[1] << 10 | y[1];
+    w.z = y[3] << 10 | v[1];
+  }
+  return w;
+}
+
 // A gamma LUT as the kernels see it: either the compressed table in LDS or the plain f32 table
 // in global memory (tables that do not compress, or the "lds_lut" option switched off).
 struct LutInLds {
@@ -173,16 +205,19 @@ struct LutInGlobal {
 __device__ __forceinline__ bool ycbcr_matrix_is_standard(const ReadK &k) {
   return k.r.y == 0.0f && k.b.z == 0.0f && k.r.x == k.g.x && k.g.x == k.b.x;
 }
+// `last`: the fourth component of the reference's (Y, Cb, Cr, 1) vector.  It is 1 everywhere except in the tail of a line whose
+// width is not a multiple of 6, where the reference's reader builds its vectors with a 0 there (v210.ts:88-93) and so drops the
+// matrix's offset column; callers that serve such widths pass 0.0f / 1.0f per lane, everybody else the constant.
 template <bool STD = false>
-__device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const ReadK &k, const LutK &lut) {
+__device__ __forceinline__ float4 read_px_lds(float y, float cb, float cr, const ReadK &k, const LutK &lut, float last = 1.0f) {
   float tr, tg, tb;
   if (STD) {
     const float ym = y * k.r.x;
-    tr = fma_rn(1.0f, k.r.w, fma_rn(cr, k.r.z, ym));
-    tg = fma_rn(1.0f, k.g.w, fma_rn(cr, k.g.z, fma_rn(cb, k.g.y, ym)));
-    tb = fma_rn(1.0f, k.b.w, fma_rn(cb, k.b.y, ym));
+    tr = fma_rn(last, k.r.w, fma_rn(cr, k.r.z, ym));
+    tg = fma_rn(last, k.g.w, fma_rn(cr, k.g.z, fma_rn(cb, k.g.y, ym)));
+    tb = fma_rn(last, k.b.w, fma_rn(cb, k.b.y, ym));
   } else {
-    tr = dot4(y, cb, cr, 1.0f, k.r), tg = dot4(y, cb, cr, 1.0f, k.g), tb = dot4(y, cb, cr, 1.0f, k.b);
+    tr = dot4(y, cb, cr, last, k.r), tg = dot4(y, cb, cr, last, k.g), tb = dot4(y, cb, cr, last, k.b);
   }
   const float r = lds_lut_at_unit(lut, tr);
   const float g = lds_lut_at_unit(lut, tg);
@@ -198,15 +233,15 @@ struct PxPending {
   LutPending r, g, b;
 };
 template <bool STD>
-__device__ __forceinline__ PxPending read_px_issue(float y, float cb, float cr, const ReadK &k, const LutK &lut) {
+__device__ __forceinline__ PxPending read_px_issue(float y, float cb, float cr, const ReadK &k, const LutK &lut, float last = 1.0f) {
   float tr, tg, tb;
   if (STD) {
     const float ym = y * k.r.x;
-    tr = fma_rn(1.0f, k.r.w, fma_rn(cr, k.r.z, ym));
-    tg = fma_rn(1.0f, k.g.w, fma_rn(cr, k.g.z, fma_rn(cb, k.g.y, ym)));
-    tb = fma_rn(1.0f, k.b.w, fma_rn(cb, k.b.y, ym));
+    tr = fma_rn(last, k.r.w, fma_rn(cr, k.r.z, ym));
+    tg = fma_rn(last, k.g.w, fma_rn(cr, k.g.z, fma_rn(cb, k.g.y, ym)));
+    tb = fma_rn(last, k.b.w, fma_rn(cb, k.b.y, ym));
   } else {
-    tr = dot4(y, cb, cr, 1.0f, k.r), tg = dot4(y, cb, cr, 1.0f, k.g), tb = dot4(y, cb, cr, 1.0f, k.b);
+    tr = dot4(y, cb, cr, last, k.r), tg = dot4(y, cb, cr, last, k.g), tb = dot4(y, cb, cr, last, k.b);
   }
   PxPending p;
   p.r = lds_lut_issue(lut, lds_lut_index_unit(tr));

@@ -96,7 +96,8 @@ def test_argument_validation_needs_no_device():
         (lambda: l.ph_v210_read(None, 1, None, one, 1920, 1080, one, one, one), "ph_v210_read"),
         (lambda: l.ph_v210_write(None, 1, one, one, 1920, 1080, 2, one, one), "interlace must be 0, 1 or 3"),
         (lambda: l.ph_fused_v210_combine(None, 1, 9, arr3, one, 1920, 1080, one, one, one, one, one), "1..8 layers"),
-        (lambda: l.ph_fused_v210_combine(None, 1, 3, arr3, one, 1280, 720, one, one, one, one, one), "multiple of 48"),
+        (lambda: l.ph_fused_v210_combine(None, 1, 3, arr3, one, 1281, 720, one, one, one, one, one), "is odd"),
+        (lambda: l.ph_fused_v210_combine(None, 1, 3, arr3, one, 1280, 720, one, one, one, one, one), "ctx is NULL"),  # (1280 is a served width)
         (lambda: l.ph_combine(None, 1, 1, arr3, 64, 64, one), "between 2 and 8"),
         (lambda: l.ph_yadif(None, 1, None, one, one, 64, 64, 0, 1, 0, one), "ph_yadif"),
         (lambda: l.ph_transform(None, 1, one, 0, 64, one, one, 64, 64), "ph_transform"),

@@ -126,7 +126,9 @@ def test_config3_chain_one_field_full_size(config3_sources, second_field, pip):
 def test_config3_deinterlacing_reader_full_size(config3_sources, tff):
     """ph_v210_yadif_pair on config 3's four full-size windows in ONE launch (the strip height the launcher picks for
     4 x 1080 rows, every column block, both outputs) against the oracle's read -> yadif for both parities - and the
-    whole best route of config 3: its outputs through the fused compositor equal the oracle chain's v210 frame."""
+    whole best route of config 3: its outputs through the fused compositor equal the oracle chain's v210 frame.
+    Then config 3 exactly as bench.py times it (packed-RGB fields, both fields' compositors in one launch) against the
+    same oracle frames (yadif.ts:88-145, mixer.ts:209-223, combiner.ts:219-254, v210.ts:113-195)."""
     import hip_harness as hh
     from phaneron_amd import capi
     words, rgba_o, rgba_d = config3_sources
@@ -143,12 +145,32 @@ def test_config3_deinterlacing_reader_full_size(config3_sources, tff):
     m = capi.transform_matrix(OW, OH)
     dm = hh.dev(m)
     wcm, wlut = hh.ColourParams.writer("2020")
+    wants = []
     for parity in (0, 1):
         out = _v210_out(OW, OH)
         k.compose_write_v210([(outs[l][parity], SW, SH, dm) for l in range(4)], out, OW, OH, 0, wcm, wlut)
         up_o = [orc.transform(deint_o[l][parity], orc.transform_matrix(OW, OH), OW, OH) for l in range(4)]
         want = orc.v210_write(orc.combine(up_o), OW, OH, 0, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
         _bits_equal(hh.host(out, np.uint32), want, "config 3 best route, parity %d tff %d" % (parity, tff))
+        wants.append(want)
+    # ---- the route bench.py times NOW (`secondary`, config 3), against the ORACLE at full size: the de-interlacing reader
+    # writing packed-RGB fields (ph_v210_yadif_pair_fmt, PH_IMG_RGB_F32), then both fields' 2 x 2-block compositors as ONE
+    # launch (ph_compose_up_write_v210_pair) - and a launch per field (ph_compose_up_write_v210)
+    import torch
+    rgb = [[torch.zeros(SW * SH * 3, dtype=torch.float32, device="cuda") for _ in range(2)] for _ in range(4)]
+    k.v210_yadif_pair([(dwords[l][0], dwords[l][1], dwords[l][2], rgb[l][0], rgb[l][1]) for l in range(4)], SW, SH, tff, False, cm, lut, gm, rgb=True)
+    for l in range(4):
+        for parity in (0, 1):
+            _bits_equal(hh.host(rgb[l][parity]).reshape(-1, 3), np.ascontiguousarray(deint_o[l][parity].reshape(-1, 4)[:, :3]),
+                        "packed-RGB field, layer %d parity %d tff %d" % (l, parity, tff))
+    pair = [_v210_out(OW, OH), _v210_out(OW, OH)]
+    k.compose_up_write_v210_pair([(rgb[l][0], SW, SH, m) for l in range(4)], [(rgb[l][1], SW, SH, m) for l in range(4)], pair[0], pair[1],
+                                 OW, OH, 0, wcm, wlut, rgb=True)
+    for parity in (0, 1):
+        _bits_equal(hh.host(pair[parity], np.uint32), wants[parity], "config 3 as benched (pair launch), parity %d tff %d" % (parity, tff))
+        single = _v210_out(OW, OH)
+        k.compose_up_write_v210([(rgb[l][parity], SW, SH, m) for l in range(4)], single, OW, OH, 0, wcm, wlut, rgb=True)
+        _bits_equal(hh.host(single, np.uint32), wants[parity], "config 3 as benched (launch per field), parity %d tff %d" % (parity, tff))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -277,4 +299,84 @@ def test_fused_batch_sees_every_layer_of_every_job(jobs, n):
     k.fused_v210_combine_batch([[hh.dev(l) for l in job] for job in layers], outs, w, h, cm, dlut, gm, wcm, wlut)
     for j in range(jobs):
         _bits_equal(hh.host(outs[j], np.uint32), orc.pipeline_v210_combine(layers[j], w, h, *rd_o, *wr_o), "job %d" % j)
+    k.unregister_lut(dlut)
+
+
+# ---------------------------------------------------------------------------------------------------
+# 720p50: the reference's third video format (src/config.ts:43-54).  1280 % 48 = 32 and 1280 % 6 = 2: every line ends
+# in a tail quad and two cleared slots, so every operator's tail path is on the chain (v210.ts:84-110, 166-193)
+# ---------------------------------------------------------------------------------------------------
+HW, HH = 1280, 720
+
+
+@pytest.fixture(scope="module")
+def hd720_chain():
+    """four 1280 x 720 v210 sources, the Mixer placements of config 2 (a full-frame layer through the identity fill and three
+    quarter-size insets, producer/mixer.ts:209-223), and the oracle's chain read -> transform -> combine_4 (combiner.ts:219-254)"""
+    rd_o = (orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "709"))
+    words = [frames.v210_random(HW, HH, frames.layer_seed(7, l), legal=(l != 2)) for l in range(4)]
+    kws = [dict()] + [dict(scale_x=0.5, scale_y=0.5, offset_x=ox, offset_y=oy) for ox, oy in ((-0.25, -0.25), (0.25, -0.25), (0.25, 0.25))]
+    mats = [capi.transform_matrix(HW, HH, **kw) for kw in kws]
+    for kw, mat in zip(kws, mats):
+        _bits_equal(mat, orc.transform_matrix(HW, HH, **kw), "transform matrix")
+    rgba = [orc.v210_read(f, HW, HH, *rd_o) for f in words]
+    placed = [orc.transform(rgba[l], mats[l], HW, HH) for l in range(4)]
+    return words, mats, rgba, placed, orc.combine(placed)
+
+
+@pytest.mark.parametrize("interlace", [0, 1, 3])
+def test_720p_chain_full_size(hd720_chain, interlace):
+    """read (tail) -> transform -> combine_4 -> write (tail, progressive and both fields) at 1280 x 720 against the oracle: one kernel
+    per operator as the reference's job queue posts them, and the same frame from the channel compositor in ONE launch"""
+    import hip_harness as hh
+    words, mats, rgba_o, placed_o, comb_o = hd720_chain
+    wr_o = (orc.rgb2ycbcr_matrix("709"), orc.linear2gamma_lut("709"))
+    before = np.full(frames.v210_pitch_bytes(HW) * HH // 4, 0x2AAAAAAA, np.uint32)
+    want = np.asarray(orc.v210_write(comb_o, HW, HH, interlace, *wr_o, out=before.copy())).reshape(-1)
+    k = hh.ctx()
+    cm, lut, gm = hh.ColourParams.reader("709", "709")
+    wcm, wlut = hh.ColourParams.writer("709")
+    dwords = [hh.dev(f) for f in words]
+    # ---- one kernel per operator
+    up = []
+    for l in range(4):
+        img = _img(HW, HH)
+        k.v210_read(dwords[l], img, HW, HH, cm, lut, gm)
+        if interlace == 0:
+            _bits_equal(hh.host(img), rgba_o[l], "720p read, layer %d" % l)
+        placed = _img(HW, HH)
+        k.transform(img, HW, HH, hh.dev(mats[l]), placed, HW, HH)
+        up.append(placed)
+    comb = _img(HW, HH)
+    k.combine(up, comb, HW, HH)
+    out = hh.dev(before.copy())
+    k.v210_write(comb, out, HW, HH, interlace, wcm, wlut)
+    _bits_equal(hh.host(out, np.uint32), want, "720p, one kernel per operator, interlace %d" % interlace)
+    # ---- the channel compositor straight from the v210 words
+    out2 = hh.dev(before.copy())
+    k.chan_compose_v210([dict(src=(dwords[l], HW, HH, mats[l])) for l in range(4)], out2, HW, HH, interlace, cm, lut, gm, wcm, wlut)
+    _bits_equal(hh.host(out2, np.uint32), want, "720p, channel compositor, interlace %d" % interlace)
+
+
+def test_720p_headline_shape_full_size(hd720_chain):
+    """four 1:1 layers -> combine_4 -> write at 1280 x 720: the fused kernel and the channel compositor against the oracle chain,
+    with the lower layers made visible (entry 0 of the reader table is +Inf)"""
+    import hip_harness as hh
+    words = hd720_chain[0]
+    lut = orc.gamma2linear_lut("709").copy()
+    lut[0] = np.inf
+    cm_o, gm_o = orc.ycbcr2rgb_matrix("709"), orc.rgb2rgb_matrix("709", "2020")
+    want = orc.pipeline_v210_combine(words, HW, HH, cm_o, lut, gm_o, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    k = hh.ctx()
+    dlut = hh.dev(lut)
+    assert k.register_lut(dlut, lut)
+    cm, _, gm = hh.ColourParams.reader("709", "2020")
+    wcm, wlut = hh.ColourParams.writer("2020")
+    dwords = [hh.dev(f) for f in words]
+    out = _v210_out(HW, HH)
+    k.fused_v210_combine(dwords, out, HW, HH, cm, dlut, gm, wcm, wlut)
+    _bits_equal(hh.host(out, np.uint32), want, "720p fused kernel")
+    out2 = _v210_out(HW, HH)
+    k.chan_compose_v210([dict(src=(d, HW, HH, None)) for d in dwords], out2, HW, HH, 0, cm, dlut, gm, wcm, wlut)
+    _bits_equal(hh.host(out2, np.uint32), want, "720p channel compositor, 1:1 layers")
     k.unregister_lut(dlut)

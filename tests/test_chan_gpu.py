@@ -101,7 +101,8 @@ PIP = [dict(), dict(scale_x=0.5, scale_y=0.5, offset_x=-0.25, offset_y=-0.25), d
 
 
 def pip_layers(w, h, seed, n=4):
-    srcs = [frames.v210_ramp(w, h)] + [frames.v210_random(w, h, frames.layer_seed(seed, l)) for l in range(1, n)]
+    first = frames.v210_ramp(w, h) if w % 6 == 0 else frames.v210_random(w, h, frames.layer_seed(seed, 0))  # (the ramp is defined for whole quads)
+    srcs = [first] + [frames.v210_random(w, h, frames.layer_seed(seed, l)) for l in range(1, n)]
     return [dict(src=Src(srcs[l], w, h, m(w, h, **PIP[l]))) for l in range(n)]
 
 
@@ -223,16 +224,16 @@ def test_refusals():
     src = hh.dev(frames.v210_random(w, h, 1))
     out = torch.zeros(frames.v210_pitch_bytes(w) * h // 4, dtype=torch.int32, device="cuda")
     ok = dict(src=(src, w, h, None))
-    with pytest.raises(capi.PhaneronError, match="multiple of 48"):
-        k.chan_compose_v210([dict(src=(src, 330, h, None))], out, 330, h, 0, *rd_d, *wr_d)
+    with pytest.raises(capi.PhaneronError, match="needs an even width"):  # (ragged even widths are served: test_ragged_output_widths)
+        k.chan_compose_v210([dict(src=(src, 331, h, None))], out, 331, h, 0, *rd_d, *wr_d)
     with pytest.raises(capi.PhaneronError, match="not the output size"):
         k.chan_compose_v210([dict(src=(src, 192, h, None))], out, w, h, 0, *rd_d, *wr_d)
     with pytest.raises(capi.PhaneronError, match="incoming source is empty"):
         k.chan_compose_v210([dict(ok, transition="dissolve", mix=0.5)], out, w, h, 0, *rd_d, *wr_d)
     with pytest.raises(capi.PhaneronError, match="mask is empty"):
         k.chan_compose_v210([dict(ok, transition="wipe", incoming=(src, w, h, None))], out, w, h, 0, *rd_d, *wr_d)
-    with pytest.raises(capi.PhaneronError, match="multiple of 6"):
-        k.chan_compose_v210([dict(src=(src, 100, h, capi.transform_matrix(w, h)))], out, w, h, 0, *rd_d, *wr_d)
+    with pytest.raises(capi.PhaneronError, match="an odd width"):
+        k.chan_compose_v210([dict(src=(src, 101, h, capi.transform_matrix(w, h)))], out, w, h, 0, *rd_d, *wr_d)
     with pytest.raises(capi.PhaneronError, match="1..8 layers"):
         k.chan_compose_v210([ok] * 9, out, w, h, 0, *rd_d, *wr_d)
     plain = hh.dev(orc.linear2gamma_lut("709"))  # never registered: no LDS form
@@ -421,6 +422,16 @@ def test_other_output_formats(fmt, interlace):
     layers = pip_layers(w, h, 700 + interlace, 3)
     layers.append(dict(src=Src(frames.pack_random("bgra8", 100, 30, 701), 100, 30, m(w, h, scale_x=0.3, scale_y=0.5, offset_x=0.3, offset_y=-0.2), fmt="bgra8")))
     layers.append(dict(src=Src(frames.pack_random("yuv420p", w, h, 702), w, h, m(w, h, **PIP[3]), fmt="yuv420p")))
+    check_format(layers, w, h, fmt, "%s interlace %d" % (fmt, interlace), interlace)
+
+
+def check_format(layers, w, h, fmt, what, interlace=0):
+    """the channel's frame in another wire format against the oracle's chain ending in that format's writer; the planes are
+    poisoned first (a field write leaves the other field's lines alone)"""
+    import torch
+    import hip_harness as hh
+    from phaneron_amd import capi
+    rd_o, _, rd_d, _ = colour("709", "709")
     rng = orc.FORMAT_RANGE[fmt]
     wcm_o = None if rng is None else orc.rgb2ycbcr_matrix("709", *rng)
     wlut_o = orc.linear2gamma_lut("709")
@@ -437,4 +448,46 @@ def test_other_output_formats(fmt, interlace):
     for i, (g, wnt) in enumerate(zip(dst, want)):
         got = hh.host(g, np.uint8)
         bad = np.flatnonzero(got != wnt)
-        assert bad.size == 0, "%s interlace %d plane %d: %d of %d bytes differ, first at %d" % (fmt, interlace, i, bad.size, got.size, bad[0])
+        assert bad.size == 0, "%s plane %d: %d of %d bytes differ, first at %d" % (what, i, bad.size, got.size, bad[0])
+
+
+# ---- widths that are not a multiple of 48: 1280 x 720 is one of the reference's three video formats (src/config.ts:43-54) ------------------
+@pytest.mark.parametrize("w,h", [(1280, 24), (100, 9), (52, 6), (1302, 4), (50, 3)])
+def test_ragged_output_widths(w, h):
+    """a channel whose frames end in a tail quad (1280 % 6 = 2, 100 % 6 = 4) and cleared slots (1302: whole quads only): sources of
+    the same ragged width taken 1:1 and placed (their tail pixels are read without the matrix's offset column, v210.ts:88-93), the
+    writer's tail arithmetic (v210.ts:173-184), lines by pitch, both fields; the output is poisoned first"""
+    v = [frames.v210_random(w, h, frames.layer_seed(80, l), legal=(l != 1)) for l in range(4)]
+    check([dict(src=Src(x, w, h)) for x in v[:2]], w, h, "1:1 layers %dx%d" % (w, h), poison_dst=True)
+    check(pip_layers(w, h, 81), w, h, "PiP layers %dx%d" % (w, h), specs=("709", "2020"), poison_dst=True)
+    check([dict(src=Src(v[0], w, h, m(w, h, scale_x=1.3, scale_y=1.3, rotate=0.05))), dict(src=Src(v[1], w, h, m(w, h, scale_x=0.6, scale_y=0.7, offset_x=0.2)))],
+          w, h, "rotated, enlarged and shrunk %dx%d" % (w, h), poison_dst=True)
+    if h % 2 == 0:
+        for interlace in (1, 3):
+            check(pip_layers(w, h, 82, 3), w, h, "field %d of %dx%d" % (interlace, w, h), interlace=interlace, poison_dst=True)
+
+
+def test_ragged_sources_on_regular_outputs_and_the_other_way_round():
+    """a 1280-wide source shown on a 1920 channel (only its reads meet a tail) and 1920-wide sources on a 1280 channel (only the write
+    does); a transition whose incoming source and mask are ragged; an f32 layer in between"""
+    ow, oh = 1920, 20
+    hd = frames.v210_random(1280, 16, frames.layer_seed(83, 0), legal=False)
+    full = frames.v210_random(ow, oh, frames.layer_seed(83, 1))
+    check([dict(src=Src(full, ow, oh)), dict(src=Src(hd, 1280, 16, m(ow, oh, scale_x=0.9, scale_y=0.9)))], ow, oh, "720-line source on an HD channel")
+    ow, oh = 1280, 18
+    a, b = frames.v210_random(1920, 24, frames.layer_seed(84, 0)), frames.v210_random(1280, 18, frames.layer_seed(84, 1))
+    mask = frames.v210_ramp(96, 6)
+    rgba = frames.rgba_random(ow, oh, 85, -0.05, 1.05)
+    layers = [dict(src=Src(a, 1920, 24, m(ow, oh))), dict(src=Src(rgba, ow, oh, fmt="rgba")),
+              dict(src=Src(b, 1280, 18, m(ow, oh, scale_x=0.5, scale_y=0.5, offset_x=0.25)), transition="wipe", incoming=Src(b, 1280, 18), mask=Src(mask, 96, 6, m(ow, oh))),
+              dict(src=Src(a, 1920, 24, m(ow, oh, scale_x=0.4, scale_y=0.4, offset_x=-0.3, offset_y=0.3)), transition="dissolve", mix=0.25, incoming=Src(b, 1280, 18, m(ow, oh, scale_x=0.4, scale_y=0.4, offset_x=-0.3, offset_y=0.3)))]
+    check(layers, ow, oh, "HD sources, an image, a wipe and a dissolve on a 1280 channel", specs=("709", "2020"), poison_dst=True)
+
+
+@pytest.mark.parametrize("fmt", ["rgba8", "bgra8", "yuv422p8", "yuv422p10"])
+def test_other_output_formats_at_1280(fmt):
+    """the screen's and an encoder's frames of a 1280-wide channel (widths in multiples of 8 for the planar writers)"""
+    w, h = 1280, 12
+    v = [frames.v210_random(w, h, frames.layer_seed(86, l)) for l in range(2)]
+    layers = [dict(src=Src(v[0], w, h)), dict(src=Src(v[1], w, h, m(w, h, scale_x=0.5, scale_y=0.5, offset_x=0.1)))]
+    check_format(layers, w, h, fmt, "1280-wide %s frame" % fmt)

@@ -341,6 +341,46 @@ def test_fused_pipeline_vs_oracle_chain(n, w, h, rspec, wspec):
     assert_bits(hh.host(out, np.uint32), want, "fused n=%d" % n)
 
 
+@pytest.mark.parametrize("n,w,h", [(4, 1280, 36), (1, 1280, 5), (3, 100, 7), (8, 52, 3), (2, 1302, 4), (4, 50, 2), (2, 2, 1)])
+def test_fused_pipeline_ragged_widths(n, w, h):
+    """Widths that are not a multiple of 48 (1280: the reference's 720p50, src/config.ts:43-54; 100 and 52: a tail of 4 pixels; 1302: whole
+    quads, then cleared slots; 50, 2: less than a block): lines addressed by pitch, the tail quad read with the fourth vector
+    component 0 (v210.ts:88-93) and written from truncated indices with round() (v210.ts:173-184), the slots behind it cleared
+    (v210.ts:131-136) - all of it in the fused kernel, against the oracle's chain.  Illegal codes included; the output is poisoned first."""
+    import torch
+    import hip_harness as hh
+    layers = [frames.v210_random(w, h, frames.layer_seed(6, i), legal=(i % 2 == 1)) for i in range(n)]
+    cm, lut, gm = hh.ColourParams.reader("709", "2020")
+    wcm, wlut = hh.ColourParams.writer("2020")
+    out = torch.full((frames.v210_pitch_bytes(w) * h // 4,), 0x2AAAAAAA, dtype=torch.int32, device="cuda")
+    hh.ctx().fused_v210_combine([hh.dev(l) for l in layers], out, w, h, cm, lut, gm, wcm, wlut)
+    want = orc.pipeline_v210_combine(layers, w, h, orc.ycbcr2rgb_matrix("709"), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"),
+                                     orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    assert_bits(hh.host(out, np.uint32), want, "fused n=%d %dx%d" % (n, w, h))
+
+
+def test_fused_pipeline_ragged_width_shows_every_layer():
+    """the same with the lower layers made visible (a reader table whose entry 0 is +Inf poisons what `combine` would drop) and a
+    non-standard matrix, so that the tail's missing offset column shows in every layer"""
+    import torch
+    import hip_harness as hh
+    w, h, n = 1280, 9, 4
+    layers = [frames.v210_random(w, h, frames.layer_seed(8, i), legal=False) for i in range(n)]
+    m = (orc.ycbcr2rgb_matrix("709").reshape(3, 4) * np.array([[1.0], [1.03125], [0.96875]], np.float32)).reshape(-1).astype(np.float32)
+    m[1], m[10] = np.float32(1.5e-4), np.float32(-2.5e-4)
+    lut = orc.gamma2linear_lut("709").copy()
+    lut[0] = np.inf
+    gm = orc.rgb2rgb_matrix("709", "2020")
+    dlut = hh.dev(lut)
+    assert hh.ctx().register_lut(dlut, lut)
+    wcm, wlut = hh.ColourParams.writer("2020")
+    out = torch.zeros(frames.v210_pitch_bytes(w) * h // 4, dtype=torch.int32, device="cuda")
+    hh.ctx().fused_v210_combine([hh.dev(l) for l in layers], out, w, h, hh.dev(m), dlut, hh.dev(np.concatenate([gm, np.zeros(3, np.float32)])), wcm, wlut)
+    want = orc.pipeline_v210_combine(layers, w, h, m, lut, gm, orc.rgb2ycbcr_matrix("2020"), orc.linear2gamma_lut("2020"))
+    assert_bits(hh.host(out, np.uint32), want, "ragged, every layer visible")
+    hh.ctx().unregister_lut(dlut)
+
+
 @pytest.mark.parametrize("shape", ["full", "negative_luma_gain", "cb_in_red_only", "standard_with_negative_zero"])
 def test_fused_pipeline_with_non_standard_matrices(shape):
     """The fused kernel has a fast path for the matrix shape colourMaths produces (one luma gain, no Cb
