@@ -248,6 +248,8 @@ int ph_yadif_pair(ph_ctx *ctx, int queue, const void *prev, const void *cur, con
  *      RGBA frames are written.  out_parity0 / out_parity1 are bit-identical to ph_v210_read on prev, cur and next
  *      followed by ph_yadif with parity 0 / 1.  n sources of one size and one colour recipe per call (the layers of a
  *      channel).  Needs width % 6 == 0 and the reader LUT registered (PH_E_INVALID otherwise - run the separate kernels). */
+/* (ABI 4 and later: 88 bytes - the six chroma-plane pointers were added behind the original five; an array of the 40-byte
+ * struct of ABI 2 / 3 has the wrong stride, see the ABI history at the top) */
 typedef struct ph_deint_source {
   const void *prev, *cur, *next;      /* device, v210, width x height (ph_yadif_pair_packed: or the Y planes of planar frames) */
   void *out_parity0, *out_parity1;    /* device, float RGBA, width x height */
@@ -335,8 +337,9 @@ int ph_fused_v210_combine_batch(ph_ctx *ctx, int queue, int jobs, int n, const v
  *      v210 write (io.ts:152-164) as ONE kernel, so the N + 1 consumer-size f32 RGBA frames between
  *      them never reach HBM.  Bit-identical to ph_transform x N + ph_combine + ph_v210_write.
  *      A layer with matrix9 == NULL is used 1:1 and must have the output size.  n == 1: passthrough
- *      of the single (transformed) layer as the combiner does.  out_width % 48 == 0; the writer
- *      LUT must be registered (LDS form).  interlace as ph_v210_write. ------------------------- */
+ *      of the single (transformed) layer as the combiner does.  Any even out_width (one that is not a
+ *      multiple of 48 - 1280 - is served by the quad-per-lane kernel with the reference's tail
+ *      arithmetic); the writer LUT must be registered (LDS form).  interlace as ph_v210_write. -- */
 typedef struct ph_layer {
   const void *rgba;     /* device, float RGBA, width x height */
   int width, height;
@@ -367,7 +370,7 @@ int ph_compose_wipe_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *la
  *      == 1 implied: ph_v210_yadif_pair_fmt), all layers of a call in the same layout.  Bit-identical to ph_transform +
  *      ph_combine + ph_v210_write.  A field write (interlace 1 / 3) needs more than 2x vertically: its rows are two lines apart.
  *      PH_E_INVALID when a placement does not qualify (use ph_compose_write_v210),
- *      out_width % 6 != 0 or the writer LUT is not registered.  interlace as ph_v210_write. -------------------- */
+ *      out_width % 48 != 0 or the writer LUT is not registered.  interlace as ph_v210_write. ------------------- */
 typedef struct ph_image_layer {
   const void *data;          /* device: width x height texels, rows unpadded */
   int format;                /* PH_IMG_RGBA_F32 | PH_IMG_RGB_F32 */
@@ -393,8 +396,10 @@ int ph_compose_up_write_v210_pair(ph_ctx *ctx, int queue, int n, const ph_image_
  *      to ph_v210_read + ph_transform (+ ph_transition_dissolve / ph_transition_wipe) + ph_combine + ph_v210_write.
  *      A source is a v210 frame or (e.g. a routed frame, a generated mask) an f32 RGBA image; with matrix9_host ==
  *      NULL it is taken 1:1 and must have the output size.  All v210 sources share the reader's colour recipe.
- *      Limits (PH_E_INVALID otherwise - run the separate kernels): out_width % 192 == 0, v210 source widths % 6 == 0,
- *      frames below 1 GiB, both gamma LUTs registered (LDS form).  interlace as ph_v210_write. ------------------ */
+ *      Limits (PH_E_INVALID otherwise - run the separate kernels): even widths for v210 frames, input or output (a width that
+ *      is not a multiple of 6 / of 48 - 1280 x 720 - takes the reference's tail arithmetic, v210.ts:84-110,166-193, lines by
+ *      pitch), planar output widths % 8 == 0, frames below 1 GiB, both gamma LUTs registered (LDS form).  interlace as
+ *      ph_v210_write. ---------------------------------------------------------------------------------------------- */
 #define PH_SRC_NONE 0
 #define PH_SRC_V210 1
 #define PH_SRC_RGBA_F32 2
@@ -472,8 +477,9 @@ int ph_lut_layout_of(const float *host_lut65536, ph_lut_layout *layout, void *ld
  *          larger than "stream_threshold_mb" MiB (default 64; measured neutral on the reference-shaped chains).  By
  *          default an image is treated as what it is in a channel, an intermediate the next operator reads back;
  *          wire-format outputs always stream;
- *          "host_pool_mb" (default 4096): how much pinned host memory released buffers' mirrors may keep for the next
- *          buffer of the same size (the reference creates its destinations per job and frame: io.ts:64-72). */
+ *          "host_pool_mb" (default 1024): how much pinned host memory released buffers' mirrors may keep for the next
+ *          buffer of the same size (the reference creates its destinations per job and frame: io.ts:64-72); over the
+ *          budget the oldest blocks are freed first. */
 int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value);
 
 /* ---- host colour maths (src/process/colourMaths.ts, run by Loader/Saver constructors

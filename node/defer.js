@@ -51,6 +51,7 @@ const sourceKeys = (prefix) => {
 const LAYER_PREFIX = [0, 1, 2, 3, 4, 5, 6, 7].map((i) => `l${i}`)
 const LAYER_INCOMING = LAYER_PREFIX.map((p) => `${p}Incoming`)
 const LAYER_MASK = LAYER_PREFIX.map((p) => `${p}Mask`)
+const NONE = Object.freeze([])
 const pushNew = (list, v) => { if (!list.includes(v)) list.push(v) }
 
 class Deferral {
@@ -68,7 +69,7 @@ class Deferral {
 	// (plain assignments: Object.defineProperty is a runtime call per field and buffer - a fifth of the recording's host time was here)
 	static adopt(buf) {
 		if (buf._readers !== undefined) return
-		buf._readers = new Set() // pending nodes that read the buffer
+		buf._readers = NONE // pending nodes that read the buffer (a small array; NONE until there is one)
 		buf._producer = null // the pending node that will write it
 		buf._held = 0 // recorded nodes that hold it (ONE native reference stands for all of them: _hold)
 		buf._failed = null // the error of the job that should have produced it (ADVICE r3: every later consumer sees it, not only the first)
@@ -109,7 +110,7 @@ class Deferral {
 			program._checked = this._signature(names, params, queue)
 		}
 		const node = { program, params: Object.assign({}, params), queue, ins, outs, state: 'pending' }
-		for (let k = 0; k < ins.length; ++k) { this._hold(ins[k]); ins[k]._readers.add(node) }
+		for (let k = 0; k < ins.length; ++k) { const b = ins[k]; this._hold(b); if (b._readers === NONE) b._readers = [node]; else b._readers.push(node) }
 		for (let k = 0; k < outs.length; ++k) if (!ins.includes(outs[k])) this._hold(outs[k])
 		// a buffer this job overwrites: whoever still wants its present (or pending) contents goes first.  A pending producer is
 		// dropped unseen only if this job is known to write the WHOLE buffer; a job that fills part of it (an interlaced `write`:
@@ -117,7 +118,7 @@ class Deferral {
 		const whole = WHOLE_OUTPUT.test(program.name) && !params.interlace
 		for (let k = 0; k < outs.length; ++k) {
 			const o = outs[k]
-			if (o._readers.size) for (const r of Array.from(o._readers)) if (r !== node) this._run(r)
+			if (o._readers.length) for (const r of o._readers.slice()) if (r !== node) this._run(r)
 			const p = o._producer
 			if (p && whole && p.outs.length === 1 && !ins.includes(o)) { this.stats.dropped++; this._retire(p, 'dropped') } // its result would be overwritten unseen
 			else if (p) this._run(p)
@@ -160,7 +161,7 @@ class Deferral {
 		this.pending.delete(node)
 		const { ins, outs } = node
 		for (let k = 0; k < outs.length; ++k) if (outs[k]._producer === node) outs[k]._producer = null
-		for (let k = 0; k < ins.length; ++k) ins[k]._readers.delete(node)
+		for (let k = 0; k < ins.length; ++k) { const rd = ins[k]._readers; const at = rd.indexOf(node); if (at >= 0) { if (rd.length === 1) ins[k]._readers = NONE; else rd.splice(at, 1) } }
 		// operands that are recipes themselves go with it if nobody else can ask for them (we still hold them here)
 		for (let k = 0; k < ins.length; ++k) this._reap(ins[k])
 		for (let k = 0; k < ins.length; ++k) this._unhold(ins[k])
@@ -170,7 +171,7 @@ class Deferral {
 	_reap(buf) {
 		const p = buf._producer
 		if (!p || p.state !== 'pending') return
-		for (const o of p.outs) if (o._readers.size || this._appRefs(o) > 0) return
+		for (const o of p.outs) if (o._readers.length || this._appRefs(o) > 0) return
 		this.stats.dropped++
 		this._retire(p, 'dropped')
 	}
@@ -204,8 +205,8 @@ class Deferral {
 	// ---- forcing ------------------------------------------------------------------------------------------------
 	// the buffer's contents are about to be replaced: every pending job that reads them runs now
 	beforeWrite(buf) {
-		if (!buf._readers || !buf._readers.size) return
-		for (const r of Array.from(buf._readers)) this._run(r)
+		if (!buf._readers || !buf._readers.length) return
+		for (const r of buf._readers.slice()) this._run(r)
 	}
 	// make the buffer's contents real
 	// (a buffer whose producer FAILED stays failed until somebody writes it again: every consumer gets the error, not only

@@ -78,10 +78,12 @@ class clContext {
 		// extension: waitFinish first polls the queue on the JS thread for up to this many microseconds
 		// before handing the wait to the libuv pool (a hand-off costs ~30 us; 0 = always hand off)
 		this.spinWaitMicros = params.spinWaitMicros || 0
-		// extension (node/defer.js): runProgram records instead of launching, and a frame's recorded operator chain
-		// reaches the device as one fused kernel when its result is asked for.  PHANERON_DEFERRED=1 turns it on for
-		// code that constructs the context itself (src/index.ts:94-107)
-		this.deferred = params.deferred === undefined ? process.env.PHANERON_DEFERRED === '1' : !!params.deferred
+		// The recording context (node/defer.js): runProgram records instead of launching, and a frame's recorded operator chain
+		// reaches the device as one fused kernel when its result is asked for.  It is the DEFAULT since round 4 - the reference
+		// constructs the context itself (src/index.ts:94-107) and should get the fused kernels without asking; `deferred: false`
+		// or PHANERON_DEFERRED=0 gives the launch-as-posted context (every job its own kernel, RunTimings measured when
+		// `profile` is set, waitFinish(queue.process) a real wait)
+		this.deferred = params.deferred === undefined ? process.env.PHANERON_DEFERRED !== '0' : !!params.deferred
 		this._deferral = null
 		this._addon = params.addon || null // tests: a stand-in for the N-API addon (node/test/defer_host_bench.js counts the calls the JS layer makes)
 		this.queue = this.overlapping ? { load: 0, process: 1, unload: 2 } : { load: 1, process: 1, unload: 1 }

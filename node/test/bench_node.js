@@ -15,7 +15,8 @@ async function main() {
 	const w = parseInt(process.argv[3] || '3840')
 	const h = parseInt(process.argv[4] || '2160')
 	const n = parseInt(process.argv[5] || '4')
-	for (const mode of ['coalesced', 'per-key', 'fused', 'deferred']) {
+	const modes = process.env.PH_NODE_BENCH_MODES ? process.env.PH_NODE_BENCH_MODES.split(',') : ['coalesced', 'per-key', 'fused', 'deferred']
+	for (const mode of modes) {
 		const rig = await Rig.open({ deviceIndex: 0, coalesce: mode !== 'per-key', spinWaitMicros: 200, deferred: mode === 'deferred' })
 		const read = await rig.unpack('v210', w, h, '709', '2020')
 		const write = await rig.pack('v210', w, h, '2020', false)
@@ -34,6 +35,7 @@ async function main() {
 		const comb = await rig.image(w, h)
 		const out = await rig.planes('v210', w, h, 'writeonly')
 		const ring = [out, await rig.planes('v210', w, h, 'writeonly'), await rig.planes('v210', w, h, 'writeonly')]
+		const slotDone = []
 		const one = async (f) => {
 			if (mode === 'fused') { await rig.run(fused(src.map((p) => p[0]), out[0])); return rig.sync() }
 			if (mode === 'deferred') {
@@ -49,12 +51,17 @@ async function main() {
 				const c = { source: 'combine', timestamp: f }
 				const cm = combine ? await rig.image(w, h) : fresh[0]
 				if (combine) rig.post(c, combine(fresh, cm), () => fresh.forEach((b) => b.release()))
-				const o = ring[f % ring.length] // three output frames in flight: the host prepares frame f + 1 while the device makes frame f
+				// three output frames in flight: the host prepares frame f + 1 while the device makes frame f.  A consumer waits for the
+				// slot it is about to reuse (the frame made three frames ago), not for the whole queue
+				const slot = f % ring.length
+				const o = ring[slot]
+				if (slotDone[slot] && !slotDone[slot].done()) await slotDone[slot].wait()
 				rig.post(c, write(cm, o, 0), () => cm.release())
 				ids.push(c)
 				await Promise.all(ids.map((id) => rig.board.flush(id)))
 				rig.ctx.realise(o[0])
-				return f % ring.length === ring.length - 1 ? rig.ctx.drain() : undefined
+				slotDone[slot] = rig.ctx.recordEvent(rig.ctx.queue.process)
+				return undefined
 			}
 			const ids = []
 			for (let l = 0; l < n; ++l) { const id = { source: `L${l}`, timestamp: f }; rig.post(id, read(src[l], rgba[l])); ids.push(id) }

@@ -68,9 +68,17 @@ struct ph_ctx {
   // Pinned host mirrors by exact size.  The reference makes a fresh destination per job and frame (io.ts:64-72, mixer.ts:196,
   // combiner.ts:230) and the node binding gives every buffer its mirror at once (an OpenCLBuffer IS a node Buffer): a
   // hipHostMalloc / hipHostFree pair of a 2160p image is ~40 ms, a pool hit nothing
-  std::multimap<size_t, void *> host_pool;
+  // (a block carries the event recorded behind the last asynchronous copy that touched it: the next owner waits for it -
+  // normally long complete - before it writes the mirror; blocks are evicted oldest first when the budget is exceeded)
+  struct HostBlock {
+    void *p;
+    hipEvent_t busy;  // may be null
+    uint64_t seq;
+  };
+  std::multimap<size_t, HostBlock> host_pool;
   size_t host_pooled_bytes = 0;
-  int host_pool_mb = 4096;  // what the pool may keep pinned
+  uint64_t host_pool_seq = 0;
+  int host_pool_mb = 1024;  // what the pool may keep pinned
   void *chan_index[3] = {nullptr, nullptr, nullptr};  // index frame of the channel compositor, one per queue (ph_chan_compose_v210)
   size_t chan_index_bytes[3] = {0, 0, 0};
   std::vector<struct ph_route *> routes;  // open ROUTEs: a recycled block must not be handed out under a transfer in flight
@@ -92,6 +100,7 @@ struct ph_buf {
   std::atomic<bool> host_dirty;
   std::atomic<bool> lut_dirty;  // host data went into a table-sized buffer since its LDS form was last built
   std::string owner;
+  hipEvent_t mirror_busy = nullptr;  // recorded behind the last asynchronous copy into or out of the mirror (travels with it into the pool)
 };
 
 
@@ -193,7 +202,10 @@ void ctx_unref(ph_ctx *ctx) {
       hipStreamDestroy(ctx->streams[i]);
     }
   for (auto &kv : ctx->pool) hipFree(kv.second);
-  for (auto &kv : ctx->host_pool) hipHostFree(kv.second);
+  for (auto &kv : ctx->host_pool) {
+    hipHostFree(kv.second.p);
+    if (kv.second.busy) hipEventDestroy(kv.second.busy);
+  }
   for (auto &kv : ctx->luts)
     if (kv.second.blob_dev) hipFree(kv.second.blob_dev);
   for (int i = 0; i < 3; ++i)
@@ -341,14 +353,34 @@ int ph_buf_release(ph_buf *b) {
   ph_lut_unregister(ctx, b->dptr);  // the storage goes back to the pool: forget any LUT form of it
   if (b->owned) pool_free(ctx, b->bytes, b->dptr);
   if (b->hptr) {
-    // as with device blocks: whoever releases a buffer has waited for the copies it started on it
-    bool keep = false;
+    // The mirror goes to the pool WITH the event behind its last asynchronous copy (the next owner waits for it).  Over budget the
+    // OLDEST blocks make room - after a format change the pool would otherwise fill with sizes nobody asks for any more and every
+    // new size pay hipHostMalloc / hipHostFree again (~40 ms for a 2160p image); a block larger than the whole budget is freed.
+    std::vector<ph_ctx::HostBlock> victims;
     {
       std::lock_guard<std::mutex> lock(ctx->mu);
-      keep = ctx->host_pooled_bytes + b->bytes <= (size_t)ctx->host_pool_mb << 20;
-      if (keep) ctx->host_pool.emplace(b->bytes, b->hptr), ctx->host_pooled_bytes += b->bytes;
+      const size_t budget = (size_t)ctx->host_pool_mb << 20;
+      if (b->bytes > budget) {
+        victims.push_back(ph_ctx::HostBlock{b->hptr, b->mirror_busy, 0});
+      } else {
+        while (ctx->host_pooled_bytes + b->bytes > budget && !ctx->host_pool.empty()) {
+          auto oldest = ctx->host_pool.begin();
+          for (auto it = ctx->host_pool.begin(); it != ctx->host_pool.end(); ++it)
+            if (it->second.seq < oldest->second.seq) oldest = it;
+          victims.push_back(oldest->second);
+          ctx->host_pooled_bytes -= oldest->first;
+          ctx->host_pool.erase(oldest);
+        }
+        ctx->host_pool.emplace(b->bytes, ph_ctx::HostBlock{b->hptr, b->mirror_busy, ctx->host_pool_seq++});
+        ctx->host_pooled_bytes += b->bytes;
+      }
     }
-    if (!keep) hipHostFree(b->hptr);
+    for (auto &v : victims) {
+      hipHostFree(v.p);  // (waits for copies in flight)
+      if (v.busy) hipEventDestroy(v.busy);
+    }
+  } else if (b->mirror_busy) {
+    hipEventDestroy(b->mirror_busy);
   }
   {
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -370,16 +402,31 @@ int ph_buf_dims(const ph_buf *b, int *w, int *h) {
   return PH_OK;
 }
 
+// an asynchronous copy into or out of b's mirror has just been enqueued on `s`
+static void mirror_mark(ph_buf *b, hipStream_t s) {
+  if (!b->mirror_busy && hipEventCreateWithFlags(&b->mirror_busy, hipEventDisableTiming) != hipSuccess) {
+    b->mirror_busy = nullptr;
+    hipStreamSynchronize(s);  // no event to carry: wait here rather than let the mirror go back to the pool under the copy
+    return;
+  }
+  hipEventRecord(b->mirror_busy, s);
+}
+
 void *ph_buf_host_ptr(ph_buf *b) {
   if (!b) return nullptr;
   if (!b->hptr) {
     {
-      std::lock_guard<std::mutex> lock(b->ctx->mu);
+      std::unique_lock<std::mutex> lock(b->ctx->mu);
       auto it = b->ctx->host_pool.find(b->bytes);
       if (it != b->ctx->host_pool.end()) {
-        b->hptr = it->second;
+        b->hptr = it->second.p;
+        b->mirror_busy = it->second.busy;
         b->ctx->host_pool.erase(it);
         b->ctx->host_pooled_bytes -= b->bytes;
+        lock.unlock();
+        // the previous owner may have released the buffer with a download or an upload of this block still in flight
+        // (release after downloadAsync, before its waitFinish: ADVICE r3); normally the event completed long ago
+        if (b->mirror_busy) hipEventSynchronize(b->mirror_busy);
         return b->hptr;
       }
     }
@@ -407,6 +454,7 @@ int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t by
         PH_HIP(hipStreamSynchronize(s));
         memcpy(b->hptr, src, bytes);
         PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, bytes, hipMemcpyHostToDevice, s));
+        mirror_mark(b, s);
         b->host_dirty = false;
         b->lut_dirty = b->lut_dirty || b->bytes >= 65536 * 4;
       } else {
@@ -416,6 +464,7 @@ int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t by
     case PH_HOST_NONE:
       if (b->host_dirty) {
         PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, b->bytes, hipMemcpyHostToDevice, s));
+        mirror_mark(b, s);
         b->host_dirty = false;
         b->lut_dirty = b->lut_dirty || b->bytes >= 65536 * 4;
       }
@@ -462,7 +511,9 @@ int ph_buf_download_async(ph_buf *b, int queue) {
   int rc = set_device(b->ctx);
   if (rc) return rc;
   if (!ph_buf_host_ptr(b)) return PH_E_HIP;
-  PH_HIP(hipMemcpyAsync(b->hptr, b->dptr, b->bytes, hipMemcpyDeviceToHost, stream_of(b->ctx, queue)));
+  hipStream_t s = stream_of(b->ctx, queue);
+  PH_HIP(hipMemcpyAsync(b->hptr, b->dptr, b->bytes, hipMemcpyDeviceToHost, s));
+  mirror_mark(b, s);
   return PH_OK;
 }
 
@@ -638,6 +689,10 @@ namespace {
 // Buffer lifetime against ROUTE (the source rank's `send(frame); frame.release()`): the pool hands a recycled block out
 // only after the three queues have been ordered behind every transfer enqueued so far.  Device-side waits only, and
 // only while a transfer is really in flight (hipEventQuery).  Called with ctx->mu held.
+// `busy` and `last` change only under ctx->mu (route_mark takes it too): a pool thread that found the old record complete
+// cannot clear the flag after another thread has recorded a new transfer.  A queue that is being captured
+// (ph_graph_begin) is left alone - an event recorded outside the capture cannot be waited for inside it; if a wait cannot
+// be enqueued the host waits for the transfer instead, so a recycled block is never handed out under RCCL's read.
 void order_queues_after_routes(ph_ctx *ctx) {
   for (ph_route *r : ctx->routes) {
     if (!r->busy.load() || !r->last) continue;
@@ -645,10 +700,20 @@ void order_queues_after_routes(ph_ctx *ctx) {
       r->busy.store(false);
       continue;
     }
-    for (int q = 0; q < 3; ++q) hipStreamWaitEvent(ctx->streams[q], r->last, 0);
+    for (int q = 0; q < 3; ++q) {
+      hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(ctx->streams[q], &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) continue;
+      if (hipStreamWaitEvent(ctx->streams[q], r->last, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        hipEventSynchronize(r->last);
+        r->busy.store(false);
+        break;
+      }
+    }
   }
 }
 int route_mark(ph_route *r) {  // a transfer has just been enqueued on the communication stream
+  std::lock_guard<std::mutex> lock(r->ctx->mu);
   PH_HIP(hipEventRecord(r->last, r->stream));
   r->busy.store(true);
   return PH_OK;
@@ -889,7 +954,7 @@ int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
   }
   if (0 == strcmp(name, "host_pool_mb")) {
     if (value < 0) return fail(PH_E_INVALID, "host_pool_mb: a size in MiB");
-    std::vector<void *> drop;
+    std::vector<ph_ctx::HostBlock> drop;
     {
       std::lock_guard<std::mutex> lock(ctx->mu);
       ctx->host_pool_mb = value;
@@ -900,7 +965,10 @@ int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
         ctx->host_pool.erase(it);
       }
     }
-    for (void *p : drop) hipHostFree(p);
+    for (auto &v : drop) {
+      hipHostFree(v.p);
+      if (v.busy) hipEventDestroy(v.busy);
+    }
     return PH_OK;
   }
   return fail(PH_E_INVALID, "unknown option '%s'", name);
@@ -974,7 +1042,9 @@ static int flush_dirty_args(ph_ctx *ctx, const ph_arg *args, int n, int queue) {
     if (args[i].kind != PH_ARG_BUF || !args[i].v.buf) continue;
     ph_buf *b = args[i].v.buf;
     if (b->host_dirty && b->hptr) {
-      PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, b->bytes, hipMemcpyHostToDevice, stream_of(ctx, queue)));
+      hipStream_t s = stream_of(ctx, queue);
+      PH_HIP(hipMemcpyAsync(b->dptr, b->hptr, b->bytes, hipMemcpyHostToDevice, s));
+      mirror_mark(b, s);
       b->host_dirty = false;
       b->lut_dirty = b->lut_dirty || b->bytes >= 65536 * 4;
     }
@@ -1655,7 +1725,9 @@ static int compose_write(ph_ctx *ctx, int queue, int n, const ph_layer *layers, 
                          uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut) {
   if (!ctx || !layers || !out || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_compose_write_v210: NULL argument");
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_compose_write_v210: 1..%d layers", ph::kMaxLayers);
-  if (!out_w || out_w % 48) return fail(PH_E_INVALID, "ph_compose_write_v210: width %u is not a multiple of 48; run the separate kernels", out_w);
+  // (a width that is not a multiple of 48 - 1280 x 720 - goes to the quad-per-lane kernel, which writes the reference's tail quad
+  // and cleared slots, v210.ts:131-136,166-193; the reference's writer serves tails of 2 or 4 pixels)
+  if (!out_w || (out_w & 1)) return fail(PH_E_INVALID, "ph_compose_write_v210: width %u is zero or odd; run the separate kernels", out_w);
   if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_compose_write_v210: interlace must be 0, 1 or 3");
   const ph::LutView *wv = lds_view(ctx, wr_lut);
   if (!wv) return fail(PH_E_INVALID, "ph_compose_write_v210: the writer gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)");

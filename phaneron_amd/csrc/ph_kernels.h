@@ -73,7 +73,10 @@ struct ChanSrc {
 // The channel's frame as a flat program the kernel walks per pixel: one op per source to sample, with what to do with
 // the sample.  A layer without a transition is one op (Layer); a dissolve is Hold (the layer's own source) + Dissolve (the
 // incoming source); a wipe is Hold + Incoming + Wipe (the mask).  kChanActFirst marks the op that completes layer 0.
-enum : uint32_t { kChanActLayer = 0, kChanActHold = 1, kChanActDissolve = 2, kChanActIncoming = 3, kChanActWipe = 4, kChanActFirst = 0x100 };
+enum : uint32_t { kChanActLayer = 0, kChanActHold = 1, kChanActDissolve = 2, kChanActIncoming = 3, kChanActWipe = 4, kChanActFirst = 0x100,
+                  // launcher: a v210 source shown at its own scale, unrotated - neighbouring lanes' taps are neighbouring columns, so a
+                  // lane converts ONE column and takes the other from the lane beside it; bits 12..14: which halo table is the op's
+                  kChanActShare = 0x200, kChanActShareShift = 12 };
 constexpr int kMaxChanOps = 3 * kMaxLayers;
 struct ChanOp {
   ChanSrc src;
@@ -101,6 +104,9 @@ struct ChanArgs {
   // v210 frames of any even width (1280: src/config.ts:43-54): quad slots per line by pitch, and the first column of the line's
   // tail (v210.ts:166-193; 0xFFFFFFFF when the width is a multiple of 6 or the frame is not v210)
   uint32_t out_qpitch, out_tail_from;
+  // tap sharing (launcher): per sharing op and wave step of a workgroup, the converted LEFT column of the step's first lane
+  // (3 rows x rgb = 36 bytes), made by a pass in front of phase 1 and kept in the LDS behind the table
+  uint32_t halo_off, halo_steps;  // byte offset in the LDS; steps per op the area holds (0: no sharing in this launch)
 };
 
 // ph_kernels_up.hip: the 2 x 2-block compositor for magnifying placements

@@ -19,6 +19,8 @@
 //   phase 2 (writer table swapped in): quad per lane, indices -> writer table -> RGB->YCbCr matrix -> packed words.
 // A workgroup reads back only what it wrote itself, so one workgroup barrier (the table swap's) orders the phases.
 // Results are bit-identical to running the separate kernels (tests/test_chan_gpu.py).
+#include <cstdlib>
+
 #include "ph_device.h"
 #include "ph_kernels.h"
 #include "ph_ldslut.h"
@@ -303,9 +305,22 @@ __device__ __forceinline__ void chan_sample_rgb8(const ChanSrc &s, float px, con
 // TAILS: v210 sources may have a width that is not a multiple of 6 (1280 x 720).  The pixels of such a line's tail are unpacked from
 // the same bit positions, but the reference's reader converts them without the matrix's offset column (v210.ts:88-93, `last` of
 // read_px_issue): a tap in a column >= tail_from passes 0.  (The other instantiation has no such sources: the launcher sees to it.)
+// Tap sharing.  A layer shown at its own scale and unrotated (the Mixer's default fill of a full-frame source) has lane l's taps in
+// columns c + l and c + l + 1: every column is converted by two lanes.  With `halo.on` (the launcher found the placement, the
+// pass in front of phase 1 left the step's first left column in the LDS) and the pattern confirmed for this step (ballots), a lane
+// converts its RIGHT column only - three rows for its two stacked pixels - and takes its left column from the lane before it (one
+// DPP wave shift per value; lane 0 from the LDS): 3 conversions and 9 loads per pixel pair instead of 6 and 18.  The values are
+// the same conversions of the same words, so nothing changes in the result.
+struct ChanHalo {
+  bool on;        // uniform
+  uint32_t addr;  // LDS byte address of this step's 9 floats: rows j0, j0 + 1, j0 + 2 of column i0(lane 0), r g b each
+};
+__device__ __forceinline__ float wave_from_prev_lane(float mine, float lane0_gets) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0_gets), __float_as_int(mine), 0x138 /* wave_shr:1: lane i reads lane i - 1 */, 0xf, 0xf, false));
+}
 template <bool STD, bool TAILS>
 __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const float (&py)[kChanP], uint32_t x, const uint32_t (&line)[kChanP],
-                                            const ReadK &k, const LutK &lut, float4 (&out)[kChanP]) {
+                                            const ReadK &k, const LutK &lut, float4 (&out)[kChanP], const ChanHalo halo = ChanHalo{false, 0u}) {
   const bool is_v210 = s.kind == kChanV210;  // uniform
   auto last_of = [&](uint32_t column) __attribute__((always_inline)) { return TAILS ? (column < s.tail_from ? 1.0f : 0.0f) : 1.0f; };
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(s.pitch * s.h), 0x00020000);
@@ -351,6 +366,45 @@ __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const fl
     // rows, not four: six conversions instead of eight.
     static_assert(kChanP == 2, "the row sharing below is written for a pair");
     const bool stacked = __builtin_amdgcn_ballot_w64(!(t[1].i0 == t[0].i0 && t[1].j0 == t[0].j0 + 1u)) == 0;
+    // neighbouring lanes on neighbouring columns, all on the same rows (and lane 0 where the halo pass put it: it ran this very arithmetic)
+    const uint32_t i0_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t[0].i0), j0_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t[0].j0);
+    const bool shared = halo.on && stacked &&
+                        __builtin_amdgcn_ballot_w64(!(t[0].i0 == i0_first + (threadIdx.x & 63u) && t[0].j0 == j0_first)) == 0;
+    if (shared) {
+      const uint32_t c_right = t[0].i0 + 1u;
+      const V210Col cr = v210_col(c_right);
+      const uint32_t c1 = c_right < s.w ? cr.g16 : kOutsideBit;
+      V210Words w3[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const uint32_t row = j0_first + (uint32_t)r;
+        w3[r] = v210_load(rs, (row < s.h ? __umul24(row, s.pitch) : kOutsideBit) + c1, cr);
+      }
+      PxPending pend[3];
+      const float last_r = last_of(c_right);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) pend[r] = v210_issue<STD>(w3[r], cr, k, lut, last_r);
+      // the halo of this step: nine floats at a uniform address (a broadcast read), asked for while the table reads are on their way
+      const __attribute__((address_space(3))) float *hp = (const __attribute__((address_space(3))) float *)(uintptr_t)halo.addr;
+      float h[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) h[i] = hp[i];
+      __builtin_amdgcn_sched_barrier(0);
+      float4 right[3], left[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        right[r] = read_px_finish(pend[r], k);
+        left[r] = make_float4(wave_from_prev_lane(right[r].x, h[3 * r]), wave_from_prev_lane(right[r].y, h[3 * r + 1]),
+                              wave_from_prev_lane(right[r].z, h[3 * r + 2]), 1.0f);
+      }
+      const bool ci0 = t[0].i0 < s.w, ci1 = c_right < s.w;
+#pragma unroll
+      for (int p = 0; p < kChanP; ++p) {
+        const bool ri0 = j0_first + (uint32_t)p < s.h, ri1 = j0_first + (uint32_t)p + 1u < s.h;
+        tap[p][0] = left[p], tap[p][1] = right[p], tap[p][2] = left[p + 1], tap[p][3] = right[p + 1];
+        in[p] = (ci0 && ri0 ? 1u : 0u) | (ci1 && ri0 ? 2u : 0u) | (ci0 && ri1 ? 4u : 0u) | (ci1 && ri1 ? 8u : 0u);
+      }
+    } else {
 #pragma unroll
     for (int p = 0; p < kChanP; ++p) {
       col[p][0] = v210_col(t[p].i0), col[p][1] = v210_col(t[p].i0 + 1u);
@@ -393,6 +447,7 @@ __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const fl
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) tap[1][i] = read_px_finish(pend[i], k);
+    }
     }
     bool some_outside = false;
 #pragma unroll
@@ -499,6 +554,45 @@ __device__ __forceinline__ void chan_apply(const ChanOp &op, const float4 v, Cha
   }
 }
 
+// The pass in front of phase 1 for the ops that share taps (ChanHalo): one lane per (wave step of this workgroup, row) converts the
+// LEFT column of the step's first lane - the one value per row no lane of the step converts - with the arithmetic phase 1 itself
+// uses for that lane (same step -> chunk -> pixel mapping, same chan_taps), and parks r, g, b in the LDS behind the table.
+template <bool STD, bool TAILS>
+__device__ __forceinline__ void chan_halo_pass(const ChanArgs &a, const ChanShare &sh, const ReadK &rk, const LutK &rlut) {
+  if (!a.halo_steps) return;
+  const uint32_t steps = 3u * sh.slots < a.halo_steps ? 3u * sh.slots : a.halo_steps;
+  const float fow = (float)(int)a.out_w, foh = (float)(int)a.out_h;
+  for (int k = 0; k < a.n_ops; ++k) {
+    const ChanOp op = a.op[k];
+    if (!(op.action & kChanActShare)) continue;  // uniform
+    const ChanSrc &s = op.src;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(s.pitch * s.h), 0x00020000);
+    float *const area = reinterpret_cast<float *>(g_lds + a.halo_off) + ((op.action >> kChanActShareShift) & 7u) * a.halo_steps * 9u;
+    for (uint32_t item = threadIdx.x; item < 3u * steps; item += kLdsBlock) {
+      const uint32_t n = item / 3u, r = item - 3u * n;
+      const uint32_t slot = n / 3u, sub = n - 3u * slot;
+      const uint32_t chunk = chan_chunk(a, sh, slot);
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (chunk != ~0u) {
+        uint32_t rp, x0;
+        chan_place(a, sh, chunk, rp, x0);
+        const uint32_t x = x0 + sub * 64u;  // the step's first lane
+        const uint32_t line = a.first_line + 2u * rp * a.line_step;
+        const ChanTaps t = chan_taps(s, (float)(int)x / fow - 0.5f, (float)(int)line / foh - 0.5f);
+        const uint32_t col = t.i0, row = t.j0 + r;
+        if (col < s.w && row < s.h) {
+          const V210Col c = v210_col(col);
+          const V210Words w = v210_load(rs, __umul24(row, s.pitch) + c.g16, c);
+          const PxPending pend = v210_issue<STD>(w, c, rk, rlut, TAILS ? (col < s.tail_from ? 1.0f : 0.0f) : 1.0f);
+          v = read_px_finish(pend, rk);
+        }
+      }
+      area[9u * n + 3u * r] = v.x, area[9u * n + 3u * r + 1u] = v.y, area[9u * n + 3u * r + 2u] = v.z;
+    }
+  }
+  __syncthreads();
+}
+
 template <bool STD, bool PLANAR>
 __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &sh, const ReadK &rk, const LutK &rlut) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -549,7 +643,10 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
         if (cm) chan_sample_planar<false>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, load_read_k(cm, a.rd_gm), rlut, v);
         else chan_sample_planar<STD>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, rk, rlut, v);
       } else {
-        chan_sample<STD, PLANAR>(op.src, px, py, x, line, rk, rlut, v);
+        ChanHalo halo{false, 0u};
+        if ((op.action & kChanActShare) && n < a.halo_steps)  // uniform
+          halo = ChanHalo{true, a.halo_off + (((op.action >> kChanActShareShift) & 7u) * a.halo_steps + n) * 36u};
+        chan_sample<STD, PLANAR>(op.src, px, py, x, line, rk, rlut, v, halo);
       }
 #pragma unroll
       for (int p = 0; p < kChanP; ++p) chan_apply(op, v[p], acc[p]);
@@ -656,8 +753,13 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
   lds_lut_load(a.rd);
   __syncthreads();
   PH_CPHASE(1);
-  if (ycbcr_matrix_is_standard(rk)) chan_phase1<true, PLANAR>(a, sh, rk, rlut);
-  else chan_phase1<false, PLANAR>(a, sh, rk, rlut);
+  if (ycbcr_matrix_is_standard(rk)) {
+    chan_halo_pass<true, PLANAR>(a, sh, rk, rlut);
+    chan_phase1<true, PLANAR>(a, sh, rk, rlut);
+  } else {
+    chan_halo_pass<false, PLANAR>(a, sh, rk, rlut);
+    chan_phase1<false, PLANAR>(a, sh, rk, rlut);
+  }
   PH_CPHASE(2);
   __syncthreads();  // every index of this workgroup has been stored (the barrier drains the stores) and nobody reads the reader table any more
   PH_CPHASE(3);
@@ -716,10 +818,38 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
   b.magic_cpr = cpr > 1 ? (uint32_t)(((1ull << 32) + cpr - 1) / cpr) : 0u;
   b.magic_cpg = (uint32_t)(((1ull << 32) + cpg - 1) / cpg);
   const uint32_t grid = want < num_cus ? want : num_cus;
+  // Tap sharing (ChanHalo): v210 sources shown at their own scale, unrotated and unmirrored - columns and rows advance by one texel
+  // per output pixel (the kernel still confirms the pattern per wave step).  Each such op needs 36 bytes of LDS per wave step of a
+  // workgroup behind the table; ops that do not fit any more go without.
+  uint32_t lds_total = lds;
+  b.halo_steps = 0, b.halo_off = (lds + 15u) & ~15u;
+  static const bool no_share = getenv("PH_CHAN_NO_SHARE") != nullptr;  // A/B runs (tools/chan_bench.py)
+  if (!no_share) {
+    // the most slots any workgroup has (chan_share)
+    uint32_t slots;
+    if ((grid & 7u) == 0) {
+      const uint32_t groups = (chunks + cpg - 1u) / cpg, mine = (groups + 7u) / 8u, vstep = grid >> 3;
+      slots = (mine * cpg + vstep - 1u) / vstep;
+    } else {
+      slots = (chunks + grid - 1u) / grid;
+    }
+    const uint32_t steps = 3u * slots, room = 160u * 1024u > b.halo_off ? 160u * 1024u - b.halo_off : 0u;
+    uint32_t n_share = 0;
+    for (int k = 0; k < b.n_ops && steps; ++k) {
+      const ChanSrc &s = b.op[k].src;
+      if (s.kind != kChanV210 || !s.sampled || s.m[1] != 0.0f || s.m[3] != 0.0f) continue;
+      const float sx = s.m[0] * (float)s.w / (float)a.out_w, sy = s.m[4] * (float)s.h / (float)(a.out_h) * (float)a.line_step;
+      if (!(sx > 0.9999f && sx < 1.0001f && sy > 0.9999f && sy < 1.0001f)) continue;
+      if (n_share == 8u || (n_share + 1u) * steps * 36u > room) break;
+      b.op[k].action |= kChanActShare | (n_share << kChanActShareShift);
+      ++n_share;
+    }
+    if (n_share) b.halo_steps = steps, lds_total = b.halo_off + n_share * steps * 36u;
+  }
   auto go = [&](auto kernel) -> hipError_t {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
     if (e != hipSuccess) return e;
-    kernel<<<grid, kLdsBlock, lds, s>>>(b);
+    kernel<<<grid, kLdsBlock, lds_total, s>>>(b);
     return hipGetLastError();
   };
   switch (a.out_fmt) {  // frames other than v210 are made by the wire-format instantiation, whatever the sources

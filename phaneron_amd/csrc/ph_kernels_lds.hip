@@ -476,11 +476,18 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_kernel(ComposeAr
   const LutK lk = make_lut_k(a.wr);
   lds_lut_load(a.wr);
   __syncthreads();
-  const uint32_t qpl = a.out_w / 6;  // out_w % 48 == 0
+  // A line has `qpl` quad slots by pitch: `full` whole quads, then - widths that are not a multiple of 6 - the tail quad
+  // (v210.ts:169-194), then slots the reference's writer clears (v210.ts:131-136).  Widths in multiples of 48 fill every slot;
+  // this kernel is the one that serves the others (1280 x 720: the launcher sends them here).
+  const uint32_t qpl = (a.out_w + 47u) / 48u * 8u, full = a.out_w / 6u, remain = a.out_w - 6u * full;
   const uint32_t total = qpl * a.lines;
   for (uint32_t f = blockIdx.x * kLdsBlock + threadIdx.x; f < total; f += gridDim.x * kLdsBlock) {
     const uint32_t li = f / qpl, g = f - li * qpl;
     const uint32_t line = a.first_line + li * a.line_step;
+    if (g > full || (g == full && !remain)) {  // past the line's pixels
+      store_stream(reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + g, make_uint4(0u, 0u, 0u, 0u));
+      continue;
+    }
     float acc[24];
 #pragma unroll 1
     for (int l = 0; l < a.n; ++l) {
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_kernel(ComposeAr
       const float py = (float)(int)line / (float)(int)a.out_h - 0.5f;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const int x = 6 * g + j;
+        const int x = 6 * g + j < a.out_w ? (int)(6 * g + j) : (int)a.out_w - 1;  // (the pixels a tail quad does not have: never packed)
         float4 t;
         if (m) {  // transform.ts:53-57
           const float px = (float)x / (float)(int)a.out_w - 0.5f;
@@ -516,6 +523,13 @@ __global__ __launch_bounds__(kLdsBlock) void compose_write_v210_kernel(ComposeAr
     float rgb[18];
 #pragma unroll
     for (int j = 0; j < 6; ++j) rgb[3 * j] = acc[4 * j], rgb[3 * j + 1] = acc[4 * j + 1], rgb[3 * j + 2] = acc[4 * j + 2];
+    if (g == full) {  // the tail: truncated table indices, round() (v210.ts:173-184)
+      float yi[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) yi[i] = lds_lut_index_unit_tail(rgb[i], true);
+      store_stream(reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + g, write_quad_idx_lds_tail(yi, wk, lk, remain));
+      continue;
+    }
     store_stream(reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + g, write_quad_lds(rgb, wk, lk));
   }
 }
@@ -1005,14 +1019,14 @@ hipError_t launch_fused_v210_combine_lds(hipStream_t s, int n, const FusedLdsArg
 }
 
 hipError_t launch_compose_write_v210(hipStream_t s, const ComposeArgs &a, uint32_t num_cus) {
-  const uint32_t total = a.out_w / 6 * a.lines;
+  const uint32_t total = (a.out_w + 47u) / 48u * 8u * a.lines;  // quad slots by pitch
   if (!total) return hipSuccess;
   bool any_wipe = false;
   for (int l = 0; l < a.n; ++l) any_wipe = any_wipe || a.wipe_with[l] != nullptr;
   if (any_wipe && !compose_uses_taps(a)) return hipErrorInvalidValue;  // no other kernel applies the wipes: never drop them silently
   // pixel-per-lane form: needs the staging area behind the table (160 KiB of LDS per workgroup)
   const uint32_t stage_off = (a.wr.bytes + 15u) & ~15u;
-  if (!compose_quad_forced() && compose_stage_fits(a)) {
+  if (!compose_quad_forced() && compose_stage_fits(a) && a.out_w % 48u == 0) {  // (lines with a tail: the quad-per-lane kernel)
     const uint32_t chunks = (a.out_w * a.lines + kComposeChunk - 1) / kComposeChunk;
     const uint32_t want = (chunks + kLdsBlock / 64 - 1) / (kLdsBlock / 64);
     const uint32_t grid = want < num_cus ? want : num_cus;

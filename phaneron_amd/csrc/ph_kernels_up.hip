@@ -306,9 +306,12 @@ __device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, cons
     else half = make_uint2(eu << 20 | from_prev, y1 << 20 | ev << 10 | ey);      // w2, w3 (lane C)
     const bool store = st.live && role != 1u && (dy == 0 || st.li[1] != st.li[0]);
     if (store) {
-      uint2 *dst = reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(st.job ? a.out2 : a.out) + (size_t)st.line[dy] * qpl + st.x0 / 6u) + (role == 2u ? 1 : 0);
-      __builtin_nontemporal_store(half.x, &dst->x);
-      __builtin_nontemporal_store(half.y, &dst->y);
+      // ONE eight-byte store per lane: the wave's lanes A and C then cover their row segment without a gap, every 32-byte sector
+      // written whole and once.  (As two dword stores each instruction wrote every other dword and each sector went out twice,
+      // half filled: WRITE_SIZE 36.7 MB for a 22.1 MB frame, profiles/r03_pmc_up.txt.)
+      typedef uint32_t ph_u2v __attribute__((ext_vector_type(2)));
+      ph_u2v *dst = reinterpret_cast<ph_u2v *>(reinterpret_cast<uint4 *>(st.job ? a.out2 : a.out) + (size_t)st.line[dy] * qpl + st.x0 / 6u) + (role == 2u ? 1 : 0);
+      __builtin_nontemporal_store(ph_u2v{half.x, half.y}, dst);
     }
   }
 }

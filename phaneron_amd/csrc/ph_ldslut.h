@@ -93,6 +93,18 @@ __device__ __forceinline__ float lds_lut_fetch(const LutK &k, float y) {
   const uint32_t a = *(lds_u32_ptr)a_addr;
   const uint32_t d = *(lds_u16_ptr)d_addr;
 #endif
+#if PH_ABLATE & 16
+  // timing experiment only (results unchanged): the five instructions a COMPACT table form would add to every lookup - anchors
+  // interpolated between neighbouring blocks plus a one-byte residual, small enough for reader and writer table to be resident
+  // together: v_and_or_b32 (the position inside the block), v_fma_f32 (its scale), v_sub_f32 (the anchors'
+  // difference), v_fma_f32 (the prediction), and the residual's v_add_u32 on top of the one that is there.  DESIGN.md 5 has what it cost.
+  {
+    uint32_t t;
+    asm volatile("v_and_or_b32 %0, %1, %2, %3\n\tv_fma_f32 %0, %0, %0, %0\n\tv_sub_f32 %0, %0, %1\n\tv_fma_f32 %0, %0, %1, %0\n\tv_add_u32 %0, %0, %2"
+                 : "=&v"(t)
+                 : "v"(a), "v"(d), "v"(a_addr));
+  }
+#endif
   return __uint_as_float(a + d);
 }
 // The same lookup in two halves, for software-pipelined callers: `issue` computes both addresses and starts the
@@ -115,7 +127,17 @@ __device__ __forceinline__ LutPending lds_lut_issue(const LutK &k, float y) {
   return LutPending{*(lds_u32_ptr)a_addr, *(lds_u16_ptr)d_addr};
 #endif
 }
-__device__ __forceinline__ float lds_lut_finish(const LutPending &p) { return __uint_as_float(p.a + p.d); }
+__device__ __forceinline__ float lds_lut_finish(const LutPending &p) {
+#if PH_ABLATE & 16  // timing experiment only: the compact form's five more instructions per lookup (see lds_lut_fetch)
+  {
+    uint32_t t;
+    asm volatile("v_and_or_b32 %0, %1, %2, %1\n\tv_fma_f32 %0, %0, %0, %0\n\tv_sub_f32 %0, %0, %1\n\tv_fma_f32 %0, %0, %1, %0\n\tv_add_u32 %0, %0, %2"
+                 : "=&v"(t)
+                 : "v"(p.a), "v"(p.d));
+  }
+#endif
+  return __uint_as_float(p.a + p.d);
+}
 
 // The rounded, clamped index of a unit-range value as the float M + idx (idx = its low 16 bits).
 __device__ __forceinline__ float lds_lut_index_unit(float t) {

@@ -63,6 +63,43 @@ def test_buffers_are_pooled_and_refcounted(ctx):
     b.release()
 
 
+def test_pinned_mirrors_are_recycled_behind_their_copies_and_evicted_oldest_first(ctx):
+    """A buffer released right after downloadAsync (before its waitFinish) hands its pinned mirror to the pool with the copy
+    possibly still in flight: the next buffer of that size must not see the stale copy land in what it uploads.  And a pool that
+    is over its budget lets the OLDEST blocks go instead of refusing the newcomer (a format change does not pin dead sizes for ever)."""
+    n = 64 << 20
+    old = np.full(n, 0xA5, np.uint8)
+    new = (np.arange(n, dtype=np.uint32) * 2654435761 >> 24).astype(np.uint8)
+    for _ in range(4):
+        a = ctx.create_buffer(n, owner="old")
+        a.host_access("writeonly", capi.QUEUE_LOAD, old)
+        ctx.wait(capi.QUEUE_LOAD)
+        a.download_async(capi.QUEUE_UNLOAD)   # 64 MiB device -> mirror, asynchronous
+        a.release()                           # ... and the mirror is pooled while that copy may still be running
+        b = ctx.create_buffer(n, owner="new")
+        b.host_access("writeonly", capi.QUEUE_LOAD, new)  # fills the recycled mirror, then uploads from it
+        ctx.wait(capi.QUEUE_LOAD)
+        ctx.wait(capi.QUEUE_UNLOAD)
+        b.host()[:] = 0
+        b.host_access("readonly", capi.QUEUE_UNLOAD)
+        assert np.array_equal(b.host(), new)
+        b.release()
+    # eviction: a budget of 8 MiB, blocks of 3 MiB in three sizes - the pool keeps serving, and a block beyond the budget is just freed
+    ctx.set_option("host_pool_mb", 8)
+    try:
+        for size in (3 << 20, (3 << 20) + 4096, (3 << 20) + 8192, 3 << 20, 16 << 20, (3 << 20) + 4096):
+            c = ctx.create_buffer(size)
+            data = (frames.splitmix64(size, 1024) & np.uint64(0xFF)).astype(np.uint8)
+            c.host_access("writeonly", capi.QUEUE_LOAD, data)
+            ctx.wait(capi.QUEUE_LOAD)
+            c.host()[:1024] = 0
+            c.host_access("readonly", capi.QUEUE_UNLOAD)
+            assert np.array_equal(c.host()[:1024], data)
+            c.release()
+    finally:
+        ctx.set_option("host_pool_mb", 1024)
+
+
 def test_host_access_round_trip_and_range_check(ctx):
     data = (frames.splitmix64(77, 4096) & np.uint64(0xFF)).astype(np.uint8)
     b = ctx.create_buffer(4096)

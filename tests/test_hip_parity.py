@@ -410,7 +410,7 @@ def test_fused_pipeline_with_non_standard_matrices(shape):
     assert_bits(hh.host(out, np.uint32), want, shape)
 
 
-@pytest.mark.parametrize("case", ["pip_1080", "upscale2x", "single_layer", "interlaced", "all_direct"])
+@pytest.mark.parametrize("case", ["pip_1080", "upscale2x", "single_layer", "interlaced", "all_direct", "ragged_1280", "ragged_100_field", "ragged_1302"])
 def test_compose_write_vs_oracle_chain(case, lut_path):
     """ph_compose_write_v210 == transform x N -> combine_N -> v210 write of the oracle."""
     import torch
@@ -429,6 +429,15 @@ def test_compose_write_vs_oracle_chain(case, lut_path):
     elif case == "single_layer":
         ow, oh, il = 192, 40, 0
         specs = [(96, 20, dict(flip_h=True))]
+    elif case == "ragged_1280":  # 720p50's width: a tail quad of two pixels and two cleared slots on every line (v210.ts:131-136,166-193)
+        ow, oh, il = 1280, 18, 0
+        specs = [(1280, 18, None), (640, 9, dict(scale_x=0.5, scale_y=0.5, offset_x=0.25)), (1280, 18, dict(rotate=0.03))]
+    elif case == "ragged_100_field":  # a tail of four pixels, one field
+        ow, oh, il = 100, 12, 3
+        specs = [(100, 12, None), (50, 6, dict(scale_x=0.8, scale_y=0.8))]
+    elif case == "ragged_1302":  # whole quads only, then cleared slots
+        ow, oh, il = 1302, 5, 0
+        specs = [(1302, 5, {})]
     elif case == "all_direct":  # no layer sampled: the one-load-per-layer variant of the kernel
         ow, oh, il = 480, 50, 1
         specs = [(480, 50, None) for _ in range(3)]

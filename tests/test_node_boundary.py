@@ -598,6 +598,19 @@ def test_channel_js_equals_the_reference_valves_frame_for_frame(tmp_path):
 
 
 @needs_node
+def test_recording_context_is_the_default():
+    """`new clContext()` - what src/index.ts:94-107 writes - records; `deferred: false` or PHANERON_DEFERRED=0 gives launch-as-posted"""
+    js = ("const { clContext } = require('%s'); delete process.env.PHANERON_DEFERRED;"
+          "const out = [new clContext().deferred, new clContext({ deferred: false }).deferred];"
+          "process.env.PHANERON_DEFERRED = '0'; out.push(new clContext().deferred, new clContext({ deferred: true }).deferred);"
+          "process.env.PHANERON_DEFERRED = '1'; out.push(new clContext().deferred);"
+          "console.log(JSON.stringify(out))") % os.path.join(ROOT, "node", "index.js")
+    r = subprocess.run([NODE, "-e", js], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == [True, False, False, True, True]
+
+
+@needs_node
 @pytest.mark.gpu
 def test_recording_context_gives_the_same_frames_with_one_launch_per_frame():
     """node/defer.js (new clContext({deferred: true})): operator-by-operator job streams shaped like the valves' - fresh
