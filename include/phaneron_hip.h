@@ -438,7 +438,9 @@ int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *lay
                          const void *rd_gamut9, const void *wr_col_matrix12, const void *wr_gamma_lut);
 /* The same with the packed frame in another wire format - FromRGBA with the Writers of the reference's other consumers: rgba8 / bgra8
  * (the screen, screenConsumer.ts:131; alpha 255, no writer matrix: wr_col_matrix12 may be NULL), yuv422p8 (an encoder,
- * ffmpegConsumer.ts:144) and yuv422p10; out_planes as ph_pack_plane_bytes(out_format, ...) sizes them.  PH_FMT_V210 = the call above. */
+ * ffmpegConsumer.ts:144), yuv422p10, and the 4:2:0 formats yuv420p / nv12 (yuv420p.ts:150-216, nv12.ts:139-196: chroma from the upper
+ * line of a line pair; even heights; nv12: out_planes[1] is the interleaved CbCr plane); out_planes as ph_pack_plane_bytes(out_format,
+ * ...) sizes them.  PH_FMT_V210 = the call above. */
 int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, int out_format, void *const out_planes[3],
                     uint32_t out_width, uint32_t out_height, uint32_t interlace, const void *rd_col_matrix12, const void *rd_gamma_lut,
                     const void *rd_gamut9, const void *wr_col_matrix12, const void *wr_gamma_lut);

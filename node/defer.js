@@ -63,6 +63,7 @@ class Deferral {
 		this.launchedOn = new Map() // queue -> number of launches made on it
 		this.orderedAt = new Map() // `${waiter}<${signal}` -> the signal queue's launch count the waiter is ordered behind
 		this.stats = { recorded: 0, launched: 0, fused: 0, fusedNodes: 0, plain: 0, dropped: 0, fallbacks: 0, lastFallback: null }
+		this.fieldTwin = new WeakMap() // a de-interlaced field image -> the other field of the same frame (set by the pair launch that made both)
 	}
 
 	// ---- bookkeeping on buffers -----------------------------------------------------------------------------
@@ -360,14 +361,52 @@ class Deferral {
 			if (!this._try(this._program(`v210_yadif_pair_${g.length}`, e0.w, e0.h), params, e0.nodes[0].queue)) continue
 			this.stats.fused++
 			this.stats.fusedNodes += 2 * g.length
-			for (const e of g) for (const y of e.nodes) this._retire(y, 'done')
+			for (const e of g) {
+				this.fieldTwin.set(e.out[0], e.out[1])
+				this.fieldTwin.set(e.out[1], e.out[0])
+				for (const y of e.nodes) this._retire(y, 'done')
+			}
 		}
+	}
+
+	// The OTHER field of a de-interlaced frame, if its chain is recorded too: a pending `write` of the same kind whose frame is
+	// [combine_N of] transforms - the same placements - of the twin images of this frame's layers (fieldTwin).  Both fields then go to
+	// the device as ONE compose_up_write_v210 launch (ph_compose_up_write_v210_pair: one table load, one partly filled last round of
+	// wave steps instead of two).  layers: this frame's, as _fused found them ({ source, matrix }).
+	_twinWrite(node, layers) {
+		const n = layers.length
+		const first = this.fieldTwin.get(layers[0].source)
+		if (!first || !first._readers) return null
+		const sameWrite = (w) => w !== node && w.state === 'pending' && w.program.name === 'write' && w.program.format === node.program.format &&
+			w.program.workItemsPerGroup === node.program.workItemsPerGroup && w.program.globalWorkItems[0] === node.program.globalWorkItems[0] &&
+			(w.params.interlace || 0) === (node.params.interlace || 0) && w.params.output && w.params.output !== node.params.output &&
+			Deferral.same(w.params.colMatrix, node.params.colMatrix) && Deferral.same(w.params.gammaLut, node.params.gammaLut)
+		const placedTwin = (img, l) => { // img: a layer of the other frame; l: this frame's layer in that position
+			const p = img && img._producer
+			return p && p.state === 'pending' && p.program.name === 'transform' && p.params.input === this.fieldTwin.get(l.source) &&
+				Deferral.same(p.params.transformMatrix, l.matrix) ? p : null
+		}
+		for (const t of first._readers) {
+			if (!placedTwin(t.params && t.params.output, layers[0])) continue
+			for (const c of t.params.output._readers) {
+				let write = null
+				let images = null
+				if (n === 1 && sameWrite(c)) { write = c; images = [t.params.output] }
+				else if (n > 1 && c.state === 'pending' && c.program.name === `combine_${n}` && c.params.output) {
+					images = LAYER_PREFIX.slice(0, n).map((p) => c.params[sourceKeys(p).In])
+					for (const w of c.params.output._readers) if (sameWrite(w) && w.params.input === c.params.output) write = w
+				}
+				if (!write || images.some((im, i) => !placedTwin(im, layers[i]))) continue
+				return { node: write, output: write.params.output, sources: layers.map((l) => this.fieldTwin.get(l.source)) }
+			}
+		}
+		return null
 	}
 
 	// node: a pending v210 `write`.  true = the frame has been produced by one fused launch
 	_fused(node) {
 		// FromRGBA with a Writer whose frame the channel kernel can make: v210 (SDI), yuv422p8 / yuv422p10 (an encoder), rgba8 / bgra8 (the screen)
-		const OUT = { v210: 0, yuv422p10: 1, yuv422p8: 2, rgba8: 5, bgra8: 6 }
+		const OUT = { v210: 0, yuv422p10: 1, yuv422p8: 2, yuv420p: 3, nv12: 4, rgba8: 5, bgra8: 6 }
 		if (node.program.name !== 'write' || OUT[node.program.format] === undefined) return false
 		const outFmt = OUT[node.program.format]
 		const outRgb8 = outFmt >= 5
@@ -379,10 +418,12 @@ class Deferral {
 		const height = dims.height
 		const interlace = node.params.interlace || 0
 		const geo = Deferral._frameOf(node)
-		if (geo.width !== width || geo.lines !== (interlace ? height / 2 : height)) return false
-		const output = outFmt === 1 || outFmt === 2 ? node.params.outputY : node.params.output
+		// (a 4:2:0 Writer's work groups are line PAIRS whatever the field mode: yuv420p.ts:381 - its geometry gives the whole height)
+		if (geo.width !== width || geo.lines !== (interlace && outFmt !== 3 && outFmt !== 4 ? height / 2 : height)) return false
+		const planarOut = outFmt >= 1 && outFmt <= 4 // planes: Y, U, V - nv12: Y and the interleaved CbCr plane (nv12.ts:374)
+		const output = planarOut ? node.params.outputY : node.params.output
 		if (!output || (!outRgb8 && !node.params.colMatrix) || !node.params.gammaLut) return false
-		if ((outFmt === 1 || outFmt === 2) && (!node.params.outputU || !node.params.outputV)) return false
+		if (planarOut && (outFmt === 4 ? !node.params.outputC : !node.params.outputU || !node.params.outputV)) return false
 
 		let layerImages = [image]
 		const m = /^combine_(\d+)$/.exec(top.program.name)
@@ -490,7 +531,7 @@ class Deferral {
 		if (!used.size) return false // every layer is a finished image taken as it is: the recorded write is as good
 		const saver = { outGammaLut: node.params.gammaLut }
 		if (!outRgb8) saver.outColMatrix = node.params.colMatrix
-		if (outFmt) Object.assign(saver, { outPacking: outFmt }, outFmt < 5 ? { outputU: node.params.outputU, outputV: node.params.outputV } : {})
+		if (outFmt) Object.assign(saver, { outPacking: outFmt }, outFmt === 4 ? { outputC: node.params.outputC } : outFmt < 5 ? { outputU: node.params.outputU, outputV: node.params.outputV } : {})
 		const candidates = [] // [program name, params], best first; the library refuses the shapes a kernel does not take
 		if (!outFmt && !interlace && layers.every((l) => l.v210 && !l.planar && !l.matrix && !l.transition)) {
 			const params = Object.assign({ output }, reader, saver)
@@ -500,6 +541,12 @@ class Deferral {
 		if (!outFmt && !anyV210 && layers.every((l) => l.matrix && !l.transition)) { // finished images, placed: enlarged ones share their taps
 			const params = Object.assign({ output, interlace }, saver)
 			layers.forEach((l, i) => { params[`l${i}In`] = l.source; params[`l${i}Matrix`] = l.matrix })
+			const twin = this._twinWrite(node, layers) // the frame's other field, recorded too: both in one launch
+			if (twin) {
+				const both = Object.assign({ output2: twin.output }, params)
+				twin.sources.forEach((im, i) => { both[`l${i}In2`] = im })
+				candidates.push([`compose_up_write_v210_${n}`, both, twin])
+			}
 			candidates.push([`compose_up_write_v210_${n}`, params])
 		}
 		// the channel kernel wants a whole Loader recipe even if no layer turns out to need its YCbCr matrix (packed RGB and image layers only)
@@ -533,8 +580,14 @@ class Deferral {
 			candidates.push([`chan_compose_v210_${n}`, params])
 		}
 		let done = false
-		for (const [name, params] of candidates) {
-			if (this._try(this._program(name, width, height), params, node.queue)) { done = true; break }
+		for (const [name, params, twin] of candidates) {
+			if (!this._try(this._program(name, width, height), params, node.queue)) continue
+			done = true
+			if (twin && twin.node.state === 'pending') { // the other field's frame came out of the same launch
+				this.stats.fusedNodes += 1 + (n > 1 ? 1 : 0) + n
+				this._retire(twin.node, 'done')
+			}
+			break
 		}
 		if (!done) return false
 		this.stats.fused++

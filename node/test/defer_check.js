@@ -176,11 +176,34 @@ function rig() {
 		outs.push(out)
 	}
 	r.d.touch(outs[0], 'readonly', 2)
-	expect('pair launch, then the tap-sharing compositor for the finished image', r.names(), ['v210_yadif_pair_1', 'compose_up_write_v210_1'])
-	r.native.refuse = (name) => name !== 'write' && name !== 'transform'
+	expect('pair launch, then the tap-sharing compositor for BOTH fields of the frame in one launch (the other field\'s chain is recorded too)',
+		r.launches.map((l) => [l[0], /output2/.test(l[2]), /l0In2/.test(l[2])]), [['v210_yadif_pair_1', false, false], ['compose_up_write_v210_1', true, true]])
 	r.d.touch(outs[1], 'readonly', 2)
-	expect('refused fused launches: the jobs as recorded', r.names().slice(2), ['transform', 'write'])
-	expect('fallbacks counted', r.d.stats.fallbacks, 2)
+	expect('the second field has been made already', r.names().length, 2)
+	expect('nothing pending but the recipes of images their owners still hold', Array.from(r.d.pending).map((nd) => nd.program.name).sort(), ['read', 'read', 'read', 'transform', 'transform'])
+}
+// 5b. the same, refused: first the two-field form, then the single one, then the jobs as recorded; the other field likewise
+{
+	const r = rig()
+	const L = r.loader()
+	const win = [0, 1, 2].map((i) => { const im = r.image(`w${i}`); r.d.record(r.P.read, Object.assign({ input: r.v210(`s${i}`), output: im, width: r.W }, L), 1); return im })
+	const m = r.buffer(48, undefined, 'matrix')
+	const outs = []
+	for (const parity of [0, 1]) {
+		const y = r.image(`y${parity}`)
+		r.d.record(r.P.yadif, { prev: win[0], cur: win[1], next: win[2], parity, tff: 1, skipSpatial: 0, output: y }, 1)
+		const t = r.image(`t${parity}`)
+		r.d.record(r.P.transform, { input: y, transformMatrix: m, output: t }, 1)
+		const out = r.v210(`out${parity}`)
+		r.d.record(r.P.write, Object.assign({ input: t, output: out, width: r.W, interlace: 0 }, r.saver), 1)
+		outs.push(out)
+	}
+	r.native.refuse = (name) => name !== 'write' && name !== 'transform' && name !== 'v210_yadif_pair_1'
+	r.d.touch(outs[0], 'readonly', 2)
+	expect('refused fused launches: the jobs as recorded', r.names(), ['v210_yadif_pair_1', 'transform', 'write'])
+	expect('fallbacks counted: the pair form, the single form, the channel kernel', r.d.stats.fallbacks, 3)
+	r.d.touch(outs[1], 'readonly', 2)
+	expect('the other field: as recorded too', r.names().slice(3), ['transform', 'write'])
 }
 
 // 6. a packed frame made on the device and read back (write -> read -> write): the fused launch reads `mid` itself, so the job

@@ -40,7 +40,7 @@ async function side(deferred) {
 	s.write = await rig.pack('v210', W, H, '709', false)
 	s.writeField = await rig.pack('v210', W, H, '709', true)
 	s.writeAs = {}
-	for (const fmt of ['rgba8', 'bgra8', 'yuv422p8', 'yuv422p10']) s.writeAs[fmt] = await rig.pack(fmt, W, H, '709', false)
+	for (const fmt of ['rgba8', 'bgra8', 'yuv422p8', 'yuv422p10', 'yuv420p', 'nv12']) s.writeAs[fmt] = await rig.pack(fmt, W, H, '709', false)
 	s.combine = {}
 	for (const n of [2, 3, 4]) s.combine[n] = await rig.combine(n, W, H)
 	s.transform = await rig.transform(W, H)
@@ -355,6 +355,48 @@ async function main() {
 		return seen
 	}, { fused: 3, plain: 0, launched: 3, fallbacks: 0 })
 
+	// the same with BOTH fields' chains posted before the first frame is asked for (a consumer that takes frames in pairs, or one
+	// that runs a frame behind): the de-interlacing reader's pair launch, then both fields' compositors in ONE launch
+	await scenario('de-interlaced layers enlarged 2x, both fields posted before either is consumed', async (s) => {
+		s.frame = 5
+		const L = 3
+		const u = []
+		const srcs = []
+		for (let l = 0; l < L; ++l) {
+			u.push([])
+			for (let i = 0; i < 3; ++i) {
+				const src = await s.source(v210Frame(half, 650 + 10 * l + i), W / 2, H / 2)
+				const im = await s.rig.image(W / 2, H / 2)
+				await s.rig.run(s.readHalf([src], im))
+				srcs.push(src)
+				u[l].push(im)
+			}
+		}
+		const fill = await s.transform.matrix({})
+		const outs = []
+		for (const second of [0, 1]) {
+			const placed = []
+			for (let l = 0; l < L; ++l) {
+				const y = await s.rig.image(W / 2, H / 2)
+				await s.rig.run(s.yadifHalf(u[l][0], u[l][1], u[l][2], y, { parity: second ? 1 : 0, tff: 1, skipSpatial: 0 }))
+				const im = await s.rig.image(W, H)
+				await s.rig.run(s.transform(y, im, fill))
+				y.release()
+				placed.push(im)
+			}
+			const comb = await s.rig.image(W, H)
+			await s.rig.run(s.combine[3](placed, comb))
+			const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+			await s.rig.run(s.write(comb, [out], 0))
+			;[...placed, comb].forEach((x) => x.release())
+			outs.push(out)
+		}
+		const seen = []
+		for (const out of outs) { seen.push(await s.consume(out)); out.release() }
+		;[...srcs, ...u.flat()].forEach((x) => x.release())
+		return seen
+	}, { fused: 2, plain: 0, launched: 2, fallbacks: 0 })
+
 	// finished images only, one of them rotated: the tap-sharing compositor declines, the channel kernel takes them
 	await scenario('finished images, placed and rotated', async (s) => {
 		s.frame = 6
@@ -434,7 +476,7 @@ async function main() {
 	await scenario('frames for the screen and for an encoder', async (s) => {
 		s.frame = 10
 		const seen = []
-		for (const fmt of ['rgba8', 'yuv422p8', 'bgra8', 'yuv422p10']) {
+		for (const fmt of ['rgba8', 'yuv422p8', 'bgra8', 'yuv422p10', 'yuv420p', 'nv12']) { // (the last two: 4:2:0 frames, chroma from the upper line of a pair)
 			const a = await s.source(v210Frame(full, 1000))
 			const b = await s.sourcePlanar('yuv420p', 1001)
 			const ua = await s.rig.image(W, H)
@@ -452,7 +494,7 @@ async function main() {
 			s.frame++
 		}
 		return seen
-	}, { fused: 4, plain: 0, launched: 4, fallbacks: 0 })
+	}, { fused: 6, plain: 0, launched: 6, fallbacks: 0 })
 
 	// interlaced file sources: windows of planar 4:2:2 frames (yuv422p10, yuv422p8), both fields de-interlaced, placed, packed
 	await scenario('interlaced file sources: planar windows de-interlaced', async (s) => {

@@ -1287,8 +1287,8 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
         if (layers[i].transition != PH_TRANSITION_CUT) TRY(source(i, "Incoming", &layers[i].incoming));
         if (layers[i].transition == PH_TRANSITION_WIPE) TRY(source(i, "Mask", &layers[i].mask));
       }
-      // output: the packed frame - v210, or with outPacking = PH_FMT_* another wire format: 1 yuv422p10 / 2 yuv422p8 (output = the Y plane,
-      // outputU, outputV), 5 rgba8 / 6 bgra8 (no outColMatrix)
+      // output: the packed frame - v210, or with outPacking = PH_FMT_* another wire format: 1 yuv422p10 / 2 yuv422p8 / 3 yuv420p (output =
+      // the Y plane, outputU, outputV), 4 nv12 (output, outputC), 5 rgba8 / 6 bgra8 (no outColMatrix)
       double interlace = 0, out_packing = 0;
       ph_buf *wcm = nullptr, *wl = nullptr, *ou = nullptr, *ov = nullptr;
       if (find_arg(args, n, "outPacking")) TRY(need_num(args, n, "outPacking", &out_packing));
@@ -1296,9 +1296,11 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       size_t opb[3] = {0, 0, 0};
       if (ph_pack_plane_bytes(ofmt, width, height, opb) < 0) return fail(PH_E_INVALID, "kernel argument 'outPacking': %g is not a pack format", out_packing);
       TRY(need_buf(args, n, "output", opb[0], &o));
-      if (ofmt == PH_FMT_YUV422P10 || ofmt == PH_FMT_YUV422P8) {
+      if (ofmt == PH_FMT_YUV422P10 || ofmt == PH_FMT_YUV422P8 || ofmt == PH_FMT_YUV420P) {
         TRY(need_buf(args, n, "outputU", opb[1], &ou));
         TRY(need_buf(args, n, "outputV", opb[2], &ov));
+      } else if (ofmt == PH_FMT_NV12) {  // nv12.ts:374: the interleaved CbCr plane is `outputC`
+        TRY(need_buf(args, n, "outputC", opb[1], &ou));
       }
       TRY(need_buf(args, n, "colMatrix", 48, &b));
       TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
@@ -1319,13 +1321,27 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
       double rgb = 0, interlace = 0;
       if (find_arg(args, n, "packedRgb")) TRY(need_num(args, n, "packedRgb", &rgb));
-      ph_image_layer layers[ph::kMaxLayers];
+      // output2 + l<i>In2 (optional): a second job of the same shape in the same launch - the other field of a de-interlaced frame
+      // (ph_compose_up_write_v210_pair): same sizes, formats and placements, other data
+      const bool pair = find_arg(args, n, "output2") != nullptr;
+      ph_image_layer layers[ph::kMaxLayers], layers2[ph::kMaxLayers];
       for (int i = 0; i < prog->n_layers; ++i) {
         char nm[24];
-        ph_buf *x = nullptr, *m = nullptr;
+        ph_buf *x = nullptr, *m = nullptr, *x2 = nullptr;
         double lw = 0, lh = 0;
         snprintf(nm, sizeof nm, "l%dIn", i);
         TRY(need_buf(args, n, nm, 0, &x));
+        if (pair) {
+          snprintf(nm, sizeof nm, "l%dIn2", i);
+          TRY(need_buf(args, n, nm, x->bytes, &x2));
+          if (rgb == 0) {
+            int w2, h2, w1, h1;
+            TRY(need_image(x2, nm, &w2, &h2));
+            TRY(need_image(x, nm, &w1, &h1));
+            if (w1 != w2 || h1 != h2) return fail(PH_E_INVALID, "kernel argument '%s': the second job's image is %dx%d, the first's %dx%d", nm, w2, h2, w1, h1);
+          }
+          snprintf(nm, sizeof nm, "l%dIn", i);
+        }
         if (rgb != 0) {
           snprintf(nm, sizeof nm, "l%dWidth", i);
           TRY(need_num(args, n, nm, &lw));
@@ -1342,14 +1358,20 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
         if (!m->hptr) return fail(PH_E_INVALID, "kernel argument '%s': the matrix must have been written through hostAccess (its host copy is what the launch reads)", nm);
         layers[i].data = x->dptr, layers[i].format = rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32;
         layers[i].width = (int)lw, layers[i].height = (int)lh, layers[i].matrix9_host = (const float *)m->hptr;
+        layers2[i] = layers[i];
+        if (pair) layers2[i].data = x2->dptr;
       }
-      ph_buf *wcm = nullptr, *wl = nullptr;
+      ph_buf *wcm = nullptr, *wl = nullptr, *o2 = nullptr;
       TRY(need_buf(args, n, "output", (size_t)ph_v210_pitch_bytes(width) * height, &o));
+      if (pair) TRY(need_buf(args, n, "output2", (size_t)ph_v210_pitch_bytes(width) * height, &o2));
       TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
       TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
       if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
       if (!check_only) refresh_buf_lut(ctx, wl);
-      return check_only ? PH_OK : ph_compose_up_write_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
+      if (check_only) return PH_OK;
+      if (pair)
+        return ph_compose_up_write_v210_pair(ctx, queue, prog->n_layers, layers, layers2, o->dptr, o2->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
+      return ph_compose_up_write_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
     }
     case K_COMPOSE_V210: {
       // l<i>In: RGBA image; l<i>Matrix (optional): its 3x3 placement, absent = taken 1:1; l<i>WipeIn + l<i>WipeMask (optional):
@@ -1808,11 +1830,14 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
                     const void *wr_lut) {
   if (!ctx || !layers || !out_planes || !out_planes[0] || !rd_cm || !rd_lut || !rd_gm || !wr_lut) return fail(PH_E_INVALID, "ph_chan_compose_v210: NULL argument");
   void *const out = out_planes[0];
-  const bool out_rgb8 = out_format == PH_FMT_RGBA8 || out_format == PH_FMT_BGRA8, out_planar = out_format == PH_FMT_YUV422P10 || out_format == PH_FMT_YUV422P8;
+  const bool out_rgb8 = out_format == PH_FMT_RGBA8 || out_format == PH_FMT_BGRA8, out_420 = out_format == PH_FMT_YUV420P || out_format == PH_FMT_NV12;
+  const bool out_planar = out_format == PH_FMT_YUV422P10 || out_format == PH_FMT_YUV422P8 || out_420;
   if (out_format != PH_FMT_V210 && !out_rgb8 && !out_planar)
-    return fail(PH_E_INVALID, "ph_chan_compose_v210: output format %d (v210, yuv422p10, yuv422p8, rgba8 or bgra8; run the separate kernels for the others)", out_format);
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: output format %d is not a PH_FMT_*", out_format);
   if (!out_rgb8 && !wr_cm) return fail(PH_E_INVALID, "ph_chan_compose_v210: the writer's RGB -> YCbCr matrix is missing");
-  if (out_planar && (!out_planes[1] || !out_planes[2])) return fail(PH_E_INVALID, "ph_chan_compose_v210: a planar output needs its three planes");
+  if (out_planar && (!out_planes[1] || (out_format != PH_FMT_NV12 && !out_planes[2])))
+    return fail(PH_E_INVALID, "ph_chan_compose_v210: a planar output needs its three planes (nv12: Y and the interleaved CbCr plane)");
+  if (out_420 && (out_h & 1)) return fail(PH_E_INVALID, "ph_chan_compose_v210: a 4:2:0 frame needs an even height (%u)", out_h);
   PH_QUEUE("ph_chan_compose_v210", queue);
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_chan_compose_v210: 1..%d layers", ph::kMaxLayers);
   // A v210 line of a width that is not a multiple of 48 (1280 x 720, src/config.ts:43-54) ends in a padded block: whole quads, the

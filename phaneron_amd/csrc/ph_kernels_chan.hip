@@ -691,8 +691,11 @@ __device__ __forceinline__ void chan_phase2_other(const ChanArgs &a, const ChanS
     return;
   }
   // planar 4:2:2 (yuv422p10.ts:140-189, yuv422p8.ts): eight pixels per lane - chroma from the even pixels, codes rounded to 16 bits and
-  // cut to the sample width on store (widths are multiples of 8 here: no tail group)
-  constexpr bool WIDE = OUT == 1;
+  // cut to the sample width on store (widths are multiples of 8 here: no tail group).
+  // 4:2:0 (yuv420p.ts:150-216, nv12.ts:139-196): the same luma; a chroma line serves a line PAIR and is taken from the pair's upper
+  // line only (`if (l == 0)`) - a field write makes one line per pair, which then is the one that gives the chroma; nv12 keeps Cb and
+  // Cr interleaved in one plane (out_u).
+  constexpr bool WIDE = OUT == 1, V420 = OUT == 3 || OUT == 4, NV12 = OUT == 4;
   constexpr uint32_t kGroups = kChanChunk / 8u;  // per chunk row
   for (uint32_t t = threadIdx.x; t < 2u * kGroups * sh.slots; t += kLdsBlock) {
     const uint32_t slot = t / (2u * kGroups), within = t - slot * (2u * kGroups);
@@ -722,7 +725,24 @@ __device__ __forceinline__ void chan_phase2_other(const ChanArgs &a, const ChanS
     }
     const uint32_t line = a.first_line + li * a.line_step;
     const size_t o8 = ((size_t)line * a.out_pitch + x) >> 3;
-    if (WIDE) {
+    if (V420) {
+      uint2 wy;
+      wy.x = (y[0] & 0xff) | (y[1] & 0xff) << 8 | (y[2] & 0xff) << 16 | y[3] << 24;
+      wy.y = (y[4] & 0xff) | (y[5] & 0xff) << 8 | (y[6] & 0xff) << 16 | y[7] << 24;
+      reinterpret_cast<uint2 *>(a.out)[o8] = wy;
+      if (a.line_step == 2u || !(line & 1u)) {  // the line that gives its pair the chroma
+        const size_t c8 = ((size_t)(line >> 1) * a.out_pitch + x) >> 3;
+        if (NV12) {
+          uint2 wc;
+          wc.x = (u[0] & 0xff) | (v[0] & 0xff) << 8 | (u[1] & 0xff) << 16 | v[1] << 24;
+          wc.y = (u[2] & 0xff) | (v[2] & 0xff) << 8 | (u[3] & 0xff) << 16 | v[3] << 24;
+          reinterpret_cast<uint2 *>(a.out_u)[c8] = wc;
+        } else {
+          reinterpret_cast<uint32_t *>(a.out_u)[c8] = (u[0] & 0xff) | (u[1] & 0xff) << 8 | (u[2] & 0xff) << 16 | u[3] << 24;
+          reinterpret_cast<uint32_t *>(a.out_v)[c8] = (v[0] & 0xff) | (v[1] & 0xff) << 8 | (v[2] & 0xff) << 16 | v[3] << 24;
+        }
+      }
+    } else if (WIDE) {
       uint4 wy;
       wy.x = (y[0] & 0xffff) | y[1] << 16, wy.y = (y[2] & 0xffff) | y[3] << 16, wy.z = (y[4] & 0xffff) | y[5] << 16, wy.w = (y[6] & 0xffff) | y[7] << 16;
       store_stream(reinterpret_cast<uint4 *>(a.out) + o8, wy);
@@ -856,6 +876,8 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
     case 0: return a.planar ? go(chan_compose_v210_kernel<true, 0>) : go(chan_compose_v210_kernel<false, 0>);
     case 1: return go(chan_compose_v210_kernel<true, 1>);
     case 2: return go(chan_compose_v210_kernel<true, 2>);
+    case 3: return go(chan_compose_v210_kernel<true, 3>);
+    case 4: return go(chan_compose_v210_kernel<true, 4>);
     case 5: return go(chan_compose_v210_kernel<true, 5>);
     case 6: return go(chan_compose_v210_kernel<true, 6>);
   }

@@ -60,7 +60,7 @@ def test_default_line_as_the_driver_runs_it():
     line = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2"])
     check_line(line, 1, 20, 5)
     assert line["roofline"]["valu"]["frac"] > 0.2
-    assert [s["config"][0] for s in line["secondary"]] == ["2", "3"]
+    assert [s["config"][0] for s in line["secondary"]] == ["2", "7", "7", "3"]  # configs 2 and 3, and 720p50 (the reference's third format) twice
     for s in line["secondary"]:
         assert 0 < s["roofline"]["frac"] < 1
     cb = line["cpu_baseline"]

@@ -408,12 +408,13 @@ def placed_and_combined(layers, ow, oh, rd_o):
     return placed[0] if len(placed) == 1 else orc.combine(placed)
 
 
-@pytest.mark.parametrize("fmt", ["rgba8", "bgra8", "yuv422p8", "yuv422p10"])
+@pytest.mark.parametrize("fmt", ["rgba8", "bgra8", "yuv422p8", "yuv422p10", "yuv420p", "nv12"])
 @pytest.mark.parametrize("interlace", [0, 1, 3])
 def test_other_output_formats(fmt, interlace):
     """the channel's packed frame in the formats of the reference's other consumers - rgba8 / bgra8 for the screen
-    (screenConsumer.ts:131), yuv422p8 for an encoder (ffmpegConsumer.ts:144), yuv422p10 - whole frames and single fields (the other
-    field's lines stay as they were), from v210, planar and graphics sources: against the oracle's chain ending in that format's writer"""
+    (screenConsumer.ts:131), yuv422p8 for an encoder (ffmpegConsumer.ts:144), yuv422p10, and the 4:2:0 Writers (yuv420p.ts, nv12.ts:
+    chroma from the upper line of a line pair) - whole frames and single fields (the other field's lines stay as they were), from
+    v210, planar and graphics sources: against the oracle's chain ending in that format's writer"""
     import torch
     import hip_harness as hh
     from phaneron_amd import capi
@@ -484,7 +485,7 @@ def test_ragged_sources_on_regular_outputs_and_the_other_way_round():
     check(layers, ow, oh, "HD sources, an image, a wipe and a dissolve on a 1280 channel", specs=("709", "2020"), poison_dst=True)
 
 
-@pytest.mark.parametrize("fmt", ["rgba8", "bgra8", "yuv422p8", "yuv422p10"])
+@pytest.mark.parametrize("fmt", ["rgba8", "bgra8", "yuv422p8", "yuv422p10", "yuv420p", "nv12"])
 def test_other_output_formats_at_1280(fmt):
     """the screen's and an encoder's frames of a 1280-wide channel (widths in multiples of 8 for the planar writers)"""
     w, h = 1280, 12

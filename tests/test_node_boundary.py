@@ -623,7 +623,7 @@ def test_recording_context_gives_the_same_frames_with_one_launch_per_frame():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         res = json.loads(r.stdout.strip().splitlines()[-1])
         assert res["problems"] == [], res["problems"][:3]
-        assert len(res["scenarios"]) >= 13 and all(s["frames"] >= 1 for s in res["scenarios"])
+        assert len(res["scenarios"]) >= 15 and all(s["frames"] >= 1 for s in res["scenarios"])
         first = res["scenarios"][0]["deferred"]
         assert first["recorded"] == 18 and first["launched"] == 3 and first["fused"] == 3, first
 

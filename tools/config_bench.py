@@ -144,6 +144,24 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
         record(name2, "fused compositor, each frame's batch replayed as one hipGraph", "frame",
                timeit(lambda i: graphs[i % R].launch(), reps), algo2, 8)
 
+    # ---------------- 720p50: the reference's third video format (src/config.ts:43-54) -------------------
+    # 1280 % 48 = 32, 1280 % 6 = 2: every line ends in a tail quad and two cleared slots (v210.ts:84-110, 166-193).  Two figures:
+    # the headline's shape (4 x 1:1 layers, ph_fused_v210_combine) and config 2's placements without the transition (ph_chan_compose_v210)
+    w7, h7 = 1280, 720
+    rd7, wr7 = colour("709", "709")
+    src7 = [v210(w7, h7, 4) for _ in range(R)]
+    out7 = torch.empty(capi.v210_pitch_bytes(w7) * h7 // 4, dtype=torch.int32, device="cuda")
+    mats7 = [capi.transform_matrix(w7, h7)] + [capi.transform_matrix(w7, h7, scale_x=0.5, scale_y=0.5, offset_x=ox, offset_y=oy)
+                                               for ox, oy in ((-0.25, -0.25), (0.25, -0.25), (0.25, 0.25))]
+    chan7 = [ctx.chan_compose_v210([dict(src=(s[l], w7, h7, mats7[l])) for l in range(4)], out7, w7, h7, 0, *rd7, *wr7, prepare_only=True) for s in src7]
+    torch.cuda.synchronize()
+    algo7 = 5 * capi.v210_pitch_bytes(w7) * h7
+    name7 = "720p50: 1 channel, 4 x 1280x720 v210 layers -> 1 v210 frame (lines with a tail quad: the reference's tail arithmetic)"
+    record(name7, "fused unpack / CSC / combine_4 / CSC / pack, 1:1 layers (ph_fused_v210_combine, tail instantiation)", "frame",
+           timeit(lambda i: ctx.fused_v210_combine(src7[i % R], out7, w7, h7, *rd7, *wr7), reps), algo7, 1)
+    record(name7, "channel compositor straight from v210, a full-frame layer and three quarter-size insets (ph_chan_compose_v210, general instantiation)", "frame",
+           timeit(lambda i: chan7[i % R](), reps), algo7, 1)
+
     # ---------------- config 3 -------------------------------------------------------------
     sw, sh, ow, oh = 1920, 1080, 3840, 2160
     rd, wr = colour("709", "2020")
