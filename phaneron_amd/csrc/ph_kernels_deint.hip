@@ -105,6 +105,11 @@ __device__ __forceinline__ float lane_tap(float v, uint32_t lane, int d) {
 }
 
 #define PH_RGB(v, c) ((c) == 0 ? (v).r : (c) == 1 ? (v).g : (v).b)
+// PH_DEINT_PRICE_INDEX builds (tools/config3_price.py; timing only, never shipped): what the de-interlacing reader would gain if a
+// field's KEPT lines left as three 16-bit table indices instead of three floats (first candidate)
+#ifndef PH_DEINT_PRICE_INDEX
+#define PH_DEINT_PRICE_INDEX 0
+#endif
 
 template <int TFF, bool STD, int PACK = 0>
 __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const ReadK &k, const LutK &lk) {
@@ -176,8 +181,16 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
           ph_f3v *const pc = reinterpret_cast<ph_f3v *>(reinterpret_cast<char *>(out_copy) + ((size_t)y * w + xr) * 12);
           ph_f3v *const pi = reinterpret_cast<ph_f3v *>(reinterpret_cast<char *>(out_interp) + ((size_t)y * w + xr) * 12);
           const ph_f3v vc = {PH_W(C, 2).r, PH_W(C, 2).g, PH_W(C, 2).b}, vi = {res[0], res[1], res[2]};
+#if PH_DEINT_PRICE_INDEX  // timing only (tools/config3_price.py): the kept line stored as three 16-bit values - half the bytes
+          typedef uint16_t ph_h3v __attribute__((ext_vector_type(3)));
+          *reinterpret_cast<ph_h3v *>(reinterpret_cast<char *>(out_copy) + ((size_t)y * w + xr) * 6) =
+              ph_h3v{(uint16_t)__float_as_uint(vc.x), (uint16_t)__float_as_uint(vc.y), (uint16_t)__float_as_uint(vc.z)};
+          if (a.nt) __builtin_nontemporal_store(vi, pi);
+          else *pi = vi;
+#else
           if (a.nt) __builtin_nontemporal_store(vc, pc), __builtin_nontemporal_store(vi, pi);
           else *pc = vc, *pi = vi;
+#endif
         } else {
           store_image(out_copy + (size_t)y * w + xr, make_float4(PH_W(C, 2).r, PH_W(C, 2).g, PH_W(C, 2).b, 1.0f), a.nt);  // yadifCl.ts:117-121
           store_image(out_interp + (size_t)y * w + xr, make_float4(res[0], res[1], res[2], 1.0f), a.nt);                  // :164 alpha from cur

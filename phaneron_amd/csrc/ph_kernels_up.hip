@@ -250,14 +250,28 @@ __device__ __forceinline__ void up_fetch(const UpLayer &L, const UpGeo &g, UpPat
 #pragma unroll
     for (int c = 0; c < 3; ++c) p.P[r][c] = up_load<RGB12>(img, g.roff[r] + g.coff[c]);
 }
+// PH_UP_PRICE_INDEX builds (tools/config3_price.py; timing only, WRONG pixels, never shipped): what it would cost this kernel if the
+// fields' KEPT lines - half of a field's lines are copies of the source frame's - arrived as three 16-bit reader-table indices
+// instead of three floats (first candidate): every such texel then needs the reader's three table lookups and its
+// gamut matrix here.  Five of a patch's nine texels get that arithmetic (on average 4.5 lie on kept lines).
+#ifndef PH_UP_PRICE_INDEX
+#define PH_UP_PRICE_INDEX 0
+#endif
 template <bool RGB12, bool INSIDE, bool FIRST>
-__device__ __forceinline__ void up_filter(const UpPatch &p, const UpGeo &g, UpAcc (&acc)[2][2]) {
+__device__ __forceinline__ void up_filter(const UpPatch &p, const UpGeo &g, UpAcc (&acc)[2][2], const LutK &price_lut) {
   UpTexel P[3][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       P[r][c] = p.P[r][c];
+#if PH_UP_PRICE_INDEX
+      if (r == 0 || (r == 2 && c < 2)) {
+        const float lr = lds_lut_at_unit(price_lut, P[r][c].r), lg = lds_lut_at_unit(price_lut, P[r][c].g), lb = lds_lut_at_unit(price_lut, P[r][c].b);
+        P[r][c].r = dot3(lr, lg, lb, 0.6274f, 0.3293f, 0.0433f), P[r][c].g = dot3(lr, lg, lb, 0.0691f, 0.9195f, 0.0114f);
+        P[r][c].b = dot3(lr, lg, lb, 0.0164f, 0.0880f, 0.8956f);
+      }
+#endif
       if (RGB12) P[r][c].a = (!INSIDE && ((g.rin >> r) & 1u) && ((g.cin >> c) & 1u)) ? 1.0f : 0.0f;  // unused when all are inside
     }
   const bool d1 = g.d1;
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs 
         if (!SHARED) geo = up_geo<RGB12>(L, st);
         UpPatch p;
         up_fetch<RGB12>(L, geo, p);
-        up_filter<RGB12, INSIDE, true>(p, geo, acc);
+        up_filter<RGB12, INSIDE, true>(p, geo, acc, lk);
       }
 #pragma unroll 1
       for (int l = 1; l < a.n; ++l) {
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs 
         if (!SHARED) geo = up_geo<RGB12>(L, st);
         UpPatch p;
         up_fetch<RGB12>(L, geo, p);
-        up_filter<RGB12, INSIDE, false>(p, geo, acc);
+        up_filter<RGB12, INSIDE, false>(p, geo, acc, lk);
       }
     };
     if (a.shared) {  // uniform

@@ -61,9 +61,11 @@ def main():
         res["compose_px_rgba_us_per_field"] = timeit(lambda i: ctx.compose_write_v210([(rgba[i & 1][l][(i >> 1) & 1], sw, sh, md) for l in range(4)], out, ow, oh, 0, *wr))
         jobs_a = [ctx.compose_up_write_v210([(rgba[s][l][p], sw, sh, mh) for l in range(4)], out, ow, oh, 0, *wr, prepare_only=True) for s in range(2) for p in range(2)]
         res["compose_up_rgba_us_per_field"] = timeit(lambda i: jobs_a[i & 3]())
-    if which in ("all", "compose", "up"):
+    if which in ("all", "compose", "up", "up_single"):  # up_single: one launch per field only (the counters of tools/pmc_kernel.sh are means per dispatch:
+        # a two-field launch among them reads as write amplification - round 3's "36.7 MB for a 22.1 MB frame" was that)
         jobs_b = [ctx.compose_up_write_v210([(rgb[s][l][p], sw, sh, mh) for l in range(4)], out, ow, oh, 0, *wr, rgb=True, prepare_only=True) for s in range(2) for p in range(2)]
         res["compose_up_rgb_us_per_field"] = timeit(lambda i: jobs_b[i & 3]())
+    if which in ("all", "compose", "up"):
         pair_jobs = [ctx.compose_up_write_v210_pair([(rgb[s][l][0], sw, sh, mh) for l in range(4)], [(rgb[s][l][1], sw, sh, mh) for l in range(4)], out, out2,
                                                     ow, oh, 0, *wr, rgb=True, prepare_only=True) for s in range(2)]
         res["compose_up_rgb_pair_us_per_field"] = round(timeit(lambda i: pair_jobs[i & 1]()) / 2, 2)
