@@ -1581,7 +1581,7 @@ int ph_v210_read(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t wid
                  const void *lut, const void *gm) {
   if (!in || !out || !cm || !lut || !gm || !width) return fail(PH_E_INVALID, "ph_v210_read: NULL/zero argument");
   if (!height) return PH_OK;
-  if (ctx && width % 6 == 0)
+  if (ctx && width % 2 == 0)  // (a tail of 2 or 4 pixels is the reference's: v210.ts:84-110; other widths: the general kernel)
     if (const ph::LutView *v = lds_view(ctx, lut))
       PH_LAUNCH(ph::launch_v210_read_lds(stream_of(ctx, queue), in, out, width, height, cm, gm, *v,
                                          (uint32_t)ctx->props.multiProcessorCount));
@@ -1595,7 +1595,7 @@ int ph_v210_read_batch(ph_ctx *ctx, int queue, int n, const void *const *ins, vo
   for (int i = 0; i < n; ++i)
     if (!ins[i] || !outs[i]) return fail(PH_E_INVALID, "ph_v210_read_batch: frame %d is NULL", i);
   if (!height) return PH_OK;
-  if (ctx && width % 6 == 0)
+  if (ctx && width % 2 == 0)
     if (const ph::LutView *v = lds_view(ctx, lut))
       PH_LAUNCH(ph::launch_v210_read_lds_batch(stream_of(ctx, queue), n, ins, outs, width, height, cm, gm, *v,
                                                (uint32_t)ctx->props.multiProcessorCount));
@@ -1611,7 +1611,7 @@ int ph_v210_write(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t wi
   if (!in || !out || !cm || !lut || !width) return fail(PH_E_INVALID, "ph_v210_write: NULL/zero argument");
   if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_v210_write: interlace must be 0, 1 or 3");
   if (!height) return PH_OK;
-  if (ctx && width % 48 == 0)
+  if (ctx && width % 2 == 0)
     if (const ph::LutView *v = lds_view(ctx, lut))
       PH_LAUNCH(ph::launch_v210_write_lds(stream_of(ctx, queue), in, out, width, height, interlace, cm, *v,
                                           (uint32_t)ctx->props.multiProcessorCount));

@@ -386,8 +386,9 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_kernel(const uint4 *_
   const LutK lk = make_lut_k(lut);
   lds_lut_load(lut);
   __syncthreads();
+  const uint32_t tail_from = width - width % 6u;  // the pixels of a line's tail are converted without the matrix's offset column (v210.ts:88-93)
   for (uint32_t p = blockIdx.x * kLdsBlock + threadIdx.x; p < total_px; p += gridDim.x * kLdsBlock) {
-    const uint32_t line = p / width, x = p - line * width;  // width % 6 == 0: quads never straddle lines
+    const uint32_t line = p / width, x = p - line * width;  // lines by pitch: any even width
     const uint32_t g = x / 6, j = x - 6 * g, pr = j >> 1;
     const uint4 w = in[(size_t)line * quads_per_line_pitch + g];
     // v210.ts:58-63: Y of pixel j sits in word {0,1,1,2,3,3} at bit {10,0,20,10,0,20};
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_kernel(const uint4 *_
     const float yf = (float)((wy >> sy) & 0x3ff);
     const float cbf = (float)((wcb >> (10u * pr)) & 0x3ff);
     const float crf = (float)((wcr >> scr) & 0x3ff);
-    store_image(out + p, read_px_lds(yf, cbf, crf, k, lk), nt);
+    store_image(out + p, read_px_lds(yf, cbf, crf, k, lk, x < tail_from ? 1.0f : 0.0f), nt);
   }
 }
 
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_batch_kernel(ReadBatc
   const uint32_t frame = blockIdx.x / a.wg_per_frame, wg = blockIdx.x - frame * a.wg_per_frame;
   const uint4 *__restrict__ in = a.in[frame];
   float4 *__restrict__ out = a.out[frame];
+  const uint32_t tail_from = width - width % 6u;
   for (uint32_t p = wg * kLdsBlock + threadIdx.x; p < total_px; p += a.wg_per_frame * kLdsBlock) {
     const uint32_t line = p / width, x = p - line * width;
     const uint32_t g = x / 6, j = x - 6 * g, pr = j >> 1;
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(kLdsBlock) void v210_read_lds_batch_kernel(ReadBatc
     const float yf = (float)((wy >> sy) & 0x3ff);
     const float cbf = (float)((wcb >> (10u * pr)) & 0x3ff);
     const float crf = (float)((wcr >> scr) & 0x3ff);
-    store_image(out + p, read_px_lds(yf, cbf, crf, k, lk), nt);
+    store_image(out + p, read_px_lds(yf, cbf, crf, k, lk, x < tail_from ? 1.0f : 0.0f), nt);
   }
 }
 
@@ -448,16 +450,30 @@ __global__ __launch_bounds__(kLdsBlock) void v210_write_lds_kernel(const float4 
   const LutK lk = make_lut_k(lut);
   lds_lut_load(lut);
   __syncthreads();
-  const uint32_t total = quads_per_line * lines;  // width % 48 == 0: used == pitch
+  // quads_per_line: the slots of the pitch.  `full` whole quads, then the tail quad of a width that is not a multiple of 6
+  // (v210.ts:169-194), then slots the reference clears (v210.ts:131-136); a width in multiples of 48 fills every slot
+  const uint32_t total = quads_per_line * lines, full = width / 6u, remain = width - 6u * full;
   for (uint32_t f = blockIdx.x * kLdsBlock + threadIdx.x; f < total; f += gridDim.x * kLdsBlock) {
     const uint32_t li = f / quads_per_line, g = f - li * quads_per_line;
     const uint32_t line = first_line + li * line_step;
-    const float4 *px = in + (size_t)line * width + 6 * g;
+    if (g > full || (g == full && !remain)) {
+      store_stream(out + (size_t)line * quads_per_line + g, make_uint4(0u, 0u, 0u, 0u));
+      continue;
+    }
+    const float4 *row = in + (size_t)line * width;
     float rgb[18];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const float4 p = px[j];
+      const uint32_t x = 6u * g + (uint32_t)j < width ? 6u * g + (uint32_t)j : width - 1u;  // (a tail quad's missing pixels: never packed)
+      const float4 p = row[x];
       rgb[3 * j] = p.x, rgb[3 * j + 1] = p.y, rgb[3 * j + 2] = p.z;
+    }
+    if (g == full) {
+      float yi[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) yi[i] = lds_lut_index_unit_tail(rgb[i], true);
+      store_stream(out + (size_t)line * quads_per_line + g, write_quad_idx_lds_tail(yi, k, lk, remain));
+      continue;
     }
     store_stream(out + (size_t)line * quads_per_line + g, write_quad_lds(rgb, k, lk));
   }
@@ -1105,7 +1121,7 @@ hipError_t launch_v210_write_lds(hipStream_t s, const void *in, void *out, uint3
   hipError_t e = allow_lds(v210_write_lds_kernel, lut.bytes);
   if (e != hipSuccess) return e;
   const uint32_t step = interlace ? 2 : 1, first = (interlace == 3) ? 1 : 0;
-  const uint32_t lines = interlace ? height / 2 : height, qpl = width / 6;
+  const uint32_t lines = interlace ? height / 2 : height, qpl = v210_pitch_bytes(width) / 16;  // quad slots by pitch
   if (!lines) return hipSuccess;
   const uint32_t want = (qpl * lines + kLdsBlock - 1) / kLdsBlock;
   v210_write_lds_kernel<<<want < num_cus ? want : num_cus, kLdsBlock, lut.bytes, s>>>(

@@ -27,7 +27,7 @@ import tempfile
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-HEADLINE = "fused_v210_combine_lds_kernelILi4ELi6ELi1024ELb0ELi0EEE"
+HEADLINE = "fused_v210_combine_lds_kernelILi4ELi6ELi1024ELb0ELi0ELb0E"  # N = 4, P = 6, 1024 lanes, shipped form (no pipelining, whole kernel, lines without tails)
 
 # mnemonics opbench3 did not time, priced as the measured instruction of the same hardware class
 SAME_AS = {
