@@ -72,8 +72,10 @@ export interface DeferredStats {
 }
 
 export class clContext {
-	/** `deferred` (default: PHANERON_DEFERRED === '1'): runProgram records instead of launching; a packed frame's recorded operator chain
-	 * reaches the device as one fused kernel when the frame is asked for (node/defer.js) */
+	/** `deferred` (default TRUE since round 4; `false`, or PHANERON_DEFERRED=0 in the environment, gives the launch-as-posted context):
+	 * runProgram records instead of launching; a packed frame's recorded operator chain reaches the device as one fused kernel when its
+	 * result is asked for (hostAccess 'readonly', downloadAsync, a route send, realise).  RunTimings of recorded jobs are zeros and
+	 * waitFinish(queue.process) returns at once - INTEGRATION.md 3a. */
 	constructor(params?: { platformIndex?: number; deviceIndex?: number; overlapping?: boolean; profile?: boolean; spinWaitMicros?: number; deferred?: boolean })
 	readonly queue: { load: number; process: number; unload: number }
 	initialise(): Promise<void>
