@@ -766,8 +766,7 @@ __device__ __forceinline__ void chan_phase2_other(const ChanArgs &a, const ChanS
 template <bool PLANAR, int OUT = 0>
 __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a) {
   const ReadK rk = load_read_k(a.rd_cm, a.rd_gm);
-  const WriteK wk = load_write_k(a.wr_cm);
-  const LutK rlut = make_lut_k(a.rd), wlut = make_lut_k(a.wr);
+  const LutK rlut = make_lut_k(a.rd);
   const ChanShare sh = chan_share(a);
   PH_CPHASE(0);
   lds_lut_load(a.rd);
@@ -786,6 +785,10 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
   lds_lut_load(a.wr);
   __syncthreads();
   PH_CPHASE(4);
+  // (the writer's constants are loaded HERE, not at the top: seventeen scalar registers that phase 1 - which spills scalars to
+  // VGPR lanes as it is - does not have to keep alive)
+  const WriteK wk = load_write_k(a.wr_cm);
+  const LutK wlut = make_lut_k(a.wr);
   if (OUT != 0) {
     chan_phase2_other<OUT>(a, sh, wk, wlut);
     return;
