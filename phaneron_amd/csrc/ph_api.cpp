@@ -1791,16 +1791,16 @@ static int chan_source(const ph_chan_source &s, const char *what, int layer, uin
   if (s.format != PH_SRC_V210 && s.format != PH_SRC_RGBA_F32 && !is_planar && !is_rgb8)
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has format %d (not a PH_SRC_*)", layer, what, s.format);
   *pu = *pv = nullptr, *cm = nullptr;
-  if (is_rgb8) *planar = 1;  // (served by the kernel's wire-format instantiation)
+  if (is_rgb8) *planar = 2;  // (served by the kernel's wire-format instantiation)
   if (is_planar) {
     if (!s.data_u || (s.format != PH_SRC_NV12 && !s.data_v) || (s.width & 1) || ((s.format == PH_SRC_YUV420P || s.format == PH_SRC_NV12) && (s.height & 1)))
       return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is planar: it needs its chroma plane(s), an even width and, for 4:2:0, an even height", layer, what);
-    *pu = s.data_u, *pv = s.data_v, *cm = (const float *)s.col_matrix12, *planar = 1;
+    *pu = s.data_u, *pv = s.data_v, *cm = (const float *)s.col_matrix12, *planar = 2;
   }
   // (the reference's v210 reader serves tails of 2 or 4 pixels: v210.ts:84-110)
   if (s.format == PH_SRC_V210 && (s.width & 1))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s is a v210 frame %d wide, an odd width; run the separate kernels", layer, what, s.width);
-  if (s.format == PH_SRC_V210 && s.width % 6) *planar = 1;  // a line with a tail: the kernel's general instantiation
+  if (s.format == PH_SRC_V210 && s.width % 6 && *planar < 1) *planar = 1;  // a line with a tail: the kernel's instantiation for those
   if (!s.matrix9_host && ((uint32_t)s.width != out_w || (uint32_t)s.height != out_h))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: the %s has no transform but is %dx%d, not the output size", layer, what, s.width, s.height);
   o->ptr = s.data, o->w = (uint32_t)s.width, o->h = (uint32_t)s.height;
@@ -1885,7 +1885,7 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
   a.out_qpitch = ph_v210_pitch_bytes(out_w) / 16u;
   a.out_tail_from = 0xFFFFFFFFu;
   if (out_format == PH_FMT_V210 && out_w % 48) {
-    a.planar = 1;  // the general instantiation writes lines that end in a tail / cleared slots
+    if (a.planar < 1) a.planar = 1;  // the tail instantiation writes lines that end in a tail / cleared slots
     if (out_w % 6) a.out_tail_from = out_w - out_w % 6u;
   }
   if (!a.lines) return PH_OK;

@@ -96,7 +96,7 @@ struct ChanArgs {
   // matrix (12 floats, device; NULL = rd_cm) - read by the planar instantiation of the kernel only
   const void *plane_u[kMaxChanOps], *plane_v[kMaxChanOps];
   const float *cm_op[kMaxChanOps];
-  uint32_t planar;  // launcher: some op is planar
+  uint32_t planar;  // which instantiation the launch needs: 0 v210 / images on whole 48-pixel blocks, 1 v210 lines with tails, 2 planar / RGB sources
   // the packed frame the writer makes: 0 v210 (out), 1 yuv422p10 / 2 yuv422p8 (out = the Y plane, out_u, out_v; out_pitch = luma
   // samples per line), 5 rgba8 / 6 bgra8 (out; out_pitch = pixels per line) - PH_FMT_* numbering
   uint32_t out_fmt, out_pitch;

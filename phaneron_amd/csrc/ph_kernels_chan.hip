@@ -593,7 +593,8 @@ __device__ __forceinline__ void chan_halo_pass(const ChanArgs &a, const ChanShar
   __syncthreads();
 }
 
-template <bool STD, bool PLANAR>
+// PLANAR: the program may have planar / packed-RGB sources; TAILS: v210 frames (sources, output) may have lines that end in a tail
+template <bool STD, bool PLANAR, bool TAILS>
 __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &sh, const ReadK &rk, const LutK &rlut) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   uint2 *const index = reinterpret_cast<uint2 *>(a.index);
@@ -646,18 +647,18 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
         ChanHalo halo{false, 0u};
         if ((op.action & kChanActShare) && n < a.halo_steps)  // uniform
           halo = ChanHalo{true, a.halo_off + (((op.action >> kChanActShareShift) & 7u) * a.halo_steps + n) * 36u};
-        chan_sample<STD, PLANAR>(op.src, px, py, x, line, rk, rlut, v, halo);
+        chan_sample<STD, TAILS>(op.src, px, py, x, line, rk, rlut, v, halo);
       }
 #pragma unroll
       for (int p = 0; p < kChanP; ++p) chan_apply(op, v[p], acc[p]);
     }
     // the writer's first step needs no table (v210.ts:148-150): park the three 16-bit indices
     // (in the tail of a v210 line whose width is not a multiple of 6 the writer truncates its index: v210.ts:176-178)
-    const bool trunc_idx = PLANAR && x >= a.out_tail_from;
+    const bool trunc_idx = TAILS && x >= a.out_tail_from;
 #pragma unroll
     for (int p = 0; p < kChanP; ++p) {
       auto index_of = [&](float t) __attribute__((always_inline)) {
-        return __float_as_uint(PLANAR ? lds_lut_index_unit_tail(t, trunc_idx) : lds_lut_index_unit(t)) & 0xFFFFu;
+        return __float_as_uint(TAILS ? lds_lut_index_unit_tail(t, trunc_idx) : lds_lut_index_unit(t)) & 0xFFFFu;
       };
       const uint32_t ir = index_of(acc[p].r), ig = index_of(acc[p].g), ib = index_of(acc[p].b);
       if (x < a.out_w) index[li[p] * a.out_w + x] = make_uint2(ir | (ig << 16), ib);  // (lanes beyond a short last chunk have nothing to park)
@@ -762,9 +763,14 @@ __device__ __forceinline__ void chan_phase2_other(const ChanArgs &a, const ChanS
   }
 }
 
-// OUT: the packed frame's format (0 v210; the others only with the wire-format instantiation PLANAR = true)
-template <bool PLANAR, int OUT = 0>
+// MODE: 0 = v210 frames whose lines end on a 48-pixel block and f32 images (the fast instantiation); 1 = the same with lines that may end
+// in a tail (1280 x 720: sources and / or output); 2 = everything (planar and packed-RGB sources, frames other than v210).  An
+// instantiation carries the scalar state of every path it contains, whether a launch takes it or not - the channel kernel's op loop
+// spills scalars to VGPR lanes (6 in mode 0, 76 in mode 2) - so 1280-wide v210 channels get one of their own.
+// OUT: the packed frame's format (0 v210; the others only with MODE 2)
+template <int MODE, int OUT = 0>
 __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a) {
+  constexpr bool PLANAR = MODE == 2, TAILS = MODE >= 1;
   const ReadK rk = load_read_k(a.rd_cm, a.rd_gm);
   const LutK rlut = make_lut_k(a.rd);
   const ChanShare sh = chan_share(a);
@@ -773,11 +779,11 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
   __syncthreads();
   PH_CPHASE(1);
   if (ycbcr_matrix_is_standard(rk)) {
-    chan_halo_pass<true, PLANAR>(a, sh, rk, rlut);
-    chan_phase1<true, PLANAR>(a, sh, rk, rlut);
+    chan_halo_pass<true, TAILS>(a, sh, rk, rlut);
+    chan_phase1<true, PLANAR, TAILS>(a, sh, rk, rlut);
   } else {
-    chan_halo_pass<false, PLANAR>(a, sh, rk, rlut);
-    chan_phase1<false, PLANAR>(a, sh, rk, rlut);
+    chan_halo_pass<false, TAILS>(a, sh, rk, rlut);
+    chan_phase1<false, PLANAR, TAILS>(a, sh, rk, rlut);
   }
   PH_CPHASE(2);
   __syncthreads();  // every index of this workgroup has been stored (the barrier drains the stores) and nobody reads the reader table any more
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
     if (li >= a.lines || g >= qpl) continue;
     const uint32_t line = a.first_line + li * a.line_step;
     uint4 *const dst = reinterpret_cast<uint4 *>(a.out) + (size_t)line * qpl + g;
-    if (PLANAR && g > full - (remain ? 0u : 1u)) {  // past the line's pixels
+    if (TAILS && g > full - (remain ? 0u : 1u)) {  // past the line's pixels
       store_stream(dst, make_uint4(0u, 0u, 0u, 0u));
       continue;
     }
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
       yi[3 * j + 1] = __uint_as_float((pk[2 * j] >> 16) | 0x4B400000u);
       yi[3 * j + 2] = __uint_as_float((pk[2 * j + 1] & 0xFFFFu) | 0x4B400000u);
     }
-    if (PLANAR && g == full) store_stream(dst, write_quad_idx_lds_tail(yi, wk, wlut, remain));  // (the index frame is padded: the tail's loads stay inside)
+    if (TAILS && g == full) store_stream(dst, write_quad_idx_lds_tail(yi, wk, wlut, remain));  // (the index frame is padded: the tail's loads stay inside)
     else store_stream(dst, write_quad_idx_lds(yi, wk, wlut));
   }
   PH_CPHASE(5);
@@ -876,13 +882,13 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
     return hipGetLastError();
   };
   switch (a.out_fmt) {  // frames other than v210 are made by the wire-format instantiation, whatever the sources
-    case 0: return a.planar ? go(chan_compose_v210_kernel<true, 0>) : go(chan_compose_v210_kernel<false, 0>);
-    case 1: return go(chan_compose_v210_kernel<true, 1>);
-    case 2: return go(chan_compose_v210_kernel<true, 2>);
-    case 3: return go(chan_compose_v210_kernel<true, 3>);
-    case 4: return go(chan_compose_v210_kernel<true, 4>);
-    case 5: return go(chan_compose_v210_kernel<true, 5>);
-    case 6: return go(chan_compose_v210_kernel<true, 6>);
+    case 0: return a.planar == 2 ? go(chan_compose_v210_kernel<2, 0>) : a.planar == 1 ? go(chan_compose_v210_kernel<1, 0>) : go(chan_compose_v210_kernel<0, 0>);
+    case 1: return go(chan_compose_v210_kernel<2, 1>);
+    case 2: return go(chan_compose_v210_kernel<2, 2>);
+    case 3: return go(chan_compose_v210_kernel<2, 3>);
+    case 4: return go(chan_compose_v210_kernel<2, 4>);
+    case 5: return go(chan_compose_v210_kernel<2, 5>);
+    case 6: return go(chan_compose_v210_kernel<2, 6>);
   }
   return hipErrorInvalidValue;
 }
