@@ -11,7 +11,7 @@ const { colour } = require('../index.js')
 
 // frame size: small by default (many streams per second); PHANERON_FUZZ_SIZE=1920x270 makes the kernels long enough for an ordering
 // mistake between queues, or a block recycled too early, to show
-const [W, H] = (process.env.PHANERON_FUZZ_SIZE || '192x12').split('x').map((v) => parseInt(v)) // (widths: multiples of 48)
+const [W, H] = (process.env.PHANERON_FUZZ_SIZE || '192x12').split('x').map((v) => parseInt(v)) // (widths: multiples of 8; one that is not a multiple of 48 - 176 - puts a tail quad into every v210 line)
 const first = parseInt(process.argv[2] || '1')
 const streams = parseInt(process.argv[3] || '20')
 const steps = parseInt(process.argv[4] || '60')
@@ -36,7 +36,7 @@ async function play(seed, deferred) {
 	}
 	const FORMATS = ['v210', 'v210', 'yuv422p10', 'yuv422p8', 'yuv420p', 'nv12', 'rgba8', 'bgra8'] // sources come in every pack format (v210 twice as often)
 	for (const f of FORMATS.slice(2)) S.readAs[f] = await rig.unpack(f, W, H, '709', '2020')
-	const OUT_FORMATS = ['v210', 'v210', 'v210', 'rgba8', 'bgra8', 'yuv422p8', 'yuv422p10'] // packed frames for every consumer of the reference (v210 most often)
+	const OUT_FORMATS = ['v210', 'v210', 'v210', 'rgba8', 'bgra8', 'yuv422p8', 'yuv422p10', 'yuv420p', 'nv12'] // packed frames in every Writer's format (v210 most often)
 	S.writeAs = { v210: [S.write, S.writeField] }
 	for (const f of OUT_FORMATS.slice(3)) S.writeAs[f] = [await rig.pack(f, W, H, '2020', false), await rig.pack(f, W, H, '2020', true)]
 	const r = rng(seed)
