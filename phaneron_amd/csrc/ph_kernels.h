@@ -9,6 +9,9 @@
 namespace ph {
 
 constexpr int kMaxLayers = 8;
+// every kernel with a dynamic LDS array is allowed the CU's whole 160 KiB once and for all: the attribute is per-function state, and
+// setting it to each launch's own size would let two launching threads undercut each other
+constexpr int kMaxDynamicLds = 160 * 1024;
 
 // 1 = f32 image outputs of the launches issued by this thread are streamed past the caches (ph_device.h store_image);
 // set from the context's "stream_images" option before every launch (ph_api.cpp set_device)

@@ -876,7 +876,7 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
     if (n_share) b.halo_steps = steps, lds_total = b.halo_off + n_share * steps * 36u;
   }
   auto go = [&](auto kernel) -> hipError_t {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     if (e != hipSuccess) return e;
     kernel<<<grid, kLdsBlock, lds_total, s>>>(b);
     return hipGetLastError();

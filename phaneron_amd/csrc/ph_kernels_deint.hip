@@ -245,7 +245,7 @@ hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t 
   const uint32_t want = (tasks + kDeintBlock / 64 - 1) / (kDeintBlock / 64);
   const uint32_t grid = want < num_cus ? want : num_cus;
   auto go = [&](auto kernel) -> hipError_t {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lut.bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     if (e != hipSuccess) return e;
     kernel<<<grid, kDeintBlock, a.lut.bytes, s>>>(a);
     return hipGetLastError();

@@ -256,7 +256,7 @@ static hipError_t launch_read_fmt(hipStream_t s, const FmtReadArgs &a, const flo
   if (!total) return hipSuccess;
   if (lv) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fmt_read_lds_kernel<FMT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lv->bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     if (e != hipSuccess) return e;
     const uint32_t want = (total + kLdsBlock - 1) / kLdsBlock;
     fmt_read_lds_kernel<FMT><<<want < num_cus ? want : num_cus, kLdsBlock, lv->bytes, s>>>(a, *lv);
@@ -291,7 +291,7 @@ static hipError_t launch_write_fmt(hipStream_t s, const FmtWriteArgs &a, const f
   if (!total) return hipSuccess;
   if (lv) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fmt_write_lds_kernel<FMT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lv->bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     if (e != hipSuccess) return e;
     const uint32_t want = (total + kLdsBlock - 1) / kLdsBlock;
     fmt_write_lds_kernel<FMT><<<want < num_cus ? want : num_cus, kLdsBlock, lv->bytes, s>>>(a, *lv);

@@ -859,7 +859,7 @@ static hipError_t launch_compose_taps_n(hipStream_t s, const ComposeArgs &a, uin
   }
   if (wipe) {  // one variant: 1:1 layers allowed, placements per layer
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, true, false, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(stage_off + kComposeStageBytes));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     if (e != hipSuccess) return e;
     compose_write_v210_taps_kernel<N, true, false, true><<<grid, kLdsBlock, stage_off + kComposeStageBytes, s>>>(a, stage_off);
     return hipGetLastError();
@@ -867,7 +867,7 @@ static hipError_t launch_compose_taps_n(hipStream_t s, const ComposeArgs &a, uin
   const void *fn = shared ? reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, false, true>)
                    : mixed ? reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, true>)
                            : reinterpret_cast<const void *>(compose_write_v210_taps_kernel<N, false>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(stage_off + kComposeStageBytes));
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
   if (e != hipSuccess) return e;
   if (shared)
     compose_write_v210_taps_kernel<N, false, true><<<grid, kLdsBlock, stage_off + kComposeStageBytes, s>>>(a, stage_off);
@@ -916,7 +916,7 @@ bool compose_can_wipe(const ComposeArgs &a) { return compose_uses_taps(a); }
 template <int N, bool ALL_DIRECT>
 static hipError_t launch_compose_px_nd(hipStream_t s, const ComposeArgs &a, uint32_t grid, uint32_t stage_off) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(compose_write_v210_px_kernel<N, ALL_DIRECT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(stage_off + kComposeStageBytes));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
   if (e != hipSuccess) return e;
   compose_write_v210_px_kernel<N, ALL_DIRECT><<<grid, kLdsBlock, stage_off + kComposeStageBytes, s>>>(a, stage_off);
   return hipGetLastError();
@@ -933,8 +933,7 @@ static hipError_t launch_compose_px_n(hipStream_t s, const ComposeArgs &a, uint3
 // ------------------------------------------------------------------------------------------
 template <typename K>
 static hipError_t allow_lds(K kernel, uint32_t bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)bytes);
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
 }
 
 #if PH_FUSED_SPLIT

@@ -407,7 +407,7 @@ hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb
   if (!a.lines) return hipSuccess;
   const void *fn = rgb12 ? reinterpret_cast<const void *>(compose_up_write_v210_kernel<true>)
                          : reinterpret_cast<const void *>(compose_up_write_v210_kernel<false>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.wr.bytes);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
   if (e != hipSuccess) return e;
   UpArgs b = a;
   b.shared = 1;  // every layer has the size and the placement of the first: the patch geometry and the weights are computed once per block
