@@ -34,8 +34,9 @@ extern "C" {
  *    ph_yadif_pair_packed), so an array of sources built against 2 / 3 has the wrong stride.  ph_chan_compose added
  * 5: ph_compose_up_write_v210_pair, ph_lut_layout_of
  * 6: ph_fused_field_v210 / ph_field_layer REMOVED (the slowest route of its workload by 2.7x, no caller).  The fused entry
- *    points take widths that are not a multiple of 48 (1280 x 720: the reference's third format, src/config.ts:43-54) */
-#define PH_ABI_VERSION 6
+ *    points take widths that are not a multiple of 48 (1280 x 720: the reference's third format, src/config.ts:43-54)
+ * 7: additive over 6 - ph_chan_compose_batch (ph_chan_job): several channels' frames in one launch */
+#define PH_ABI_VERSION 7
 
 enum {
   PH_OK = 0,
@@ -444,6 +445,23 @@ int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *lay
 int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, int out_format, void *const out_planes[3],
                     uint32_t out_width, uint32_t out_height, uint32_t interlace, const void *rd_col_matrix12, const void *rd_gamma_lut,
                     const void *rd_gamut9, const void *wr_col_matrix12, const void *wr_gamma_lut);
+/* Several channels' frames in ONE launch.  The reference runs its channels - four of them, 1080p50 or smaller - in one context through
+ * one queue (src/index.ts:45-71,156-160; src/clJobQueue.ts:114-141); a frame of that size does not fill the chip on its own.  Here the
+ * jobs (frames of one geometry, one Loader / Saver colour recipe; each with its own layers, placements, transitions and interlace:
+ * two jobs may be the two fields of one frame) share the workgroups of one launch: the gamma tables are loaded once, and the wave
+ * steps of all jobs together are handed to the waves as they come free, dearest first.  Exactly `n_jobs` calls of ph_chan_compose_v210
+ * in the order given, PROVIDED no job reads what another job of the call writes (jobs of one launch run side by side).  Jobs the
+ * batch kernel does not take (planar / packed-RGB sources; more jobs, ops or wave steps than one launch holds) are split off into
+ * launches of their own inside the call.  Limits and errors as ph_chan_compose_v210. */
+typedef struct ph_chan_job {
+  int n;                       /* layers */
+  const ph_chan_layer *layers;
+  void *out;                   /* device: the v210 frame, out_width x out_height */
+  uint32_t interlace;          /* as ph_v210_write: 0 frame, 1 / 3 one field */
+} ph_chan_job;
+int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job *jobs, uint32_t out_width, uint32_t out_height,
+                          const void *rd_col_matrix12, const void *rd_gamma_lut, const void *rd_gamut9, const void *wr_col_matrix12,
+                          const void *wr_gamma_lut);
 
 /* ---- gamma LUT placement.  The reference hands its kernels a 65536-entry f32 `gammaLut` buffer
  *      (loadSave.ts:65-73,152-160) and gathers from it 3x per pixel.  Registering the table's

@@ -33,7 +33,7 @@ EXPORTS = [
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
     "ph_program_resolve", "ph_route_unique_id", "ph_route_init", "ph_route_destroy", "ph_route_group_begin",
     "ph_route_group_end", "ph_route_send", "ph_route_recv", "ph_route_after_queue", "ph_queue_after_route",
-    "ph_route_wait", "ph_route_stream", "ph_route_comm_count", "ph_chan_compose_v210",
+    "ph_route_wait", "ph_route_stream", "ph_route_comm_count", "ph_chan_compose_v210", "ph_chan_compose_batch",
     "ph_v210_yadif_pair_fmt", "ph_compose_up_write_v210",
 ]
 
@@ -70,6 +70,10 @@ class PhChanSource(C.Structure):
 
 class PhChanLayer(C.Structure):
     _fields_ = [("src", PhChanSource), ("transition", C.c_int), ("mix", C.c_float), ("incoming", PhChanSource), ("mask", PhChanSource)]
+
+
+class PhChanJob(C.Structure):
+    _fields_ = [("n", C.c_int), ("layers", C.POINTER(PhChanLayer)), ("out", C.c_void_p), ("interlace", C.c_uint32)]
 
 
 class PhImageLayer(C.Structure):
@@ -188,6 +192,7 @@ def lib():
         "ph_compose_up_write_v210": (ci, [vp, ci, ci, C.POINTER(PhImageLayer), vp, cu, cu, cu, vp, vp]),
         "ph_chan_compose_v210": (ci, [vp, ci, ci, C.POINTER(PhChanLayer), vp, cu, cu, cu, vp, vp, vp, vp, vp]),
         "ph_chan_compose": (ci, [vp, ci, ci, C.POINTER(PhChanLayer), ci, C.POINTER(C.c_void_p), cu, cu, cu, vp, vp, vp, vp, vp]),
+        "ph_chan_compose_batch": (ci, [vp, ci, ci, C.POINTER(PhChanJob), cu, cu, vp, vp, vp, vp, vp]),
         "ph_route_unique_id": (ci, [vp]),
         "ph_route_init": (ci, [vp, vp, ci, ci, C.POINTER(vp)]),
         "ph_route_destroy": (ci, [vp]),
@@ -516,14 +521,9 @@ class Context:
         check(lib().ph_compose_wipe_write_v210(self.h, queue, len(layers), arr, wp, _ptr(dst), out_w, out_h, interlace,
                                                _ptr(wr_cm), _ptr(wr_lut)), self.h)
 
-    def chan_compose_v210(self, layers, dst, out_w, out_h, interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut, queue=QUEUE_PROCESS,
-                          prepare_only=False, out_fmt="v210"):
-        """The channel compositor straight from v210 sources (ph_chan_compose_v210).  layers: list of dicts
-        {src: SOURCE, transition: "cut" | "dissolve" | "wipe", mix: float, incoming: SOURCE, mask: SOURCE}; a SOURCE is
-        (tensor, width, height, matrix) or (tensor, width, height, matrix, "rgba") or ((y, u, v) plane tensors, width, height,
-        matrix, "yuv422p10" | "yuv422p8" | "yuv420p" | "nv12"[, own Loader matrix tensor]) - matrix: nine host floats
-        (transform_matrix) or None for 1:1; format v210 unless "rgba" (f32 RGBA image), a planar pack format, or "rgba8" / "bgra8"
-        (tensor of packed 8-bit pixels)."""
+    @staticmethod
+    def _chan_layers(layers):
+        """the ph_chan_layer array of a list of layer dicts (chan_compose_v210) + what has to stay alive with it"""
         import numpy as np
         arr = (PhChanLayer * len(layers))()
         keep = []
@@ -553,6 +553,17 @@ class Context:
                 fill(arr[i].incoming, L["incoming"])
             if L.get("mask") is not None:
                 fill(arr[i].mask, L["mask"])
+        return arr, keep
+
+    def chan_compose_v210(self, layers, dst, out_w, out_h, interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut, queue=QUEUE_PROCESS,
+                          prepare_only=False, out_fmt="v210"):
+        """The channel compositor straight from v210 sources (ph_chan_compose_v210).  layers: list of dicts
+        {src: SOURCE, transition: "cut" | "dissolve" | "wipe", mix: float, incoming: SOURCE, mask: SOURCE}; a SOURCE is
+        (tensor, width, height, matrix) or (tensor, width, height, matrix, "rgba") or ((y, u, v) plane tensors, width, height,
+        matrix, "yuv422p10" | "yuv422p8" | "yuv420p" | "nv12"[, own Loader matrix tensor]) - matrix: nine host floats
+        (transform_matrix) or None for 1:1; format v210 unless "rgba" (f32 RGBA image), a planar pack format, or "rgba8" / "bgra8"
+        (tensor of packed 8-bit pixels)."""
+        arr, keep = self._chan_layers(layers)
         if out_fmt != "v210":  # dst: the planes of the packed frame (ph_chan_compose); wr_cm None for rgba8 / bgra8
             planes = (C.c_void_p * 3)(*([_ptr(p).value for p in dst] + [None] * (3 - len(dst))))
             keep.append(planes)
@@ -569,6 +580,24 @@ class Context:
                 check(fn(*args), h)
             return job
         check(fn(*args), self.h)
+
+    def chan_compose_batch(self, jobs, out_w, out_h, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut, queue=QUEUE_PROCESS, prepare_only=False):
+        """Several channels' frames in one launch (ph_chan_compose_batch).  jobs: list of (layers, dst, interlace) - layers as
+        chan_compose_v210 takes them, dst the job's v210 frame."""
+        arr = (PhChanJob * len(jobs))()
+        keep = []
+        for j, (layers, dst, interlace) in enumerate(jobs):
+            la, k = self._chan_layers(layers)
+            keep.append((la, k, layers, dst))
+            arr[j].n, arr[j].layers, arr[j].out, arr[j].interlace = len(layers), la, _ptr(dst).value, interlace
+        args = (self.h, queue, len(jobs), arr, out_w, out_h, _ptr(rd_cm), _ptr(rd_lut), _ptr(rd_gm), _ptr(wr_cm), _ptr(wr_lut))
+        fn, h = lib().ph_chan_compose_batch, self.h
+        if prepare_only:
+
+            def job(_keep=(keep, arr)):
+                check(fn(*args), h)
+            return job
+        check(fn(*args), h)
 
     def fused_v210_combine(self, layers, dst, width, height, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut,
                            queue=QUEUE_PROCESS, prepare_only=False):

@@ -1818,6 +1818,70 @@ static int chan_source(const ph_chan_source &s, const char *what, int layer, uin
   return PH_OK;
 }
 
+// PH_CHAN_SCHED=0: the one-job kernel with its wave steps dealt in turn (A/B runs, tools/chan_bench.py)
+static bool chan_sched_on() {
+  static const bool on = !(getenv("PH_CHAN_SCHED") && getenv("PH_CHAN_SCHED")[0] == '0');
+  return on;
+}
+// the index frames between the phases: one area per queue (launches on one queue are in order), grown on demand (ctx->mu held)
+static int chan_index_reserve(ph_ctx *ctx, int queue, size_t need) {
+  if (ctx->chan_index_bytes[queue] >= need) return PH_OK;
+  if (ctx->chan_index[queue]) {
+    hipStreamSynchronize(ctx->streams[queue]);
+    hipFree(ctx->chan_index[queue]);
+    ctx->chan_index[queue] = nullptr, ctx->chan_index_bytes[queue] = 0;
+  }
+  PH_HIP(hipMalloc(&ctx->chan_index[queue], need));
+  ctx->chan_index_bytes[queue] = need;
+  return PH_OK;
+}
+// one launch of the batch kernel: b holds the jobs and their ops, g the geometry, colour recipe and tables (set_device done)
+static int chan_batch_launch(ph_ctx *ctx, int queue, ph::ChanBatchArgs &b, const ph::ChanArgs &g) {
+  b.out_w = g.out_w, b.out_h = g.out_h, b.lines = g.lines, b.line_step = g.line_step;
+  b.rd_cm = g.rd_cm, b.rd_gm = g.rd_gm, b.wr_cm = g.wr_cm, b.rd = g.rd, b.wr = g.wr;
+  b.tails = g.planar >= 1 ? 1u : 0u, b.out_qpitch = g.out_qpitch, b.out_tail_from = g.out_tail_from;
+  const size_t each = (ph::chan_index_bytes(g.out_w, g.lines) + 255u) & ~(size_t)255u;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  int rc = chan_index_reserve(ctx, queue, each * b.jobs);
+  if (rc) return rc;
+  for (uint32_t j = 0; j < b.jobs; ++j) b.job[j].index = (char *)ctx->chan_index[queue] + each * j;
+  hipError_t e = ph::launch_chan_compose_batch(stream_of(ctx, queue), b, (uint32_t)ctx->props.multiProcessorCount);
+  if (e != hipSuccess) return fail(PH_E_HIP, "ph_chan_compose_batch: launch failed: %s", hipGetErrorString(e));
+  return PH_OK;
+}
+
+// a channel's layers as the kernel's flat program: one op per source to sample (ph_kernels.h ChanOp)
+static int chan_ops(int n, const ph_chan_layer *layers, uint32_t out_w, uint32_t out_h, ph::ChanOp *op, const void **plane_u, const void **plane_v,
+                    const float **cm_op, uint32_t *planar, int *n_ops) {
+  int k = 0;
+  for (int i = 0; i < n; ++i) {
+    const ph_chan_layer &L = layers[i];
+    const uint32_t first = i == 0 ? ph::kChanActFirst : 0u;
+    int rc = chan_source(L.src, "source", i, out_w, out_h, &op[k].src, &plane_u[k], &plane_v[k], &cm_op[k], planar);
+    if (rc) return rc;
+    if (L.transition == PH_TRANSITION_CUT) {
+      op[k++].action = ph::kChanActLayer | first;
+    } else if (L.transition == PH_TRANSITION_DISSOLVE || L.transition == PH_TRANSITION_WIPE) {
+      op[k++].action = ph::kChanActHold;
+      rc = chan_source(L.incoming, "transition's incoming source", i, out_w, out_h, &op[k].src, &plane_u[k], &plane_v[k], &cm_op[k], planar);
+      if (rc) return rc;
+      if (L.transition == PH_TRANSITION_DISSOLVE) {
+        op[k].mix = L.mix;
+        op[k++].action = ph::kChanActDissolve | first;
+      } else {
+        op[k++].action = ph::kChanActIncoming;
+        rc = chan_source(L.mask, "wipe's mask", i, out_w, out_h, &op[k].src, &plane_u[k], &plane_v[k], &cm_op[k], planar);
+        if (rc) return rc;
+        op[k++].action = ph::kChanActWipe | first;
+      }
+    } else {
+      return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: transition %d", i, L.transition);
+    }
+  }
+  *n_ops = k;
+  return PH_OK;
+}
+
 int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
                          uint32_t interlace, const void *rd_cm, const void *rd_lut, const void *rd_gm, const void *wr_cm,
                          const void *wr_lut) {
@@ -1851,30 +1915,8 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
     return fail(PH_E_INVALID, "ph_chan_compose_v210: the %s gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)", rv ? "writer" : "reader");
   ph::ChanArgs a{};
   int k = 0;
-  for (int i = 0; i < n; ++i) {
-    const ph_chan_layer &L = layers[i];
-    const uint32_t first = i == 0 ? ph::kChanActFirst : 0u;
-    int rc = chan_source(L.src, "source", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.cm_op[k], &a.planar);
-    if (rc) return rc;
-    if (L.transition == PH_TRANSITION_CUT) {
-      a.op[k++].action = ph::kChanActLayer | first;
-    } else if (L.transition == PH_TRANSITION_DISSOLVE || L.transition == PH_TRANSITION_WIPE) {
-      a.op[k++].action = ph::kChanActHold;
-      rc = chan_source(L.incoming, "transition's incoming source", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.cm_op[k], &a.planar);
-      if (rc) return rc;
-      if (L.transition == PH_TRANSITION_DISSOLVE) {
-        a.op[k].mix = L.mix;
-        a.op[k++].action = ph::kChanActDissolve | first;
-      } else {
-        a.op[k++].action = ph::kChanActIncoming;
-        rc = chan_source(L.mask, "wipe's mask", i, out_w, out_h, &a.op[k].src, &a.plane_u[k], &a.plane_v[k], &a.cm_op[k], &a.planar);
-        if (rc) return rc;
-        a.op[k++].action = ph::kChanActWipe | first;
-      }
-    } else {
-      return fail(PH_E_INVALID, "ph_chan_compose_v210: layer %d: transition %d", i, L.transition);
-    }
-  }
+  int rc_ops = chan_ops(n, layers, out_w, out_h, a.op, a.plane_u, a.plane_v, a.cm_op, &a.planar, &k);
+  if (rc_ops) return rc_ops;
   a.n_ops = k;
   a.out = out, a.out_w = out_w, a.out_h = out_h;
   a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0;
@@ -1891,22 +1933,93 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
   if (!a.lines) return PH_OK;
   int rc = set_device(ctx);
   if (rc) return rc;
-  // the index frame between the phases: one per queue (launches on one queue are in order), grown on demand
-  const size_t need = ph::chan_index_bytes(out_w, a.lines);
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  if (ctx->chan_index_bytes[queue] < need) {
-    if (ctx->chan_index[queue]) {
-      hipStreamSynchronize(ctx->streams[queue]);
-      hipFree(ctx->chan_index[queue]);
-      ctx->chan_index[queue] = nullptr, ctx->chan_index_bytes[queue] = 0;
-    }
-    PH_HIP(hipMalloc(&ctx->chan_index[queue], need));
-    ctx->chan_index_bytes[queue] = need;
+  // v210 frames from v210 / f32 sources: the kernel that hands its wave steps out at run time, dearest first (one job of a batch)
+  if (out_format == PH_FMT_V210 && a.planar < 2 && chan_sched_on() && k <= ph::kMaxChanBatchOps &&
+      ph::chan_batch_max_jobs(out_w, a.lines, (uint32_t)ctx->props.multiProcessorCount) >= 1) {
+    ph::ChanBatchArgs b{};
+    for (int i = 0; i < k; ++i) b.op[i] = a.op[i], b.op_job[i] = 0;
+    b.jobs = 1, b.n_ops = (uint32_t)k;
+    b.job[0].out = out, b.job[0].first_op = 0, b.job[0].n_ops = (uint32_t)k, b.job[0].first_line = a.first_line;
+    return chan_batch_launch(ctx, queue, b, a);
   }
+  // the index frame between the phases: one per queue (launches on one queue are in order), grown on demand
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  rc = chan_index_reserve(ctx, queue, ph::chan_index_bytes(out_w, a.lines));
+  if (rc) return rc;
   a.index = ctx->chan_index[queue];
   hipError_t e = ph::launch_chan_compose_v210(stream_of(ctx, queue), a, (uint32_t)ctx->props.multiProcessorCount);
   if (e != hipSuccess) return fail(PH_E_HIP, "ph_chan_compose_v210: launch failed: %s", hipGetErrorString(e));
   return PH_OK;
+}
+
+/* Several channels' frames in one launch: see include/phaneron_hip.h.  Jobs the batch kernel does not take (planar / packed-RGB sources,
+ * more ops or wave steps than one launch holds) run through ph_chan_compose_v210 in their turn, so the call as a whole is always the
+ * `n_jobs` separate calls it stands for. */
+int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job *jobs, uint32_t out_w, uint32_t out_h, const void *rd_cm,
+                          const void *rd_lut, const void *rd_gm, const void *wr_cm, const void *wr_lut) {
+  if (!ctx || !jobs || !rd_cm || !rd_lut || !rd_gm || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "ph_chan_compose_batch: NULL argument");
+  PH_QUEUE("ph_chan_compose_batch", queue);
+  if (n_jobs < 1) return fail(PH_E_INVALID, "ph_chan_compose_batch: no jobs");
+  if (!out_w || (out_w & 1)) return fail(PH_E_INVALID, "ph_chan_compose_batch: width %u (a v210 frame needs an even width)", out_w);
+  const ph::LutView *rv = lds_view(ctx, rd_lut), *wv = lds_view(ctx, wr_lut);
+  if (!rv || !wv)
+    return fail(PH_E_INVALID, "ph_chan_compose_batch: the %s gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)", rv ? "writer" : "reader");
+  for (int j = 0; j < n_jobs; ++j) {
+    const ph_chan_job &J = jobs[j];
+    if (!J.layers || !J.out || J.n < 1 || J.n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_chan_compose_batch: job %d: 1..%d layers and an output", j, ph::kMaxLayers);
+    if (J.interlace != 0 && J.interlace != 1 && J.interlace != 3) return fail(PH_E_INVALID, "ph_chan_compose_batch: job %d: interlace must be 0, 1 or 3", j);
+  }
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  const uint32_t num_cus = (uint32_t)ctx->props.multiProcessorCount;
+  // the common part of a launch's arguments (ChanArgs carries it to chan_batch_launch)
+  auto common = [&](uint32_t interlace) {
+    ph::ChanArgs a{};
+    a.out_w = out_w, a.out_h = out_h;
+    a.line_step = interlace ? 2 : 1, a.lines = interlace ? out_h / 2 : out_h;
+    a.rd_cm = (const float *)rd_cm, a.rd_gm = (const float *)rd_gm, a.wr_cm = (const float *)wr_cm, a.rd = *rv, a.wr = *wv;
+    a.out_qpitch = ph_v210_pitch_bytes(out_w) / 16u;
+    a.out_tail_from = out_w % 6 ? out_w - out_w % 6u : 0xFFFFFFFFu;
+    a.planar = out_w % 48 ? 1u : 0u;
+    return a;
+  };
+  ph::ChanBatchArgs b{};
+  ph::ChanArgs a = common(0);
+  bool fields = false;
+  auto flush = [&]() -> int {
+    if (!b.jobs) return PH_OK;
+    const int r = chan_batch_launch(ctx, queue, b, a);
+    b = ph::ChanBatchArgs{};
+    return r;
+  };
+  for (int j = 0; j < n_jobs; ++j) {
+    const ph_chan_job &J = jobs[j];
+    ph::ChanArgs one{};  // this job's program, checked as the single call checks it
+    int k = 0;
+    rc = chan_ops(J.n, J.layers, out_w, out_h, one.op, one.plane_u, one.plane_v, one.cm_op, &one.planar, &k);
+    if (rc) return rc;
+    const bool is_field = J.interlace != 0;
+    const uint32_t lines = is_field ? out_h / 2 : out_h;
+    const uint32_t fit = chan_sched_on() ? ph::chan_batch_max_jobs(out_w, lines, num_cus) : 0u;
+    if (one.planar == 2 || k > ph::kMaxChanBatchOps || fit < 1 || !lines) {  // not for the batch kernel: in its turn, on its own
+      if ((rc = flush())) return rc;
+      if ((rc = ph_chan_compose_v210(ctx, queue, J.n, J.layers, J.out, out_w, out_h, J.interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut))) return rc;
+      continue;
+    }
+    // a launch holds jobs of one kind (frames or fields: the same lines), no two of which write the same lines of one frame
+    bool clash = false;
+    for (uint32_t i = 0; i < b.jobs; ++i)
+      clash = clash || (b.job[i].out == J.out && (!is_field || b.job[i].first_line == (J.interlace == 3 ? 1u : 0u)));
+    if (b.jobs && (fields != is_field || clash || b.jobs >= fit || b.n_ops + (uint32_t)k > (uint32_t)ph::kMaxChanBatchOps))
+      if ((rc = flush())) return rc;
+    if (!b.jobs) a = common(J.interlace), fields = is_field;
+    if (one.planar > a.planar) a.planar = one.planar;  // a source whose lines end in a tail
+    ph::ChanJob &jb = b.job[b.jobs];
+    jb.out = J.out, jb.first_op = b.n_ops, jb.n_ops = (uint32_t)k, jb.first_line = J.interlace == 3 ? 1u : 0u;
+    for (int i = 0; i < k; ++i) b.op[b.n_ops + i] = one.op[i], b.op_job[b.n_ops + i] = (uint8_t)b.jobs;
+    b.n_ops += (uint32_t)k, ++b.jobs;
+  }
+  return flush();
 }
 
 int ph_yadif(ph_ctx *ctx, int queue, const void *prev, const void *cur, const void *next, int w, int h, int parity,

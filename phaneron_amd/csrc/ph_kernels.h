@@ -112,6 +112,46 @@ struct ChanArgs {
   uint32_t halo_off, halo_steps;  // byte offset in the LDS; steps per op the area holds (0: no sharing in this launch)
 };
 
+// Several channels' frames of ONE geometry and colour recipe in one launch (ph_chan_compose_batch) - what the reference runs: four
+// channels of <= 1080p in one context through one queue (src/index.ts:45-71,156-160, clJobQueue.ts:114-141).  A workgroup takes its
+// share of EVERY job (the same chunks of each frame), so the tables are loaded once, and the wave steps of all jobs together are
+// handed to the waves as they come free, dearest first (the scheduler in ph_kernels_chan.hip).  v210 / f32 image sources, v210 out.
+constexpr int kMaxChanJobs = 8;
+constexpr int kMaxChanBatchOps = 40;       // the ops of all jobs of a launch (the argument block has to stay below 4 KiB)
+constexpr uint32_t kMaxChanEntries = 768;   // wave steps of a workgroup over all jobs: one lane per step, of at most twelve waves, when the list is made
+struct ChanJob {
+  void *out, *index;  // the v210 frame; this job's index frame (chan_index_bytes each)
+  uint32_t first_op, n_ops, first_line, pad;
+};
+struct ChanBox {  // where an op's source can show in the output (pixels / frame lines, inclusive; conservative) - scheduling only
+  int16_t x0, x1, y0, y1;
+  uint32_t job_cost;  // the op's job | its relative price for a wave step it shows in (conversions per pixel pair) << 8
+};
+struct ChanBatchArgs {
+  ChanOp op[kMaxChanBatchOps];
+  ChanJob job[kMaxChanJobs];
+  ChanBox box[kMaxChanBatchOps];
+  uint8_t op_job[kMaxChanBatchOps];  // the job an op belongs to (the caller fills this in; the kernel reads ChanBox::job_cost)
+  uint32_t share_op[8];              // the ops that share taps (ChanHalo), by halo table
+  uint32_t jobs, n_ops, n_share;
+  uint32_t magic_cpr, magic_cpg;     // as ChanArgs
+  uint32_t steps;                    // wave steps per job of the workgroups that have the most chunks (launcher)
+  uint32_t magic_spj, magic_qpj;     // ceil(2^32 / steps), ceil(2^32 / quads per job and workgroup = 64 * steps / 3)
+  uint32_t out_w, out_h, lines, line_step;
+  const float *rd_cm, *rd_gm, *wr_cm;
+  LutView rd, wr;
+  uint32_t tails;  // 1: lines may end in a tail (the TAILS instantiation)
+  uint32_t out_qpitch, out_tail_from;
+  uint32_t job_rot[kMaxChanJobs][4];  // per job and XCD (two 16-bit values per word): how far the job's share is rotated round the XCD's workgroups
+  uint32_t sched_off;              // LDS byte offset of the scheduler's area behind the table
+  uint32_t flags;                  // experiments: 1 = natural order, no pricing
+  uint32_t halo_off, halo_steps;   // as ChanArgs; halo_steps = wave steps per job and workgroup
+};
+static_assert(sizeof(ChanBatchArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+hipError_t launch_chan_compose_batch(hipStream_t s, const ChanBatchArgs &a, uint32_t num_cus);
+// how many jobs of this geometry one launch takes (the launcher refuses more with hipErrorInvalidValue: callers split)
+uint32_t chan_batch_max_jobs(uint32_t out_w, uint32_t lines, uint32_t num_cus);
+
 // ph_kernels_up.hip: the 2 x 2-block compositor for magnifying placements
 struct UpLayer {
   const void *ptr;       // f32 RGBA (16 bytes per texel) or packed f32 RGB (12)

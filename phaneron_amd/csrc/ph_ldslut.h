@@ -21,7 +21,8 @@ constexpr int kLdsBlock = 1024;
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
 // all lanes of the workgroup copy the table blob global -> LDS (16 bytes per lane per step)
-template <int BS = kLdsBlock>
+// WAIT = false: the caller waits (s_waitcnt vmcnt(0)) and synchronises itself, having done something else meanwhile
+template <int BS = kLdsBlock, bool WAIT = true>
 __device__ __forceinline__ void lds_lut_load(const LutView &v) {
 #if PH_ABLATE & 2  // timing experiment only: no table loads
   return;
@@ -38,7 +39,7 @@ __device__ __forceinline__ void lds_lut_load(const LutView &v) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i),
                                        (__attribute__((address_space(3))) void *)(dst + 16 * base), 16, 0, 0);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // table[clamp(rint(x), 0, 65535)] for x = (gamma- or linear-domain value) * 65535, see ph_lut.h:

@@ -492,3 +492,106 @@ def test_other_output_formats_at_1280(fmt):
     v = [frames.v210_random(w, h, frames.layer_seed(86, l)) for l in range(2)]
     layers = [dict(src=Src(v[0], w, h)), dict(src=Src(v[1], w, h, m(w, h, scale_x=0.5, scale_y=0.5, offset_x=0.1)))]
     check_format(layers, w, h, fmt, "1280-wide %s frame" % fmt)
+
+
+# ---- several channels' frames per launch (ph_chan_compose_batch, round 5) -----------------------------------------------------
+
+def device_layers(layers):
+    dl = []
+    for L in layers:
+        d = dict(src=L["src"].device(), transition=L.get("transition", "cut"), mix=L.get("mix", 0.0))
+        for role in ("incoming", "mask"):
+            if L.get(role) is not None:
+                d[role] = L[role].device()
+        dl.append(d)
+    return dl
+
+
+def check_batch(jobs, ow, oh, what, specs=("709", "709")):
+    """jobs: list of (layers, interlace, out_slot) - jobs with the same out_slot write into one frame (its two fields).  Every frame
+    against the oracle's chain, word for word, and against the same jobs posted one call each."""
+    import torch
+    import hip_harness as hh
+    rd_o, wr_o, rd_d, wr_d = colour(*specs)
+    k = hh.ctx()
+    words = frames.v210_pitch_bytes(ow) * oh // 4
+    slots = sorted({s for _, _, s in jobs})
+    want = {s: np.full(words, 0x2AAAAAAA, np.uint32) for s in slots}
+    for layers, interlace, s in jobs:
+        want[s] = np.asarray(oracle_chain(layers, ow, oh, interlace, rd_o, wr_o, want[s])).reshape(-1)
+    outs = {s: hh.dev(np.full(words, 0x2AAAAAAA, np.uint32)) for s in slots}
+    single = {s: hh.dev(np.full(words, 0x2AAAAAAA, np.uint32)) for s in slots}
+    dls = [device_layers(layers) for layers, _, _ in jobs]
+    k.chan_compose_batch([(dl, outs[s], il) for dl, (_, il, s) in zip(dls, jobs)], ow, oh, *rd_d, *wr_d)
+    for dl, (_, il, s) in zip(dls, jobs):
+        k.chan_compose_v210(dl, single[s], ow, oh, il, *rd_d, *wr_d)
+    for s in slots:
+        got, one = hh.host(outs[s], np.uint32), hh.host(single[s], np.uint32)
+        bad = np.flatnonzero(got != want[s])
+        assert bad.size == 0, "%s: frame %d: %d of %d words differ from the oracle chain, first at word %d (line %d)" % (
+            what, s, bad.size, got.size, bad[0], bad[0] // (frames.v210_pitch_bytes(ow) // 4))
+        assert np.array_equal(got, one), "%s: frame %d: the batch differs from the separate calls" % (what, s)
+
+
+def channel_variants(w, h, seed):
+    """four channels as a gallery would run them: PiP, PiP in mid-wipe, a dissolve against a placed source under an f32 layer, one plain layer"""
+    second = frames.v210_random(w, h, frames.layer_seed(seed, 9), legal=False)
+    a = pip_layers(w, h, seed)
+    b = pip_layers(w, h, seed + 1)
+    b[3].update(transition="wipe", incoming=Src(second, w, h), mask=Src(frames.mask_ramp(w, h), w, h, fmt="rgba"))
+    c = pip_layers(w, h, seed + 2, 2)
+    c[1].update(transition="dissolve", mix=0.375, incoming=Src(second, w, h, m(w, h, scale_x=0.5, scale_y=0.5, rotate=0.1)))
+    c.append(dict(src=Src(frames.rgba_random(w, h, seed + 3, -0.05, 1.05), w, h, fmt="rgba")))
+    d = [dict(src=Src(frames.v210_random(w, h, frames.layer_seed(seed, 7)), w, h))]
+    return [a, b, c, d]
+
+
+def test_chan_batch_equals_separate_calls():
+    """four different channels' frames in one launch = the oracle's chain per channel = four separate calls"""
+    w, h = 384, 108
+    check_batch([(layers, 0, i) for i, layers in enumerate(channel_variants(w, h, 300))], w, h, "4 channels %dx%d" % (w, h))
+    check_batch([(layers, 0, i) for i, layers in enumerate(channel_variants(w, h, 310))], w, h, "4 channels 709 -> 2020", specs=("709", "2020"))
+
+
+def test_chan_batch_fields_and_mixed_kinds():
+    """both fields of a frame as two jobs of one launch; fields and frames in one call (split into launches inside); eight jobs; nine jobs"""
+    w, h = 384, 54
+    v = channel_variants(w, h, 320)
+    check_batch([(v[0], 1, 0), (v[1], 3, 0)], w, h, "two fields of one frame from two programs")
+    check_batch([(v[0], 1, 0), (v[0], 3, 0), (v[2], 1, 1), (v[2], 3, 1)], w, h, "two channels' field pairs")
+    check_batch([(v[0], 0, 0), (v[1], 1, 1), (v[2], 3, 1), (v[3], 0, 2)], w, h, "frames and fields in one call")
+    more = channel_variants(w, h, 330)
+    check_batch([(x, 0, i) for i, x in enumerate(v + more)], w, h, "eight jobs")
+    check_batch([(x, 0, i) for i, x in enumerate(v + more + [v[1]])], w, h, "nine jobs: two launches")
+
+
+def test_chan_batch_same_frame_twice_keeps_call_order():
+    """two jobs that write the same lines of one frame are not put into one launch: the later job wins, as with separate calls"""
+    w, h = 192, 12
+    v = channel_variants(w, h, 340)
+    check_batch([(v[0], 0, 0), (v[3], 0, 0)], w, h, "same frame twice")
+    check_batch([(v[0], 1, 0), (v[3], 0, 0)], w, h, "a field, then the whole frame")
+
+
+def test_chan_batch_lines_with_tails():
+    """1280-wide channels (src/config.ts:43-54): tail quads and cleared slots in every job; a narrower ragged source in one of them"""
+    w, h = 1280, 24
+    v = channel_variants(w, h, 350)
+    small = frames.v210_random(332, 10, frames.layer_seed(350, 5))
+    v[3].append(dict(src=Src(small, 332, 10, m(w, h, scale_x=0.4, scale_y=0.4, offset_x=0.2))))
+    check_batch([(x, 0, i) for i, x in enumerate(v)], w, h, "4 channels 1280 wide")
+    check_batch([(v[0], 1, 0), (v[3], 3, 0)], w, h, "1280 wide, the two fields")
+
+
+def test_chan_batch_with_a_planar_job_in_the_middle():
+    """a job the batch kernel does not take (planar sources) runs in its turn through the one-job kernel; the jobs around it are batched"""
+    w, h = 384, 32
+    v = channel_variants(w, h, 360)
+    planar = [dict(src=Src(frames.pack_random("yuv422p10", w, h, 361), w, h, fmt="yuv422p10")), v[3][0]]
+    check_batch([(v[0], 0, 0), (planar, 0, 1), (v[1], 0, 2), (v[2], 0, 3)], w, h, "planar job between batched ones")
+
+
+def test_chan_batch_full_size_four_1080p_channels():
+    """the reference's deployment: four 1080p channels in one context (src/index.ts:45-71) - one launch, each frame = the oracle's chain"""
+    w, h = 1920, 1080
+    check_batch([(layers, 0, i) for i, layers in enumerate(channel_variants(w, h, 370))], w, h, "4 channels 1920x1080")

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE config 2 through ph_chan_compose_v210 alone (one launch per frame): the timing loop tools/pmc_kernel.sh profiles.
-  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets] [sources: v210|yuv422p10|yuv422p8|yuv420p|nv12]"""
+  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets] [sources: v210|yuv422p10|yuv422p8|yuv420p|nv12]
+  PH_CHAN_BENCH_JOBS=C: C channels' frames per launch (ph_chan_compose_batch); PH_CHAN_BENCH_W / _H: another frame size;
+  PH_CHAN_SCHED=0: the one-job kernel with its wave steps dealt in turn (the A/B of round 5)"""
 import json
 import os
 import sys
@@ -20,7 +22,9 @@ def main():
     ctx = capi.Context(0)
     stream = ctx.torch_stream()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    w, h, R = 1920, int(os.environ.get("PH_CHAN_BENCH_H", "1080")), 8  # (another height: how much of a frame's time is the last, partial round of chunks)
+    # (another height: how much of a frame's time is the last, partial round of chunks)
+    w, h, R = int(os.environ.get("PH_CHAN_BENCH_W", "1920")), int(os.environ.get("PH_CHAN_BENCH_H", "1080")), 8
+    C = int(os.environ.get("PH_CHAN_BENCH_JOBS", "1"))
     rd = [dev(capi.ycbcr2rgb_matrix("709")), dev(capi.gamma2linear_lut("709")), dev(np.concatenate([capi.rgb2rgb_matrix("709", "709"), np.zeros(3, np.float32)]))]
     wr = [dev(capi.rgb2ycbcr_matrix("709")), dev(capi.linear2gamma_lut("709"))]
     torch.cuda.synchronize()
@@ -56,7 +60,11 @@ def main():
         elif variant == "insets":
             ls = ls[1:]
         return ls
-    jobs = [ctx.chan_compose_v210(layers(s), out, w, h, 0, *rd, *wr, prepare_only=True) for s in src]
+    if C > 1:  # C channels per launch: each job its own sources (rotated through the ring) and its own output
+        outs = [torch.empty(words, dtype=torch.int32, device="cuda") for _ in range(C)]
+        jobs = [ctx.chan_compose_batch([(layers(src[(i + j) % R]), outs[j], 0) for j in range(C)], w, h, *rd, *wr, prepare_only=True) for i in range(R)]
+    else:
+        jobs = [ctx.chan_compose_v210(layers(s), out, w, h, 0, *rd, *wr, prepare_only=True) for s in src]
     import time
     i, t0 = 0, time.perf_counter()
     while i < 8 or time.perf_counter() - t0 < 0.15:  # until the chip's clocks have settled (tools/config_bench.py timeit)
@@ -71,7 +79,9 @@ def main():
         jobs[i % R]()
     e1.record(stream)
     ctx.wait()
-    print(json.dumps({"kernel": "chan_compose_v210", "height": h, "variant": variant, "mask": mask_kind, "sources": packing, "us_per_frame": round(1e3 * e0.elapsed_time(e1) / reps, 2)}), flush=True)
+    print(json.dumps({"kernel": "chan_compose_v210", "width": w, "height": h, "variant": variant, "mask": mask_kind, "sources": packing, "jobs_per_launch": C,
+                      "sched": os.environ.get("PH_CHAN_SCHED", "1"), "us_per_launch": round(1e3 * e0.elapsed_time(e1) / reps, 2),
+                      "us_per_frame": round(1e3 * e0.elapsed_time(e1) / reps / C, 2)}), flush=True)
     ctx.close()
 
 
