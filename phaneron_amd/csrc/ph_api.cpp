@@ -1818,9 +1818,9 @@ static int chan_source(const ph_chan_source &s, const char *what, int layer, uin
   return PH_OK;
 }
 
-// PH_CHAN_SCHED=0: the one-job kernel with its wave steps dealt in turn (A/B runs, tools/chan_bench.py)
-static bool chan_sched_on() {
-  static const bool on = !(getenv("PH_CHAN_SCHED") && getenv("PH_CHAN_SCHED")[0] == '0');
+// PH_CHAN_BATCH=0: every job of a batch call through the one-job kernel (A/B runs, tools/chan_bench.py)
+static bool chan_batch_on() {
+  static const bool on = !(getenv("PH_CHAN_BATCH") && getenv("PH_CHAN_BATCH")[0] == '0');
   return on;
 }
 // the index frames between the phases: one area per queue (launches on one queue are in order), grown on demand (ctx->mu held)
@@ -1933,15 +1933,6 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
   if (!a.lines) return PH_OK;
   int rc = set_device(ctx);
   if (rc) return rc;
-  // v210 frames from v210 / f32 sources: the kernel that hands its wave steps out at run time, dearest first (one job of a batch)
-  if (out_format == PH_FMT_V210 && a.planar < 2 && chan_sched_on() && k <= ph::kMaxChanBatchOps &&
-      ph::chan_batch_max_jobs(out_w, a.lines, (uint32_t)ctx->props.multiProcessorCount) >= 1) {
-    ph::ChanBatchArgs b{};
-    for (int i = 0; i < k; ++i) b.op[i] = a.op[i], b.op_job[i] = 0;
-    b.jobs = 1, b.n_ops = (uint32_t)k;
-    b.job[0].out = out, b.job[0].first_op = 0, b.job[0].n_ops = (uint32_t)k, b.job[0].first_line = a.first_line;
-    return chan_batch_launch(ctx, queue, b, a);
-  }
   // the index frame between the phases: one per queue (launches on one queue are in order), grown on demand
   std::lock_guard<std::mutex> lock(ctx->mu);
   rc = chan_index_reserve(ctx, queue, ph::chan_index_bytes(out_w, a.lines));
@@ -1971,7 +1962,6 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
   }
   int rc = set_device(ctx);
   if (rc) return rc;
-  const uint32_t num_cus = (uint32_t)ctx->props.multiProcessorCount;
   // the common part of a launch's arguments (ChanArgs carries it to chan_batch_launch)
   auto common = [&](uint32_t interlace) {
     ph::ChanArgs a{};
@@ -1983,12 +1973,36 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
     a.planar = out_w % 48 ? 1u : 0u;
     return a;
   };
+  // How many jobs a launch should take so that the launches come out even (eight jobs of six ops are 4 + 4, not 6 + 2: a launch of
+  // two is a poor one): by the jobs and ops of the call as a whole - a plan, the limits below still hold for every launch
+  uint32_t plan_jobs = 0, plan_ops = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    bool wire = false;  // planar / packed-RGB sources: not for the batch kernel
+    uint32_t ops = 0;
+    for (int l = 0; l < jobs[j].n; ++l) {
+      const ph_chan_layer &L = jobs[j].layers[l];
+      ops += L.transition == PH_TRANSITION_WIPE ? 3u : L.transition == PH_TRANSITION_DISSOLVE ? 2u : 1u;
+      wire = wire || L.src.format > PH_SRC_RGBA_F32 || L.incoming.format > PH_SRC_RGBA_F32 || L.mask.format > PH_SRC_RGBA_F32;
+    }
+    if (!wire && ops <= (uint32_t)ph::kMaxChanBatchOps) ++plan_jobs, plan_ops += ops;
+  }
+  const uint32_t by_jobs = (plan_jobs + (uint32_t)ph::kMaxChanJobs - 1u) / (uint32_t)ph::kMaxChanJobs;
+  const uint32_t by_ops = (plan_ops + (uint32_t)ph::kMaxChanBatchOps - 1u) / (uint32_t)ph::kMaxChanBatchOps;
+  const uint32_t launches = by_jobs > by_ops ? by_jobs : by_ops;
+  const uint32_t jobs_per_launch = launches ? (plan_jobs + launches - 1u) / launches : 1u;
   ph::ChanBatchArgs b{};
   ph::ChanArgs a = common(0);
   bool fields = false;
+  int first_job = 0;  // of the launch being collected
   auto flush = [&]() -> int {
     if (!b.jobs) return PH_OK;
-    const int r = chan_batch_launch(ctx, queue, b, a);
+    int r;
+    if (b.jobs == 1) {  // nothing to share: the one-job kernel
+      const ph_chan_job &J = jobs[first_job];
+      r = ph_chan_compose_v210(ctx, queue, J.n, J.layers, J.out, out_w, out_h, J.interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut);
+    } else {
+      r = chan_batch_launch(ctx, queue, b, a);
+    }
     b = ph::ChanBatchArgs{};
     return r;
   };
@@ -2000,7 +2014,7 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
     if (rc) return rc;
     const bool is_field = J.interlace != 0;
     const uint32_t lines = is_field ? out_h / 2 : out_h;
-    const uint32_t fit = chan_sched_on() ? ph::chan_batch_max_jobs(out_w, lines, num_cus) : 0u;
+    const uint32_t fit = chan_batch_on() ? jobs_per_launch : 0u;
     if (one.planar == 2 || k > ph::kMaxChanBatchOps || fit < 1 || !lines) {  // not for the batch kernel: in its turn, on its own
       if ((rc = flush())) return rc;
       if ((rc = ph_chan_compose_v210(ctx, queue, J.n, J.layers, J.out, out_w, out_h, J.interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut))) return rc;
@@ -2012,7 +2026,7 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
       clash = clash || (b.job[i].out == J.out && (!is_field || b.job[i].first_line == (J.interlace == 3 ? 1u : 0u)));
     if (b.jobs && (fields != is_field || clash || b.jobs >= fit || b.n_ops + (uint32_t)k > (uint32_t)ph::kMaxChanBatchOps))
       if ((rc = flush())) return rc;
-    if (!b.jobs) a = common(J.interlace), fields = is_field;
+    if (!b.jobs) a = common(J.interlace), fields = is_field, first_job = j;
     if (one.planar > a.planar) a.planar = one.planar;  // a source whose lines end in a tail
     ph::ChanJob &jb = b.job[b.jobs];
     jb.out = J.out, jb.first_op = b.n_ops, jb.n_ops = (uint32_t)k, jb.first_line = J.interlace == 3 ? 1u : 0u;

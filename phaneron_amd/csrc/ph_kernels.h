@@ -114,25 +114,19 @@ struct ChanArgs {
 
 // Several channels' frames of ONE geometry and colour recipe in one launch (ph_chan_compose_batch) - what the reference runs: four
 // channels of <= 1080p in one context through one queue (src/index.ts:45-71,156-160, clJobQueue.ts:114-141).  A workgroup takes its
-// share of EVERY job (the same chunks of each frame), so the tables are loaded once, and the wave steps of all jobs together are
-// handed to the waves as they come free, dearest first (the scheduler in ph_kernels_chan.hip).  v210 / f32 image sources, v210 out.
+// share of EVERY job, so the tables are loaded once and the wave steps of all jobs together are dealt to the waves in front of one
+// barrier (ph_kernels_chan.hip).  v210 / f32 image sources, v210 out.
 constexpr int kMaxChanJobs = 8;
-constexpr int kMaxChanBatchOps = 40;       // the ops of all jobs of a launch (the argument block has to stay below 4 KiB)
-constexpr uint32_t kMaxChanEntries = 768;   // wave steps of a workgroup over all jobs: one lane per step, of at most twelve waves, when the list is made
+constexpr int kMaxChanBatchOps = 40;  // the ops of all jobs of a launch (the argument block has to stay below 4 KiB)
 struct ChanJob {
   void *out, *index;  // the v210 frame; this job's index frame (chan_index_bytes each)
   uint32_t first_op, n_ops, first_line, pad;
 };
-struct ChanBox {  // where an op's source can show in the output (pixels / frame lines, inclusive; conservative) - scheduling only
-  int16_t x0, x1, y0, y1;
-  uint32_t job_cost;  // the op's job | its relative price for a wave step it shows in (conversions per pixel pair) << 8
-};
 struct ChanBatchArgs {
   ChanOp op[kMaxChanBatchOps];
   ChanJob job[kMaxChanJobs];
-  ChanBox box[kMaxChanBatchOps];
-  uint8_t op_job[kMaxChanBatchOps];  // the job an op belongs to (the caller fills this in; the kernel reads ChanBox::job_cost)
-  uint32_t share_op[8];              // the ops that share taps (ChanHalo), by halo table
+  uint8_t op_job[kMaxChanBatchOps];  // the job an op belongs to (for the launcher)
+  uint32_t share_op[8];              // launcher: the ops that share taps (ChanHalo), by halo table: op | its job << 8 | the job's first line << 16
   uint32_t jobs, n_ops, n_share;
   uint32_t magic_cpr, magic_cpg;     // as ChanArgs
   uint32_t steps;                    // wave steps per job of the workgroups that have the most chunks (launcher)
@@ -143,14 +137,12 @@ struct ChanBatchArgs {
   uint32_t tails;  // 1: lines may end in a tail (the TAILS instantiation)
   uint32_t out_qpitch, out_tail_from;
   uint32_t job_rot[kMaxChanJobs][4];  // per job and XCD (two 16-bit values per word): how far the job's share is rotated round the XCD's workgroups
-  uint32_t sched_off;              // LDS byte offset of the scheduler's area behind the table
-  uint32_t flags;                  // experiments: 1 = natural order, no pricing
-  uint32_t halo_off, halo_steps;   // as ChanArgs; halo_steps = wave steps per job and workgroup
+  uint32_t sched_off;              // LDS byte offset of the jobs' tables behind the gamma table
+  uint32_t halo_off, halo_steps;   // as ChanArgs; halo_steps = steps
 };
 static_assert(sizeof(ChanBatchArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+// refuses (hipErrorInvalidValue) more than kMaxChanJobs jobs / kMaxChanBatchOps ops: callers split
 hipError_t launch_chan_compose_batch(hipStream_t s, const ChanBatchArgs &a, uint32_t num_cus);
-// how many jobs of this geometry one launch takes (the launcher refuses more with hipErrorInvalidValue: callers split)
-uint32_t chan_batch_max_jobs(uint32_t out_w, uint32_t lines, uint32_t num_cus);
 
 // ph_kernels_up.hip: the 2 x 2-block compositor for magnifying placements
 struct UpLayer {

@@ -41,6 +41,9 @@
 #ifndef PH_CHAN_PROBE
 #define PH_CHAN_PROBE 0
 #endif
+#ifndef PH_CHAN_ARG_PREFETCH  // 0: an A/B build without the batch kernel's argument-block prefetch
+#define PH_CHAN_ARG_PREFETCH 1
+#endif
 #if PH_CHAN_PROBE
 __device__ unsigned long long g_chan_probe[8 * 64];
 __device__ unsigned long long g_chan_phase[256 * 16];  // per workgroup: s_memrealtime at the phase boundaries (wave 0)
@@ -838,34 +841,37 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
   PH_CPHASE(5);
 }
 
-// ---- several channels per launch, wave steps handed out at run time -------------------------------------------------------------
-// The one-job kernel above deals a workgroup's wave steps to its sixteen waves in turn.  At 1080p that is 63 or 66 steps of very
-// different price (a step outside every inset converts one column per pixel, one under three layers and a wipe eleven): four rounds
-// whose last one decides when the workgroup reaches its barrier - 4.9 of 46 us waiting, workgroups ending 2.8 us apart
-// (profiles/r04_chan_probe.jsonl).  Here
-//   * the jobs of a launch (channels of one geometry and colour recipe: the reference's deployment is four such channels in one
-//     context, src/index.ts:45-71) share the workgroups: every workgroup takes chunks of every frame, so the tables are loaded once
-//     and there are `jobs` times as many steps to even out over.  Which workgroup has a chunk more than its neighbours, and which
-//     XCD a band more, rotates from job to job (ChanBatchArgs::job_rot), so the shares add up evenly;
-//   * while the reader table is on its way (its LDS-DMA is issued by the upper waves) the lower waves price the workgroup's steps
-//     (one lane per step: which ops' boxes - worked out by the launcher - the step touches) and make the list the waves then TAKE
-//     their steps from as they come free (an LDS counter): the steps in their natural order (neighbours share cache lines, and dear
-//     and cheap steps side by side use the pipes better than dear ones all at once: measured), except the cheapest one and a half
-//     rounds' worth, which come last, dearest of them first - what is left for the end are cheap steps, so the wait for the
-//     workgroup's slowest wave shrinks from a dear step's length to a cheap one's;
-//   * the words of the halo columns (ChanHalo) are asked for before the table is there and converted once it is.
-// Everything a step computes is what the one-job kernel computes for it; only who runs it and when differs.
-constexpr uint32_t kSchedHist = 16, kSchedOut = kSchedHist + 32 * 4, kSchedIndex = kSchedOut + 8 * kMaxChanJobs, kSchedFirst = kSchedIndex + 8 * kMaxChanJobs,
-                   kSchedShare = kSchedFirst + 4 * kMaxChanJobs, kSchedOrder = kSchedShare + 16 * kMaxChanJobs;
-// byte offsets inside the scheduler's LDS area: [0] the counter, the price histogram, the jobs' pointers and shares, the order list
-// (u16 per step; first the sort keys), then the ranks (u32 per step)
-__host__ __device__ constexpr uint32_t chan_sched_pad(uint32_t entries) { return (entries + 7u) & ~7u; }
-__host__ __device__ constexpr uint32_t chan_sched_bytes(uint32_t entries) { return (kSchedOrder + 6u * chan_sched_pad(entries) + 15u) & ~15u; }
-constexpr uint32_t kSchedNoStep = 0xFFFFu;  // in the order list: no chunk behind this step (they sort last: the list ends at the first one)
-constexpr uint32_t kSchedTail = 24u;        // about this many of the cheapest steps are kept for the end (one and a half rounds of the sixteen waves)
+// ---- several channels' frames per launch ------------------------------------------------------------------------------------------
+// A 1080p frame is 63 or 66 wave steps per workgroup for sixteen waves: four rounds of steps of very different price, the last
+// of which decides when the workgroup reaches its barrier, and two table loads - 4.9 + 3.1 of 46 us (profiles/r04_chan_probe.jsonl).
+// The reference runs four such channels in one context through one queue (src/index.ts:45-71,156-160).  Here the jobs of a launch
+// (frames of one geometry and colour recipe, each with its own layers) share the workgroups: every workgroup takes chunks of every
+// frame, the tables are loaded once, and the steps of all jobs together are dealt to the waves - sixteen rounds instead of four
+// in front of ONE barrier.  Which workgroup has a chunk more than its neighbours, and which XCD a band more, rotates from job
+// to job (ChanBatchArgs::job_rot), so the shares add up evenly.  The words of the halo columns (ChanHalo) are asked for before
+// the table is there and converted once it is.  Everything a step computes is what the one-job kernel computes for it.
+//
+// What was built on top of this and measured NOT to pay (round 5, profiles/r05_chan_sched_probe.txt, commit c6043a8): the workgroup
+// pricing its steps (which ops' boxes a step touches) and handing them out at run time from a sorted list, cheapest last - the
+// wait for the slowest wave does shrink (4.8 -> 2.6 us per launch), but a workgroup's phase 1 as a whole only by 0.5 - 1.2 us,
+// and making the list costs 3 us per launch even beside the table's DMA (four barriers' worth of LDS round trips while the DMA
+// fills the LDS); dearest-first over ALL steps slows phase 1 itself (like steps side by side use the pipes worse than a mix).
+constexpr uint32_t kSchedOut = 16, kSchedIndex = kSchedOut + 8 * kMaxChanJobs, kSchedFirst = kSchedIndex + 8 * kMaxChanJobs,
+                   kSchedShare = kSchedFirst + 4 * kMaxChanJobs, kSchedBytes = kSchedShare + 16 * kMaxChanJobs;
+// byte offsets inside the batch kernel's LDS area behind the table: the jobs' pointers, first lines and shares, indexable per lane
 
-// barrier for the LDS traffic of the scheduler alone: the table's LDS-DMA (counted by vmcnt) stays in flight across it
-__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// One aligned dword-vector of the argument block per lane, through a vector load (the scalar loads the compiler makes of plain
+// accesses are one cold miss after the other where several entries are read in a loop)
+template <class T>
+__device__ __forceinline__ T chan_arg_lane(size_t offset, uint32_t index) {
+  static_assert(sizeof(T) % 4 == 0, "dword vectors");
+  T v;
+  const __attribute__((address_space(1))) uint32_t *p =
+      (const __attribute__((address_space(1))) uint32_t *)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offset + index * sizeof(T));
+#pragma unroll
+  for (size_t i = 0; i < sizeof(T) / 4; ++i) reinterpret_cast<uint32_t *>(&v)[i] = p[i];
+  return v;
+}
 
 // a job's share of this workgroup: as chan_share, with the workgroup's place among its XCD's workgroups and the XCD's place among
 // the bands rotated by the job (so that the workgroups / XCDs with one chunk / band more are different ones for every job)
@@ -890,275 +896,80 @@ __device__ __forceinline__ uint32_t chan_chunk_of(const ChanBatchArgs &a, const 
   return chunk < sh.chunks ? chunk : ~0u;
 }
 
-// How the waves split the prologue: waves [0, NS) make the list, waves [NS, 16) bring the table in.  NS: two waves per 64 steps
-// (the comparisons of the ranking are split over them), at least four, at most twelve.
-__device__ __forceinline__ uint32_t chan_sort_waves(uint32_t entries) {  // (entries <= kMaxChanEntries = 12 * 64: the launcher)
-  const uint32_t ns = 2u * ((entries + 63u) / 64u);
-  return ns < 4u ? 4u : ns > 12u ? 12u : ns;
-}
-constexpr int kSchedBarriers = 4;  // lds_only_barrier calls inside chan_sched_build: the table-loading waves make as many
-
-// One aligned dword-vector of the argument block per lane, through a vector load: what the list is made from (the ops' boxes, the
-// jobs) is read ONCE, all lanes at a time, at the very start - a scalar load per op or job inside the loops below is a dependent
-// chain of misses, each queued behind the table's DMA traffic of the whole chip (measured: 5 us for one job, 10 for four).
-template <class T>
-__device__ __forceinline__ T chan_arg_lane(size_t offset, uint32_t index) {
-  static_assert(sizeof(T) % 4 == 0, "dword vectors");
-  T v;
-  const __attribute__((address_space(1))) uint32_t *p =
-      (const __attribute__((address_space(1))) uint32_t *)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offset + index * sizeof(T));
-#pragma unroll
-  for (size_t i = 0; i < sizeof(T) / 4; ++i) reinterpret_cast<uint32_t *>(&v)[i] = p[i];
-  return v;
-}
-
-// flags (ChanBatchArgs::flags; experiments of tools/chan_bench.py): 1 = steps in their natural order, no pricing (the run-time
-// hand-out alone); 2 = every step sorted dearest first (no natural-order part)
-__device__ __forceinline__ void chan_sched_build(const ChanBatchArgs &a, const ChanShare &sh, uint32_t n_waves) {
-  uint32_t *const ctrl = reinterpret_cast<uint32_t *>(g_lds + a.sched_off);
-  uint32_t *const hist = reinterpret_cast<uint32_t *>(g_lds + a.sched_off + kSchedHist);
-  uint16_t *const keys = reinterpret_cast<uint16_t *>(g_lds + a.sched_off + kSchedOrder);  // later the order list itself
-  // S: the most wave steps any workgroup has per job (this workgroup may have a chunk less: such steps have no chunk and sort last)
-  const uint32_t S = a.steps, E = a.jobs * S, Epad = chan_sched_pad(E);  // (the launcher keeps E <= 64 * n_waves)
-  uint32_t *const rank = reinterpret_cast<uint32_t *>(g_lds + a.sched_off + kSchedOrder + 2u * Epad);
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  // lane k: op k's box; lane j: job j (every wave keeps its own copy: the loops below take them with v_readlane)
-  struct BoxWords {
-    uint32_t x, y, job_cost;
-  };
-  static_assert(sizeof(ChanBox) == 12 && sizeof(ChanJob) == 32 && kMaxChanBatchOps <= 64, "one lane per op / job");
-  const BoxWords box = chan_arg_lane<BoxWords>(offsetof(ChanBatchArgs, box), lane < a.n_ops ? lane : 0u);
-  if (threadIdx.x == 0u) ctrl[0] = 0u;
-  if (threadIdx.x < 32u) hist[threadIdx.x] = 0u;
-  if (wave == 1u && lane < a.jobs) {  // the job's share (chan_job_share, in vector code) and pointers where the steps and phase 2 can index them per lane
-    const uint4 jw0 = chan_arg_lane<uint4>(offsetof(ChanBatchArgs, job), 2u * lane), jw1 = chan_arg_lane<uint4>(offsetof(ChanBatchArgs, job), 2u * lane + 1u);
-    const uint4 rot = chan_arg_lane<uint4>(offsetof(ChanBatchArgs, job_rot), lane);
-    const uint32_t xcd = sh.banded ? (sh.xcd + lane) & 7u : 0u;
-    const uint32_t vend = sh.banded ? ((sh.groups + 7u - xcd) >> 3) * sh.cpg : sh.chunks;
-    const uint32_t word = (xcd >> 1) == 0u ? rot.x : (xcd >> 1) == 1u ? rot.y : (xcd >> 1) == 2u ? rot.z : rot.w;
-    uint32_t v0 = sh.v0 + ((xcd & 1u) ? word >> 16 : word & 0xFFFFu);
-    v0 = v0 >= sh.vstep ? v0 - sh.vstep : v0;
-    reinterpret_cast<uint4 *>(g_lds + a.sched_off + kSchedShare)[lane] = make_uint4(v0, xcd, vend, 0u);
-    reinterpret_cast<uint2 *>(g_lds + a.sched_off + kSchedOut)[lane] = make_uint2(jw0.x, jw0.y);    // ChanJob::out
-    reinterpret_cast<uint2 *>(g_lds + a.sched_off + kSchedIndex)[lane] = make_uint2(jw0.z, jw0.w);  // ChanJob::index
-    reinterpret_cast<uint32_t *>(g_lds + a.sched_off + kSchedFirst)[lane] = jw1.z;                  // ChanJob::first_line
-  }
-  lds_only_barrier();  // 1
-  PH_CPHASE(8);
-  // one lane per step: its price = 1 + the sum over the ops of its job whose box it touches (0: no chunk behind the step)
-  const uint32_t e = threadIdx.x;
-  uint32_t entry = kSchedNoStep, price = 0u;
-  if (e < E) {
-    const uint32_t j = __umulhi(e, a.magic_spj), n = e - j * S;
-    const uint32_t slot = n / 3u, sub = n - 3u * slot;
-    const uint4 js = reinterpret_cast<const uint4 *>(g_lds + a.sched_off + kSchedShare)[j];
-    const uint32_t chunk = chan_chunk_of(a, sh, js.x, js.y, js.z, slot);
-    if (chunk != ~0u) {
-      entry = (j << 12) | n;
-      price = 1u;
-      if (!(a.flags & 1u)) {
-        uint32_t rp, cx;
-        chan_place(a, sh, chunk, rp, cx);
-        const int x0 = (int)(cx + sub * 64u), x1 = x0 + 63;
-        const int y0 = (int)(2u * rp * a.line_step), y1 = y0 + (int)(2u * a.line_step);  // (first_line is 0 or 1: inside the boxes' margin)
-        for (uint32_t k = 0; k < a.n_ops; ++k) {  // uniform: op k's box out of lane k
-          const uint32_t bx = (uint32_t)__builtin_amdgcn_readlane((int)box.x, (int)k), by = (uint32_t)__builtin_amdgcn_readlane((int)box.y, (int)k);
-          const uint32_t jc = (uint32_t)__builtin_amdgcn_readlane((int)box.job_cost, (int)k);
-          const int bx0 = (int16_t)(bx & 0xFFFFu), bx1 = (int16_t)(bx >> 16), by0 = (int16_t)(by & 0xFFFFu), by1 = (int16_t)(by >> 16);
-          const bool hit = (jc & 0xFFu) == j && x0 <= bx1 && x1 >= bx0 && y0 <= by1 && y1 >= by0;
-          price += hit ? jc >> 8 : 0u;
-        }
-        price = price < 30u ? price : 30u;
-      }
-      atomicAdd(&hist[price], 1u);
-    }
-  }
-  lds_only_barrier();  // 2
-  PH_CPHASE(9);
-  // the price up to which a step belongs to the tail: the smallest T with at least kSchedTail steps of price <= T (every wave works it out)
-  uint32_t tail_up_to;
-  {
-    const uint32_t mine = lane < 32u ? hist[lane] : 0u;
-    uint32_t incl = mine;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-      incl += lane >= (uint32_t)d ? up : 0u;
-    }
-    const uint64_t enough = __builtin_amdgcn_ballot_w64(lane >= 1u && lane < 32u && incl >= kSchedTail);
-    tail_up_to = enough ? (uint32_t)__builtin_ctzll(enough) : 31u;
-    if (a.flags & 1u) tail_up_to = 0u;
-    if (a.flags & 2u) tail_up_to = 31u;
-  }
-  // key: the steps in their natural order, then the tail dearest first, then the steps without a chunk
-  {
-    const uint32_t key = price == 0u ? 0xFC00u | e : price <= tail_up_to ? 0x8000u | ((30u - price) << 10) | e : e;
-    if (e < Epad) keys[e] = (uint16_t)(e < E ? key : 0xFFFFu), rank[e] = 0u;
-  }
-  lds_only_barrier();  // 3
-  PH_CPHASE(10);
-  // rank = how many keys are smaller.  The comparisons of a step are split over P waves (wave w serves steps (w / P) * 64 + lane
-  // against the p-th slice of the keys, p = w % P), eight keys per uniform 16-byte read
-  {
-    const uint32_t blocks = (E + 63u) / 64u, P = n_waves / blocks;  // >= 1 (chan_sort_waves)
-    const uint32_t blk = wave / P, p = wave - blk * P, mine = blk * 64u + lane;
-    const uint32_t groups = Epad / 8u, per = (groups + P - 1u) / P;
-    const uint32_t g0 = p * per, g1 = g0 + per < groups ? g0 + per : groups;
-    const bool live = blk < blocks && mine < E;
-    const uint32_t my_key = live ? (uint32_t)keys[mine] : 0u;
-    uint32_t r = 0u;
-    const uint4 *const k8 = reinterpret_cast<const uint4 *>(keys);
-    if (blk < blocks)
-      for (uint32_t g = g0; g < g1; ++g) {
-        const uint4 v = k8[g];
-        r += ((v.x & 0xFFFFu) < my_key) + ((v.x >> 16) < my_key) + ((v.y & 0xFFFFu) < my_key) + ((v.y >> 16) < my_key) +
-             ((v.z & 0xFFFFu) < my_key) + ((v.z >> 16) < my_key) + ((v.w & 0xFFFFu) < my_key) + ((v.w >> 16) < my_key);
-      }
-    if (live && r) atomicAdd(&rank[mine], r);
-  }
-  PH_CPHASE(11);
-  lds_only_barrier();  // 4: every rank is complete and nobody reads a key any more: the list goes where the keys were
-  if (e < E) keys[rank[e]] = (uint16_t)entry;
-  // (the barrier in front of phase 1 publishes the list)
-}
-
-// the reader table brought in by waves [first_wave, 16) alone (lds_lut_load with the workgroup's other waves busy elsewhere)
-__device__ __forceinline__ void lds_lut_load_upper(const LutView &v, uint32_t first_wave) {
-  const uint32_t n = (v.bytes - v.hole) / 16;
-  unsigned char *const dst = g_lds + v.hole;
-  const uint32_t wave = (threadIdx.x >> 6) - first_wave, lane = threadIdx.x & 63, stride = ((uint32_t)(kLdsBlock / 64) - first_wave) * 64u;
-  const uint4 *src = reinterpret_cast<const uint4 *>(v.blob);
-  for (uint32_t base = wave * 64; base < n; base += stride) {
-    const uint32_t i = base + lane;
-    if (i < n)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i),
-                                       (__attribute__((address_space(3))) void *)(dst + 16 * base), 16, 0, 0);
-  }
-}
-
-// The halo tables (ChanHalo), in two halves: `issue` works out each item's column and row and asks for its three words - before the
-// reader table is there; `finish` converts them and fills the tables.  The sharing ops side by side: waves [s * wps, (s + 1) * wps)
-// serve op s (what depends on the op is then uniform); a lane holds up to kHaloHeld items across the prologue, any more are loaded in `finish`.
-constexpr int kHaloHeld = 2;
-struct ChanHaloHeld {
-  V210Words w[kHaloHeld];
-  uint32_t col[kHaloHeld];  // the column, or ~0u: nothing to convert (outside the source / no chunk / no item)
-};
-struct ChanHaloWho {
-  uint32_t s, ws, wps, k, first_line, steps, j;
-  bool on;
-};
-__device__ __forceinline__ ChanHaloWho chan_halo_who(const ChanBatchArgs &a, uint32_t first_wave) {  // the waves that bring the table in serve the halo tables too
-  ChanHaloWho h{};
-  h.on = false;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (!a.n_share || wave < first_wave) return h;
-  const uint32_t waves = (uint32_t)(kLdsBlock / 64) - first_wave;  // >= 4 (chan_sort_waves) >= n_share (the launcher)
-  h.wps = waves / a.n_share;
-  h.s = (wave - first_wave) / h.wps, h.ws = (wave - first_wave) - h.s * h.wps;
-  if (h.s >= a.n_share) return h;
-  h.on = true;
-  h.k = __builtin_amdgcn_readfirstlane(a.share_op[h.s]);
-  h.j = a.box[h.k].job_cost & 0xFFu;
-  h.first_line = a.job[h.j].first_line;
-  h.steps = a.halo_steps;
-  return h;
-}
-// item -> the source column / row its value comes from (col = ~0u: none)
-__device__ __forceinline__ void chan_halo_item(const ChanBatchArgs &a, const ChanShare &sh, const ChanHaloWho &h, const ChanJobShare &js, const ChanSrc &src,
-                                               uint32_t item, uint32_t &col, uint32_t &row) {
-  col = ~0u, row = 0u;
-  if (item >= 3u * h.steps) return;
-  const uint32_t n = item / 3u, r = item - 3u * n;
-  const uint32_t slot = n / 3u, sub = n - 3u * slot;
-  const uint32_t chunk = chan_chunk_of(a, sh, js.v0, js.xcd, js.vend, slot);
-  if (chunk == ~0u) return;
-  uint32_t rp, x0;
-  chan_place(a, sh, chunk, rp, x0);
-  const uint32_t x = x0 + sub * 64u;
-  const uint32_t line = h.first_line + 2u * rp * a.line_step;
-  const ChanTaps t = chan_taps(src, (float)(int)x / (float)(int)a.out_w - 0.5f, (float)(int)line / (float)(int)a.out_h - 0.5f);
-  if (t.i0 < src.w && t.j0 + r < src.h) col = t.i0, row = t.j0 + r;
-}
-__device__ __forceinline__ ChanHaloHeld chan_halo_issue(const ChanBatchArgs &a, const ChanShare &sh, const ChanHaloWho &h) {
-  ChanHaloHeld held;
-#pragma unroll
-  for (int i = 0; i < kHaloHeld; ++i) held.col[i] = ~0u, held.w[i] = V210Words{0u, 0u, 0u};
-  if (!h.on) return held;
-  const ChanOp op = a.op[h.k];
-  const ChanSrc &src = op.src;
-  const ChanJobShare js = chan_job_share(a, sh, h.j);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(src.ptr), 0, (int)(src.pitch * src.h), 0x00020000);
-  const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-  for (int i = 0; i < kHaloHeld; ++i) {
-    uint32_t col, row;
-    chan_halo_item(a, sh, h, js, src, h.ws * 64u + lane + (uint32_t)i * h.wps * 64u, col, row);
-    held.col[i] = col;
-    const V210Col c = v210_col(col == ~0u ? 0u : col);
-    held.w[i] = v210_load(rs, col == ~0u ? kOutsideBit : __umul24(row, src.pitch) + c.g16, c);
-  }
-  return held;
-}
+// The halo tables (ChanHalo) as in the one-job kernel, the sharing ops side by side: waves [s * wps, (s + 1) * wps) fill op s's table
+// (what depends on the op is then uniform, and every op's loads are in flight at once).
+// (Asking for the columns' words BEFORE the table's DMA and converting them after it was built and measured: the table then takes
+// 3.7 us to arrive instead of 1.6 - its wait is for the words too, which come late in the chip-wide rush for the table - 6.0 us of
+// prologue against 4.3.)
 template <bool STD, bool TAILS>
-__device__ __forceinline__ void chan_halo_finish(const ChanBatchArgs &a, const ChanShare &sh, const ChanHaloWho &h, const ChanHaloHeld &held, const ReadK &rk,
-                                                 const LutK &rlut) {
-  if (!h.on) return;
-  const ChanOp op = a.op[h.k];
+__device__ __forceinline__ void chan_halo_pass_batch(const ChanBatchArgs &a, const ChanShare &sh, const ReadK &rk, const LutK &rlut) {
+  if (!a.n_share) return;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t wps = (uint32_t)(kLdsBlock / 64) / a.n_share, s = wave / wps, ws = wave - s * wps;
+  if (s >= a.n_share) return;
+  const uint32_t packed = a.share_op[s];  // op | its job << 8 | the job's first line << 16 (the launcher)
+  const ChanOp op = a.op[packed & 0xFFu];
   const ChanSrc &src = op.src;
-  const ChanJobShare js = chan_job_share(a, sh, h.j);
+  const uint32_t first_line = packed >> 16;
+  const uint4 jsv = reinterpret_cast<const uint4 *>(g_lds + a.sched_off + kSchedShare)[(packed >> 8) & 0xFFu];
+  const uint32_t v0 = __builtin_amdgcn_readfirstlane(jsv.x), xcd = __builtin_amdgcn_readfirstlane(jsv.y), vend = __builtin_amdgcn_readfirstlane(jsv.z);
+  const float fow = (float)(int)a.out_w, foh = (float)(int)a.out_h;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(src.ptr), 0, (int)(src.pitch * src.h), 0x00020000);
-  float *const area = reinterpret_cast<float *>(g_lds + a.halo_off) + h.s * a.halo_steps * 9u;
-  const uint32_t lane = threadIdx.x & 63u;
-  auto put = [&](uint32_t item, uint32_t col, const V210Words &w) __attribute__((always_inline)) {
+  float *const area = reinterpret_cast<float *>(g_lds + a.halo_off) + s * a.halo_steps * 9u;
+  for (uint32_t item = ws * 64u + lane; item < 3u * a.halo_steps; item += wps * 64u) {
+    const uint32_t n = item / 3u, r = item - 3u * n;
+    const uint32_t slot = n / 3u, sub = n - 3u * slot;
+    const uint32_t chunk = chan_chunk_of(a, sh, v0, xcd, vend, slot);
     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (col != ~0u) {
-      const V210Col c = v210_col(col);
-      const PxPending pend = v210_issue<STD>(w, c, rk, rlut, TAILS ? (col < src.tail_from ? 1.0f : 0.0f) : 1.0f);
-      v = read_px_finish(pend, rk);
+    if (chunk != ~0u) {
+      uint32_t rp, x0;
+      chan_place(a, sh, chunk, rp, x0);
+      const uint32_t x = x0 + sub * 64u;
+      const uint32_t line = first_line + 2u * rp * a.line_step;
+      const ChanTaps t = chan_taps(src, (float)(int)x / fow - 0.5f, (float)(int)line / foh - 0.5f);
+      const uint32_t col = t.i0, row = t.j0 + r;
+      if (col < src.w && row < src.h) {
+        const V210Col c = v210_col(col);
+        const V210Words w = v210_load(rs, __umul24(row, src.pitch) + c.g16, c);
+        const PxPending pend = v210_issue<STD>(w, c, rk, rlut, TAILS ? (col < src.tail_from ? 1.0f : 0.0f) : 1.0f);
+        v = read_px_finish(pend, rk);
+      }
     }
-    if (item < 3u * h.steps) area[3u * item] = v.x, area[3u * item + 1u] = v.y, area[3u * item + 2u] = v.z;  // (9 n + 3 r = 3 item)
-  };
-#pragma unroll
-  for (int i = 0; i < kHaloHeld; ++i) put(h.ws * 64u + lane + (uint32_t)i * h.wps * 64u, held.col[i], held.w[i]);
-  for (uint32_t item = h.ws * 64u + lane + (uint32_t)kHaloHeld * h.wps * 64u; item < 3u * h.steps; item += h.wps * 64u) {  // (a 2160p frame with two sharing layers)
-    uint32_t col, row;
-    chan_halo_item(a, sh, h, js, src, item, col, row);
-    const V210Col c = v210_col(col == ~0u ? 0u : col);
-    put(item, col, v210_load(rs, col == ~0u ? kOutsideBit : __umul24(row, src.pitch) + c.g16, c));
+    area[3u * item] = v.x, area[3u * item + 1u] = v.y, area[3u * item + 2u] = v.z;  // (9 n + 3 r = 3 item)
   }
 }
 
 template <bool STD, bool TAILS>
 __device__ __forceinline__ void chan_phase1_batch(const ChanBatchArgs &a, const ChanShare &sh, const ReadK &rk, const LutK &rlut) {
   const uint32_t lane = threadIdx.x & 63;
-  uint32_t *const ctrl = reinterpret_cast<uint32_t *>(g_lds + a.sched_off);
-  const uint16_t *const order = reinterpret_cast<const uint16_t *>(g_lds + a.sched_off + kSchedOrder);
-  const uint32_t limit = a.jobs * a.steps;
+  const uint32_t S = a.steps, total = a.jobs * S;  // S: the most wave steps any workgroup has per job (a step beyond this workgroup's own has no chunk)
   const float fow = (float)(int)a.out_w, foh = (float)(int)a.out_h;
+  uint32_t *const counter = reinterpret_cast<uint32_t *>(g_lds + a.sched_off);
+  // The steps of all jobs, one job after the other, TAKEN by the waves as they come free (an LDS counter).  Dealt in turn (wave w:
+  // steps w, w + 16, ...) four jobs' steps left the workgroup waiting 21 of 132 us for its slowest wave: a step's price goes with
+  // its place in the frame, and a fixed stride meets the same places again and again.
   for (;;) {
     uint32_t i = 0u;
-    if (lane == 0u) i = atomicAdd(&ctrl[0], 1u);
+    if (lane == 0u) i = atomicAdd(counter, 1u);
     i = __builtin_amdgcn_readfirstlane(i);
-    if (i >= limit) break;
+    if (i >= total) break;
 #if PH_CHAN_BALANCE
-    {  // as in the one-job kernel: a wave lowers its priority as the list runs down, so the SIMD serves whoever took an earlier step
-      const uint32_t quarter = (4u * i) / (limit + 1u);
+    {  // as in the one-job kernel: a wave lowers its priority as it advances, so the SIMD serves whoever is behind
+      const uint32_t quarter = (4u * i) / (total + 1u);
       if (quarter == 0) __builtin_amdgcn_s_setprio(3);
       else if (quarter == 1) __builtin_amdgcn_s_setprio(2);
       else if (quarter == 2) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     }
 #endif
-    const uint32_t entry = __builtin_amdgcn_readfirstlane((uint32_t)order[i]);
-    if (entry == kSchedNoStep) break;  // the steps without a chunk sort last
-    const uint32_t j = entry >> 12, n = entry & 0xFFFu;
-    const ChanJob jb = a.job[j];
+    const uint32_t j = __umulhi(i, a.magic_spj), n = i - j * S;
     const uint4 jsv = reinterpret_cast<const uint4 *>(g_lds + a.sched_off + kSchedShare)[j];  // the job's share (chan_job_share), left here by the prologue
-    uint2 *const index = reinterpret_cast<uint2 *>(jb.index);
     const uint32_t slot = n / 3u, sub = n - 3u * slot;
     const uint32_t chunk = chan_chunk_of(a, sh, __builtin_amdgcn_readfirstlane(jsv.x), __builtin_amdgcn_readfirstlane(jsv.y),
-                                         __builtin_amdgcn_readfirstlane(jsv.z), slot);  // (a step on the list has a chunk)
+                                         __builtin_amdgcn_readfirstlane(jsv.z), slot);
+    if (chunk == ~0u) continue;  // uniform
+    const ChanJob jb = a.job[j];
+    uint2 *const index = reinterpret_cast<uint2 *>(jb.index);
     uint32_t rp, x0;
     chan_place(a, sh, chunk, rp, x0);
     const uint32_t x = x0 + sub * 64u + lane;
@@ -1203,30 +1014,42 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_batch_kernel(ChanBatch
   const LutK rlut = make_lut_k(a.rd);
   const ChanShare sh = chan_share(a);
   PH_CPHASE(0);
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t sort_waves = chan_sort_waves(a.jobs * a.steps);
-  ChanHaloWho who{};
-  ChanHaloHeld held{};
-  if (wave >= sort_waves) {  // the reader table's pieces on their way, the halo columns' words behind them ...
-    lds_lut_load_upper(a.rd, sort_waves);
-    who = chan_halo_who(a, sort_waves);
-    held = chan_halo_issue(a, sh, who);
-#pragma unroll
-    for (int i = 0; i < kSchedBarriers; ++i) lds_only_barrier();
-  } else {  // ... while the steps are priced and listed (these waves have no LDS-DMA of their own to wait for at their LDS reads)
-    chan_sched_build(a, sh, sort_waves);
+  // The jobs' shares (chan_job_share, in vector code: lane j for job j) and pointers where the steps and phase 2 can index them per
+  // lane.  Through ONE vector load per lane: a scalar load per job is a chain of cold misses of the argument block, a microsecond each
+  // (measured: the workgroup waited 3.8 us for the wave that made four jobs' tables that way).
+  if (threadIdx.x < a.jobs) {
+    const uint32_t j = threadIdx.x;
+    const uint4 jw0 = chan_arg_lane<uint4>(offsetof(ChanBatchArgs, job), 2u * j), jw1 = chan_arg_lane<uint4>(offsetof(ChanBatchArgs, job), 2u * j + 1u);
+    const uint4 rot = chan_arg_lane<uint4>(offsetof(ChanBatchArgs, job_rot), j);
+    const uint32_t xcd = sh.banded ? (sh.xcd + j) & 7u : 0u;
+    const uint32_t vend = sh.banded ? ((sh.groups + 7u - xcd) >> 3) * sh.cpg : sh.chunks;
+    const uint32_t word = (xcd >> 1) == 0u ? rot.x : (xcd >> 1) == 1u ? rot.y : (xcd >> 1) == 2u ? rot.z : rot.w;
+    uint32_t v0 = sh.v0 + ((xcd & 1u) ? word >> 16 : word & 0xFFFFu);
+    v0 = v0 >= sh.vstep ? v0 - sh.vstep : v0;
+    reinterpret_cast<uint4 *>(g_lds + a.sched_off + kSchedShare)[j] = make_uint4(v0, xcd, vend, 0u);
+    reinterpret_cast<uint2 *>(g_lds + a.sched_off + kSchedOut)[j] = make_uint2(jw0.x, jw0.y);    // ChanJob::out
+    reinterpret_cast<uint2 *>(g_lds + a.sched_off + kSchedIndex)[j] = make_uint2(jw0.z, jw0.w);  // ChanJob::index
+    reinterpret_cast<uint32_t *>(g_lds + a.sched_off + kSchedFirst)[j] = jw1.z;                  // ChanJob::first_line
   }
+  if (threadIdx.x == 64u) *reinterpret_cast<uint32_t *>(g_lds + a.sched_off) = 0u;  // the counter the waves take their steps from
+  // The ops' descriptors are 64 bytes each that nobody has touched yet: the halo pass and every wave's first step would each wait a
+  // cold miss for theirs.  The last wave asks for the whole argument block at once (one lane per 64 bytes; vector loads fill the L2
+  // the scalar cache misses into) while the table comes in.
+  uint32_t touched = 0u;
+  if (PH_CHAN_ARG_PREFETCH && threadIdx.x >= (uint32_t)kLdsBlock - 64u && (threadIdx.x & 63u) * 64u < (uint32_t)sizeof(ChanBatchArgs))
+    touched = *(const __attribute__((address_space(1))) uint32_t *)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + (threadIdx.x & 63u) * 64u);
   PH_CPHASE(7);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_lut_load(a.rd);
+  if (touched == 0x9E3779B9u && a.jobs == 0xFFFFFFFFu) reinterpret_cast<uint32_t *>(g_lds + a.sched_off)[3] = touched;  // (never: keeps the loads above)
   __syncthreads();
   PH_CPHASE(1);
   if (ycbcr_matrix_is_standard(rk)) {
-    chan_halo_finish<true, TAILS>(a, sh, who, held, rk, rlut);
+    chan_halo_pass_batch<true, TAILS>(a, sh, rk, rlut);
     __syncthreads();
     PH_CPHASE(6);
     chan_phase1_batch<true, TAILS>(a, sh, rk, rlut);
   } else {
-    chan_halo_finish<false, TAILS>(a, sh, who, held, rk, rlut);
+    chan_halo_pass_batch<false, TAILS>(a, sh, rk, rlut);
     __syncthreads();
     PH_CPHASE(6);
     chan_phase1_batch<false, TAILS>(a, sh, rk, rlut);
@@ -1289,33 +1112,6 @@ static uint32_t chan_grid(uint32_t out_w, uint32_t lines, uint32_t num_cus) {
   const uint32_t cpr = (out_w + kChanChunk - 1u) / kChanChunk, chunks = cpr * ((lines + 1u) / 2u);
   return chunks < num_cus ? chunks : num_cus;
 }
-uint32_t chan_batch_max_jobs(uint32_t out_w, uint32_t lines, uint32_t num_cus) {
-  if (!lines || !out_w) return 0;
-  const uint32_t steps = 3u * chan_max_slots(out_w, lines, chan_grid(out_w, lines, num_cus));
-  const uint32_t fit = steps > 0xFFFu ? 0u : kMaxChanEntries / steps;  // (a step's number has twelve bits in the order list)
-  return fit < (uint32_t)kMaxChanJobs ? fit : (uint32_t)kMaxChanJobs;
-}
-
-// where an op's source can show in the output: the source's rectangle (a texel of margin) through the inverse placement
-static ChanBox chan_box_of(const ChanSrc &s, uint32_t out_w, uint32_t out_h) {
-  const ChanBox whole{0, 32767, 0, 32767};
-  if (!s.sampled) return whole;
-  const double m0 = s.m[0], m1 = s.m[1], m2 = s.m[2], m3 = s.m[3], m4 = s.m[4], m5 = s.m[5];
-  const double det = m0 * m4 - m1 * m3;
-  if (!(det > 1e-12 || det < -1e-12)) return whole;
-  const double lo_x = -2.0 / s.w, hi_x = 1.0 + 2.0 / s.w, lo_y = -2.0 / s.h, hi_y = 1.0 + 2.0 / s.h;
-  double bx0 = 1e30, bx1 = -1e30, by0 = 1e30, by1 = -1e30;
-  for (int c = 0; c < 4; ++c) {
-    // sx = m0 px + m1 py + m2 + 0.5 (chan_taps): px, py from the corner's sx, sy
-    const double sx = ((c & 1) ? hi_x : lo_x) - 0.5 - m2, sy = ((c & 2) ? hi_y : lo_y) - 0.5 - m5;
-    const double px = (m4 * sx - m1 * sy) / det, py = (m0 * sy - m3 * sx) / det;
-    const double x = (px + 0.5) * out_w, y = (py + 0.5) * out_h;
-    bx0 = x < bx0 ? x : bx0, bx1 = x > bx1 ? x : bx1, by0 = y < by0 ? y : by0, by1 = y > by1 ? y : by1;
-  }
-  auto clamp16 = [](double v) { return (int16_t)(v < -32768.0 ? -32768.0 : v > 32767.0 ? 32767.0 : v); };
-  return ChanBox{clamp16(bx0 - 2.0), clamp16(bx1 + 2.0), clamp16(by0 - 3.0), clamp16(by1 + 3.0)};
-}
-
 hipError_t launch_chan_compose_batch(hipStream_t s, const ChanBatchArgs &a, uint32_t num_cus) {
   if (!a.lines || !a.jobs) return hipSuccess;
   if (a.jobs > (uint32_t)kMaxChanJobs || a.n_ops > (uint32_t)kMaxChanBatchOps) return hipErrorInvalidValue;
@@ -1323,8 +1119,7 @@ hipError_t launch_chan_compose_batch(hipStream_t s, const ChanBatchArgs &a, uint
   const uint32_t cpr = (a.out_w + kChanChunk - 1u) / kChanChunk, cpg = (uint32_t)(PH_CHAN_GROUP_ROWS / 2) * cpr;
   const uint32_t grid = chan_grid(a.out_w, a.lines, num_cus);
   const uint32_t chunks = cpr * ((a.lines + 1u) / 2u);
-  const uint32_t slots = chan_max_slots(a.out_w, a.lines, grid), steps = 3u * slots, entries = a.jobs * steps;
-  if (steps > 0xFFFu || entries > kMaxChanEntries) return hipErrorInvalidValue;
+  const uint32_t slots = chan_max_slots(a.out_w, a.lines, grid), steps = 3u * slots;
   ChanBatchArgs b = a;
   b.magic_cpr = cpr > 1 ? (uint32_t)(((1ull << 32) + cpr - 1) / cpr) : 0u;
   b.magic_cpg = (uint32_t)(((1ull << 32) + cpg - 1) / cpg);
@@ -1346,30 +1141,22 @@ hipError_t launch_chan_compose_batch(hipStream_t s, const ChanBatchArgs &a, uint
   b.magic_spj = (uint32_t)(((1ull << 32) + steps - 1) / steps);
   b.magic_qpj = (uint32_t)(((1ull << 32) + 64u * slots - 1) / (64u * slots));
   b.sched_off = (lds + 15u) & ~15u;
-  b.halo_off = b.sched_off + chan_sched_bytes(entries);
+  b.halo_off = b.sched_off + kSchedBytes;
   if (b.halo_off > 160u * 1024u) return hipErrorInvalidValue;
+  // tap sharing as in the one-job launcher; each sharing op needs 36 bytes per wave step and job behind the table, ops that do not fit go without
   b.halo_steps = 0, b.n_share = 0;
   static const bool no_share = getenv("PH_CHAN_NO_SHARE") != nullptr;
-  static const uint32_t flags = getenv("PH_CHAN_SCHED_FLAGS") ? (uint32_t)atoi(getenv("PH_CHAN_SCHED_FLAGS")) : 0u;  // experiments (tools/chan_bench.py)
-  b.flags = flags;
   const uint32_t room = 160u * 1024u - b.halo_off;
   for (uint32_t k = 0; k < b.n_ops; ++k) {
     ChanSrc &src = b.op[k].src;
-    b.box[k] = chan_box_of(src, a.out_w, a.out_h);
     b.op[k].action &= ~(kChanActShare | (7u << kChanActShareShift));
-    const bool v210 = src.kind == kChanV210;
-    uint32_t cost = v210 ? (src.sampled ? 8u : 2u) : (src.sampled ? 2u : 1u);
-    if (v210 && src.sampled && src.m[1] == 0.0f && src.m[3] == 0.0f) {
-      const float sx = src.m[0] * (float)src.w / (float)a.out_w, sy = src.m[4] * (float)src.h / (float)(a.out_h) * (float)a.line_step;
-      const bool unit_x = sx > 0.9999f && sx < 1.0001f, unit_y = sy > 0.9999f && sy < 1.0001f;
-      if (unit_y) cost = 6u;  // the pair's rows overlap: three source rows, not four
-      if (unit_x && unit_y && !no_share && b.n_share < 4u && (b.n_share + 1u) * steps * 36u <= room) {  // (four: every sharing op has a wave of its own among those that fill the halo tables)
-        b.op[k].action |= kChanActShare | (b.n_share << kChanActShareShift);
-        b.share_op[b.n_share++] = k;
-        cost = 3u;
-      }
-    }
-    b.box[k].job_cost = (uint32_t)b.op_job[k] | cost << 8;
+    if (no_share || src.kind != kChanV210 || !src.sampled || src.m[1] != 0.0f || src.m[3] != 0.0f) continue;
+    const float sx = src.m[0] * (float)src.w / (float)a.out_w, sy = src.m[4] * (float)src.h / (float)(a.out_h) * (float)a.line_step;
+    if (!(sx > 0.9999f && sx < 1.0001f && sy > 0.9999f && sy < 1.0001f)) continue;
+    if (b.n_share == 8u || (b.n_share + 1u) * steps * 36u > room) break;
+    b.op[k].action |= kChanActShare | (b.n_share << kChanActShareShift);
+    const uint32_t j = b.op_job[k];
+    b.share_op[b.n_share++] = k | j << 8 | b.job[j].first_line << 16;
   }
   if (b.n_share) b.halo_steps = steps;
   const uint32_t lds_total = b.halo_off + b.n_share * steps * 36u;

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE config 2 through ph_chan_compose_v210 alone (one launch per frame): the timing loop tools/pmc_kernel.sh profiles.
   python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets] [sources: v210|yuv422p10|yuv422p8|yuv420p|nv12]
-  PH_CHAN_BENCH_JOBS=C: C channels' frames per launch (ph_chan_compose_batch); PH_CHAN_BENCH_W / _H: another frame size;
-  PH_CHAN_SCHED=0: the one-job kernel with its wave steps dealt in turn (the A/B of round 5)"""
+  PH_CHAN_BENCH_JOBS=C: C channels' frames per call of ph_chan_compose_batch (PH_CHAN_BATCH=0: the same call, every job through the
+  one-job kernel - the A/B of round 5); PH_CHAN_BENCH_W / _H: another frame size"""
 import json
 import os
 import sys
@@ -80,7 +80,7 @@ def main():
     e1.record(stream)
     ctx.wait()
     print(json.dumps({"kernel": "chan_compose_v210", "width": w, "height": h, "variant": variant, "mask": mask_kind, "sources": packing, "jobs_per_launch": C,
-                      "sched": os.environ.get("PH_CHAN_SCHED", "1"), "us_per_launch": round(1e3 * e0.elapsed_time(e1) / reps, 2),
+                      "batch_kernel": os.environ.get("PH_CHAN_BATCH", "1") != "0" and C > 1, "us_per_launch": round(1e3 * e0.elapsed_time(e1) / reps, 2),
                       "us_per_frame": round(1e3 * e0.elapsed_time(e1) / reps / C, 2)}), flush=True)
     ctx.close()
 

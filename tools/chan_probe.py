@@ -47,13 +47,10 @@ def main():
         rec = {"workgroups": len(rows), "us_mean": {n: mean(lambda r, i=i: r[i + 1] - r[i]) for i, n in enumerate(names_p)},
                "start_skew_us": mean(lambda r: r[0] - t0), "end_us_after_first_start": {"mean": mean(lambda r: r[5] - t0),
                "max": round(max(r[5] - t0 for r in rows) / 100.0, 2)}}
-        if all(r[7] for r in rows):  # the kernel that hands its steps out at run time stamps two more points: list made (7), halo tables made (6)
-            rec["us_mean"] = {"steps priced and sorted": mean(lambda r: r[7] - r[0]), "reader table load + barrier": mean(lambda r: r[1] - r[7]),
+        if all(r[7] for r in rows):  # the batch kernel stamps two more points: halo columns' words asked for (7), halo tables made (6)
+            rec["us_mean"] = {"jobs' tables + halo words asked for": mean(lambda r: r[7] - r[0]), "reader table load + barrier": mean(lambda r: r[1] - r[7]),
                               "halo tables + barrier": mean(lambda r: r[6] - r[1]), "phase 1 (wave 0)": mean(lambda r: r[2] - r[6]),
                               **{n: rec["us_mean"][n] for n in names_p[2:]}}
-            if all(r[11] for r in rows):  # inside the list making: the barriers between its stages
-                rec["list_stages_us"] = {"boxes / jobs loaded, tables written": mean(lambda r: r[8] - r[0]), "priced": mean(lambda r: r[9] - r[8]),
-                                         "keys": mean(lambda r: r[10] - r[9]), "ranked": mean(lambda r: r[11] - r[10]), "listed + table in": mean(lambda r: r[1] - r[11])}
         print(json.dumps(rec))
     print(json.dumps({"variant": variant, "turns": turns, "mean_cycles": {n: round(tot[i] / max(turns, 1)) for i, n in enumerate(names)}}))
 
