@@ -35,7 +35,9 @@ extern "C" {
  * 5: ph_compose_up_write_v210_pair, ph_lut_layout_of
  * 6: ph_fused_field_v210 / ph_field_layer REMOVED (the slowest route of its workload by 2.7x, no caller).  The fused entry
  *    points take widths that are not a multiple of 48 (1280 x 720: the reference's third format, src/config.ts:43-54)
- * 7: additive over 6 - ph_chan_compose_batch (ph_chan_job): several channels' frames in one launch */
+ * 7: additive over 6 - ph_chan_compose_batch (ph_chan_job): several channels' frames in one launch; ph_run_programs;
+ *    ph_event_record_timed / ph_event_elapsed_us; ph_ctx_host_pool_stats; "host_pool_mb" defaults to 4096 again and never
+ *    keeps less than the working set */
 #define PH_ABI_VERSION 7
 
 enum {
@@ -116,6 +118,11 @@ int ph_event_record(ph_ctx *ctx, int queue, ph_event **out);
 int ph_event_wait(ph_event *ev);
 int ph_event_query(ph_event *ev); /* 1 = finished, 0 = still running, negative = error */
 int ph_event_destroy(ph_event *ev);
+/* Timed points: ph_event_record_timed records an event that ph_event_elapsed_us can measure from / to (microseconds of device
+ * time between two such points of one queue, both finished).  nodencl's RunTimings (clJobQueue.ts:159-215 prints them) for a binding
+ * whose launches do not coincide with its runProgram calls (node/defer.js with `profile`). */
+int ph_event_record_timed(ph_ctx *ctx, int queue, ph_event **out);
+int ph_event_elapsed_us(ph_event *from, ph_event *to, uint32_t *microseconds);
 /* Recorded batches.  The reference submits a channel's per-frame batch (read x N, transform x N, wipe,
  * combine, write: 13 kernels at config 2) one `runProgram` at a time; at 1080p those kernels run for
  * 5-15 us each and the gaps between launches are a fifth of the frame.  A caller whose batch touches
@@ -168,6 +175,10 @@ int ph_route_comm_count(ph_route *route, int *count);
 
 /* the `logBuffers()` debug hook (src/index.ts:184): live buffers / pooled bytes */
 int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, size_t *pooled_bytes);
+/* the pinned host mirrors (an OpenCLBuffer of the node binding IS its mirror): bytes attached to live buffers, bytes kept for reuse,
+ * the most that was ever attached at once, and how many blocks have been pinned (hipHostMalloc) since the context was made - a
+ * count that keeps growing in steady state means the pool is smaller than the working set (context option "host_pool_mb") */
+int ph_ctx_host_pool_stats(ph_ctx *ctx, size_t *in_use_bytes, size_t *pooled_bytes, size_t *peak_in_use_bytes, uint64_t *pins);
 
 /* ---- programs: `createProgram(kernelSrc, {name, globalWorkItems, workItemsPerGroup})`
  *      (imageProcess.ts:69-72, packer.ts:97-103).  The OpenCL C text is NOT compiled: it (or a
@@ -218,6 +229,12 @@ int ph_run_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args
  * that records jobs and launches them later (node/defer.js): a bad job is reported where the reference posts it
  * (clJobQueue.ts:126 awaits runProgram), not where it is finally run. */
 int ph_check_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args, int queue);
+/* Several jobs in one call, for a binding that records jobs and launches them later (node/defer.js): exactly ph_run_program(progs[j],
+ * args[j], n_args[j]) for j = 0 .. n_jobs - 1 in that order, PROVIDED no job reads what another job of the call writes.  Every job is
+ * checked before anything is launched (a bad job refuses the whole call).  Channel frames among the jobs - chan_compose_v210_<n>
+ * programs of one geometry that name the SAME Loader / Saver buffers and make v210 frames - go to the device together
+ * (ph_chan_compose_batch: the reference's channels share one context and one queue, src/index.ts:45-71,156-160). */
+int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_arg *const *args, const int *n_args, int queue);
 
 /* ---- typed entry points: the same kernels on raw device pointers, launched on `queue`.
  *      Images are row-major float RGBA (16 B/pixel); v210 is LE 32-bit words with line pitch
@@ -497,9 +514,10 @@ int ph_lut_layout_of(const float *host_lut65536, ph_lut_layout *layout, void *ld
  *          larger than "stream_threshold_mb" MiB (default 64; measured neutral on the reference-shaped chains).  By
  *          default an image is treated as what it is in a channel, an intermediate the next operator reads back;
  *          wire-format outputs always stream;
- *          "host_pool_mb" (default 1024): how much pinned host memory released buffers' mirrors may keep for the next
- *          buffer of the same size (the reference creates its destinations per job and frame: io.ts:64-72); over the
- *          budget the oldest blocks are freed first. */
+ *          "host_pool_mb" (default 4096): how much pinned host memory released buffers' mirrors may keep for the next
+ *          buffer of the same size (the reference creates its destinations per job and frame: io.ts:64-72) - this much,
+ *          or as much as was ever attached to live buffers at once if that is more (a pool smaller than the working set
+ *          pins a block per buffer again, ~40 ms each); over the budget the oldest blocks are freed first; 0: no pool. */
 int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value);
 
 /* ---- host colour maths (src/process/colourMaths.ts, run by Loader/Saver constructors

@@ -64,12 +64,30 @@ class Deferral {
 		this.orderedAt = new Map() // `${waiter}<${signal}` -> the signal queue's launch count the waiter is ordered behind
 		this.stats = { recorded: 0, launched: 0, fused: 0, fusedNodes: 0, plain: 0, dropped: 0, fallbacks: 0, lastFallback: null }
 		this.fieldTwin = new WeakMap() // a de-interlaced field image -> the other field of the same frame (set by the pair launch that made both)
+		// Terminal wire-format `write` jobs that are recorded and not launched yet.  When somebody asks for one of them, the others whose
+		// frames the same kernel can make in the same launch go with it (channels of one format in one context: src/index.ts:45-71).
+		// With `earlyLaunch` they are launched at the END OF THE TICK that posted them (setImmediate) instead - for a host whose consumers
+		// map their frames long after posting them.  Not the default: where the consumer asks right after its jobs' flush (the reference's
+		// saveFrame, this repo's benches) the tick-end launch only adds its own bookkeeping (measured: 143 against 132 us per frame for
+		// one 1080p channel, 92 against 82 for four - profiles/r05_node_bench.jsonl)
+		this.terminals = []
+		this.tickScheduled = false
+		this.running = false // inside _runMany (a launch that forces another terminal write runs that one on its own)
+		this._tick = () => {
+			this.tickScheduled = false
+			const list = this.terminals.filter((n) => n.state === 'pending')
+			this.terminals = []
+			// nobody is waiting for these frames yet: a failure stays with the buffers (_failed) for whoever asks, as everywhere
+			try { this._runMany(list, null) } catch (e) { /* recorded with the buffers */ }
+		}
+		this.earlyLaunch = ctx.earlyLaunch === true
 	}
 
 	// ---- bookkeeping on buffers -----------------------------------------------------------------------------
 	// (plain assignments: Object.defineProperty is a runtime call per field and buffer - a fifth of the recording's host time was here)
-	static adopt(buf) {
-		if (buf._readers !== undefined) return
+	static adopt(buf, fresh) { // fresh: a new buffer, or a parked one taken over (node/index.js createBuffer)
+		if (buf._readers !== undefined && !fresh) return
+		buf._digest = null
 		buf._readers = NONE // pending nodes that read the buffer (a small array; NONE until there is one)
 		buf._producer = null // the pending node that will write it
 		buf._held = 0 // recorded nodes that hold it (ONE native reference stands for all of them: _hold)
@@ -85,11 +103,11 @@ class Deferral {
 		return a._digest === b._digest
 	}
 	static sameRecipe(r, q) { return Deferral.same(r.colMatrix, q.colMatrix) && Deferral.same(r.gammaLut, q.gammaLut) && Deferral.same(r.gamutMatrix, q.gamutMatrix) }
-	// The recorded nodes' hold on a buffer is ONE native reference however many nodes hold it (29 addRef + 34 release calls into the
-	// addon per 4-layer frame before; now one pair per buffer)
-	_hold(buf) { if (buf._held++ === 0) this.ctx._native.bufAddRef(buf._handle) }
-	_unhold(buf) { if (--buf._held === 0) this.ctx._native.bufRelease(buf._handle) }
-	_appRefs(buf) { return this.ctx._native.bufRefCount(buf._handle) - (buf._held > 0 ? 1 : 0) }
+	// The recorded nodes' hold on a buffer: a count beside the owners' own (buf._refs, node/index.js) - the buffer goes when both are
+	// zero.  (29 addRef + 34 release calls into the addon per 4-layer frame in round 3, one pair per buffer in round 4, none now.)
+	_hold(buf) { buf._held++ }
+	_unhold(buf) { if (--buf._held === 0 && buf._refs === 0) buf._free() }
+	_appRefs(buf) { return buf._refs }
 
 	// ---- recording --------------------------------------------------------------------------------------------
 	record(program, params, queue) {
@@ -100,6 +118,7 @@ class Deferral {
 			const v = params[names[k]]
 			if (!Buffer.isBuffer(v)) continue
 			if (!v._handle) throw new Error(`runProgram: parameter '${names[k]}' is a plain Buffer, not an OpenCLBuffer`)
+			if (v._dead) throw new Error('runProgram: a buffer argument has already been released')
 			Deferral.adopt(v)
 			pushNew(isOutputArg(names[k]) ? outs : ins, v)
 		}
@@ -115,22 +134,44 @@ class Deferral {
 		for (let k = 0; k < outs.length; ++k) if (!ins.includes(outs[k])) this._hold(outs[k])
 		// a buffer this job overwrites: whoever still wants its present (or pending) contents goes first.  A pending producer is
 		// dropped unseen only if this job is known to write the WHOLE buffer; a job that fills part of it (an interlaced `write`:
-		// every other line) or a program this layer does not know runs the producer first
+		// every other line) or a program this layer does not know runs the producer first.
+		// (The job holds its buffers and is registered as their reader BEFORE this - dropping a displaced producer lets go of recipes
+		// nobody reads, and this job's own operands must not be among them - so a failure here, e.g. the stored error of an unrelated
+		// job that one of the displaced ones depended on, has to undo that: ADVICE r4.)
 		const whole = WHOLE_OUTPUT.test(program.name) && !params.interlace
+		try {
+			for (let k = 0; k < outs.length; ++k) {
+				const o = outs[k]
+				if (o._readers.length) for (const r of o._readers.slice()) if (r !== node) this._run(r)
+				const p = o._producer
+				if (p && whole && p.outs.length === 1 && !ins.includes(o)) { this.stats.dropped++; this._retire(p, 'dropped') } // its result would be overwritten unseen
+				else if (p) this._run(p)
+			}
+		} catch (e) {
+			this._retire(node, 'error') // never recorded: its holds and reader entries go; the caller's runProgram rejects
+			throw e
+		}
 		for (let k = 0; k < outs.length; ++k) {
 			const o = outs[k]
-			if (o._readers.length) for (const r of o._readers.slice()) if (r !== node) this._run(r)
-			const p = o._producer
-			if (p && whole && p.outs.length === 1 && !ins.includes(o)) { this.stats.dropped++; this._retire(p, 'dropped') } // its result would be overwritten unseen
-			else if (p) this._run(p)
 			o._producer = node
 			o._failed = null
+			this._untwin(o) // (it is no longer the field image a pair launch made)
 		}
 		if (Deferral._isV210(program, 'read') && params.colMatrix && params.gammaLut && params.gamutMatrix)
 			this.lastReader = { colMatrix: params.colMatrix, gammaLut: params.gammaLut, gamutMatrix: params.gamutMatrix }
 		this.pending.add(node)
 		this.stats.recorded++
+		if (program.name === 'write' && program.format !== undefined) this._noteTerminal(node)
 		return ZERO_TIMINGS()
+	}
+	_noteTerminal(node) {
+		if (this.terminals.length >= 32) this.terminals = this.terminals.filter((n) => n.state === 'pending')
+		this.terminals.push(node)
+		if (this.earlyLaunch && !this.tickScheduled) { this.tickScheduled = true; setImmediate(this._tick) }
+	}
+	_untwin(buf) {
+		const t = this.fieldTwin.get(buf)
+		if (t) { this.fieldTwin.delete(buf); this.fieldTwin.delete(t) }
 	}
 	// what ph_check_program looks at, as a flat list: the names in order, per buffer its size and image dimensions, the scalars
 	_signature(names, params, queue) {
@@ -190,6 +231,7 @@ class Deferral {
 		if (dir === 'readonly') this.force(buf)
 		else {
 			if (buf._digest) buf._digest = null
+			this._untwin(buf)
 			this.beforeWrite(buf)
 			if (buf._producer) this.force(buf) // (a recorded result the host overwrites: run it rather than reason about partial writes)
 			buf._failed = null
@@ -222,7 +264,87 @@ class Deferral {
 	}
 	_run(node) {
 		if (node.state !== 'pending') return
+		if (!this.running && node.program.name === 'write' && this.terminals.length > 1) {
+			// somebody needs this frame now: the other recorded frames the same launch can make go with it
+			const others = this.terminals.filter((n) => n !== node && n.state === 'pending' && n.queue === node.queue)
+			this.terminals = this.terminals.filter((n) => n.state === 'pending' && n !== node && n.queue !== node.queue)
+			if (others.length) return this._runMany([node, ...others], node)
+		}
 		if (!this._fused(node)) this._plain(node)
+	}
+	// Several terminal writes at once.  `must` (or null) has to be done when this returns - fused, or as recorded; the others are
+	// launched only if their chain folds (what does not fold stays recorded until somebody asks).  Frames the channel kernel makes
+	// from sources of one recipe, at one size, go to the device as ONE launch (runPrograms -> ph_chan_compose_batch).
+	_runMany(nodes, must) {
+		this.running = true
+		const plans = []
+		let failure = null
+		try {
+			for (const n of nodes) {
+				if (n.state !== 'pending') continue
+				let plan = null
+				try { plan = this._plan(n) } catch (e) { if (n === must) failure = e; continue }
+				if (plan) plans.push(plan)
+			}
+			// groups of plans one launch can take
+			const groups = []
+			for (const p of plans) {
+				if (!p.batchable || !this.ctx._native.runPrograms) { groups.push([p]); continue }
+				let g = groups.find((v) => v[0].batchable && v.length < 8 && v[0].width === p.width && v[0].height === p.height && v[0].node.queue === p.node.queue &&
+					Deferral.sameRecipe(v[0].loader, p.loader) && Deferral.same(v[0].saver.outColMatrix, p.saver.outColMatrix) && Deferral.same(v[0].saver.outGammaLut, p.saver.outGammaLut))
+				if (!g) groups.push((g = []))
+				g.push(p)
+			}
+			for (const g of groups) {
+				const live = g.filter((p) => this._fresh(p))
+				for (const p of g) if (!live.includes(p) && p.node.state === 'pending' && p.node === must) { if (!this._fused(p.node)) this._plain(p.node) } // (planning another frame ran part of this one's chain: look again)
+				if (live.length > 1 && this._batch(live)) continue
+				for (const p of live) if (!this._commit(p) && p.node === must) this._plain(p.node)
+			}
+			if (must && must.state === 'pending' && !failure) { if (!this._fused(must)) this._plain(must) }
+		} finally { this.running = false }
+		if (failure) throw failure
+	}
+	// a plan is good as long as the write and every node it stands in for are still pending
+	_fresh(plan) {
+		if (plan.node.state !== 'pending') return false
+		for (const u of plan.used) if (u.state !== 'pending') return false
+		return true
+	}
+	// several channel frames in one launch: every plan's one candidate with the FIRST plan's Loader / Saver buffers (equal contents)
+	_batch(plans) {
+		const first = plans[0].candidates[0][1]
+		const progs = []
+		const names = []
+		const values = []
+		for (const p of plans) {
+			const [name, params] = p.candidates[0]
+			progs.push(this._program(name, p.width, p.height)._handle)
+			const nm = []
+			const vs = []
+			for (const k of Object.keys(params)) {
+				let v = params[k]
+				if (v === undefined || v === null) continue
+				if (k === 'colMatrix' || k === 'gammaLut' || k === 'gamutMatrix' || k === 'outColMatrix' || k === 'outGammaLut') v = first[k]
+				nm.push(k)
+				vs.push(Buffer.isBuffer(v) ? v._handle : typeof v === 'boolean' ? (v ? 1 : 0) : v)
+			}
+			names.push(nm)
+			values.push(vs)
+		}
+		const queue = plans[0].node.queue
+		try {
+			this.ctx._native.runPrograms(this.ctx._ctx, progs, names, values, queue)
+		} catch (e) {
+			this.stats.fallbacks++
+			this.stats.lastFallback = `batch of ${plans.length}: ${e && e.message || e}`
+			return false
+		}
+		this.stats.launched++
+		this.stats.batched = (this.stats.batched || 0) + plans.length
+		this.launchedOn.set(queue, (this.launchedOn.get(queue) || 0) + 1)
+		for (const p of plans) this._done(p, null)
+		return true
 	}
 
 	_launch(program, params, queue, checkOnly = false) {
@@ -377,6 +499,9 @@ class Deferral {
 		const n = layers.length
 		const first = this.fieldTwin.get(layers[0].source)
 		if (!first || !first._readers) return null
+		// the twin images must be what the pair launch made: one that has a producer again (re-recorded since) or whose producer failed
+		// is not a finished field image (ADVICE r4: the launch would have read it before - or instead of - its producer's run)
+		for (const l of layers) { const t = this.fieldTwin.get(l.source); if (!t || t._producer || t._failed) return null }
 		const sameWrite = (w) => w !== node && w.state === 'pending' && w.program.name === 'write' && w.program.format === node.program.format &&
 			w.program.workItemsPerGroup === node.program.workItemsPerGroup && w.program.globalWorkItems[0] === node.program.globalWorkItems[0] &&
 			(w.params.interlace || 0) === (node.params.interlace || 0) && w.params.output && w.params.output !== node.params.output &&
@@ -403,27 +528,33 @@ class Deferral {
 		return null
 	}
 
-	// node: a pending v210 `write`.  true = the frame has been produced by one fused launch
+	// node: a pending wire-format `write`.  true = the frame has been produced by one fused launch
 	_fused(node) {
+		const plan = this._plan(node)
+		return plan ? this._commit(plan) : false
+	}
+	// what one fused launch would stand in for: null = the chain does not fold (or there is nothing to gain); else the candidates,
+	// best first, and the nodes they replace.  Making a layer real may launch other recorded jobs (never this write).
+	_plan(node) {
 		// FromRGBA with a Writer whose frame the channel kernel can make: v210 (SDI), yuv422p8 / yuv422p10 (an encoder), rgba8 / bgra8 (the screen)
 		const OUT = { v210: 0, yuv422p10: 1, yuv422p8: 2, yuv420p: 3, nv12: 4, rgba8: 5, bgra8: 6 }
-		if (node.program.name !== 'write' || OUT[node.program.format] === undefined) return false
+		if (node.program.name !== 'write' || OUT[node.program.format] === undefined) return null
 		const outFmt = OUT[node.program.format]
 		const outRgb8 = outFmt >= 5
 		const image = node.params.input
 		const dims = image && image.imageDims
 		const top = image && image._producer
-		if (!dims || !top || top.state !== 'pending') return false
+		if (!dims || !top || top.state !== 'pending') return null
 		const width = dims.width
 		const height = dims.height
 		const interlace = node.params.interlace || 0
 		const geo = Deferral._frameOf(node)
 		// (a 4:2:0 Writer's work groups are line PAIRS whatever the field mode: yuv420p.ts:381 - its geometry gives the whole height)
-		if (geo.width !== width || geo.lines !== (interlace && outFmt !== 3 && outFmt !== 4 ? height / 2 : height)) return false
+		if (geo.width !== width || geo.lines !== (interlace && outFmt !== 3 && outFmt !== 4 ? height / 2 : height)) return null
 		const planarOut = outFmt >= 1 && outFmt <= 4 // planes: Y, U, V - nv12: Y and the interleaved CbCr plane (nv12.ts:374)
 		const output = planarOut ? node.params.outputY : node.params.output
-		if (!output || (!outRgb8 && !node.params.colMatrix) || !node.params.gammaLut) return false
-		if (planarOut && (outFmt === 4 ? !node.params.outputC : !node.params.outputU || !node.params.outputV)) return false
+		if (!output || (!outRgb8 && !node.params.colMatrix) || !node.params.gammaLut) return null
+		if (planarOut && (outFmt === 4 ? !node.params.outputC : !node.params.outputU || !node.params.outputV)) return null
 
 		let layerImages = [image]
 		const m = /^combine_(\d+)$/.exec(top.program.name)
@@ -431,11 +562,11 @@ class Deferral {
 			layerImages = []
 			for (let i = 0; i < Number(m[1]); ++i) {
 				const l = top.params[`l${i}In`]
-				if (!l) return false
+				if (!l) return null
 				layerImages.push(l)
 			}
 		}
-		if (layerImages.length > 8) return false
+		if (layerImages.length > 8) return null
 		this._deinterlace(layerImages)
 
 		// what each layer is made of.  The fused kernel applies ONE gamma table and gamut matrix (`reader`: a call is one colour
@@ -508,27 +639,28 @@ class Deferral {
 			const kind = p && p.state === 'pending' ? p.program.name : ''
 			if (kind === 'transition_dissolve' || kind === 'transition_wipe') {
 				const wipe = kind === 'transition_wipe'
-				if (!p.params.input0 || !p.params.input1 || (wipe && !p.params.maskIn) || !sameSize(img)) return false
+				if (!p.params.input0 || !p.params.input1 || (wipe && !p.params.maskIn) || !sameSize(img)) return null
 				const l = placed(p.params.input0)
 				const incoming = l && placed(p.params.input1)
 				const mask = incoming && wipe ? placed(p.params.maskIn) : null
-				if (!l || !incoming || (wipe && !mask)) return false
+				if (!l || !incoming || (wipe && !mask)) return null
 				used.add(p)
 				l.transition = { wipe, mix: wipe ? 0 : Number(p.params.mix), incoming, mask }
 				layers.push(l)
 			} else {
 				const l = placed(img)
-				if (!l) return false
+				if (!l) return null
 				layers.push(l)
 			}
 		}
 		if (m) used.add(top)
 		// making a layer real may have run a producer another layer was going to stand in for: look again, with that image real
-		for (const u of used) if (u.state !== 'pending') return this._fused(node)
+		for (const u of used) if (u.state !== 'pending') return node.state === 'pending' ? this._plan(node) : null
+		if (node.state !== 'pending') return null
 
 		const n = layers.length
 		const anyV210 = layers.some((l) => l.v210 || (l.transition && (l.transition.incoming.v210 || (l.transition.mask && l.transition.mask.v210))))
-		if (!used.size) return false // every layer is a finished image taken as it is: the recorded write is as good
+		if (!used.size) return null // every layer is a finished image taken as it is: the recorded write is as good
 		const saver = { outGammaLut: node.params.gammaLut }
 		if (!outRgb8) saver.outColMatrix = node.params.colMatrix
 		if (outFmt) Object.assign(saver, { outPacking: outFmt }, outFmt === 4 ? { outputC: node.params.outputC } : outFmt < 5 ? { outputU: node.params.outputU, outputV: node.params.outputV } : {})
@@ -579,21 +711,30 @@ class Deferral {
 			})
 			candidates.push([`chan_compose_v210_${n}`, params])
 		}
-		let done = false
-		for (const [name, params, twin] of candidates) {
-			if (!this._try(this._program(name, width, height), params, node.queue)) continue
-			done = true
-			if (twin && twin.node.state === 'pending') { // the other field's frame came out of the same launch
-				this.stats.fusedNodes += 1 + (n > 1 ? 1 : 0) + n
-				this._retire(twin.node, 'done')
-			}
-			break
+		if (!candidates.length) return null
+		// one launch of the batch kernel can take it: the channel kernel is the only candidate, v210 / image sources, a v210 frame
+		const batchable = candidates.length === 1 && candidates[0][0].startsWith('chan_compose_v210_') && !outFmt &&
+			!layers.some((l) => l.planar || (l.transition && (l.transition.incoming.planar || (l.transition.mask && l.transition.mask.planar))))
+		return { node, candidates, used, n, width, height, batchable, loader, saver }
+	}
+	// launch the first candidate the library takes; false = none (nothing was launched)
+	_commit(plan) {
+		if (!this._fresh(plan)) return plan.node.state === 'pending' ? this._fused(plan.node) : true
+		for (const [name, params, twin] of plan.candidates) {
+			if (!this._try(this._program(name, plan.width, plan.height), params, plan.node.queue)) continue
+			this._done(plan, twin)
+			return true
 		}
-		if (!done) return false
+		return false
+	}
+	_done(plan, twin) {
+		if (twin && twin.node.state === 'pending') { // the other field's frame came out of the same launch
+			this.stats.fusedNodes += 1 + (plan.n > 1 ? 1 : 0) + plan.n
+			this._retire(twin.node, 'done')
+		}
 		this.stats.fused++
-		this.stats.fusedNodes += used.size + 1
-		this._retire(node, 'done') // the producers it stood in for stay recipes until nobody can ask for their images
-		return true
+		this.stats.fusedNodes += plan.used.size + 1
+		this._retire(plan.node, 'done') // the producers it stood in for stay recipes until nobody can ask for their images
 	}
 }
 

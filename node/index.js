@@ -23,13 +23,14 @@ const ACCESS = { readonly: 0, writeonly: 1, readwrite: 2 }
 const SVM = { none: 0, coarse: 1, fine: 2 }
 const HOSTDIR = { readonly: 0, writeonly: 1, none: 2 }
 
-// Decorate the node Buffer the addon returned (pinned host mirror of the device buffer) with the OpenCLBuffer members the
-// reference uses.  The methods are shared functions on `this` and the fields plain assignments: the reference makes a fresh
-// destination per job and frame (io.ts:64-72), and five closures plus an Object.defineProperty per buffer showed in the profile
-// of the recording context (node/test/defer_host_bench.js).
+// The OpenCLBuffer members the reference uses, on the node Buffer the addon returned (the pinned host mirror of the device buffer).
+// The methods are shared functions on `this`, reached through a per-context prototype (bufferPrototype below); the per-buffer fields
+// are plain assignments: the reference makes a fresh destination per job and frame (io.ts:64-72), and five closures plus an
+// Object.defineProperty per buffer showed in the profile of the recording context (node/test/defer_host_bench.js).
 function hostAccess(dir, queue, src) {
 	if (!(dir in HOSTDIR)) return Promise.reject(new Error(`hostAccess: unknown direction '${dir}'`))
 	if (Buffer.isBuffer(queue)) { src = queue; queue = 0 } // hostAccess(dir, src)
+	if (this._dead) return Promise.reject(new Error('hostAccess on a released buffer'))
 	if (this._deferral) {
 		try {
 			this._deferral.touch(this, dir, queue || 0)
@@ -37,34 +38,71 @@ function hostAccess(dir, queue, src) {
 	}
 	return this._native.hostAccess(this._handle, HOSTDIR[dir], queue || 0, src)
 }
-function addRef() { this._native.bufAddRef(this._handle) }
-// deferred contexts: recorded jobs hold ONE reference of their own while any of them needs the buffer (buf._held counts the jobs);
-// the owner sees only its own
-function release() { this._native.bufRelease(this._handle); if (this._deferral && this._held) this._deferral.released(this) }
-function refCount() { return this._native.bufRefCount(this._handle) - (this._held > 0 ? 1 : 0) }
+// Reference counting is done HERE: a buffer holds one native reference from createBuffer to the moment its last owner AND the last
+// recorded job that names it (node/defer.js: buf._held) have let go.  addRef / release / refCount were a call into the addon each -
+// 35 calls per 4-layer frame of the recording context, 20 of them made by the recording itself.
+// _dead: let go for good (a later use is refused with the messages the addon has for a released handle).
+function addRef() { if (this._dead) throw new Error('addRef on a released buffer'); ++this._refs }
+function release() {
+	if (this._dead || this._refs <= 0) throw new Error('release on a released buffer')
+	--this._refs
+	if (this._held > 0) { if (this._deferral) this._deferral.released(this); return } // recorded jobs still need it: the last of them lets it go
+	if (this._refs === 0) this._free()
+}
+function refCount() { return this._dead ? 0 : this._refs }
+// The buffer goes.  Frames and images are PARKED instead - the JS object, its handle, its device block and its pinned mirror stay as
+// they are, and the next createBuffer of the same size, kind and image dimensions takes them over whole: the reference makes a fresh
+// destination per job and frame (io.ts:64-72, mixer.ts:196, combiner.ts:230), five to ten a frame, and a createBuffer is 3.5 us
+// (pool lookup, node Buffer, external handle, decoration) where taking a parked one is 0.1.  What is parked is what the library's
+// own pools would hold otherwise; clContext.trim() gives it back to them.
+function free() {
+	this._dead = true
+	const park = this._park
+	if (this._parkKey && park.on) {
+		park.live -= this.length
+		if (park.parked + this.length <= Math.max(park.budget, park.peak)) {
+			let list = park.lists.get(this._parkKey)
+			if (!list) park.lists.set(this._parkKey, (list = []))
+			list.push(this)
+			park.parked += this.length
+			park.count++
+			return
+		}
+	}
+	this._native.bufRelease(this._handle)
+}
 // staging extension (not nodencl): device -> mirror on `queue` without a host wait; the bytes are
 // valid after waitFinish(queue) or after an event recorded behind it has been awaited
 function downloadAsync(queue) {
+	if (this._dead) throw new Error('downloadAsync on a released buffer')
 	if (this._deferral) this._deferral.touch(this, 'readonly', queue === undefined ? 2 : queue)
 	return this._native.downloadAsync(this._handle, queue === undefined ? 2 : queue)
 }
-function makeOpenCLBuffer(native, created, numBytes, imageDims, owner, deferral) {
+// What every buffer of a context shares lives on ONE prototype object per context (between the buffer and Buffer.prototype): the
+// methods, the addon, the recording and the parking lot.  They are then neither own nor enumerable - console.log / deepEqual of a
+// buffer do not walk into the context (ADVICE r4) - and a fresh buffer costs one Object.setPrototypeOf (0.08 us) instead of seven
+// assignments; Object.defineProperty per field was measured at 3.8 us per buffer, five buffers a frame.
+function bufferPrototype(native, deferral, park) {
+	return Object.create(Buffer.prototype, {
+		hostAccess: { value: hostAccess }, addRef: { value: addRef }, release: { value: release }, refCount: { value: refCount },
+		downloadAsync: { value: downloadAsync }, _free: { value: free }, _native: { value: native }, _deferral: { value: deferral }, _park: { value: park }
+	})
+}
+const newPark = (on, budgetMb) => ({ on, lists: new Map(), parked: 0, count: 0, live: 0, peak: 0, budget: budgetMb * 1048576 })
+function makeOpenCLBuffer(proto, created, numBytes, imageDims, owner, deferral, parkKey) {
 	const buf = created.buffer
+	Object.setPrototypeOf(buf, proto)
 	buf._handle = created.handle
-	buf._native = native
-	buf._deferral = deferral
+	buf._refs = 1
+	buf._dead = false
+	buf._parkKey = parkKey
 	buf.numBytes = numBytes
 	buf.owner = owner || ''
 	buf.imageDims = imageDims
 	buf.timestamp = 0
 	buf.loadstamp = 0
 	buf.creationTime = process.hrtime()
-	buf.hostAccess = hostAccess
-	buf.addRef = addRef
-	buf.release = release
-	buf.refCount = refCount
-	buf.downloadAsync = downloadAsync
-	if (deferral) Deferral.adopt(buf)
+	if (deferral) Deferral.adopt(buf, true)
 	return buf
 }
 
@@ -85,6 +123,14 @@ class clContext {
 		// `profile` is set, waitFinish(queue.process) a real wait)
 		this.deferred = params.deferred === undefined ? process.env.PHANERON_DEFERRED !== '0' : !!params.deferred
 		this._deferral = null
+		// recording context: launch a frame's fused chain at the end of the tick that posted its terminal `write` instead of when somebody
+		// asks for the frame (node/defer.js: for hosts whose consumers map their frames long after posting them)
+		this.earlyLaunch = params.earlyLaunch === undefined ? process.env.PHANERON_EARLY_LAUNCH === '1' : !!params.earlyLaunch
+		// released frames and images are parked and taken over whole by the next createBuffer of the same shape (free() above);
+		// `recycleBuffers: false` or PHANERON_RECYCLE=0 returns every buffer to the library at once.  parkMb: what may stay parked
+		// (default 4096 MiB - or as much as was ever in use at once, if that is more)
+		this.recycleBuffers = params.recycleBuffers === undefined ? process.env.PHANERON_RECYCLE !== '0' : !!params.recycleBuffers
+		this.parkMb = params.parkMb === undefined ? 4096 : params.parkMb
 		this._addon = params.addon || null // tests: a stand-in for the N-API addon (node/test/defer_host_bench.js counts the calls the JS layer makes)
 		this.queue = this.overlapping ? { load: 0, process: 1, unload: 2 } : { load: 1, process: 1, unload: 1 }
 		this._ctx = null
@@ -95,6 +141,8 @@ class clContext {
 		this._native = this._addon || loadAddon()
 		this._ctx = this._native.createContext(this.deviceIndex)
 		if (this.deferred) this._deferral = new Deferral(this)
+		this._park = newPark(this.recycleBuffers, this.parkMb)
+		this._bufferProto = bufferPrototype(this._native, this._deferral, this._park)
 	}
 
 	_need() {
@@ -115,8 +163,39 @@ class clContext {
 		if (!(bufType in SVM)) throw new Error(`createBuffer: unknown svm type '${bufType}'`)
 		const w = imageDims ? imageDims.width : 0
 		const h = imageDims ? imageDims.height : 0
+		// frames and images (not parameter buffers: a gamma table's registered LDS form goes with its native buffer) may be parked ones
+		const park = this._park
+		const key = park.on && (imageDims || numBytes >= 1048576) ? `${numBytes}|${w}|${h}|${bufDir}|${bufType}` : null
+		if (key) {
+			park.live += numBytes
+			if (park.live > park.peak) park.peak = park.live
+			const list = park.lists.get(key)
+			if (list && list.length) {
+				const buf = list.pop()
+				park.parked -= numBytes
+				park.count--
+				buf._refs = 1
+				buf._dead = false
+				buf.owner = owner || ''
+				buf.imageDims = imageDims
+				buf.timestamp = 0
+				buf.loadstamp = 0
+				buf.creationTime = process.hrtime()
+				if (this._deferral) Deferral.adopt(buf, true)
+				return buf
+			}
+		}
 		const created = native.createBuffer(this._ctx, numBytes, ACCESS[bufDir], SVM[bufType], w, h, owner || '')
-		return makeOpenCLBuffer(native, created, numBytes, imageDims, owner, this._deferral)
+		return makeOpenCLBuffer(this._bufferProto, created, numBytes, imageDims, owner, this._deferral, key)
+	}
+	// give the parked buffers back to the library (its own pools keep the blocks): before counting live buffers, or to shed memory
+	trim() {
+		const park = this._park
+		if (!park) return
+		for (const list of park.lists.values()) for (const buf of list) this._native.bufRelease(buf._handle)
+		park.lists.clear()
+		park.parked = 0
+		park.count = 0
 	}
 
 	async createProgram(kernel, options) {
@@ -133,7 +212,15 @@ class clContext {
 
 	async runProgram(program, params, queue) {
 		const native = this._need()
-		if (this._deferral) return this._deferral.record(program, params, queue === undefined ? this.queue.process : queue)
+		if (this._deferral) {
+			const q = queue === undefined ? this.queue.process : queue
+			const zeros = this._deferral.record(program, params, q)
+			// `profile` on a recording context: a frame's jobs reach the device as one launch, when its terminal `write` is posted (or
+			// later).  That job is launched here and now and gets the launch's device time - the whole chain's - as its RunTimings; the
+			// jobs folded into it keep their zeros (the reference prints what runProgram returns: clJobQueue.ts:159-215)
+			if (this.profile && program.name === 'write' && program.format !== undefined && params.output) return this._timedWrite(params, q, zeros)
+			return zeros
+		}
 		const names = []
 		const values = []
 		for (const name of Object.keys(params)) {
@@ -142,6 +229,7 @@ class clContext {
 			names.push(name)
 			if (Buffer.isBuffer(v)) {
 				if (!v._handle) throw new Error(`runProgram: parameter '${name}' is a plain Buffer, not an OpenCLBuffer`)
+				if (v._dead) throw new Error('runProgram: a buffer argument has already been released')
 				values.push(v._handle)
 			} else {
 				values.push(typeof v === 'boolean' ? (v ? 1 : 0) : v)
@@ -149,6 +237,17 @@ class clContext {
 		}
 		const q = queue === undefined ? this.queue.process : queue
 		return native.runProgram(this._ctx, program._handle, names, values, q, this.profile)
+	}
+
+	async _timedWrite(params, q, zeros) {
+		const native = this._native
+		const t0 = process.hrtime.bigint()
+		const from = native.eventRecord(this._ctx, q, true)
+		this._deferral.touch(params.outputY || params.output, 'readonly', q) // runs the frame's chain (a failure rejects runProgram, as on a plain context)
+		const to = native.eventRecord(this._ctx, q, true)
+		await native.eventWait(to)
+		const kernelExec = native.eventElapsed(from, to)
+		return { dataToKernel: zeros.dataToKernel, kernelExec, totalTime: Number((process.hrtime.bigint() - t0) / 1000n) }
 	}
 
 	async waitFinish(queue) {
@@ -220,8 +319,18 @@ class clContext {
 
 	// library options (include/phaneron_hip.h ph_ctx_set_option): 'lds_lut', 'stream_images', 'stream_threshold_mb', 'host_pool_mb'
 	setOption(name, value) { this._need().setOption(this._ctx, String(name), value | 0) }
-	logBuffers() {
+	// the library's buffer counters, less what is parked here (nobody's: index.js free()): { liveBuffers, liveBytes, pooledBytes,
+	// parkedBuffers, parkedBytes, pinnedInUse, pinnedPooled, pinnedPeak, pins }
+	bufferStats() {
 		const s = this._need().bufferStats(this._ctx)
+		s.liveBuffers -= this._park.count
+		s.liveBytes -= this._park.parked
+		s.parkedBuffers = this._park.count
+		s.parkedBytes = this._park.parked
+		return s
+	}
+	logBuffers() {
+		const s = this.bufferStats()
 		console.log(`phaneron HIP buffers: ${s.liveBuffers} live (${s.liveBytes} bytes), ${s.pooledBytes} bytes pooled`)
 		return s
 	}
@@ -256,4 +365,4 @@ function planeBytes(format, width, height) {
 	return loadAddon().planeBytes(f, width, height)
 }
 
-module.exports = { clContext, resolveProgram, colour, planeBytes, FORMATS }
+module.exports = { clContext, resolveProgram, colour, planeBytes, FORMATS, bufferPrototype, newPark }

@@ -387,15 +387,17 @@ static void event_finalize(napi_env env, void *data, void *hint) {
 
 /* eventRecord(ctx, queue) -> external (destroyed with the JS object) */
 static napi_value EventRecord(napi_env env, napi_callback_info info) {
-  size_t argc = 2;
-  napi_value argv[2], out;
+  size_t argc = 3;
+  napi_value argv[3], out;
   ctx_box *c;
   int32_t q = PH_QUEUE_PROCESS;
   ph_event *ev = NULL;
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   if (argc < 1 || !get_box(env, argv[0], (void **)&c)) return throw_ph(env, "eventRecord: bad context");
+  bool timed = false; /* eventRecord(ctx, queue, timed): a point eventElapsed can measure from / to */
   if (argc > 1) get_i32(env, argv[1], &q);
-  if (ph_event_record(c->ctx, q, &ev) != PH_OK) return throw_ph(env, "eventRecord");
+  if (argc > 2) napi_get_value_bool(env, argv[2], &timed);
+  if ((timed ? ph_event_record_timed(c->ctx, q, &ev) : ph_event_record(c->ctx, q, &ev)) != PH_OK) return throw_ph(env, "eventRecord");
   NAPI_OK(napi_create_external(env, ev, event_finalize, NULL, &out));
   return out;
 }
@@ -423,6 +425,19 @@ static napi_value EventDone(napi_env env, napi_callback_info info) {
   int r = ph_event_query(ev);
   if (r < 0) return throw_ph(env, "eventDone");
   NAPI_OK(napi_get_boolean(env, r == 1, &out));
+  return out;
+}
+
+/* eventElapsed(from, to) -> microseconds of device time between two timed, finished events of one queue */
+static napi_value EventElapsed(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2], out;
+  ph_event *a, *b;
+  uint32_t us = 0;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 2 || !get_box(env, argv[0], (void **)&a) || !get_box(env, argv[1], (void **)&b)) return throw_ph(env, "eventElapsed: bad event");
+  if (ph_event_elapsed_us(a, b, &us) != PH_OK) return throw_ph(env, "eventElapsed");
+  NAPI_OK(napi_create_uint32(env, us, &out));
   return out;
 }
 
@@ -475,29 +490,18 @@ static napi_value CreateProgram(napi_env env, napi_callback_info info) {
  * numeric argument of either kind as a number (ph_api.cpp need_num). */
 static const char *FLOAT_ARGS[] = {"scale", "offsetX", "offsetY", "mix", "wipe", NULL};
 
-static napi_value RunProgram(napi_env env, napi_callback_info info) {
-  size_t argc = 7;
-  napi_value argv[7];
-  ctx_box *c;
-  prog_box *p;
+/* names[] / values[] of one job -> ph_arg array (caller frees *args and *names); 0 = a JS exception is pending */
+static int marshal_args(napi_env env, napi_value names_arr, napi_value values_arr, ph_arg **args_out, char **names_out, uint32_t *n_out) {
   uint32_t n = 0;
-  int32_t q = PH_QUEUE_PROCESS;
-  bool timed = false, check_only = false; /* check_only: ph_check_program - the job's arguments are examined, nothing is launched */
-  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  if (argc < 4 || !get_box(env, argv[0], (void **)&c) || !get_box(env, argv[1], (void **)&p))
-    return throw_ph(env, "runProgram: bad context/program");
-  if (argc > 6) napi_get_value_bool(env, argv[6], &check_only);
-  napi_get_array_length(env, argv[2], &n);
-  if (argc > 4) get_i32(env, argv[4], &q);
-  if (argc > 5) napi_get_value_bool(env, argv[5], &timed);
+  napi_get_array_length(env, names_arr, &n);
   ph_arg *args = (ph_arg *)calloc(n ? n : 1, sizeof *args);
   char *names = (char *)calloc(n ? n : 1, 64);
   for (uint32_t i = 0; i < n; ++i) {
     napi_value nm, val;
     napi_valuetype t;
     size_t len;
-    napi_get_element(env, argv[2], i, &nm);
-    napi_get_element(env, argv[3], i, &val);
+    napi_get_element(env, names_arr, i, &nm);
+    napi_get_element(env, values_arr, i, &val);
     napi_get_value_string_utf8(env, nm, names + 64 * i, 64, &len);
     args[i].name = names + 64 * i;
     napi_typeof(env, val, &t);
@@ -507,7 +511,7 @@ static napi_value RunProgram(napi_env env, napi_callback_info info) {
       if (!b || !b->buf) {
         free(args), free(names);
         napi_throw_error(env, NULL, "runProgram: a buffer argument has already been released");
-        return NULL;
+        return 0;
       }
       args[i].kind = PH_ARG_BUF, args[i].v.buf = b->buf;
     } else {
@@ -522,6 +526,69 @@ static napi_value RunProgram(napi_env env, napi_callback_info info) {
         args[i].kind = PH_ARG_I32, args[i].v.i32 = (int32_t)d;
     }
   }
+  *args_out = args, *names_out = names, *n_out = n;
+  return 1;
+}
+
+/* runPrograms(ctx, progs[], names[][], values[][], queue): several recorded jobs in one call (ph_run_programs) - the jobs in their
+ * order, channel frames of one shape among them in one launch.  Asynchronous like an untimed runProgram; throws what the library refuses. */
+static napi_value RunPrograms(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value argv[5];
+  ctx_box *c;
+  uint32_t jobs = 0;
+  int32_t q = PH_QUEUE_PROCESS;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 4 || !get_box(env, argv[0], (void **)&c)) return throw_ph(env, "runPrograms: bad context");
+  napi_get_array_length(env, argv[1], &jobs);
+  if (argc > 4) get_i32(env, argv[4], &q);
+  if (!jobs) return NULL;
+  ph_program **progs = (ph_program **)calloc(jobs, sizeof *progs);
+  ph_arg **args = (ph_arg **)calloc(jobs, sizeof *args);
+  char **names = (char **)calloc(jobs, sizeof *names);
+  int *counts = (int *)calloc(jobs, sizeof *counts);
+  int ok = 1;
+  for (uint32_t j = 0; j < jobs && ok; ++j) {
+    napi_value pv, nv, vv;
+    prog_box *p = NULL;
+    uint32_t n = 0;
+    napi_get_element(env, argv[1], j, &pv);
+    napi_get_element(env, argv[2], j, &nv);
+    napi_get_element(env, argv[3], j, &vv);
+    if (!get_box(env, pv, (void **)&p)) {
+      napi_throw_error(env, NULL, "runPrograms: bad program");
+      ok = 0;
+      break;
+    }
+    progs[j] = p->prog;
+    ok = marshal_args(env, nv, vv, &args[j], &names[j], &n);
+    counts[j] = (int)n;
+  }
+  int rc = ok ? ph_run_programs(c->ctx, (int)jobs, progs, (const ph_arg *const *)args, counts, q) : PH_OK;
+  for (uint32_t j = 0; j < jobs; ++j) free(args[j]), free(names[j]);
+  free(progs), free(args), free(names), free(counts);
+  if (!ok) return NULL;
+  if (rc != PH_OK) return throw_ph(env, "runPrograms");
+  return NULL;
+}
+
+static napi_value RunProgram(napi_env env, napi_callback_info info) {
+  size_t argc = 7;
+  napi_value argv[7];
+  ctx_box *c;
+  prog_box *p;
+  uint32_t n = 0;
+  int32_t q = PH_QUEUE_PROCESS;
+  bool timed = false, check_only = false; /* check_only: ph_check_program - the job's arguments are examined, nothing is launched */
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 4 || !get_box(env, argv[0], (void **)&c) || !get_box(env, argv[1], (void **)&p))
+    return throw_ph(env, "runProgram: bad context/program");
+  if (argc > 6) napi_get_value_bool(env, argv[6], &check_only);
+  if (argc > 4) get_i32(env, argv[4], &q);
+  if (argc > 5) napi_get_value_bool(env, argv[5], &timed);
+  ph_arg *args = NULL;
+  char *names = NULL;
+  if (!marshal_args(env, argv[2], argv[3], &args, &names, &n)) return NULL;
   if (timed && !check_only) {
     job *j = (job *)calloc(1, sizeof *j);
     j->kind = JOB_RUN_TIMED, j->ctx = c->ctx, j->prog = p->prog, j->args = args, j->names = names;
@@ -552,6 +619,15 @@ static napi_value BufferStats(napi_env env, napi_callback_info info) {
   napi_create_double(env, (double)a, &v), napi_set_named_property(env, out, "liveBuffers", v);
   napi_create_double(env, (double)b, &v), napi_set_named_property(env, out, "liveBytes", v);
   napi_create_double(env, (double)p, &v), napi_set_named_property(env, out, "pooledBytes", v);
+  { /* the pinned host mirrors (ph_ctx_host_pool_stats): a `pins` count that keeps growing = the pool is smaller than the working set */
+    size_t in_use = 0, pooled = 0, peak = 0;
+    uint64_t pins = 0;
+    ph_ctx_host_pool_stats(c->ctx, &in_use, &pooled, &peak, &pins);
+    napi_create_double(env, (double)in_use, &v), napi_set_named_property(env, out, "pinnedInUse", v);
+    napi_create_double(env, (double)pooled, &v), napi_set_named_property(env, out, "pinnedPooled", v);
+    napi_create_double(env, (double)peak, &v), napi_set_named_property(env, out, "pinnedPeak", v);
+    napi_create_double(env, (double)pins, &v), napi_set_named_property(env, out, "pins", v);
+  }
   return out;
 }
 
@@ -763,7 +839,7 @@ NAPI_MODULE_INIT() {
       {"abiVersion", AbiVersion},   {"setOption", SetOption},   {"createContext", CreateContext}, {"contextInfo", ContextInfo},
       {"createBuffer", CreateBuffer}, {"bufAddRef", BufAddRef},       {"bufRelease", BufRelease},
       {"bufRefCount", BufRefCount}, {"hostAccess", HostAccess},       {"waitFinish", WaitFinish},
-      {"createProgram", CreateProgram}, {"runProgram", RunProgram},   {"bufferStats", BufferStats},
+      {"createProgram", CreateProgram}, {"runProgram", RunProgram}, {"runPrograms", RunPrograms}, {"eventElapsed", EventElapsed},   {"bufferStats", BufferStats},
       {"queueWaitQueue", QueueWaitQueue}, {"downloadAsync", DownloadAsync}, {"eventRecord", EventRecord},
       {"eventWait", EventWait},     {"eventDone", EventDone},       {"waitFinishSpin", WaitFinishSpin},
       {"resolveProgram", ResolveProgram}, {"gammaLut", GammaLut},   {"colourMatrix", ColourMatrix},

@@ -14,7 +14,7 @@ async function main() {
 	const rig = await Rig.open({ deviceIndex: 0 })
 	const server = new Server(rig, { width: job.width, height: job.height, channels: 1, readSpec: job.readSpec, writeSpec: job.writeSpec })
 	await server.init()
-	const base = rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers - rig.constants.size
+	const base = rig.ctx.bufferStats().liveBuffers - rig.constants.size
 	const responses = []
 	let n = 0
 	for (const step of job.script) {
@@ -22,7 +22,7 @@ async function main() {
 		else for (let i = 0; i < step.tick; ++i) fs.writeFileSync(path.join(dir, `out_${n++}.bin`), await server.tick(1))
 	}
 	server.close()
-	const leaked = rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers - rig.constants.size - base
+	const leaked = rig.ctx.bufferStats().liveBuffers - rig.constants.size - base
 	rig.close()
 	fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify({ responses, frames: n, leaked }))
 }

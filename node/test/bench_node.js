@@ -7,6 +7,10 @@
 //   (d) the job stream of (a) posted to a RECORDING context (node/defer.js) the way the reference's valves post it - a
 //       fresh destination image per job, released in the job's callback - and the packed frame asked for by a consumer
 //       on the device (ctx.realise): the recording folds each frame's six jobs into the one fused launch of (c).
+//   (e) 'channels': PH_NODE_BENCH_CHANNELS channels (default 4) of one format in one recording context, each posting a frame per tick
+//       the way (d) does - four placed layers (a full-frame one and three quarter-size insets: the channel kernel's shape), combine_4,
+//       write - the frames of a tick reach the device in one launch (ph_chan_compose_batch); us_per_frame is per CHANNEL frame.
+//       PHANERON_EARLY_LAUNCH=1: frames are launched at the end of the tick that posted them instead of when the consumer asks.
 // usage: node bench_node.js [frames=200] [width=3840] [height=2160] [layers=4]; prints one JSON line per mode.
 const { Rig } = require('../device.js')
 
@@ -17,6 +21,7 @@ async function main() {
 	const n = parseInt(process.argv[5] || '4')
 	const modes = process.env.PH_NODE_BENCH_MODES ? process.env.PH_NODE_BENCH_MODES.split(',') : ['coalesced', 'per-key', 'fused', 'deferred']
 	for (const mode of modes) {
+		if (mode === 'channels') { await channels(frames, w, h); continue }
 		const rig = await Rig.open({ deviceIndex: 0, coalesce: mode !== 'per-key', spinWaitMicros: 200, deferred: mode === 'deferred' })
 		const read = await rig.unpack('v210', w, h, '709', '2020')
 		const write = await rig.pack('v210', w, h, '2020', false)
@@ -80,5 +85,69 @@ async function main() {
 		;[...src.flat(), ...rgba, comb, ...ring.flat()].forEach((b) => b.release())
 		rig.close()
 	}
+}
+// (e): C channels, each a config-2-like frame per tick through the recording context
+async function channels(frames, w, h) {
+	const C = parseInt(process.env.PH_NODE_BENCH_CHANNELS || '4')
+	const n = 4
+	const rig = await Rig.open({ deviceIndex: 0, spinWaitMicros: 200, deferred: true })
+	const read = await rig.unpack('v210', w, h, '709', '709')
+	const write = await rig.pack('v210', w, h, '709', false)
+	const combine = await rig.combine(n, w, h)
+	const transform = await rig.transform(w, h)
+	const PIP = [{}, { scaleX: 0.5, scaleY: 0.5, offsetX: -0.25, offsetY: -0.25 }, { scaleX: 0.5, scaleY: 0.5, offsetX: 0.25, offsetY: -0.25 },
+		{ scaleX: 0.5, scaleY: 0.5, offsetX: 0.25, offsetY: 0.25 }]
+	const mats = []
+	for (const p of PIP) mats.push(await transform.matrix(p))
+	const src = []
+	for (let c = 0; c < C; ++c) {
+		const layers = []
+		for (let l = 0; l < n; ++l) {
+			const p = await rig.planes('v210', w, h)
+			for (let i = 0; i < p[0].length; i += 4) p[0].writeUInt32LE(((0x200 + ((i + 977 * c + 13 * l) * 2654435761 >>> 22)) & 0x3ff) * 0x00100401 & 0x3fffffff, i)
+			await p[0].hostAccess('none', rig.ctx.queue.load)
+			layers.push(p)
+		}
+		src.push(layers)
+	}
+	await rig.sync(rig.ctx.queue.load)
+	const ring = []
+	for (let c = 0; c < C; ++c) ring.push([await rig.planes('v210', w, h, 'writeonly'), await rig.planes('v210', w, h, 'writeonly'), await rig.planes('v210', w, h, 'writeonly')])
+	const slotDone = []
+	const one = async (f) => {
+		const slot = f % 3
+		if (slotDone[slot] && !slotDone[slot].done()) await slotDone[slot].wait()
+		const ids = []
+		for (let c = 0; c < C; ++c) {
+			const id = { source: `chan${c}`, timestamp: f }
+			const fresh = []
+			const placed = []
+			for (let l = 0; l < n; ++l) {
+				const im = await rig.image(w, h)
+				rig.post(id, read(src[c][l], im))
+				const pl = await rig.image(w, h)
+				rig.post(id, transform(im, pl, mats[l]), () => im.release())
+				fresh.push(im)
+				placed.push(pl)
+			}
+			const cm = await rig.image(w, h)
+			rig.post(id, combine(placed, cm), () => placed.forEach((b) => b.release()))
+			rig.post(id, write(cm, ring[c][slot], 0), () => cm.release())
+			ids.push(id)
+		}
+		await Promise.all(ids.map((id) => rig.board.flush(id)))
+		for (let c = 0; c < C; ++c) rig.ctx.realise(ring[c][slot][0])
+		slotDone[slot] = rig.ctx.recordEvent(rig.ctx.queue.process)
+	}
+	for (let f = 0; f < 10; ++f) await one(f)
+	const t0 = process.hrtime.bigint()
+	for (let f = 0; f < frames; ++f) await one(10 + f)
+	await rig.ctx.drain()
+	const sec = Number(process.hrtime.bigint() - t0) / 1e9
+	console.log(JSON.stringify({ bench: 'node', mode: 'channels', channels: C, early_launch: rig.ctx.earlyLaunch, width: w, height: h, layers: n, frames, channel_frames_per_sec: +(C * frames / sec).toFixed(1),
+		us_per_frame: +(1e6 * sec / frames / C).toFixed(1), us_per_tick: +(1e6 * sec / frames).toFixed(1), deferred: rig.ctx.deferredStats(),
+		buffers: rig.ctx.bufferStats() }))
+	;[...src.flat(2), ...ring.flat(2)].forEach((b) => b.release())
+	rig.close()
 }
 main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })

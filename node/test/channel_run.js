@@ -45,7 +45,7 @@ async function main() {
 	]
 	const chan = new Channel(rig, w, h, layers)
 	await chan.init()
-	const base = rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers - rig.constants.size // cached parameter buffers are not frames
+	const base = rig.ctx.bufferStats().liveBuffers - rig.constants.size // cached parameter buffers are not frames
 	const stamps = []
 	for (let f = 0; f < job.frames; ++f) {
 		await A.prepare(f)
@@ -58,7 +58,7 @@ async function main() {
 		fs.writeFileSync(path.join(dir, `out_${f}.bin`), out)
 		out.release()
 	}
-	const leaked = rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers - rig.constants.size - base
+	const leaked = rig.ctx.bufferStats().liveBuffers - rig.constants.size - base
 	chan.close()
 	fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify({ stamps, leaked, board: rig.board.stats }))
 	rig.close()

@@ -2,6 +2,7 @@
 // node/defer.js without a device: the recording's graph logic (what is launched, in which order, what is dropped, who
 // holds which buffer) against a stand-in for the addon that only counts.  Prints one JSON object { checks, problems }.
 const { Deferral } = require('../defer.js')
+const { bufferPrototype, newPark } = require('../index.js')
 
 const problems = []
 let checks = 0
@@ -10,7 +11,8 @@ const expect = (what, got, want) => {
 	if (JSON.stringify(got) !== JSON.stringify(want)) problems.push({ what, got, want })
 }
 
-function rig() {
+function rig(opt) { // opt.early: frames are launched at the end of the posting tick (clContext's earlyLaunch); opt.batch: the addon has runPrograms
+	opt = opt || {}
 	const launches = [] // [program name, queue]
 	const orders = [] // [waiter, signal]
 	let nextId = 1
@@ -29,18 +31,27 @@ function rig() {
 		},
 		queueWaitQueue: (_ctx, waiter, signal) => orders.push([waiter, signal])
 	}
-	const ctx = { _native: native, _ctx: {}, queue: { load: 0, process: 1, unload: 2 } }
+	if (opt.batch) native.runPrograms = (_ctx, progs, names, values, queue) => {
+		if (native.refuse && native.refuse('batch')) throw new Error('batch: refused')
+		for (const vs of values) for (const v of vs) if (v && typeof v === 'object' && !refs.get(v)) throw new Error('batch launched on a freed buffer')
+		launches.push([`batch:${progs.map((p) => p.name).join('+')}`, queue, names.map((n) => n.join(',')).join(';'), values])
+	}
+	const ctx = { _native: native, _ctx: {}, queue: { load: 0, process: 1, unload: 2 }, earlyLaunch: !!opt.early }
 	const d = new Deferral(ctx)
+	const proto = bufferPrototype(native, d, newPark(false, 0)) // the real reference counting of node/index.js; nothing is parked here
 	const buffer = (bytes, dims, owner) => {
 		const b = Buffer.alloc(bytes)
 		const h = { id: nextId++ }
 		refs.set(h, 1)
+		Object.setPrototypeOf(b, proto)
 		Object.defineProperty(b, '_handle', { value: h })
+		b._refs = 1
+		b._dead = false
 		b.imageDims = dims
 		b.owner = owner || ''
-		b.release = () => { native.bufRelease(h); if (b._held) d.released(b) }
 		b.alive = () => refs.get(h) > 0
-		b.appRefs = () => refs.get(h) - (b._held > 0 ? 1 : 0)
+		b.appRefs = () => b._refs
+		Deferral.adopt(b, true)
 		return b
 	}
 	const W = 96
@@ -201,7 +212,7 @@ function rig() {
 	r.native.refuse = (name) => name !== 'write' && name !== 'transform' && name !== 'v210_yadif_pair_1'
 	r.d.touch(outs[0], 'readonly', 2)
 	expect('refused fused launches: the jobs as recorded', r.names(), ['v210_yadif_pair_1', 'transform', 'write'])
-	expect('fallbacks counted: the pair form, the single form, the channel kernel', r.d.stats.fallbacks, 3)
+	expect('fallbacks counted: the pair form, the single form, the channel kernel - and the other field\'s frame, tried along with the one asked for, likewise', r.d.stats.fallbacks, 6)
 	r.d.touch(outs[1], 'readonly', 2)
 	expect('the other field: as recorded too', r.names().slice(3), ['transform', 'write'])
 }
@@ -281,4 +292,114 @@ function rig() {
 	expect('a whole-frame operator over it: the superseded job is dropped unseen', [r2.names(), r2.d.stats.dropped], [['read'], 1])
 }
 
-process.stdout.write(JSON.stringify({ checks, problems }) + '\n')
+// 8. ADVICE r4: field images re-recorded since the pair launch made them are no twins any more
+{
+	const r = rig()
+	const L = r.loader()
+	const m = r.buffer(48, undefined, 'matrix')
+	const y = [r.image('y0'), r.image('y1')]
+	const frame = () => {
+		const win = [0, 1, 2].map((i) => { const im = r.image(`w${i}`); r.d.record(r.P.read, Object.assign({ input: r.v210(`s${i}`), output: im, width: r.W }, L), 1); return im })
+		for (const parity of [0, 1]) r.d.record(r.P.yadif, { prev: win[0], cur: win[1], next: win[2], parity, tff: 1, skipSpatial: 0, output: y[parity] }, 1)
+	}
+	const writes = () => [0, 1].map((parity) => {
+		const t = r.image(`t${parity}`)
+		r.d.record(r.P.transform, { input: y[parity], transformMatrix: m, output: t }, 1)
+		const out = r.v210(`out${parity}`)
+		r.d.record(r.P.write, Object.assign({ input: t, output: out, width: r.W, interlace: 0 }, r.saver), 1)
+		return out
+	})
+	frame()
+	let outs = writes()
+	r.d.touch(outs[0], 'readonly', 2)
+	expect('frame k: the pair launch and both fields\' frames in one launch', r.names(), ['v210_yadif_pair_1', 'compose_up_write_v210_1'])
+	// frame k + 1 into the SAME field images, but y1 gets another producer (not a pairable one) while y0 keeps its contents
+	r.d.record(r.P.other, { input: r.image('still'), output: y[1] }, 1)
+	outs = writes()
+	r.launches.length = 0
+	r.d.touch(outs[0], 'readonly', 2)
+	expect('frame k + 1: y1 is no finished field image any more - no launch takes it as the other field of y0 (no output2 / l0In2); the other frame, tried along with the one asked for, is made from y1 AFTER y1\'s new producer has run',
+		r.launches.map((l) => [l[0], /output2/.test(l[2])]), [['resize', false], ['compose_up_write_v210_1', false], ['compose_up_write_v210_1', false]])
+	r.d.touch(outs[1], 'readonly', 2)
+	expect('and asking for that frame launches nothing more', r.names().length, 3)
+}
+
+// 9. ADVICE r4: a failure while the jobs a new job displaces are run leaves nothing of the new job behind
+{
+	const r = rig()
+	const L = r.loader()
+	const a = r.image('a')
+	const b = r.image('b')
+	const dst = r.image('dst')
+	const m = r.buffer(48, undefined, 'matrix')
+	r.d.record(r.P.read, Object.assign({ input: r.v210('s'), output: a, width: r.W }, L), 1)
+	r.d.record(r.P.other, { input: a, output: dst }, 1) // a pending producer of dst that depends on the read ...
+	r.native.refuse = (name) => name === 'read' // ... which will fail
+	let msg = null
+	try { r.d.record(Object.assign({}, r.P.other, { name: 'paint_region' }), { input: b, output: dst }, 1) } catch (e) { msg = e.message } // a partial writer: dst's producer runs first
+	expect('the new job is refused with the displaced job\'s failure', msg, 'read: refused')
+	expect('and holds nothing: b is only its owner\'s, nobody reads it, nothing pending writes dst', [b.appRefs(), b._held, b._readers.length, dst._producer], [1, 0, 0, null])
+	b.release()
+	expect('b goes with its owner', b.alive(), false)
+}
+
+// 10. frames are launched at the end of the tick that posted them; channels of one shape go to the device in one launch
+{
+	const r = rig({ early: true, batch: true })
+	const m = [r.buffer(48, undefined, 'm0'), r.buffer(48, undefined, 'm1')]
+	m[1].fill(3)
+	const channel = (tag, fill, lines) => { // a channel of its own Loader (equal contents: fill) - two placed layers -> combine_2 -> write
+		const L = r.loader(fill)
+		const img = [0, 1].map((i) => { const im = r.image(`${tag}u${i}`); r.d.record(r.P.read, Object.assign({ input: r.v210(`${tag}s${i}`), output: im, width: r.W }, L), 1); return im })
+		const placed = img.map((im, i) => { const t = r.image(`${tag}t${i}`); r.d.record(r.P.transform, { input: im, transformMatrix: m[i], output: t }, 1); return t })
+		const comb = r.image(`${tag}comb`)
+		r.d.record(r.P.combine2, { l0In: placed[0], l1In: placed[1], output: comb }, 1)
+		const out = r.v210(`${tag}out`)
+		r.d.record(r.P.write, Object.assign({ input: comb, output: out, width: r.W, interlace: 0 }, r.saver), 1)
+		;[...img, ...placed, comb].forEach((b) => b.release())
+		return out
+	}
+	const outs = [channel('A', 1), channel('B', 1), channel('C', 5)] // C: another colour recipe
+	expect('nothing is launched while the tick records', r.names(), [])
+	setImmediate(() => {
+		expect('end of the tick: A and B in one launch, C (another Loader) on its own', r.names().sort(), ['batch:chan_compose_v210_2+chan_compose_v210_2', 'chan_compose_v210_2'])
+		const batch = r.launches.find((l) => l[0].startsWith('batch'))
+		const at = (job, name) => batch[3][job][batch[2].split(';')[job].split(',').indexOf(name)]
+		expect('the batch names ONE Loader / Saver: the first job\'s buffers', ['colMatrix', 'gammaLut', 'gamutMatrix', 'outColMatrix', 'outGammaLut'].map((k) => at(0, k) === at(1, k)), [true, true, true, true, true])
+		expect('every frame is made: nothing recorded is left', [r.d.pending.size, r.d.stats.fused, r.d.stats.launched], [0, 3, 2])
+		outs.forEach((o) => r.d.touch(o, 'readonly', 2))
+		expect('asking for the frames afterwards launches nothing', r.launches.length, 2)
+		// a frame asked for BEFORE the tick ends takes the others of its shape with it
+		const r2 = rig({ early: true, batch: true })
+		const L = r2.loader()
+		const m2 = r2.buffer(48, undefined, 'm')
+		const outs2 = [0, 1, 2].map((c) => {
+			const im = r2.image(`u${c}`)
+			r2.d.record(r2.P.read, Object.assign({ input: r2.v210(`s${c}`), output: im, width: r2.W }, L), 1)
+			const t = r2.image(`t${c}`)
+			r2.d.record(r2.P.transform, { input: im, transformMatrix: m2, output: t }, 1)
+			const out = r2.v210(`out${c}`)
+			r2.d.record(r2.P.write, Object.assign({ input: t, output: out, width: r2.W, interlace: 0 }, r2.saver), 1)
+			return out
+		})
+		r2.d.touch(outs2[1], 'readonly', 2)
+		expect('asked for in the middle of the tick: all three channels\' frames in one launch', r2.names(), ['batch:chan_compose_v210_1+chan_compose_v210_1+chan_compose_v210_1'])
+		// the batch refused: every frame on its own
+		const r3 = rig({ early: true, batch: true })
+		const L3 = r3.loader()
+		const m3 = r3.buffer(48, undefined, 'm')
+		const outs3 = [0, 1].map((c) => {
+			const im = r3.image(`u${c}`)
+			r3.d.record(r3.P.read, Object.assign({ input: r3.v210(`s${c}`), output: im, width: r3.W }, L3), 1)
+			const t = r3.image(`t${c}`)
+			r3.d.record(r3.P.transform, { input: im, transformMatrix: m3, output: t }, 1)
+			const out = r3.v210(`out${c}`)
+			r3.d.record(r3.P.write, Object.assign({ input: t, output: out, width: r3.W, interlace: 0 }, r3.saver), 1)
+			return out
+		})
+		r3.native.refuse = (name) => name === 'batch'
+		r3.d.touch(outs3[0], 'readonly', 2)
+		expect('a refused batch: the frames one launch each', [r3.names(), r3.d.stats.fallbacks], [['chan_compose_v210_1', 'chan_compose_v210_1'], 1])
+		setImmediate(() => process.stdout.write(JSON.stringify({ checks, problems }) + '\n'))
+	})
+}

@@ -136,7 +136,7 @@ async function play(seed, deferred) {
 	rig.close()
 	const stats = rig.ctx.deferredStats()
 	const left = rig.ctx.flushDeferred()
-	const liveBuffers = rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers
+	const liveBuffers = rig.ctx.bufferStats().liveBuffers
 	return { seen, stats, pending: left ? left.pending : 0, liveBuffers, log }
 }
 

@@ -91,7 +91,7 @@ async function scenario(name, fn, expect) {
 			stats.push(st)
 			s.rig.close()
 			const left = s.rig.ctx.flushDeferred()
-			const live = s.rig.ctx._native.bufferStats(s.rig.ctx._ctx)
+			const live = s.rig.ctx.bufferStats()
 			if (deferred && left && left.pending) problems.push({ scenario: name, what: `${left.pending} recorded jobs are still pending after everything was released` })
 			if (live.liveBuffers !== 0) problems.push({ scenario: name, what: `${live.liveBuffers} buffers still alive on the ${deferred ? 'deferred' : 'plain'} side` })
 		} catch (e) {
@@ -186,6 +186,55 @@ async function main() {
 		out.release()
 		return seen
 	}, { fused: 1, plain: 0, launched: 1 })
+
+	// the reference's deployment: several channels of one format in one context (src/index.ts:45-71), their frames posted in the same
+	// tick - the recording hands them to the device as ONE launch (runPrograms -> ph_chan_compose_batch); a fifth channel with a
+	// dissolve in progress and a sixth that is a plain 1:1 layer go along
+	await scenario('six channels of one format posted in one tick', async (s) => {
+		s.frame = 9
+		const outs = []
+		const flushes = []
+		for (let c = 0; c < 6; ++c) {
+			const n = c === 5 ? 1 : 2
+			const srcs = []
+			for (let l = 0; l < n + (c === 4 ? 1 : 0); ++l) srcs.push(await s.source(v210Frame(full, 900 + 10 * c + l, l !== 1)))
+			const id = s.id(`chan${c}`)
+			const unpacked = []
+			for (let l = 0; l < srcs.length; ++l) {
+				const im = await s.rig.image(W, H)
+				s.rig.post(id, s.read([srcs[l]], im), () => srcs[l].release())
+				unpacked.push(im)
+			}
+			const placed = []
+			for (let l = 0; l < srcs.length; ++l) {
+				const im = await s.rig.image(W, H)
+				const where = c === 5 ? {} : l === 0 ? {} : Object.assign({}, PIP[1 + (c + l) % 3], { rotate: 0.02 * c })
+				s.rig.post(id, s.transform(unpacked[l], im, await s.transform.matrix(where)), () => unpacked[l].release())
+				placed.push(im)
+			}
+			let layers = placed
+			if (c === 4) { // the top layer in mid-dissolve against a third source
+				const mixed = await s.rig.image(W, H)
+				s.rig.post(id, s.dissolve(placed[1], placed[2], 0.375, mixed), () => { placed[1].release(); placed[2].release() })
+				layers = [placed[0], mixed]
+			}
+			let frame = layers[0]
+			if (n > 1) {
+				frame = await s.rig.image(W, H)
+				const these = layers
+				s.rig.post(id, s.combine[2](these, frame), () => these.forEach((b) => b.release()))
+			}
+			const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+			const last = frame
+			s.rig.post(id, s.write(last, [out], 0), () => last.release())
+			outs.push(out)
+			flushes.push(id)
+		}
+		await Promise.all(flushes.map((id) => s.flush(id)))
+		const seen = []
+		for (const out of outs) { seen.push(await s.consume(out)); out.release() }
+		return seen
+	}, { fused: 6, plain: 0, launched: 1, batched: 6 })
 
 	// a dissolve against a half-size, rotated incoming source, over a plain read
 	await scenario('dissolve layer over a plain read', async (s) => {

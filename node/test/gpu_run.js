@@ -322,7 +322,7 @@ async function main() {
 	}
 
 	rig.close()
-	result.liveAfter = ctx.logBuffers ? rig.ctx._native.bufferStats(rig.ctx._ctx).liveBuffers : -1
+	result.liveAfter = ctx.logBuffers ? rig.ctx.bufferStats().liveBuffers : -1
 	save('result.json', JSON.stringify(result))
 }
 

@@ -151,7 +151,7 @@ async function main() {
 		}
 	}
 	await ctx.waitFinish(ctx.queue.process)
-	const stats = ctx.logBuffers ? ctx._native.bufferStats(ctx._ctx) : null
+	const stats = ctx.logBuffers ? ctx.bufferStats() : null
 	const deferred = ctx.deferredStats() // PHANERON_DEFERRED=1: the same calls through the recording context (node/defer.js)
 	fs.writeFileSync(path.join(dir, 'replay.json'), JSON.stringify({ events: trace.length, calls, problems, dumps, stats, deferred, device: ctx.getPlatformInfo().devices[0].name }))
 }

@@ -33,7 +33,7 @@ EXPORTS = [
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
     "ph_program_resolve", "ph_route_unique_id", "ph_route_init", "ph_route_destroy", "ph_route_group_begin",
     "ph_route_group_end", "ph_route_send", "ph_route_recv", "ph_route_after_queue", "ph_queue_after_route",
-    "ph_route_wait", "ph_route_stream", "ph_route_comm_count", "ph_chan_compose_v210", "ph_chan_compose_batch",
+    "ph_route_wait", "ph_route_stream", "ph_route_comm_count", "ph_chan_compose_v210", "ph_chan_compose_batch", "ph_run_programs", "ph_event_record_timed", "ph_event_elapsed_us", "ph_ctx_host_pool_stats",
     "ph_v210_yadif_pair_fmt", "ph_compose_up_write_v210",
 ]
 
@@ -193,6 +193,10 @@ def lib():
         "ph_chan_compose_v210": (ci, [vp, ci, ci, C.POINTER(PhChanLayer), vp, cu, cu, cu, vp, vp, vp, vp, vp]),
         "ph_chan_compose": (ci, [vp, ci, ci, C.POINTER(PhChanLayer), ci, C.POINTER(C.c_void_p), cu, cu, cu, vp, vp, vp, vp, vp]),
         "ph_chan_compose_batch": (ci, [vp, ci, ci, C.POINTER(PhChanJob), cu, cu, vp, vp, vp, vp, vp]),
+        "ph_ctx_host_pool_stats": (ci, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+        "ph_event_record_timed": (ci, [vp, ci, C.POINTER(vp)]),
+        "ph_event_elapsed_us": (ci, [vp, vp, C.POINTER(cu)]),
+        "ph_run_programs": (ci, [vp, ci, C.POINTER(vp), C.POINTER(C.POINTER(PhArg)), C.POINTER(ci), ci]),
         "ph_route_unique_id": (ci, [vp]),
         "ph_route_init": (ci, [vp, vp, ci, ci, C.POINTER(vp)]),
         "ph_route_destroy": (ci, [vp]),
@@ -629,10 +633,8 @@ class Context:
         """`clContext.createProgram(kernelSrc, {name, globalWorkItems, workItemsPerGroup})`"""
         return Program(self, source, name, global_work_items, work_items_per_group)
 
-    def run_program(self, program, params, queue=QUEUE_PROCESS, check_only=False):
-        """`clContext.runProgram(program, params, queue)`: params maps kernel argument NAMES to a
-        Buffer, an int or a float (floats must be Python floats).  Returns the RunTimings in us.
-        check_only: examine the job as a launch would and enqueue nothing (ph_check_program)."""
+    @staticmethod
+    def _args(params):
         n = len(params)
         arr = (PhArg * n)()
         keep = []
@@ -653,6 +655,22 @@ class Context:
                 arr[i].kind, arr[i].v.f32 = ARG_F32, v
             else:
                 raise TypeError("kernel parameter %r: unsupported value %r" % (k, type(v)))
+        return arr, keep
+
+    def run_programs(self, jobs, queue=QUEUE_PROCESS):
+        """Several jobs in one call (ph_run_programs): jobs = [(program, params), ...] as run_program takes them."""
+        marshalled = [self._args(params) for _, params in jobs]
+        progs = (C.c_void_p * len(jobs))(*[p.h for p, _ in jobs])
+        args = (C.POINTER(PhArg) * len(jobs))(*[C.cast(a, C.POINTER(PhArg)) for a, _ in marshalled])
+        counts = (C.c_int * len(jobs))(*[len(params) for _, params in jobs])
+        check(lib().ph_run_programs(self.h, len(jobs), progs, args, counts, queue), self.h)
+
+    def run_program(self, program, params, queue=QUEUE_PROCESS, check_only=False):
+        """`clContext.runProgram(program, params, queue)`: params maps kernel argument NAMES to a
+        Buffer, an int or a float (floats must be Python floats).  Returns the RunTimings in us.
+        check_only: examine the job as a launch would and enqueue nothing (ph_check_program)."""
+        arr, keep = self._args(params)
+        n = len(params)
         if check_only:  # ph_check_program: the checks of a launch, nothing enqueued
             check(lib().ph_check_program(self.h, program.h, arr, n, queue), self.h)
             return None
@@ -682,6 +700,12 @@ class Context:
 
     def record_event(self, queue):
         return Event(self, queue)
+
+    def host_pool_stats(self):
+        """pinned host mirrors: {in_use, pooled, peak_in_use} bytes and `pins` = hipHostMalloc calls so far (ph_ctx_host_pool_stats)"""
+        a, b, c, n = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_uint64()
+        check(lib().ph_ctx_host_pool_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)), self.h)
+        return {"in_use": a.value, "pooled": b.value, "peak_in_use": c.value, "pins": n.value}
 
     def buffer_stats(self):
         a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()

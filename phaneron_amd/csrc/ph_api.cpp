@@ -78,7 +78,12 @@ struct ph_ctx {
   std::multimap<size_t, HostBlock> host_pool;
   size_t host_pooled_bytes = 0;
   uint64_t host_pool_seq = 0;
-  int host_pool_mb = 1024;  // what the pool may keep pinned
+  // what the pool may keep pinned: this many MiB, or - if that is more - as much as was ever in use at once (host_peak_bytes): a
+  // pool smaller than the working set frees and pins a block per buffer again, 40 ms each (four 1080p channels create 36 images of
+  // 33 MB per tick: round 5 measured 40 ms per tick under the fixed 1 GiB of round 4)
+  int host_pool_mb = 4096;
+  size_t host_live_bytes = 0, host_peak_bytes = 0;  // mirrors attached to buffers now / at most
+  uint64_t host_pins = 0;                           // hipHostMalloc calls so far (ph_ctx_host_pool_stats)
   void *chan_index[3] = {nullptr, nullptr, nullptr};  // index frame of the channel compositor, one per queue (ph_chan_compose_v210)
   size_t chan_index_bytes[3] = {0, 0, 0};
   std::vector<struct ph_route *> routes;  // open ROUTEs: a recycled block must not be handed out under a transfer in flight
@@ -359,7 +364,9 @@ int ph_buf_release(ph_buf *b) {
     std::vector<ph_ctx::HostBlock> victims;
     {
       std::lock_guard<std::mutex> lock(ctx->mu);
-      const size_t budget = (size_t)ctx->host_pool_mb << 20;
+      const size_t fixed = (size_t)ctx->host_pool_mb << 20;
+      const size_t budget = ctx->host_pool_mb && ctx->host_peak_bytes > fixed ? ctx->host_peak_bytes : fixed;  // (0: no pool at all)
+      ctx->host_live_bytes -= b->bytes;
       if (b->bytes > budget) {
         victims.push_back(ph_ctx::HostBlock{b->hptr, b->mirror_busy, 0});
       } else {
@@ -423,6 +430,8 @@ void *ph_buf_host_ptr(ph_buf *b) {
         b->mirror_busy = it->second.busy;
         b->ctx->host_pool.erase(it);
         b->ctx->host_pooled_bytes -= b->bytes;
+        b->ctx->host_live_bytes += b->bytes;
+        if (b->ctx->host_live_bytes > b->ctx->host_peak_bytes) b->ctx->host_peak_bytes = b->ctx->host_live_bytes;
         lock.unlock();
         // the previous owner may have released the buffer with a download or an upload of this block still in flight
         // (release after downloadAsync, before its waitFinish: ADVICE r3); normally the event completed long ago
@@ -434,6 +443,11 @@ void *ph_buf_host_ptr(ph_buf *b) {
     if (hipHostMalloc(&b->hptr, b->bytes ? b->bytes : 1, hipHostMallocDefault) != hipSuccess) {
       fail(PH_E_HIP, "hipHostMalloc(%zu) failed", b->bytes);
       b->hptr = nullptr;
+    } else {
+      std::lock_guard<std::mutex> lock(b->ctx->mu);
+      b->ctx->host_pins++;
+      b->ctx->host_live_bytes += b->bytes;
+      if (b->ctx->host_live_bytes > b->ctx->host_peak_bytes) b->ctx->host_peak_bytes = b->ctx->host_live_bytes;
     }
   }
   return b->hptr;
@@ -536,6 +550,33 @@ int ph_event_record(ph_ctx *ctx, int queue, ph_event **out) {
   }
   *out = new ph_event{ctx, ev};
   ctx_ref(ctx);
+  return PH_OK;
+}
+
+/* a point in `queue` that can be timed against another (ph_event_elapsed_us): RunTimings of a recording binding's fused launches */
+int ph_event_record_timed(ph_ctx *ctx, int queue, ph_event **out) {
+  if (!ctx || !out) return fail(PH_E_INVALID, "ph_event_record_timed: NULL argument");
+  PH_QUEUE("ph_event_record_timed", queue);
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  hipEvent_t ev;
+  PH_HIP(hipEventCreate(&ev));
+  hipError_t e = hipEventRecord(ev, stream_of(ctx, queue));
+  if (e != hipSuccess) {
+    hipEventDestroy(ev);
+    return fail(PH_E_HIP, "ph_event_record_timed: %s", hipGetErrorString(e));
+  }
+  *out = new ph_event{ctx, ev};
+  ctx_ref(ctx);
+  return PH_OK;
+}
+
+int ph_event_elapsed_us(ph_event *from, ph_event *to, uint32_t *us) {
+  if (!from || !to || !us) return fail(PH_E_INVALID, "ph_event_elapsed_us: NULL argument");
+  float ms = 0.f;
+  hipError_t e = hipEventElapsedTime(&ms, from->ev, to->ev);  // both finished, both recorded with timing (ph_event_record_timed)
+  if (e != hipSuccess) return fail(PH_E_HIP, "ph_event_elapsed_us: %s", hipGetErrorString(e));
+  *us = (uint32_t)(ms * 1000.0f + 0.5f);
   return PH_OK;
 }
 
@@ -862,6 +903,16 @@ int ph_ctx_buffer_stats(ph_ctx *ctx, size_t *live_buffers, size_t *live_bytes, s
   return PH_OK;
 }
 
+int ph_ctx_host_pool_stats(ph_ctx *ctx, size_t *in_use_bytes, size_t *pooled_bytes, size_t *peak_in_use_bytes, uint64_t *pins) {
+  if (!ctx) return fail(PH_E_INVALID, "ph_ctx_host_pool_stats: ctx is NULL");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (in_use_bytes) *in_use_bytes = ctx->host_live_bytes;
+  if (pooled_bytes) *pooled_bytes = ctx->host_pooled_bytes;
+  if (peak_in_use_bytes) *peak_in_use_bytes = ctx->host_peak_bytes;
+  if (pins) *pins = ctx->host_pins;
+  return PH_OK;
+}
+
 // ---- gamma LUT registry ------------------------------------------------------------------------
 int ph_lut_unregister(ph_ctx *ctx, const void *dev) {
   if (!ctx) return fail(PH_E_INVALID, "ph_lut_unregister: ctx is NULL");
@@ -1052,6 +1103,135 @@ static int flush_dirty_args(ph_ctx *ctx, const ph_arg *args, int n, int queue) {
   return PH_OK;
 }
 
+// A channel's frame as the by-name program chan_compose_v210_<n> describes it (dispatch K_CHAN_COMPOSE; ph_run_programs puts several
+// such calls into one launch): the arguments checked and turned into ph_chan_compose's own.
+struct ChanCall {
+  ph_chan_layer layers[ph::kMaxLayers];
+  int n_layers, out_format;
+  uint32_t width, height, interlace;
+  void *out_planes[3];
+  ph_buf *rd_cm, *rd_lut, *rd_gm, *wr_cm, *wr_lut;
+};
+static int chan_call_parse(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, bool check_only, ChanCall *call) {
+  ph_buf *b = nullptr, *c = nullptr, *d = nullptr, *o = nullptr;
+  int rc;
+#define TRY(x) \
+  if ((rc = (x)) != PH_OK) return rc
+  // l<i>In: a layer's source - a v210 frame (l<i>Width / l<i>Height: its size, default the output's) or an RGBA image buffer;
+  // l<i>Matrix (optional): its placement, a buffer whose host mirror holds the nine floats (Transform writes it through
+  // hostAccess: transform.ts:84-89), absent = 1:1; l<i>Transition: 0 cut / 1 dissolve / 2 wipe; l<i>Mix; l<i>Incoming(In|Matrix|
+  // Width|Height) and l<i>Mask(...): the transition's other sources; output: v210; colMatrix / gammaLut / gamutMatrix: the
+  // Loader's, outColMatrix / outGammaLut: the Saver's; interlace as 'write'
+  {
+      const uint32_t width = prog->global[0], height = prog->global[1];
+      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
+      ph_chan_layer layers[ph::kMaxLayers];
+      memset(layers, 0, sizeof layers);
+      auto source = [&](int i, const char *role, ph_chan_source *s) -> int {
+        char nm[40];
+        ph_buf *x = nullptr;
+        snprintf(nm, sizeof nm, "l%d%sIn", i, role);
+        TRY(need_buf(args, n, nm, 0, &x));
+        double sw = width, sh = height;
+        s->data = x->dptr;
+        if (x->width > 0 && x->height > 0) {  // an image buffer (createBuffer with imageDims): f32 RGBA
+          s->format = PH_SRC_RGBA_F32, sw = x->width, sh = x->height;
+        } else {
+          s->format = PH_SRC_V210;
+          s->data_u = s->data_v = nullptr, s->col_matrix12 = nullptr;
+          // another wire format: l<i>Packing = its PH_FMT_* (1 yuv422p10, 2 yuv422p8, 3 yuv420p, 4 nv12: l<i>In the Y plane, l<i>InU /
+          // l<i>InV the chroma planes (nv12: l<i>InU the CbCr plane), l<i>ColMatrix (optional) its own Loader matrix; 5 rgba8, 6 bgra8: l<i>In the frame)
+          double packing = 0;
+          snprintf(nm, sizeof nm, "l%d%sPacking", i, role);
+          if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &packing));
+          if (packing != 0) {
+            if (packing < PH_FMT_YUV422P10 || packing > PH_FMT_BGRA8) return fail(PH_E_INVALID, "kernel argument '%s': %g is not a pack format other than v210", nm, packing);
+            s->format = PH_SRC_YUV422P10 + ((int)packing - PH_FMT_YUV422P10);  // PH_SRC_* follow PH_FMT_* from here on
+          }
+          snprintf(nm, sizeof nm, "l%d%sWidth", i, role);
+          if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sw));
+          snprintf(nm, sizeof nm, "l%d%sHeight", i, role);
+          if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sh));
+          if (s->format == PH_SRC_RGBA8 || s->format == PH_SRC_BGRA8) {
+            if (sw > 0 && sh > 0 && x->bytes < (size_t)sw * (size_t)sh * 4) return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than a %gx%g frame of 4 bytes per pixel", i, role, x->bytes, sw, sh);
+          } else if (s->format != PH_SRC_V210) {
+            const int fmt = PH_FMT_YUV422P10 + (s->format - PH_SRC_YUV422P10);
+            size_t pb[3] = {0, 0, 0};
+            if (sw > 0 && sh > 0) ph_pack_plane_bytes(fmt, (uint32_t)sw, (uint32_t)sh, pb);
+            char nu[40];
+            ph_buf *pu = nullptr, *pv = nullptr, *pm = nullptr;
+            snprintf(nu, sizeof nu, "l%d%sInU", i, role);
+            TRY(need_buf(args, n, nu, pb[1], &pu));
+            s->data_u = pu->dptr;
+            if (fmt != PH_FMT_NV12) {
+              snprintf(nu, sizeof nu, "l%d%sInV", i, role);
+              TRY(need_buf(args, n, nu, pb[2], &pv));
+              s->data_v = pv->dptr;
+            }
+            snprintf(nu, sizeof nu, "l%d%sColMatrix", i, role);
+            if (find_arg(args, n, nu)) {
+              TRY(need_buf(args, n, nu, 48, &pm));
+              s->col_matrix12 = pm->dptr;
+            }
+            if (x->bytes < pb[0]) return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than the Y plane of a %gx%g frame", i, role, x->bytes, sw, sh);
+          } else if (sw > 0 && sh > 0 && x->bytes < (size_t)ph_v210_pitch_bytes((uint32_t)sw) * (size_t)sh)
+            return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than a %gx%g v210 frame", i, role, x->bytes, sw, sh);
+        }
+        s->width = (int)sw, s->height = (int)sh, s->matrix9_host = nullptr;
+        snprintf(nm, sizeof nm, "l%d%sMatrix", i, role);
+        if (find_arg(args, n, nm)) {
+          ph_buf *m = nullptr;
+          TRY(need_buf(args, n, nm, 36, &m));
+          if (!m->hptr) return fail(PH_E_INVALID, "kernel argument '%s': the matrix must have been written through hostAccess (its host copy is what the launch reads)", nm);
+          s->matrix9_host = (const float *)m->hptr;
+        }
+        return PH_OK;
+      };
+      for (int i = 0; i < prog->n_layers; ++i) {
+        char nm[40];
+        TRY(source(i, "", &layers[i].src));
+        double tr = 0, mix = 0;
+        snprintf(nm, sizeof nm, "l%dTransition", i);
+        if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &tr));
+        snprintf(nm, sizeof nm, "l%dMix", i);
+        if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &mix));
+        layers[i].transition = (int)tr, layers[i].mix = (float)mix;
+        if (layers[i].transition != PH_TRANSITION_CUT) TRY(source(i, "Incoming", &layers[i].incoming));
+        if (layers[i].transition == PH_TRANSITION_WIPE) TRY(source(i, "Mask", &layers[i].mask));
+      }
+      // output: the packed frame - v210, or with outPacking = PH_FMT_* another wire format: 1 yuv422p10 / 2 yuv422p8 / 3 yuv420p (output =
+      // the Y plane, outputU, outputV), 4 nv12 (output, outputC), 5 rgba8 / 6 bgra8 (no outColMatrix)
+      double interlace = 0, out_packing = 0;
+      ph_buf *wcm = nullptr, *wl = nullptr, *ou = nullptr, *ov = nullptr;
+      if (find_arg(args, n, "outPacking")) TRY(need_num(args, n, "outPacking", &out_packing));
+      const int ofmt = (int)out_packing;
+      size_t opb[3] = {0, 0, 0};
+      if (ph_pack_plane_bytes(ofmt, width, height, opb) < 0) return fail(PH_E_INVALID, "kernel argument 'outPacking': %g is not a pack format", out_packing);
+      TRY(need_buf(args, n, "output", opb[0], &o));
+      if (ofmt == PH_FMT_YUV422P10 || ofmt == PH_FMT_YUV422P8 || ofmt == PH_FMT_YUV420P) {
+        TRY(need_buf(args, n, "outputU", opb[1], &ou));
+        TRY(need_buf(args, n, "outputV", opb[2], &ov));
+      } else if (ofmt == PH_FMT_NV12) {  // nv12.ts:374: the interleaved CbCr plane is `outputC`
+        TRY(need_buf(args, n, "outputC", opb[1], &ou));
+      }
+      TRY(need_buf(args, n, "colMatrix", 48, &b));
+      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
+      TRY(need_buf(args, n, "gamutMatrix", 36, &d));
+      if (ofmt != PH_FMT_RGBA8 && ofmt != PH_FMT_BGRA8) TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
+      TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
+      if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
+      if (!check_only) refresh_buf_lut(ctx, c);
+      if (!check_only) refresh_buf_lut(ctx, wl);
+      ph_chan_layer *dst = call->layers;
+      memcpy(dst, layers, sizeof layers);
+      call->n_layers = prog->n_layers, call->out_format = ofmt, call->width = width, call->height = height, call->interlace = (uint32_t)interlace;
+      call->out_planes[0] = o->dptr, call->out_planes[1] = ou ? ou->dptr : nullptr, call->out_planes[2] = ov ? ov->dptr : nullptr;
+      call->rd_cm = b, call->rd_lut = c, call->rd_gm = d, call->wr_cm = wcm, call->wr_lut = wl;
+  }
+#undef TRY
+  return PH_OK;
+}
+
 // check_only: everything up to the launch - argument names, kinds, buffer sizes, geometry - and nothing on the device
 // (ph_check_program: a recording binding reports a bad job where it is posted, not where it is run)
 static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue, bool check_only = false) {
@@ -1206,113 +1386,10 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
                                     b->dptr, c->dptr, d->dptr);
     }
     case K_CHAN_COMPOSE: {
-      // l<i>In: a layer's source - a v210 frame (l<i>Width / l<i>Height: its size, default the output's) or an RGBA image buffer;
-      // l<i>Matrix (optional): its placement, a buffer whose host mirror holds the nine floats (Transform writes it through
-      // hostAccess: transform.ts:84-89), absent = 1:1; l<i>Transition: 0 cut / 1 dissolve / 2 wipe; l<i>Mix; l<i>Incoming(In|Matrix|
-      // Width|Height) and l<i>Mask(...): the transition's other sources; output: v210; colMatrix / gammaLut / gamutMatrix: the
-      // Loader's, outColMatrix / outGammaLut: the Saver's; interlace as 'write'
-      const uint32_t width = prog->global[0], height = prog->global[1];
-      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
-      ph_chan_layer layers[ph::kMaxLayers];
-      memset(layers, 0, sizeof layers);
-      auto source = [&](int i, const char *role, ph_chan_source *s) -> int {
-        char nm[40];
-        ph_buf *x = nullptr;
-        snprintf(nm, sizeof nm, "l%d%sIn", i, role);
-        TRY(need_buf(args, n, nm, 0, &x));
-        double sw = width, sh = height;
-        s->data = x->dptr;
-        if (x->width > 0 && x->height > 0) {  // an image buffer (createBuffer with imageDims): f32 RGBA
-          s->format = PH_SRC_RGBA_F32, sw = x->width, sh = x->height;
-        } else {
-          s->format = PH_SRC_V210;
-          s->data_u = s->data_v = nullptr, s->col_matrix12 = nullptr;
-          // another wire format: l<i>Packing = its PH_FMT_* (1 yuv422p10, 2 yuv422p8, 3 yuv420p, 4 nv12: l<i>In the Y plane, l<i>InU /
-          // l<i>InV the chroma planes (nv12: l<i>InU the CbCr plane), l<i>ColMatrix (optional) its own Loader matrix; 5 rgba8, 6 bgra8: l<i>In the frame)
-          double packing = 0;
-          snprintf(nm, sizeof nm, "l%d%sPacking", i, role);
-          if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &packing));
-          if (packing != 0) {
-            if (packing < PH_FMT_YUV422P10 || packing > PH_FMT_BGRA8) return fail(PH_E_INVALID, "kernel argument '%s': %g is not a pack format other than v210", nm, packing);
-            s->format = PH_SRC_YUV422P10 + ((int)packing - PH_FMT_YUV422P10);  // PH_SRC_* follow PH_FMT_* from here on
-          }
-          snprintf(nm, sizeof nm, "l%d%sWidth", i, role);
-          if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sw));
-          snprintf(nm, sizeof nm, "l%d%sHeight", i, role);
-          if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &sh));
-          if (s->format == PH_SRC_RGBA8 || s->format == PH_SRC_BGRA8) {
-            if (sw > 0 && sh > 0 && x->bytes < (size_t)sw * (size_t)sh * 4) return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than a %gx%g frame of 4 bytes per pixel", i, role, x->bytes, sw, sh);
-          } else if (s->format != PH_SRC_V210) {
-            const int fmt = PH_FMT_YUV422P10 + (s->format - PH_SRC_YUV422P10);
-            size_t pb[3] = {0, 0, 0};
-            if (sw > 0 && sh > 0) ph_pack_plane_bytes(fmt, (uint32_t)sw, (uint32_t)sh, pb);
-            char nu[40];
-            ph_buf *pu = nullptr, *pv = nullptr, *pm = nullptr;
-            snprintf(nu, sizeof nu, "l%d%sInU", i, role);
-            TRY(need_buf(args, n, nu, pb[1], &pu));
-            s->data_u = pu->dptr;
-            if (fmt != PH_FMT_NV12) {
-              snprintf(nu, sizeof nu, "l%d%sInV", i, role);
-              TRY(need_buf(args, n, nu, pb[2], &pv));
-              s->data_v = pv->dptr;
-            }
-            snprintf(nu, sizeof nu, "l%d%sColMatrix", i, role);
-            if (find_arg(args, n, nu)) {
-              TRY(need_buf(args, n, nu, 48, &pm));
-              s->col_matrix12 = pm->dptr;
-            }
-            if (x->bytes < pb[0]) return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than the Y plane of a %gx%g frame", i, role, x->bytes, sw, sh);
-          } else if (sw > 0 && sh > 0 && x->bytes < (size_t)ph_v210_pitch_bytes((uint32_t)sw) * (size_t)sh)
-            return fail(PH_E_RANGE, "kernel argument 'l%d%sIn': buffer of %zu bytes is smaller than a %gx%g v210 frame", i, role, x->bytes, sw, sh);
-        }
-        s->width = (int)sw, s->height = (int)sh, s->matrix9_host = nullptr;
-        snprintf(nm, sizeof nm, "l%d%sMatrix", i, role);
-        if (find_arg(args, n, nm)) {
-          ph_buf *m = nullptr;
-          TRY(need_buf(args, n, nm, 36, &m));
-          if (!m->hptr) return fail(PH_E_INVALID, "kernel argument '%s': the matrix must have been written through hostAccess (its host copy is what the launch reads)", nm);
-          s->matrix9_host = (const float *)m->hptr;
-        }
-        return PH_OK;
-      };
-      for (int i = 0; i < prog->n_layers; ++i) {
-        char nm[40];
-        TRY(source(i, "", &layers[i].src));
-        double tr = 0, mix = 0;
-        snprintf(nm, sizeof nm, "l%dTransition", i);
-        if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &tr));
-        snprintf(nm, sizeof nm, "l%dMix", i);
-        if (find_arg(args, n, nm)) TRY(need_num(args, n, nm, &mix));
-        layers[i].transition = (int)tr, layers[i].mix = (float)mix;
-        if (layers[i].transition != PH_TRANSITION_CUT) TRY(source(i, "Incoming", &layers[i].incoming));
-        if (layers[i].transition == PH_TRANSITION_WIPE) TRY(source(i, "Mask", &layers[i].mask));
-      }
-      // output: the packed frame - v210, or with outPacking = PH_FMT_* another wire format: 1 yuv422p10 / 2 yuv422p8 / 3 yuv420p (output =
-      // the Y plane, outputU, outputV), 4 nv12 (output, outputC), 5 rgba8 / 6 bgra8 (no outColMatrix)
-      double interlace = 0, out_packing = 0;
-      ph_buf *wcm = nullptr, *wl = nullptr, *ou = nullptr, *ov = nullptr;
-      if (find_arg(args, n, "outPacking")) TRY(need_num(args, n, "outPacking", &out_packing));
-      const int ofmt = (int)out_packing;
-      size_t opb[3] = {0, 0, 0};
-      if (ph_pack_plane_bytes(ofmt, width, height, opb) < 0) return fail(PH_E_INVALID, "kernel argument 'outPacking': %g is not a pack format", out_packing);
-      TRY(need_buf(args, n, "output", opb[0], &o));
-      if (ofmt == PH_FMT_YUV422P10 || ofmt == PH_FMT_YUV422P8 || ofmt == PH_FMT_YUV420P) {
-        TRY(need_buf(args, n, "outputU", opb[1], &ou));
-        TRY(need_buf(args, n, "outputV", opb[2], &ov));
-      } else if (ofmt == PH_FMT_NV12) {  // nv12.ts:374: the interleaved CbCr plane is `outputC`
-        TRY(need_buf(args, n, "outputC", opb[1], &ou));
-      }
-      TRY(need_buf(args, n, "colMatrix", 48, &b));
-      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
-      TRY(need_buf(args, n, "gamutMatrix", 36, &d));
-      if (ofmt != PH_FMT_RGBA8 && ofmt != PH_FMT_BGRA8) TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
-      TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
-      if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
-      if (!check_only) refresh_buf_lut(ctx, c);
-      if (!check_only) refresh_buf_lut(ctx, wl);
-      void *oplanes[3] = {o->dptr, ou ? ou->dptr : nullptr, ov ? ov->dptr : nullptr};
-      return check_only ? PH_OK : ph_chan_compose(ctx, queue, prog->n_layers, layers, ofmt, oplanes, width, height, (uint32_t)interlace, b->dptr, c->dptr, d->dptr,
-                                  wcm ? wcm->dptr : nullptr, wl->dptr);
+      ChanCall call;
+      TRY(chan_call_parse(ctx, prog, args, n, check_only, &call));
+      return check_only ? PH_OK : ph_chan_compose(ctx, queue, call.n_layers, call.layers, call.out_format, call.out_planes, call.width, call.height, call.interlace,
+                                  call.rd_cm->dptr, call.rd_lut->dptr, call.rd_gm->dptr, call.wr_cm ? call.wr_cm->dptr : nullptr, call.wr_lut->dptr);
     }
     case K_COMPOSE_UP: {
       // l<i>In: the layer's image - an RGBA image buffer, or with packedRgb = 1 a buffer of packed f32 RGB (l<i>Width / l<i>Height:
@@ -1561,6 +1638,51 @@ int ph_check_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_ar
   if (!ctx || !prog || (n_args > 0 && !args)) return fail(PH_E_INVALID, "ph_check_program: NULL argument");
   PH_QUEUE("ph_check_program", queue);
   return dispatch(ctx, prog, args, n_args, queue, true);
+}
+
+/* Several recorded jobs handed over in one call (a binding that records jobs and launches them later: node/defer.js).  Exactly the
+ * ph_run_program calls in the order given, PROVIDED no job reads what another job of the call writes - with the channel frames among
+ * them (chan_compose_v210_<n> programs of one geometry that name the SAME Loader / Saver buffers and make v210 frames) put into
+ * launches together (ph_chan_compose_batch). */
+int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_arg *const *args, const int *n_args, int queue) {
+  if (!ctx || n_jobs < 1 || !progs || !args || !n_args) return fail(PH_E_INVALID, "ph_run_programs: NULL argument");
+  PH_QUEUE("ph_run_programs", queue);
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  std::vector<ChanCall> calls((size_t)n_jobs);
+  std::vector<char> is_chan((size_t)n_jobs, 0);
+  for (int j = 0; j < n_jobs; ++j) {  // every job is checked before anything is launched: a bad one refuses the call as a whole
+    if (!progs[j] || (n_args[j] > 0 && !args[j])) return fail(PH_E_INVALID, "ph_run_programs: job %d: NULL argument", j);
+    if ((rc = flush_dirty_args(ctx, args[j], n_args[j], queue))) return rc;
+    if (progs[j]->id == K_CHAN_COMPOSE) {
+      if ((rc = chan_call_parse(ctx, progs[j], args[j], n_args[j], false, &calls[(size_t)j]))) return rc;
+      is_chan[(size_t)j] = calls[(size_t)j].out_format == PH_FMT_V210;
+    } else if ((rc = dispatch(ctx, progs[j], args[j], n_args[j], queue, true))) {
+      return rc;
+    }
+  }
+  for (int j = 0; j < n_jobs;) {
+    if (!is_chan[(size_t)j]) {
+      if ((rc = dispatch(ctx, progs[j], args[j], n_args[j], queue))) return rc;
+      ++j;
+      continue;
+    }
+    const ChanCall &c0 = calls[(size_t)j];
+    std::vector<ph_chan_job> batch;
+    int k = j;
+    for (; k < n_jobs && is_chan[(size_t)k]; ++k) {
+      const ChanCall &c = calls[(size_t)k];
+      if (c.width != c0.width || c.height != c0.height || c.rd_cm != c0.rd_cm || c.rd_lut != c0.rd_lut || c.rd_gm != c0.rd_gm || c.wr_cm != c0.wr_cm ||
+          c.wr_lut != c0.wr_lut)
+        break;
+      batch.push_back(ph_chan_job{c.n_layers, c.layers, c.out_planes[0], c.interlace});
+    }
+    rc = ph_chan_compose_batch(ctx, queue, (int)batch.size(), batch.data(), c0.width, c0.height, c0.rd_cm->dptr, c0.rd_lut->dptr, c0.rd_gm->dptr,
+                               c0.wr_cm->dptr, c0.wr_lut->dptr);
+    if (rc) return rc;
+    j = k;
+  }
+  return PH_OK;
 }
 
 // ---- typed entry points ------------------------------------------------------------------------

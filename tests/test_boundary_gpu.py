@@ -363,3 +363,30 @@ def test_channel_program_by_name_with_a_dissolve(ctx):
     for x in (va, vb, bm_id, bm_in, vout):
         x.release()
     col.release()
+
+
+def test_host_mirror_pool_covers_the_working_set():
+    """the pool of pinned mirrors keeps what was in use at once even when that is more than `host_pool_mb` - a steady stream of
+    create / map / release rounds pins nothing after the first round (36 images a tick was 40 ms a tick under a fixed 1 GiB budget)"""
+    from phaneron_amd import capi
+    with capi.Context(0) as ctx:
+        ctx.set_option("host_pool_mb", 8)          # far less than a round's 64 x 1 MiB
+        pins = []
+        for rnd in range(4):
+            bufs = [ctx.create_buffer(1 << 20) for _ in range(64)]
+            for b in bufs:
+                b.host()                            # attaches the mirror (the node binding does this for every buffer)
+            for b in bufs:
+                b.release()
+            pins.append(ctx.host_pool_stats()["pins"])
+        st = ctx.host_pool_stats()
+        assert pins[0] == 64 and pins[1:] == [64, 64, 64], pins
+        assert st["in_use"] == 0 and st["peak_in_use"] == 64 << 20 and st["pooled"] == 64 << 20, st
+        # another size: the old blocks make room oldest first, the budget is still the peak
+        bufs = [ctx.create_buffer(2 << 20) for _ in range(32)]
+        for b in bufs:
+            b.host()
+        for b in bufs:
+            b.release()
+        st2 = ctx.host_pool_stats()
+        assert st2["pooled"] <= 64 << 20 and st2["pins"] == 64 + 32, st2

@@ -112,7 +112,7 @@ def test_napi_addon_builds_loads_and_refuses_without_gpu():
           "console.log(a.abiVersion())") % os.path.join(ROOT, "node", "phaneron_napi.node")
     r = subprocess.run([NODE, "-e", js], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.strip() == "6"
+    assert r.stdout.strip() == "7"
     import torch
     if not torch.cuda.is_available():
         js = ("const {clContext}=require('%s'); const c=new clContext({deviceIndex:0});"
