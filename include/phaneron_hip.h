@@ -517,7 +517,9 @@ int ph_lut_layout_of(const float *host_lut65536, ph_lut_layout *layout, void *ld
  *          "host_pool_mb" (default 4096): how much pinned host memory released buffers' mirrors may keep for the next
  *          buffer of the same size (the reference creates its destinations per job and frame: io.ts:64-72) - this much,
  *          or as much as was ever attached to live buffers at once if that is more (a pool smaller than the working set
- *          pins a block per buffer again, ~40 ms each); over the budget the oldest blocks are freed first; 0: no pool. */
+ *          pins a block per buffer again, ~40 ms each); over the budget the oldest blocks are freed first; 0: no pool;
+ *          "fail_launches" (default 0): while non-zero every launch made through ph_run_program / ph_run_programs fails with
+ *          PH_E_HIP - a fault injection for the error paths of a binding (node/test/soak_run.js); checks still pass. */
 int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value);
 
 /* ---- host colour maths (src/process/colourMaths.ts, run by Loader/Saver constructors

@@ -60,7 +60,23 @@ function free() {
 	const park = this._park
 	if (this._parkKey && park.on) {
 		park.live -= this.length
-		if (park.parked + this.length <= Math.max(park.budget, park.peak)) {
+		const room = Math.max(park.budget, park.peak)
+		// over the budget the shapes nobody has asked for longest make room (a format change: 1080 -> 720 -> 2160 leaves lots of the
+		// old sizes parked; the Map keeps its keys in the order they were last used - createBuffer moves a key to the end)
+		if (park.parked + this.length > room) {
+			for (const [key, list] of park.lists) {
+				if (key === this._parkKey) continue
+				while (list.length && park.parked + this.length > room) {
+					const old = list.pop()
+					park.parked -= old.length
+					park.count--
+					this._native.bufRelease(old._handle)
+				}
+				if (!list.length) park.lists.delete(key)
+				if (park.parked + this.length <= room) break
+			}
+		}
+		if (park.parked + this.length <= room) {
 			let list = park.lists.get(this._parkKey)
 			if (!list) park.lists.set(this._parkKey, (list = []))
 			list.push(this)
@@ -170,6 +186,7 @@ class clContext {
 			park.live += numBytes
 			if (park.live > park.peak) park.peak = park.live
 			const list = park.lists.get(key)
+			if (list && park.lists.size > 1) { park.lists.delete(key); park.lists.set(key, list) } // most recently used last
 			if (list && list.length) {
 				const buf = list.pop()
 				park.parked -= numBytes

@@ -81,6 +81,7 @@ struct ph_ctx {
   // what the pool may keep pinned: this many MiB, or - if that is more - as much as was ever in use at once (host_peak_bytes): a
   // pool smaller than the working set frees and pins a block per buffer again, 40 ms each (four 1080p channels create 36 images of
   // 33 MB per tick: round 5 measured 40 ms per tick under the fixed 1 GiB of round 4)
+  std::atomic<int> fail_launches{0};  // option "fail_launches": while non-zero every launch through ph_run_program(s) fails (tests of a binding's error paths)
   int host_pool_mb = 4096;
   size_t host_live_bytes = 0, host_peak_bytes = 0;  // mirrors attached to buffers now / at most
   uint64_t host_pins = 0;                           // hipHostMalloc calls so far (ph_ctx_host_pool_stats)
@@ -1003,6 +1004,7 @@ int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
     if (value < 0) return fail(PH_E_INVALID, "stream_threshold_mb: a size in MiB");
     return ctx->stream_threshold_mb = value, PH_OK;
   }
+  if (0 == strcmp(name, "fail_launches")) return ctx->fail_launches.store(value), PH_OK;
   if (0 == strcmp(name, "host_pool_mb")) {
     if (value < 0) return fail(PH_E_INVALID, "host_pool_mb: a size in MiB");
     std::vector<ph_ctx::HostBlock> drop;
@@ -1238,6 +1240,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
   ph_buf *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr, *o = nullptr;
   double num = 0;
   int rc, w, h;
+  if (!check_only && ctx->fail_launches.load()) return fail(PH_E_HIP, "%s: launch failed: injected (context option fail_launches)", prog->kernel.c_str());
 #define TRY(x) \
   if ((rc = (x)) != PH_OK) return rc
   switch (prog->id) {
@@ -1649,6 +1652,7 @@ int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_
   PH_QUEUE("ph_run_programs", queue);
   int rc = set_device(ctx);
   if (rc) return rc;
+  if (ctx->fail_launches.load()) return fail(PH_E_HIP, "ph_run_programs: launch failed: injected (context option fail_launches)");
   std::vector<ChanCall> calls((size_t)n_jobs);
   std::vector<char> is_chan((size_t)n_jobs, 0);
   for (int j = 0; j < n_jobs; ++j) {  // every job is checked before anything is launched: a bad one refuses the call as a whole

@@ -711,3 +711,21 @@ def test_random_job_streams_give_the_same_bytes_through_the_recording_context():
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["problems"] == [], res["problems"][:2]
     assert res["fusedLaunches"] > 50, res
+
+
+@needs_node
+@pytest.mark.gpu
+def test_recording_context_soak_fault_and_timings():
+    """The default (recording) context over 10^5 frames with a format change every 25 000 (1080 -> 720 -> 2160 -> 1080): buffer and
+    pinned-memory counters flat, nothing pinned in steady state, no fused launch refused; launches made to fail while one frame's
+    consumer maps it (context option fail_launches): that consumer is told, every job callback fires, the frames after it are the
+    launch-as-posted context's bytes, nothing leaks; and with `profile` the terminal write of a frame returns the fused launch's
+    device time as its RunTimings (what src/clJobQueue.ts:159-215 prints), the jobs folded into it zeros.  """
+    _build_addon()
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "soak_run.js"), "100000"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["problems"] == [], res["problems"][:4]
+    assert res["soak"]["frames"] == 100000 and res["soak"]["deferred"]["fallbacks"] == 0
+    assert "injected" in res["fault"]["deferred"]["rejected"] and res["fault"]["plain"]["rejected"] is None
+    assert all(t["write"]["kernelExec"] > 0 for t in res["timings"])
