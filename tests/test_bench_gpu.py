@@ -60,9 +60,18 @@ def test_default_line_as_the_driver_runs_it():
     line = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2"])
     check_line(line, 1, 20, 5)
     assert line["roofline"]["valu"]["frac"] > 0.2
-    assert [s["config"][0] for s in line["secondary"]] == ["2", "7", "7", "3"]  # configs 2 and 3, and 720p50 (the reference's third format) twice
+    # config 2 alone and four such channels per launch (round 5), 720p50 (the reference's third format) fused / through the channel kernel /
+    # four channels per launch, config 3
+    assert [s["config"][:5] for s in line["secondary"]] == ["2: 1 ", "2 x 4", "720p5", "720p5", "720p5", "3: 1 "]
     for s in line["secondary"]:
         assert 0 < s["roofline"]["frac"] < 1
+    batch, alone = line["secondary"][1], line["secondary"][0]
+    assert batch["channels_per_launch"] == 4 and batch["ms_per_frame"] < 0.92 * alone["ms_per_frame"]  # the batch kernel pays
+    assert alone["bytes_as_benched"] > alone["algorithmic_bytes"]  # config 2's bytes both ways
+    ceil = line["roofline"]["ceiling"]  # north_star's 0.80 answered by a number
+    assert 0.45 < ceil["hbm_frac_at_valu_issue_peak"] < 0.65 and ceil["hbm_frac_at_sustained_issue_rate"][0] < ceil["hbm_frac_at_sustained_issue_rate"][1] < ceil["hbm_frac_at_valu_issue_peak"]
+    assert line["roofline"]["frac"] < ceil["hbm_frac_at_valu_issue_peak"]
+    assert "shader_clock" in line["roofline"]
     cb = line["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert line["value"] > 100 * cb["value"]
@@ -72,6 +81,14 @@ def test_default_line_as_the_driver_runs_it():
     if shutil.which("rocprofv3"):
         assert rf["traffic_source"].startswith("measured in this run"), rf.get("traffic_not_measured")
         assert 0.95 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.25, rf
+        # every secondary roofline names what binds it, from counters taken in the run
+        assert "secondary_counters_not_measured" not in line, line.get("secondary_counters_not_measured")
+        for s in line["secondary"]:
+            r2 = s["roofline"]
+            assert r2["binding_resource"] in ("valu issue", "hbm") and 0 < r2["valu"]["frac"] < 1 and r2["traffic"] > 0.9 * s["algorithmic_bytes"], s
+            unit_ms = [v for k, v in s.items() if k.startswith("ms_per_")][0]
+            assert abs(r2["valu"]["achieved"] - r2["valu"]["instructions_per_unit"] / (unit_ms * 1e-3) / 1e12) < 0.02 * r2["valu"]["achieved"]
+        assert rf["valu"]["source"].startswith("measured in this run")
     else:
         assert rf["traffic_source"].startswith("recorded")
 

@@ -21,7 +21,9 @@ HBM_PEAK_GBS = 8000.0
 
 
 def measure(ctx, torch, np, capi, routes="all", reps=200):
-    """routes: "all" or "best" (the fastest route of each config).  Returns a list of records."""
+    """routes: "all" or "best" (the fastest route of each config).  Returns a list of records.  A record's `kernel_launches` names the
+    kernels of its route and how many launches of each one unit (frame / field) takes: bench.py adds the counters of a profiled
+    child run of this script (VALU instructions, HBM traffic) per unit from them."""
     stream = ctx.torch_stream()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
@@ -47,7 +49,7 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
         # the same route measured second (config 3: 113.9 against 105.2 us per field)
         import time
         i, t0 = 0, time.perf_counter()
-        while i < 4 or time.perf_counter() - t0 < 0.15:
+        while i < 4 or time.perf_counter() - t0 < float(os.environ.get("PH_CONFIG_BENCH_WARM_S", "0.15")):
             fn(i)
             i += 1
             if i % 64 == 0:
@@ -64,12 +66,16 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
 
     out_records = []
 
-    def record(config, route, unit, ms, algo, kernels):
-        out_records.append({"config": config, "route": route, "kernels_per_%s" % unit: kernels, "ms_per_%s" % unit: round(ms, 4),
-                            "%ss_per_sec" % unit: round(1e3 / ms, 1), "algorithmic_bytes": algo,
-                            "roofline": {"bound": "hbm", "achieved": round(algo / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": round(algo / ms / 1e6 / HBM_PEAK_GBS, 4)},
-                            "x_realtime_50fps": round(1e3 / ms / 50, 1)})
+    def record(config, route, unit, ms, algo, kernels, kernel_launches=None, **extra):
+        rec = {"config": config, "route": route, "kernels_per_%s" % unit: kernels, "ms_per_%s" % unit: round(ms, 4),
+               "%ss_per_sec" % unit: round(1e3 / ms, 1), "algorithmic_bytes": algo,
+               "roofline": {"bound": "hbm", "achieved": round(algo / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(algo / ms / 1e6 / HBM_PEAK_GBS, 4)},
+               "x_realtime_50fps": round(1e3 / ms / 50, 1)}
+        if kernel_launches:
+            rec["kernel_launches"] = kernel_launches
+        rec.update(extra)
+        out_records.append(rec)
 
     R = 8
     # ---------------- config 2 -------------------------------------------------------------
@@ -130,8 +136,24 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     # 4 layers + second source + the mask counted as one more v210-sized input + 1 output (38 707 200 during a transition)
     algo2 = 7 * capi.v210_pitch_bytes(w) * h
     name2 = "2: 1 channel, 4-layer 1080p50, three quarter-size insets, wipe transition on the top layer"
+    # what the benched kernel really reads and writes: five v210 frames in, one out, and the wipe's mask as an f32 RGBA image
+    # (SURVEY's 38.7 MB counts the mask as a sixth v210-sized input)
+    benched2 = 6 * capi.v210_pitch_bytes(w) * h + w * h * 16
     record(name2, "channel compositor straight from v210 (ph_chan_compose_v210): [read x5 + transform x4 + transition_wipe + combine_4 + write] "
-           "as one kernel, no f32 frame in HBM", "frame", timeit(config2_chan, reps), algo2, 1)
+           "as one kernel, no f32 frame in HBM", "frame", timeit(config2_chan, reps), algo2, 1, {"chan_compose_v210_kernel<0, 0>": 1.0},
+           bytes_as_benched=benched2, bytes_as_benched_note="5 v210 frames in + 1 out + the wipe's mask as the f32 RGBA image the kernel reads "
+           "(33 MB); algorithmic_bytes is SURVEY 8d's figure, which counts the mask as a v210-sized input")
+    # round 5: the reference runs FOUR channels of <= 1080p in one context through one queue (src/index.ts:45-71,156-160): their frames
+    # of a tick in ONE launch (ph_chan_compose_batch) - per channel frame
+    C2 = 4
+    outs2 = [torch.empty_like(out) for _ in range(C2)]
+    chan_layers = lambda s: ([dict(src=(s[l], w, h, mats_h[l])) for l in range(3)] +
+                             [dict(src=(s[3], w, h, mats_h[3]), transition="wipe", incoming=(s[4], w, h, None), mask=(mask, w, h, None, "rgba"))])
+    batch_jobs = [ctx.chan_compose_batch([(chan_layers(src[(i + j) % R]), outs2[j], 0) for j in range(C2)], w, h, *rd, *wr, prepare_only=True) for i in range(R)]
+    record("2 x 4: four channels of config 2's shape in one context, their frames of a tick in one launch (per channel frame)",
+           "ph_chan_compose_batch: the four frames share the workgroups of one launch - tables loaded once, the wave steps of all four taken "
+           "by the waves as they come free", "frame", timeit(lambda i: batch_jobs[i % R](), reps) / C2, algo2, 1.0 / C2,
+           {"chan_compose_batch_kernel<false>": 1.0 / C2}, bytes_as_benched=benched2, channels_per_launch=C2)
     if routes == "all":
         record(name2, "batched reads + compositor with the wipe inside: [read x5], [transform x4 + transition_wipe + combine_4 + write]", "frame",
                timeit(config2_wipe_inside, reps), algo2, 2)
@@ -158,9 +180,16 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     algo7 = 5 * capi.v210_pitch_bytes(w7) * h7
     name7 = "720p50: 1 channel, 4 x 1280x720 v210 layers -> 1 v210 frame (lines with a tail quad: the reference's tail arithmetic)"
     record(name7, "fused unpack / CSC / combine_4 / CSC / pack, 1:1 layers (ph_fused_v210_combine, tail instantiation)", "frame",
-           timeit(lambda i: ctx.fused_v210_combine(src7[i % R], out7, w7, h7, *rd7, *wr7), reps), algo7, 1)
+           timeit(lambda i: ctx.fused_v210_combine(src7[i % R], out7, w7, h7, *rd7, *wr7), reps), algo7, 1, {"fused_v210_combine_lds_kernel": 1.0})
     record(name7, "channel compositor straight from v210, a full-frame layer and three quarter-size insets (ph_chan_compose_v210, general instantiation)", "frame",
-           timeit(lambda i: chan7[i % R](), reps), algo7, 1)
+           timeit(lambda i: chan7[i % R](), reps), algo7, 1, {"chan_compose_v210_kernel<1, 0>": 1.0})
+    C7 = 4
+    outs7 = [torch.empty_like(out7) for _ in range(C7)]
+    batch7 = [ctx.chan_compose_batch([([dict(src=(src7[(i + j) % R][l], w7, h7, mats7[l])) for l in range(4)], outs7[j], 0) for j in range(C7)],
+                                     w7, h7, *rd7, *wr7, prepare_only=True) for i in range(R)]
+    record("720p50 x 4: four such channels in one context, their frames of a tick in one launch (per channel frame)",
+           "ph_chan_compose_batch, a full-frame layer and three quarter-size insets per channel", "frame",
+           timeit(lambda i: batch7[i % R](), reps) / C7, algo7, 1.0 / C7, {"chan_compose_batch_kernel<true>": 1.0 / C7}, channels_per_launch=C7)
 
     # ---------------- config 3 -------------------------------------------------------------
     sw, sh, ow, oh = 1920, 1080, 3840, 2160
@@ -243,7 +272,7 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     name3 = "3: 1 channel, 4 x 1080i50 -> yadif -> 2x up-scale -> 709->2020 -> combine_4 -> 2160p50 (per output field)"
     record(name3, "fused de-interlacing reader (packed RGB fields) + 2x2-block compositor, two launches per frame: [unpack + yadif, both fields, x4 layers] "
            "(ph_v210_yadif_pair_fmt), [transform x4 + combine_4 + write, both fields] (ph_compose_up_write_v210_pair)", "field",
-           timeit(config3_up_pair, reps), algo3, 1.0)
+           timeit(config3_up_pair, reps), algo3, 1.0, {"v210_yadif_pair_kernel": 0.5, "compose_up_write_v210_kernel": 0.5})
     if routes == "all":
         record(name3, "fused de-interlacing reader (packed RGB fields) + 2x2-block compositor: per frame [unpack + yadif, both fields, x4 layers] "
                "(ph_v210_yadif_pair_fmt), per field [transform x4 + combine_4 + write] (ph_compose_up_write_v210)", "field",
@@ -275,7 +304,9 @@ def main():
     import torch
     from phaneron_amd import capi
     ctx = capi.Context(0)
-    for r in measure(ctx, torch, np, capi, "all"):
+    best = "--best" in sys.argv  # the fastest route of each config only (bench.py's profiled child runs)
+    reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 200
+    for r in measure(ctx, torch, np, capi, "best" if best else "all", reps):
         print(json.dumps(r), flush=True)
     ctx.close()
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that regenerates every measured artifact under profiles/ (written to
 # gpurun_out/profile/, copied into profiles/ afterwards).  usage: bash tools/profile_round.sh <tag>
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profile; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -66,13 +66,13 @@ rm -rf $ROOT/gpurun_out/pmc_sq/*/  # keep the summary only
 
 # 4b. configs 2 and 3: their kernels timed alone, in-kernel phase probe, and counters incl. FETCH_SIZE / WRITE_SIZE (separate passes)
 (for v in wipe nowipe layer0; do python $ROOT/tools/chan_bench.py 300 rgba $v; done; python $ROOT/tools/chan_bench.py 300 v210 wipe; python $ROOT/tools/chan_bench.py 300 rgba wipe yuv422p10; python $ROOT/tools/chan_bench.py 300 rgba nowipe yuv422p10; python $ROOT/tools/chan_bench.py 300 rgba wipe yuv420p; python $ROOT/tools/chan_bench.py 300 rgba wipe nv12) 2>/dev/null | grep '^{' > $OUT/${TAG}_chan_bench.jsonl
-(for v in wipe layer0 insets; do python $ROOT/tools/chan_probe.py $v 2>/dev/null | grep '^{' | grep -v '"turn"'; done) > $OUT/${TAG}_chan_probe.jsonl
-# round 4: tap sharing on / off (A/B in one call), the compact co-resident table form and config 3's index lines priced with timing builds
-(for v in wipe nowipe layer0 insets; do for e in 0 1; do if [ $e = 1 ]; then export PH_CHAN_NO_SHARE=1; else unset PH_CHAN_NO_SHARE; fi; python $ROOT/tools/chan_bench.py 400 rgba $v 2>/dev/null | grep '^{' | sed "s/^{/{\"tap_sharing\": $((1-e)), /"; done; done; unset PH_CHAN_NO_SHARE) > $OUT/${TAG}_chan_share_ab.jsonl
-python $ROOT/tools/compact_lut_price.py 2>/dev/null | grep '^{' > $OUT/${TAG}_compact_lut_price.jsonl
-python $ROOT/tools/config3_price.py 2>/dev/null | grep '^{' > $OUT/${TAG}_config3_price.jsonl
+# round 5: the in-kernel phase probe of the one-job kernel and of the batch kernel (2 / 4 channels per launch), and the A/B of one
+# ph_chan_compose_batch call run by the batch kernel against the same call with every job through the one-job kernel
+bash $ROOT/tools/r05_probe_run.sh > $OUT/${TAG}_chan_batch_probe.txt 2>&1
+(cd $ROOT && bash tools/r05_chan_ab.sh $OUT/${TAG}_chan_batch_ab.jsonl > $OUT/${TAG}_chan_batch_ab_summary.txt 2>&1)
 python $ROOT/tools/up_bench.py 100 2>/dev/null | grep '^{' > $OUT/${TAG}_up_bench.jsonl
 bash $ROOT/tools/pmc_kernel.sh chan_compose python $ROOT/tools/chan_bench.py 40 rgba wipe 2>&1 | grep -v '^{\|simple_timer\|^W2\|^find' > $OUT/${TAG}_pmc_chan.txt
+PH_CHAN_BENCH_JOBS=4 bash $ROOT/tools/pmc_kernel.sh chan_compose_batch python $ROOT/tools/chan_bench.py 40 rgba wipe 2>&1 | grep -v '^{\|simple_timer\|^W2\|^find' > $OUT/${TAG}_pmc_chan_batch.txt
 bash $ROOT/tools/pmc_kernel.sh compose_up python $ROOT/tools/up_bench.py 12 up_single 2>&1 | grep -v '^{\|simple_timer\|^W2\|^find' > $OUT/${TAG}_pmc_up.txt
 bash $ROOT/tools/pmc_kernel.sh v210_yadif_pair python $ROOT/tools/up_bench.py 12 deint 2>&1 | grep -v '^{\|simple_timer\|^W2\|^find' > $OUT/${TAG}_pmc_deint.txt
 rm -rf $ROOT/gpurun_out/pmc_kernel
@@ -116,7 +116,13 @@ $ROOT/tools/opbench4 > $OUT/${TAG}_opbench4.jsonl 2>/dev/null
 python $ROOT/tools/route_bench.py --loopback 2>/dev/null | grep '^{' > $OUT/${TAG}_route_loopback.jsonl
 python $ROOT/tools/staging_bench.py 60 2>/dev/null | grep '^{' > $OUT/${TAG}_staging_bench.jsonl
 $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
-(node $ROOT/node/test/bench_node.js 600; node $ROOT/node/test/bench_node.js 1000 1920 1080 4) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_bench.jsonl
+# through node: the four modes at 2160p and 1080p (3000 frames: a 600-frame run is a third warm-up), released buffers parked or not,
+# and 1 / 4 channels of config 2's shape per tick (their frames in one launch)
+(node $ROOT/node/test/bench_node.js 3000; node $ROOT/node/test/bench_node.js 5000 1920 1080 4;
+ for r in 1 0; do for size in "3000 3840 2160" "5000 1920 1080"; do PHANERON_RECYCLE=$r PH_NODE_BENCH_MODES=deferred node $ROOT/node/test/bench_node.js $size | sed "s/^{/{\"recycle_buffers\": $r, /"; done;
+   for c in 1 4; do PHANERON_RECYCLE=$r PH_NODE_BENCH_CHANNELS=$c PH_NODE_BENCH_MODES=channels node $ROOT/node/test/bench_node.js 3000 1920 1080 | sed "s/^{/{\"recycle_buffers\": $r, /"; done; done;
+ PHANERON_EARLY_LAUNCH=1 PH_NODE_BENCH_CHANNELS=4 PH_NODE_BENCH_MODES=channels node $ROOT/node/test/bench_node.js 3000 1920 1080) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_bench.jsonl
+node $ROOT/node/test/soak_run.js 100000 2>/dev/null | grep '^{' > $OUT/${TAG}_node_soak.json
 (node $ROOT/node/test/napi_costs.js 1920 1080; node $ROOT/node/test/napi_costs.js 3840 2160; node $ROOT/node/test/defer_host_bench.js 20000; node $ROOT/node/test/defer_host_bench.js 20000 --plain) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_host_costs.jsonl
 # the recording context (node/defer.js) against the launch-as-posted one: scenarios, frames compared byte for byte, launch counters
 (node $ROOT/node/test/defer_run.js; node $ROOT/node/test/defer_run.js 1920 64) 2>/dev/null | grep '^{' > $OUT/${TAG}_defer_run.jsonl
