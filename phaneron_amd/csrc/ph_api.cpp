@@ -107,6 +107,7 @@ struct ph_buf {
   std::atomic<bool> lut_dirty;  // host data went into a table-sized buffer since its LDS form was last built
   std::string owner;
   hipEvent_t mirror_busy = nullptr;  // recorded behind the last asynchronous copy into or out of the mirror (travels with it into the pool)
+  hipStream_t mirror_stream = nullptr;  // the stream that copy was enqueued on
 };
 
 
@@ -417,6 +418,10 @@ static void mirror_mark(ph_buf *b, hipStream_t s) {
     hipStreamSynchronize(s);  // no event to carry: wait here rather than let the mirror go back to the pool under the copy
     return;
   }
+  // ONE event stands for every copy of this mirror still in flight: a copy on another queue than the last one's (an upload on LOAD,
+  // then a downloadAsync on UNLOAD) is ordered behind it first, so that the event recorded now covers both
+  if (b->mirror_stream && b->mirror_stream != s) hipStreamWaitEvent(s, b->mirror_busy, 0);
+  b->mirror_stream = s;
   hipEventRecord(b->mirror_busy, s);
 }
 
@@ -2185,7 +2190,8 @@ static int compose_up_common(const char *fn, ph_ctx *ctx, int queue, int n, cons
   const bool pair = layers_b != nullptr;
   if (!ctx || !layers || !out || !wr_cm || !wr_lut || (pair && !out_b)) return fail(PH_E_INVALID, "%s: NULL argument", fn);
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "%s: 1..%d layers", fn, ph::kMaxLayers);
-  if (!out_w || out_w % 48) return fail(PH_E_INVALID, "%s: width %u is not a multiple of 48; run the separate kernels", fn, out_w);
+  // (a width that is not a multiple of 48 - 1280 - ends its lines in a tail quad and cleared slots: the kernel's TAILS instantiation)
+  if (!out_w || out_w % 2) return fail(PH_E_INVALID, "%s: width %u is odd (a v210 frame needs an even width); run the separate kernels", fn, out_w);
   if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "%s: interlace must be 0, 1 or 3", fn);
   if (pair && out == out_b) return fail(PH_E_INVALID, "%s: the two outputs are the same buffer", fn);
   const ph::LutView *wv = lds_view(ctx, wr_lut);

@@ -160,6 +160,9 @@ struct UpArgs {
   LutView wr;
   uint32_t magic_upr, magic_upg;  // launcher
   uint32_t shared;                // launcher: all layers have one size and one placement
+  // launcher: lines by pitch - quad slots per line; the columns the wave steps cover (out_w, or the whole pitch when lines end in a
+  // tail quad and cleared slots: the TAILS instantiation writes those too)
+  uint32_t out_qpitch, cover_w;
   // a second job of the same shape in the same launch (both fields of a frame): its layers' data and its output; jobs = 1 | 2
   const void *ptr2[kMaxLayers];
   void *out2;

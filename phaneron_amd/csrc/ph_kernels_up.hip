@@ -67,7 +67,7 @@ struct UpShare {  // as ChanShare (ph_kernels_chan.hip): units dealt XCD-aware i
 };
 __device__ __forceinline__ UpShare up_share(const UpArgs &a) {
   UpShare s;
-  s.upr = (a.out_w + kUpCols - 1u) / kUpCols;  // wave steps per row pair
+  s.upr = (a.cover_w + kUpCols - 1u) / kUpCols;  // wave steps per row pair
   s.units = s.upr * ((a.lines + 1u) / 2u) * (a.jobs > 1u ? 2u : 1u);  // a second job's row pairs follow the first's
   s.upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * s.upr;
   s.banded = (gridDim.x & 7u) == 0;
@@ -295,22 +295,36 @@ __device__ __forceinline__ void up_filter(const UpPatch &p, const UpGeo &g, UpAc
 }
 
 // writer (v210.ts:145-162) of the lane's block: the even pixel gives Y, Cb, Cr, the odd one Y; then the quad's three lanes trade halves
+// TAILS: lines that do not end on a 48-pixel block (1280: src/config.ts:43-54) - `full` whole quads, the tail quad of out_w % 6 = 2 or 4
+// pixels with the reference's tail arithmetic (table indices truncated, code values through round() and a truncating convert, the words
+// it does not set 0: v210.ts:166-193), then the slots it clears up to the pitch (:131-136).  A lane beyond the line's pixels contributes
+// zero code values, so the same hand-overs and stores make the tail quad's unset words and the cleared slots.
+template <bool TAILS>
 __device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, const UpAcc (&acc)[2][2], uint32_t role, const WriteK &wk, const LutK &lk) {
-  const uint32_t qpl = a.out_w / 6u;
+  const uint32_t qpl = TAILS ? a.out_qpitch : a.out_w / 6u;
+  const uint32_t quad = st.x0 / 6u, full = a.out_w / 6u;
+  const bool in_tail = TAILS && quad == full, beyond = TAILS && st.x0 >= a.out_w;  // (a tail's pixels are inside: beyond is false for them)
   // the twelve table reads of the block's four pixels are started together
   PxPending pend[2][2];
 #pragma unroll
   for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-    for (int dx = 0; dx < 2; ++dx)
-      pend[dy][dx] = write_px_issue(lds_lut_index_unit(acc[dy][dx].r), lds_lut_index_unit(acc[dy][dx].g), lds_lut_index_unit(acc[dy][dx].b), lk);
+    for (int dx = 0; dx < 2; ++dx) {
+      auto index_of = [&](float t) __attribute__((always_inline)) { return TAILS ? lds_lut_index_unit_tail(t, in_tail) : lds_lut_index_unit(t); };
+      pend[dy][dx] = write_px_issue(index_of(acc[dy][dx].r), index_of(acc[dy][dx].g), index_of(acc[dy][dx].b), lk);
+    }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int dy = 0; dy < 2; ++dy) {
     const float er = lds_lut_finish(pend[dy][0].r), eg = lds_lut_finish(pend[dy][0].g), eb = lds_lut_finish(pend[dy][0].b);
     const float orr = lds_lut_finish(pend[dy][1].r), og = lds_lut_finish(pend[dy][1].g), ob = lds_lut_finish(pend[dy][1].b);
-    const uint32_t ey = sat_u16_rte(dot4(er, eg, eb, 1.0f, wk.y)), eu = sat_u16_rte(dot4(er, eg, eb, 1.0f, wk.u)), ev = sat_u16_rte(dot4(er, eg, eb, 1.0f, wk.v));
-    const uint32_t y1 = sat_u16_rte(dot4(orr, og, ob, 1.0f, wk.y));
+    auto code = [&](float v) __attribute__((always_inline)) {
+      if (!TAILS) return sat_u16_rte(v);
+      const uint32_t c = in_tail ? sat_u16_trunc(__builtin_roundf(v)) : sat_u16_rte(v);
+      return beyond ? 0u : c;
+    };
+    const uint32_t ey = code(dot4(er, eg, eb, 1.0f, wk.y)), eu = code(dot4(er, eg, eb, 1.0f, wk.u)), ev = code(dot4(er, eg, eb, 1.0f, wk.v));
+    const uint32_t y1 = code(dot4(orr, og, ob, 1.0f, wk.y));
     // lane B's gifts: to A (the lane before it) Cb2 << 10 | Y2 << 20, to C (the lane after it) Cr2 | Y3 << 10
     const uint32_t to_prev = eu << 10 | ey << 20, to_next = ev | y1 << 10;
     const uint32_t from_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)to_prev, 0x130 /* wave_shl:1: lane i reads lane i + 1 */, 0xf, 0xf, false);
@@ -318,7 +332,8 @@ __device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, cons
     uint2 half;
     if (role == 0u) half = make_uint2(ev << 20 | ey << 10 | eu, from_next | y1);  // w0, w1
     else half = make_uint2(eu << 20 | from_prev, y1 << 20 | ev << 10 | ey);      // w2, w3 (lane C)
-    const bool store = st.live && role != 1u && (dy == 0 || st.li[1] != st.li[0]);
+    // (TAILS: every quad slot of the pitch is written - the tail quad's unset words and the cleared slots come out of the zero lanes)
+    const bool store = (TAILS ? (threadIdx.x & 63u) < 63u && quad < qpl : st.live) && role != 1u && (dy == 0 || st.li[1] != st.li[0]);
     if (store) {
       // ONE eight-byte store per lane: the wave's lanes A and C then cover their row segment without a gap, every 32-byte sector
       // written whole and once.  (As two dword stores each instruction wrote every other dword and each sector went out twice,
@@ -330,7 +345,7 @@ __device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, cons
   }
 }
 
-template <bool RGB12>
+template <bool RGB12, bool TAILS = false>
 __global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs a) {
   const WriteK wk = load_write_k(a.wr_cm);
   const LutK lk = make_lut_k(a.wr);
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs 
     } else {
       layers(std::false_type{}, std::false_type{});
     }
-    up_write(a, st, acc, role, wk, lk);
+    up_write<TAILS>(a, st, acc, role, wk, lk);
   }
 }
 
@@ -389,7 +404,7 @@ __global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs 
 // pixels of a block are at most one texel apart, rounding noise included, and the block's taps lie in a 3 x 3 patch), images
 // below 1 GiB.
 bool compose_up_eligible(const UpArgs &a) {
-  if (a.out_w % 6u || !a.n) return false;
+  if (a.out_w % 2u || !a.n) return false;  // (any even width: lines with a tail take the TAILS instantiation)
   for (int l = 0; l < a.n; ++l) {
     const UpLayer &L = a.layer[l];
     if (L.m[1] != 0.0f || L.m[3] != 0.0f || !(L.m[0] > 0.0f) || !(L.m[4] > 0.0f)) return false;
@@ -405,24 +420,31 @@ bool compose_up_eligible(const UpArgs &a) {
 
 hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb12, uint32_t num_cus) {
   if (!a.lines) return hipSuccess;
-  const void *fn = rgb12 ? reinterpret_cast<const void *>(compose_up_write_v210_kernel<true>)
-                         : reinterpret_cast<const void *>(compose_up_write_v210_kernel<false>);
+  const bool tails = a.out_w % 48u != 0;  // lines that end in a tail quad and / or cleared slots: an instantiation of its own
+  const void *fn = tails ? (rgb12 ? reinterpret_cast<const void *>(compose_up_write_v210_kernel<true, true>)
+                                  : reinterpret_cast<const void *>(compose_up_write_v210_kernel<false, true>))
+                         : (rgb12 ? reinterpret_cast<const void *>(compose_up_write_v210_kernel<true>)
+                                  : reinterpret_cast<const void *>(compose_up_write_v210_kernel<false>));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
   if (e != hipSuccess) return e;
   UpArgs b = a;
+  b.out_qpitch = v210_pitch_bytes(a.out_w) / 16u;
+  b.cover_w = tails ? b.out_qpitch * 6u : a.out_w;
   b.shared = 1;  // every layer has the size and the placement of the first: the patch geometry and the weights are computed once per block
   for (int l = 1; l < a.n; ++l) {
     b.shared = b.shared && a.layer[l].w == a.layer[0].w && a.layer[l].h == a.layer[0].h && a.layer[l].pitch == a.layer[0].pitch;
     for (int k = 0; k < 6; ++k) b.shared = b.shared && a.layer[l].m[k] == a.layer[0].m[k];
   }
-  const uint32_t upr = (a.out_w + kUpCols - 1u) / kUpCols, upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * upr;
+  const uint32_t upr = (b.cover_w + kUpCols - 1u) / kUpCols, upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * upr;
   const uint32_t units = upr * ((a.lines + 1u) / 2u) * (a.jobs > 1u ? 2u : 1u);
   // reciprocals for the kernel's uniform divisions: umulhi(v, ceil(2^32 / d)) == v / d while v * d < 2^32
   b.magic_upr = upr > 1 ? (uint32_t)(((1ull << 32) + upr - 1) / upr) : 0u;
   b.magic_upg = (uint32_t)(((1ull << 32) + upg - 1) / upg);
   const uint32_t want = (units + kUpBlock / 64 - 1) / (kUpBlock / 64);
   const uint32_t grid = want < num_cus ? want : num_cus;
-  if (rgb12) compose_up_write_v210_kernel<true><<<grid, kUpBlock, a.wr.bytes, s>>>(b);
+  if (tails && rgb12) compose_up_write_v210_kernel<true, true><<<grid, kUpBlock, a.wr.bytes, s>>>(b);
+  else if (tails) compose_up_write_v210_kernel<false, true><<<grid, kUpBlock, a.wr.bytes, s>>>(b);
+  else if (rgb12) compose_up_write_v210_kernel<true><<<grid, kUpBlock, a.wr.bytes, s>>>(b);
   else compose_up_write_v210_kernel<false><<<grid, kUpBlock, a.wr.bytes, s>>>(b);
   return hipGetLastError();
 }

@@ -249,3 +249,52 @@ def test_8k_from_four_uhd_layers_equals_the_pixel_per_lane_compositor():
         k.wait()
         torch.cuda.synchronize()
         assert torch.equal(got, want), "packed RGB" if rgb else "RGBA"
+
+
+@pytest.mark.parametrize("rgb", [False, True], ids=["rgba", "packed-rgb"])
+@pytest.mark.parametrize("ow", [134, 136, 90, 1280, 1276, 1290])
+def test_output_lines_with_tails(ow, rgb):
+    """Round 5: output widths that are not a multiple of 48 (1280 x 720: src/config.ts:43-54) - whole quads, the tail quad of 2 or 4
+    pixels with the reference's tail arithmetic (truncated table indices, round() and a truncating convert: v210.ts:166-193), the
+    slots its writer clears up to the pitch (:131-136), lines addressed by pitch; the destination starts out poisoned"""
+    oh = 14
+    sw, sh = ow // 2 - 3, 6
+    mk = (lambda w, h, s: opaque(w, h, s)) if rgb else (lambda w, h, s: frames.rgba_random(w, h, s, -0.05, 1.05).reshape(h, w, 4))
+    layers = [(mk(sw, sh, 40), m(ow, oh)), (mk(max(sw // 3, 2), 3, 41), m(ow, oh, scale_x=0.5, scale_y=0.5, offset_x=0.26, offset_y=-0.1))]
+    dst = np.full(frames.v210_pitch_bytes(ow) * oh // 4, 0x2AAAAAAA, np.uint32)
+    check(layers, ow, oh, "%d wide" % ow, rgb=rgb, dst=dst)
+    check(layers[:1], ow, oh, "%d wide, one layer" % ow, rgb=rgb, dst=dst)
+
+
+@pytest.mark.parametrize("interlace", [1, 3])
+def test_field_outputs_on_lines_with_tails(interlace):
+    ow, oh = 1280, 36
+    dst = np.full(frames.v210_pitch_bytes(ow) * oh // 4, 0x2AAAAAAA, np.uint32)
+    layers = [(opaque(320, 8, 50), m(ow, oh)), (opaque(100, 4, 51), m(ow, oh, scale_x=0.5, scale_y=0.5, offset_x=0.2))]
+    check(layers, ow, oh, "1280 wide, interlace %d" % interlace, interlace=interlace, rgb=True, dst=dst)
+
+
+def test_720p_sources_enlarged_at_full_size():
+    """1280 x 720 images enlarged 2x to 2560 x 1440 (lines that end in a tail quad of four pixels) and 3x to
+    3840 x 2160, against the oracle's transform -> combine -> write; and two fields' frames of the 2560-wide shape in one launch"""
+    import torch
+    import hip_harness as hh
+    sw, sh = 1280, 720
+    imgs = [opaque(sw, sh, 60), opaque(sw, sh, 61)]
+    for ow, oh in ((2560, 1440), (3840, 2160)):
+        layers = [(imgs[0], m(ow, oh)), (imgs[1], m(ow, oh, scale_x=0.75, scale_y=0.75, offset_x=0.1, offset_y=-0.1))]
+        check(layers, ow, oh, "1280x720 -> %dx%d" % (ow, oh), rgb=True)
+    ow, oh = 2560, 1440
+    k = hh.ctx()
+    wcm, wlut = hh.ColourParams.writer("2020")
+    mat = m(ow, oh)
+    dev = [[(hh.dev(np.ascontiguousarray(img[..., :3]).reshape(-1)), sw, sh, mat)] for img in imgs]
+    words = frames.v210_pitch_bytes(ow) * oh // 4
+    single = [torch.zeros(words, dtype=torch.int32, device="cuda") for _ in range(2)]
+    pair = [torch.zeros(words, dtype=torch.int32, device="cuda") for _ in range(2)]
+    for f in range(2):
+        k.compose_up_write_v210(dev[f], single[f], ow, oh, 0, wcm, wlut, rgb=True)
+    k.compose_up_write_v210_pair(dev[0], dev[1], pair[0], pair[1], ow, oh, 0, wcm, wlut, rgb=True)
+    k.wait()
+    for f in range(2):
+        assert torch.equal(single[f], pair[f]), "set %d: the pair launch differs from the single one" % f
