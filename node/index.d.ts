@@ -69,14 +69,32 @@ export interface PlatformInfo {
 
 export interface DeferredStats {
 	pending: number; recorded: number; launched: number; fused: number; fusedNodes: number; plain: number; dropped: number; fallbacks: number; lastFallback: string | null
+	/** frames that went to the device together with other channels' frames, several to a launch */
+	batched?: number
+}
+
+export interface BufferStats {
+	/** buffers somebody owns (parked ones are nobody's) */
+	liveBuffers: number; liveBytes: number
+	/** device bytes in the library's own pool */
+	pooledBytes: number
+	/** released frames / images kept whole for the next createBuffer of their shape */
+	parkedBuffers: number; parkedBytes: number
+	/** pinned host mirrors: attached to buffers, pooled, the most ever attached at once, hipHostMalloc calls so far */
+	pinnedInUse: number; pinnedPooled: number; pinnedPeak: number; pins: number
 }
 
 export class clContext {
 	/** `deferred` (default TRUE since round 4; `false`, or PHANERON_DEFERRED=0 in the environment, gives the launch-as-posted context):
 	 * runProgram records instead of launching; a packed frame's recorded operator chain reaches the device as one fused kernel when its
 	 * result is asked for (hostAccess 'readonly', downloadAsync, a route send, realise).  RunTimings of recorded jobs are zeros and
-	 * waitFinish(queue.process) returns at once - INTEGRATION.md 3a. */
-	constructor(params?: { platformIndex?: number; deviceIndex?: number; overlapping?: boolean; profile?: boolean; spinWaitMicros?: number; deferred?: boolean })
+	 * waitFinish(queue.process) returns at once - INTEGRATION.md 3a.
+	 * `profile` on a deferred context: a frame's terminal `write` is launched where it is posted and returns the fused launch's device time.
+	 * `earlyLaunch` (default false; PHANERON_EARLY_LAUNCH=1): launch a frame at the end of the tick that posted its terminal `write`.
+	 * `recycleBuffers` (default true; PHANERON_RECYCLE=0): released frames / images are parked for the next createBuffer of their shape,
+	 * up to `parkMb` MiB (default 4096) or the most that was ever in use at once. */
+	constructor(params?: { platformIndex?: number; deviceIndex?: number; overlapping?: boolean; profile?: boolean; spinWaitMicros?: number; deferred?: boolean;
+		earlyLaunch?: boolean; recycleBuffers?: boolean; parkMb?: number })
 	readonly queue: { load: number; process: number; unload: number }
 	initialise(): Promise<void>
 	getPlatformInfo(): PlatformInfo
@@ -100,7 +118,11 @@ export class clContext {
 	static routeUniqueId(): Buffer
 	/** library options: 'lds_lut' (0 | 1), 'stream_images' (0 cached | 1 streamed | 2 by size), 'stream_threshold_mb', 'host_pool_mb' (pinned mirrors kept for reuse) */
 	setOption(name: string, value: number): void
-	logBuffers(): { liveBuffers: number; liveBytes: number; pooledBytes: number }
+	/** library options also: 'fail_launches' (tests: every launch fails while set) */
+	logBuffers(): BufferStats
+	bufferStats(): BufferStats
+	/** hand the parked buffers back to the library */
+	trim(): void
 }
 
 /** which precompiled kernel createProgram(kernelSrc, {name}) selects - needs no context and no GPU */
