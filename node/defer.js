@@ -637,7 +637,8 @@ class Deferral {
 		for (const img of layerImages) {
 			const p = img._producer
 			const kind = p && p.state === 'pending' ? p.program.name : ''
-			if (kind === 'transition_dissolve' || kind === 'transition_wipe') {
+			// (`mixer` - mix.ts:30-45 - is transition_dissolve's arithmetic under another name: fma(in0, mix, in1 * (1 - mix)))
+			if (kind === 'transition_dissolve' || kind === 'mixer' || kind === 'transition_wipe') {
 				const wipe = kind === 'transition_wipe'
 				if (!p.params.input0 || !p.params.input1 || (wipe && !p.params.maskIn) || !sameSize(img)) return null
 				const l = placed(p.params.input0)

@@ -45,6 +45,7 @@ async function side(deferred) {
 	for (const n of [2, 3, 4]) s.combine[n] = await rig.combine(n, W, H)
 	s.transform = await rig.transform(W, H)
 	s.dissolve = await rig.two('transition_dissolve', W, H)
+	s.mixer = await rig.two('mixer', W, H)
 	s.wipe = await rig.two('transition_wipe', W, H)
 	s.yadif = await rig.yadif(W, H)
 	s.yadifHalf = await rig.yadif(W / 2, H / 2)
@@ -262,6 +263,27 @@ async function main() {
 		;[a, b, ua, ub, pa, pb, d, comb, out].forEach((x) => x.release())
 		return seen
 	}, { fused: 1 })
+
+	// `mixer` (mix.ts: the scalar mix of two images) is the dissolve's arithmetic under another name: its chain folds the same way
+	await scenario('a mixer between two placed sources, under a plain layer', async (s) => {
+		s.frame = 3
+		const srcs = []
+		for (let l = 0; l < 3; ++l) srcs.push(await s.source(v210Frame(full, 320 + l, l !== 1)))
+		const u = []
+		for (let l = 0; l < 3; ++l) { const im = await s.rig.image(W, H); s.rig.post(s.id('mix'), s.read([srcs[l]], im), () => srcs[l].release()); u.push(im) }
+		const p = []
+		for (let l = 0; l < 2; ++l) { const im = await s.rig.image(W, H); s.rig.post(s.id('mix'), s.transform(u[l], im, await s.transform.matrix(PIP[l])), () => u[l].release()); p.push(im) }
+		const mixed = await s.rig.image(W, H)
+		s.rig.post(s.id('mix'), s.mixer(p[0], p[1], 0.3125, mixed), () => p.forEach((b) => b.release()))
+		const comb = await s.rig.image(W, H)
+		s.rig.post(s.id('mix'), s.combine[2]([mixed, u[2]], comb), () => { mixed.release(); u[2].release() })
+		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+		s.rig.post(s.id('mix'), s.write(comb, [out], 0), () => comb.release())
+		await s.flush(s.id('mix'))
+		const seen = [await s.consume(out)]
+		out.release()
+		return seen
+	}, { fused: 1, plain: 0, launched: 1 })
 
 	// a finished image (a routed frame, real alpha) as a layer over a plain read and under a placed one
 	await scenario('a finished image as a layer', async (s) => {
