@@ -233,7 +233,9 @@ int ph_check_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_ar
  * args[j], n_args[j]) for j = 0 .. n_jobs - 1 in that order, PROVIDED no job reads what another job of the call writes.  Every job is
  * checked before anything is launched (a bad job refuses the whole call).  Channel frames among the jobs - chan_compose_v210_<n>
  * programs of one geometry that name the SAME Loader / Saver buffers and make v210 frames - go to the device together
- * (ph_chan_compose_batch: the reference's channels share one context and one queue, src/index.ts:45-71,156-160). */
+ * (ph_chan_compose_batch: the reference's channels share one context and one queue, src/index.ts:45-71,156-160); likewise consecutive
+ * fused_v210_combine_<n> programs of one geometry, layer count and recipe (ph_fused_v210_combine_batch, up to eight per launch; a frame
+ * that touches an earlier one's output starts the next launch). */
 int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_arg *const *args, const int *n_args, int queue);
 
 /* ---- typed entry points: the same kernels on raw device pointers, launched on `queue`.

@@ -273,8 +273,9 @@ class Deferral {
 		if (!this._fused(node)) this._plain(node)
 	}
 	// Several terminal writes at once.  `must` (or null) has to be done when this returns - fused, or as recorded; the others are
-	// launched only if their chain folds (what does not fold stays recorded until somebody asks).  Frames the channel kernel makes
-	// from sources of one recipe, at one size, go to the device as ONE launch (runPrograms -> ph_chan_compose_batch).
+	// launched only if their chain folds (what does not fold stays recorded until somebody asks).  Frames the channel kernel (or the
+	// headline kernel: plain reads) makes from sources of one recipe, at one size, go to the device as ONE launch (runPrograms ->
+	// ph_chan_compose_batch / ph_fused_v210_combine_batch).
 	_runMany(nodes, must) {
 		this.running = true
 		const plans = []
@@ -311,7 +312,7 @@ class Deferral {
 		for (const u of plan.used) if (u.state !== 'pending') return false
 		return true
 	}
-	// several channel frames in one launch: every plan's one candidate with the FIRST plan's Loader / Saver buffers (equal contents)
+	// several channel frames in one launch: every plan's first candidate with the FIRST plan's Loader / Saver buffers (equal contents)
 	_batch(plans) {
 		const first = plans[0].candidates[0][1]
 		const progs = []
@@ -713,9 +714,10 @@ class Deferral {
 			candidates.push([`chan_compose_v210_${n}`, params])
 		}
 		if (!candidates.length) return null
-		// one launch of the batch kernel can take it: the channel kernel is the only candidate, v210 / image sources, a v210 frame
-		const batchable = candidates.length === 1 && candidates[0][0].startsWith('chan_compose_v210_') && !outFmt &&
-			!layers.some((l) => l.planar || (l.transition && (l.transition.incoming.planar || (l.transition.mask && l.transition.mask.planar))))
+		// one launch can take it together with other channels' frames: plain reads of the output's size (the headline kernel's batch form),
+		// or the channel kernel as the only candidate, v210 / image sources, a v210 frame (the batch kernel)
+		const batchable = candidates[0][0].startsWith('fused_v210_combine_') || (candidates.length === 1 && candidates[0][0].startsWith('chan_compose_v210_') && !outFmt &&
+			!layers.some((l) => l.planar || (l.transition && (l.transition.incoming.planar || (l.transition.mask && l.transition.mask.planar)))))
 		return { node, candidates, used, n, width, height, batchable, loader, saver }
 	}
 	// launch the first candidate the library takes; false = none (nothing was launched)

@@ -90,6 +90,7 @@ async function main() {
 async function channels(frames, w, h) {
 	const C = parseInt(process.env.PH_NODE_BENCH_CHANNELS || '4')
 	const n = 4
+	const plain = process.env.PH_NODE_BENCH_PLAIN === '1' // layers that are plain reads (no Mixer in the chain): the headline shape per channel
 	const rig = await Rig.open({ deviceIndex: 0, spinWaitMicros: 200, deferred: true })
 	const read = await rig.unpack('v210', w, h, '709', '709')
 	const write = await rig.pack('v210', w, h, '709', false)
@@ -125,6 +126,7 @@ async function channels(frames, w, h) {
 			for (let l = 0; l < n; ++l) {
 				const im = await rig.image(w, h)
 				rig.post(id, read(src[c][l], im))
+				if (plain) { placed.push(im); continue }
 				const pl = await rig.image(w, h)
 				rig.post(id, transform(im, pl, mats[l]), () => im.release())
 				fresh.push(im)
@@ -144,7 +146,7 @@ async function channels(frames, w, h) {
 	for (let f = 0; f < frames; ++f) await one(10 + f)
 	await rig.ctx.drain()
 	const sec = Number(process.hrtime.bigint() - t0) / 1e9
-	console.log(JSON.stringify({ bench: 'node', mode: 'channels', channels: C, early_launch: rig.ctx.earlyLaunch, width: w, height: h, layers: n, frames, channel_frames_per_sec: +(C * frames / sec).toFixed(1),
+	console.log(JSON.stringify({ bench: 'node', mode: 'channels', shape: plain ? 'plain reads' : 'config 2', channels: C, early_launch: rig.ctx.earlyLaunch, width: w, height: h, layers: n, frames, channel_frames_per_sec: +(C * frames / sec).toFixed(1),
 		us_per_frame: +(1e6 * sec / frames / C).toFixed(1), us_per_tick: +(1e6 * sec / frames).toFixed(1), deferred: rig.ctx.deferredStats(),
 		buffers: rig.ctx.bufferStats() }))
 	;[...src.flat(2), ...ring.flat(2)].forEach((b) => b.release())

@@ -153,7 +153,7 @@ async function main() {
 		}
 		for (const out of outs) { seen.push(await s.consume(out)); out.release() }
 		return seen
-	}, { fused: 3, plain: 0, launched: 3 })
+	}, { fused: 3, plain: 0, launched: 1, batched: 3 }) // asked for together, the three frames go as one call (ph_fused_v210_combine_batch)
 
 	// BASELINE config 2's shape: placed layers, a wipe against a placed second source with an image mask
 	await scenario('PiP transforms + wipe on the top layer -> combine_4 -> write', async (s) => {
@@ -236,6 +236,35 @@ async function main() {
 		for (const out of outs) { seen.push(await s.consume(out)); out.release() }
 		return seen
 	}, { fused: 6, plain: 0, launched: 1, batched: 6 })
+
+	// channels whose layers are plain reads of the output's size (the headline shape): their frames of one tick are ONE call too -
+	// runPrograms -> ph_fused_v210_combine_batch for the four with three layers each, the two-layer channel in its own launch inside the same call
+	await scenario('five channels of plain reads posted in one tick', async (s) => {
+		s.frame = 10
+		const outs = []
+		const flushes = []
+		for (let c = 0; c < 5; ++c) {
+			const n = c === 4 ? 2 : 3
+			const id = s.id(`plain${c}`)
+			const unpacked = []
+			for (let l = 0; l < n; ++l) {
+				const src = await s.source(v210Frame(full, 1200 + 10 * c + l, l !== 2))
+				const im = await s.rig.image(W, H)
+				s.rig.post(id, s.read([src], im), () => src.release())
+				unpacked.push(im)
+			}
+			const frame = await s.rig.image(W, H)
+			s.rig.post(id, s.combine[n](unpacked, frame), () => unpacked.forEach((b) => b.release()))
+			const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+			s.rig.post(id, s.write(frame, [out], 0), () => frame.release())
+			outs.push(out)
+			flushes.push(id)
+		}
+		await Promise.all(flushes.map((id) => s.flush(id)))
+		const seen = []
+		for (const out of outs) { seen.push(await s.consume(out)); out.release() }
+		return seen
+	}, { fused: 5, plain: 0, launched: 1, batched: 5 })
 
 	// a dissolve against a half-size, rotated incoming source, over a plain read
 	await scenario('dissolve layer over a plain read', async (s) => {

@@ -1241,6 +1241,43 @@ static int chan_call_parse(ph_ctx *ctx, ph_program *prog, const ph_arg *args, in
 
 // check_only: everything up to the launch - argument names, kinds, buffer sizes, geometry - and nothing on the device
 // (ph_check_program: a recording binding reports a bad job where it is posted, not where it is run)
+// fused_v210_combine_<n> (dispatch K_FUSED_V210; ph_run_programs puts several such calls of one shape into one launch):
+// l<i>In: v210 sources; colMatrix / gammaLut / gamutMatrix: the Loader's; outColMatrix / outGammaLut: the Saver's
+struct FusedCall {
+  const void *layers[ph::kMaxLayers];
+  int n;
+  void *out;
+  uint32_t width, height;
+  size_t frame_bytes;
+  ph_buf *rd_cm, *rd_lut, *rd_gm, *wr_cm, *wr_lut;
+};
+static int fused_call_parse(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, bool check_only, FusedCall *call) {
+  int rc;
+#define TRY(x) \
+  if ((rc = (x)) != PH_OK) return rc
+  call->width = prog->global[0], call->height = prog->global[1], call->n = prog->n_layers;
+  if (!call->width || !call->height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
+  call->frame_bytes = (size_t)ph_v210_pitch_bytes(call->width) * call->height;
+  ph_buf *a = nullptr, *o = nullptr;
+  for (int i = 0; i < prog->n_layers; ++i) {
+    char nm[16];
+    snprintf(nm, sizeof nm, "l%dIn", i);
+    TRY(need_buf(args, n, nm, call->frame_bytes, &a));
+    call->layers[i] = a->dptr;
+  }
+  TRY(need_buf(args, n, "output", call->frame_bytes, &o));
+  call->out = o->dptr;
+  TRY(need_buf(args, n, "colMatrix", 48, &call->rd_cm));
+  TRY(need_buf(args, n, "gammaLut", 65536 * 4, &call->rd_lut));
+  TRY(need_buf(args, n, "gamutMatrix", 36, &call->rd_gm));
+  TRY(need_buf(args, n, "outColMatrix", 48, &call->wr_cm));
+  TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &call->wr_lut));
+  if (!check_only) refresh_buf_lut(ctx, call->rd_lut);
+  if (!check_only) refresh_buf_lut(ctx, call->wr_lut);
+  return PH_OK;
+#undef TRY
+}
+
 static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue, bool check_only = false) {
   ph_buf *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr, *o = nullptr;
   double num = 0;
@@ -1559,28 +1596,10 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       return check_only ? PH_OK : ph_combine(ctx, queue, prog->n_layers, layers, w, h, o->dptr);
     }
     case K_FUSED_V210: {
-      // l<i>In: v210 sources; colMatrix / gammaLut / gamutMatrix: the Loader's; outColMatrix / outGammaLut: the Saver's
-      const uint32_t width = prog->global[0], height = prog->global[1];
-      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
-      const size_t vb = (size_t)ph_v210_pitch_bytes(width) * height;
-      const void *layers[ph::kMaxLayers];
-      ph_buf *wcm = nullptr, *wl = nullptr;
-      for (int i = 0; i < prog->n_layers; ++i) {
-        char nm[16];
-        snprintf(nm, sizeof nm, "l%dIn", i);
-        TRY(need_buf(args, n, nm, vb, &a));
-        layers[i] = a->dptr;
-      }
-      TRY(need_buf(args, n, "output", vb, &o));
-      TRY(need_buf(args, n, "colMatrix", 48, &b));
-      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
-      TRY(need_buf(args, n, "gamutMatrix", 36, &d));
-      TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
-      TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
-      if (!check_only) refresh_buf_lut(ctx, c);
-      if (!check_only) refresh_buf_lut(ctx, wl);
-      return check_only ? PH_OK : ph_fused_v210_combine(ctx, queue, prog->n_layers, layers, o->dptr, width, height, b->dptr, c->dptr, d->dptr,
-                                   wcm->dptr, wl->dptr);
+      FusedCall f;
+      TRY(fused_call_parse(ctx, prog, args, n, check_only, &f));
+      return check_only ? PH_OK : ph_fused_v210_combine(ctx, queue, f.n, f.layers, f.out, f.width, f.height, f.rd_cm->dptr, f.rd_lut->dptr, f.rd_gm->dptr,
+                                   f.wr_cm->dptr, f.wr_lut->dptr);
     }
     case K_DISSOLVE:
     case K_MIXER:
@@ -1659,27 +1678,61 @@ int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_
   if (rc) return rc;
   if (ctx->fail_launches.load()) return fail(PH_E_HIP, "ph_run_programs: launch failed: injected (context option fail_launches)");
   std::vector<ChanCall> calls((size_t)n_jobs);
-  std::vector<char> is_chan((size_t)n_jobs, 0);
+  std::vector<FusedCall> fused((size_t)n_jobs);
+  std::vector<char> kind((size_t)n_jobs, 0);  // 1: a v210 frame from the channel kernel, 2: fused_v210_combine, 0: whatever else, launched as it is
   for (int j = 0; j < n_jobs; ++j) {  // every job is checked before anything is launched: a bad one refuses the call as a whole
     if (!progs[j] || (n_args[j] > 0 && !args[j])) return fail(PH_E_INVALID, "ph_run_programs: job %d: NULL argument", j);
     if ((rc = flush_dirty_args(ctx, args[j], n_args[j], queue))) return rc;
     if (progs[j]->id == K_CHAN_COMPOSE) {
       if ((rc = chan_call_parse(ctx, progs[j], args[j], n_args[j], false, &calls[(size_t)j]))) return rc;
-      is_chan[(size_t)j] = calls[(size_t)j].out_format == PH_FMT_V210;
+      kind[(size_t)j] = calls[(size_t)j].out_format == PH_FMT_V210;
+    } else if (progs[j]->id == K_FUSED_V210) {
+      if ((rc = fused_call_parse(ctx, progs[j], args[j], n_args[j], false, &fused[(size_t)j]))) return rc;
+      kind[(size_t)j] = 2;
     } else if ((rc = dispatch(ctx, progs[j], args[j], n_args[j], queue, true))) {
       return rc;
     }
   }
   for (int j = 0; j < n_jobs;) {
-    if (!is_chan[(size_t)j]) {
+    if (!kind[(size_t)j]) {
       if ((rc = dispatch(ctx, progs[j], args[j], n_args[j], queue))) return rc;
       ++j;
       continue;
     }
+    int k = j;
+    if (kind[(size_t)j] == 2) {
+      // frames of one size, layer count and recipe: one launch of the headline kernel (ph_fused_v210_combine_batch).  A frame that reads
+      // what an earlier frame of the run writes (or writes what one reads or writes) starts the next launch: call order is kept.
+      const FusedCall &f0 = fused[(size_t)j];
+      std::vector<const void *> layers;
+      std::vector<void *> outs;
+      auto overlap = [&](const void *p, const void *q) {
+        const char *a0 = (const char *)p, *b0 = (const char *)q;
+        return a0 < b0 + f0.frame_bytes && b0 < a0 + f0.frame_bytes;
+      };
+      for (; k < n_jobs && kind[(size_t)k] == 2 && k - j < ph::kMaxBatch; ++k) {
+        const FusedCall &f = fused[(size_t)k];
+        if (f.n != f0.n || f.width != f0.width || f.height != f0.height || f.rd_cm != f0.rd_cm || f.rd_lut != f0.rd_lut || f.rd_gm != f0.rd_gm ||
+            f.wr_cm != f0.wr_cm || f.wr_lut != f0.wr_lut)
+          break;
+        bool clash = false;
+        for (size_t e = 0; e < outs.size() && !clash; ++e) {
+          clash = overlap(f.out, outs[e]);
+          for (int l = 0; l < f.n && !clash; ++l) clash = overlap(f.layers[l], outs[e]) || overlap(f.out, layers[e * (size_t)f0.n + (size_t)l]);
+        }
+        if (clash) break;
+        layers.insert(layers.end(), f.layers, f.layers + f.n);
+        outs.push_back(f.out);
+      }
+      rc = ph_fused_v210_combine_batch(ctx, queue, (int)outs.size(), f0.n, layers.data(), outs.data(), f0.width, f0.height, f0.rd_cm->dptr, f0.rd_lut->dptr,
+                                       f0.rd_gm->dptr, f0.wr_cm->dptr, f0.wr_lut->dptr);
+      if (rc) return rc;
+      j = k;
+      continue;
+    }
     const ChanCall &c0 = calls[(size_t)j];
     std::vector<ph_chan_job> batch;
-    int k = j;
-    for (; k < n_jobs && is_chan[(size_t)k]; ++k) {
+    for (; k < n_jobs && kind[(size_t)k] == 1; ++k) {
       const ChanCall &c = calls[(size_t)k];
       if (c.width != c0.width || c.height != c0.height || c.rd_cm != c0.rd_cm || c.rd_lut != c0.rd_lut || c.rd_gm != c0.rd_gm || c.wr_cm != c0.wr_cm ||
           c.wr_lut != c0.wr_lut)

@@ -365,6 +365,43 @@ def test_channel_program_by_name_with_a_dissolve(ctx):
     col.release()
 
 
+def test_run_programs_puts_plain_read_channels_into_one_launch(ctx):
+    """ph_run_programs with fused_v210_combine_<n> jobs (what node/defer.js makes of channels whose layers are plain reads): four frames of
+    three layers, one of two layers, and a frame that READS the first frame's output (it has to wait for it: call order) - every output
+    equals the oracle's read -> combine -> write of its own sources"""
+    w, h = 384, 54
+    col = Colour(ctx, "709", "709")
+    src = [frames.v210_random(w, h, frames.layer_seed(120, i)) for i in range(7)]
+    dev = [upload(ctx, a, svm="coarse") for a in src]
+    nbytes = capi.v210_pitch_bytes(w) * h
+    outs = [ctx.create_buffer(nbytes, "writeonly", "coarse") for _ in range(6)]
+    ctx.wait(capi.QUEUE_LOAD)
+    recipe = {"colMatrix": col.rd_cm, "gammaLut": col.rd_lut, "gamutMatrix": col.rd_gm, "outColMatrix": col.wr_cm, "outGammaLut": col.wr_lut}
+    p3 = ctx.create_program("phaneron:fused", "fused_v210_combine_3", [w, h])
+    p2 = ctx.create_program("phaneron:fused", "fused_v210_combine_2", [w, h])
+    picks = [(0, 1, 2), (1, 2, 3), (3, 4, 5), (6, 0, 4), (5, 6), None]
+    jobs = []
+    for j, pick in enumerate(picks):
+        if pick is None:  # layers: frame 0's OUTPUT under two sources
+            params = dict(recipe, output=outs[j], l0In=outs[0], l1In=dev[1], l2In=dev[2])
+        else:
+            params = dict(recipe, output=outs[j], **{"l%dIn" % l: dev[i] for l, i in enumerate(pick)})
+        jobs.append((p3 if len(params) - 6 == 3 else p2, params))
+    ctx.run_programs(jobs)
+    ctx.wait()
+    rd = [orc.v210_read(a, w, h, *col.oracle_rd) for a in src]
+    want = []
+    for pick in picks:
+        layers = [rd[i] for i in pick] if pick is not None else [orc.v210_read(want[0].reshape(-1), w, h, *col.oracle_rd), rd[1], rd[2]]
+        want.append(np.asarray(orc.v210_write(orc.combine(layers), w, h, 0, *col.oracle_wr)).reshape(-1))
+    for j, o in enumerate(outs):
+        o.host_access("readonly", capi.QUEUE_UNLOAD)
+        assert np.array_equal(o.host(np.uint32), want[j].view(np.uint32) if want[j].dtype != np.uint32 else want[j]), "frame %d" % j
+    for x in dev + outs:
+        x.release()
+    col.release()
+
+
 def test_host_mirror_pool_covers_the_working_set():
     """the pool of pinned mirrors keeps what was in use at once even when that is more than `host_pool_mb` - a steady stream of
     create / map / release rounds pins nothing after the first round (36 images a tick was 40 ms a tick under a fixed 1 GiB budget)"""

@@ -625,7 +625,8 @@ def test_recording_context_gives_the_same_frames_with_one_launch_per_frame():
         assert res["problems"] == [], res["problems"][:3]
         assert len(res["scenarios"]) >= 15 and all(s["frames"] >= 1 for s in res["scenarios"])
         first = res["scenarios"][0]["deferred"]
-        assert first["recorded"] == 18 and first["launched"] == 3 and first["fused"] == 3, first
+        # (three frames recorded, asked for together: one call, ph_fused_v210_combine_batch)
+        assert first["recorded"] == 18 and first["launched"] == 1 and first["fused"] == 3 and first["batched"] == 3, first
 
 
 # ---------------------------------------------------------------------------------------------------------------------
