@@ -56,7 +56,8 @@ class Channel {
 		const { rig, width: w, height: h } = this
 		this.stages = { transform: await rig.transform(w, h), dissolve: await rig.two('transition_dissolve', w, h), wipe: await rig.two('transition_wipe', w, h), combine: new Map() }
 		this.black = await rig.image(w, h, `${this.name} black`)
-		this.black.fill(0) // blackSilence.ts:129-135: a zero-filled RGBA frame, uploaded once
+		await this.black.hostAccess('writeonly', rig.ctx.queue.load) // blackSilence.ts:129-135: a zero-filled RGBA frame, mapped, filled, uploaded once
+		this.black.fill(0)
 		await this.black.hostAccess('none', rig.ctx.queue.load)
 		await rig.sync(rig.ctx.queue.load)
 	}

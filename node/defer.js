@@ -314,6 +314,9 @@ class Deferral {
 	}
 	// several channel frames in one launch: every plan's first candidate with the FIRST plan's Loader / Saver buffers (equal contents)
 	_batch(plans) {
+		// (frames of a group do not depend on each other - what a frame needs of another was made real when it was planned - so like
+		// programs may stand together: the library puts CONSECUTIVE jobs of one kind and shape into a launch)
+		plans = plans.map((p, i) => [p, i]).sort((a, b) => (a[0].candidates[0][0] < b[0].candidates[0][0] ? -1 : a[0].candidates[0][0] > b[0].candidates[0][0] ? 1 : a[1] - b[1])).map((v) => v[0])
 		const first = plans[0].candidates[0][1]
 		const progs = []
 		const names = []

@@ -30,6 +30,7 @@ async function main() {
 		const src = []
 		for (let l = 0; l < n; ++l) {
 			const p = await rig.planes('v210', w, h)
+			await p[0].hostAccess('writeonly', rig.ctx.queue.load) // map, fill, unmap ('none' uploads what was mapped for writing)
 			for (let i = 0; i < p[0].length; i += 4) p[0].writeUInt32LE(((0x200 + (i * 2654435761 >>> 22)) & 0x3ff) * 0x00100401 & 0x3fffffff, i)
 			await p[0].hostAccess('none', rig.ctx.queue.load)
 			src.push(p)
@@ -105,6 +106,7 @@ async function channels(frames, w, h) {
 		const layers = []
 		for (let l = 0; l < n; ++l) {
 			const p = await rig.planes('v210', w, h)
+			await p[0].hostAccess('writeonly', rig.ctx.queue.load)
 			for (let i = 0; i < p[0].length; i += 4) p[0].writeUInt32LE(((0x200 + ((i + 977 * c + 13 * l) * 2654435761 >>> 22)) & 0x3ff) * 0x00100401 & 0x3fffffff, i)
 			await p[0].hostAccess('none', rig.ctx.queue.load)
 			layers.push(p)

@@ -3,10 +3,12 @@
 //   soak     FRAMES frames of the valves' posting pattern (a fresh destination per job, released in its callback, three output frames
 //            in flight), the format changing every FRAMES / 4 frames (1080 -> 720 -> 2160 -> 1080): the library's buffer counters and
 //            pinned bytes must come back to where they were, nothing pinned in steady state, no fused launch refused;
+//   channels four channels posting a frame per tick (placed layers / plain reads alternately) for FRAMES / 5 ticks, the format changing half
+//            way: one runPrograms call per tick, every frame through a batch launch, the same counters flat;
 //   fault    launches made to fail (context option fail_launches) while frame K's consumer maps its frame: that hostAccess rejects,
 //            every job callback has fired, the frames after it are the launch-as-posted context's bytes, nothing leaks;
 //   timings  `profile: true`: the terminal `write` of a frame returns the fused launch's device time, the jobs folded into it zeros.
-// usage: node soak_run.js [frames=100000]; prints one JSON object { soak, fault, timings, problems }
+// usage: node soak_run.js [frames=100000] (PH_SOAK_ONLY=soak,channels,fault,timings picks phases); prints one JSON object { soak, channels, fault, timings, problems }
 const { Rig } = require('../device.js')
 
 const problems = []
@@ -22,6 +24,7 @@ async function channel(rig, w, h, n) {
 	const c = { w, h, n, read: await rig.unpack('v210', w, h, '709', '709'), write: await rig.pack('v210', w, h, '709', false), combine: await rig.combine(n, w, h), src: [], ring: [] }
 	for (let l = 0; l < n; ++l) {
 		const p = await rig.planes('v210', w, h)
+		await p[0].hostAccess('writeonly', rig.ctx.queue.load) // map, fill, unmap: 'none' uploads what was mapped for writing (io.ts:89-94)
 		fill(p[0], 7 * w + l)
 		await p[0].hostAccess('none', rig.ctx.queue.load)
 		c.src.push(p)
@@ -89,6 +92,68 @@ async function soak() {
 	return { frames: formats.length * per, seconds: +sec.toFixed(2), us_per_frame: +(1e6 * sec / (formats.length * per)).toFixed(1), formats: marks, deferred: st }
 }
 
+// the reference's deployment over a long stream: C channels in one context (src/index.ts:45-71), every channel posting a frame per tick -
+// two placed layers each (the channel kernel) or, every other channel, two plain reads (the headline kernel) - so that a tick is ONE
+// runPrograms call; the format changes half way (1080 -> 720); counters flat, every frame through a batch, nothing refused
+async function soakChannels(ticks) {
+	const C = 4
+	const rig = await Rig.open({ deviceIndex: 0, spinWaitMicros: 200 })
+	const marks = []
+	const per = Math.max(8, Math.floor(ticks / 2))
+	const t0 = process.hrtime.bigint()
+	for (const [w, h] of [[1920, 1080], [1280, 720]]) {
+		const chans = []
+		for (let c = 0; c < C; ++c) chans.push(await channel(rig, w, h, 2))
+		const transform = await rig.transform(w, h)
+		const mats = [await transform.matrix({}), await transform.matrix({ scaleX: 0.5, scaleY: 0.5, offsetX: 0.25, offsetY: -0.25 })]
+		const done = []
+		let warm = null
+		for (let f = 0; f < per; ++f) {
+			const slot = f % 3
+			if (done[slot] && !done[slot].done()) await done[slot].wait()
+			const ids = []
+			for (let c = 0; c < C; ++c) {
+				const ch = chans[c]
+				const id = { source: `chan${c}`, timestamp: f }
+				const layers = []
+				for (let l = 0; l < 2; ++l) {
+					const im = await rig.image(w, h)
+					rig.post(id, ch.read(ch.src[l], im))
+					if (c % 2) { layers.push(im); continue }
+					const pl = await rig.image(w, h)
+					rig.post(id, transform(im, pl, mats[l]), () => im.release())
+					layers.push(pl)
+				}
+				const cm = await rig.image(w, h)
+				rig.post(id, ch.combine(layers, cm), () => layers.forEach((b) => b.release()))
+				rig.post(id, ch.write(cm, ch.ring[slot], 0), () => cm.release())
+				ids.push(id)
+			}
+			await Promise.all(ids.map((id) => rig.board.flush(id)))
+			for (const ch of chans) rig.ctx.realise(ch.ring[slot][0])
+			done[slot] = rig.ctx.recordEvent(rig.ctx.queue.process)
+			if (f === Math.min(64, per - 1)) warm = rig.ctx.bufferStats()
+		}
+		await rig.ctx.drain()
+		const end = rig.ctx.bufferStats()
+		if (end.pins !== warm.pins) problems.push({ channels: `${w}x${h}`, what: `${end.pins - warm.pins} blocks pinned after the format's first ticks` })
+		if (end.liveBuffers !== warm.liveBuffers) problems.push({ channels: `${w}x${h}`, what: `live buffers ${warm.liveBuffers} -> ${end.liveBuffers} over ${per} ticks` })
+		if (end.pinnedInUse + end.pinnedPooled !== warm.pinnedInUse + warm.pinnedPooled) problems.push({ channels: `${w}x${h}`, what: `pinned bytes ${warm.pinnedInUse + warm.pinnedPooled} -> ${end.pinnedInUse + end.pinnedPooled}` })
+		chans.forEach((ch) => ch.close())
+		marks.push({ format: `${w}x${h}`, ticks: per, live: end.liveBuffers, parked: end.parkedBuffers, pinned_mb: Math.round((end.pinnedInUse + end.pinnedPooled) / 1048576), pins: end.pins })
+	}
+	const sec = Number(process.hrtime.bigint() - t0) / 1e9
+	const st = rig.ctx.deferredStats()
+	rig.close()
+	rig.ctx.trim()
+	const left = rig.ctx.bufferStats()
+	if (st.fallbacks) problems.push({ channels: 'all', what: `${st.fallbacks} fused launches refused: ${st.lastFallback}` })
+	if (st.pending) problems.push({ channels: 'all', what: `${st.pending} jobs still recorded at the end` })
+	if (st.fused !== 2 * per * C || st.batched !== st.fused || st.launched !== 2 * per) problems.push({ channels: 'all', what: `fused ${st.fused}, batched ${st.batched}, launched ${st.launched} for ${2 * per} ticks of ${C} channels` })
+	if (left.liveBuffers) problems.push({ channels: 'all', what: `${left.liveBuffers} buffers alive after everything was released` })
+	return { channels: C, ticks: 2 * per, seconds: +sec.toFixed(2), us_per_channel_frame: +(1e6 * sec / (2 * per * C)).toFixed(1), formats: marks, deferred: st }
+}
+
 async function fault() {
 	const W = 384
 	const H = 108
@@ -103,9 +168,10 @@ async function fault() {
 		const fired = { n: 0 }
 		let rejected = null
 		for (let f = 0; f < N; ++f) {
-			// every frame another picture: the first source is rewritten (its pending readers - none by now - would run first)
-			fill(c.src[0][0], 1000 + f)
-			await c.src[0][0].hostAccess('none', rig.ctx.queue.load)
+			// every frame another picture: the top source is rewritten (its pending readers - none by now - would run first)
+			await c.src[1][0].hostAccess('writeonly', rig.ctx.queue.load)
+			fill(c.src[1][0], 1000 + f)
+			await c.src[1][0].hostAccess('none', rig.ctx.queue.load)
 			await rig.sync(rig.ctx.queue.load)
 			const broken = deferred && f === K
 			let o = null
@@ -136,9 +202,15 @@ async function fault() {
 		if (deferred && st.pending) problems.push({ fault: true, what: `${st.pending} jobs still recorded at the end` })
 		if (deferred && !/injected/.test(rejected || '')) problems.push({ fault: true, what: `frame ${K}'s consumer was not told: ${rejected}` })
 	}
+	if (seen[false][0] && seen[false][1] && Buffer.compare(seen[false][0], seen[false][1]) === 0) problems.push({ fault: false, what: 'frames 0 and 1 are the same picture: the rewritten source did not reach the device' })
 	for (let f = 0; f < N; ++f) {
 		if (f === K) { if (seen[true][f] !== null) problems.push({ fault: true, what: `frame ${K} was delivered although its launches failed` }); continue }
-		if (!seen[true][f] || Buffer.compare(seen[true][f], seen[false][f]) !== 0) problems.push({ fault: true, what: `frame ${f} differs from the launch-as-posted context's` })
+		if (!seen[true][f] || Buffer.compare(seen[true][f], seen[false][f]) !== 0) {
+			let at = 0
+			let count = 0
+			if (seen[true][f]) for (let i = 0; i < seen[true][f].length; ++i) if (seen[true][f][i] !== seen[false][f][i]) { if (!count) at = i; ++count }
+			problems.push({ fault: true, what: `frame ${f} differs from the launch-as-posted context's`, first_byte: at, bytes: count })
+		}
 	}
 	return out
 }
@@ -167,7 +239,10 @@ async function timings() {
 }
 
 async function main() {
-	const result = { soak: await soak(), fault: await fault(), timings: await timings(), problems }
+	const only = process.env.PH_SOAK_ONLY ? process.env.PH_SOAK_ONLY.split(',') : null
+	const want = (what) => !only || only.includes(what)
+	const result = { soak: want('soak') ? await soak() : null, channels: want('channels') ? await soakChannels(Math.max(16, Math.floor(FRAMES / 5))) : null, fault: want('fault') ? await fault() : null,
+		timings: want('timings') ? await timings() : null, problems }
 	process.stdout.write(JSON.stringify(result) + '\n')
 }
 main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })

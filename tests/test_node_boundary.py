@@ -721,12 +721,14 @@ def test_recording_context_soak_fault_and_timings():
     pinned-memory counters flat, nothing pinned in steady state, no fused launch refused; launches made to fail while one frame's
     consumer maps it (context option fail_launches): that consumer is told, every job callback fires, the frames after it are the
     launch-as-posted context's bytes, nothing leaks; and with `profile` the terminal write of a frame returns the fused launch's
-    device time as its RunTimings (what src/clJobQueue.ts:159-215 prints), the jobs folded into it zeros.  """
+    device time as its RunTimings (what src/clJobQueue.ts:159-215 prints), the jobs folded into it zeros; four
+    channels posting a frame per tick for 20 000 ticks with a format change: one call per tick, every frame through a batch launch, counters flat."""
     _build_addon()
     r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "soak_run.js"), "100000"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["problems"] == [], res["problems"][:4]
     assert res["soak"]["frames"] == 100000 and res["soak"]["deferred"]["fallbacks"] == 0
+    assert res["channels"]["ticks"] == 20000 and res["channels"]["deferred"]["batched"] == 80000 and res["channels"]["deferred"]["launched"] == 20000
     assert "injected" in res["fault"]["deferred"]["rejected"] and res["fault"]["plain"]["rejected"] is None
     assert all(t["write"]["kernelExec"] > 0 for t in res["timings"])
