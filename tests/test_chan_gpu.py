@@ -241,6 +241,41 @@ def test_refusals():
         k.chan_compose_v210([ok], out, w, h, 0, *rd_d, wr_d[0], plain)
 
 
+def random_layers(r, ow, oh, n_layers):
+    """n_layers random layers for an ow x oh channel: source sizes and formats, placements, transitions (see test_random_channel_programs)"""
+    def source(must_fill=False):
+        rgba = r.random() < 0.25
+        one_to_one = r.random() < 0.3
+        if one_to_one:
+            w, h = ow, oh
+        else:
+            w, h = int(r.choice([48, 96, 192, 288, 384])), int(r.integers(2, 40))
+        seed = int(r.integers(1, 1 << 30))
+        data = frames.rgba_random(w, h, seed, -0.05, 1.05) if rgba else frames.v210_random(w, h, seed, legal=bool(r.random() < 0.7))
+        mat = None
+        if not one_to_one or r.random() < 0.5:
+            kw = dict(scale_x=float(r.choice([0.3, 0.5, 1.0, 1.0, 1.7, 2.0])), scale_y=float(r.choice([0.3, 0.5, 1.0, 1.0, 1.7, 2.0])),
+                      offset_x=float(r.uniform(-0.6, 0.6)), offset_y=float(r.uniform(-0.6, 0.6)))
+            if r.random() < 0.3:
+                kw["rotate"] = float(r.uniform(-0.5, 0.5))
+            if r.random() < 0.2:
+                kw["flip_h"] = True
+            if must_fill:
+                kw = dict()
+            mat = m(ow, oh, **kw)
+        return Src(data, w, h, mat, "rgba" if rgba else "v210")
+    layers = []
+    for l in range(n_layers):
+        L = dict(src=source(must_fill=(l == 0 and r.random() < 0.5)))
+        t = r.random()
+        if t < 0.2:
+            L.update(transition="dissolve", mix=float(r.choice([0.0, 0.25, 1.0 / 3.0, 1.0])), incoming=source())
+        elif t < 0.4:
+            L.update(transition="wipe", incoming=source(), mask=source())
+        layers.append(L)
+    return layers
+
+
 def test_random_channel_programs():
     """seeded random channels: output sizes around the kernel's units (192-column chunks, row pairs, fewer chunks than waves),
     1-6 layers of random source sizes and formats, random placements (scales either side of 1, rotations, flips, offsets that
@@ -250,37 +285,7 @@ def test_random_channel_programs():
     for case in range(18):
         ow, oh = sizes[case % len(sizes)]
         interlace = int(r.choice([0, 0, 1, 3]))
-
-        def source(must_fill=False):
-            rgba = r.random() < 0.25
-            one_to_one = r.random() < 0.3
-            if one_to_one:
-                w, h = ow, oh
-            else:
-                w, h = int(r.choice([48, 96, 192, 288, 384])), int(r.integers(2, 40))
-            seed = int(r.integers(1, 1 << 30))
-            data = frames.rgba_random(w, h, seed, -0.05, 1.05) if rgba else frames.v210_random(w, h, seed, legal=bool(r.random() < 0.7))
-            mat = None
-            if not one_to_one or r.random() < 0.5:
-                kw = dict(scale_x=float(r.choice([0.3, 0.5, 1.0, 1.0, 1.7, 2.0])), scale_y=float(r.choice([0.3, 0.5, 1.0, 1.0, 1.7, 2.0])),
-                          offset_x=float(r.uniform(-0.6, 0.6)), offset_y=float(r.uniform(-0.6, 0.6)))
-                if r.random() < 0.3:
-                    kw["rotate"] = float(r.uniform(-0.5, 0.5))
-                if r.random() < 0.2:
-                    kw["flip_h"] = True
-                if must_fill:
-                    kw = dict()
-                mat = m(ow, oh, **kw)
-            return Src(data, w, h, mat, "rgba" if rgba else "v210")
-        layers = []
-        for l in range(int(r.integers(1, 7))):
-            L = dict(src=source(must_fill=(l == 0 and r.random() < 0.5)))
-            t = r.random()
-            if t < 0.2:
-                L.update(transition="dissolve", mix=float(r.choice([0.0, 0.25, 1.0 / 3.0, 1.0])), incoming=source())
-            elif t < 0.4:
-                L.update(transition="wipe", incoming=source(), mask=source())
-            layers.append(L)
+        layers = random_layers(r, ow, oh, int(r.integers(1, 7)))
         check(layers, ow, oh, "random channel %d: %dx%d il %d, %d layers" % (case, ow, oh, interlace, len(layers)), interlace=interlace,
               specs=[("709", "709"), ("709", "2020"), ("2020", "709")][case % 3], poison_dst=bool(interlace))
 
@@ -595,3 +600,22 @@ def test_chan_batch_full_size_four_1080p_channels():
     """the reference's deployment: four 1080p channels in one context (src/index.ts:45-71) - one launch, each frame = the oracle's chain"""
     w, h = 1920, 1080
     check_batch([(layers, 0, i) for i, layers in enumerate(channel_variants(w, h, 370))], w, h, "4 channels 1920x1080")
+
+
+def test_chan_batch_random_calls():
+    """seeded random calls of ph_chan_compose_batch: 2 - 10 jobs of 1 - 5 random layers each (40 ops and 8 jobs per launch: longer calls split inside),
+    frames and fields mixed, two jobs now and then the two fields of ONE frame, output widths with and without tails - every frame
+    against the oracle's chain and against the same jobs posted one call each"""
+    r = np.random.default_rng(20260930)
+    sizes = [(192, 9), (384, 33), (576, 16), (100, 9), (1280, 6), (960, 20)]
+    for case in range(12):
+        ow, oh = sizes[case % len(sizes)]
+        jobs, slot = [], 0
+        while len(jobs) < int(r.integers(2, 11)):
+            if r.random() < 0.25:  # both fields of one frame, from two programs
+                jobs.append((random_layers(r, ow, oh, int(r.integers(1, 4))), 1, slot))
+                jobs.append((random_layers(r, ow, oh, int(r.integers(1, 4))), 3, slot))
+            else:
+                jobs.append((random_layers(r, ow, oh, int(r.integers(1, 6))), int(r.choice([0, 0, 0, 1, 3])), slot))
+            slot += 1
+        check_batch(jobs, ow, oh, "random call %d: %dx%d, %d jobs" % (case, ow, oh, len(jobs)), specs=[("709", "709"), ("709", "2020")][case % 2])
