@@ -2,6 +2,8 @@
 dissolve / wipe) -> combine_N -> FromRGBA - as one kernel that samples the v210 words directly.  Every case is compared,
 word for word, with the oracle's chain of the reference's operators (v210.ts read, transform.ts, transition.ts,
 combine.ts, v210.ts write) on the same inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -280,9 +282,9 @@ def test_random_channel_programs():
     """seeded random channels: output sizes around the kernel's units (192-column chunks, row pairs, fewer chunks than waves),
     1-6 layers of random source sizes and formats, random placements (scales either side of 1, rotations, flips, offsets that
     push layers partly or wholly off screen), random transitions with placed or 1:1 partners, every interlace mode"""
-    r = np.random.default_rng(20260929)
+    r = np.random.default_rng(int(os.environ.get("PH_FUZZ_SEED", "20260929")))  # (PH_FUZZ_SEED / PH_FUZZ_CASES: longer campaigns by hand)
     sizes = [(192, 2), (192, 9), (384, 33), (576, 17), (768, 6), (960, 20)]
-    for case in range(18):
+    for case in range(int(os.environ.get("PH_FUZZ_CASES", "18"))):
         ow, oh = sizes[case % len(sizes)]
         interlace = int(r.choice([0, 0, 1, 3]))
         layers = random_layers(r, ow, oh, int(r.integers(1, 7)))
@@ -606,9 +608,9 @@ def test_chan_batch_random_calls():
     """seeded random calls of ph_chan_compose_batch: 2 - 10 jobs of 1 - 5 random layers each (40 ops and 8 jobs per launch: longer calls split inside),
     frames and fields mixed, two jobs now and then the two fields of ONE frame, output widths with and without tails - every frame
     against the oracle's chain and against the same jobs posted one call each"""
-    r = np.random.default_rng(20260930)
+    r = np.random.default_rng(int(os.environ.get("PH_FUZZ_SEED", "20260930")))
     sizes = [(192, 9), (384, 33), (576, 16), (100, 9), (1280, 6), (960, 20)]
-    for case in range(12):
+    for case in range(int(os.environ.get("PH_FUZZ_CASES", "12"))):
         ow, oh = sizes[case % len(sizes)]
         jobs, slot = [], 0
         while len(jobs) < int(r.integers(2, 11)):
