@@ -675,7 +675,16 @@ class Deferral {
 			layers.forEach((l, i) => { params[`l${i}In`] = l.source })
 			candidates.push([`fused_v210_combine_${n}`, params])
 		}
-		if (!outFmt && !anyV210 && layers.every((l) => l.matrix && !l.transition)) { // finished images, placed: enlarged ones share their taps
+		// finished images, placed: enlarged ones share their taps.  What the 2 x 2-block compositor takes (ph_kernels_up.hip compose_up_eligible:
+		// no rotation, no mirroring, less than 0.99 source texels per output pixel and written row) is decided here from the matrices' host
+		// copies - a refused launch is an exception through the addon, and a field shown at its own size is the everyday case (1080i on 1080)
+		const enlarged = (l) => {
+			const m = l.matrix, d = l.source.imageDims
+			if (!m || !d || m.length < 36) return false
+			const f = new Float32Array(m.buffer, m.byteOffset, 9)
+			return f[1] === 0 && f[3] === 0 && f[0] > 0 && f[4] > 0 && f[0] * d.width <= 0.99 * width && f[4] * d.height * (interlace ? 2 : 1) <= 0.99 * height
+		}
+		if (!outFmt && !anyV210 && width % 2 === 0 && layers.every((l) => l.matrix && !l.transition && enlarged(l))) {
 			const params = Object.assign({ output, interlace }, saver)
 			layers.forEach((l, i) => { params[`l${i}In`] = l.source; params[`l${i}Matrix`] = l.matrix })
 			const twin = this._twinWrite(node, layers) // the frame's other field, recorded too: both in one launch

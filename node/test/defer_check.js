@@ -69,7 +69,9 @@ function rig(opt) { // opt.early: frames are launched at the end of the posting 
 	const saver = { colMatrix: param('wcm', 48, 7), gammaLut: param('wlut', 64, 8) }
 	const image = (owner) => buffer(W * H * 16, { width: W, height: H }, owner)
 	const v210 = (owner) => buffer(256 * H, undefined, owner)
-	return { d, native, launches, orders, buffer, image, v210, P, loader, saver, W, H, names: () => launches.map((l) => l[0]) }
+	// a placement the 2 x 2-block compositor takes (node/defer.js `enlarged`): half a source texel per output pixel, no rotation
+	const enlarging = () => { const b = buffer(48, undefined, 'matrix'); b.fill(0); new Float32Array(b.buffer, b.byteOffset, 9).set([0.5, 0, 0, 0, 0.5, 0, 0, 0, 1]); return b }
+	return { d, native, launches, orders, buffer, image, v210, P, loader, saver, enlarging, W, H, names: () => launches.map((l) => l[0]) }
 }
 
 // 1. read x2 -> combine_2 -> write: one fused launch, intermediates never made, everything let go when the owners release
@@ -175,7 +177,7 @@ function rig(opt) { // opt.early: frames are launched at the end of the posting 
 	const r = rig()
 	const L = r.loader()
 	const win = [0, 1, 2].map((i) => { const im = r.image(`w${i}`); r.d.record(r.P.read, Object.assign({ input: r.v210(`s${i}`), output: im, width: r.W }, L), 1); return im })
-	const m = r.buffer(48, undefined, 'matrix')
+	const m = r.enlarging()
 	const outs = []
 	for (const parity of [0, 1]) {
 		const y = r.image(`y${parity}`)
@@ -193,12 +195,28 @@ function rig(opt) { // opt.early: frames are launched at the end of the posting 
 	expect('the second field has been made already', r.names().length, 2)
 	expect('nothing pending but the recipes of images their owners still hold', Array.from(r.d.pending).map((nd) => nd.program.name).sort(), ['read', 'read', 'read', 'transform', 'transform'])
 }
+// 5a. a de-interlaced layer shown at its OWN size (1080i on a 1080 channel): the 2 x 2-block compositor is for enlargements and is not even tried
+{
+	const r = rig()
+	const L = r.loader()
+	const win = [0, 1, 2].map((i) => { const im = r.image(`w${i}`); r.d.record(r.P.read, Object.assign({ input: r.v210(`s${i}`), output: im, width: r.W }, L), 1); return im })
+	const m = r.enlarging()
+	new Float32Array(m.buffer, m.byteOffset, 9).set([1, 0, 0, 0, 1, 0, 0, 0, 1])
+	const y = r.image('y0')
+	r.d.record(r.P.yadif, { prev: win[0], cur: win[1], next: win[2], parity: 0, tff: 1, skipSpatial: 0, output: y }, 1)
+	const t = r.image('t0')
+	r.d.record(r.P.transform, { input: y, transformMatrix: m, output: t }, 1)
+	const out = r.v210('out0')
+	r.d.record(r.P.write, Object.assign({ input: t, output: out, width: r.W, interlace: 0 }, r.saver), 1)
+	r.d.touch(out, 'readonly', 2)
+	expect('own-size field: the field is made, then the channel kernel - no refused attempt', [r.names().slice(-2), r.names().some((n) => /compose_up/.test(n)), r.d.stats.fallbacks], [['yadif', 'chan_compose_v210_1'], false, 0])
+}
 // 5b. the same, refused: first the two-field form, then the single one, then the jobs as recorded; the other field likewise
 {
 	const r = rig()
 	const L = r.loader()
 	const win = [0, 1, 2].map((i) => { const im = r.image(`w${i}`); r.d.record(r.P.read, Object.assign({ input: r.v210(`s${i}`), output: im, width: r.W }, L), 1); return im })
-	const m = r.buffer(48, undefined, 'matrix')
+	const m = r.enlarging()
 	const outs = []
 	for (const parity of [0, 1]) {
 		const y = r.image(`y${parity}`)
@@ -244,7 +262,7 @@ function rig(opt) { // opt.early: frames are launched at the end of the posting 
 	r2.d.record(r2.P.read, Object.assign({ input: r2.v210('s'), output: pre, width: r2.W }, L2), 1)
 	r2.d.record(r2.P.write, Object.assign({ input: pre, output: packed, width: r2.W, interlace: 0 }, r2.saver), 1)
 	const win = [r2.v210('w0'), packed, r2.v210('w2')].map((src, i) => { const im = r2.image(`u${i}`); r2.d.record(r2.P.read, Object.assign({ input: src, output: im, width: r2.W }, L2), 1); return im })
-	const m = r2.buffer(48, undefined, 'matrix')
+	const m = r2.enlarging()
 	const outs = []
 	for (const parity of [0, 1]) {
 		const y = r2.image(`y${parity}`)
@@ -296,7 +314,7 @@ function rig(opt) { // opt.early: frames are launched at the end of the posting 
 {
 	const r = rig()
 	const L = r.loader()
-	const m = r.buffer(48, undefined, 'matrix')
+	const m = r.enlarging()
 	const y = [r.image('y0'), r.image('y1')]
 	const frame = () => {
 		const win = [0, 1, 2].map((i) => { const im = r.image(`w${i}`); r.d.record(r.P.read, Object.assign({ input: r.v210(`s${i}`), output: im, width: r.W }, L), 1); return im })

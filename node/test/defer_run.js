@@ -516,7 +516,7 @@ async function main() {
 		const seen = [await s.consume(out)]
 		;[warm, uw, a, b, pa, pb, comb, out].forEach((x) => x.release())
 		return seen
-	}, { fused: 1, plain: 0, fallbacks: 1 })
+	}, { fused: 1, plain: 0, fallbacks: 0 }) // (a rotated placement is none of the 2 x 2-block compositor's: decided from the matrix, not by a refused launch)
 
 	// file sources: planar frames as decoders hand them over - 10-bit 4:2:2 (the v210 Loader recipe) and the 8-bit formats (a Loader
 	// matrix of their own) - beside a v210 one, placed, combined, packed
