@@ -521,7 +521,11 @@ int ph_lut_layout_of(const float *host_lut65536, ph_lut_layout *layout, void *ld
  *          or as much as was ever attached to live buffers at once if that is more (a pool smaller than the working set
  *          pins a block per buffer again, ~40 ms each); over the budget the oldest blocks are freed first; 0: no pool;
  *          "fail_launches" (default 0): while non-zero every launch made through ph_run_program / ph_run_programs fails with
- *          PH_E_HIP - a fault injection for the error paths of a binding (node/test/soak_run.js); checks still pass. */
+ *          PH_E_HIP - a fault injection for the error paths of a binding (node/test/soak_run.js); checks still pass;
+ *          "chan_enlarged" (default 1; 0 when PH_CHAN_ENLARGED=0 is in the environment): ph_chan_compose* make a frame all of whose
+ *          layers are ENLARGED v210 clips (a 720p or SD clip filling a 1080 channel: the reference uploads clips at their own size,
+ *          ffmpegProducer.ts:395-442) by ph_v210_read into scratch images + ph_compose_up_write_v210 - one conversion per source pixel
+ *          instead of four per output pixel, the same bits; 0: the channel kernel for those frames too. */
 int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value);
 
 /* ---- host colour maths (src/process/colourMaths.ts, run by Loader/Saver constructors

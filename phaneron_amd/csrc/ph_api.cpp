@@ -81,12 +81,15 @@ struct ph_ctx {
   // what the pool may keep pinned: this many MiB, or - if that is more - as much as was ever in use at once (host_peak_bytes): a
   // pool smaller than the working set frees and pins a block per buffer again, 40 ms each (four 1080p channels create 36 images of
   // 33 MB per tick: round 5 measured 40 ms per tick under the fixed 1 GiB of round 4)
+  // option "chan_enlarged" (default 1; PH_CHAN_ENLARGED=0 in the environment makes it 0): frames of enlarged clips by read + 2 x 2-block compositor
+  int chan_enlarged = !(getenv("PH_CHAN_ENLARGED") && getenv("PH_CHAN_ENLARGED")[0] == '0');
   std::atomic<int> fail_launches{0};  // option "fail_launches": while non-zero every launch through ph_run_program(s) fails (tests of a binding's error paths)
   int host_pool_mb = 4096;
   size_t host_live_bytes = 0, host_peak_bytes = 0;  // mirrors attached to buffers now / at most
   uint64_t host_pins = 0;                           // hipHostMalloc calls so far (ph_ctx_host_pool_stats)
   void *chan_index[3] = {nullptr, nullptr, nullptr};  // index frame of the channel compositor, one per queue (ph_chan_compose_v210)
   size_t chan_index_bytes[3] = {0, 0, 0};
+  unsigned chan_scratch_turn[3] = {0, 0, 0};  // which third of the area the next frame of enlarged clips puts its images in (chan_compose_enlarged)
   std::vector<struct ph_route *> routes;  // open ROUTEs: a recycled block must not be handed out under a transfer in flight
   std::mutex mu;
   std::atomic<int> refs{1};
@@ -1010,6 +1013,7 @@ int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
     return ctx->stream_threshold_mb = value, PH_OK;
   }
   if (0 == strcmp(name, "fail_launches")) return ctx->fail_launches.store(value), PH_OK;
+  if (0 == strcmp(name, "chan_enlarged")) return ctx->chan_enlarged = (value != 0), PH_OK;
   if (0 == strcmp(name, "host_pool_mb")) {
     if (value < 0) return fail(PH_E_INVALID, "host_pool_mb: a size in MiB");
     std::vector<ph_ctx::HostBlock> drop;
@@ -2066,6 +2070,67 @@ static int chan_ops(int n, const ph_chan_layer *layers, uint32_t out_w, uint32_t
   return PH_OK;
 }
 
+// ---- a frame of ENLARGED clips: read once, then the 2 x 2-block compositor --------------------------------------------------------------
+// The reference uploads a clip at its own size and lets the Mixer's transform fill the channel (src/producer/ffmpegProducer.ts:395-442,
+// mixer.ts:189-228): a 720p or SD clip on a 1080 channel, an HD clip on a 2160p one.  The channel kernel converts every TAP - four
+// conversions per output pixel - where an enlarged clip has fewer pixels than the frame it fills.  When every layer of a frame is such a
+// clip (v210, no transition, placed without rotation or mirroring, under 0.99 source texels per output pixel and written row: what
+// ph_compose_up_write_v210 takes), the frame is made by the kernels that exist for exactly this: ph_v210_read(_batch) into scratch images,
+// one conversion per SOURCE pixel, then ph_compose_up_write_v210 on them.  Same arithmetic, same bits (tests/test_chan_gpu.py checks both
+// routes against the chain of the reference's operators); 1280 x 720 -> 1920 x 1080: 26.4 -> 17.7 us, 1080p -> 2160p: 82 -> 38 us (tools/enlarge_bench.py).
+// Context option "chan_enlarged" = 0 (or PH_CHAN_ENLARGED=0): such frames through the channel kernel like any other (A/B runs, tests of that path).
+static bool chan_layers_enlarged(int n, const ph_chan_layer *layers, uint32_t out_w, uint32_t out_h, uint32_t interlace) {
+  if (out_w % 2u) return false;
+  for (int i = 0; i < n; ++i) {
+    const ph_chan_layer &L = layers[i];
+    const float *m = L.src.matrix9_host;
+    if (L.transition != PH_TRANSITION_CUT || L.src.format != PH_SRC_V210 || !m || L.src.width <= 0 || L.src.height <= 0 || (L.src.width & 1)) return false;
+    if (m[1] != 0.0f || m[3] != 0.0f || !(m[0] > 0.0f) || !(m[4] > 0.0f)) return false;                      // (ph_kernels_up.hip compose_up_eligible)
+    if ((double)m[0] * L.src.width > 0.99 * out_w || (double)m[4] * L.src.height * (interlace ? 2 : 1) > 0.99 * out_h) return false;
+    if ((uint64_t)L.src.width * 16u * (uint64_t)L.src.height >= (1ull << 30) || L.src.width >= (1 << 22)) return false;
+  }
+  return true;
+}
+static int chan_compose_enlarged(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, void *out, uint32_t out_w, uint32_t out_h, uint32_t interlace,
+                                 const void *rd_cm, const void *rd_lut, const void *rd_gm, const void *wr_cm, const void *wr_lut) {
+  // the images live in the channel compositor's scratch area of the queue (launches on one queue are in order)
+  size_t off[ph::kMaxLayers], total = 0;
+  bool one_size = true;
+  for (int i = 0; i < n; ++i) {
+    off[i] = total;
+    total += ((size_t)layers[i].src.width * layers[i].src.height * 16u + 255u) & ~(size_t)255u;
+    one_size = one_size && layers[i].src.width == layers[0].src.width && layers[i].src.height == layers[0].src.height;
+  }
+  // Three sets of images taken in turn: a frame's read kernel overwriting the very lines the previous frame's compositor has just read
+  // (still cached, in several XCDs' L2s) measured 11.7 us against 7.9 us into lines nobody holds (tools/enlarge_bench.py, PH_ENLARGE_RING)
+  // - while the sets together stay inside the 256 MB of last-level cache: four 1080p images (132 MB) in three sets measured 109 us per
+  // 2160p frame against 94 in one set that stays cached
+  const unsigned kTurns = total <= ((size_t)64 << 20) ? 3u : 1u;
+  char *base;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int rc = chan_index_reserve(ctx, queue, total * kTurns);
+    if (rc) return rc;
+    base = (char *)ctx->chan_index[queue] + total * (ctx->chan_scratch_turn[queue]++ % kTurns);
+  }
+  const void *ins[ph::kMaxLayers];
+  void *imgs[ph::kMaxLayers];
+  ph_image_layer il[ph::kMaxLayers];
+  for (int i = 0; i < n; ++i) {
+    ins[i] = layers[i].src.data, imgs[i] = base + off[i];
+    il[i] = ph_image_layer{imgs[i], PH_IMG_RGBA_F32, layers[i].src.width, layers[i].src.height, layers[i].src.matrix9_host};
+  }
+  int rc = PH_OK;
+  if (one_size && n > 1) {
+    rc = ph_v210_read_batch(ctx, queue, n, ins, imgs, (uint32_t)layers[0].src.width, (uint32_t)layers[0].src.height, rd_cm, rd_lut, rd_gm);
+  } else {
+    for (int i = 0; i < n && rc == PH_OK; ++i)
+      rc = ph_v210_read(ctx, queue, ins[i], imgs[i], (uint32_t)layers[i].src.width, (uint32_t)layers[i].src.height, rd_cm, rd_lut, rd_gm);
+  }
+  if (rc) return rc;
+  return ph_compose_up_write_v210(ctx, queue, n, il, out, out_w, out_h, interlace, wr_cm, wr_lut);
+}
+
 int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
                          uint32_t interlace, const void *rd_cm, const void *rd_lut, const void *rd_gm, const void *wr_cm,
                          const void *wr_lut) {
@@ -2117,6 +2182,8 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
   if (!a.lines) return PH_OK;
   int rc = set_device(ctx);
   if (rc) return rc;
+  if (out_format == PH_FMT_V210 && wr_cm && ctx->chan_enlarged && chan_layers_enlarged(n, layers, out_w, out_h, interlace))
+    return chan_compose_enlarged(ctx, queue, n, layers, out, out_w, out_h, interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut);
   // the index frame between the phases: one per queue (launches on one queue are in order), grown on demand
   std::lock_guard<std::mutex> lock(ctx->mu);
   rc = chan_index_reserve(ctx, queue, ph::chan_index_bytes(out_w, a.lines));
@@ -2168,7 +2235,8 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
       ops += L.transition == PH_TRANSITION_WIPE ? 3u : L.transition == PH_TRANSITION_DISSOLVE ? 2u : 1u;
       wire = wire || L.src.format > PH_SRC_RGBA_F32 || L.incoming.format > PH_SRC_RGBA_F32 || L.mask.format > PH_SRC_RGBA_F32;
     }
-    if (!wire && ops <= (uint32_t)ph::kMaxChanBatchOps) ++plan_jobs, plan_ops += ops;
+    if (!wire && ops <= (uint32_t)ph::kMaxChanBatchOps && !(ctx->chan_enlarged && chan_layers_enlarged(jobs[j].n, jobs[j].layers, out_w, out_h, jobs[j].interlace)))
+      ++plan_jobs, plan_ops += ops;
   }
   const uint32_t by_jobs = (plan_jobs + (uint32_t)ph::kMaxChanJobs - 1u) / (uint32_t)ph::kMaxChanJobs;
   const uint32_t by_ops = (plan_ops + (uint32_t)ph::kMaxChanBatchOps - 1u) / (uint32_t)ph::kMaxChanBatchOps;
@@ -2199,7 +2267,8 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
     const bool is_field = J.interlace != 0;
     const uint32_t lines = is_field ? out_h / 2 : out_h;
     const uint32_t fit = chan_batch_on() ? jobs_per_launch : 0u;
-    if (one.planar == 2 || k > ph::kMaxChanBatchOps || fit < 1 || !lines) {  // not for the batch kernel: in its turn, on its own
+    const bool enlarged = ctx->chan_enlarged && chan_layers_enlarged(J.n, J.layers, out_w, out_h, J.interlace);  // read + 2 x 2-block compositor
+    if (one.planar == 2 || k > ph::kMaxChanBatchOps || fit < 1 || !lines || enlarged) {  // not for the batch kernel: in its turn, on its own
       if ((rc = flush())) return rc;
       if ((rc = ph_chan_compose_v210(ctx, queue, J.n, J.layers, J.out, out_w, out_h, J.interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut))) return rc;
       continue;

@@ -621,3 +621,44 @@ def test_chan_batch_random_calls():
                 jobs.append((random_layers(r, ow, oh, int(r.integers(1, 6))), int(r.choice([0, 0, 0, 1, 3])), slot))
             slot += 1
         check_batch(jobs, ow, oh, "random call %d: %dx%d, %d jobs" % (case, ow, oh, len(jobs)), specs=[("709", "709"), ("709", "2020")][case % 2])
+
+
+def both_routes(fn):
+    """run fn() with frames of enlarged clips made by read + 2 x 2-block compositor (the default) and by the channel kernel (option chan_enlarged = 0)"""
+    import hip_harness as hh
+    k = hh.ctx()
+    try:
+        for on in (1, 0):
+            k.set_option("chan_enlarged", on)
+            fn("read + 2x2-block compositor" if on else "channel kernel")
+    finally:
+        k.set_option("chan_enlarged", 1)
+
+
+@pytest.mark.parametrize("sw,sh,ow,oh,interlace", [(128, 36, 192, 54, 0), (96, 30, 192, 54, 1), (96, 30, 192, 54, 3), (100, 24, 384, 33, 0), (128, 36, 1280, 10, 0),
+                                                   (720, 48, 1920, 24, 0), (52, 7, 100, 9, 3)])
+def test_enlarged_clips_on_both_routes(sw, sh, ow, oh, interlace):
+    """the reference's everyday case - a clip smaller than its channel, uploaded at its own size, filling the frame through the Mixer's transform
+    (ffmpegProducer.ts:395-442, mixer.ts:189-228): one clip, two clips of one size (one batched read), three of different sizes and
+    placements - by ph_v210_read + ph_compose_up_write_v210 and by the channel kernel, each against the oracle's chain"""
+    def clip(seed, w, h, **kw):
+        return dict(src=Src(frames.v210_random(w, h, frames.layer_seed(seed, w + h), legal=bool(seed & 1)), w, h, m(ow, oh, **kw)))
+    cases = [[clip(400, sw, sh)],
+             [clip(401, sw, sh), clip(402, sw, sh, scale_x=0.8, scale_y=0.8, offset_x=0.1, offset_y=-0.1)],
+             [clip(403, sw, sh), clip(404, sw // 2 // 2 * 2, max(2, sh // 2), scale_x=0.7, scale_y=0.9, offset_x=-0.15), clip(405, sw, sh, scale_x=0.6, scale_y=0.6, offset_y=0.2)]]
+    for i, layers in enumerate(cases):
+        both_routes(lambda route: check(layers, ow, oh, "%d enlarged clips %dx%d on %dx%d il %d by the %s" % (len(layers), sw, sh, ow, oh, interlace, route),
+                                        interlace=interlace, poison_dst=bool(interlace)))
+
+
+def test_enlarged_clips_at_full_size_and_in_a_batch_call():
+    """1280 x 720 clips on a 1920 x 1080 channel at full size (both routes), and such frames among the jobs of ph_chan_compose_batch
+    (they are made in their turn, on their own; the other jobs still share a launch)"""
+    w, h, ow, oh = 1280, 720, 1920, 1080
+    layers = [dict(src=Src(frames.v210_random(w, h, frames.layer_seed(410, l)), w, h, m(ow, oh, scale_x=1.0 - 0.2 * l, scale_y=1.0 - 0.2 * l))) for l in range(2)]
+    both_routes(lambda route: check(layers, ow, oh, "two 720p clips on a 1080p channel by the %s" % route))
+    sw, sh, ow, oh = 128, 36, 384, 54
+    v = channel_variants(ow, oh, 420)
+    small = [dict(src=Src(frames.v210_random(sw, sh, frames.layer_seed(421, 0)), sw, sh, m(ow, oh)))]
+    both_routes(lambda route: check_batch([(v[0], 0, 0), (small, 0, 1), (v[1], 0, 2), (small, 1, 3), (small, 3, 3), (v[3], 0, 4)], ow, oh,
+                                          "a batch call with frames of enlarged clips among its jobs, those by the %s" % route))
