@@ -35,7 +35,7 @@ extern "C" {
  * 5: ph_compose_up_write_v210_pair, ph_lut_layout_of
  * 6: ph_fused_field_v210 / ph_field_layer REMOVED (the slowest route of its workload by 2.7x, no caller).  The fused entry
  *    points take widths that are not a multiple of 48 (1280 x 720: the reference's third format, src/config.ts:43-54)
- * 7: additive over 6 - ph_chan_compose_batch (ph_chan_job): several channels' frames in one launch; ph_run_programs;
+ * 7: additive over 6 - ph_chan_compose_batch (ph_chan_job): several channels' frames in one launch; ph_run_programs; ph_compose_up_write_v210_batch;
  *    ph_event_record_timed / ph_event_elapsed_us; ph_ctx_host_pool_stats; "host_pool_mb" defaults to 4096 again and never
  *    keeps less than the working set */
 #define PH_ABI_VERSION 7
@@ -406,6 +406,12 @@ int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer
 int ph_compose_up_write_v210_pair(ph_ctx *ctx, int queue, int n, const ph_image_layer *layers_a, const ph_image_layer *layers_b, void *out_a,
                                   void *out_b, uint32_t out_width, uint32_t out_height, uint32_t interlace, const void *wr_col_matrix12,
                                   const void *wr_gamma_lut);
+/* The same for 1 .. 4 sets of layers that differ in their data only - several channels showing clips of one size under one placement
+ * (the reference's channels share a context and a queue: src/index.ts:45-71,156-160): layer_sets[j][l] is layer l of job j, outs[j] its
+ * output (all different).  ph_chan_compose_batch uses it for the frames of enlarged clips among its jobs. */
+int ph_compose_up_write_v210_batch(ph_ctx *ctx, int queue, int jobs, int n, const ph_image_layer *const *layer_sets, void *const *outs,
+                                   uint32_t out_width, uint32_t out_height, uint32_t interlace, const void *wr_col_matrix12,
+                                   const void *wr_gamma_lut);
 
 /* ---- the channel compositor straight from the wire format (no single reference equivalent): a channel's whole
  *      per-frame job batch - per layer ToRGBA (io.ts:79-98, v210.ts:25-111) -> Mixer transform (producer/mixer.ts:

@@ -27,7 +27,7 @@ EXPORTS = [
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
-    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_lut_layout_of", "ph_compose_up_write_v210_pair", "ph_ctx_set_option", "ph_compose_write_v210", "ph_compose_wipe_write_v210",
+    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_lut_layout_of", "ph_compose_up_write_v210_pair", "ph_compose_up_write_v210_batch", "ph_ctx_set_option", "ph_compose_write_v210", "ph_compose_wipe_write_v210",
     "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
     "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy", "ph_queue_query",
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
@@ -183,6 +183,7 @@ def lib():
         "ph_lut_query": (ci, [vp, vp, C.POINTER(cu), C.POINTER(cu), C.POINTER(cu)]),
         "ph_lut_layout_of": (ci, [f32p, C.POINTER(LutLayout), vp, C.c_size_t]),
         "ph_compose_up_write_v210_pair": (ci, [vp, ci, ci, C.POINTER(PhImageLayer), C.POINTER(PhImageLayer), vp, vp, cu, cu, cu, vp, vp]),
+        "ph_compose_up_write_v210_batch": (ci, [vp, ci, ci, ci, C.POINTER(C.POINTER(PhImageLayer)), C.POINTER(vp), cu, cu, cu, vp, vp]),
         "ph_ctx_set_option": (ci, [vp, C.c_char_p, ci]),
         "ph_pack_plane_bytes": (ci, [ci, cu, cu, C.POINTER(cs)]),
         "ph_pack_read": (ci, [vp, ci, ci, C.POINTER(vp), vp, cu, cu, vp, vp, vp]),
@@ -446,6 +447,32 @@ class Context:
                 check(fn(*args), h)
             return job
         check(lib().ph_compose_up_write_v210_pair(*args), self.h)
+
+    def compose_up_write_v210_batch(self, layer_sets, dsts, out_w, out_h, interlace, wr_cm, wr_lut, queue=QUEUE_PROCESS, rgb=False, prepare_only=False):
+        """1 .. 4 sets of layers that differ in their tensors only, each into its own frame, in one launch (ph_compose_up_write_v210_batch).
+        Arguments as compose_up_write_v210."""
+        import numpy as np
+        keep = []
+        arrs = []
+        for layers in layer_sets:
+            arr = (PhImageLayer * len(layers))()
+            for i, (t, w, h, m) in enumerate(layers):
+                mh = np.ascontiguousarray(m, np.float32)
+                keep.append(mh)
+                arr[i].data, arr[i].width, arr[i].height = _ptr(t).value, w, h
+                arr[i].format = IMG_RGB_F32 if rgb else IMG_RGBA_F32
+                arr[i].matrix9_host = mh.ctypes.data_as(C.POINTER(C.c_float))
+            arrs.append(arr)
+        sets = (C.POINTER(PhImageLayer) * len(arrs))(*[C.cast(a, C.POINTER(PhImageLayer)) for a in arrs])
+        outs = (C.c_void_p * len(dsts))(*[_ptr(d).value for d in dsts])
+        args = (self.h, queue, len(layer_sets), len(layer_sets[0]), sets, outs, out_w, out_h, interlace, _ptr(wr_cm), _ptr(wr_lut))
+        if prepare_only:
+            fn, h = lib().ph_compose_up_write_v210_batch, self.h
+
+            def job(_keep=(keep, arrs, layer_sets, dsts, sets, outs)):
+                check(fn(*args), h)
+            return job
+        check(lib().ph_compose_up_write_v210_batch(*args), self.h)
 
     def compose_up_write_v210(self, layers, dst, out_w, out_h, interlace, wr_cm, wr_lut, queue=QUEUE_PROCESS, rgb=False, prepare_only=False):
         """The 2 x 2-block compositor for layers enlarged 2x or more (ph_compose_up_write_v210).  layers: [(tensor, width,

@@ -2091,16 +2091,28 @@ static bool chan_layers_enlarged(int n, const ph_chan_layer *layers, uint32_t ou
   }
   return true;
 }
-static int chan_compose_enlarged(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, void *out, uint32_t out_w, uint32_t out_h, uint32_t interlace,
-                                 const void *rd_cm, const void *rd_lut, const void *rd_gm, const void *wr_cm, const void *wr_lut) {
+// two such frames of one shape (layer count, clip sizes, placements): one launch of the compositor can make both
+static bool chan_enlarged_same_shape(int n, const ph_chan_layer *a, const ph_chan_layer *b) {
+  for (int i = 0; i < n; ++i) {
+    if (a[i].src.width != b[i].src.width || a[i].src.height != b[i].src.height) return false;
+    for (int k = 0; k < 9; ++k)
+      if (a[i].src.matrix9_host[k] != b[i].src.matrix9_host[k]) return false;
+  }
+  return true;
+}
+// `jobs` frames of one shape and field mode (1 .. kMaxUpJobs, different outputs): the clips read - as few launches as their sizes allow -
+// and ONE compositor launch (ph_compose_up_write_v210_batch)
+static int chan_compose_enlarged(ph_ctx *ctx, int queue, int jobs, int n, const ph_chan_layer *const *layers, void *const *outs, uint32_t out_w, uint32_t out_h,
+                                 uint32_t interlace, const void *rd_cm, const void *rd_lut, const void *rd_gm, const void *wr_cm, const void *wr_lut) {
   // the images live in the channel compositor's scratch area of the queue (launches on one queue are in order)
-  size_t off[ph::kMaxLayers], total = 0;
+  size_t off[ph::kMaxLayers], per_job = 0;
   bool one_size = true;
   for (int i = 0; i < n; ++i) {
-    off[i] = total;
-    total += ((size_t)layers[i].src.width * layers[i].src.height * 16u + 255u) & ~(size_t)255u;
-    one_size = one_size && layers[i].src.width == layers[0].src.width && layers[i].src.height == layers[0].src.height;
+    off[i] = per_job;
+    per_job += ((size_t)layers[0][i].src.width * layers[0][i].src.height * 16u + 255u) & ~(size_t)255u;
+    one_size = one_size && layers[0][i].src.width == layers[0][0].src.width && layers[0][i].src.height == layers[0][0].src.height;
   }
+  const size_t total = per_job * (size_t)jobs;
   // Three sets of images taken in turn: a frame's read kernel overwriting the very lines the previous frame's compositor has just read
   // (still cached, in several XCDs' L2s) measured 11.7 us against 7.9 us into lines nobody holds (tools/enlarge_bench.py, PH_ENLARGE_RING)
   // - while the sets together stay inside the 256 MB of last-level cache: four 1080p images (132 MB) in three sets measured 109 us per
@@ -2113,22 +2125,30 @@ static int chan_compose_enlarged(ph_ctx *ctx, int queue, int n, const ph_chan_la
     if (rc) return rc;
     base = (char *)ctx->chan_index[queue] + total * (ctx->chan_scratch_turn[queue]++ % kTurns);
   }
-  const void *ins[ph::kMaxLayers];
-  void *imgs[ph::kMaxLayers];
-  ph_image_layer il[ph::kMaxLayers];
-  for (int i = 0; i < n; ++i) {
-    ins[i] = layers[i].src.data, imgs[i] = base + off[i];
-    il[i] = ph_image_layer{imgs[i], PH_IMG_RGBA_F32, layers[i].src.width, layers[i].src.height, layers[i].src.matrix9_host};
+  const void *ins[ph::kMaxUpJobs * ph::kMaxLayers];
+  void *imgs[ph::kMaxUpJobs * ph::kMaxLayers];
+  ph_image_layer il[ph::kMaxUpJobs][ph::kMaxLayers];
+  const ph_image_layer *sets[ph::kMaxUpJobs];
+  for (int j = 0; j < jobs; ++j) {
+    for (int i = 0; i < n; ++i) {
+      const ph_chan_source &S = layers[j][i].src;
+      ins[j * n + i] = S.data, imgs[j * n + i] = base + per_job * (size_t)j + off[i];
+      il[j][i] = ph_image_layer{imgs[j * n + i], PH_IMG_RGBA_F32, S.width, S.height, S.matrix9_host};
+    }
+    sets[j] = il[j];
   }
   int rc = PH_OK;
-  if (one_size && n > 1) {
-    rc = ph_v210_read_batch(ctx, queue, n, ins, imgs, (uint32_t)layers[0].src.width, (uint32_t)layers[0].src.height, rd_cm, rd_lut, rd_gm);
+  const int frames = jobs * n;
+  if (one_size && frames > 1) {
+    for (int f = 0; f < frames && rc == PH_OK; f += ph::kMaxLayers)
+      rc = ph_v210_read_batch(ctx, queue, frames - f < ph::kMaxLayers ? frames - f : ph::kMaxLayers, ins + f, imgs + f, (uint32_t)layers[0][0].src.width,
+                              (uint32_t)layers[0][0].src.height, rd_cm, rd_lut, rd_gm);
   } else {
-    for (int i = 0; i < n && rc == PH_OK; ++i)
-      rc = ph_v210_read(ctx, queue, ins[i], imgs[i], (uint32_t)layers[i].src.width, (uint32_t)layers[i].src.height, rd_cm, rd_lut, rd_gm);
+    for (int f = 0; f < frames && rc == PH_OK; ++f)
+      rc = ph_v210_read(ctx, queue, ins[f], imgs[f], (uint32_t)layers[f / n][f % n].src.width, (uint32_t)layers[f / n][f % n].src.height, rd_cm, rd_lut, rd_gm);
   }
   if (rc) return rc;
-  return ph_compose_up_write_v210(ctx, queue, n, il, out, out_w, out_h, interlace, wr_cm, wr_lut);
+  return ph_compose_up_write_v210_batch(ctx, queue, jobs, n, sets, outs, out_w, out_h, interlace, wr_cm, wr_lut);
 }
 
 int ph_chan_compose_v210(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
@@ -2183,7 +2203,7 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
   int rc = set_device(ctx);
   if (rc) return rc;
   if (out_format == PH_FMT_V210 && wr_cm && ctx->chan_enlarged && chan_layers_enlarged(n, layers, out_w, out_h, interlace))
-    return chan_compose_enlarged(ctx, queue, n, layers, out, out_w, out_h, interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut);
+    return chan_compose_enlarged(ctx, queue, 1, n, &layers, &out, out_w, out_h, interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut);
   // the index frame between the phases: one per queue (launches on one queue are in order), grown on demand
   std::lock_guard<std::mutex> lock(ctx->mu);
   rc = chan_index_reserve(ctx, queue, ph::chan_index_bytes(out_w, a.lines));
@@ -2246,6 +2266,17 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
   ph::ChanArgs a = common(0);
   bool fields = false;
   int first_job = 0;  // of the launch being collected
+  // frames of enlarged clips among the jobs (chan_compose_enlarged): those of one shape and field mode, one after the other, are made together
+  const ph_chan_layer *enl_layers[ph::kMaxUpJobs];
+  void *enl_outs[ph::kMaxUpJobs];
+  int enl = 0, enl_n = 0;
+  uint32_t enl_interlace = 0;
+  auto flush_enlarged = [&]() -> int {
+    if (!enl) return PH_OK;
+    const int r = chan_compose_enlarged(ctx, queue, enl, enl_n, enl_layers, enl_outs, out_w, out_h, enl_interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut);
+    enl = 0;
+    return r;
+  };
   auto flush = [&]() -> int {
     if (!b.jobs) return PH_OK;
     int r;
@@ -2267,8 +2298,16 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
     const bool is_field = J.interlace != 0;
     const uint32_t lines = is_field ? out_h / 2 : out_h;
     const uint32_t fit = chan_batch_on() ? jobs_per_launch : 0u;
-    const bool enlarged = ctx->chan_enlarged && chan_layers_enlarged(J.n, J.layers, out_w, out_h, J.interlace);  // read + 2 x 2-block compositor
-    if (one.planar == 2 || k > ph::kMaxChanBatchOps || fit < 1 || !lines || enlarged) {  // not for the batch kernel: in its turn, on its own
+    if (lines && ctx->chan_enlarged && chan_layers_enlarged(J.n, J.layers, out_w, out_h, J.interlace)) {  // read + 2 x 2-block compositor, in its turn
+      if ((rc = flush())) return rc;
+      bool fits = enl > 0 && enl < ph::kMaxUpJobs && J.n == enl_n && J.interlace == enl_interlace && chan_enlarged_same_shape(J.n, enl_layers[0], J.layers);
+      for (int e = 0; e < enl && fits; ++e) fits = enl_outs[e] != J.out;
+      if (!fits && (rc = flush_enlarged())) return rc;
+      enl_layers[enl] = J.layers, enl_outs[enl] = J.out, enl_n = J.n, enl_interlace = J.interlace, ++enl;
+      continue;
+    }
+    if ((rc = flush_enlarged())) return rc;
+    if (one.planar == 2 || k > ph::kMaxChanBatchOps || fit < 1 || !lines) {  // not for the batch kernel: in its turn, on its own
       if ((rc = flush())) return rc;
       if ((rc = ph_chan_compose_v210(ctx, queue, J.n, J.layers, J.out, out_w, out_h, J.interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut))) return rc;
       continue;
@@ -2286,6 +2325,7 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
     for (int i = 0; i < k; ++i) b.op[b.n_ops + i] = one.op[i], b.op_job[b.n_ops + i] = (uint8_t)b.jobs;
     b.n_ops += (uint32_t)k, ++b.jobs;
   }
+  if ((rc = flush_enlarged())) return rc;
   return flush();
 }
 
@@ -2307,15 +2347,21 @@ int ph_v210_yadif_pair(ph_ctx *ctx, int queue, int n, const ph_deint_source *src
   return ph_v210_yadif_pair_fmt(ctx, queue, n, src, width, height, tff, skip, PH_IMG_RGBA_F32, cm, lut, gm);
 }
 
-static int compose_up_common(const char *fn, ph_ctx *ctx, int queue, int n, const ph_image_layer *layers, const ph_image_layer *layers_b, void *out, void *out_b,
+// `jobs` sets of layers that differ in their data only (same count, formats, sizes and placements), each into its own output: one launch
+static int compose_up_common(const char *fn, ph_ctx *ctx, int queue, int jobs, int n, const ph_image_layer *const *sets, void *const *outs,
                              uint32_t out_w, uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut) {
-  const bool pair = layers_b != nullptr;
-  if (!ctx || !layers || !out || !wr_cm || !wr_lut || (pair && !out_b)) return fail(PH_E_INVALID, "%s: NULL argument", fn);
+  if (!ctx || !sets || !outs || !wr_cm || !wr_lut) return fail(PH_E_INVALID, "%s: NULL argument", fn);
+  if (jobs < 1 || jobs > ph::kMaxUpJobs) return fail(PH_E_INVALID, "%s: 1..%d jobs", fn, ph::kMaxUpJobs);
+  for (int j = 0; j < jobs; ++j)
+    if (!sets[j] || !outs[j]) return fail(PH_E_INVALID, "%s: NULL argument", fn);
+  const ph_image_layer *layers = sets[0];
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "%s: 1..%d layers", fn, ph::kMaxLayers);
   // (a width that is not a multiple of 48 - 1280 - ends its lines in a tail quad and cleared slots: the kernel's TAILS instantiation)
   if (!out_w || out_w % 2) return fail(PH_E_INVALID, "%s: width %u is odd (a v210 frame needs an even width); run the separate kernels", fn, out_w);
   if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "%s: interlace must be 0, 1 or 3", fn);
-  if (pair && out == out_b) return fail(PH_E_INVALID, "%s: the two outputs are the same buffer", fn);
+  for (int j = 1; j < jobs; ++j)
+    for (int k = 0; k < j; ++k)
+      if (outs[j] == outs[k]) return fail(PH_E_INVALID, jobs == 2 ? "%s: the two outputs are the same buffer" : "%s: two jobs have the same output buffer", fn);
   const ph::LutView *wv = lds_view(ctx, wr_lut);
   if (!wv) return fail(PH_E_INVALID, "%s: the writer gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)", fn);
   ph::UpArgs a{};
@@ -2329,16 +2375,18 @@ static int compose_up_common(const char *fn, ph_ctx *ctx, int queue, int n, cons
     a.layer[i].ptr = L.data, a.layer[i].w = (uint32_t)L.width, a.layer[i].h = (uint32_t)L.height;
     a.layer[i].pitch = (uint32_t)L.width * (fmt == PH_IMG_RGB_F32 ? 12u : 16u);
     for (int k = 0; k < 6; ++k) a.layer[i].m[k] = L.matrix9_host[k];
-    if (pair) {
-      const ph_image_layer &B = layers_b[i];
+    for (int j = 1; j < jobs; ++j) {
+      const ph_image_layer &B = sets[j][i];
       if (!B.data || !B.matrix9_host || B.format != L.format || B.width != L.width || B.height != L.height)
-        return fail(PH_E_INVALID, "%s: layer %d of the second set differs from the first in more than its data", fn, i);
+        return fail(PH_E_INVALID, jobs == 2 ? "%s: layer %d of the second set differs from the first in more than its data" : "%s: layer %d of a further set differs from the first in more than its data", fn, i);
       for (int k = 0; k < 9; ++k)
-        if (B.matrix9_host[k] != L.matrix9_host[k]) return fail(PH_E_INVALID, "%s: layer %d of the second set is placed differently", fn, i);
-      a.ptr2[i] = B.data;
+        if (B.matrix9_host[k] != L.matrix9_host[k])
+          return fail(PH_E_INVALID, jobs == 2 ? "%s: layer %d of the second set is placed differently" : "%s: layer %d of a further set is placed differently", fn, i);
+      a.more_ptr[j - 1][i] = B.data;
     }
   }
-  a.out = out, a.out2 = out_b, a.jobs = pair ? 2u : 1u, a.out_w = out_w, a.out_h = out_h;
+  a.out = outs[0], a.jobs = (uint32_t)jobs, a.out_w = out_w, a.out_h = out_h;
+  for (int j = 1; j < jobs; ++j) a.more_out[j - 1] = outs[j];
   a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0;
   a.lines = interlace ? out_h / 2 : out_h;
   a.wr_cm = (const float *)wr_cm, a.wr = *wv;
@@ -2351,13 +2399,21 @@ static int compose_up_common(const char *fn, ph_ctx *ctx, int queue, int n, cons
 
 int ph_compose_up_write_v210(ph_ctx *ctx, int queue, int n, const ph_image_layer *layers, void *out, uint32_t out_w, uint32_t out_h,
                              uint32_t interlace, const void *wr_cm, const void *wr_lut) {
-  return compose_up_common("ph_compose_up_write_v210", ctx, queue, n, layers, nullptr, out, nullptr, out_w, out_h, interlace, wr_cm, wr_lut);
+  if (!layers || !out) return fail(PH_E_INVALID, "ph_compose_up_write_v210: NULL argument");
+  return compose_up_common("ph_compose_up_write_v210", ctx, queue, 1, n, &layers, &out, out_w, out_h, interlace, wr_cm, wr_lut);
 }
 
 int ph_compose_up_write_v210_pair(ph_ctx *ctx, int queue, int n, const ph_image_layer *layers_a, const ph_image_layer *layers_b, void *out_a, void *out_b,
                                   uint32_t out_w, uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut) {
-  if (!layers_b) return fail(PH_E_INVALID, "ph_compose_up_write_v210_pair: NULL argument");
-  return compose_up_common("ph_compose_up_write_v210_pair", ctx, queue, n, layers_a, layers_b, out_a, out_b, out_w, out_h, interlace, wr_cm, wr_lut);
+  if (!layers_a || !layers_b || !out_a || !out_b) return fail(PH_E_INVALID, "ph_compose_up_write_v210_pair: NULL argument");
+  const ph_image_layer *sets[2] = {layers_a, layers_b};
+  void *outs[2] = {out_a, out_b};
+  return compose_up_common("ph_compose_up_write_v210_pair", ctx, queue, 2, n, sets, outs, out_w, out_h, interlace, wr_cm, wr_lut);
+}
+
+int ph_compose_up_write_v210_batch(ph_ctx *ctx, int queue, int jobs, int n, const ph_image_layer *const *layer_sets, void *const *outs, uint32_t out_w,
+                                   uint32_t out_h, uint32_t interlace, const void *wr_cm, const void *wr_lut) {
+  return compose_up_common("ph_compose_up_write_v210_batch", ctx, queue, jobs, n, layer_sets, outs, out_w, out_h, interlace, wr_cm, wr_lut);
 }
 
 int ph_v210_yadif_pair_fmt(ph_ctx *ctx, int queue, int n, const ph_deint_source *src, uint32_t width, uint32_t height, int tff,

@@ -151,6 +151,7 @@ struct UpLayer {
   uint32_t pad;
   float m[6];            // rows 0 and 1 of the 3x3 transform matrix
 };
+constexpr int kMaxUpJobs = 4;
 struct UpArgs {
   UpLayer layer[kMaxLayers];
   int n;
@@ -163,9 +164,10 @@ struct UpArgs {
   // launcher: lines by pitch - quad slots per line; the columns the wave steps cover (out_w, or the whole pitch when lines end in a
   // tail quad and cleared slots: the TAILS instantiation writes those too)
   uint32_t out_qpitch, cover_w;
-  // a second job of the same shape in the same launch (both fields of a frame): its layers' data and its output; jobs = 1 | 2
-  const void *ptr2[kMaxLayers];
-  void *out2;
+  // more jobs of the same shape in the same launch (both fields of a frame; several channels under one placement): their layers' data and
+  // their outputs; jobs = 1 .. kMaxUpJobs
+  const void *more_ptr[kMaxUpJobs - 1][kMaxLayers];
+  void *more_out[kMaxUpJobs - 1];
   uint32_t jobs;
 };
 bool compose_up_eligible(const UpArgs &a);

@@ -68,7 +68,7 @@ struct UpShare {  // as ChanShare (ph_kernels_chan.hip): units dealt XCD-aware i
 __device__ __forceinline__ UpShare up_share(const UpArgs &a) {
   UpShare s;
   s.upr = (a.cover_w + kUpCols - 1u) / kUpCols;  // wave steps per row pair
-  s.units = s.upr * ((a.lines + 1u) / 2u) * (a.jobs > 1u ? 2u : 1u);  // a second job's row pairs follow the first's
+  s.units = s.upr * ((a.lines + 1u) / 2u) * a.jobs;  // a further job's row pairs follow the one before's
   s.upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * s.upr;
   s.banded = (gridDim.x & 7u) == 0;
   s.xcd = 0, s.v0 = blockIdx.x * (kUpBlock / 64), s.vstep = gridDim.x * (kUpBlock / 64), s.vend = s.units;
@@ -131,8 +131,9 @@ __device__ __forceinline__ void up_over(const UpColour &c, UpAcc &acc) {
 }
 
 // where a wave step lies: 126 columns x 2 rows; the lane's block starts at (x0, line[0])
+static_assert(kMaxUpJobs == 4, "up_step finds a row pair's job by three comparisons");
 struct UpStep {
-  uint32_t job;  // uniform: 0, or 1 for a row pair of the launch's second job
+  uint32_t job;  // uniform: which of the launch's jobs the row pair belongs to
   uint32_t x0, li[2], line[2];
   float px[2], py[2];
   bool live;
@@ -152,7 +153,7 @@ __device__ __forceinline__ bool up_step(const UpArgs &a, const UpShare &sh, uint
     if (unit == ~0u) continue;  // uniform
     uint32_t rp = sh.upr == 1u ? unit : __umulhi(unit, a.magic_upr);  // unit / upr
     const uint32_t col_unit = unit - rp * sh.upr, rp_per_job = (a.lines + 1u) / 2u;
-    st.job = rp >= rp_per_job ? 1u : 0u;
+    st.job = (rp >= rp_per_job ? 1u : 0u) + (rp >= 2u * rp_per_job ? 1u : 0u) + (rp >= 3u * rp_per_job ? 1u : 0u);  // kMaxUpJobs == 4
     rp -= st.job * rp_per_job;
     st.x0 = col_unit * kUpCols + 2u * lane;  // even
     st.live = lane < 63u && st.x0 < a.out_w;               // lane 63 has no quad; the row's last step may be short
@@ -339,7 +340,7 @@ __device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, cons
       // written whole and once.  (As two dword stores each instruction wrote every other dword and each sector went out twice,
       // half filled: WRITE_SIZE 36.7 MB for a 22.1 MB frame, profiles/r03_pmc_up.txt.)
       typedef uint32_t ph_u2v __attribute__((ext_vector_type(2)));
-      ph_u2v *dst = reinterpret_cast<ph_u2v *>(reinterpret_cast<uint4 *>(st.job ? a.out2 : a.out) + (size_t)st.line[dy] * qpl + st.x0 / 6u) + (role == 2u ? 1 : 0);
+      ph_u2v *dst = reinterpret_cast<ph_u2v *>(reinterpret_cast<uint4 *>(st.job ? a.more_out[st.job - 1u] : a.out) + (size_t)st.line[dy] * qpl + st.x0 / 6u) + (role == 2u ? 1 : 0);
       __builtin_nontemporal_store(ph_u2v{half.x, half.y}, dst);
     }
   }
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs 
       constexpr bool INSIDE = decltype(inside_tag)::value, SHARED = decltype(shared_tag)::value;
       {
         UpLayer L = a.layer[0];  // one 48-byte scalar load
-        if (st.job) L.ptr = a.ptr2[0];
+        if (st.job) L.ptr = a.more_ptr[st.job - 1u][0];
         if (!SHARED) geo = up_geo<RGB12>(L, st);
         UpPatch p;
         up_fetch<RGB12>(L, geo, p);
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs 
 #pragma unroll 1
       for (int l = 1; l < a.n; ++l) {
         UpLayer L = a.layer[l];
-        if (st.job) L.ptr = a.ptr2[l];
+        if (st.job) L.ptr = a.more_ptr[st.job - 1u][l];
         if (!SHARED) geo = up_geo<RGB12>(L, st);
         UpPatch p;
         up_fetch<RGB12>(L, geo, p);
@@ -428,6 +429,7 @@ hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
   if (e != hipSuccess) return e;
   UpArgs b = a;
+  if (!b.jobs) b.jobs = 1;
   b.out_qpitch = v210_pitch_bytes(a.out_w) / 16u;
   b.cover_w = tails ? b.out_qpitch * 6u : a.out_w;
   b.shared = 1;  // every layer has the size and the placement of the first: the patch geometry and the weights are computed once per block
@@ -436,7 +438,7 @@ hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb
     for (int k = 0; k < 6; ++k) b.shared = b.shared && a.layer[l].m[k] == a.layer[0].m[k];
   }
   const uint32_t upr = (b.cover_w + kUpCols - 1u) / kUpCols, upg = (uint32_t)(PH_UP_GROUP_ROWS / 2) * upr;
-  const uint32_t units = upr * ((a.lines + 1u) / 2u) * (a.jobs > 1u ? 2u : 1u);
+  const uint32_t units = upr * ((a.lines + 1u) / 2u) * b.jobs;
   // reciprocals for the kernel's uniform divisions: umulhi(v, ceil(2^32 / d)) == v / d while v * d < 2^32
   b.magic_upr = upr > 1 ? (uint32_t)(((1ull << 32) + upr - 1) / upr) : 0u;
   b.magic_upg = (uint32_t)(((1ull << 32) + upg - 1) / upg);

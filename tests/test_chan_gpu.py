@@ -662,3 +662,13 @@ def test_enlarged_clips_at_full_size_and_in_a_batch_call():
     small = [dict(src=Src(frames.v210_random(sw, sh, frames.layer_seed(421, 0)), sw, sh, m(ow, oh)))]
     both_routes(lambda route: check_batch([(v[0], 0, 0), (small, 0, 1), (v[1], 0, 2), (small, 1, 3), (small, 3, 3), (v[3], 0, 4)], ow, oh,
                                           "a batch call with frames of enlarged clips among its jobs, those by the %s" % route))
+
+
+def test_channels_of_enlarged_clips_share_their_launches():
+    """ph_chan_compose_batch with four channels that show clips of ONE size under ONE placement (one batched read, one launch of the
+    2 x 2-block compositor for all four), a fifth under another placement, both fields of a sixth, and the same jobs with the option off"""
+    sw, sh, ow, oh = 128, 36, 384, 54
+    clip = lambda seed, **kw: [dict(src=Src(frames.v210_random(sw, sh, frames.layer_seed(seed, 0)), sw, sh, m(ow, oh, **kw)))]
+    two = lambda seed: [dict(src=Src(frames.v210_random(sw, sh, frames.layer_seed(seed, l)), sw, sh, m(ow, oh, scale_x=1.0 - 0.3 * l, scale_y=1.0 - 0.3 * l))) for l in range(2)]
+    jobs = [(clip(430 + c), 0, c) for c in range(4)] + [(clip(435, scale_x=0.8, scale_y=0.8), 0, 4), (clip(436), 1, 5), (clip(437), 3, 5)] + [(two(440 + c), 0, 6 + c) for c in range(3)]
+    both_routes(lambda route: check_batch(jobs, ow, oh, "channels of enlarged clips in one call, by the %s" % route))

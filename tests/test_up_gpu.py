@@ -298,3 +298,44 @@ def test_720p_sources_enlarged_at_full_size():
     k.wait()
     for f in range(2):
         assert torch.equal(single[f], pair[f]), "set %d: the pair launch differs from the single one" % f
+
+
+@pytest.mark.parametrize("rgb", [False, True], ids=["rgba", "packed-rgb"])
+@pytest.mark.parametrize("shape", [(192, 54, 384, 108, 2, 0), (96, 24, 288, 124, 1, 3), (128, 36, 1280, 72, 3, 0), (1280, 720, 1920, 1080, 1, 0)])
+def test_several_channels_in_one_launch_equal_their_own_launches(shape, rgb):
+    """ph_compose_up_write_v210_batch with 3 and 4 sets of layers of one shape == ph_compose_up_write_v210 per set (and, at the small sizes,
+    == the oracle's chain for each set); more than four sets, a set placed differently and a shared output are refused"""
+    import hip_harness as hh
+    sw, sh, ow, oh, n, interlace = shape
+    k = hh.ctx()
+    wcm, wlut = hh.ColourParams.writer("709")
+    mat = m(ow, oh, scale_x=0.9, scale_y=0.9, offset_x=0.02)
+    words = frames.v210_pitch_bytes(ow) * oh // 4
+    fill = np.random.default_rng(sw + n).integers(0, 2 ** 30, words, dtype=np.int64).astype(np.uint32)
+    sets = [[opaque(sw, sh, 500 + 10 * f + l) if rgb else frames.rgba_random(sw, sh, 500 + 10 * f + l, -0.05, 1.05).reshape(sh, sw, 4) for l in range(n)] for f in range(4)]
+    dev = [[(hh.dev((np.ascontiguousarray(img[..., :3]) if rgb else img).reshape(-1)), sw, sh, mat) for img in imgs] for imgs in sets]
+    single = [hh.dev(fill.copy()) for _ in range(4)]
+    for f in range(4):
+        k.compose_up_write_v210(dev[f], single[f], ow, oh, interlace, wcm, wlut, rgb=rgb)
+    for jobs in (3, 4):
+        outs = [hh.dev(fill.copy()) for _ in range(jobs)]
+        k.compose_up_write_v210_batch(dev[:jobs], outs, ow, oh, interlace, wcm, wlut, rgb=rgb)
+        k.wait()
+        for f in range(jobs):
+            a, b = hh.host(single[f], np.uint32), hh.host(outs[f], np.uint32)
+            bad = np.flatnonzero(a != b)
+            assert bad.size == 0, "%d jobs, set %d: %d words differ from its own launch, first at %d" % (jobs, f, bad.size, bad[0])
+    if ow <= 384:
+        wr_o = (orc.rgb2ycbcr_matrix("709"), orc.linear2gamma_lut("709"))
+        for f in range(4):
+            placed = [orc.transform(img, mat, ow, oh) for img in sets[f]]
+            want = orc.v210_write(placed[0] if n == 1 else orc.combine(placed), ow, oh, interlace, *wr_o, out=fill.copy())
+            assert np.array_equal(hh.host(single[f], np.uint32), np.asarray(want).reshape(-1)), "set %d differs from the oracle" % f
+    outs = [hh.dev(fill.copy()) for _ in range(5)]
+    with pytest.raises(Exception, match="jobs"):
+        k.compose_up_write_v210_batch(dev + dev[:1], outs, ow, oh, interlace, wcm, wlut, rgb=rgb)
+    with pytest.raises(Exception, match="same output"):
+        k.compose_up_write_v210_batch(dev[:3], [outs[0], outs[1], outs[0]], ow, oh, interlace, wcm, wlut, rgb=rgb)
+    with pytest.raises(Exception, match="placed differently"):
+        other = [(t, w, h, m(ow, oh, scale_x=0.9, scale_y=0.9)) for t, w, h, _ in dev[2]]
+        k.compose_up_write_v210_batch([dev[0], dev[1], other], outs[:3], ow, oh, interlace, wcm, wlut, rgb=rgb)

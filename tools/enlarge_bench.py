@@ -40,7 +40,14 @@ def main():
     # layer l: the whole clip over the whole channel, each a little smaller than the one below so that all of them show
     mats = [capi.transform_matrix(ow, oh, scale_x=1.0 - 0.1 * l, scale_y=1.0 - 0.1 * l) for l in range(n)]
     torch.cuda.synchronize()
-    chan_jobs = [[ctx.chan_compose_v210([dict(src=(s[l], sw, sh, mats[l])) for l in range(n)], out[0], ow, oh, 0, *rd, *wr, prepare_only=True)] for s in src]
+    C = int(os.environ.get("PH_ENLARGE_CHANNELS", "1"))  # C channels' frames per ph_chan_compose_batch call (routes chan / routed only)
+    if C > 1:
+        outs = [torch.empty(owords, dtype=torch.int32, device="cuda") for _ in range(C)]
+        chan_jobs = [[ctx.chan_compose_batch([([dict(src=(src[(i + c) % R][l], sw, sh, mats[l])) for l in range(n)], outs[c], 0) for c in range(C)], ow, oh, *rd, *wr, prepare_only=True)]
+                     for i in range(R)]
+        out[0] = outs[0]
+    else:
+        chan_jobs = [[ctx.chan_compose_v210([dict(src=(s[l], sw, sh, mats[l])) for l in range(n)], out[0], ow, oh, 0, *rd, *wr, prepare_only=True)] for s in src]
     routes = {
         "chan": chan_jobs, "routed": chan_jobs,
         "_unused": [[ctx.chan_compose_v210([dict(src=(s[l], sw, sh, mats[l])) for l in range(n)], out[0], ow, oh, 0, *rd, *wr, prepare_only=True)] for s in src],
@@ -56,6 +63,8 @@ def main():
     only = os.environ.get("PH_ENLARGE_ONLY")  # one route alone (for a rocprofv3 kernel trace of it)
     if only:
         routes = {k: v for k, v in routes.items() if k in ("chan", only)}
+    if C > 1:
+        routes = {k: v for k, v in routes.items() if k in ("chan", "routed")}
     for name, jobs in routes.items():
         ctx.set_option("chan_enlarged", 0 if name == "chan" else 1)
         i, t0 = 0, time.perf_counter()
@@ -73,11 +82,11 @@ def main():
                 j()
         e1.record(stream)
         ctx.wait()
-        res[name] = round(1e3 * e0.elapsed_time(e1) / reps, 2)
+        res[name] = round(1e3 * e0.elapsed_time(e1) / reps / C, 2)
         if name == "chan":
             kept = out[0].clone()
     same = {k: bool(torch.equal(kept, out[i])) for k, i in (("routed", 0), ("read+chan", 1), ("read+up", 2)) if k in res}
-    print(json.dumps({"bench": "enlarge", "layers": n, "source": [sw, sh], "channel": [ow, oh], "us_per_frame": res, "same_frame_as_chan": same}), flush=True)
+    print(json.dumps({"bench": "enlarge", "channels_per_call": C, "layers": n, "source": [sw, sh], "channel": [ow, oh], "us_per_frame": res, "same_frame_as_chan": same}), flush=True)
     ctx.close()
 
 
