@@ -110,6 +110,7 @@ struct ChanArgs {
   // tap sharing (launcher): per sharing op and wave step of a workgroup, the converted LEFT column of the step's first lane
   // (3 rows x rgb = 36 bytes), made by a pass in front of phase 1 and kept in the LDS behind the table
   uint32_t halo_off, halo_steps;  // byte offset in the LDS; steps per op the area holds (0: no sharing in this launch)
+  uint32_t any_cm;                // launcher: some op brings a Loader matrix of its own (cm_op): the whole launch takes the general dot products
 };
 
 // Several channels' frames of ONE geometry and colour recipe in one launch (ph_chan_compose_batch) - what the reference runs: four

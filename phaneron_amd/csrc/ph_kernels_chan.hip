@@ -176,9 +176,18 @@ template <bool STD>
 __device__ __forceinline__ PxPending planar_issue(const V210Words &w, const ReadK &k, const LutK &lut) {
   return read_px_issue<STD>((float)w.wy, (float)w.wcb, (float)w.wcr, k, lut);
 }
-template <bool STD>
+// (tap sharing: see chan_sample below)
+struct ChanHalo {
+  bool on;        // uniform
+  uint32_t addr;  // LDS byte address of this step's 9 floats: rows j0, j0 + 1, j0 + 2 of column i0(lane 0), r g b each
+};
+__device__ __forceinline__ float wave_from_prev_lane(float mine, float lane0_gets) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0_gets), __float_as_int(mine), 0x138 /* wave_shr:1: lane i reads lane i - 1 */, 0xf, 0xf, false));
+}
+template <bool STD, bool SHARE = false>  // SHARE: the instantiation for programs of clips at their own scale (the others carry the plain loop only)
 __device__ __forceinline__ void chan_sample_planar(const ChanSrc &s, const void *pu, const void *pv, float px, const float (&py)[kChanP], uint32_t x,
-                                                   const uint32_t (&line)[kChanP], const ReadK &k, const LutK &lut, float4 (&out)[kChanP]) {
+                                                   const uint32_t (&line)[kChanP], const ReadK &k, const LutK &lut, float4 (&out)[kChanP],
+                                                   const ChanHalo halo = ChanHalo{false, 0u}) {
   const Planes pl = planes_of(s, pu, pv);
   if (!s.sampled) {
     PxPending pend[kChanP];
@@ -201,6 +210,69 @@ __device__ __forceinline__ void chan_sample_planar(const ChanSrc &s, const void 
     for (int p = 0; p < kChanP; ++p) out[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     return;
   }
+  // Tap sharing as for v210 sources (chan_sample): a clip shown at its own scale - a file decoder's frame on a channel of its format, the
+  // reference's everyday case (ffmpegProducer.ts:398-412) - has the lower pixel's upper taps on the upper pixel's lower taps (three source
+  // rows for the pair, not four) and lane l's left column on lane l - 1's right one (lane 0's from the halo table): three conversions
+  // per pair of pixels instead of eight.
+  static_assert(kChanP == 2, "the row sharing below is written for a pair");
+  auto load = [&](uint32_t row, uint32_t col) __attribute__((always_inline)) {  // a tap outside the frame loads zeros
+    const bool inside = row < s.h && col < s.w;
+    return planar_load(pl, inside ? row : 0u, inside ? col : kOutsideBit);  // (rows inside are below 2^24: the 24-bit products are exact)
+  };
+  // the filter on four converted taps: the sampler's border colour (0, 0, 0, 0) for taps outside (bit i of `in` clear), alpha 1 inside
+  auto blend = [&](int p, float4 (&q)[4], uint32_t in) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool inside = (in >> i) & 1u;
+      q[i].x = inside ? q[i].x : 0.0f, q[i].y = inside ? q[i].y : 0.0f, q[i].z = inside ? q[i].z : 0.0f, q[i].w = inside ? 1.0f : 0.0f;
+    }
+    const float a = t[p].a, b = t[p].b, oma = 1.0f - a, omb = 1.0f - b;
+    const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
+    out[p].x = ((w00 * q[0].x + w10 * q[1].x) + w01 * q[2].x) + w11 * q[3].x;
+    out[p].y = ((w00 * q[0].y + w10 * q[1].y) + w01 * q[2].y) + w11 * q[3].y;
+    out[p].z = ((w00 * q[0].z + w10 * q[1].z) + w01 * q[2].z) + w11 * q[3].z;
+    out[p].w = ((w00 * q[0].w + w10 * q[1].w) + w01 * q[2].w) + w11 * q[3].w;
+  };
+  auto inside_bits = [&](int p) __attribute__((always_inline)) {
+    const bool ci0 = t[p].i0 < s.w, ci1 = t[p].i0 + 1u < s.w, ri0 = t[p].j0 < s.h, ri1 = t[p].j0 + 1u < s.h;
+    return (ci0 && ri0 ? 1u : 0u) | (ci1 && ri0 ? 2u : 0u) | (ci0 && ri1 ? 4u : 0u) | (ci1 && ri1 ? 8u : 0u);
+  };
+  const bool stacked = SHARE && halo.on && __builtin_amdgcn_ballot_w64(!(t[1].i0 == t[0].i0 && t[1].j0 == t[0].j0 + 1u)) == 0;
+  if (SHARE && stacked) {  // (only ops the launcher found at their own scale get here: the others keep the plain loop below as it always was)
+    const uint32_t i0_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t[0].i0), j0_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t[0].j0);
+    const bool shared = __builtin_amdgcn_ballot_w64(!(t[0].i0 == i0_first + (threadIdx.x & 63u) && t[0].j0 == j0_first)) == 0;
+    float4 left[3], right[3];
+    if (shared) {
+      PxPending pend[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) pend[r] = planar_issue<STD>(load(j0_first + (uint32_t)r, t[0].i0 + 1u), k, lut);
+      const __attribute__((address_space(3))) float *hp = (const __attribute__((address_space(3))) float *)(uintptr_t)halo.addr;
+      float h[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) h[i] = hp[i];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        right[r] = read_px_finish(pend[r], k);
+        left[r] = make_float4(wave_from_prev_lane(right[r].x, h[3 * r]), wave_from_prev_lane(right[r].y, h[3 * r + 1]),
+                              wave_from_prev_lane(right[r].z, h[3 * r + 2]), 1.0f);
+      }
+    } else {  // three source rows for the pair, both columns converted by the lane itself
+      PxPending pend[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pend[i] = planar_issue<STD>(load(t[0].j0 + (uint32_t)(i >> 1), t[0].i0 + (uint32_t)(i & 1)), k, lut);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) left[r] = read_px_finish(pend[2 * r], k), right[r] = read_px_finish(pend[2 * r + 1], k);
+    }
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) {
+      float4 q[4] = {left[p], right[p], left[p + 1], right[p + 1]};
+      blend(p, q, inside_bits(p));
+    }
+    return;
+  }
+  // the plain loop, as it always was (a pixel's four taps converted and filtered before the next pixel's are touched)
 #pragma unroll
   for (int p = 0; p < kChanP; ++p) {
     const bool ci[2] = {t[p].i0 < s.w, t[p].i0 + 1u < s.w}, ri[2] = {t[p].j0 < s.h, t[p].j0 + 1u < s.h};
@@ -314,17 +386,10 @@ __device__ __forceinline__ void chan_sample_rgb8(const ChanSrc &s, float px, con
 // converts its RIGHT column only - three rows for its two stacked pixels - and takes its left column from the lane before it (one
 // DPP wave shift per value; lane 0 from the LDS): 3 conversions and 9 loads per pixel pair instead of 6 and 18.  The values are
 // the same conversions of the same words, so nothing changes in the result.
-struct ChanHalo {
-  bool on;        // uniform
-  uint32_t addr;  // LDS byte address of this step's 9 floats: rows j0, j0 + 1, j0 + 2 of column i0(lane 0), r g b each
-};
-__device__ __forceinline__ float wave_from_prev_lane(float mine, float lane0_gets) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0_gets), __float_as_int(mine), 0x138 /* wave_shr:1: lane i reads lane i - 1 */, 0xf, 0xf, false));
-}
-template <bool STD, bool TAILS>
+template <bool STD, bool TAILS, bool V210 = true>  // V210 = false: an instantiation whose programs have no v210 sources (images only come here)
 __device__ __forceinline__ void chan_sample(const ChanSrc &s, float px, const float (&py)[kChanP], uint32_t x, const uint32_t (&line)[kChanP],
                                             const ReadK &k, const LutK &lut, float4 (&out)[kChanP], const ChanHalo halo = ChanHalo{false, 0u}) {
-  const bool is_v210 = s.kind == kChanV210;  // uniform
+  const bool is_v210 = V210 && s.kind == kChanV210;  // uniform
   auto last_of = [&](uint32_t column) __attribute__((always_inline)) { return TAILS ? (column < s.tail_from ? 1.0f : 0.0f) : 1.0f; };
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(s.pitch * s.h), 0x00020000);
   if (!s.sampled) {  // uniform: the source has the output's size, pixel for pixel
@@ -564,7 +629,7 @@ __device__ __forceinline__ void chan_apply(const ChanOp &op, const float4 v, Cha
 // The pass in front of phase 1 for the ops that share taps (ChanHalo): one lane per (wave step of this workgroup, row) converts the
 // LEFT column of the step's first lane - the one value per row no lane of the step converts - with the arithmetic phase 1 itself
 // uses for that lane (same step -> chunk -> pixel mapping, same chan_taps), and parks r, g, b in the LDS behind the table.
-template <bool STD, bool TAILS>
+template <bool STD, bool TAILS, int SRC = 0>
 __device__ __forceinline__ void chan_halo_pass(const ChanArgs &a, const ChanShare &sh, const ReadK &rk, const LutK &rlut) {
   if (!a.halo_steps) return;
   const uint32_t steps = 3u * sh.slots < a.halo_steps ? 3u * sh.slots : a.halo_steps;
@@ -588,10 +653,21 @@ __device__ __forceinline__ void chan_halo_pass(const ChanArgs &a, const ChanShar
         const ChanTaps t = chan_taps(s, (float)(int)x / fow - 0.5f, (float)(int)line / foh - 0.5f);
         const uint32_t col = t.i0, row = t.j0 + r;
         if (col < s.w && row < s.h) {
-          const V210Col c = v210_col(col);
-          const V210Words w = v210_load(rs, __umul24(row, s.pitch) + c.g16, c);
-          const PxPending pend = v210_issue<STD>(w, c, rk, rlut, TAILS ? (col < s.tail_from ? 1.0f : 0.0f) : 1.0f);
-          v = read_px_finish(pend, rk);
+          if (SRC >= 1 && s.kind >= kChanP10) {  // uniform: a planar YCbCr clip, converted as chan_sample_planar converts it (its own Loader matrix if it has one)
+            const V210Words w = planar_load(planes_of(s, a.plane_u[k], a.plane_v[k]), row, col);
+            if (STD) {  // (no op of a launch that takes the short form has a matrix of its own: ChanArgs::any_cm)
+              v = read_px_finish(planar_issue<true>(w, rk, rlut), rk);
+            } else {
+              const float *cm = a.cm_op[k];
+              const ReadK own = load_read_k(cm ? cm : a.rd_cm, a.rd_gm);
+              v = read_px_finish(planar_issue<false>(w, own, rlut), own);
+            }
+          } else if (SRC != 2) {
+            const V210Col c = v210_col(col);
+            const V210Words w = v210_load(rs, __umul24(row, s.pitch) + c.g16, c);
+            const PxPending pend = v210_issue<STD>(w, c, rk, rlut, TAILS ? (col < s.tail_from ? 1.0f : 0.0f) : 1.0f);
+            v = read_px_finish(pend, rk);
+          }
         }
       }
       area[9u * n + 3u * r] = v.x, area[9u * n + 3u * r + 1u] = v.y, area[9u * n + 3u * r + 2u] = v.z;
@@ -600,8 +676,10 @@ __device__ __forceinline__ void chan_halo_pass(const ChanArgs &a, const ChanShar
   __syncthreads();
 }
 
-// PLANAR: the program may have planar / packed-RGB sources; TAILS: v210 frames (sources, output) may have lines that end in a tail
-template <bool STD, bool PLANAR, bool TAILS>
+// SRC: what the program's sources may be - 0: v210 frames and f32 images; 1: anything (planar, packed RGB too); 2: planar YCbCr frames and f32
+// images only (a file decoder's clips, ffmpegProducer.ts:398-412: an instantiation without the v210 and packed-RGB samplers' code and scalar
+// state); TAILS: v210 frames (sources, output) may have lines that end in a tail
+template <bool STD, int SRC, bool TAILS, bool PSHARE = false>
 __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &sh, const ReadK &rk, const LutK &rlut) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   uint2 *const index = reinterpret_cast<uint2 *>(a.index);
@@ -642,19 +720,27 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
     for (int k = 0; k < a.n_ops; ++k) {
       const ChanOp op = a.op[k];
       float4 v[kChanP];
-      if (PLANAR && op.src.kind >= kChanRgba8) {  // uniform
+      if (SRC == 1 && op.src.kind >= kChanRgba8) {  // uniform
         chan_sample_rgb8(op.src, px, py, x, line, rk, rlut, v);
-      } else if (PLANAR && op.src.kind >= kChanP10) {
+      } else if (SRC >= 1 && op.src.kind >= kChanP10) {
         // a source with code ranges of its own (8-bit) brings its Loader matrix: the general dot products serve any matrix and give
         // the same bits as the short form where that applies (its missing terms are exact zeros)
-        const float *cm = a.cm_op[k];
-        if (cm) chan_sample_planar<false>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, load_read_k(cm, a.rd_gm), rlut, v);
-        else chan_sample_planar<STD>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, rk, rlut, v);
+        // (ONE copy of the planar sampler per instantiation: a launch in which some source brings a matrix takes the general form throughout -
+        // the kernel's any_cm test - so the short form never meets one)
+        ChanHalo halo{false, 0u};
+        if ((op.action & kChanActShare) && n < a.halo_steps)  // uniform
+          halo = ChanHalo{true, a.halo_off + (((op.action >> kChanActShareShift) & 7u) * a.halo_steps + n) * 36u};
+        if (STD) {
+          chan_sample_planar<true, PSHARE>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, rk, rlut, v, halo);
+        } else {
+          const float *cm = a.cm_op[k];
+          chan_sample_planar<false, PSHARE>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, load_read_k(cm ? cm : a.rd_cm, a.rd_gm), rlut, v, halo);
+        }
       } else {
         ChanHalo halo{false, 0u};
         if ((op.action & kChanActShare) && n < a.halo_steps)  // uniform
           halo = ChanHalo{true, a.halo_off + (((op.action >> kChanActShareShift) & 7u) * a.halo_steps + n) * 36u};
-        chan_sample<STD, TAILS>(op.src, px, py, x, line, rk, rlut, v, halo);
+        chan_sample<STD, TAILS, SRC != 2>(op.src, px, py, x, line, rk, rlut, v, halo);
       }
 #pragma unroll
       for (int p = 0; p < kChanP; ++p) chan_apply(op, v[p], acc[p]);
@@ -771,13 +857,17 @@ __device__ __forceinline__ void chan_phase2_other(const ChanArgs &a, const ChanS
 }
 
 // MODE: 0 = v210 frames whose lines end on a 48-pixel block and f32 images (the fast instantiation); 1 = the same with lines that may end
-// in a tail (1280 x 720: sources and / or output); 2 = everything (planar and packed-RGB sources, frames other than v210).  An
+// in a tail (1280 x 720: sources and / or output); 2 = everything (planar and packed-RGB sources, frames other than v210); 3 = planar YCbCr
+// clips and f32 images into a v210 frame (what file playback is: ffmpegProducer.ts:398-412); 4 = the same with the clips' taps shared
+// (clips at their own scale: a program that is mostly such clips - the tap-sharing paths cost the plain loop's register allocation).  An
 // instantiation carries the scalar state of every path it contains, whether a launch takes it or not - the channel kernel's op loop
 // spills scalars to VGPR lanes (6 in mode 0, 76 in mode 2) - so 1280-wide v210 channels get one of their own.
 // OUT: the packed frame's format (0 v210; the others only with MODE 2)
 template <int MODE, int OUT = 0>
 __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a) {
-  constexpr bool PLANAR = MODE == 2, TAILS = MODE >= 1;
+  constexpr int SRC = MODE == 2 ? 1 : MODE >= 3 ? 2 : 0;
+  constexpr bool TAILS = MODE >= 1, PSHARE = MODE == 4;
+  static_assert(MODE < 3 || OUT == 0, "the planar-clips instantiations make v210 frames");
   const ReadK rk = load_read_k(a.rd_cm, a.rd_gm);
   const LutK rlut = make_lut_k(a.rd);
   const ChanShare sh = chan_share(a);
@@ -785,12 +875,12 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
   lds_lut_load(a.rd);
   __syncthreads();
   PH_CPHASE(1);
-  if (ycbcr_matrix_is_standard(rk)) {
-    chan_halo_pass<true, TAILS>(a, sh, rk, rlut);
-    chan_phase1<true, PLANAR, TAILS>(a, sh, rk, rlut);
+  if (ycbcr_matrix_is_standard(rk) && !(SRC >= 1 && a.any_cm)) {
+    chan_halo_pass<true, TAILS, SRC>(a, sh, rk, rlut);
+    chan_phase1<true, SRC, TAILS, PSHARE>(a, sh, rk, rlut);
   } else {
-    chan_halo_pass<false, TAILS>(a, sh, rk, rlut);
-    chan_phase1<false, PLANAR, TAILS>(a, sh, rk, rlut);
+    chan_halo_pass<false, TAILS, SRC>(a, sh, rk, rlut);
+    chan_phase1<false, SRC, TAILS, PSHARE>(a, sh, rk, rlut);
   }
   PH_CPHASE(2);
   __syncthreads();  // every index of this workgroup has been stored (the barrier drains the stores) and nobody reads the reader table any more
@@ -1182,9 +1272,28 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
   b.magic_cpr = cpr > 1 ? (uint32_t)(((1ull << 32) + cpr - 1) / cpr) : 0u;
   b.magic_cpg = (uint32_t)(((1ull << 32) + cpg - 1) / cpg);
   const uint32_t grid = want < num_cus ? want : num_cus;
+  b.any_cm = 0;
+  for (int k = 0; k < b.n_ops; ++k) b.any_cm |= b.cm_op[k] ? 1u : 0u;
   // Tap sharing (ChanHalo): v210 sources shown at their own scale, unrotated and unmirrored - columns and rows advance by one texel
   // per output pixel (the kernel still confirms the pattern per wave step).  Each such op needs 36 bytes of LDS per wave step of a
   // workgroup behind the table; ops that do not fit any more go without.
+  // Planar YCbCr clips share their taps in an instantiation of its own (mode 4): taken when the program has nothing but such clips and
+  // f32 images, makes a v210 frame, and at least half of its ops are clips at their own scale (a full-frame clip; not config 2's one
+  // background under three insets and a wipe: there the plain loop's better register allocation is worth more, 61.5 against 68.7 us)
+  bool clips_only = a.planar == 2 && a.out_fmt == 0;
+  uint32_t own_scale = 0;
+  for (int k = 0; k < b.n_ops; ++k) {
+    const ChanSrc &s = b.op[k].src;
+    const bool clip = s.kind >= kChanP10 && s.kind <= kChanNv12;
+    clips_only = clips_only && (clip || s.kind == kChanRgba);
+    if (clip && s.sampled && s.m[1] == 0.0f && s.m[3] == 0.0f) {
+      const float sx = s.m[0] * (float)s.w / (float)a.out_w, sy = s.m[4] * (float)s.h / (float)(a.out_h) * (float)a.line_step;
+      if (sx > 0.9999f && sx < 1.0001f && sy > 0.9999f && sy < 1.0001f) ++own_scale;
+    }
+  }
+  static const bool no_clips_kernel = getenv("PH_CHAN_NO_CLIPS_KERNEL") != nullptr;  // A/B runs (tools/chan_bench.py): mode 2 for everything planar
+  if (no_clips_kernel) clips_only = false;
+  const bool planar_share = clips_only && 2u * own_scale >= (uint32_t)b.n_ops;
   uint32_t lds_total = lds;
   b.halo_steps = 0, b.halo_off = (lds + 15u) & ~15u;
   static const bool no_share = getenv("PH_CHAN_NO_SHARE") != nullptr;  // A/B runs (tools/chan_bench.py)
@@ -1201,7 +1310,7 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
     uint32_t n_share = 0;
     for (int k = 0; k < b.n_ops && steps; ++k) {
       const ChanSrc &s = b.op[k].src;
-      if (s.kind != kChanV210 || !s.sampled || s.m[1] != 0.0f || s.m[3] != 0.0f) continue;
+      if ((s.kind != kChanV210 && !(planar_share && s.kind >= kChanP10 && s.kind <= kChanNv12)) || !s.sampled || s.m[1] != 0.0f || s.m[3] != 0.0f) continue;  // v210 clips; planar ones in their instantiation
       const float sx = s.m[0] * (float)s.w / (float)a.out_w, sy = s.m[4] * (float)s.h / (float)(a.out_h) * (float)a.line_step;
       if (!(sx > 0.9999f && sx < 1.0001f && sy > 0.9999f && sy < 1.0001f)) continue;
       if (n_share == 8u || (n_share + 1u) * steps * 36u > room) break;
@@ -1217,7 +1326,11 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
     return hipGetLastError();
   };
   switch (a.out_fmt) {  // frames other than v210 are made by the wire-format instantiation, whatever the sources
-    case 0: return a.planar == 2 ? go(chan_compose_v210_kernel<2, 0>) : a.planar == 1 ? go(chan_compose_v210_kernel<1, 0>) : go(chan_compose_v210_kernel<0, 0>);
+    case 0: {
+      if (a.planar == 2)  // a program of planar YCbCr clips (and f32 images: a wipe's mask) has instantiations of its own
+        return planar_share ? go(chan_compose_v210_kernel<4, 0>) : clips_only ? go(chan_compose_v210_kernel<3, 0>) : go(chan_compose_v210_kernel<2, 0>);
+      return a.planar == 1 ? go(chan_compose_v210_kernel<1, 0>) : go(chan_compose_v210_kernel<0, 0>);
+    }
     case 1: return go(chan_compose_v210_kernel<2, 1>);
     case 2: return go(chan_compose_v210_kernel<2, 2>);
     case 3: return go(chan_compose_v210_kernel<2, 3>);

@@ -243,7 +243,7 @@ def test_refusals():
         k.chan_compose_v210([ok], out, w, h, 0, *rd_d, wr_d[0], plain)
 
 
-def random_layers(r, ow, oh, n_layers):
+def random_layers(r, ow, oh, n_layers, with_planar=False):
     """n_layers random layers for an ow x oh channel: source sizes and formats, placements, transitions (see test_random_channel_programs)"""
     def source(must_fill=False):
         rgba = r.random() < 0.25
@@ -253,7 +253,13 @@ def random_layers(r, ow, oh, n_layers):
         else:
             w, h = int(r.choice([48, 96, 192, 288, 384])), int(r.integers(2, 40))
         seed = int(r.integers(1, 1 << 30))
-        data = frames.rgba_random(w, h, seed, -0.05, 1.05) if rgba else frames.v210_random(w, h, seed, legal=bool(r.random() < 0.7))
+        planar = None if rgba or not with_planar or r.random() < 0.6 else str(r.choice(["yuv422p10", "yuv422p8", "yuv420p", "nv12"]))
+        if planar:
+            if not one_to_one:
+                h += h & 1  # (4:2:0: an even height)
+            elif oh & 1 and planar in ("yuv420p", "nv12"):
+                planar = "yuv422p8"
+        data = frames.rgba_random(w, h, seed, -0.05, 1.05) if rgba else frames.pack_random(planar, w, h, seed) if planar else frames.v210_random(w, h, seed, legal=bool(r.random() < 0.7))
         mat = None
         if not one_to_one or r.random() < 0.5:
             kw = dict(scale_x=float(r.choice([0.3, 0.5, 1.0, 1.0, 1.7, 2.0])), scale_y=float(r.choice([0.3, 0.5, 1.0, 1.0, 1.7, 2.0])),
@@ -265,7 +271,7 @@ def random_layers(r, ow, oh, n_layers):
             if must_fill:
                 kw = dict()
             mat = m(ow, oh, **kw)
-        return Src(data, w, h, mat, "rgba" if rgba else "v210")
+        return Src(data, w, h, mat, "rgba" if rgba else planar or "v210")
     layers = []
     for l in range(n_layers):
         L = dict(src=source(must_fill=(l == 0 and r.random() < 0.5)))
@@ -672,3 +678,38 @@ def test_channels_of_enlarged_clips_share_their_launches():
     two = lambda seed: [dict(src=Src(frames.v210_random(sw, sh, frames.layer_seed(seed, l)), sw, sh, m(ow, oh, scale_x=1.0 - 0.3 * l, scale_y=1.0 - 0.3 * l))) for l in range(2)]
     jobs = [(clip(430 + c), 0, c) for c in range(4)] + [(clip(435, scale_x=0.8, scale_y=0.8), 0, 4), (clip(436), 1, 5), (clip(437), 3, 5)] + [(two(440 + c), 0, 6 + c) for c in range(3)]
     both_routes(lambda route: check_batch(jobs, ow, oh, "channels of enlarged clips in one call, by the %s" % route))
+
+
+@pytest.mark.parametrize("fmt", ["yuv422p10", "yuv422p8", "yuv420p", "nv12"])
+def test_planar_clips_at_their_own_scale(fmt):
+    """a file decoder's frame on a channel of its format under the Mixer's default fill (ffmpegProducer.ts:398-412, mixer.ts:189-228) - the
+    everyday case - shares its taps between the pixels of a pair and between neighbouring lanes as v210 clips do: alone, two such clips
+    (the upper one moved by whole and by fractional pixels), under an inset, in both fields, on frames that do not fill the chip and
+    on a 1280-wide channel (lines with tails on the output side)"""
+    for w, h in ((384, 54), (720, 60), (1280, 18)):
+        a, b = frames.pack_random(fmt, w, h, 600 + w), frames.pack_random(fmt, w, h, 601 + w)
+        v = frames.v210_random(w // 2 // 6 * 6, h // 2 // 2 * 2, frames.layer_seed(97, w))
+        fill = dict(src=Src(a, w, h, m(w, h), fmt=fmt))
+        check([fill], w, h, "%s %dx%d under the default fill" % (fmt, w, h))
+        check([fill, dict(src=Src(b, w, h, m(w, h, offset_x=8.0 / w, offset_y=-4.0 / h), fmt=fmt))], w, h, "%s: a second clip moved by whole pixels" % fmt)
+        check([fill, dict(src=Src(b, w, h, m(w, h, offset_x=0.3 / w + 0.25, offset_y=0.4 / h), fmt=fmt)),
+               dict(src=Src(v, w // 2 // 6 * 6, h // 2 // 2 * 2, m(w, h, **PIP[2])))], w, h, "%s: a clip moved by a fraction of a pixel, a v210 inset on top" % fmt, specs=("709", "2020"))
+        for interlace in (1, 3):
+            check([fill], w, h, "%s %dx%d under the default fill, field %d" % (fmt, w, h, interlace), interlace=interlace, poison_dst=True)
+
+
+def test_random_channel_programs_with_planar_clips():
+    """the random channels of test_random_channel_programs with file decoders' frames among the sources (yuv422p10 / yuv422p8 / yuv420p / nv12:
+    the kernel's planar instantiations - everything, clips only, clips with shared taps), fields included"""
+    r = np.random.default_rng(int(os.environ.get("PH_FUZZ_SEED", "20261001")))
+    sizes = [(192, 2), (192, 10), (384, 33), (576, 18), (768, 6), (960, 20), (100, 8)]
+    for case in range(int(os.environ.get("PH_FUZZ_CASES", "21"))):
+        ow, oh = sizes[case % len(sizes)]
+        interlace = int(r.choice([0, 0, 1, 3]))
+        layers = random_layers(r, ow, oh, int(r.integers(1, 6)), with_planar=True)
+        if case % 3 == 0:  # a program of planar clips at their own scale: the tap-sharing instantiation
+            h2 = oh + (oh & 1)
+            layers = [dict(src=Src(frames.pack_random(f, ow, h2 if f in ("yuv420p", "nv12") else oh, 7000 + case + i), ow, h2 if f in ("yuv420p", "nv12") else oh,
+                                   m(ow, oh, offset_x=float(i) / ow, offset_y=0.5 * i / oh), fmt=f)) for i, f in enumerate(r.choice(["yuv422p10", "yuv420p", "nv12", "yuv422p8"], 2))]
+        check(layers, ow, oh, "random channel with planar clips %d: %dx%d il %d, %d layers" % (case, ow, oh, interlace, len(layers)), interlace=interlace,
+              specs=[("709", "709"), ("709", "2020")][case % 2], poison_dst=bool(interlace))
