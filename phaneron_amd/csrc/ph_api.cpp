@@ -2074,8 +2074,8 @@ static int chan_ops(int n, const ph_chan_layer *layers, uint32_t out_w, uint32_t
 // The reference uploads a clip at its own size and lets the Mixer's transform fill the channel (src/producer/ffmpegProducer.ts:395-442,
 // mixer.ts:189-228): a 720p or SD clip on a 1080 channel, an HD clip on a 2160p one.  The channel kernel converts every TAP - four
 // conversions per output pixel - where an enlarged clip has fewer pixels than the frame it fills.  When every layer of a frame is such a
-// clip (v210, no transition, placed without rotation or mirroring, under 0.99 source texels per output pixel and written row: what
-// ph_compose_up_write_v210 takes), the frame is made by the kernels that exist for exactly this: ph_v210_read(_batch) into scratch images,
+// clip (v210 or a decoder's planar / packed-RGB frame, no transition, placed without rotation or mirroring, under 0.99 source texels per output pixel and written row: what
+// ph_compose_up_write_v210 takes), the frame is made by the kernels that exist for exactly this: ph_v210_read(_batch) / ph_pack_read into scratch images,
 // one conversion per SOURCE pixel, then ph_compose_up_write_v210 on them.  Same arithmetic, same bits (tests/test_chan_gpu.py checks both
 // routes against the chain of the reference's operators); 1280 x 720 -> 1920 x 1080: 26.4 -> 17.7 us, 1080p -> 2160p: 82 -> 38 us (tools/enlarge_bench.py).
 // Context option "chan_enlarged" = 0 (or PH_CHAN_ENLARGED=0): such frames through the channel kernel like any other (A/B runs, tests of that path).
@@ -2084,7 +2084,10 @@ static bool chan_layers_enlarged(int n, const ph_chan_layer *layers, uint32_t ou
   for (int i = 0; i < n; ++i) {
     const ph_chan_layer &L = layers[i];
     const float *m = L.src.matrix9_host;
-    if (L.transition != PH_TRANSITION_CUT || L.src.format != PH_SRC_V210 || !m || L.src.width <= 0 || L.src.height <= 0 || (L.src.width & 1)) return false;
+    // (v210 frames, a file decoder's planar frames, packed 8-bit RGB: whatever has a reader of its own - ph_v210_read, ph_pack_read)
+    if (L.transition != PH_TRANSITION_CUT || L.src.format == PH_SRC_RGBA_F32 || L.src.format < PH_SRC_V210 || L.src.format > PH_SRC_BGRA8 || !m || L.src.width <= 0 ||
+        L.src.height <= 0 || ((L.src.width & 1) && L.src.format != PH_SRC_RGBA8 && L.src.format != PH_SRC_BGRA8))
+      return false;
     if (m[1] != 0.0f || m[3] != 0.0f || !(m[0] > 0.0f) || !(m[4] > 0.0f)) return false;                      // (ph_kernels_up.hip compose_up_eligible)
     if ((double)m[0] * L.src.width > 0.99 * out_w || (double)m[4] * L.src.height * (interlace ? 2 : 1) > 0.99 * out_h) return false;
     if ((uint64_t)L.src.width * 16u * (uint64_t)L.src.height >= (1ull << 30) || L.src.width >= (1 << 22)) return false;
@@ -2139,7 +2142,20 @@ static int chan_compose_enlarged(ph_ctx *ctx, int queue, int jobs, int n, const 
   }
   int rc = PH_OK;
   const int frames = jobs * n;
-  if (one_size && frames > 1) {
+  bool all_v210 = true;
+  for (int f = 0; f < frames; ++f) all_v210 = all_v210 && layers[f / n][f % n].src.format == PH_SRC_V210;
+  if (!all_v210) {  // each clip through the reader of its format (a source with code ranges of its own brings its Loader matrix)
+    for (int f = 0; f < frames && rc == PH_OK; ++f) {
+      const ph_chan_source &S = layers[f / n][f % n].src;
+      if (S.format == PH_SRC_V210) {
+        rc = ph_v210_read(ctx, queue, S.data, imgs[f], (uint32_t)S.width, (uint32_t)S.height, rd_cm, rd_lut, rd_gm);
+      } else {
+        const void *planes[3] = {S.data, S.data_u, S.data_v};
+        rc = ph_pack_read(ctx, queue, PH_FMT_YUV422P10 + (S.format - PH_SRC_YUV422P10), planes, imgs[f], (uint32_t)S.width, (uint32_t)S.height,
+                          S.col_matrix12 ? S.col_matrix12 : rd_cm, rd_lut, rd_gm);
+      }
+    }
+  } else if (one_size && frames > 1) {
     for (int f = 0; f < frames && rc == PH_OK; f += ph::kMaxLayers)
       rc = ph_v210_read_batch(ctx, queue, frames - f < ph::kMaxLayers ? frames - f : ph::kMaxLayers, ins + f, imgs + f, (uint32_t)layers[0][0].src.width,
                               (uint32_t)layers[0][0].src.height, rd_cm, rd_lut, rd_gm);

@@ -713,3 +713,18 @@ def test_random_channel_programs_with_planar_clips():
                                    m(ow, oh, offset_x=float(i) / ow, offset_y=0.5 * i / oh), fmt=f)) for i, f in enumerate(r.choice(["yuv422p10", "yuv420p", "nv12", "yuv422p8"], 2))]
         check(layers, ow, oh, "random channel with planar clips %d: %dx%d il %d, %d layers" % (case, ow, oh, interlace, len(layers)), interlace=interlace,
               specs=[("709", "709"), ("709", "2020")][case % 2], poison_dst=bool(interlace))
+
+
+@pytest.mark.parametrize("fmt", ["yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"])
+def test_enlarged_decoder_frames_on_both_routes(fmt):
+    """a file smaller than its channel - a 720p H.264 clip (yuv420p) on a 1080 channel - by the reader of its format (ph_pack_read) + the
+    2 x 2-block compositor and by the channel kernel: one clip, two clips, a clip beside a v210 clip, fields, a 1280-wide channel"""
+    for (sw, sh, ow, oh) in ((128, 36, 192, 54), (200, 30, 384, 54), (96, 24, 1280, 30)):
+        a, b = frames.pack_random(fmt, sw, sh, 800 + sw), frames.pack_random(fmt, sw, sh, 801 + sw)
+        v = frames.v210_random(sw // 6 * 6, sh, frames.layer_seed(95, sw))
+        one = [dict(src=Src(a, sw, sh, m(ow, oh), fmt=fmt))]
+        two = one + [dict(src=Src(b, sw, sh, m(ow, oh, scale_x=0.8, scale_y=0.8, offset_x=0.1), fmt=fmt))]
+        mixed = one + [dict(src=Src(v, sw // 6 * 6, sh, m(ow, oh, scale_x=0.7, scale_y=0.7, offset_y=-0.1)))]
+        for what, layers in (("one", one), ("two", two), ("beside a v210 clip", mixed)):
+            both_routes(lambda route: check(layers, ow, oh, "%s enlarged %s clip(s) %dx%d on %dx%d by the %s" % (what, fmt, sw, sh, ow, oh, route)))
+        both_routes(lambda route: check(two, ow, oh, "two enlarged %s clips, field 3, by the %s" % (fmt, route), interlace=3, poison_dst=True, specs=("709", "2020")))

@@ -35,6 +35,16 @@ def main():
     R = int(os.environ.get("PH_ENLARGE_RING", "6"))  # sets of sources / images the routes rotate through
     swords, owords = capi.v210_pitch_bytes(sw) * sh // 4, capi.v210_pitch_bytes(ow) * oh // 4
     src = [[torch.randint(0, 2 ** 30, (swords,), dtype=torch.int32, device="cuda") for _ in range(n)] for _ in range(R)]
+    packing = os.environ.get("PH_ENLARGE_FORMAT", "v210")  # a decoder's planar frames instead (yuv422p10 | yuv422p8 | yuv420p | nv12): routes chan / routed only
+    kind = ()
+    if packing != "v210":
+        pitch = (sw + 7) // 8 * 8
+        wide = packing == "yuv422p10"
+        plane = lambda k: torch.randint(0, 1024, (k,), dtype=torch.int16, device="cuda") if wide else torch.randint(0, 256, (k,), dtype=torch.uint8, device="cuda")
+        sizes = {"yuv422p10": (pitch * sh, pitch // 2 * sh, pitch // 2 * sh), "yuv422p8": (pitch * sh, pitch // 2 * sh, pitch // 2 * sh),
+                 "yuv420p": (pitch * sh, pitch * sh // 4, pitch * sh // 4), "nv12": (pitch * sh, pitch * sh // 2)}[packing]
+        src = [[tuple(plane(k) for k in sizes) for _ in range(n)] for _ in range(R)]
+        kind = (packing, None if wide else dev(capi.ycbcr2rgb_matrix("709", 8, 16, 235, 224)))
     img = [[torch.empty(sw * sh * 4, dtype=torch.float32, device="cuda") for _ in range(n)] for _ in range(R)]
     out = [torch.empty(owords, dtype=torch.int32, device="cuda") for _ in range(3)]
     # layer l: the whole clip over the whole channel, each a little smaller than the one below so that all of them show
@@ -43,28 +53,23 @@ def main():
     C = int(os.environ.get("PH_ENLARGE_CHANNELS", "1"))  # C channels' frames per ph_chan_compose_batch call (routes chan / routed only)
     if C > 1:
         outs = [torch.empty(owords, dtype=torch.int32, device="cuda") for _ in range(C)]
-        chan_jobs = [[ctx.chan_compose_batch([([dict(src=(src[(i + c) % R][l], sw, sh, mats[l])) for l in range(n)], outs[c], 0) for c in range(C)], ow, oh, *rd, *wr, prepare_only=True)]
+        chan_jobs = [[ctx.chan_compose_batch([([dict(src=(src[(i + c) % R][l], sw, sh, mats[l]) + kind) for l in range(n)], outs[c], 0) for c in range(C)], ow, oh, *rd, *wr, prepare_only=True)]
                      for i in range(R)]
         out[0] = outs[0]
     else:
-        chan_jobs = [[ctx.chan_compose_v210([dict(src=(s[l], sw, sh, mats[l])) for l in range(n)], out[0], ow, oh, 0, *rd, *wr, prepare_only=True)] for s in src]
-    routes = {
-        "chan": chan_jobs, "routed": chan_jobs,
-        "_unused": [[ctx.chan_compose_v210([dict(src=(s[l], sw, sh, mats[l])) for l in range(n)], out[0], ow, oh, 0, *rd, *wr, prepare_only=True)] for s in src],
-        "read+chan": [[(lambda s=s, im=im: [ctx.v210_read(s[l], im[l], sw, sh, *rd) for l in range(n)]),
-                       ctx.chan_compose_v210([dict(src=(im[l], sw, sh, mats[l], "rgba")) for l in range(n)], out[1], ow, oh, 0, *rd, *wr, prepare_only=True)]
-                      for s, im in zip(src, img)],
-        "read+up": [[(lambda s=s, im=im: [ctx.v210_read(s[l], im[l], sw, sh, *rd) for l in range(n)]),
-                     ctx.compose_up_write_v210([(im[l], sw, sh, mats[l]) for l in range(n)], out[2], ow, oh, 0, *wr, prepare_only=True)]
-                    for s, im in zip(src, img)],
-    }
+        chan_jobs = [[ctx.chan_compose_v210([dict(src=(s[l], sw, sh, mats[l]) + kind) for l in range(n)], out[0], ow, oh, 0, *rd, *wr, prepare_only=True)] for s in src]
+    routes = {"chan": chan_jobs, "routed": chan_jobs}
+    if C == 1 and packing == "v210":
+        routes["read+chan"] = [[(lambda s=s, im=im: [ctx.v210_read(s[l], im[l], sw, sh, *rd) for l in range(n)]),
+                                ctx.chan_compose_v210([dict(src=(im[l], sw, sh, mats[l], "rgba")) for l in range(n)], out[1], ow, oh, 0, *rd, *wr, prepare_only=True)]
+                               for s, im in zip(src, img)]
+        routes["read+up"] = [[(lambda s=s, im=im: [ctx.v210_read(s[l], im[l], sw, sh, *rd) for l in range(n)]),
+                              ctx.compose_up_write_v210([(im[l], sw, sh, mats[l]) for l in range(n)], out[2], ow, oh, 0, *wr, prepare_only=True)]
+                             for s, im in zip(src, img)]
     res = {}
-    routes.pop("_unused")
     only = os.environ.get("PH_ENLARGE_ONLY")  # one route alone (for a rocprofv3 kernel trace of it)
     if only:
         routes = {k: v for k, v in routes.items() if k in ("chan", only)}
-    if C > 1:
-        routes = {k: v for k, v in routes.items() if k in ("chan", "routed")}
     for name, jobs in routes.items():
         ctx.set_option("chan_enlarged", 0 if name == "chan" else 1)
         i, t0 = 0, time.perf_counter()
@@ -86,7 +91,7 @@ def main():
         if name == "chan":
             kept = out[0].clone()
     same = {k: bool(torch.equal(kept, out[i])) for k, i in (("routed", 0), ("read+chan", 1), ("read+up", 2)) if k in res}
-    print(json.dumps({"bench": "enlarge", "channels_per_call": C, "layers": n, "source": [sw, sh], "channel": [ow, oh], "us_per_frame": res, "same_frame_as_chan": same}), flush=True)
+    print(json.dumps({"bench": "enlarge", "channels_per_call": C, "format": packing, "layers": n, "source": [sw, sh], "channel": [ow, oh], "us_per_frame": res, "same_frame_as_chan": same}), flush=True)
     ctx.close()
 
 

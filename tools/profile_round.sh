@@ -116,7 +116,10 @@ $ROOT/tools/opbench4 > $OUT/${TAG}_opbench4.jsonl 2>/dev/null
 python $ROOT/tools/route_bench.py --loopback 2>/dev/null | grep '^{' > $OUT/${TAG}_route_loopback.jsonl
 # clips smaller than their channel (read + 2 x 2-block compositor inside ph_chan_compose*), alone and 2 / 4 channels per call; config 3 in the reference's own formats
 (for args in "500 1 1280 720 1920 1080" "500 1 720 576 1920 1080" "500 2 1280 720 1920 1080" "500 4 1280 720 1920 1080" "500 1 1920 1080 3840 2160" "500 2 1920 1080 3840 2160" "500 4 1920 1080 3840 2160" "500 1 720 576 1280 720" "500 1 1280 720 3840 2160"; do python $ROOT/tools/enlarge_bench.py $args; done;
- for C in 2 4; do for args in "500 1 1280 720 1920 1080" "500 2 1280 720 1920 1080" "500 1 720 576 1280 720"; do PH_ENLARGE_CHANNELS=$C python $ROOT/tools/enlarge_bench.py $args; done; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_enlarge_bench.jsonl
+ for C in 2 4; do for args in "500 1 1280 720 1920 1080" "500 2 1280 720 1920 1080" "500 1 720 576 1280 720"; do PH_ENLARGE_CHANNELS=$C python $ROOT/tools/enlarge_bench.py $args; done; done;
+ for f in yuv420p yuv422p10 nv12; do PH_ENLARGE_FORMAT=$f python $ROOT/tools/enlarge_bench.py 500 1 1280 720 1920 1080; done; PH_ENLARGE_FORMAT=yuv420p python $ROOT/tools/enlarge_bench.py 500 1 720 576 1920 1080;
+ PH_ENLARGE_FORMAT=yuv420p python $ROOT/tools/enlarge_bench.py 500 2 1280 720 1920 1080; PH_ENLARGE_FORMAT=yuv422p10 python $ROOT/tools/enlarge_bench.py 500 1 1920 1080 3840 2160;
+ PH_ENLARGE_CHANNELS=4 PH_ENLARGE_FORMAT=yuv420p python $ROOT/tools/enlarge_bench.py 500 1 1280 720 1920 1080) 2>/dev/null | grep '^{' > $OUT/${TAG}_enlarge_bench.jsonl
 python $ROOT/tools/config3b_bench.py 300 2>/dev/null | grep '^{' > $OUT/${TAG}_config3b.json
 python $ROOT/tools/staging_bench.py 60 2>/dev/null | grep '^{' > $OUT/${TAG}_staging_bench.jsonl
 $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
