@@ -287,8 +287,9 @@ int ph_v210_yadif_pair_fmt(ph_ctx *ctx, int queue, int n, const ph_deint_source 
                            int tff, int skip_spatial, int out_format, const void *rd_col_matrix12, const void *rd_gamma_lut,
                            const void *rd_gamut_matrix9);
 /* the same over windows of interlaced FILE frames: packing = PH_FMT_YUV422P10 or PH_FMT_YUV422P8 (planar 4:2:2, what decoders of
- * XDCAM / ProRes / DNxHD material hand over; every source of the call in that packing, unpacked with the call's Loader recipe - for
- * the 8-bit packing the 8-bit Loader's matrix), or PH_FMT_V210 (= the call above) */
+ * XDCAM / ProRes / DNxHD material hand over), PH_FMT_YUV420P or PH_FMT_NV12 (4:2:0: interlaced H.264 / MPEG-2; nv12: *_u are the
+ * interleaved CbCr planes, *_v unused; even heights) - every source of the call in that packing, unpacked with the call's Loader recipe
+ * (for the 8-bit packings the 8-bit Loader's matrix) - or PH_FMT_V210 (= the call above) */
 int ph_yadif_pair_packed(ph_ctx *ctx, int queue, int n, const ph_deint_source *sources, int packing, uint32_t width, uint32_t height,
                          int tff, int skip_spatial, int out_format, const void *rd_col_matrix12, const void *rd_gamma_lut,
                          const void *rd_gamut_matrix9);

@@ -424,13 +424,13 @@ class Deferral {
 	// fit (one field only, an image of the window already real, mixed sizes) is left to run as recorded.
 	_deinterlace(layerImages) {
 		const found = new Map() // cur image -> { windows of wire-format sources, the two yadif nodes }
-		const PACKING = { v210: 0, yuv422p10: 1, yuv422p8: 2 } // SDI frames, or planar 4:2:2 frames of interlaced files
+		const PACKING = { v210: 0, yuv422p10: 1, yuv422p8: 2, yuv420p: 3, nv12: 4 } // SDI frames, or the planar frames of interlaced files (PH_FMT_*)
 		// the wire-format frame behind an image of the window: [planes], if it is a pending ToRGBA of `fmt` with the window's Loader recipe
 		const framesOf = (img, w, h, reader, fmt) => {
 			const p = img && img._producer
 			if (!p || p.state !== 'pending' || p.program.name !== 'read' || p.program.format !== fmt) return null
 			const q = p.params
-			const planes = fmt === 'v210' ? [q.input] : [q.inputY, q.inputU, q.inputV]
+			const planes = fmt === 'v210' ? [q.input] : fmt === 'nv12' ? [q.inputY, q.inputC] : [q.inputY, q.inputU, q.inputV]
 			if (planes.some((b) => !b)) return null
 			// a frame that is itself the pending result of a recorded job (a packed frame made on the device and read back) is made
 			// real first: the fused launch reads the planes, not the images (ADVICE r3)
@@ -480,7 +480,8 @@ class Deferral {
 			g.forEach((e, i) => {
 				;['Prev', 'Cur', 'Next'].forEach((which, f) => {
 					params[`l${i}${which}`] = e.src[f][0]
-					if (e.src[f].length === 3) { params[`l${i}${which}U`] = e.src[f][1]; params[`l${i}${which}V`] = e.src[f][2] }
+					if (e.src[f].length >= 2) params[`l${i}${which}U`] = e.src[f][1] // (nv12: the interleaved CbCr plane)
+					if (e.src[f].length === 3) params[`l${i}${which}V`] = e.src[f][2]
 				})
 				params[`l${i}Out0`] = e.out[0]; params[`l${i}Out1`] = e.out[1]
 			})

@@ -596,11 +596,11 @@ async function main() {
 		return seen
 	}, { fused: 6, plain: 0, launched: 6, fallbacks: 0 })
 
-	// interlaced file sources: windows of planar 4:2:2 frames (yuv422p10, yuv422p8), both fields de-interlaced, placed, packed
+	// interlaced file sources: windows of planar frames (4:2:2: yuv422p10, yuv422p8; 4:2:0: yuv420p, nv12 - interlaced H.264), both fields de-interlaced, placed, packed
 	await scenario('interlaced file sources: planar windows de-interlaced', async (s) => {
 		s.frame = 20
 		const seen = []
-		for (const fmt of ['yuv422p10', 'yuv422p8']) {
+		for (const fmt of ['yuv422p10', 'yuv422p8', 'yuv420p', 'nv12']) {
 			const win = []
 			const u = []
 			for (let i = 0; i < 3; ++i) {
@@ -633,7 +633,7 @@ async function main() {
 			;[...win.flat(), ...u, bg, ubg].forEach((x) => x.release())
 		}
 		return seen
-	}, { fused: 6, plain: 0, launched: 6, fallbacks: 0 })
+	}, { fused: 12, plain: 0, launched: 12, fallbacks: 0 })
 
 	// a packed frame made on the device and unpacked again (a channel whose consumer's frame feeds another channel's producer):
 	// write -> read -> write.  The second frame's fused launch reads `mid` itself, so the job that makes `mid` must run first

@@ -402,14 +402,14 @@ class Context:
                         prepare_only=False, packing="v210"):
         """sources: [(prev, cur, next, dst_parity0, dst_parity1)] - v210 windows in, both de-interlaced fields out (f32 RGBA,
         or with rgb=True packed f32 RGB, 12 bytes per pixel); == v210_read x 3 -> yadif x 2 per source, as one kernel.
-        packing "yuv422p10" / "yuv422p8": prev, cur, next are (y, u, v) plane triples (ph_yadif_pair_packed)"""
+        packing "yuv422p10" / "yuv422p8" / "yuv420p": prev, cur, next are (y, u, v) plane triples, "nv12": (y, cbcr) pairs (ph_yadif_pair_packed)"""
         arr = (PhDeintSource * len(sources))()
         for i, s in enumerate(sources):
             if packing == "v210":
                 arr[i].prev, arr[i].cur, arr[i].next = (_ptr(b).value for b in s[:3])
-            else:
+            else:  # (nv12: two planes per frame - Y and the interleaved CbCr plane)
                 (arr[i].prev, arr[i].prev_u, arr[i].prev_v), (arr[i].cur, arr[i].cur_u, arr[i].cur_v), (arr[i].next, arr[i].next_u, arr[i].next_v) = (
-                    tuple(_ptr(p).value for p in frame) for frame in s[:3])
+                    (tuple(_ptr(p).value for p in frame) + (None,))[:3] for frame in s[:3])
             arr[i].out_parity0, arr[i].out_parity1 = _ptr(s[3]).value, _ptr(s[4]).value
         args = (self.h, queue, len(sources), arr, FORMATS[packing], width, height, int(tff), int(skip_spatial), IMG_RGB_F32 if rgb else IMG_RGBA_F32,
                 _ptr(col_matrix), _ptr(lut), _ptr(gamut))

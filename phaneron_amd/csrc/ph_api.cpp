@@ -1386,12 +1386,13 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
       double tff, skip, rgb = 0, packing = 0;  // packedRgb (optional): 1 = the outputs are packed f32 RGB (12 bytes per pixel) for compose_up_write_v210_<n>
       if (find_arg(args, n, "packedRgb")) TRY(need_num(args, n, "packedRgb", &rgb));
-      // packing (optional): 1 yuv422p10 / 2 yuv422p8 - the windows are planar 4:2:2 frames: l<i>Prev / Cur / Next their Y planes,
+      // packing (optional): 1 yuv422p10 / 2 yuv422p8 / 3 yuv420p / 4 nv12 - the windows are planar frames: l<i>Prev / Cur / Next their Y planes,
       // l<i>PrevU, l<i>PrevV, l<i>CurU ... their chroma planes
       if (find_arg(args, n, "packing")) TRY(need_num(args, n, "packing", &packing));
       const int pfmt = (int)packing;
       size_t pb[3] = {0, 0, 0};
-      if (pfmt != PH_FMT_V210 && pfmt != PH_FMT_YUV422P10 && pfmt != PH_FMT_YUV422P8) return fail(PH_E_INVALID, "kernel argument 'packing': %g (0 v210, 1 yuv422p10, 2 yuv422p8)", packing);
+      if (pfmt != PH_FMT_V210 && pfmt != PH_FMT_YUV422P10 && pfmt != PH_FMT_YUV422P8 && pfmt != PH_FMT_YUV420P && pfmt != PH_FMT_NV12)
+        return fail(PH_E_INVALID, "kernel argument 'packing': %g (0 v210, 1 yuv422p10, 2 yuv422p8, 3 yuv420p, 4 nv12)", packing);
       ph_pack_plane_bytes(pfmt, width, height, pb);
       const size_t vb = pb[0], img = (size_t)width * height * (rgb != 0 ? 12 : 16);
       ph_deint_source src[ph::kMaxLayers];
@@ -1403,7 +1404,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
           static const char *const which[3] = {"Prev", "Cur", "Next"};
           const void **slots[3][2] = {{&src[i].prev_u, &src[i].prev_v}, {&src[i].cur_u, &src[i].cur_v}, {&src[i].next_u, &src[i].next_v}};
           for (int f = 0; f < 3; ++f)
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < (pfmt == PH_FMT_NV12 ? 1 : 2); ++c) {  // (nv12: l<i>PrevU ... are the interleaved CbCr planes)
               snprintf(nm, sizeof nm, "l%d%s%c", i, which[f], c ? 'V' : 'U');
               TRY(need_buf(args, n, nm, pb[1 + c], &x));
               *slots[f][c] = x->dptr;
@@ -2440,8 +2441,10 @@ int ph_v210_yadif_pair_fmt(ph_ctx *ctx, int queue, int n, const ph_deint_source 
 int ph_yadif_pair_packed(ph_ctx *ctx, int queue, int n, const ph_deint_source *src, int packing, uint32_t width, uint32_t height, int tff,
                          int skip, int out_format, const void *cm, const void *lut, const void *gm) {
   if (!ctx || !src || !cm || !lut || !gm) return fail(PH_E_INVALID, "ph_v210_yadif_pair: NULL argument");
-  if (packing != PH_FMT_V210 && packing != PH_FMT_YUV422P10 && packing != PH_FMT_YUV422P8)
-    return fail(PH_E_INVALID, "ph_v210_yadif_pair: packing %d (v210, yuv422p10 or yuv422p8; run the separate kernels for the others)", packing);
+  if (packing != PH_FMT_V210 && packing != PH_FMT_YUV422P10 && packing != PH_FMT_YUV422P8 && packing != PH_FMT_YUV420P && packing != PH_FMT_NV12)
+    return fail(PH_E_INVALID, "ph_v210_yadif_pair: packing %d (v210 or a planar YCbCr format; run the separate kernels for the others)", packing);
+  if ((packing == PH_FMT_YUV420P || packing == PH_FMT_NV12) && (height & 1))
+    return fail(PH_E_INVALID, "ph_v210_yadif_pair: a 4:2:0 frame needs an even height (%u)", height);
   const bool planar = packing != PH_FMT_V210;
   if (out_format != PH_IMG_RGBA_F32 && out_format != PH_IMG_RGB_F32) return fail(PH_E_INVALID, "ph_v210_yadif_pair: output format %d", out_format);
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_v210_yadif_pair: 1..%d sources", ph::kMaxLayers);
@@ -2458,12 +2461,13 @@ int ph_yadif_pair_packed(ph_ctx *ctx, int queue, int n, const ph_deint_source *s
     a.prev[i] = (const uint4 *)s.prev, a.cur[i] = (const uint4 *)s.cur, a.next[i] = (const uint4 *)s.next;
     a.out0[i] = (float4 *)s.out_parity0, a.out1[i] = (float4 *)s.out_parity1;
     if (planar) {
-      if (!s.prev_u || !s.prev_v || !s.cur_u || !s.cur_v || !s.next_u || !s.next_v) return fail(PH_E_INVALID, "ph_v210_yadif_pair: source %d: a planar window needs its chroma planes", i);
+      if (!s.prev_u || !s.cur_u || !s.next_u || (packing != PH_FMT_NV12 && (!s.prev_v || !s.cur_v || !s.next_v)))
+        return fail(PH_E_INVALID, "ph_v210_yadif_pair: source %d: a planar window needs its chroma planes", i);
       a.prev_u[i] = s.prev_u, a.prev_v[i] = s.prev_v, a.cur_u[i] = s.cur_u, a.cur_v[i] = s.cur_v, a.next_u[i] = s.next_u, a.next_v[i] = s.next_v;
     }
   }
   if (!height) return PH_OK;
-  a.pack = packing == PH_FMT_V210 ? 0u : packing == PH_FMT_YUV422P10 ? 1u : 2u;
+  a.pack = packing == PH_FMT_V210 ? 0u : packing == PH_FMT_YUV422P10 ? 1u : packing == PH_FMT_YUV422P8 ? 2u : packing == PH_FMT_YUV420P ? 3u : 4u;
   // quads_pitch: a v210 line in 16-byte quads, or (planar) the luma samples per line: the width rounded up to 8 (yuv422p10.ts:221)
   a.n = n, a.skip = skip ? 1 : 0, a.width = width, a.height = height, a.quads_pitch = planar ? ((width + 7u) & ~7u) : ph_v210_pitch_bytes(width) / 16;
   a.rgb12 = out_format == PH_IMG_RGB_F32 ? 1u : 0u;

@@ -79,9 +79,12 @@ __device__ __forceinline__ RawPx load_row_px(__amdgpu_buffer_rsrc_t frame, uint3
                (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(frame, (int)p.off_cb, row, 0),
                (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(frame, (int)p.off_cr, row, 0)};
 }
+// PACK: 1 yuv422p10 (16-bit samples), 2 yuv422p8, 3 yuv420p (a chroma line serves two luma lines: yuv420p.ts), 4 nv12 (the same with Cb and Cr
+// interleaved in one plane: nv12.ts:61-74; FramePlanes::v is u, the lane's offsets the pair's two bytes)
 template <int PACK>
 __device__ __forceinline__ RawPx load_row_planar(const FramePlanes &f, uint32_t pitch_y, int line, const LanePick &p) {
-  const int row_y = (int)((uint32_t)line * pitch_y), row_c = (int)((uint32_t)line * (pitch_y >> 1));  // uniform
+  const int row_y = (int)((uint32_t)line * pitch_y);  // uniform
+  const int row_c = PACK >= 3 ? (int)(((uint32_t)line >> 1) * (PACK == 4 ? pitch_y : pitch_y >> 1)) : (int)((uint32_t)line * (pitch_y >> 1));
   if (PACK == 1)
     return RawPx{(uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(f.y, (int)p.off_y, row_y, 0),
                  (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(f.u, (int)p.off_cb, row_c, 0),
@@ -124,9 +127,12 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
     auto planes = [&](const uint4 *y, const void *u, const void *v) __attribute__((always_inline)) {
       FramePlanes f;
       f.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(y), 0, frame_bytes, 0x00020000);
-      if (PACK) {
-        f.u = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(u), 0, frame_bytes / 2, 0x00020000);
-        f.v = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(v), 0, frame_bytes / 2, 0x00020000);
+      if (PACK == 4) {  // nv12: (height + 1) / 2 lines of CbCr pairs, a luma line's bytes each
+        f.u = f.v = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(u), 0, (int)(line_bytes * ((a.height + 1u) >> 1)), 0x00020000);
+      } else if (PACK) {  // 4:2:2: half a luma line per line; 4:2:0: that for every other line
+        const int chroma_bytes = PACK == 3 ? (int)((line_bytes >> 1) * ((a.height + 1u) >> 1)) : frame_bytes / 2;
+        f.u = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(u), 0, chroma_bytes, 0x00020000);
+        f.v = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(v), 0, chroma_bytes, 0x00020000);
       } else {
         f.u = f.v = f.y;
       }
@@ -138,7 +144,8 @@ __device__ __forceinline__ void v210_yadif_pair_body(const DeintArgs &a, const R
     float4 *__restrict__ out0 = a.out0[l], *__restrict__ out1 = a.out1[l];
     const int xr = (int)(cb * kDeintCols) - 3 + (int)lane, x = clampi(xr, 0, w - 1);  // CLAMP_TO_EDGE
     const bool emit = lane >= 3 && lane < 64 - 3 && xr < w;
-    const LanePick pick = PACK == 0 ? lane_pick((uint32_t)x) : PACK == 1 ? lane_pick_planar<2>((uint32_t)x) : lane_pick_planar<1>((uint32_t)x);
+    LanePick pick = PACK == 0 ? lane_pick((uint32_t)x) : PACK == 1 ? lane_pick_planar<2>((uint32_t)x) : lane_pick_planar<1>((uint32_t)x);
+    if (PACK == 4) pick.off_cb = (uint32_t)x & ~1u, pick.off_cr = pick.off_cb + 1u;
     const int y0 = (int)(strip * a.rows_per_strip), y_end = (y0 + (int)a.rows_per_strip < h) ? y0 + (int)a.rows_per_strip : h;
     auto raw = [&](const FramePlanes &frame, int y) {
       return PACK == 0 ? load_row_px(frame.y, line_bytes, clampi(y, 0, h - 1), pick) : load_row_planar<PACK>(frame, line_bytes, clampi(y, 0, h - 1), pick);
@@ -254,6 +261,8 @@ hipError_t launch_v210_yadif_pair(hipStream_t s, DeintArgs a, int tff, uint32_t 
     case 0: return tff ? go(v210_yadif_pair_kernel<1, 0>) : go(v210_yadif_pair_kernel<0, 0>);
     case 1: return tff ? go(v210_yadif_pair_kernel<1, 1>) : go(v210_yadif_pair_kernel<0, 1>);
     case 2: return tff ? go(v210_yadif_pair_kernel<1, 2>) : go(v210_yadif_pair_kernel<0, 2>);
+    case 3: return tff ? go(v210_yadif_pair_kernel<1, 3>) : go(v210_yadif_pair_kernel<0, 3>);
+    case 4: return tff ? go(v210_yadif_pair_kernel<1, 4>) : go(v210_yadif_pair_kernel<0, 4>);
   }
   return hipErrorInvalidValue;
 }

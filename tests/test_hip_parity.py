@@ -212,7 +212,7 @@ def test_v210_yadif_pair_vs_oracle(w, h, n, lut_path):
         hh.ctx().v210_yadif_pair([(hh.dev(wins[0][0]), hh.dev(wins[0][1]), hh.dev(wins[0][2]), outs[0][0], outs[0][0])], w, h, 1, False, rcm, rlut, rgm)
 
 
-@pytest.mark.parametrize("fmt", ["yuv422p10", "yuv422p8"])
+@pytest.mark.parametrize("fmt", ["yuv422p10", "yuv422p8", "yuv420p", "nv12"])
 @pytest.mark.parametrize("w,h,n", [(1920, 64, 2), (100, 33, 3), (346, 17, 1), (2, 2, 1)])
 def test_planar_yadif_pair_vs_oracle(fmt, w, h, n, lut_path):
     """windows of interlaced FILE frames (planar 4:2:2, what decoders of XDCAM / ProRes material hand over): the fused de-interlacing
@@ -222,6 +222,8 @@ def test_planar_yadif_pair_vs_oracle(fmt, w, h, n, lut_path):
     from phaneron_amd import capi
     if lut_path == "global_lut":  # the fused de-interlacing reader exists in the LDS-table form only (its refusal is checked with v210 above)
         return
+    if fmt in ("yuv420p", "nv12"):
+        h += h & 1  # (4:2:0: a chroma line serves two luma lines - even heights)
     _, rlut, rgm = hh.ColourParams.reader("709", "2020")
     rng = orc.FORMAT_RANGE[fmt]
     rcm = hh.dev(capi.ycbcr2rgb_matrix("709", *rng))
