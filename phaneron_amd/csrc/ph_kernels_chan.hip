@@ -862,12 +862,11 @@ __device__ __forceinline__ void chan_phase2_other(const ChanArgs &a, const ChanS
 // (clips at their own scale: a program that is mostly such clips - the tap-sharing paths cost the plain loop's register allocation).  An
 // instantiation carries the scalar state of every path it contains, whether a launch takes it or not - the channel kernel's op loop
 // spills scalars to VGPR lanes (6 in mode 0, 76 in mode 2) - so 1280-wide v210 channels get one of their own.
-// OUT: the packed frame's format (0 v210; the others only with MODE 2)
+// OUT: the packed frame's format (PH_FMT_*: 0 v210; 2 yuv422p8 and 5 rgba8 - the other consumers' - with the lean modes too; the rest only with MODE 2)
 template <int MODE, int OUT = 0>
 __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a) {
   constexpr int SRC = MODE == 2 ? 1 : MODE >= 3 ? 2 : 0;
   constexpr bool TAILS = MODE >= 1, PSHARE = MODE == 4;
-  static_assert(MODE < 3 || OUT == 0, "the planar-clips instantiations make v210 frames");
   const ReadK rk = load_read_k(a.rd_cm, a.rd_gm);
   const LutK rlut = make_lut_k(a.rd);
   const ChanShare sh = chan_share(a);
@@ -1280,7 +1279,8 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
   // Planar YCbCr clips share their taps in an instantiation of its own (mode 4): taken when the program has nothing but such clips and
   // f32 images, makes a v210 frame, and at least half of its ops are clips at their own scale (a full-frame clip; not config 2's one
   // background under three insets and a wipe: there the plain loop's better register allocation is worth more, 61.5 against 68.7 us)
-  bool clips_only = a.planar == 2 && a.out_fmt == 0;
+  const bool lean_out = a.out_fmt == 0 || a.out_fmt == 2 || a.out_fmt == 5;  // v210 (SDI), yuv422p8 (an encoder), rgba8 (the screen): the reference's three consumers
+  bool clips_only = a.planar == 2 && lean_out;
   uint32_t own_scale = 0;
   for (int k = 0; k < b.n_ops; ++k) {
     const ChanSrc &s = b.op[k].src;
@@ -1325,17 +1325,22 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
     kernel<<<grid, kLdsBlock, lds_total, s>>>(b);
     return hipGetLastError();
   };
-  switch (a.out_fmt) {  // frames other than v210 are made by the wire-format instantiation, whatever the sources
-    case 0: {
-      if (a.planar == 2)  // a program of planar YCbCr clips (and f32 images: a wipe's mask) has instantiations of its own
-        return planar_share ? go(chan_compose_v210_kernel<4, 0>) : clips_only ? go(chan_compose_v210_kernel<3, 0>) : go(chan_compose_v210_kernel<2, 0>);
-      return a.planar == 1 ? go(chan_compose_v210_kernel<1, 0>) : go(chan_compose_v210_kernel<0, 0>);
-    }
+  // The writer's phase is independent of the readers': the lean instantiations of phase 1 (v210 / image programs on whole 48-pixel blocks;
+  // planar clips; planar clips with shared taps) exist for the frames of the reference's three consumers - v210 (macadamConsumer.ts:165),
+  // yuv422p8 (ffmpegConsumer.ts:144), rgba8 (screenConsumer.ts:131); the other formats and v210 lines with tails take the "everything" one
+  auto lean = [&](auto out_tag) -> hipError_t {
+    constexpr int O = decltype(out_tag)::value;
+    if (a.planar == 2) return planar_share ? go(chan_compose_v210_kernel<4, O>) : clips_only ? go(chan_compose_v210_kernel<3, O>) : go(chan_compose_v210_kernel<2, O>);
+    if (a.planar == 1) return O == 0 ? go(chan_compose_v210_kernel<1, 0>) : go(chan_compose_v210_kernel<2, O>);
+    return go(chan_compose_v210_kernel<0, O>);
+  };
+  switch (a.out_fmt) {
+    case 0: return lean(std::integral_constant<int, 0>{});
     case 1: return go(chan_compose_v210_kernel<2, 1>);
-    case 2: return go(chan_compose_v210_kernel<2, 2>);
+    case 2: return lean(std::integral_constant<int, 2>{});
     case 3: return go(chan_compose_v210_kernel<2, 3>);
     case 4: return go(chan_compose_v210_kernel<2, 4>);
-    case 5: return go(chan_compose_v210_kernel<2, 5>);
+    case 5: return lean(std::integral_constant<int, 5>{});
     case 6: return go(chan_compose_v210_kernel<2, 6>);
   }
   return hipErrorInvalidValue;

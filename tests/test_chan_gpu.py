@@ -728,3 +728,19 @@ def test_enlarged_decoder_frames_on_both_routes(fmt):
         for what, layers in (("one", one), ("two", two), ("beside a v210 clip", mixed)):
             both_routes(lambda route: check(layers, ow, oh, "%s enlarged %s clip(s) %dx%d on %dx%d by the %s" % (what, fmt, sw, sh, ow, oh, route)))
         both_routes(lambda route: check(two, ow, oh, "two enlarged %s clips, field 3, by the %s" % (fmt, route), interlace=3, poison_dst=True, specs=("709", "2020")))
+
+
+@pytest.mark.parametrize("out", ["yuv422p8", "rgba8", "yuv422p10"])
+@pytest.mark.parametrize("src", ["v210", "yuv420p", "yuv422p10"])
+def test_other_consumers_frames_from_every_kind_of_program(src, out):
+    """the encoder's and the screen's frames (ffmpegConsumer.ts:144 yuv422p8, screenConsumer.ts:131 rgba8; yuv422p10 for comparison: the
+    "everything" instantiation) from programs of v210 clips, of planar clips under the default fill (shared taps) and of placed planar
+    clips: the kernel's lean instantiations with another writer behind them"""
+    w, h = 384, 54
+    def clip(seed, ww, hh_, **kw):
+        data = frames.v210_random(ww, hh_, frames.layer_seed(seed, 0)) if src == "v210" else frames.pack_random(src, ww, hh_, seed)
+        return dict(src=Src(data, ww, hh_, m(w, h, **kw), fmt=src))
+    for interlace in (0, 3):
+        check_format([clip(900, w, h)], w, h, out, "%s clip under the default fill -> %s il %d" % (src, out, interlace), interlace=interlace)
+        check_format([clip(901, w, h), clip(902, 192, 30, **PIP[1]), clip(903, 192, 30, scale_x=0.4, scale_y=0.4, rotate=0.1, offset_x=0.2)], w, h, out,
+                     "%s clips placed -> %s il %d" % (src, out, interlace), interlace=interlace)

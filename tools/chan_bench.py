@@ -33,6 +33,12 @@ def main():
     words = capi.v210_pitch_bytes(w) * h // 4
     src = [[torch.randint(0, 2 ** 30, (words,), dtype=torch.int32, device="cuda") for _ in range(6)] for _ in range(R)]
     out = torch.empty(words, dtype=torch.int32, device="cuda")
+    out_fmt = os.environ.get("PH_CHAN_BENCH_OUT", "v210")  # another consumer's frame: yuv422p8 (ffmpegConsumer.ts:144), rgba8 (screenConsumer.ts:131), yuv422p10
+    if out_fmt in ("yuv422p8", "yuv422p10"):
+        dt = torch.uint8 if out_fmt == "yuv422p8" else torch.int16
+        out = (torch.empty(w * h, dtype=dt, device="cuda"), torch.empty(w * h // 2, dtype=dt, device="cuda"), torch.empty(w * h // 2, dtype=dt, device="cuda"))
+    elif out_fmt in ("rgba8", "bgra8"):
+        out = (torch.empty(w * h, dtype=torch.int32, device="cuda"),)
     kind = ()
     if packing != "v210":  # planar sources (file decoders' formats); the 8-bit ones bring a Loader matrix of their own
         pitch = (w + 7) // 8 * 8
@@ -64,7 +70,7 @@ def main():
         outs = [torch.empty(words, dtype=torch.int32, device="cuda") for _ in range(C)]
         jobs = [ctx.chan_compose_batch([(layers(src[(i + j) % R]), outs[j], 0) for j in range(C)], w, h, *rd, *wr, prepare_only=True) for i in range(R)]
     else:
-        jobs = [ctx.chan_compose_v210(layers(s), out, w, h, 0, *rd, *wr, prepare_only=True) for s in src]
+        jobs = [ctx.chan_compose_v210(layers(s), out, w, h, 0, *rd, *((None, wr[1]) if out_fmt in ("rgba8", "bgra8") else wr), prepare_only=True, out_fmt=out_fmt) for s in src]
     import time
     i, t0 = 0, time.perf_counter()
     while i < 8 or time.perf_counter() - t0 < 0.15:  # until the chip's clocks have settled (tools/config_bench.py timeit)
@@ -79,7 +85,7 @@ def main():
         jobs[i % R]()
     e1.record(stream)
     ctx.wait()
-    print(json.dumps({"kernel": "chan_compose_v210", "width": w, "height": h, "variant": variant, "mask": mask_kind, "sources": packing, "jobs_per_launch": C,
+    print(json.dumps({"kernel": "chan_compose_v210", "width": w, "height": h, "variant": variant, "mask": mask_kind, "sources": packing, "out": out_fmt, "jobs_per_launch": C,
                       "batch_kernel": os.environ.get("PH_CHAN_BATCH", "1") != "0" and C > 1, "us_per_launch": round(1e3 * e0.elapsed_time(e1) / reps, 2),
                       "us_per_frame": round(1e3 * e0.elapsed_time(e1) / reps / C, 2)}), flush=True)
     ctx.close()
