@@ -68,7 +68,7 @@ rm -rf $ROOT/gpurun_out/pmc_sq/*/  # keep the summary only
 (for v in wipe nowipe layer0; do python $ROOT/tools/chan_bench.py 300 rgba $v; done; python $ROOT/tools/chan_bench.py 300 v210 wipe; python $ROOT/tools/chan_bench.py 300 rgba wipe yuv422p10; python $ROOT/tools/chan_bench.py 300 rgba nowipe yuv422p10; python $ROOT/tools/chan_bench.py 300 rgba wipe yuv420p; python $ROOT/tools/chan_bench.py 300 rgba wipe nv12) 2>/dev/null | grep '^{' > $OUT/${TAG}_chan_bench.jsonl
 # round 5: the in-kernel phase probe of the one-job kernel and of the batch kernel (2 / 4 channels per launch), and the A/B of one
 # ph_chan_compose_batch call run by the batch kernel against the same call with every job through the one-job kernel
-bash $ROOT/tools/r05_probe_run.sh > $OUT/${TAG}_chan_batch_probe.txt 2>&1
+(cd $ROOT && bash tools/r05_probe_run.sh) > $OUT/${TAG}_chan_batch_probe.txt 2>&1
 (cd $ROOT && bash tools/r05_chan_ab.sh $OUT/${TAG}_chan_batch_ab.jsonl > $OUT/${TAG}_chan_batch_ab_summary.txt 2>&1)
 python $ROOT/tools/up_bench.py 100 2>/dev/null | grep '^{' > $OUT/${TAG}_up_bench.jsonl
 bash $ROOT/tools/pmc_kernel.sh chan_compose python $ROOT/tools/chan_bench.py 40 rgba wipe 2>&1 | grep -v '^{\|simple_timer\|^W2\|^find' > $OUT/${TAG}_pmc_chan.txt
