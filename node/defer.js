@@ -727,10 +727,11 @@ class Deferral {
 			candidates.push([`chan_compose_v210_${n}`, params])
 		}
 		if (!candidates.length) return null
-		// one launch can take it together with other channels' frames: plain reads of the output's size (the headline kernel's batch form),
-		// or the channel kernel as the only candidate, v210 / image sources, a v210 frame (the batch kernel)
-		const batchable = candidates[0][0].startsWith('fused_v210_combine_') || (candidates.length === 1 && candidates[0][0].startsWith('chan_compose_v210_') && !outFmt &&
-			!layers.some((l) => l.planar || (l.transition && (l.transition.incoming.planar || (l.transition.mask && l.transition.mask.planar)))))
+		// one call can take it together with other channels' frames: plain reads of the output's size (the headline kernel's batch form),
+		// or the channel kernel as the only candidate making a v210 frame (the batch kernel for v210 / image sources)
+		// (frames from planar / packed-RGB clips go along in the same call: the library runs those it cannot put into a shared launch in their turn,
+		// and makes the ones of enlarged clips of one shape together)
+		const batchable = candidates[0][0].startsWith('fused_v210_combine_') || (candidates.length === 1 && candidates[0][0].startsWith('chan_compose_v210_') && !outFmt)
 		return { node, candidates, used, n, width, height, batchable, loader, saver }
 	}
 	// launch the first candidate the library takes; false = none (nothing was launched)

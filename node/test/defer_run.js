@@ -190,7 +190,7 @@ async function main() {
 
 	// the reference's deployment: several channels of one format in one context (src/index.ts:45-71), their frames posted in the same
 	// tick - the recording hands them to the device as ONE launch (runPrograms -> ph_chan_compose_batch); a fifth channel with a
-	// dissolve in progress and a sixth that is a plain 1:1 layer go along
+	// dissolve in progress and a sixth that is a plain 1:1 layer go along; so does a channel whose background is a planar (yuv420p) clip
 	await scenario('six channels of one format posted in one tick', async (s) => {
 		s.frame = 9
 		const outs = []
@@ -203,7 +203,10 @@ async function main() {
 			const unpacked = []
 			for (let l = 0; l < srcs.length; ++l) {
 				const im = await s.rig.image(W, H)
-				s.rig.post(id, s.read([srcs[l]], im), () => srcs[l].release())
+				if (c === 3 && l === 0) { // channel 3's background is a file decoder's frame: the library runs that channel's frame in its turn inside the same call
+					const planes = await s.sourcePlanar('yuv420p', 950)
+					s.rig.post(id, s.readAs.yuv420p(planes, im), () => { planes.forEach((p) => p.release()); srcs[l].release() })
+				} else s.rig.post(id, s.read([srcs[l]], im), () => srcs[l].release())
 				unpacked.push(im)
 			}
 			const placed = []
