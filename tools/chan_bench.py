@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 2 through ph_chan_compose_v210 alone (one launch per frame): the timing loop tools/pmc_kernel.sh profiles.
-  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets] [sources: v210|yuv422p10|yuv422p8|yuv420p|nv12]
+  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets|overlay] [sources: v210|yuv422p10|yuv422p8|yuv420p|nv12]
   PH_CHAN_BENCH_JOBS=C: C channels' frames per call of ph_chan_compose_batch (PH_CHAN_BATCH=0: the same call, every job through the
   one-job kernel - the A/B of round 5); PH_CHAN_BENCH_W / _H: another frame size"""
 import json
@@ -49,6 +49,7 @@ def main():
         src = [[tuple(plane(n) for n in sizes) for _ in range(6)] for _ in range(R)]
         own = None if wide else dev(capi.ycbcr2rgb_matrix("709", 8, 16, 235, 224))
         kind = (packing, own)
+    overlay = torch.randint(0, 2 ** 31 - 1, (w * h,), dtype=torch.int32, device="cuda")
     mask = torch.zeros(h, w, 4, device="cuda")
     mask[..., 0] = torch.linspace(0, 1, w, device="cuda")[None, :]
     mask = mask.reshape(-1).contiguous()
@@ -65,6 +66,8 @@ def main():
             ls = ls[:1]
         elif variant == "insets":
             ls = ls[1:]
+        elif variant == "overlay":  # a clip under a full-frame graphic with alpha (a bgra8 frame: png / html overlays come as packed RGB)
+            ls = [ls[0], dict(src=(overlay, w, h, mats[0], "bgra8"))]
         return ls
     if C > 1:  # C channels per launch: each job its own sources (rotated through the ring) and its own output
         outs = [torch.empty(words, dtype=torch.int32, device="cuda") for _ in range(C)]
