@@ -89,6 +89,9 @@ struct ph_ctx {
   uint64_t host_pins = 0;                           // hipHostMalloc calls so far (ph_ctx_host_pool_stats)
   void *chan_index[3] = {nullptr, nullptr, nullptr};  // index frame of the channel compositor, one per queue (ph_chan_compose_v210)
   size_t chan_index_bytes[3] = {0, 0, 0};
+  // who is between taking a piece of a queue's area and enqueueing the last launch that uses it (callers on several threads: the launches of
+  // two calls on one queue must not interleave around the shared scratch); taken before ctx->mu, never the other way round
+  std::mutex chan_scratch_mu[3];
   unsigned chan_scratch_turn[3] = {0, 0, 0};  // which third of the area the next frame of enlarged clips puts its images in (chan_compose_enlarged)
   std::vector<struct ph_route *> routes;  // open ROUTEs: a recycled block must not be handed out under a transfer in flight
   std::mutex mu;
@@ -2030,10 +2033,13 @@ static int chan_batch_launch(ph_ctx *ctx, int queue, ph::ChanBatchArgs &b, const
   b.rd_cm = g.rd_cm, b.rd_gm = g.rd_gm, b.wr_cm = g.wr_cm, b.rd = g.rd, b.wr = g.wr;
   b.tails = g.planar >= 1 ? 1u : 0u, b.out_qpitch = g.out_qpitch, b.out_tail_from = g.out_tail_from;
   const size_t each = (ph::chan_index_bytes(g.out_w, g.lines) + 255u) & ~(size_t)255u;
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  int rc = chan_index_reserve(ctx, queue, each * b.jobs);
-  if (rc) return rc;
-  for (uint32_t j = 0; j < b.jobs; ++j) b.job[j].index = (char *)ctx->chan_index[queue] + each * j;
+  std::lock_guard<std::mutex> scratch(ctx->chan_scratch_mu[queue]);
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int rc = chan_index_reserve(ctx, queue, each * b.jobs);
+    if (rc) return rc;
+    for (uint32_t j = 0; j < b.jobs; ++j) b.job[j].index = (char *)ctx->chan_index[queue] + each * j;
+  }
   hipError_t e = ph::launch_chan_compose_batch(stream_of(ctx, queue), b, (uint32_t)ctx->props.multiProcessorCount);
   if (e != hipSuccess) return fail(PH_E_HIP, "ph_chan_compose_batch: launch failed: %s", hipGetErrorString(e));
   return PH_OK;
@@ -2122,6 +2128,7 @@ static int chan_compose_enlarged(ph_ctx *ctx, int queue, int jobs, int n, const 
   // - while the sets together stay inside the 256 MB of last-level cache: four 1080p images (132 MB) in three sets measured 109 us per
   // 2160p frame against 94 in one set that stays cached
   const unsigned kTurns = total <= ((size_t)64 << 20) ? 3u : 1u;
+  std::lock_guard<std::mutex> scratch(ctx->chan_scratch_mu[queue]);  // until the compositor's launch is enqueued
   char *base;
   {
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -2222,10 +2229,13 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
   if (out_format == PH_FMT_V210 && wr_cm && ctx->chan_enlarged && chan_layers_enlarged(n, layers, out_w, out_h, interlace))
     return chan_compose_enlarged(ctx, queue, 1, n, &layers, &out, out_w, out_h, interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut);
   // the index frame between the phases: one per queue (launches on one queue are in order), grown on demand
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  rc = chan_index_reserve(ctx, queue, ph::chan_index_bytes(out_w, a.lines));
-  if (rc) return rc;
-  a.index = ctx->chan_index[queue];
+  std::lock_guard<std::mutex> scratch(ctx->chan_scratch_mu[queue]);
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    rc = chan_index_reserve(ctx, queue, ph::chan_index_bytes(out_w, a.lines));
+    if (rc) return rc;
+    a.index = ctx->chan_index[queue];
+  }
   hipError_t e = ph::launch_chan_compose_v210(stream_of(ctx, queue), a, (uint32_t)ctx->props.multiProcessorCount);
   if (e != hipSuccess) return fail(PH_E_HIP, "ph_chan_compose_v210: launch failed: %s", hipGetErrorString(e));
   return PH_OK;
