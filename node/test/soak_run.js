@@ -93,7 +93,8 @@ async function soak() {
 }
 
 // the reference's deployment over a long stream: C channels in one context (src/index.ts:45-71), every channel posting a frame per tick -
-// two placed layers each (the channel kernel) or, every other channel, two plain reads (the headline kernel) - so that a tick is ONE
+// two placed layers each (the channel kernel), two plain reads (the headline kernel), or - the last channel - two clips of half the
+// channel's size filling the frame (read + 2 x 2-block compositor inside the call) - so that a tick is ONE
 // runPrograms call; the format changes half way (1080 -> 720); counters flat, every frame through a batch, nothing refused
 async function soakChannels(ticks) {
 	const C = 4
@@ -104,8 +105,14 @@ async function soakChannels(ticks) {
 	for (const [w, h] of [[1920, 1080], [1280, 720]]) {
 		const chans = []
 		for (let c = 0; c < C; ++c) chans.push(await channel(rig, w, h, 2))
+		// the last channel shows clips of HALF the channel's size, filling the frame: the library makes such frames by read + 2 x 2-block compositor
+		const small = await channel(rig, w / 2, h / 2, 2)
+		chans[C - 1].src.flat().forEach((b) => b.release())
+		chans[C - 1].src = small.src
+		chans[C - 1].read = small.read
 		const transform = await rig.transform(w, h)
 		const mats = [await transform.matrix({}), await transform.matrix({ scaleX: 0.5, scaleY: 0.5, offsetX: 0.25, offsetY: -0.25 })]
+		const fills = [await transform.matrix({}), await transform.matrix({ scaleX: 0.9, scaleY: 0.9 })]
 		const done = []
 		let warm = null
 		for (let f = 0; f < per; ++f) {
@@ -117,11 +124,12 @@ async function soakChannels(ticks) {
 				const id = { source: `chan${c}`, timestamp: f }
 				const layers = []
 				for (let l = 0; l < 2; ++l) {
-					const im = await rig.image(w, h)
+					const enlarged = c === C - 1
+					const im = enlarged ? await rig.image(w / 2, h / 2) : await rig.image(w, h)
 					rig.post(id, ch.read(ch.src[l], im))
-					if (c % 2) { layers.push(im); continue }
+					if (c % 2 && !enlarged) { layers.push(im); continue }
 					const pl = await rig.image(w, h)
-					rig.post(id, transform(im, pl, mats[l]), () => im.release())
+					rig.post(id, transform(im, pl, enlarged ? fills[l] : mats[l]), () => im.release())
 					layers.push(pl)
 				}
 				const cm = await rig.image(w, h)
@@ -139,7 +147,9 @@ async function soakChannels(ticks) {
 		if (end.pins !== warm.pins) problems.push({ channels: `${w}x${h}`, what: `${end.pins - warm.pins} blocks pinned after the format's first ticks` })
 		if (end.liveBuffers !== warm.liveBuffers) problems.push({ channels: `${w}x${h}`, what: `live buffers ${warm.liveBuffers} -> ${end.liveBuffers} over ${per} ticks` })
 		if (end.pinnedInUse + end.pinnedPooled !== warm.pinnedInUse + warm.pinnedPooled) problems.push({ channels: `${w}x${h}`, what: `pinned bytes ${warm.pinnedInUse + warm.pinnedPooled} -> ${end.pinnedInUse + end.pinnedPooled}` })
+		chans[C - 1].src = []
 		chans.forEach((ch) => ch.close())
+		small.close()
 		marks.push({ format: `${w}x${h}`, ticks: per, live: end.liveBuffers, parked: end.parkedBuffers, pinned_mb: Math.round((end.pinnedInUse + end.pinnedPooled) / 1048576), pins: end.pins })
 	}
 	const sec = Number(process.hrtime.bigint() - t0) / 1e9
