@@ -19,6 +19,12 @@
 //   phase 2 (writer table swapped in): quad per lane, indices -> writer table -> RGB->YCbCr matrix -> packed words.
 // A workgroup reads back only what it wrote itself, so one workgroup barrier (the table swap's) orders the phases.
 // Results are bit-identical to running the separate kernels (tests/test_chan_gpu.py).
+//
+// Sources are v210 frames, f32 images, a file decoder's planar YCbCr frames and packed 8-bit RGB (ffmpegProducer.ts:398-442); the frame made
+// is v210 or another consumer's format.  The kernel exists in several instantiations (chan_compose_v210_kernel<MODE, OUT>, picked by the
+// launcher at the bottom) because an instantiation carries the code and scalar state of every sampler it contains.  Two kinds of frame do
+// not come here at all: layers that are all plain reads of the output's size (the headline kernel), and frames all of whose layers are
+// ENLARGED clips - those are read once per source pixel and composited by ph_kernels_up.hip (ph_api.cpp chan_compose_enlarged).
 #include <cstdlib>
 
 #include "ph_device.h"
