@@ -683,7 +683,9 @@ class Deferral {
 			const m = l.matrix, d = l.source.imageDims
 			if (!m || !d || m.length < 36) return false
 			const f = new Float32Array(m.buffer, m.byteOffset, 9)
-			return f[1] === 0 && f[3] === 0 && f[0] > 0 && f[4] > 0 && f[0] * d.width <= 0.99 * width && f[4] * d.height * (interlace ? 2 : 1) <= 0.99 * height
+			if (f[1] !== 0 || f[3] !== 0 || !(f[0] > 0) || !(f[4] > 0)) return false
+			if (!interlace && d.width === width && d.height === height && f[0] === 1 && f[4] === 1 && f[2] === 0 && f[5] === 0) return true // the default fill of a frame-size image
+			return f[0] * d.width <= 0.99 * width && f[4] * d.height * (interlace ? 2 : 1) <= 0.99 * height
 		}
 		if (!outFmt && !anyV210 && width % 2 === 0 && layers.every((l) => l.matrix && !l.transition && enlarged(l))) {
 			const params = Object.assign({ output, interlace }, saver)

@@ -195,13 +195,14 @@ function rig(opt) { // opt.early: frames are launched at the end of the posting 
 	expect('the second field has been made already', r.names().length, 2)
 	expect('nothing pending but the recipes of images their owners still hold', Array.from(r.d.pending).map((nd) => nd.program.name).sort(), ['read', 'read', 'read', 'transform', 'transform'])
 }
-// 5a. a de-interlaced layer shown at its OWN size (1080i on a 1080 channel): the 2 x 2-block compositor is for enlargements and is not even tried
-{
+// 5a. a de-interlaced layer shown at its OWN size (1080i on a 1080 channel): under the default fill the 2 x 2-block compositor takes it (the one
+// placement at scale one it serves); moved by a fraction of a pixel it is the channel kernel's - decided from the matrix, no refused attempt
+for (const moved of [false, true]) {
 	const r = rig()
 	const L = r.loader()
 	const win = [0, 1, 2].map((i) => { const im = r.image(`w${i}`); r.d.record(r.P.read, Object.assign({ input: r.v210(`s${i}`), output: im, width: r.W }, L), 1); return im })
 	const m = r.enlarging()
-	new Float32Array(m.buffer, m.byteOffset, 9).set([1, 0, 0, 0, 1, 0, 0, 0, 1])
+	new Float32Array(m.buffer, m.byteOffset, 9).set([1, 0, moved ? 0.01 : 0, 0, 1, 0, 0, 0, 1])
 	const y = r.image('y0')
 	r.d.record(r.P.yadif, { prev: win[0], cur: win[1], next: win[2], parity: 0, tff: 1, skipSpatial: 0, output: y }, 1)
 	const t = r.image('t0')
@@ -209,7 +210,8 @@ function rig(opt) { // opt.early: frames are launched at the end of the posting 
 	const out = r.v210('out0')
 	r.d.record(r.P.write, Object.assign({ input: t, output: out, width: r.W, interlace: 0 }, r.saver), 1)
 	r.d.touch(out, 'readonly', 2)
-	expect('own-size field: the field is made, then the channel kernel - no refused attempt', [r.names().slice(-2), r.names().some((n) => /compose_up/.test(n)), r.d.stats.fallbacks], [['yadif', 'chan_compose_v210_1'], false, 0])
+	expect(`own-size field${moved ? ', moved' : ' under the default fill'}: the field is made, then ${moved ? 'the channel kernel' : 'the 2 x 2-block compositor'} - no refused attempt`,
+		[r.names().slice(-2), r.d.stats.fallbacks], [['yadif', moved ? 'chan_compose_v210_1' : 'compose_up_write_v210_1'], 0])
 }
 // 5b. the same, refused: first the two-field form, then the single one, then the jobs as recorded; the other field likewise
 {

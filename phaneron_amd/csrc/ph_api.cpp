@@ -2096,7 +2096,12 @@ static bool chan_layers_enlarged(int n, const ph_chan_layer *layers, uint32_t ou
         L.src.height <= 0 || ((L.src.width & 1) && L.src.format != PH_SRC_RGBA8 && L.src.format != PH_SRC_BGRA8))
       return false;
     if (m[1] != 0.0f || m[3] != 0.0f || !(m[0] > 0.0f) || !(m[4] > 0.0f)) return false;                      // (ph_kernels_up.hip compose_up_eligible)
-    if ((double)m[0] * L.src.width > 0.99 * out_w || (double)m[4] * L.src.height * (interlace ? 2 : 1) > 0.99 * out_h) return false;
+    // ... or a decoder's frame of the channel's size under the Mixer's default fill (the compositor takes exactly that placement beside the
+    // enlargements: compose_up_eligible): a 1080p yuv420p clip 26.1 -> 22.6 us, under a bgra8 graphic 45.2 -> 40.2.  Not v210 frames: the channel
+    // kernel's shared taps serve those better (22.3 against 23.2 us)
+    const bool fill = L.src.format != PH_SRC_V210 && !interlace && (uint32_t)L.src.width == out_w && (uint32_t)L.src.height == out_h && m[0] == 1.0f && m[4] == 1.0f &&
+                      m[2] == 0.0f && m[5] == 0.0f;
+    if (!fill && ((double)m[0] * L.src.width > 0.99 * out_w || (double)m[4] * L.src.height * (interlace ? 2 : 1) > 0.99 * out_h)) return false;
     if ((uint64_t)L.src.width * 16u * (uint64_t)L.src.height >= (1ull << 30) || L.src.width >= (1 << 22)) return false;
   }
   return true;

@@ -413,7 +413,11 @@ bool compose_up_eligible(const UpArgs &a) {
     // write takes every other line).  Below one texel by a margin far above the f32 noise of the coordinates (1e-4 texels at
     // 1920 columns): then the first taps of the block's two columns / rows are 0 or 1 apart; at a whole texel between them
     // the noise could make it 2.
-    if ((double)L.m[0] * L.w > 0.99 * a.out_w || (double)L.m[4] * L.h * a.line_step > 0.99 * a.out_h) return false;
+    // ... or EXACTLY one: a source of the frame's size under the Mixer's default fill (the identity, a frame write).  Its taps sit half a
+    // texel off the pixel centres (transform.ts:53 samples at x / w, not (x + 0.5) / w: fu = x - 0.5), as far from a flip as can be:
+    // neighbouring pixels' first taps are exactly 1 apart
+    const bool fill = L.w == a.out_w && L.h == a.out_h && a.line_step == 1u && L.m[0] == 1.0f && L.m[4] == 1.0f && L.m[2] == 0.0f && L.m[5] == 0.0f;
+    if (!fill && ((double)L.m[0] * L.w > 0.99 * a.out_w || (double)L.m[4] * L.h * a.line_step > 0.99 * a.out_h)) return false;
     if ((uint64_t)L.pitch * L.h >= (1ull << 30) || L.w >= (1u << 22)) return false;
   }
   return true;

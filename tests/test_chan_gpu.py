@@ -690,12 +690,20 @@ def test_planar_clips_at_their_own_scale(fmt):
         a, b = frames.pack_random(fmt, w, h, 600 + w), frames.pack_random(fmt, w, h, 601 + w)
         v = frames.v210_random(w // 2 // 6 * 6, h // 2 // 2 * 2, frames.layer_seed(97, w))
         fill = dict(src=Src(a, w, h, m(w, h), fmt=fmt))
-        check([fill], w, h, "%s %dx%d under the default fill" % (fmt, w, h))
+        # (a frame of nothing but decoders' frames under the default fill is made by read + 2 x 2-block compositor unless the option is off)
+        both_routes(lambda route: check([fill], w, h, "%s %dx%d under the default fill by the %s" % (fmt, w, h, route)))
+        both_routes(lambda route: check([fill, dict(src=Src(b, w, h, m(w, h), fmt=fmt))], w, h, "%s: two clips under the default fill by the %s" % (fmt, route), specs=("709", "2020")))
         check([fill, dict(src=Src(b, w, h, m(w, h, offset_x=8.0 / w, offset_y=-4.0 / h), fmt=fmt))], w, h, "%s: a second clip moved by whole pixels" % fmt)
         check([fill, dict(src=Src(b, w, h, m(w, h, offset_x=0.3 / w + 0.25, offset_y=0.4 / h), fmt=fmt)),
                dict(src=Src(v, w // 2 // 6 * 6, h // 2 // 2 * 2, m(w, h, **PIP[2])))], w, h, "%s: a clip moved by a fraction of a pixel, a v210 inset on top" % fmt, specs=("709", "2020"))
         for interlace in (1, 3):
             check([fill], w, h, "%s %dx%d under the default fill, field %d" % (fmt, w, h, interlace), interlace=interlace, poison_dst=True)
+        # a graphic with alpha over the clip, both of the channel's size; an enlarged clip under such a graphic
+        g = frames.pack_random("bgra8", w, h, 610 + w)
+        small = frames.pack_random(fmt, w // 2 // 2 * 2, h // 2 // 2 * 2, 611 + w)
+        both_routes(lambda route: check([fill, dict(src=Src(g, w, h, m(w, h), fmt="bgra8"))], w, h, "%s clip under a bgra8 graphic by the %s" % (fmt, route)))
+        both_routes(lambda route: check([dict(src=Src(small, w // 2 // 2 * 2, h // 2 // 2 * 2, m(w, h), fmt=fmt)), dict(src=Src(g, w, h, m(w, h), fmt="bgra8"))], w, h,
+                                        "an enlarged %s clip under a bgra8 graphic by the %s" % (fmt, route)))
 
 
 def test_random_channel_programs_with_planar_clips():

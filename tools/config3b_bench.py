@@ -60,10 +60,38 @@ def main():
         ctx.wait()
         return e0.elapsed_time(e1) / n
     both = timeit(step, reps)
+    # the same frames by the 2 x 2-block compositor, which takes the default fill of frame-size images beside the enlargements: a launch per field
+    # on RGBA fields, and the reader writing packed-RGB fields with both fields' frames as ONE launch (config 3's route)
+    outs = [torch.empty(words, dtype=torch.int32, device="cuda") for _ in range(2)]
+    up = [ctx.compose_up_write_v210([(fields[l][p], w, h, mat) for l in range(4)], out, w, h, 0, *wr, prepare_only=True) for p in range(2)]
+    rgb = [[torch.empty(w * h * 3, dtype=torch.float32, device="cuda") for _ in range(2)] for _ in range(4)]
+    pair = ctx.compose_up_write_v210_pair([(rgb[l][0], w, h, mat) for l in range(4)], [(rgb[l][1], w, h, mat) for l in range(4)], outs[0], outs[1], w, h, 0, *wr, rgb=True, prepare_only=True)
+
+    def step_up(i):
+        if not (i & 1):
+            s = srcs[(i // 2) % R]
+            for l in range(4):
+                win[l] = [win[l][1], win[l][2], s[l]]
+            ctx.v210_yadif_pair([(win[l][0], win[l][1], win[l][2], fields[l][0], fields[l][1]) for l in range(4)], w, h, 1, False, *rd)
+        up[1 ^ (0 if (i & 1) else 1)]()
+
+    def step_pair(i):
+        if not (i & 1):
+            s = srcs[(i // 2) % R]
+            for l in range(4):
+                win[l] = [win[l][1], win[l][2], s[l]]
+            ctx.v210_yadif_pair([(win[l][0], win[l][1], win[l][2], rgb[l][0], rgb[l][1]) for l in range(4)], w, h, 1, False, *rd, rgb=True)
+            pair()
+    chan[0](); up[0](); ctx.wait()
+    ref = out.clone()
+    chan[0](); ctx.wait()
+    same = bool(torch.equal(ref, out))
+    both_up, both_pair = timeit(step_up, reps), timeit(step_pair, reps)
     only_chan = timeit(lambda i: chan[i & 1](), reps)
     algo = 4 * 3 * capi.v210_pitch_bytes(w) * h // 2 + capi.v210_pitch_bytes(w) * h  # per field: half of 4 x 3 window frames in + one v210 frame out
     print(json.dumps({"config": "3b: 4 x 1080i50 -> yadif -> own size on a 1080p50 channel -> combine_4 -> v210 (per output field)", "us_per_field": round(1e3 * both, 2),
-                      "channel_kernel_alone_us": round(1e3 * only_chan, 2), "fields_per_sec": round(1e3 / both, 1), "x_realtime_50fps": round(1e3 / both / 50, 1),
+                      "channel_kernel_alone_us": round(1e3 * only_chan, 2), "us_per_field_by_2x2_block_compositor": round(1e3 * both_up, 2),
+                      "us_per_field_packed_rgb_fields_pair_launch": round(1e3 * both_pair, 2), "compositor_frame_equals_channel_kernel_frame": same, "fields_per_sec": round(1e3 / both, 1), "x_realtime_50fps": round(1e3 / both / 50, 1),
                       "algorithmic_bytes": algo, "hbm_frac": round(algo / both / 1e6 / 8000.0, 4)}))
     ctx.close()
 
