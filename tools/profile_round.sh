@@ -65,7 +65,7 @@ bash $ROOT/tools/pmc_sq.sh > $OUT/${TAG}_pmc_sq.txt 2>&1
 rm -rf $ROOT/gpurun_out/pmc_sq/*/  # keep the summary only
 
 # 4b. configs 2 and 3: their kernels timed alone, in-kernel phase probe, and counters incl. FETCH_SIZE / WRITE_SIZE (separate passes)
-(for v in wipe nowipe layer0; do python $ROOT/tools/chan_bench.py 300 rgba $v; done; python $ROOT/tools/chan_bench.py 300 v210 wipe; python $ROOT/tools/chan_bench.py 300 rgba wipe yuv422p10; python $ROOT/tools/chan_bench.py 300 rgba nowipe yuv422p10; python $ROOT/tools/chan_bench.py 300 rgba wipe yuv420p; python $ROOT/tools/chan_bench.py 300 rgba wipe nv12) 2>/dev/null | grep '^{' > $OUT/${TAG}_chan_bench.jsonl
+(for v in wipe nowipe layer0; do python $ROOT/tools/chan_bench.py 300 rgba $v; done; python $ROOT/tools/chan_bench.py 300 v210 wipe; for f in yuv422p10 yuv420p nv12; do for v in wipe nowipe layer0 overlay; do python $ROOT/tools/chan_bench.py 300 rgba $v $f; done; done; python $ROOT/tools/chan_bench.py 300 rgba overlay v210; for o in yuv422p8 rgba8; do PH_CHAN_BENCH_OUT=$o python $ROOT/tools/chan_bench.py 300 rgba layer0 v210; PH_CHAN_BENCH_OUT=$o python $ROOT/tools/chan_bench.py 300 rgba wipe v210; PH_CHAN_BENCH_OUT=$o python $ROOT/tools/chan_bench.py 300 rgba layer0 yuv420p; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_chan_bench.jsonl
 # round 5: the in-kernel phase probe of the one-job kernel and of the batch kernel (2 / 4 channels per launch), and the A/B of one
 # ph_chan_compose_batch call run by the batch kernel against the same call with every job through the one-job kernel
 (cd $ROOT && bash tools/r05_probe_run.sh) > $OUT/${TAG}_chan_batch_probe.txt 2>&1
