@@ -2092,8 +2092,9 @@ static bool chan_layers_enlarged(int n, const ph_chan_layer *layers, uint32_t ou
     const ph_chan_layer &L = layers[i];
     const float *m = L.src.matrix9_host;
     // (v210 frames, a file decoder's planar frames, packed 8-bit RGB: whatever has a reader of its own - ph_v210_read, ph_pack_read)
-    if (L.transition != PH_TRANSITION_CUT || L.src.format == PH_SRC_RGBA_F32 || L.src.format < PH_SRC_V210 || L.src.format > PH_SRC_BGRA8 || !m || L.src.width <= 0 ||
-        L.src.height <= 0 || ((L.src.width & 1) && L.src.format != PH_SRC_RGBA8 && L.src.format != PH_SRC_BGRA8))
+    // - and finished f32 images, which the compositor takes as they are
+    if (L.transition != PH_TRANSITION_CUT || L.src.format < PH_SRC_V210 || L.src.format > PH_SRC_BGRA8 || !m || L.src.width <= 0 ||
+        L.src.height <= 0 || ((L.src.width & 1) && L.src.format != PH_SRC_RGBA8 && L.src.format != PH_SRC_BGRA8 && L.src.format != PH_SRC_RGBA_F32))
       return false;
     if (m[1] != 0.0f || m[3] != 0.0f || !(m[0] > 0.0f) || !(m[4] > 0.0f)) return false;                      // (ph_kernels_up.hip compose_up_eligible)
     // ... or a decoder's frame of the channel's size under the Mixer's default fill (the compositor takes exactly that placement beside the
@@ -2148,7 +2149,7 @@ static int chan_compose_enlarged(ph_ctx *ctx, int queue, int jobs, int n, const 
   for (int j = 0; j < jobs; ++j) {
     for (int i = 0; i < n; ++i) {
       const ph_chan_source &S = layers[j][i].src;
-      ins[j * n + i] = S.data, imgs[j * n + i] = base + per_job * (size_t)j + off[i];
+      ins[j * n + i] = S.data, imgs[j * n + i] = S.format == PH_SRC_RGBA_F32 ? const_cast<void *>(S.data) : base + per_job * (size_t)j + off[i];
       il[j][i] = ph_image_layer{imgs[j * n + i], PH_IMG_RGBA_F32, S.width, S.height, S.matrix9_host};
     }
     sets[j] = il[j];
@@ -2160,6 +2161,7 @@ static int chan_compose_enlarged(ph_ctx *ctx, int queue, int jobs, int n, const 
   if (!all_v210) {  // each clip through the reader of its format (a source with code ranges of its own brings its Loader matrix)
     for (int f = 0; f < frames && rc == PH_OK; ++f) {
       const ph_chan_source &S = layers[f / n][f % n].src;
+      if (S.format == PH_SRC_RGBA_F32) continue;  // an image: nothing to read
       if (S.format == PH_SRC_V210) {
         rc = ph_v210_read(ctx, queue, S.data, imgs[f], (uint32_t)S.width, (uint32_t)S.height, rd_cm, rd_lut, rd_gm);
       } else {

@@ -752,3 +752,18 @@ def test_other_consumers_frames_from_every_kind_of_program(src, out):
         check_format([clip(900, w, h)], w, h, out, "%s clip under the default fill -> %s il %d" % (src, out, interlace), interlace=interlace)
         check_format([clip(901, w, h), clip(902, 192, 30, **PIP[1]), clip(903, 192, 30, scale_x=0.4, scale_y=0.4, rotate=0.1, offset_x=0.2)], w, h, out,
                      "%s clips placed -> %s il %d" % (src, out, interlace), interlace=interlace)
+
+
+def test_finished_images_on_both_routes():
+    """f32 images among the layers of a frame the compositor route takes (de-interlaced fields at their own size: 1080i sources on a 1080 channel;
+    an enlarged image; an image beside an enlarged clip): the compositor reads them as they are - against the oracle's chain, both routes"""
+    w, h = 384, 54
+    img = lambda seed, ww=w, hh_=h: Src(frames.rgba_random(ww, hh_, seed, -0.05, 1.05), ww, hh_, m(w, h), fmt="rgba")
+    clip = Src(frames.v210_random(192, 30, frames.layer_seed(94, 0)), 192, 30, m(w, h, scale_x=0.9, scale_y=0.9))
+    cases = [("four images under the default fill", [dict(src=img(950 + l)) for l in range(4)]),
+             ("an enlarged image", [dict(src=img(955, 128, 36))]),
+             ("an image under the default fill beside an enlarged v210 clip", [dict(src=img(956)), dict(src=clip)]),
+             ("an enlarged yuv420p clip under an image", [dict(src=Src(frames.pack_random("yuv420p", 192, 30, 957), 192, 30, m(w, h), fmt="yuv420p")), dict(src=img(958))])]
+    for what, layers in cases:
+        both_routes(lambda route: check(layers, w, h, "%s by the %s" % (what, route), specs=("709", "2020")))
+    both_routes(lambda route: check(cases[1][1], w, h, "an enlarged image, field 3, by the %s" % route, interlace=3, poison_dst=True))
