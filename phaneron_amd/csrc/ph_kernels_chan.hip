@@ -329,8 +329,13 @@ __device__ __forceinline__ float4 rgb8_finish(const Rgb8Pending &p, const ReadK 
   return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]), dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]),
                      lds_lut_finish(p.a));
 }
+// SHARE: the instantiation for graphics over v210 clips (mode 5): a graphic of the channel's size under the default fill shares its taps as
+// clips do - the pair's three source rows, lane l's left column from lane l - 1, lane 0's from the halo table; a graphic has an alpha of
+// its own, so its halo entry is TWO slots: r g b of the three rows in `halo.addr`, their alphas in the slot behind it (halo.addr + stride)
+template <bool SHARE = false>
 __device__ __forceinline__ void chan_sample_rgb8(const ChanSrc &s, float px, const float (&py)[kChanP], uint32_t x, const uint32_t (&line)[kChanP],
-                                                 const ReadK &k, const LutK &lut, float4 (&out)[kChanP]) {
+                                                 const ReadK &k, const LutK &lut, float4 (&out)[kChanP], const ChanHalo halo = ChanHalo{false, 0u},
+                                                 uint32_t halo_stride = 0u) {
   const bool bgra = s.kind == kChanBgra8;  // uniform
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(s.ptr), 0, (int)(s.pitch * s.h), 0x00020000);
   if (!s.sampled) {
@@ -353,6 +358,59 @@ __device__ __forceinline__ void chan_sample_rgb8(const ChanSrc &s, float px, con
   if (!__builtin_amdgcn_ballot_w64(touches)) {
 #pragma unroll
     for (int p = 0; p < kChanP; ++p) out[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return;
+  }
+  static_assert(kChanP == 2, "the row sharing below is written for a pair");
+  const bool stacked = SHARE && halo.on && __builtin_amdgcn_ballot_w64(!(t[1].i0 == t[0].i0 && t[1].j0 == t[0].j0 + 1u)) == 0;
+  if (SHARE && stacked) {
+    auto word = [&](uint32_t row, uint32_t col) __attribute__((always_inline)) {
+      const uint32_t off = row < s.h && col < s.w ? __umul24(row, s.pitch) + (col << 2) : kOutsideBit;
+      return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+    };
+    const uint32_t i0_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t[0].i0), j0_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t[0].j0);
+    const bool shared = __builtin_amdgcn_ballot_w64(!(t[0].i0 == i0_first + (threadIdx.x & 63u) && t[0].j0 == j0_first)) == 0;
+    float4 left[3], right[3];
+    if (shared) {
+      Rgb8Pending pend[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) pend[r] = rgb8_issue(word(j0_first + (uint32_t)r, t[0].i0 + 1u), bgra, lut);
+      const __attribute__((address_space(3))) float *hp = (const __attribute__((address_space(3))) float *)(uintptr_t)halo.addr;
+      const __attribute__((address_space(3))) float *ha = (const __attribute__((address_space(3))) float *)(uintptr_t)(halo.addr + halo_stride);
+      float h[12];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) h[i] = hp[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) h[9 + i] = ha[i];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        right[r] = rgb8_finish(pend[r], k);
+        left[r] = make_float4(wave_from_prev_lane(right[r].x, h[3 * r]), wave_from_prev_lane(right[r].y, h[3 * r + 1]),
+                              wave_from_prev_lane(right[r].z, h[3 * r + 2]), wave_from_prev_lane(right[r].w, h[9 + r]));
+      }
+    } else {
+      Rgb8Pending pend[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pend[i] = rgb8_issue(word(t[0].j0 + (uint32_t)(i >> 1), t[0].i0 + (uint32_t)(i & 1)), bgra, lut);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) left[r] = rgb8_finish(pend[2 * r], k), right[r] = rgb8_finish(pend[2 * r + 1], k);
+    }
+    const bool ci0 = t[0].i0 < s.w, ci1 = t[0].i0 + 1u < s.w;
+#pragma unroll
+    for (int p = 0; p < kChanP; ++p) {
+      const bool ri0 = t[0].j0 + (uint32_t)p < s.h, ri1 = t[0].j0 + (uint32_t)p + 1u < s.h;
+      float4 q[4] = {left[p], right[p], left[p + 1], right[p + 1]};
+      const bool in[4] = {ci0 && ri0, ci1 && ri0, ci0 && ri1, ci1 && ri1};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i].x = in[i] ? q[i].x : 0.0f, q[i].y = in[i] ? q[i].y : 0.0f, q[i].z = in[i] ? q[i].z : 0.0f, q[i].w = in[i] ? q[i].w : 0.0f;
+      const float a = t[p].a, b = t[p].b, oma = 1.0f - a, omb = 1.0f - b;
+      const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
+      out[p].x = ((w00 * q[0].x + w10 * q[1].x) + w01 * q[2].x) + w11 * q[3].x;
+      out[p].y = ((w00 * q[0].y + w10 * q[1].y) + w01 * q[2].y) + w11 * q[3].y;
+      out[p].z = ((w00 * q[0].z + w10 * q[1].z) + w01 * q[2].z) + w11 * q[3].z;
+      out[p].w = ((w00 * q[0].w + w10 * q[1].w) + w01 * q[2].w) + w11 * q[3].w;
+    }
     return;
   }
 #pragma unroll
@@ -659,7 +717,10 @@ __device__ __forceinline__ void chan_halo_pass(const ChanArgs &a, const ChanShar
         const ChanTaps t = chan_taps(s, (float)(int)x / fow - 0.5f, (float)(int)line / foh - 0.5f);
         const uint32_t col = t.i0, row = t.j0 + r;
         if (col < s.w && row < s.h) {
-          if (SRC >= 1 && s.kind >= kChanP10) {  // uniform: a planar YCbCr clip, converted as chan_sample_planar converts it (its own Loader matrix if it has one)
+          if (SRC == 3 && s.kind >= kChanRgba8) {  // uniform: a packed-RGB graphic (its alpha goes to the slot behind: below)
+            const uint32_t word = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(__umul24(row, s.pitch) + (col << 2)), 0, 0);
+            v = rgb8_finish(rgb8_issue(word, s.kind == kChanBgra8, rlut), rk);
+          } else if (SRC >= 1 && SRC != 3 && s.kind >= kChanP10) {  // uniform: a planar YCbCr clip, converted as chan_sample_planar converts it (its own Loader matrix if it has one)
             const V210Words w = planar_load(planes_of(s, a.plane_u[k], a.plane_v[k]), row, col);
             if (STD) {  // (no op of a launch that takes the short form has a matrix of its own: ChanArgs::any_cm)
               v = read_px_finish(planar_issue<true>(w, rk, rlut), rk);
@@ -677,12 +738,14 @@ __device__ __forceinline__ void chan_halo_pass(const ChanArgs &a, const ChanShar
         }
       }
       area[9u * n + 3u * r] = v.x, area[9u * n + 3u * r + 1u] = v.y, area[9u * n + 3u * r + 2u] = v.z;
+      if (SRC == 3 && s.kind >= kChanRgba8) area[a.halo_steps * 9u + 9u * n + r] = v.w;  // the graphic's second slot
     }
   }
   __syncthreads();
 }
 
-// SRC: what the program's sources may be - 0: v210 frames and f32 images; 1: anything (planar, packed RGB too); 2: planar YCbCr frames and f32
+// SRC: what the program's sources may be - 0: v210 frames and f32 images; 1: anything (planar, packed RGB too); 3: v210 frames, packed-RGB
+// graphics and f32 images; 2: planar YCbCr frames and f32
 // images only (a file decoder's clips, ffmpegProducer.ts:398-412: an instantiation without the v210 and packed-RGB samplers' code and scalar
 // state); TAILS: v210 frames (sources, output) may have lines that end in a tail
 template <bool STD, int SRC, bool TAILS, bool PSHARE = false>
@@ -726,9 +789,12 @@ __device__ __forceinline__ void chan_phase1(const ChanArgs &a, const ChanShare &
     for (int k = 0; k < a.n_ops; ++k) {
       const ChanOp op = a.op[k];
       float4 v[kChanP];
-      if (SRC == 1 && op.src.kind >= kChanRgba8) {  // uniform
-        chan_sample_rgb8(op.src, px, py, x, line, rk, rlut, v);
-      } else if (SRC >= 1 && op.src.kind >= kChanP10) {
+      if ((SRC == 1 || SRC == 3) && op.src.kind >= kChanRgba8) {  // uniform
+        ChanHalo halo{false, 0u};
+        if (SRC == 3 && (op.action & kChanActShare) && n < a.halo_steps)  // uniform
+          halo = ChanHalo{true, a.halo_off + (((op.action >> kChanActShareShift) & 7u) * a.halo_steps + n) * 36u};
+        chan_sample_rgb8<SRC == 3>(op.src, px, py, x, line, rk, rlut, v, halo, a.halo_steps * 36u);
+      } else if ((SRC == 1 || SRC == 2) && op.src.kind >= kChanP10) {
         // a source with code ranges of its own (8-bit) brings its Loader matrix: the general dot products serve any matrix and give
         // the same bits as the short form where that applies (its missing terms are exact zeros)
         // (ONE copy of the planar sampler per instantiation: a launch in which some source brings a matrix takes the general form throughout -
@@ -865,13 +931,14 @@ __device__ __forceinline__ void chan_phase2_other(const ChanArgs &a, const ChanS
 // MODE: 0 = v210 frames whose lines end on a 48-pixel block and f32 images (the fast instantiation); 1 = the same with lines that may end
 // in a tail (1280 x 720: sources and / or output); 2 = everything (planar and packed-RGB sources, frames other than v210); 3 = planar YCbCr
 // clips and f32 images into a v210 frame (what file playback is: ffmpegProducer.ts:398-412); 4 = the same with the clips' taps shared
-// (clips at their own scale: a program that is mostly such clips - the tap-sharing paths cost the plain loop's register allocation).  An
+// (clips at their own scale: a program that is mostly such clips - the tap-sharing paths cost the plain loop's register allocation); 5 = v210
+// clips, packed-RGB graphics and f32 images, the graphics' taps shared too (a logo or a lower third over a live source).  An
 // instantiation carries the scalar state of every path it contains, whether a launch takes it or not - the channel kernel's op loop
 // spills scalars to VGPR lanes (6 in mode 0, 76 in mode 2) - so 1280-wide v210 channels get one of their own.
 // OUT: the packed frame's format (PH_FMT_*: 0 v210; 2 yuv422p8 and 5 rgba8 - the other consumers' - with the lean modes too; the rest only with MODE 2)
 template <int MODE, int OUT = 0>
 __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a) {
-  constexpr int SRC = MODE == 2 ? 1 : MODE >= 3 ? 2 : 0;
+  constexpr int SRC = MODE == 2 ? 1 : MODE == 5 ? 3 : MODE >= 3 ? 2 : 0;
   constexpr bool TAILS = MODE >= 1, PSHARE = MODE == 4;
   const ReadK rk = load_read_k(a.rd_cm, a.rd_gm);
   const LutK rlut = make_lut_k(a.rd);
@@ -1300,6 +1367,14 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
   static const bool no_clips_kernel = getenv("PH_CHAN_NO_CLIPS_KERNEL") != nullptr;  // A/B runs (tools/chan_bench.py): mode 2 for everything planar
   if (no_clips_kernel) clips_only = false;
   const bool planar_share = clips_only && 2u * own_scale >= (uint32_t)b.n_ops;
+  // v210 clips under packed-RGB graphics (and f32 images), a frame of one of the three consumers: mode 5, the graphics at their own scale share their taps
+  bool graphics = a.planar == 2 && lean_out && !no_clips_kernel, any_rgb8 = false;
+  for (int k = 0; k < b.n_ops; ++k) {
+    const uint32_t kind = b.op[k].src.kind;
+    graphics = graphics && (kind == kChanV210 || kind == kChanRgba || kind >= kChanRgba8);
+    any_rgb8 = any_rgb8 || kind >= kChanRgba8;
+  }
+  graphics = graphics && any_rgb8;
   uint32_t lds_total = lds;
   b.halo_steps = 0, b.halo_off = (lds + 15u) & ~15u;
   static const bool no_share = getenv("PH_CHAN_NO_SHARE") != nullptr;  // A/B runs (tools/chan_bench.py)
@@ -1316,12 +1391,14 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
     uint32_t n_share = 0;
     for (int k = 0; k < b.n_ops && steps; ++k) {
       const ChanSrc &s = b.op[k].src;
-      if ((s.kind != kChanV210 && !(planar_share && s.kind >= kChanP10 && s.kind <= kChanNv12)) || !s.sampled || s.m[1] != 0.0f || s.m[3] != 0.0f) continue;  // v210 clips; planar ones in their instantiation
+      const bool rgb8 = graphics && s.kind >= kChanRgba8;  // (two slots: its alpha has one of its own)
+      if ((s.kind != kChanV210 && !rgb8 && !(planar_share && s.kind >= kChanP10 && s.kind <= kChanNv12)) || !s.sampled || s.m[1] != 0.0f || s.m[3] != 0.0f) continue;  // v210 clips; planar ones and graphics in their instantiations
       const float sx = s.m[0] * (float)s.w / (float)a.out_w, sy = s.m[4] * (float)s.h / (float)(a.out_h) * (float)a.line_step;
       if (!(sx > 0.9999f && sx < 1.0001f && sy > 0.9999f && sy < 1.0001f)) continue;
-      if (n_share == 8u || (n_share + 1u) * steps * 36u > room) break;
+      const uint32_t slots_needed = rgb8 ? 2u : 1u;
+      if (n_share + slots_needed > 8u || (n_share + slots_needed) * steps * 36u > room) break;
       b.op[k].action |= kChanActShare | (n_share << kChanActShareShift);
-      ++n_share;
+      n_share += slots_needed;
     }
     if (n_share) b.halo_steps = steps, lds_total = b.halo_off + n_share * steps * 36u;
   }
@@ -1336,7 +1413,8 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
   // yuv422p8 (ffmpegConsumer.ts:144), rgba8 (screenConsumer.ts:131); the other formats and v210 lines with tails take the "everything" one
   auto lean = [&](auto out_tag) -> hipError_t {
     constexpr int O = decltype(out_tag)::value;
-    if (a.planar == 2) return planar_share ? go(chan_compose_v210_kernel<4, O>) : clips_only ? go(chan_compose_v210_kernel<3, O>) : go(chan_compose_v210_kernel<2, O>);
+    if (a.planar == 2)
+      return planar_share ? go(chan_compose_v210_kernel<4, O>) : clips_only ? go(chan_compose_v210_kernel<3, O>) : graphics ? go(chan_compose_v210_kernel<5, O>) : go(chan_compose_v210_kernel<2, O>);
     if (a.planar == 1) return O == 0 ? go(chan_compose_v210_kernel<1, 0>) : go(chan_compose_v210_kernel<2, O>);
     return go(chan_compose_v210_kernel<0, O>);
   };

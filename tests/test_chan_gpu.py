@@ -767,3 +767,26 @@ def test_finished_images_on_both_routes():
     for what, layers in cases:
         both_routes(lambda route: check(layers, w, h, "%s by the %s" % (what, route), specs=("709", "2020")))
     both_routes(lambda route: check(cases[1][1], w, h, "an enlarged image, field 3, by the %s" % route, interlace=3, poison_dst=True))
+
+
+@pytest.mark.parametrize("fmt", ["rgba8", "bgra8"])
+def test_graphics_over_v210_clips(fmt):
+    """a logo / lower third / full-frame graphic with alpha (a packed-RGB frame) over a live or v210 clip - the instantiation for v210 clips,
+    graphics and images, in which a graphic of the channel's size shares its taps (its alpha travels through a halo slot of its own): the
+    graphic under the default fill, moved by whole and by fractional pixels, two graphics, a small placed one, over an image, fields,
+    frames that do not fill the chip and a 1280-wide channel"""
+    for w, h in ((384, 54), (720, 60), (1280, 18)):
+        clip = dict(src=Src(frames.v210_random(w, h, frames.layer_seed(93, w)), w, h, m(w, h)))
+        g, g2 = frames.pack_random(fmt, w, h, 970 + w), frames.pack_random(fmt, w, h, 971 + w)
+        small = frames.pack_random(fmt, 100, 20, 972 + w)
+        check([clip, dict(src=Src(g, w, h, m(w, h), fmt=fmt))], w, h, "%s graphic %dx%d over a v210 clip, both under the default fill" % (fmt, w, h))
+        check([clip, dict(src=Src(g, w, h, m(w, h, offset_x=6.0 / w, offset_y=-2.0 / h), fmt=fmt))], w, h, "%s graphic moved by whole pixels" % fmt, specs=("709", "2020"))
+        check([clip, dict(src=Src(g, w, h, m(w, h, offset_x=0.3 / w, offset_y=0.6 / h), fmt=fmt)), dict(src=Src(g2, w, h, m(w, h), fmt=fmt))], w, h,
+              "two %s graphics, one moved by a fraction of a pixel" % fmt)
+        check([clip, dict(src=Src(small, 100, 20, m(w, h, scale_x=0.3, scale_y=0.4, offset_x=0.3, offset_y=0.3, rotate=0.05), fmt=fmt)), dict(src=Src(g, w, h, m(w, h), fmt=fmt))], w, h,
+              "a small placed %s graphic under a full-frame one" % fmt)
+        check([dict(src=Src(frames.rgba_random(w, h, 973 + w, -0.05, 1.05), w, h, fmt="rgba")), dict(src=Src(g, w, h, m(w, h), fmt=fmt))], w, h, "%s graphic over an image" % fmt)
+        for interlace in (1, 3):
+            check([clip, dict(src=Src(g, w, h, m(w, h), fmt=fmt))], w, h, "%s graphic over a v210 clip, field %d" % (fmt, interlace), interlace=interlace, poison_dst=True)
+    check_format([dict(src=Src(frames.v210_random(384, 54, frames.layer_seed(92, 0)), 384, 54, m(384, 54))), dict(src=Src(frames.pack_random(fmt, 384, 54, 975), 384, 54, m(384, 54), fmt=fmt))],
+                 384, 54, "yuv422p8", "%s graphic over a v210 clip into the encoder's frame" % fmt)
