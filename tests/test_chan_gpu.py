@@ -253,7 +253,7 @@ def random_layers(r, ow, oh, n_layers, with_planar=False):
         else:
             w, h = int(r.choice([48, 96, 192, 288, 384])), int(r.integers(2, 40))
         seed = int(r.integers(1, 1 << 30))
-        planar = None if rgba or not with_planar or r.random() < 0.6 else str(r.choice(["yuv422p10", "yuv422p8", "yuv420p", "nv12"]))
+        planar = None if rgba or not with_planar or r.random() < 0.6 else str(r.choice(["yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"]))
         if planar:
             if not one_to_one:
                 h += h & 1  # (4:2:0: an even height)
@@ -715,6 +715,13 @@ def test_random_channel_programs_with_planar_clips():
         ow, oh = sizes[case % len(sizes)]
         interlace = int(r.choice([0, 0, 1, 3]))
         layers = random_layers(r, ow, oh, int(r.integers(1, 6)), with_planar=True)
+        if case % 6 == 3:  # graphics over v210 clips, some at the channel's size: the graphics' instantiation
+            layers = [dict(src=Src(frames.v210_random(ow, oh, frames.layer_seed(7100, case)), ow, oh, m(ow, oh)))]
+            for i in range(int(r.integers(1, 4))):
+                f, full = str(r.choice(["rgba8", "bgra8"])), r.random() < 0.6
+                gw, gh = (ow, oh) if full else (int(r.choice([48, 100, 192])), int(r.integers(2, 30)))
+                kw = dict(offset_x=float(r.choice([0.0, 1.0, 0.4])) / ow, offset_y=float(r.choice([0.0, -1.0, 0.7])) / oh) if full else dict(scale_x=0.4, scale_y=0.5, offset_x=float(r.uniform(-0.4, 0.4)))
+                layers.append(dict(src=Src(frames.pack_random(f, gw, gh, 7200 + case + i), gw, gh, m(ow, oh, **kw), fmt=f)))
         if case % 3 == 0:  # a program of planar clips at their own scale: the tap-sharing instantiation
             h2 = oh + (oh & 1)
             layers = [dict(src=Src(frames.pack_random(f, ow, h2 if f in ("yuv420p", "nv12") else oh, 7000 + case + i), ow, h2 if f in ("yuv420p", "nv12") else oh,
