@@ -289,7 +289,7 @@ class ClockSampler:
 
 
 def secondary_counters(timeout_s=240):
-    """Counters of the secondary workloads' kernels, measured NOW: tools/config_bench.py --best is run three more times, briefly, as a
+    """Counters of the secondary workloads' kernels, measured NOW: tools/config_bench.py --best is run again, briefly, config group by config group (PH_CONFIG_BENCH_ONLY), as a
     child of `rocprofv3 --kernel-trace --pmc <counter>` (one counter per pass: SQ_INSTS_VALU, FETCH_SIZE, WRITE_SIZE), and each
     kernel's per-dispatch values are averaged.  Returns ({counter: {kernel name: mean}}, None) or (None, reason)."""
     import csv
@@ -301,11 +301,13 @@ def secondary_counters(timeout_s=240):
     if not exe:
         return None, "rocprofv3 is not on PATH"
     got = {}
-    for counter in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+    # the configs go through the passes in groups whose kernels do not share names: the file-playback entries (f1 - f3) launch the 2 x 2-block
+    # compositor at three more shapes, and a per-name average over all of them would belong to none.  A group's counters are kept under its prefix
+    for group, counter in [(g, c) for g in ("2,7,3", "f1", "f2", "f3") for c in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE")]:
         out = tempfile.mkdtemp(prefix="ph_bench_pmc2_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
                os.path.join(ROOT, "tools", "config_bench.py"), "--best", "--reps", "12"]
-        env = dict(os.environ, TMPDIR="/tmp", PH_CONFIG_BENCH_WARM_S="0.02")
+        env = dict(os.environ, TMPDIR="/tmp", PH_CONFIG_BENCH_WARM_S="0.02", PH_CONFIG_BENCH_ONLY=group)
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PH_BENCH_FORCE_DIST"):
             env.pop(k, None)
         try:
@@ -316,8 +318,8 @@ def secondary_counters(timeout_s=240):
                     if row.get("Counter_Name") == counter:
                         vals.setdefault(row.get("Kernel_Name", ""), []).append(float(row["Counter_Value"]))
             if not vals:
-                return None, "%s pass: no counter values (exit %d)" % (counter, r.returncode)
-            got[counter] = {k: sum(v) / len(v) for k, v in vals.items()}
+                return None, "%s pass of group %s: no counter values (exit %d)" % (counter, group, r.returncode)
+            got.setdefault(group, {})[counter] = {k: sum(v) / len(v) for k, v in vals.items()}
         except Exception as e:
             return None, "%s pass failed: %s: %s" % (counter, type(e).__name__, e)
         finally:
@@ -335,7 +337,8 @@ def name_binding_resources(records, counters):
             continue
         ms = [v for k, v in rec.items() if k.startswith("ms_per_")][0]
         per_unit = {}
-        for counter, by_kernel in counters.items():
+        group = [g for g in counters if any(rec["config"].startswith(x) for x in g.split(","))]
+        for counter, by_kernel in (counters[group[0]] if group else {}).items():
             total, found = 0.0, True
             for sub, n in kl.items():
                 hit = [v for k, v in by_kernel.items() if sub in k]

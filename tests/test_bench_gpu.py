@@ -62,7 +62,8 @@ def test_default_line_as_the_driver_runs_it():
     assert line["roofline"]["valu"]["frac"] > 0.2
     # config 2 alone and four such channels per launch (round 5), 720p50 (the reference's third format) fused / through the channel kernel /
     # four channels per launch, config 3
-    assert [s["config"][:5] for s in line["secondary"]] == ["2: 1 ", "2 x 4", "720p5", "720p5", "720p5", "3: 1 "]
+    # ... and file playback (round 5): a 1080p and a 720p yuv420p clip on a 1080p channel, 4 x 1080i on a 1080p channel
+    assert [s["config"][:5] for s in line["secondary"]] == ["2: 1 ", "2 x 4", "720p5", "720p5", "720p5", "3: 1 ", "f1: 1", "f2: 1", "f3: 1"]
     for s in line["secondary"]:
         assert 0 < s["roofline"]["frac"] < 1
     batch, alone = line["secondary"][1], line["secondary"][0]

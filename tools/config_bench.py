@@ -44,6 +44,8 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
         return [torch.empty(w * h * 4, dtype=torch.float32, device="cuda") for _ in range(n)]
 
     def timeit(fn, n):
+        if only and not any(current[0].startswith(x) for x in only):  # PH_CONFIG_BENCH_ONLY: this config's kernels are not run at all
+            return float("nan")
         # the chip needs ~50 ms of load before its clocks settle (bench.py's FIXED_WARMUP, profiles/r02_bench_repeat.jsonl): a route is
         # run untimed for 0.15 s first - measured straight after an idle spell, the first route of a config came out 8 % slower than
         # the same route measured second (config 3: 113.9 against 105.2 us per field)
@@ -65,8 +67,12 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
         return e0.elapsed_time(e1) / n
 
     out_records = []
+    only = [x for x in os.environ.get("PH_CONFIG_BENCH_ONLY", "").split(",") if x]  # config-name prefixes (bench.py's counter passes take the groups one by one)
+    current = [""]  # the config whose routes are being timed (set before each config's first timeit)
 
     def record(config, route, unit, ms, algo, kernels, kernel_launches=None, **extra):
+        if ms != ms:  # not selected (timeit)
+            return
         rec = {"config": config, "route": route, "kernels_per_%s" % unit: kernels, "ms_per_%s" % unit: round(ms, 4),
                "%ss_per_sec" % unit: round(1e3 / ms, 1), "algorithmic_bytes": algo,
                "roofline": {"bound": "hbm", "achieved": round(algo / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -139,6 +145,7 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     # what the benched kernel really reads and writes: five v210 frames in, one out, and the wipe's mask as an f32 RGBA image
     # (SURVEY's 38.7 MB counts the mask as a sixth v210-sized input)
     benched2 = 6 * capi.v210_pitch_bytes(w) * h + w * h * 16
+    current[0] = name2
     record(name2, "channel compositor straight from v210 (ph_chan_compose_v210): [read x5 + transform x4 + transition_wipe + combine_4 + write] "
            "as one kernel, no f32 frame in HBM", "frame", timeit(config2_chan, reps), algo2, 1, {"chan_compose_v210_kernel<0, 0>": 1.0},
            bytes_as_benched=benched2, bytes_as_benched_note="5 v210 frames in + 1 out + the wipe's mask as the f32 RGBA image the kernel reads "
@@ -179,6 +186,7 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     torch.cuda.synchronize()
     algo7 = 5 * capi.v210_pitch_bytes(w7) * h7
     name7 = "720p50: 1 channel, 4 x 1280x720 v210 layers -> 1 v210 frame (lines with a tail quad: the reference's tail arithmetic)"
+    current[0] = name7
     record(name7, "fused unpack / CSC / combine_4 / CSC / pack, 1:1 layers (ph_fused_v210_combine, tail instantiation)", "frame",
            timeit(lambda i: ctx.fused_v210_combine(src7[i % R], out7, w7, h7, *rd7, *wr7), reps), algo7, 1, {"fused_v210_combine_lds_kernel": 1.0})
     record(name7, "channel compositor straight from v210, a full-frame layer and three quarter-size insets (ph_chan_compose_v210, general instantiation)", "frame",
@@ -270,6 +278,7 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
 
     algo3 = 4 * 3 * capi.v210_pitch_bytes(sw) * sh + capi.v210_pitch_bytes(ow) * oh  # 88 473 600
     name3 = "3: 1 channel, 4 x 1080i50 -> yadif -> 2x up-scale -> 709->2020 -> combine_4 -> 2160p50 (per output field)"
+    current[0] = name3
     record(name3, "fused de-interlacing reader (packed RGB fields) + 2x2-block compositor, two launches per frame: [unpack + yadif, both fields, x4 layers] "
            "(ph_v210_yadif_pair_fmt), [transform x4 + combine_4 + write, both fields] (ph_compose_up_write_v210_pair)", "field",
            timeit(config3_up_pair, reps), algo3, 1.0, {"v210_yadif_pair_kernel": 0.5, "compose_up_write_v210_kernel": 0.5})
@@ -283,6 +292,50 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
                "[transform x4 + combine_4 + write]", "field", timeit(config3_pair, reps), algo3, 3.5)
         record(name3, "fused compositor: read x4 every other field, yadif x4, [transform x4 + combine_4 + write]", "field",
                timeit(config3_fused, reps), algo3, 7)
+    # ---------------- file playback: what the reference's producers really hand over (ffmpegProducer.ts:395-442) ---------------------------------
+    # a decoder's planar frames at the clip's own size, the Mixer's default fill; inside ph_chan_compose_v210 such frames are the reader of the
+    # format + the 2 x 2-block compositor (DESIGN.md section 5 "Frames of ENLARGED clips")
+    fw, fh = 1920, 1080
+    frd, fwr = colour("709", "709")
+    cm8 = dev(capi.ycbcr2rgb_matrix("709", 8, 16, 235, 224))
+    fout = torch.empty(capi.v210_pitch_bytes(fw) * fh // 4, dtype=torch.int32, device="cuda")
+
+    def yuv420p(w_, h_):
+        pitch = (w_ + 7) // 8 * 8
+        return tuple(torch.randint(0, 256, (k,), dtype=torch.uint8, device="cuda") for k in (pitch * h_, pitch * h_ // 4, pitch * h_ // 4))
+    for cw, ch, what in ((1920, 1080, "f1: 1 channel, one 1080p yuv420p file clip under the default fill -> 1080p50 v210"),
+                         (1280, 720, "f2: 1 channel, one 720p yuv420p file clip filling a 1080p50 channel -> v210")):
+        clips = [yuv420p(cw, ch) for _ in range(R)]
+        fm = capi.transform_matrix(fw, fh)
+        jobs = [ctx.chan_compose_v210([dict(src=(c, cw, ch, fm, "yuv420p", cm8))], fout, fw, fh, 0, *frd, *fwr, prepare_only=True) for c in clips]
+        torch.cuda.synchronize()
+        algo_f = cw * ch * 3 // 2 + capi.v210_pitch_bytes(fw) * fh
+        current[0] = what
+        record(what, "ph_chan_compose_v210 on the decoder's planes: inside, [yuv420p -> f32 image] (ph_pack_read) + [transform + write] (ph_compose_up_write_v210), two launches", "frame",
+               timeit(lambda i: jobs[i % R](), reps), algo_f, 2, {"fmt_read_lds_kernel": 1.0, "compose_up_write_v210_kernel": 1.0})
+    # config 3 in the reference's own formats: 4 x 1080i50 -> yadif -> own size on a 1080p50 channel (src/config.ts:43-78), per output field
+    isrc = [v210(fw, fh, 4) for _ in range(R)]
+    iwin = [[isrc[k % R][l] for k in range(3)] for l in range(4)]
+    irgb = [[torch.empty(fw * fh * 3, dtype=torch.float32, device="cuda") for _ in range(2)] for _ in range(4)]
+    iouts = [torch.empty(capi.v210_pitch_bytes(fw) * fh // 4, dtype=torch.int32, device="cuda") for _ in range(2)]
+    ifill = capi.transform_matrix(fw, fh)
+    ipair = ctx.compose_up_write_v210_pair([(irgb[l][0], fw, fh, ifill) for l in range(4)], [(irgb[l][1], fw, fh, ifill) for l in range(4)], iouts[0], iouts[1], fw, fh, 0, *fwr,
+                                           rgb=True, prepare_only=True)
+    torch.cuda.synchronize()
+
+    def config3b(i):
+        if not (i & 1):
+            s = isrc[(i // 2) % R]
+            for l in range(4):
+                iwin[l] = [iwin[l][1], iwin[l][2], s[l]]
+            ctx.v210_yadif_pair([(iwin[l][0], iwin[l][1], iwin[l][2], irgb[l][0], irgb[l][1]) for l in range(4)], fw, fh, 1, False, *frd, rgb=True)
+            ipair()
+    current[0] = "f3"
+    record("f3: 1 channel, 4 x 1080i50 -> yadif -> own size -> combine_4 -> 1080p50 v210 (per output field)",
+           "fused de-interlacing reader (packed RGB fields) + 2x2-block compositor under the default fill, two launches per frame", "field",
+           timeit(config3b, reps), 4 * 3 * capi.v210_pitch_bytes(fw) * fh // 2 + capi.v210_pitch_bytes(fw) * fh, 1.0,
+           {"v210_yadif_pair_kernel": 0.5, "compose_up_write_v210_kernel": 0.5})
+    current[0] = name3
     if routes == "all":
         up = img(ow, oh, 4)
         comb3 = img(ow, oh)[0]
