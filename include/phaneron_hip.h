@@ -390,6 +390,8 @@ int ph_compose_wipe_write_v210(ph_ctx *ctx, int queue, int n, const ph_layer *la
  *      loads per layer and pixel instead of 4.  Sources are f32 RGBA images or packed f32 RGB (PH_IMG_RGB_F32, alpha
  *      == 1 implied: ph_v210_yadif_pair_fmt), all layers of a call in the same layout.  Bit-identical to ph_transform +
  *      ph_combine + ph_v210_write.  A field write (interlace 1 / 3) needs more than 2x vertically: its rows are two lines apart.
+ *      One placement at scale one qualifies too: an image of the frame's size under the Mixer's default fill (the identity matrix, a
+ *      frame write) - de-interlaced 1080i fields on a 1080 channel.
  *      PH_E_INVALID when a placement does not qualify (use ph_compose_write_v210),
  *      out_width % 48 != 0 or the writer LUT is not registered.  interlace as ph_v210_write. ------------------- */
 typedef struct ph_image_layer {
