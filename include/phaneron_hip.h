@@ -35,7 +35,7 @@ extern "C" {
  * 5: ph_compose_up_write_v210_pair, ph_lut_layout_of
  * 6: ph_fused_field_v210 / ph_field_layer REMOVED (the slowest route of its workload by 2.7x, no caller).  The fused entry
  *    points take widths that are not a multiple of 48 (1280 x 720: the reference's third format, src/config.ts:43-54)
- * 7: additive over 6 - ph_chan_compose_batch (ph_chan_job): several channels' frames in one launch; ph_run_programs; ph_compose_up_write_v210_batch;
+ * 7: additive over 6 - ph_chan_compose_batch (ph_chan_job): several channels' frames in one launch; ph_run_programs; ph_compose_up_write_v210_batch; ph_pack_read_batch;
  *    ph_event_record_timed / ph_event_elapsed_us; ph_ctx_host_pool_stats; "host_pool_mb" defaults to 4096 again and never
  *    keeps less than the working set */
 #define PH_ABI_VERSION 7
@@ -330,6 +330,11 @@ int ph_pack_plane_bytes(int format, uint32_t width, uint32_t height, size_t byte
 int ph_pack_read(ph_ctx *ctx, int queue, int format, const void *const planes[3], void *out,
                  uint32_t width, uint32_t height, const void *col_matrix12, const void *gamma_lut,
                  const void *gamut_matrix9);
+/* n frames (1 .. 8) of ONE format, size and Loader recipe in one launch - several channels' clips of a tick (the reference's channels share a
+ * context and a queue: src/index.ts:45-71,156-160): planes[i] are frame i's planes as ph_pack_read takes them, outs[i] its f32 RGBA image.
+ * Exactly n ph_pack_read calls; PH_FMT_V210 goes to ph_v210_read_batch. */
+int ph_pack_read_batch(ph_ctx *ctx, int queue, int format, int n, const void *const (*planes)[3], void *const *outs, uint32_t width,
+                       uint32_t height, const void *col_matrix12, const void *gamma_lut, const void *gamut_matrix9);
 int ph_pack_write(ph_ctx *ctx, int queue, int format, const void *in, void *const planes[3],
                   uint32_t width, uint32_t height, uint32_t interlace, const void *col_matrix12,
                   const void *gamma_lut);

@@ -27,7 +27,7 @@ EXPORTS = [
     "ph_transition_dissolve", "ph_transition_wipe", "ph_mixer", "ph_wipe", "ph_fused_v210_combine",
     "ph_colour_gamma2linear_lut", "ph_colour_linear2gamma_lut", "ph_colour_ycbcr2rgb_matrix",
     "ph_colour_rgb2ycbcr_matrix", "ph_colour_rgb2rgb_matrix", "ph_transform_matrix",
-    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_lut_layout_of", "ph_compose_up_write_v210_pair", "ph_compose_up_write_v210_batch", "ph_ctx_set_option", "ph_compose_write_v210", "ph_compose_wipe_write_v210",
+    "ph_lut_register", "ph_lut_unregister", "ph_lut_query", "ph_lut_layout_of", "ph_compose_up_write_v210_pair", "ph_compose_up_write_v210_batch", "ph_pack_read_batch", "ph_ctx_set_option", "ph_compose_write_v210", "ph_compose_wipe_write_v210",
     "ph_pack_plane_bytes", "ph_pack_read", "ph_pack_write", "ph_queue_wait_queue", "ph_buf_download_async",
     "ph_event_record", "ph_event_wait", "ph_event_query", "ph_event_destroy", "ph_queue_query",
     "ph_graph_begin", "ph_graph_end", "ph_graph_launch", "ph_graph_destroy", "ph_fused_v210_combine_batch",
@@ -184,6 +184,7 @@ def lib():
         "ph_lut_layout_of": (ci, [f32p, C.POINTER(LutLayout), vp, C.c_size_t]),
         "ph_compose_up_write_v210_pair": (ci, [vp, ci, ci, C.POINTER(PhImageLayer), C.POINTER(PhImageLayer), vp, vp, cu, cu, cu, vp, vp]),
         "ph_compose_up_write_v210_batch": (ci, [vp, ci, ci, ci, C.POINTER(C.POINTER(PhImageLayer)), C.POINTER(vp), cu, cu, cu, vp, vp]),
+        "ph_pack_read_batch": (ci, [vp, ci, ci, ci, C.POINTER(vp * 3), C.POINTER(vp), cu, cu, vp, vp, vp]),
         "ph_ctx_set_option": (ci, [vp, C.c_char_p, ci]),
         "ph_pack_plane_bytes": (ci, [ci, cu, cu, C.POINTER(cs)]),
         "ph_pack_read": (ci, [vp, ci, ci, C.POINTER(vp), vp, cu, cu, vp, vp, vp]),
@@ -523,6 +524,16 @@ class Context:
         arr = (C.c_void_p * 3)(*([_ptr(p).value for p in planes] + [None] * (3 - len(planes))))
         check(lib().ph_pack_read(self.h, queue, FORMATS[fmt], arr, _ptr(dst), width, height,
                                  None if col_matrix is None else _ptr(col_matrix), _ptr(lut), _ptr(gamut)), self.h)
+
+    def pack_read_batch(self, fmt, frames, dsts, width, height, col_matrix, lut, gamut, queue=QUEUE_PROCESS):
+        """several frames of one format, size and Loader recipe in one launch (ph_pack_read_batch): frames = [planes, ...] as pack_read takes them"""
+        arr = ((C.c_void_p * 3) * len(frames))()
+        for i, planes in enumerate(frames):
+            for k, p in enumerate(planes):
+                arr[i][k] = _ptr(p).value
+        outs = (C.c_void_p * len(dsts))(*[_ptr(d).value for d in dsts])
+        check(lib().ph_pack_read_batch(self.h, queue, FORMATS[fmt], len(frames), arr, outs, width, height,
+                                       None if col_matrix is None else _ptr(col_matrix), _ptr(lut), _ptr(gamut)), self.h)
 
     def pack_write(self, fmt, src, planes, width, height, interlace, col_matrix, lut, queue=QUEUE_PROCESS):
         arr = (C.c_void_p * 3)(*([_ptr(p).value for p in planes] + [None] * (3 - len(planes))))

@@ -1905,6 +1905,36 @@ int ph_pack_read(ph_ctx *ctx, int queue, int format, const void *const planes[3]
                                  (uint32_t)ctx->props.multiProcessorCount));
 }
 
+int ph_pack_read_batch(ph_ctx *ctx, int queue, int format, int n, const void *const (*planes)[3], void *const *outs, uint32_t width, uint32_t height,
+                       const void *cm, const void *lut, const void *gm) {
+  if (!ctx || !planes || !outs || !lut || !gm || !width) return fail(PH_E_INVALID, "ph_pack_read_batch: NULL/zero argument");
+  if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_pack_read_batch: 1..%d frames", ph::kMaxLayers);
+  const ph::LutView *v = format == PH_FMT_V210 ? nullptr : lds_view(ctx, lut);
+  if (n == 1 || !v) {  // one frame, v210 (its own batch call), or no LDS form of the table: frame by frame
+    if (format == PH_FMT_V210) {
+      const void *ins[ph::kMaxLayers];
+      for (int i = 0; i < n; ++i) ins[i] = planes[i][0];
+      return ph_v210_read_batch(ctx, queue, n, ins, outs, width, height, cm, lut, gm);
+    }
+    for (int i = 0; i < n; ++i) {
+      const int rc = ph_pack_read(ctx, queue, format, planes[i], outs[i], width, height, cm, lut, gm);
+      if (rc) return rc;
+    }
+    return PH_OK;
+  }
+  size_t pb[3];
+  const int np = ph::pack_plane_bytes(format, width, height, pb);
+  if (np < 0) return fail(PH_E_INVALID, "ph_pack_read_batch: unknown format %d", format);
+  for (int i = 0; i < n; ++i) {
+    if (!outs[i]) return fail(PH_E_INVALID, "ph_pack_read_batch: output %d is NULL", i);
+    for (int k = 0; k < np; ++k)
+      if (!planes[i][k]) return fail(PH_E_INVALID, "ph_pack_read_batch: frame %d: plane %d is NULL", i, k);
+  }
+  if (format < PH_FMT_RGBA8 && !cm) return fail(PH_E_INVALID, "ph_pack_read_batch: YCbCr formats need a colMatrix");
+  if (!height) return PH_OK;
+  PH_LAUNCH(ph::launch_pack_read_batch(stream_of(ctx, queue), format, n, planes, outs, width, height, cm, gm, *v, (uint32_t)ctx->props.multiProcessorCount));
+}
+
 int ph_pack_write(ph_ctx *ctx, int queue, int format, const void *in, void *const planes[3], uint32_t width,
                   uint32_t height, uint32_t interlace, const void *cm, const void *lut) {
   if (!ctx || !planes || !in || !lut || !width) return fail(PH_E_INVALID, "ph_pack_write: NULL/zero argument");
@@ -2158,7 +2188,22 @@ static int chan_compose_enlarged(ph_ctx *ctx, int queue, int jobs, int n, const 
   const int frames = jobs * n;
   bool all_v210 = true;
   for (int f = 0; f < frames; ++f) all_v210 = all_v210 && layers[f / n][f % n].src.format == PH_SRC_V210;
-  if (!all_v210) {  // each clip through the reader of its format (a source with code ranges of its own brings its Loader matrix)
+  bool one_reader = !all_v210 && one_size && frames > 1;  // every frame a decoder's frame of ONE format, size and Loader matrix: one launch reads them all
+  for (int f = 0; f < frames && one_reader; ++f) {
+    const ph_chan_source &S = layers[f / n][f % n].src, &S0 = layers[0][0].src;
+    one_reader = S.format == S0.format && S.format > PH_SRC_RGBA_F32 && S.col_matrix12 == S0.col_matrix12;
+  }
+  if (one_reader) {
+    const void *planes[ph::kMaxUpJobs * ph::kMaxLayers][3];
+    for (int f = 0; f < frames; ++f) {
+      const ph_chan_source &S = layers[f / n][f % n].src;
+      planes[f][0] = S.data, planes[f][1] = S.data_u, planes[f][2] = S.data_v;
+    }
+    const ph_chan_source &S0 = layers[0][0].src;
+    for (int f = 0; f < frames && rc == PH_OK; f += ph::kMaxLayers)
+      rc = ph_pack_read_batch(ctx, queue, PH_FMT_YUV422P10 + (S0.format - PH_SRC_YUV422P10), frames - f < ph::kMaxLayers ? frames - f : ph::kMaxLayers, planes + f, imgs + f,
+                              (uint32_t)S0.width, (uint32_t)S0.height, S0.col_matrix12 ? S0.col_matrix12 : rd_cm, rd_lut, rd_gm);
+  } else if (!all_v210) {  // each clip through the reader of its format (a source with code ranges of its own brings its Loader matrix)
     for (int f = 0; f < frames && rc == PH_OK; ++f) {
       const ph_chan_source &S = layers[f / n][f % n].src;
       if (S.format == PH_SRC_RGBA_F32) continue;  // an image: nothing to read

@@ -218,6 +218,8 @@ int pack_plane_bytes(int fmt, uint32_t width, uint32_t height, size_t bytes[3]);
 hipError_t launch_pack_read(hipStream_t s, int fmt, const void *const planes[3], void *out, uint32_t width,
                             uint32_t height, const void *cm, const void *table, const void *gm, const LutView *lv,
                             uint32_t num_cus);
+hipError_t launch_pack_read_batch(hipStream_t s, int fmt, int n, const void *const (*planes)[3], void *const *outs, uint32_t width, uint32_t height,
+                                  const void *cm, const void *gm, const LutView &lv, uint32_t num_cus);
 hipError_t launch_pack_write(hipStream_t s, int fmt, const void *in, void *const planes[3], uint32_t width,
                              uint32_t height, uint32_t interlace, const void *cm, const void *table, const LutView *lv,
                              uint32_t num_cus);

@@ -39,7 +39,7 @@ struct FmtReadArgs {
 
 // FMT is a template parameter: plane layout and sample width are compile-time
 template <int FMT, typename LUT, bool PERSISTENT>
-__device__ __forceinline__ void fmt_read_body(const FmtReadArgs &a, const LUT &lut) {
+__device__ __forceinline__ void fmt_read_body(const FmtReadArgs &a, const LUT &lut, uint32_t block = blockIdx.x, uint32_t blocks = gridDim.x) {
   ReadK k;
   if (FMT >= F_RGBA8) {  // the RGB formats carry no YCbCr matrix: gamut only (9 floats, never more)
 #pragma unroll
@@ -48,8 +48,8 @@ __device__ __forceinline__ void fmt_read_body(const FmtReadArgs &a, const LUT &l
     k = load_read_k(a.cm, a.gm);
   }
   const uint32_t total = a.width * a.lines;
-  const uint32_t stride = PERSISTENT ? gridDim.x * blockDim.x : total;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+  const uint32_t stride = PERSISTENT ? blocks * blockDim.x : total;
+  for (uint32_t p = block * blockDim.x + threadIdx.x; p < total; p += stride) {
     const uint32_t line = p / a.width, x = p - line * a.width;
     float4 o;
     if (FMT == F_RGBA8 || FMT == F_BGRA8) {  // rgba8.ts:49-62
@@ -86,6 +86,25 @@ __global__ __launch_bounds__(kLdsBlock) void fmt_read_lds_kernel(FmtReadArgs a, 
   lds_lut_load(lv);
   __syncthreads();
   fmt_read_body<FMT, LutInLds, true>(a, lut);
+}
+// several frames of one format, size and Loader recipe in one launch (several channels' clips of a tick: ph_pack_read_batch): the
+// workgroups go round the frames (uniform per workgroup: the frame's pointers are scalar loads), the table is loaded once per workgroup as ever
+struct FmtReadBatchArgs {
+  const void *p0[kMaxLayers], *p1[kMaxLayers], *p2[kMaxLayers];
+  float4 *out[kMaxLayers];
+  uint32_t jobs;
+  uint32_t width, lines, pitch;
+  const float *cm, *gm;
+  uint32_t nt;
+};
+template <int FMT>
+__global__ __launch_bounds__(kLdsBlock) void fmt_read_lds_batch_kernel(FmtReadBatchArgs b, LutView lv) {
+  const LutInLds lut{make_lut_k(lv)};
+  lds_lut_load(lv);
+  __syncthreads();
+  const uint32_t per_job = gridDim.x / b.jobs, job = blockIdx.x / per_job;  // (the launcher makes the grid a multiple of jobs)
+  const FmtReadArgs a{b.p0[job], b.p1[job], b.p2[job], b.out[job], b.width, b.lines, b.pitch, b.cm, b.gm, b.nt};
+  fmt_read_body<FMT, LutInLds, true>(a, lut, blockIdx.x - job * per_job, per_job);
 }
 template <int FMT>
 __global__ __launch_bounds__(kFmtBlock) void fmt_read_gather_kernel(FmtReadArgs a, const float *__restrict__ table) {
@@ -279,6 +298,35 @@ hipError_t launch_pack_read(hipStream_t s, int fmt, const void *const planes[3],
     case F_NV12: return launch_read_fmt<F_NV12>(s, a, (const float *)table, lv, num_cus);
     case F_RGBA8: return launch_read_fmt<F_RGBA8>(s, a, (const float *)table, lv, num_cus);
     case F_BGRA8: return launch_read_fmt<F_BGRA8>(s, a, (const float *)table, lv, num_cus);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int FMT>
+static hipError_t launch_read_batch_fmt(hipStream_t s, const FmtReadBatchArgs &b, const LutView &lv, uint32_t num_cus) {
+  const uint32_t total = b.width * b.lines;
+  if (!total) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fmt_read_lds_batch_kernel<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
+  if (e != hipSuccess) return e;
+  const uint32_t want = (total + kLdsBlock - 1) / kLdsBlock, share = num_cus / b.jobs ? num_cus / b.jobs : 1u, per_job = want < share ? want : share;
+  fmt_read_lds_batch_kernel<FMT><<<per_job * b.jobs, kLdsBlock, lv.bytes, s>>>(b, lv);
+  return hipGetLastError();
+}
+// n frames (1 .. kMaxLayers) of one format, size and Loader recipe; the table in its LDS form
+hipError_t launch_pack_read_batch(hipStream_t s, int fmt, int n, const void *const (*planes)[3], void *const *outs, uint32_t width, uint32_t height,
+                                  const void *cm, const void *gm, const LutView &lv, uint32_t num_cus) {
+  const bool v420 = (fmt == F_YUV420P || fmt == F_NV12);
+  FmtReadBatchArgs b{};
+  for (int i = 0; i < n; ++i) b.p0[i] = planes[i][0], b.p1[i] = planes[i][1], b.p2[i] = planes[i][2], b.out[i] = (float4 *)outs[i];
+  b.jobs = (uint32_t)n, b.width = width, b.lines = v420 ? (height / 2) * 2 : height, b.pitch = pack_pitch(fmt, width);
+  b.cm = (const float *)cm, b.gm = (const float *)gm, b.nt = image_nt((size_t)width * height * 16);
+  switch (fmt) {
+    case F_YUV422P10: return launch_read_batch_fmt<F_YUV422P10>(s, b, lv, num_cus);
+    case F_YUV422P8: return launch_read_batch_fmt<F_YUV422P8>(s, b, lv, num_cus);
+    case F_YUV420P: return launch_read_batch_fmt<F_YUV420P>(s, b, lv, num_cus);
+    case F_NV12: return launch_read_batch_fmt<F_NV12>(s, b, lv, num_cus);
+    case F_RGBA8: return launch_read_batch_fmt<F_RGBA8>(s, b, lv, num_cus);
+    case F_BGRA8: return launch_read_batch_fmt<F_BGRA8>(s, b, lv, num_cus);
     default: return hipErrorInvalidValue;
   }
 }

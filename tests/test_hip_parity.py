@@ -495,6 +495,23 @@ def test_reference_roundtrip_scripts_on_gpu(fmt, w, h, spec):
 
 
 @pytest.mark.parametrize("fmt", ["yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"])
+def test_pack_read_batch_equals_the_oracle_per_frame(fmt, lut_path):
+    """ph_pack_read_batch: 2, 5 and 8 frames of one format and size in one launch (several channels' clips of a tick) - every image the
+    oracle's reader of that frame; sizes that do not fill the chip and a ragged width"""
+    import torch
+    import hip_harness as hh
+    rng = orc.FORMAT_RANGE[fmt]
+    rcm, rlut, rgm = hh.ColourParams.fmt_reader(fmt, "709", "2020")
+    o_args = (None if rng is None else orc.ycbcr2rgb_matrix("709", *rng), orc.gamma2linear_lut("709"), orc.rgb2rgb_matrix("709", "2020"))
+    for (w, h, n) in ((384, 54, 2), (1920, 64, 5), (702 if fmt not in ("rgba8", "bgra8") else 704, 10, 8)):
+        frames_ = [frames.pack_random(fmt, w, h, 8800 + 13 * i + w) for i in range(n)]
+        outs = [torch.full((w * h * 4,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+        hh.ctx().pack_read_batch(fmt, [[hh.dev(p) for p in f] for f in frames_], outs, w, h, rcm, rlut, rgm)
+        for i in range(n):
+            assert_bits(hh.host(outs[i]), orc.pack_read(fmt, frames_[i], w, h, *o_args), "%s batch read %dx%d frame %d of %d" % (fmt, w, h, i, n))
+
+
+@pytest.mark.parametrize("fmt", ["yuv422p10", "yuv422p8", "yuv420p", "nv12", "rgba8", "bgra8"])
 def test_pack_formats_vs_oracle_1080(fmt):
     """Full-range random planes at 1920x270 (+ an odd tail width), both fields, against the oracle."""
     import torch
