@@ -92,8 +92,10 @@ async function channels(frames, w, h) {
 	const C = parseInt(process.env.PH_NODE_BENCH_CHANNELS || '4')
 	const n = 4
 	const plain = process.env.PH_NODE_BENCH_PLAIN === '1' // layers that are plain reads (no Mixer in the chain): the headline shape per channel
+	// file playback: ONE layer per channel, a decoder's yuv420p clip of PH_NODE_BENCH_FILE = "<w>x<h>" under the Mixer's default fill (ffmpegProducer.ts:395-442)
+	const file = process.env.PH_NODE_BENCH_FILE ? process.env.PH_NODE_BENCH_FILE.split('x').map((v) => parseInt(v)) : null
 	const rig = await Rig.open({ deviceIndex: 0, spinWaitMicros: 200, deferred: true })
-	const read = await rig.unpack('v210', w, h, '709', '709')
+	const read = file ? await rig.unpack('yuv420p', file[0], file[1], '709', '709') : await rig.unpack('v210', w, h, '709', '709')
 	const write = await rig.pack('v210', w, h, '709', false)
 	const combine = await rig.combine(n, w, h)
 	const transform = await rig.transform(w, h)
@@ -104,8 +106,17 @@ async function channels(frames, w, h) {
 	const src = []
 	for (let c = 0; c < C; ++c) {
 		const layers = []
-		for (let l = 0; l < n; ++l) {
-			const p = await rig.planes('v210', w, h)
+		for (let l = 0; l < (file ? 1 : n); ++l) {
+			const p = file ? await rig.planes('yuv420p', file[0], file[1]) : await rig.planes('v210', w, h)
+			if (file) {
+				for (const plane of p) {
+					await plane.hostAccess('writeonly', rig.ctx.queue.load)
+					for (let i = 0; i + 4 <= plane.length; i += 4) plane.writeUInt32LE(((i + 977 * c) * 2654435761) >>> 0, i)
+					await plane.hostAccess('none', rig.ctx.queue.load)
+				}
+				layers.push(p)
+				continue
+			}
 			await p[0].hostAccess('writeonly', rig.ctx.queue.load)
 			for (let i = 0; i < p[0].length; i += 4) p[0].writeUInt32LE(((0x200 + ((i + 977 * c + 13 * l) * 2654435761 >>> 22)) & 0x3ff) * 0x00100401 & 0x3fffffff, i)
 			await p[0].hostAccess('none', rig.ctx.queue.load)
@@ -125,6 +136,15 @@ async function channels(frames, w, h) {
 			const id = { source: `chan${c}`, timestamp: f }
 			const fresh = []
 			const placed = []
+			if (file) { // read -> transform (default fill) -> write: what a producer, the Mixer and a consumer post for one clip
+				const im = await rig.image(file[0], file[1])
+				rig.post(id, read(src[c][0], im))
+				const pl = await rig.image(w, h)
+				rig.post(id, transform(im, pl, mats[0]), () => im.release())
+				rig.post(id, write(pl, ring[c][slot], 0), () => pl.release())
+				ids.push(id)
+				continue
+			}
 			for (let l = 0; l < n; ++l) {
 				const im = await rig.image(w, h)
 				rig.post(id, read(src[c][l], im))
@@ -148,7 +168,7 @@ async function channels(frames, w, h) {
 	for (let f = 0; f < frames; ++f) await one(10 + f)
 	await rig.ctx.drain()
 	const sec = Number(process.hrtime.bigint() - t0) / 1e9
-	console.log(JSON.stringify({ bench: 'node', mode: 'channels', shape: plain ? 'plain reads' : 'config 2', channels: C, early_launch: rig.ctx.earlyLaunch, width: w, height: h, layers: n, frames, channel_frames_per_sec: +(C * frames / sec).toFixed(1),
+	console.log(JSON.stringify({ bench: 'node', mode: 'channels', shape: file ? `file playback: one ${file[0]}x${file[1]} yuv420p clip under the default fill` : plain ? 'plain reads' : 'config 2', channels: C, early_launch: rig.ctx.earlyLaunch, width: w, height: h, layers: n, frames, channel_frames_per_sec: +(C * frames / sec).toFixed(1),
 		us_per_frame: +(1e6 * sec / frames / C).toFixed(1), us_per_tick: +(1e6 * sec / frames).toFixed(1), deferred: rig.ctx.deferredStats(),
 		buffers: rig.ctx.bufferStats() }))
 	;[...src.flat(2), ...ring.flat(2)].forEach((b) => b.release())

@@ -130,7 +130,8 @@ $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
  for r in 1 0; do for size in "3000 3840 2160" "5000 1920 1080"; do PHANERON_RECYCLE=$r PH_NODE_BENCH_MODES=deferred node $ROOT/node/test/bench_node.js $size | sed "s/^{/{\"recycle_buffers\": $r, /"; done;
    for c in 1 4; do PHANERON_RECYCLE=$r PH_NODE_BENCH_CHANNELS=$c PH_NODE_BENCH_MODES=channels node $ROOT/node/test/bench_node.js 3000 1920 1080 | sed "s/^{/{\"recycle_buffers\": $r, /"; done; done;
  PHANERON_EARLY_LAUNCH=1 PH_NODE_BENCH_CHANNELS=4 PH_NODE_BENCH_MODES=channels node $ROOT/node/test/bench_node.js 3000 1920 1080;
- for c in 1 4; do for e in 0 1; do PH_NODE_BENCH_PLAIN=1 PHANERON_EARLY_LAUNCH=$e PH_NODE_BENCH_CHANNELS=$c PH_NODE_BENCH_MODES=channels node $ROOT/node/test/bench_node.js 3000 1920 1080; done; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_bench.jsonl
+ for c in 1 4; do for e in 0 1; do PH_NODE_BENCH_PLAIN=1 PHANERON_EARLY_LAUNCH=$e PH_NODE_BENCH_CHANNELS=$c PH_NODE_BENCH_MODES=channels node $ROOT/node/test/bench_node.js 3000 1920 1080; done; done;
+ for f in 1920x1080 1280x720; do for c in 1 4; do PH_NODE_BENCH_FILE=$f PH_NODE_BENCH_CHANNELS=$c PH_NODE_BENCH_MODES=channels node $ROOT/node/test/bench_node.js 3000 1920 1080; done; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_bench.jsonl
 node $ROOT/node/test/soak_run.js 100000 2>/dev/null | grep '^{' > $OUT/${TAG}_node_soak.json
 (node $ROOT/node/test/napi_costs.js 1920 1080; node $ROOT/node/test/napi_costs.js 3840 2160; node $ROOT/node/test/defer_host_bench.js 20000; node $ROOT/node/test/defer_host_bench.js 20000 --plain) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_host_costs.jsonl
 # the recording context (node/defer.js) against the launch-as-posted one: scenarios, frames compared byte for byte, launch counters
