@@ -2116,7 +2116,9 @@ static int chan_ops(int n, const ph_chan_layer *layers, uint32_t out_w, uint32_t
 // one conversion per SOURCE pixel, then ph_compose_up_write_v210 on them.  Same arithmetic, same bits (tests/test_chan_gpu.py checks both
 // routes against the chain of the reference's operators); 1280 x 720 -> 1920 x 1080: 26.4 -> 17.7 us, 1080p -> 2160p: 82 -> 38 us (tools/enlarge_bench.py).
 // Context option "chan_enlarged" = 0 (or PH_CHAN_ENLARGED=0): such frames through the channel kernel like any other (A/B runs, tests of that path).
-static bool chan_layers_enlarged(int n, const ph_chan_layer *layers, uint32_t out_w, uint32_t out_h, uint32_t interlace) {
+// v210_fill: v210 frames under the default fill count too - only worth it when several channels' frames of one shape share the launches
+// (one alone: 22.3 us by the channel kernel against 23.5; four to a call 18.7 against 15.6): ph_chan_compose_batch asks that way
+static bool chan_layers_enlarged(int n, const ph_chan_layer *layers, uint32_t out_w, uint32_t out_h, uint32_t interlace, bool v210_fill = false) {
   if (out_w % 2u) return false;
   for (int i = 0; i < n; ++i) {
     const ph_chan_layer &L = layers[i];
@@ -2130,7 +2132,7 @@ static bool chan_layers_enlarged(int n, const ph_chan_layer *layers, uint32_t ou
     // ... or a decoder's frame of the channel's size under the Mixer's default fill (the compositor takes exactly that placement beside the
     // enlargements: compose_up_eligible): a 1080p yuv420p clip 26.1 -> 22.6 us, under a bgra8 graphic 45.2 -> 40.2.  Not v210 frames: the channel
     // kernel's shared taps serve those better (22.3 against 23.2 us)
-    const bool fill = L.src.format != PH_SRC_V210 && !interlace && (uint32_t)L.src.width == out_w && (uint32_t)L.src.height == out_h && m[0] == 1.0f && m[4] == 1.0f &&
+    const bool fill = (v210_fill || L.src.format != PH_SRC_V210) && !interlace && (uint32_t)L.src.width == out_w && (uint32_t)L.src.height == out_h && m[0] == 1.0f && m[4] == 1.0f &&
                       m[2] == 0.0f && m[5] == 0.0f;
     if (!fill && ((double)m[0] * L.src.width > 0.99 * out_w || (double)m[4] * L.src.height * (interlace ? 2 : 1) > 0.99 * out_h)) return false;
     if ((uint64_t)L.src.width * 16u * (uint64_t)L.src.height >= (1ull << 30) || L.src.width >= (1 << 22)) return false;
@@ -2377,10 +2379,23 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
     const bool is_field = J.interlace != 0;
     const uint32_t lines = is_field ? out_h / 2 : out_h;
     const uint32_t fit = chan_batch_on() ? jobs_per_launch : 0u;
-    if (lines && ctx->chan_enlarged && chan_layers_enlarged(J.n, J.layers, out_w, out_h, J.interlace)) {  // read + 2 x 2-block compositor, in its turn
+    bool routed = lines && ctx->chan_enlarged && chan_layers_enlarged(J.n, J.layers, out_w, out_h, J.interlace);  // read + 2 x 2-block compositor, in its turn
+    bool fits = false;
+    auto fits_group = [&]() {
+      bool f = enl > 0 && enl < ph::kMaxUpJobs && J.n == enl_n && J.interlace == enl_interlace && chan_enlarged_same_shape(J.n, enl_layers[0], J.layers);
+      for (int e = 0; e < enl && f; ++e) f = enl_outs[e] != J.out;
+      return f;
+    };
+    if (!routed && lines && ctx->chan_enlarged && chan_layers_enlarged(J.n, J.layers, out_w, out_h, J.interlace, true)) {
+      // v210 frames under the default fill: by the route if they share its launches with a neighbour of their shape, else the batch kernel's
+      const bool with_next = j + 1 < n_jobs && jobs[j + 1].n == J.n && jobs[j + 1].interlace == J.interlace && jobs[j + 1].out != J.out && jobs[j + 1].layers &&
+                             chan_layers_enlarged(jobs[j + 1].n, jobs[j + 1].layers, out_w, out_h, jobs[j + 1].interlace, true) &&
+                             chan_enlarged_same_shape(J.n, J.layers, jobs[j + 1].layers);
+      routed = fits_group() || with_next;
+    }
+    if (routed) {
       if ((rc = flush())) return rc;
-      bool fits = enl > 0 && enl < ph::kMaxUpJobs && J.n == enl_n && J.interlace == enl_interlace && chan_enlarged_same_shape(J.n, enl_layers[0], J.layers);
-      for (int e = 0; e < enl && fits; ++e) fits = enl_outs[e] != J.out;
+      fits = fits_group();
       if (!fits && (rc = flush_enlarged())) return rc;
       enl_layers[enl] = J.layers, enl_outs[enl] = J.out, enl_n = J.n, enl_interlace = J.interlace, ++enl;
       continue;

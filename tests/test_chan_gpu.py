@@ -797,3 +797,18 @@ def test_graphics_over_v210_clips(fmt):
             check([clip, dict(src=Src(g, w, h, m(w, h), fmt=fmt))], w, h, "%s graphic over a v210 clip, field %d" % (fmt, interlace), interlace=interlace, poison_dst=True)
     check_format([dict(src=Src(frames.v210_random(384, 54, frames.layer_seed(92, 0)), 384, 54, m(384, 54))), dict(src=Src(frames.pack_random(fmt, 384, 54, 975), 384, 54, m(384, 54), fmt=fmt))],
                  384, 54, "yuv422p8", "%s graphic over a v210 clip into the encoder's frame" % fmt)
+
+
+def test_channels_of_v210_clips_under_the_default_fill_share_the_route():
+    """several channels each showing a v210 clip of the channel's size under the default fill (live sources): in one call their frames go by one
+    batched read and one launch of the 2 x 2-block compositor; one such frame alone, or between frames of other shapes, stays the channel kernel's.
+    Every frame against the oracle's chain and against its own single call (the channel kernel), with the option on and off"""
+    w, h = 384, 54
+    live = lambda seed: [dict(src=Src(frames.v210_random(w, h, frames.layer_seed(seed, 0), legal=bool(seed & 1)), w, h, m(w, h)))]
+    two = lambda seed: [dict(src=Src(frames.v210_random(w, h, frames.layer_seed(seed, l)), w, h, m(w, h))) for l in range(2)]
+    v = channel_variants(w, h, 460)
+    jobs = [(live(461), 0, 0), (live(462), 0, 1), (live(463), 0, 2), (v[0], 0, 3), (live(464), 0, 4), (v[3], 0, 5), (two(465), 0, 6), (two(467), 0, 7),
+            (live(469), 0, 8), (live(470), 0, 9), (live(471), 0, 10), (live(472), 0, 11), (live(473), 0, 12)]
+    both_routes(lambda route: check_batch(jobs, w, h, "channels of v210 clips under the default fill, those by the %s" % route))
+    w, h = 1920, 1080
+    both_routes(lambda route: check_batch([(live(480 + c), 0, c) for c in range(4)], w, h, "four 1080p channels of live clips by the %s" % route))

@@ -120,7 +120,8 @@ python $ROOT/tools/route_bench.py --loopback 2>/dev/null | grep '^{' > $OUT/${TA
  for f in yuv420p yuv422p10 nv12; do PH_ENLARGE_FORMAT=$f python $ROOT/tools/enlarge_bench.py 500 1 1280 720 1920 1080; done; PH_ENLARGE_FORMAT=yuv420p python $ROOT/tools/enlarge_bench.py 500 1 720 576 1920 1080;
  PH_ENLARGE_FORMAT=yuv420p python $ROOT/tools/enlarge_bench.py 500 2 1280 720 1920 1080; PH_ENLARGE_FORMAT=yuv422p10 python $ROOT/tools/enlarge_bench.py 500 1 1920 1080 3840 2160;
  PH_ENLARGE_CHANNELS=4 PH_ENLARGE_FORMAT=yuv420p python $ROOT/tools/enlarge_bench.py 500 1 1280 720 1920 1080;
- for C in 1 4; do PH_ENLARGE_CHANNELS=$C PH_ENLARGE_FORMAT=yuv420p python $ROOT/tools/enlarge_bench.py 500 1 1920 1080 1920 1080; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_enlarge_bench.jsonl
+ for C in 1 4; do PH_ENLARGE_CHANNELS=$C PH_ENLARGE_FORMAT=yuv420p python $ROOT/tools/enlarge_bench.py 500 1 1920 1080 1920 1080; done;
+ for C in 1 2 4; do PH_ENLARGE_CHANNELS=$C python $ROOT/tools/enlarge_bench.py 500 1 1920 1080 1920 1080; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_enlarge_bench.jsonl
 python $ROOT/tools/config3b_bench.py 300 2>/dev/null | grep '^{' > $OUT/${TAG}_config3b.json
 python $ROOT/tools/staging_bench.py 60 2>/dev/null | grep '^{' > $OUT/${TAG}_staging_bench.jsonl
 $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
