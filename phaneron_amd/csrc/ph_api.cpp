@@ -1044,12 +1044,12 @@ int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
 // entry itself may be replaced by another thread once the lock is dropped.
 static const ph::LutView *lds_view(ph_ctx *ctx, const void *dev) {
   if (!ctx->use_lds_lut) return nullptr;
-  thread_local ph::LutView slots[4];
+  thread_local ph::LutView slots[16];  // (a caller that keeps a view across calls into other entry points copies it: ph_chan_compose_batch)
   thread_local unsigned next = 0;
   std::lock_guard<std::mutex> lock(ctx->mu);
   auto it = ctx->luts.find(dev);
   if (it == ctx->luts.end() || !it->second.view.bytes) return nullptr;
-  ph::LutView *v = &slots[next++ & 3u];
+  ph::LutView *v = &slots[next++ & 15u];
   *v = it->second.view;
   return v;
 }
@@ -2312,6 +2312,9 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
     if (!J.layers || !J.out || J.n < 1 || J.n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_chan_compose_batch: job %d: 1..%d layers and an output", j, ph::kMaxLayers);
     if (J.interlace != 0 && J.interlace != 1 && J.interlace != 3) return fail(PH_E_INVALID, "ph_chan_compose_batch: job %d: interlace must be 0, 1 or 3", j);
   }
+  // (lds_view hands out slots of a small per-thread ring: the calls made from here for single jobs and for the read + compositor route take
+  // slots too - an odd number of them, and `rv` would name the WRITER's table by the time a later launch's arguments are made.  Copies.)
+  const ph::LutView rview = *rv, wview = *wv;
   int rc = set_device(ctx);
   if (rc) return rc;
   // the common part of a launch's arguments (ChanArgs carries it to chan_batch_launch)
@@ -2319,7 +2322,7 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
     ph::ChanArgs a{};
     a.out_w = out_w, a.out_h = out_h;
     a.line_step = interlace ? 2 : 1, a.lines = interlace ? out_h / 2 : out_h;
-    a.rd_cm = (const float *)rd_cm, a.rd_gm = (const float *)rd_gm, a.wr_cm = (const float *)wr_cm, a.rd = *rv, a.wr = *wv;
+    a.rd_cm = (const float *)rd_cm, a.rd_gm = (const float *)rd_gm, a.wr_cm = (const float *)wr_cm, a.rd = rview, a.wr = wview;
     a.out_qpitch = ph_v210_pitch_bytes(out_w) / 16u;
     a.out_tail_from = out_w % 6 ? out_w - out_w % 6u : 0xFFFFFFFFu;
     a.planar = out_w % 48 ? 1u : 0u;

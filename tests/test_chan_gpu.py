@@ -616,7 +616,7 @@ def test_chan_batch_random_calls():
     against the oracle's chain and against the same jobs posted one call each"""
     r = np.random.default_rng(int(os.environ.get("PH_FUZZ_SEED", "20260930")))
     sizes = [(192, 9), (384, 33), (576, 16), (100, 9), (1280, 6), (960, 20)]
-    for case in range(int(os.environ.get("PH_FUZZ_CASES", "12"))):
+    for case in range(int(os.environ.get("PH_FUZZ_CASES", "30"))):
         ow, oh = sizes[case % len(sizes)]
         jobs, slot = [], 0
         while len(jobs) < int(r.integers(2, 11)):
@@ -812,3 +812,14 @@ def test_channels_of_v210_clips_under_the_default_fill_share_the_route():
     both_routes(lambda route: check_batch(jobs, w, h, "channels of v210 clips under the default fill, those by the %s" % route))
     w, h = 1920, 1080
     both_routes(lambda route: check_batch([(live(480 + c), 0, c) for c in range(4)], w, h, "four 1080p channels of live clips by the %s" % route))
+
+
+def test_chan_batch_keeps_its_tables_across_the_jobs_it_hands_on():
+    """regression (found by the seeded campaign, seed 31 case 62): ph_chan_compose_batch makes its launches' arguments late, after jobs it
+    handed on - a frame of an enlarged image to the compositor (one table looked up), a single job to the one-job kernel (two) - and
+    must still name ITS reader and writer tables in them: an enlarged f32 field, a frame on its own, then two fields in one launch"""
+    w, h = 576, 16
+    img = dict(src=Src(frames.rgba_random(288, 2, 990, -0.05, 1.05), 288, 2, m(w, h), fmt="rgba"))
+    v = channel_variants(w, h, 991)
+    jobs = [([img], 1, 0), (v[2], 3, 0), (v[1], 0, 1), (v[0], 1, 2), (v[3], 3, 2), ([img], 0, 3), (v[0], 0, 4), (v[1], 0, 5)]
+    both_routes(lambda route: check_batch(jobs, w, h, "jobs handed on between launches, images by the %s" % route, specs=("709", "2020")))
