@@ -620,11 +620,27 @@ def test_chan_batch_random_calls():
         ow, oh = sizes[case % len(sizes)]
         jobs, slot = [], 0
         while len(jobs) < int(r.integers(2, 11)):
+            planar = case % 2 == 1  # every other call has decoders' frames and graphics among its sources (those jobs run in their turn, or by the route)
             if r.random() < 0.25:  # both fields of one frame, from two programs
-                jobs.append((random_layers(r, ow, oh, int(r.integers(1, 4))), 1, slot))
-                jobs.append((random_layers(r, ow, oh, int(r.integers(1, 4))), 3, slot))
+                jobs.append((random_layers(r, ow, oh, int(r.integers(1, 4)), planar), 1, slot))
+                jobs.append((random_layers(r, ow, oh, int(r.integers(1, 4)), planar), 3, slot))
+            elif r.random() < 0.3:  # a run of channels showing clips of one shape under one placement (the read + compositor route's groups)
+                fmt = str(r.choice(["v210", "yuv420p", "bgra8"])) if planar else "v210"
+                cw, ch = (ow, oh) if r.random() < 0.5 else (ow // 2 // 6 * 6 or 6, max(2, oh // 2 // 2 * 2))
+                if fmt == "yuv420p":
+                    ch += ch & 1
+                    if (cw, ch) != (ow, oh + (oh & 1)) and cw == ow:
+                        cw, ch = ow // 2 // 6 * 6 or 6, max(2, oh // 2 // 2 * 2)
+                if (cw, ch) == (ow, oh) or cw < ow:
+                    for _ in range(int(r.integers(2, 6))):
+                        seed = int(r.integers(1, 1 << 30))
+                        data = frames.v210_random(cw, ch, seed) if fmt == "v210" else frames.pack_random(fmt, cw, ch, seed)
+                        jobs.append(([dict(src=Src(data, cw, ch, m(ow, oh), fmt=fmt))], 0, slot))
+                        slot += 1
+                    continue
+                jobs.append((random_layers(r, ow, oh, 1, planar), 0, slot))
             else:
-                jobs.append((random_layers(r, ow, oh, int(r.integers(1, 6))), int(r.choice([0, 0, 0, 1, 3])), slot))
+                jobs.append((random_layers(r, ow, oh, int(r.integers(1, 6)), planar), int(r.choice([0, 0, 0, 1, 3])), slot))
             slot += 1
         check_batch(jobs, ow, oh, "random call %d: %dx%d, %d jobs" % (case, ow, oh, len(jobs)), specs=[("709", "709"), ("709", "2020")][case % 2])
 
