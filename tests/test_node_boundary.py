@@ -716,6 +716,21 @@ def test_random_job_streams_give_the_same_bytes_through_the_recording_context():
 
 @needs_node
 @pytest.mark.gpu
+def test_random_multi_channel_ticks_equal_the_launch_as_posted_context():
+    """node/test/channels_fuzz.js: per tick 1 - 6 channels post a frame each - plain reads, clips under the default fill (v210 and decoders'
+    planar frames), clips smaller than the channel, picture-in-picture, graphics with alpha - and the tick goes to the device as one
+    runPrograms call: batch kernel, headline batch, read + compositor route (alone and grouped), jobs in their turn, in every order the
+    seeds produce.  Every consumer's frame equals the launch-as-posted context's; nothing refused, nothing left"""
+    _build_addon()
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "channels_fuzz.js"), "1", "24", "10"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["problems"] == [], res["problems"][:4]
+    assert res["deferred"]["fallbacks"] == 0 and res["deferred"]["plain"] == 0 and res["deferred"]["batched"] > res["deferred"]["launched"]
+
+
+@needs_node
+@pytest.mark.gpu
 def test_recording_context_soak_fault_and_timings():
     """The default (recording) context over 10^5 frames with a format change every 25 000 (1080 -> 720 -> 2160 -> 1080): buffer and
     pinned-memory counters flat, nothing pinned in steady state, no fused launch refused; launches made to fail while one frame's
