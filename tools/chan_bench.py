@@ -25,6 +25,7 @@ def main():
     # (another height: how much of a frame's time is the last, partial round of chunks)
     w, h, R = int(os.environ.get("PH_CHAN_BENCH_W", "1920")), int(os.environ.get("PH_CHAN_BENCH_H", "1080")), 8
     C = int(os.environ.get("PH_CHAN_BENCH_JOBS", "1"))
+    IL = int(os.environ.get("PH_CHAN_BENCH_INTERLACE", "0"))  # 1 / 3: a field write (a 1080i50 channel's consumer writes a field per 50p frame: macadamConsumer.ts:165)
     rd = [dev(capi.ycbcr2rgb_matrix("709")), dev(capi.gamma2linear_lut("709")), dev(np.concatenate([capi.rgb2rgb_matrix("709", "709"), np.zeros(3, np.float32)]))]
     wr = [dev(capi.rgb2ycbcr_matrix("709")), dev(capi.linear2gamma_lut("709"))]
     torch.cuda.synchronize()
@@ -73,7 +74,7 @@ def main():
         outs = [torch.empty(words, dtype=torch.int32, device="cuda") for _ in range(C)]
         jobs = [ctx.chan_compose_batch([(layers(src[(i + j) % R]), outs[j], 0) for j in range(C)], w, h, *rd, *wr, prepare_only=True) for i in range(R)]
     else:
-        jobs = [ctx.chan_compose_v210(layers(s), out, w, h, 0, *rd, *((None, wr[1]) if out_fmt in ("rgba8", "bgra8") else wr), prepare_only=True, out_fmt=out_fmt) for s in src]
+        jobs = [ctx.chan_compose_v210(layers(s), out, w, h, IL, *rd, *((None, wr[1]) if out_fmt in ("rgba8", "bgra8") else wr), prepare_only=True, out_fmt=out_fmt) for s in src]
     import time
     i, t0 = 0, time.perf_counter()
     while i < 8 or time.perf_counter() - t0 < 0.15:  # until the chip's clocks have settled (tools/config_bench.py timeit)
@@ -88,7 +89,7 @@ def main():
         jobs[i % R]()
     e1.record(stream)
     ctx.wait()
-    print(json.dumps({"kernel": "chan_compose_v210", "width": w, "height": h, "variant": variant, "mask": mask_kind, "sources": packing, "out": out_fmt, "jobs_per_launch": C,
+    print(json.dumps({"kernel": "chan_compose_v210", "width": w, "height": h, "variant": variant, "mask": mask_kind, "sources": packing, "out": out_fmt, "interlace": IL, "jobs_per_launch": C,
                       "batch_kernel": os.environ.get("PH_CHAN_BATCH", "1") != "0" and C > 1, "us_per_launch": round(1e3 * e0.elapsed_time(e1) / reps, 2),
                       "us_per_frame": round(1e3 * e0.elapsed_time(e1) / reps / C, 2)}), flush=True)
     ctx.close()
