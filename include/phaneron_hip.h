@@ -230,7 +230,8 @@ int ph_run_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args
  * (clJobQueue.ts:126 awaits runProgram), not where it is finally run. */
 int ph_check_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_args, int queue);
 /* Several jobs in one call, for a binding that records jobs and launches them later (node/defer.js): exactly ph_run_program(progs[j],
- * args[j], n_args[j]) for j = 0 .. n_jobs - 1 in that order, PROVIDED no job reads what another job of the call writes.  Every job is
+ * args[j], n_args[j]) for j = 0 .. n_jobs - 1 in that order (a job that reads or writes what an earlier job of the call writes, or writes what one
+ * reads, is kept out of that job's launch).  Every job is
  * checked before anything is launched (a bad job refuses the whole call).  Channel frames among the jobs - chan_compose_v210_<n>
  * programs of one geometry that name the SAME Loader / Saver buffers and make v210 frames - go to the device together
  * (ph_chan_compose_batch: the reference's channels share one context and one queue, src/index.ts:45-71,156-160); likewise consecutive

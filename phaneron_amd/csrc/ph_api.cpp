@@ -1740,11 +1740,29 @@ int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_
     }
     const ChanCall &c0 = calls[(size_t)j];
     std::vector<ph_chan_job> batch;
+    // a frame that reads what an earlier frame of the group writes (a channel routed into another), or writes what one reads, starts the next
+    // call of ph_chan_compose_batch: the jobs of one such call may share launches, and call order has to hold
+    const size_t out_bytes = (size_t)ph_v210_pitch_bytes(c0.width) * c0.height;
+    auto touches = [&](const void *p, size_t bytes, const void *out) {
+      const char *a0 = (const char *)p, *b0 = (const char *)out;
+      return p && a0 < b0 + out_bytes && b0 < a0 + (bytes ? bytes : 1);
+    };
+    auto reads = [&](const ChanCall &c, const void *out) {  // does a source of c overlap the frame at `out`?
+      for (int l = 0; l < c.n_layers; ++l)
+        for (const ph_chan_source *s2 : {&c.layers[l].src, &c.layers[l].incoming, &c.layers[l].mask})
+          if (s2->data && (touches(s2->data, (size_t)s2->width * s2->height * 16u, out) || touches(s2->data_u, (size_t)s2->width * s2->height * 2u, out) ||
+                           touches(s2->data_v, (size_t)s2->width * s2->height * 2u, out)))
+            return true;
+      return false;
+    };
     for (; k < n_jobs && kind[(size_t)k] == 1; ++k) {
       const ChanCall &c = calls[(size_t)k];
       if (c.width != c0.width || c.height != c0.height || c.rd_cm != c0.rd_cm || c.rd_lut != c0.rd_lut || c.rd_gm != c0.rd_gm || c.wr_cm != c0.wr_cm ||
           c.wr_lut != c0.wr_lut)
         break;
+      bool clash = false;
+      for (int e = j; e < k && !clash; ++e) clash = reads(c, calls[(size_t)e].out_planes[0]) || reads(calls[(size_t)e], c.out_planes[0]);
+      if (clash) break;
       batch.push_back(ph_chan_job{c.n_layers, c.layers, c.out_planes[0], c.interlace});
     }
     rc = ph_chan_compose_batch(ctx, queue, (int)batch.size(), batch.data(), c0.width, c0.height, c0.rd_cm->dptr, c0.rd_lut->dptr, c0.rd_gm->dptr,

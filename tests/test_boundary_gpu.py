@@ -3,6 +3,8 @@ N-API addon drives it: pooled ref-counted buffers with pinned mirrors, hostAcces
 directions, createProgram by kernel name / source, runProgram with arguments keyed by OpenCL argument
 name, queue ordering primitives and the staged producer -> GPU -> consumer ring.
 Results are checked against the oracle, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -398,6 +400,68 @@ def test_run_programs_puts_plain_read_channels_into_one_launch(ctx):
         o.host_access("readonly", capi.QUEUE_UNLOAD)
         assert np.array_equal(o.host(np.uint32), want[j].view(np.uint32) if want[j].dtype != np.uint32 else want[j]), "frame %d" % j
     for x in dev + outs:
+        x.release()
+    col.release()
+
+
+def test_run_programs_random_calls_with_frames_feeding_frames(ctx):
+    """seeded random ph_run_programs calls of fused_v210_combine_<n> and chan_compose_v210_<n> jobs in which a frame's layers may be EARLIER
+    frames of the same call (a channel routed into another: call order must hold however the library groups its launches), outputs may
+    be written twice, layer counts vary: every output equals the same jobs posted one ph_run_program each"""
+    w, h = 384, 54
+    r = np.random.default_rng(int(os.environ.get("PH_FUZZ_SEED", "77")))
+    col = Colour(ctx, "709", "709")
+    nbytes = capi.v210_pitch_bytes(w) * h
+    dev = [upload(ctx, frames.v210_random(w, h, frames.layer_seed(130, i)), svm="coarse") for i in range(6)]
+    mat = np.zeros(12, np.float32)
+    mat[:9] = capi.transform_matrix(w, h, scale_x=0.5, scale_y=0.5, offset_x=0.2)
+    fill = np.zeros(12, np.float32)
+    fill[:9] = capi.transform_matrix(w, h)
+    bm, bf = upload(ctx, mat), upload(ctx, fill)
+    ctx.wait(capi.QUEUE_LOAD)
+    recipe = {"colMatrix": col.rd_cm, "gammaLut": col.rd_lut, "gamutMatrix": col.rd_gm, "outColMatrix": col.wr_cm, "outGammaLut": col.wr_lut}
+    fused = {n: ctx.create_program("phaneron:fused", "fused_v210_combine_%d" % n, [w, h]) for n in (1, 2, 3)}
+    chan = {n: ctx.create_program("phaneron:chan", "chan_compose_v210_%d" % n, [w, h]) for n in (1, 2)}
+    for case in range(int(os.environ.get("PH_FUZZ_CASES", "25"))):
+        # [one call, separate calls]: the frames start out equal on both sides (a layer may be a frame nobody of the call has written yet)
+        outs = [[upload(ctx, frames.v210_random(w, h, frames.layer_seed(140, i)), svm="coarse") for i in range(5)] for _ in range(2)]
+        ctx.wait(capi.QUEUE_LOAD)
+        spec = []
+        for j in range(int(r.integers(2, 9))):
+            n = int(r.integers(1, 4))
+            kind = "fused" if r.random() < 0.6 else "chan"
+            if kind == "chan":
+                n = min(n, 2)
+            o = int(r.integers(0, 5))
+            layers = [("out", int(r.integers(0, 5))) if r.random() < 0.3 else ("src", int(r.integers(0, 6))) for _ in range(n)]
+            layers = [("src", i) if which == "out" and i == o else (which, i) for which, i in layers]  # (no frame made from itself: a race in any context)
+            spec.append((kind, n, o, layers, [bool(r.random() < 0.5) for _ in range(n)]))
+        for side in (0, 1):
+            jobs = []
+            for kind, n, o, layers, small in spec:
+                buf = lambda which, i: outs[side][i] if which == "out" else dev[i]
+                params = dict(recipe, output=outs[side][o])
+                for l, (which, i) in enumerate(layers):
+                    params["l%dIn" % l] = buf(which, i)
+                    if kind == "chan":
+                        params.update({"l%dWidth" % l: w, "l%dHeight" % l: h, "l%dMatrix" % l: bm if small[l] else bf})
+                if kind == "chan":
+                    params["interlace"] = 0
+                jobs.append(((fused if kind == "fused" else chan)[n], params))
+            if side == 0:
+                ctx.run_programs(jobs)
+            else:
+                for prog, params in jobs:
+                    ctx.run_program(prog, params)
+            ctx.wait()
+        for i in range(5):
+            a, b = outs[0][i], outs[1][i]
+            a.host_access("readonly", capi.QUEUE_UNLOAD)
+            b.host_access("readonly", capi.QUEUE_UNLOAD)
+            assert np.array_equal(a.host(np.uint32), b.host(np.uint32)), "case %d: frame %d of the one call differs from the separate calls: %r" % (case, i, spec)
+        for x in outs[0] + outs[1]:
+            x.release()
+    for x in dev + [bm, bf]:
         x.release()
     col.release()
 
