@@ -2,7 +2,7 @@
 // Random TICKS of a multi-channel playout through the recording context and through the plain one: per tick 1 - 6 channels post a frame
 // each, every channel a random one of the shapes a playout server shows - plain reads, a clip under the Mixer's default fill (v210 or a
 // decoder's planar frame), a clip SMALLER than the channel filling it, picture-in-picture over a full-frame clip, a graphic with alpha over
-// a clip - the reference's deployment (src/index.ts:45-71: channels of one format in one context).  The frames of a tick reach the device
+// a clip; whole frames and fields - the reference's deployment (src/index.ts:45-71: channels of one format in one context).  The frames of a tick reach the device
 // as ONE runPrograms call: frames for the batch kernel, for the headline kernel's batch form, for the read + 2 x 2-block compositor route
 // (alone or grouped by shape) and frames that run in their turn, in every order a seed produces.  Everything a consumer sees must be the
 // bytes of the launch-as-posted context.
@@ -25,7 +25,7 @@ async function play(seed, deferred) {
 	const pick = (list) => list[r() % list.length]
 	const sw = W / 2
 	const sh = H / 2 + ((H / 2) & 1)
-	const S = { read: {}, transform: await rig.transform(W, H), write: await rig.pack('v210', W, H, '709', false), combine: {} }
+	const S = { read: {}, transform: await rig.transform(W, H), write: await rig.pack('v210', W, H, '709', false), writeField: await rig.pack('v210', W, H, '709', true), combine: {} }
 	for (const n of [2, 3]) S.combine[n] = await rig.combine(n, W, H)
 	for (const f of ['v210', 'yuv420p', 'yuv422p10', 'nv12', 'bgra8']) {
 		S.read[`${f}|full`] = await rig.unpack(f, W, H, '709', '709')
@@ -75,7 +75,11 @@ async function play(seed, deferred) {
 			}
 			const out = (await rig.planes('v210', W, H, 'writeonly'))[0]
 			const last = frame
-			rig.post(id, S.write(last, [out], 0), () => last.release())
+			// every third frame or so is a FIELD of its channel's frame (the reference's channels are 1080i5000: macadamConsumer.ts:231); the other
+			// field's lines are what the frame held before - zeros here
+			const interlace = pick([0, 0, 1, 3])
+			if (interlace) await rig.upload(out, Buffer.alloc(out.length))
+			rig.post(id, (interlace ? S.writeField : S.write)(last, [out], interlace), () => last.release())
 			ids.push(id)
 			outs.push(out)
 		}
