@@ -111,6 +111,7 @@ struct ChanArgs {
   // (3 rows x rgb = 36 bytes), made by a pass in front of phase 1 and kept in the LDS behind the table
   uint32_t halo_off, halo_steps;  // byte offset in the LDS; steps per op the area holds (0: no sharing in this launch)
   uint32_t any_cm;                // launcher: some op brings a Loader matrix of its own (cm_op): the whole launch takes the general dot products
+  uint32_t images_only;           // launcher: every source is an f32 image (de-interlaced fields): nothing is looked up in the reader's table, it is not loaded
 };
 
 // Several channels' frames of ONE geometry and colour recipe in one launch (ph_chan_compose_batch) - what the reference runs: four

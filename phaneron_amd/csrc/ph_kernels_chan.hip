@@ -944,7 +944,7 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_v210_kernel(ChanArgs a
   const LutK rlut = make_lut_k(a.rd);
   const ChanShare sh = chan_share(a);
   PH_CPHASE(0);
-  lds_lut_load(a.rd);
+  if (!a.images_only) lds_lut_load(a.rd);  // (uniform; a program of f32 images converts nothing)
   __syncthreads();
   PH_CPHASE(1);
   if (ycbcr_matrix_is_standard(rk) && !(SRC >= 1 && a.any_cm)) {
@@ -1344,8 +1344,8 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
   b.magic_cpr = cpr > 1 ? (uint32_t)(((1ull << 32) + cpr - 1) / cpr) : 0u;
   b.magic_cpg = (uint32_t)(((1ull << 32) + cpg - 1) / cpg);
   const uint32_t grid = want < num_cus ? want : num_cus;
-  b.any_cm = 0;
-  for (int k = 0; k < b.n_ops; ++k) b.any_cm |= b.cm_op[k] ? 1u : 0u;
+  b.any_cm = 0, b.images_only = 1;
+  for (int k = 0; k < b.n_ops; ++k) b.any_cm |= b.cm_op[k] ? 1u : 0u, b.images_only &= b.op[k].src.kind == kChanRgba ? 1u : 0u;
   // Tap sharing (ChanHalo): v210 sources shown at their own scale, unrotated and unmirrored - columns and rows advance by one texel
   // per output pixel (the kernel still confirms the pattern per wave step).  Each such op needs 36 bytes of LDS per wave step of a
   // workgroup behind the table; ops that do not fit any more go without.
