@@ -141,6 +141,7 @@ struct ChanBatchArgs {
   uint32_t job_rot[kMaxChanJobs][4];  // per job and XCD (two 16-bit values per word): how far the job's share is rotated round the XCD's workgroups
   uint32_t sched_off;              // LDS byte offset of the jobs' tables behind the gamma table
   uint32_t halo_off, halo_steps;   // as ChanArgs; halo_steps = steps
+  uint32_t images_only;            // as ChanArgs: every source of every job is an f32 image - the reader's table is not loaded
 };
 static_assert(sizeof(ChanBatchArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 // refuses (hipErrorInvalidValue) more than kMaxChanJobs jobs / kMaxChanBatchOps ops: callers split

@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_batch_kernel(ChanBatch
   if (PH_CHAN_ARG_PREFETCH && threadIdx.x >= (uint32_t)kLdsBlock - 64u && (threadIdx.x & 63u) * 64u < (uint32_t)sizeof(ChanBatchArgs))
     touched = *(const __attribute__((address_space(1))) uint32_t *)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + (threadIdx.x & 63u) * 64u);
   PH_CPHASE(7);
-  lds_lut_load(a.rd);
+  if (!a.images_only) lds_lut_load(a.rd);  // (uniform)
   if (touched == 0x9E3779B9u && a.jobs == 0xFFFFFFFFu) reinterpret_cast<uint32_t *>(g_lds + a.sched_off)[3] = touched;  // (never: keeps the loads above)
   __syncthreads();
   PH_CPHASE(1);
@@ -1306,7 +1306,8 @@ hipError_t launch_chan_compose_batch(hipStream_t s, const ChanBatchArgs &a, uint
   b.halo_off = b.sched_off + kSchedBytes;
   if (b.halo_off > 160u * 1024u) return hipErrorInvalidValue;
   // tap sharing as in the one-job launcher; each sharing op needs 36 bytes per wave step and job behind the table, ops that do not fit go without
-  b.halo_steps = 0, b.n_share = 0;
+  b.halo_steps = 0, b.n_share = 0, b.images_only = 1;
+  for (uint32_t k = 0; k < b.n_ops; ++k) b.images_only &= b.op[k].src.kind == kChanRgba ? 1u : 0u;
   static const bool no_share = getenv("PH_CHAN_NO_SHARE") != nullptr;
   const uint32_t room = 160u * 1024u - b.halo_off;
   for (uint32_t k = 0; k < b.n_ops; ++k) {
