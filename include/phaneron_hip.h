@@ -37,8 +37,9 @@ extern "C" {
  *    points take widths that are not a multiple of 48 (1280 x 720: the reference's third format, src/config.ts:43-54)
  * 7: additive over 6 - ph_chan_compose_batch (ph_chan_job): several channels' frames in one launch; ph_run_programs; ph_compose_up_write_v210_batch; ph_pack_read_batch;
  *    ph_event_record_timed / ph_event_elapsed_us; ph_ctx_host_pool_stats; "host_pool_mb" defaults to 4096 again and never
- *    keeps less than the working set */
-#define PH_ABI_VERSION 7
+ *    keeps less than the working set
+ * 8: additive over 7 - ph_trace_begin / ph_trace_end (which kernels made a frame; dry runs) */
+#define PH_ABI_VERSION 8
 
 enum {
   PH_OK = 0,
@@ -65,6 +66,16 @@ int ph_ctx_destroy(ph_ctx *ctx);
 int ph_ctx_info(ph_ctx *ctx, char *vendor, size_t vendor_len, char *device, size_t device_len);
 /* message of the last failure on this thread (ctx may be NULL for ph_ctx_create failures). */
 const char *ph_last_error(ph_ctx *ctx);
+
+/* ---- which kernels made it (no nodencl counterpart: the reference runs one kernel per job, clJobQueue.ts:126; this library folds
+ * jobs into fused launches and chooses among several routes by the shape of a frame - DESIGN.md section 5 lists them).
+ * Between ph_trace_begin and ph_trace_end every kernel launch the CALLING THREAD's calls make is noted, in order; ph_trace_end
+ * returns the names joined by '+' - e.g. "fused_v210_combine_lds", "chan_compose_v210<0,0>" (<phase-1 instantiation, output format>),
+ * "chan_compose_batch<0>x4" (four jobs in the launch), "pack_read+compose_up_write_v210", "v210_yadif_pair+compose_up_write_v210".
+ * dry_run != 0: the calls check their arguments and choose their kernels exactly as always but enqueue NOTHING (outputs untouched) -
+ * "which route would this frame take".  PH_E_RANGE when `route` is too short (the trace is dropped), PH_E_INVALID without a begin. */
+int ph_trace_begin(int dry_run);
+int ph_trace_end(char *route, size_t len);
 /* the hipStream_t behind a queue, for interop (tests wrap it as a torch external stream). */
 void *ph_ctx_stream(ph_ctx *ctx, int queue);
 /* `waitFinish(queue)` (clJobQueue.ts:131, io.ts callers): returns when the stream is idle. */

@@ -34,7 +34,7 @@ EXPORTS = [
     "ph_program_resolve", "ph_route_unique_id", "ph_route_init", "ph_route_destroy", "ph_route_group_begin",
     "ph_route_group_end", "ph_route_send", "ph_route_recv", "ph_route_after_queue", "ph_queue_after_route",
     "ph_route_wait", "ph_route_stream", "ph_route_comm_count", "ph_chan_compose_v210", "ph_chan_compose_batch", "ph_run_programs", "ph_event_record_timed", "ph_event_elapsed_us", "ph_ctx_host_pool_stats",
-    "ph_v210_yadif_pair_fmt", "ph_compose_up_write_v210",
+    "ph_v210_yadif_pair_fmt", "ph_compose_up_write_v210", "ph_trace_begin", "ph_trace_end",
 ]
 
 
@@ -211,6 +211,8 @@ def lib():
         "ph_route_wait": (ci, [vp]),
         "ph_route_stream": (vp, [vp]),
         "ph_route_comm_count": (ci, [vp, C.POINTER(C.c_int)]),
+        "ph_trace_begin": (ci, [ci]),
+        "ph_trace_end": (ci, [C.c_char_p, cs]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(l, name)  # AttributeError here = the header and the library disagree
@@ -223,6 +225,30 @@ def check(rc, ctx=None):
     if rc != 0:
         msg = lib().ph_last_error(ctx)
         raise PhaneronError("libphaneron_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+class trace:
+    """`with capi.trace(dry_run=False) as t: <calls>` - t.route is the '+'-joined list of the kernels those calls launched on
+    this thread (ph_trace_begin / ph_trace_end); dry_run: the calls choose their kernels but enqueue nothing."""
+
+    def __init__(self, dry_run=False):
+        self.dry_run, self.route = dry_run, None
+
+    def __enter__(self):
+        check(lib().ph_trace_begin(1 if self.dry_run else 0))
+        return self
+
+    def __exit__(self, *exc):
+        buf = C.create_string_buffer(4096)
+        rc = lib().ph_trace_end(buf, len(buf))
+        if exc[0] is None:
+            check(rc)
+        self.route = buf.value.decode()
+        return False
+
+    @property
+    def kernels(self):
+        return self.route.split("+") if self.route else []
 
 
 # ---- host colour maths (pure host code in the library; no device needed) ---------------------

@@ -44,6 +44,24 @@ int fail(int code, const char *fmt, ...) {
 
 }  // namespace
 
+// ---- route trace: which kernels made it ------------------------------------------------------------------------------------------
+// Which of the library's routes makes a frame is decided here and in the launchers (headline kernel / channel kernel and its
+// instantiations / batch kernel / read + 2 x 2-block compositor / pair launch ...), so a caller - and a test - can ASK: between
+// ph_trace_begin and ph_trace_end every launch of the calling thread is noted by kernel name, and in a dry run that is all that happens.
+namespace {
+thread_local bool g_trace_on = false, g_trace_dry = false;
+thread_local std::string g_trace;
+}  // namespace
+namespace ph {
+bool trace_launch(const char *name) {
+  if (!g_trace_on) return false;
+  if (const char *p = strstr(name, "launch_")) name = p + 7;
+  if (!g_trace.empty()) g_trace += '+';
+  g_trace.append(name, strcspn(name, "("));
+  return g_trace_dry;
+}
+}  // namespace ph
+
 struct LutEntry {
   ph::LutView view{};  // bytes == 0: a plain table
   void *blob_dev = nullptr;
@@ -265,6 +283,20 @@ extern "C" {
 int ph_abi_version(void) { return PH_ABI_VERSION; }
 
 const char *ph_last_error(ph_ctx *) { return g_err.c_str(); }
+
+int ph_trace_begin(int dry_run) {
+  g_trace_on = true, g_trace_dry = dry_run != 0;
+  g_trace.clear();
+  return PH_OK;
+}
+int ph_trace_end(char *route, size_t len) {
+  const bool was_on = g_trace_on;
+  g_trace_on = g_trace_dry = false;
+  if (!was_on) return fail(PH_E_INVALID, "ph_trace_end: no ph_trace_begin on this thread");
+  if (!route || len <= g_trace.size()) return fail(PH_E_RANGE, "ph_trace_end: the route takes %zu bytes", g_trace.size() + 1);
+  memcpy(route, g_trace.c_str(), g_trace.size() + 1);
+  return PH_OK;
+}
 
 int ph_ctx_create(int device_index, ph_ctx **out) {
   if (!out) return fail(PH_E_INVALID, "ph_ctx_create: out is NULL");
@@ -1039,19 +1071,22 @@ int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
   return fail(PH_E_INVALID, "unknown option '%s'", name);
 }
 
-// the compressed form of a device LUT pointer, or NULL (unknown / plain / LDS path switched off)
-// Returned by value into a small per-thread ring (a call site holds at most two at a time): the registry
-// entry itself may be replaced by another thread once the lock is dropped.
-static const ph::LutView *lds_view(ph_ctx *ctx, const void *dev) {
-  if (!ctx->use_lds_lut) return nullptr;
-  thread_local ph::LutView slots[16];  // (a caller that keeps a view across calls into other entry points copies it: ph_chan_compose_batch)
-  thread_local unsigned next = 0;
+// The compressed form of a device LUT pointer (unknown / plain / LDS path switched off: none).  A COPY, by value: the registry entry
+// may be replaced by another thread once the lock is dropped, and a caller may hold its copy across any number of further look-ups
+// (until round 6 this handed out slots of a 16-entry per-thread ring; a later launch once got the writer's table as its reader's).
+struct LutRef {
+  ph::LutView view{};
+  bool found = false;
+  const ph::LutView *get() const { return found ? &view : nullptr; }
+};
+static LutRef lds_view(ph_ctx *ctx, const void *dev) {
+  LutRef r;
+  if (!ctx || !ctx->use_lds_lut) return r;
   std::lock_guard<std::mutex> lock(ctx->mu);
   auto it = ctx->luts.find(dev);
-  if (it == ctx->luts.end() || !it->second.view.bytes) return nullptr;
-  ph::LutView *v = &slots[next++ & 15u];
-  *v = it->second.view;
-  return v;
+  if (it == ctx->luts.end() || !it->second.view.bytes) return r;
+  r.view = it->second.view, r.found = true;
+  return r;
 }
 
 // a ph_buf used as `gammaLut`: (re)compress from its host mirror if new data went in
@@ -1782,7 +1817,7 @@ uint32_t ph_v210_pitch_bytes(uint32_t width) { return width ? ph::v210_pitch_byt
     PH_QUEUE(__func__, queue);                                                                  \
     int rc_ = set_device(ctx);                                                                  \
     if (rc_) return rc_;                                                                        \
-    hipError_t e_ = (expr);                                                                     \
+    hipError_t e_ = ph::trace_launch(#expr) ? hipSuccess : (expr);                              \
     if (e_ != hipSuccess) return fail(PH_E_HIP, "%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
     return PH_OK;                                                                               \
   } while (0)
@@ -1791,10 +1826,12 @@ int ph_v210_read(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t wid
                  const void *lut, const void *gm) {
   if (!in || !out || !cm || !lut || !gm || !width) return fail(PH_E_INVALID, "ph_v210_read: NULL/zero argument");
   if (!height) return PH_OK;
-  if (ctx && width % 2 == 0)  // (a tail of 2 or 4 pixels is the reference's: v210.ts:84-110; other widths: the general kernel)
-    if (const ph::LutView *v = lds_view(ctx, lut))
+  if (ctx && width % 2 == 0) {  // (a tail of 2 or 4 pixels is the reference's: v210.ts:84-110; other widths: the general kernel)
+    const LutRef lref = lds_view(ctx, lut);
+    if (const ph::LutView *v = lref.get())
       PH_LAUNCH(ph::launch_v210_read_lds(stream_of(ctx, queue), in, out, width, height, cm, gm, *v,
                                          (uint32_t)ctx->props.multiProcessorCount));
+  }
   PH_LAUNCH(ph::launch_v210_read(stream_of(ctx, queue), in, out, width, height, cm, lut, gm));
 }
 
@@ -1805,10 +1842,12 @@ int ph_v210_read_batch(ph_ctx *ctx, int queue, int n, const void *const *ins, vo
   for (int i = 0; i < n; ++i)
     if (!ins[i] || !outs[i]) return fail(PH_E_INVALID, "ph_v210_read_batch: frame %d is NULL", i);
   if (!height) return PH_OK;
-  if (ctx && width % 2 == 0)
-    if (const ph::LutView *v = lds_view(ctx, lut))
+  if (ctx && width % 2 == 0) {
+    const LutRef lref = lds_view(ctx, lut);
+    if (const ph::LutView *v = lref.get())
       PH_LAUNCH(ph::launch_v210_read_lds_batch(stream_of(ctx, queue), n, ins, outs, width, height, cm, gm, *v,
                                                (uint32_t)ctx->props.multiProcessorCount));
+  }
   for (int i = 0; i < n; ++i) {  // table not LDS-resident / ragged width: one gather-kernel launch per frame
     const int rc = ph_v210_read(ctx, queue, ins[i], outs[i], width, height, cm, lut, gm);
     if (rc) return rc;
@@ -1821,10 +1860,12 @@ int ph_v210_write(ph_ctx *ctx, int queue, const void *in, void *out, uint32_t wi
   if (!in || !out || !cm || !lut || !width) return fail(PH_E_INVALID, "ph_v210_write: NULL/zero argument");
   if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_v210_write: interlace must be 0, 1 or 3");
   if (!height) return PH_OK;
-  if (ctx && width % 2 == 0)
-    if (const ph::LutView *v = lds_view(ctx, lut))
+  if (ctx && width % 2 == 0) {
+    const LutRef lref = lds_view(ctx, lut);
+    if (const ph::LutView *v = lref.get())
       PH_LAUNCH(ph::launch_v210_write_lds(stream_of(ctx, queue), in, out, width, height, interlace, cm, *v,
                                           (uint32_t)ctx->props.multiProcessorCount));
+  }
   PH_LAUNCH(ph::launch_v210_write(stream_of(ctx, queue), in, out, width, height, interlace, cm, lut));
 }
 
@@ -1854,7 +1895,8 @@ int ph_fused_v210_combine(ph_ctx *ctx, int queue, int n, const void *const *laye
   a.rd_cm = (const float *)rd_cm, a.rd_lut = (const float *)rd_lut, a.rd_gm = (const float *)rd_gm;
   a.wr_cm = (const float *)wr_cm, a.wr_lut = (const float *)wr_lut;
   if (ctx) {
-    const ph::LutView *rv = lds_view(ctx, rd_lut), *wv = lds_view(ctx, wr_lut);
+    const LutRef rref = lds_view(ctx, rd_lut), wref = lds_view(ctx, wr_lut);
+    const ph::LutView *rv = rref.get(), *wv = wref.get();
     if (rv && wv) {
       ph::FusedLdsArgs la{};
       la.f = a, la.rd = *rv, la.wr = *wv, la.jobs = 1;
@@ -1882,7 +1924,8 @@ int ph_fused_v210_combine_batch(ph_ctx *ctx, int queue, int jobs, int n, const v
     for (int l = 0; l < n; ++l)
       if (!layers[j * n + l]) return fail(PH_E_INVALID, "ph_fused_v210_combine_batch: job %d layer %d is NULL", j, l);
   }
-  const ph::LutView *rv = ctx ? lds_view(ctx, rd_lut) : nullptr, *wv = ctx ? lds_view(ctx, wr_lut) : nullptr;
+  const LutRef rref = lds_view(ctx, rd_lut), wref = lds_view(ctx, wr_lut);  // (a NULL context has no tables)
+  const ph::LutView *rv = rref.get(), *wv = wref.get();
   if (jobs == 1 || !rv || !wv || !width || width % 48 || !height) {
     // one job, or no LDS form of the tables: the plain entry point per job (same results)
     for (int j = 0; j < jobs; ++j) {
@@ -1919,7 +1962,7 @@ int ph_pack_read(ph_ctx *ctx, int queue, int format, const void *const planes[3]
     if (!planes[i]) return fail(PH_E_INVALID, "ph_pack_read: plane %d is NULL", i);
   if (format < PH_FMT_RGBA8 && !cm) return fail(PH_E_INVALID, "ph_pack_read: YCbCr formats need a colMatrix");
   if (!height) return PH_OK;
-  PH_LAUNCH(ph::launch_pack_read(stream_of(ctx, queue), format, planes, out, width, height, cm, lut, gm, lds_view(ctx, lut),
+  PH_LAUNCH(ph::launch_pack_read(stream_of(ctx, queue), format, planes, out, width, height, cm, lut, gm, lds_view(ctx, lut).get(),
                                  (uint32_t)ctx->props.multiProcessorCount));
 }
 
@@ -1927,7 +1970,8 @@ int ph_pack_read_batch(ph_ctx *ctx, int queue, int format, int n, const void *co
                        const void *cm, const void *lut, const void *gm) {
   if (!ctx || !planes || !outs || !lut || !gm || !width) return fail(PH_E_INVALID, "ph_pack_read_batch: NULL/zero argument");
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_pack_read_batch: 1..%d frames", ph::kMaxLayers);
-  const ph::LutView *v = format == PH_FMT_V210 ? nullptr : lds_view(ctx, lut);
+  const LutRef lref = lds_view(ctx, lut);
+  const ph::LutView *v = format == PH_FMT_V210 ? nullptr : lref.get();
   if (n == 1 || !v) {  // one frame, v210 (its own batch call), or no LDS form of the table: frame by frame
     if (format == PH_FMT_V210) {
       const void *ins[ph::kMaxLayers];
@@ -1966,7 +2010,7 @@ int ph_pack_write(ph_ctx *ctx, int queue, int format, const void *in, void *cons
   if (format < PH_FMT_RGBA8 && !cm) return fail(PH_E_INVALID, "ph_pack_write: YCbCr formats need a colMatrix");
   if (!height) return PH_OK;
   PH_LAUNCH(ph::launch_pack_write(stream_of(ctx, queue), format, in, planes, width, height, interlace, cm, lut,
-                                  lds_view(ctx, lut), (uint32_t)ctx->props.multiProcessorCount));
+                                  lds_view(ctx, lut).get(), (uint32_t)ctx->props.multiProcessorCount));
 }
 
 static int compose_write(ph_ctx *ctx, int queue, int n, const ph_layer *layers, const ph_layer_wipe *wipes, void *out, uint32_t out_w,
@@ -1991,7 +2035,8 @@ static int compose_write(ph_ctx *ctx, int queue, int n, const ph_layer *layers, 
   // and cleared slots, v210.ts:131-136,166-193; the reference's writer serves tails of 2 or 4 pixels)
   if (!out_w || (out_w & 1)) return fail(PH_E_INVALID, "ph_compose_write_v210: width %u is zero or odd; run the separate kernels", out_w);
   if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_compose_write_v210: interlace must be 0, 1 or 3");
-  const ph::LutView *wv = lds_view(ctx, wr_lut);
+  const LutRef wref = lds_view(ctx, wr_lut);
+  const ph::LutView *wv = wref.get();
   if (!wv) return fail(PH_E_INVALID, "ph_compose_write_v210: the writer gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)");
   ph::ComposeArgs a{};
   a.n = n;
@@ -2275,7 +2320,8 @@ int ph_chan_compose(ph_ctx *ctx, int queue, int n, const ph_chan_layer *layers, 
   if (!out_w || (out_format == PH_FMT_V210 && (out_w & 1)) || (out_planar && out_w % 8))
     return fail(PH_E_INVALID, "ph_chan_compose_v210: width %u (a v210 frame needs an even width, a planar one a multiple of 8); run the separate kernels", out_w);
   if (interlace != 0 && interlace != 1 && interlace != 3) return fail(PH_E_INVALID, "ph_chan_compose_v210: interlace must be 0, 1 or 3");
-  const ph::LutView *rv = lds_view(ctx, rd_lut), *wv = lds_view(ctx, wr_lut);
+  const LutRef rref = lds_view(ctx, rd_lut), wref = lds_view(ctx, wr_lut);
+  const ph::LutView *rv = rref.get(), *wv = wref.get();
   if (!rv || !wv)
     return fail(PH_E_INVALID, "ph_chan_compose_v210: the %s gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)", rv ? "writer" : "reader");
   ph::ChanArgs a{};
@@ -2322,7 +2368,8 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
   PH_QUEUE("ph_chan_compose_batch", queue);
   if (n_jobs < 1) return fail(PH_E_INVALID, "ph_chan_compose_batch: no jobs");
   if (!out_w || (out_w & 1)) return fail(PH_E_INVALID, "ph_chan_compose_batch: width %u (a v210 frame needs an even width)", out_w);
-  const ph::LutView *rv = lds_view(ctx, rd_lut), *wv = lds_view(ctx, wr_lut);
+  const LutRef rref = lds_view(ctx, rd_lut), wref = lds_view(ctx, wr_lut);
+  const ph::LutView *rv = rref.get(), *wv = wref.get();
   if (!rv || !wv)
     return fail(PH_E_INVALID, "ph_chan_compose_batch: the %s gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)", rv ? "writer" : "reader");
   for (int j = 0; j < n_jobs; ++j) {
@@ -2330,9 +2377,7 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
     if (!J.layers || !J.out || J.n < 1 || J.n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_chan_compose_batch: job %d: 1..%d layers and an output", j, ph::kMaxLayers);
     if (J.interlace != 0 && J.interlace != 1 && J.interlace != 3) return fail(PH_E_INVALID, "ph_chan_compose_batch: job %d: interlace must be 0, 1 or 3", j);
   }
-  // (lds_view hands out slots of a small per-thread ring: the calls made from here for single jobs and for the read + compositor route take
-  // slots too - an odd number of them, and `rv` would name the WRITER's table by the time a later launch's arguments are made.  Copies.)
-  const ph::LutView rview = *rv, wview = *wv;
+  const ph::LutView &rview = rref.view, &wview = wref.view;
   int rc = set_device(ctx);
   if (rc) return rc;
   // the common part of a launch's arguments (ChanArgs carries it to chan_batch_launch)
@@ -2477,7 +2522,8 @@ static int compose_up_common(const char *fn, ph_ctx *ctx, int queue, int jobs, i
   for (int j = 1; j < jobs; ++j)
     for (int k = 0; k < j; ++k)
       if (outs[j] == outs[k]) return fail(PH_E_INVALID, jobs == 2 ? "%s: the two outputs are the same buffer" : "%s: two jobs have the same output buffer", fn);
-  const ph::LutView *wv = lds_view(ctx, wr_lut);
+  const LutRef wref = lds_view(ctx, wr_lut);
+  const ph::LutView *wv = wref.get();
   if (!wv) return fail(PH_E_INVALID, "%s: the writer gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)", fn);
   ph::UpArgs a{};
   a.n = n;
@@ -2548,7 +2594,8 @@ int ph_yadif_pair_packed(ph_ctx *ctx, int queue, int n, const ph_deint_source *s
   if (n < 1 || n > ph::kMaxLayers) return fail(PH_E_INVALID, "ph_v210_yadif_pair: 1..%d sources", ph::kMaxLayers);
   if (!width || (planar ? width % 2 : width % 6))
     return fail(PH_E_INVALID, "ph_v210_yadif_pair: width %u is not a multiple of %d; run the separate kernels", width, planar ? 2 : 6);
-  const ph::LutView *v = lds_view(ctx, lut);
+  const LutRef lref = lds_view(ctx, lut);
+  const ph::LutView *v = lref.get();
   if (!v) return fail(PH_E_INVALID, "ph_v210_yadif_pair: the reader gamma LUT has no LDS form (ph_lut_register it, or run the separate kernels)");
   ph::DeintArgs a{};
   for (int i = 0; i < n; ++i) {

@@ -145,6 +145,9 @@ struct ChanBatchArgs {
 };
 static_assert(sizeof(ChanBatchArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 // refuses (hipErrorInvalidValue) more than kMaxChanJobs jobs / kMaxChanBatchOps ops: callers split
+// Route trace (ph_trace_begin / ph_trace_end, ph_api.cpp): while the calling thread traces, every launch is noted by name; returns
+// true when the launch must NOT be made (a dry run).  `name` may be a launcher call's text ("ph::launch_xxx(...": noted as "xxx").
+bool trace_launch(const char *name);
 hipError_t launch_chan_compose_batch(hipStream_t s, const ChanBatchArgs &a, uint32_t num_cus);
 
 // ph_kernels_up.hip: the 2 x 2-block compositor for magnifying placements

@@ -1324,6 +1324,9 @@ hipError_t launch_chan_compose_batch(hipStream_t s, const ChanBatchArgs &a, uint
   if (b.n_share) b.halo_steps = steps;
   const uint32_t lds_total = b.halo_off + b.n_share * steps * 36u;
   auto go = [&](auto kernel) -> hipError_t {
+    char name[48];
+    snprintf(name, sizeof name, "chan_compose_batch<%u>x%u", a.tails ? 1u : 0u, a.jobs);  // (route trace: the instantiation and the jobs sharing it)
+    if (trace_launch(name)) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     if (e != hipSuccess) return e;
     kernel<<<grid, kLdsBlock, lds_total, s>>>(b);
@@ -1403,31 +1406,37 @@ hipError_t launch_chan_compose_v210(hipStream_t s, const ChanArgs &a, uint32_t n
     }
     if (n_share) b.halo_steps = steps, lds_total = b.halo_off + n_share * steps * 36u;
   }
-  auto go = [&](auto kernel) -> hipError_t {
+  // (route trace: the instantiation is part of the route - <phase-1 mode, output format>)
+  auto go = [&](auto kernel, int mode, int out_fmt) -> hipError_t {
+    char name[48];
+    snprintf(name, sizeof name, "chan_compose_v210<%d,%d>", mode, out_fmt);
+    if (trace_launch(name)) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     if (e != hipSuccess) return e;
     kernel<<<grid, kLdsBlock, lds_total, s>>>(b);
     return hipGetLastError();
   };
+#define PH_CHAN_GO(M, O) go(chan_compose_v210_kernel<M, O>, M, O)
   // The writer's phase is independent of the readers': the lean instantiations of phase 1 (v210 / image programs on whole 48-pixel blocks;
   // planar clips; planar clips with shared taps) exist for the frames of the reference's three consumers - v210 (macadamConsumer.ts:165),
   // yuv422p8 (ffmpegConsumer.ts:144), rgba8 (screenConsumer.ts:131); the other formats and v210 lines with tails take the "everything" one
   auto lean = [&](auto out_tag) -> hipError_t {
     constexpr int O = decltype(out_tag)::value;
     if (a.planar == 2)
-      return planar_share ? go(chan_compose_v210_kernel<4, O>) : clips_only ? go(chan_compose_v210_kernel<3, O>) : graphics ? go(chan_compose_v210_kernel<5, O>) : go(chan_compose_v210_kernel<2, O>);
-    if (a.planar == 1) return O == 0 ? go(chan_compose_v210_kernel<1, 0>) : go(chan_compose_v210_kernel<2, O>);
-    return go(chan_compose_v210_kernel<0, O>);
+      return planar_share ? PH_CHAN_GO(4, O) : clips_only ? PH_CHAN_GO(3, O) : graphics ? PH_CHAN_GO(5, O) : PH_CHAN_GO(2, O);
+    if (a.planar == 1) return O == 0 ? PH_CHAN_GO(1, 0) : PH_CHAN_GO(2, O);
+    return PH_CHAN_GO(0, O);
   };
   switch (a.out_fmt) {
     case 0: return lean(std::integral_constant<int, 0>{});
-    case 1: return go(chan_compose_v210_kernel<2, 1>);
+    case 1: return PH_CHAN_GO(2, 1);
     case 2: return lean(std::integral_constant<int, 2>{});
-    case 3: return go(chan_compose_v210_kernel<2, 3>);
-    case 4: return go(chan_compose_v210_kernel<2, 4>);
+    case 3: return PH_CHAN_GO(2, 3);
+    case 4: return PH_CHAN_GO(2, 4);
     case 5: return lean(std::integral_constant<int, 5>{});
-    case 6: return go(chan_compose_v210_kernel<2, 6>);
+    case 6: return PH_CHAN_GO(2, 6);
   }
+#undef PH_CHAN_GO
   return hipErrorInvalidValue;
 }
 

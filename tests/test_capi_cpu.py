@@ -38,7 +38,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 
 def test_abi_version():
-    assert capi.lib().ph_abi_version() == 7
+    assert capi.lib().ph_abi_version() == 8
 
 
 @pytest.mark.parametrize("spec", ["601-625", "601_525", "709", "2020", "sRGB", "bogus"])
