@@ -38,7 +38,7 @@ extern "C" {
  * 7: additive over 6 - ph_chan_compose_batch (ph_chan_job): several channels' frames in one launch; ph_run_programs; ph_compose_up_write_v210_batch; ph_pack_read_batch;
  *    ph_event_record_timed / ph_event_elapsed_us; ph_ctx_host_pool_stats; "host_pool_mb" defaults to 4096 again and never
  *    keeps less than the working set
- * 8: additive over 7 - ph_trace_begin / ph_trace_end (which kernels made a frame; dry runs) */
+ * 8: additive over 7 - ph_trace_begin / ph_trace_end (which kernels made a frame; dry runs); ph_run_programs_progress; ph_buf_reuse */
 #define PH_ABI_VERSION 8
 
 enum {
@@ -107,6 +107,11 @@ int ph_buf_dims(const ph_buf *buf, int *width, int *height);
  *   READONLY        : make the device contents visible in the host mirror (sync on return) */
 enum { PH_HOST_READONLY = 0, PH_HOST_WRITEONLY = 1, PH_HOST_NONE = 2 };
 int ph_buf_host_access(ph_buf *buf, int dir, int queue, const void *src, size_t bytes);
+/* For a binding that keeps released buffers itself and hands them to their next owner whole (node/index.js parks frames and images:
+ * handle, device block, pinned mirror): what ph_buf_release + ph_buf_create would have seen to - waits for an asynchronous mirror copy
+ * still in flight, orders the queues behind ROUTE transfers still using the device block, forgets the previous owner's pending host
+ * data.  The contents are unspecified afterwards, as a fresh buffer's are. */
+int ph_buf_reuse(ph_buf *b);
 void *ph_buf_host_ptr(ph_buf *buf); /* pinned host mirror (allocated on first use) */
 /* Staged producers / consumers (the queue.load / queue.unload roles of io.ts:79-98,
  * 166-174).  nodencl orders its three queues through host-side `waitFinish`; these two calls let a
@@ -249,6 +254,10 @@ int ph_check_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_ar
  * fused_v210_combine_<n> programs of one geometry, layer count and recipe (ph_fused_v210_combine_batch, up to eight per launch; a frame
  * that touches an earlier one's output starts the next launch). */
 int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_arg *const *args, const int *n_args, int queue);
+/* How far the calling thread's LAST ph_run_programs call got: the launches of jobs 0 .. *jobs_done - 1 were made (n_jobs after a call
+ * that returned PH_OK, 0 after one refused by its checks).  A call that fails at a launch has enqueued the jobs before the failing
+ * group; a binding that falls back to ph_run_program for the rest starts at *jobs_done instead of rendering those frames twice. */
+int ph_run_programs_progress(int *jobs_done);
 
 /* ---- typed entry points: the same kernels on raw device pointers, launched on `queue`.
  *      Images are row-major float RGBA (16 B/pixel); v210 is LE 32-bit words with line pitch
@@ -546,8 +555,9 @@ int ph_lut_layout_of(const float *host_lut65536, ph_lut_layout *layout, void *ld
  *          buffer of the same size (the reference creates its destinations per job and frame: io.ts:64-72) - this much,
  *          or as much as was ever attached to live buffers at once if that is more (a pool smaller than the working set
  *          pins a block per buffer again, ~40 ms each); over the budget the oldest blocks are freed first; 0: no pool;
- *          "fail_launches" (default 0): while non-zero every launch made through ph_run_program / ph_run_programs fails with
- *          PH_E_HIP - a fault injection for the error paths of a binding (node/test/soak_run.js); checks still pass;
+ *          "fail_launches" (default 0) - TEST ONLY, a fault injection for the error paths of a binding (node/test/soak_run.js): > 0:
+ *          every launch made through ph_run_program / ph_run_programs fails with PH_E_HIP; -k: the next k launches (groups of
+ *          ph_run_programs) go through, then every one fails; checks still pass.  Nothing in a deployment sets it;
  *          "chan_enlarged" (default 1; 0 when PH_CHAN_ENLARGED=0 is in the environment): ph_chan_compose* make a frame all of whose
  *          layers are ENLARGED v210 clips (a 720p or SD clip filling a 1080 channel: the reference uploads clips at their own size,
  *          ffmpegProducer.ts:395-442) by ph_v210_read into scratch images + ph_compose_up_write_v210 - one conversion per source pixel

@@ -300,7 +300,7 @@ class Deferral {
 				const live = g.filter((p) => this._fresh(p))
 				for (const p of g) if (!live.includes(p) && p.node.state === 'pending' && p.node === must) { if (!this._fused(p.node)) this._plain(p.node) } // (planning another frame ran part of this one's chain: look again)
 				if (live.length > 1 && this._batch(live)) continue
-				for (const p of live) if (!this._commit(p) && p.node === must) this._plain(p.node)
+				for (const p of live) if (this._fresh(p) && !this._commit(p) && p.node === must) this._plain(p.node)  // (fresh: a batch that failed half way has made some)
 			}
 			if (must && must.state === 'pending' && !failure) { if (!this._fused(must)) this._plain(must) }
 		} finally { this.running = false }
@@ -342,6 +342,15 @@ class Deferral {
 		} catch (e) {
 			this.stats.fallbacks++
 			this.stats.lastFallback = `batch of ${plans.length}: ${e && e.message || e}`
+			// a call refused at a launch has made the launches of the jobs before the failing group (ph_run_programs_progress): those
+			// frames are done - the caller commits the rest one by one, not these a second time
+			const made = this.ctx._native.runProgramsProgress ? this.ctx._native.runProgramsProgress() : 0
+			if (made > 0) {
+				this.stats.launched++
+				this.stats.batched = (this.stats.batched || 0) + made
+				this.launchedOn.set(queue, (this.launchedOn.get(queue) || 0) + 1)
+				for (const p of plans.slice(0, made)) this._done(p, null)
+			}
 			return false
 		}
 		this.stats.launched++

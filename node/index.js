@@ -36,6 +36,7 @@ function hostAccess(dir, queue, src) {
 			this._deferral.touch(this, dir, queue || 0)
 		} catch (e) { return Promise.reject(e) }
 	}
+	this._unsettled = true // (its mirror has been in use: a parked buffer's next owner asks the library to settle it, see createBuffer)
 	return this._native.hostAccess(this._handle, HOSTDIR[dir], queue || 0, src)
 }
 // Reference counting is done HERE: a buffer holds one native reference from createBuffer to the moment its last owner AND the last
@@ -92,6 +93,7 @@ function free() {
 function downloadAsync(queue) {
 	if (this._dead) throw new Error('downloadAsync on a released buffer')
 	if (this._deferral) this._deferral.touch(this, 'readonly', queue === undefined ? 2 : queue)
+	this._unsettled = true
 	return this._native.downloadAsync(this._handle, queue === undefined ? 2 : queue)
 }
 // What every buffer of a context shares lives on ONE prototype object per context (between the buffer and Buffer.prototype): the
@@ -191,6 +193,12 @@ class clContext {
 				const buf = list.pop()
 				park.parked -= numBytes
 				park.count--
+				// Taken over whole, without a call into the library - unless its mirror or a ROUTE transfer may still be busy with it: a
+				// download in flight when it was released (release after downloadAsync, before its waitFinish) would land in the next
+				// owner's fill, RCCL may still be reading the device block on the communication stream, and a mirror the previous owner
+				// filled but never handed back would be uploaded over the next owner's frame.  ph_buf_reuse settles all three (ADVICE r5).
+				if (buf._unsettled) { native.bufReuse(buf._handle); buf._unsettled = false }
+				buf._gen = (buf._gen || 0) + 1
 				buf._refs = 1
 				buf._dead = false
 				buf.owner = owner || ''
@@ -324,10 +332,12 @@ class clContext {
 			// communication stream is ordered behind the process queue once more before the transfer is enqueued)
 			send: (buf, peer) => {
 				if (this._deferral) { this._deferral.touch(buf, 'readonly', this.queue.process); native.routeOp(h, 2, this.queue.process) }
+				buf._unsettled = true
 				return native.routeOp(h, 5, buf._handle, peer)
 			},
 			recv: (buf, peer) => {
 				if (this._deferral) { this._deferral.touch(buf, 'writeonly', this.queue.process); native.routeOp(h, 2, this.queue.process) } // (readers of the old contents were launched just now)
+				buf._unsettled = true
 				return native.routeOp(h, 6, buf._handle, peer)
 			}
 		}

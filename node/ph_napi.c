@@ -158,6 +158,20 @@ static napi_value BufAddRef(napi_env env, napi_callback_info info) {
   return out;
 }
 
+/* bufReuse(handle): a parked buffer gets its next owner (ph_buf_reuse) */
+static napi_value BufReuse(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  buf_box *b;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || !get_box(env, argv[0], (void **)&b) || !b->buf) {
+    napi_throw_error(env, NULL, "reuse of a released buffer");
+    return NULL;
+  }
+  if (ph_buf_reuse(b->buf) != PH_OK) return throw_ph(env, "bufReuse");
+  return NULL;
+}
+
 static napi_value BufRelease(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1], out;
@@ -572,6 +586,37 @@ static napi_value RunPrograms(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* runProgramsProgress(): how many jobs of this thread's last runPrograms call had their launches made (ph_run_programs_progress) -
+ * after a call that threw at a launch, the jobs before the failing group are on the device already. */
+static napi_value RunProgramsProgress(napi_env env, napi_callback_info info) {
+  napi_value v;
+  int done = 0;
+  (void)info;
+  if (ph_run_programs_progress(&done) != PH_OK) return throw_ph(env, "runProgramsProgress");
+  NAPI_OK(napi_create_int32(env, done, &v));
+  return v;
+}
+
+/* traceBegin(dryRun) / traceEnd() -> string: which kernels the calls in between launched, joined by '+' (ph_trace_begin / ph_trace_end);
+ * dryRun: the calls choose their kernels but enqueue nothing. */
+static napi_value TraceBegin(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  bool dry = false;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc > 0) napi_get_value_bool(env, argv[0], &dry);
+  if (ph_trace_begin(dry ? 1 : 0) != PH_OK) return throw_ph(env, "traceBegin");
+  return NULL;
+}
+static napi_value TraceEnd(napi_env env, napi_callback_info info) {
+  static char route[8192];
+  napi_value v;
+  (void)info;
+  if (ph_trace_end(route, sizeof route) != PH_OK) return throw_ph(env, "traceEnd");
+  NAPI_OK(napi_create_string_utf8(env, route, NAPI_AUTO_LENGTH, &v));
+  return v;
+}
+
 static napi_value RunProgram(napi_env env, napi_callback_info info) {
   size_t argc = 7;
   napi_value argv[7];
@@ -845,6 +890,7 @@ NAPI_MODULE_INIT() {
       {"resolveProgram", ResolveProgram}, {"gammaLut", GammaLut},   {"colourMatrix", ColourMatrix},
       {"transformMatrix", TransformMatrix}, {"planeBytes", PlaneBytes},
       {"routeUniqueId", RouteUniqueId}, {"routeInit", RouteInit},   {"routeOp", RouteOp},
+      {"runProgramsProgress", RunProgramsProgress}, {"traceBegin", TraceBegin}, {"traceEnd", TraceEnd}, {"bufReuse", BufReuse},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
     napi_value f;

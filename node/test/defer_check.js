@@ -420,6 +420,25 @@ for (const moved of [false, true]) {
 		r3.native.refuse = (name) => name === 'batch'
 		r3.d.touch(outs3[0], 'readonly', 2)
 		expect('a refused batch: the frames one launch each', [r3.names(), r3.d.stats.fallbacks], [['chan_compose_v210_1', 'chan_compose_v210_1'], 1])
+		// a batch that fails HALF WAY (a later group refused at its launch, ph_run_programs_progress = 2): the two frames already on the device
+		// are done, only the third is launched on its own - nothing twice
+		const r4 = rig({ early: true, batch: true })
+		const L4 = r4.loader()
+		const m4 = r4.buffer(48, undefined, 'm')
+		const outs4 = [0, 1, 2].map((c) => {
+			const im = r4.image(`u${c}`)
+			r4.d.record(r4.P.read, Object.assign({ input: r4.v210(`s${c}`), output: im, width: r4.W }, L4), 1)
+			const t = r4.image(`t${c}`)
+			r4.d.record(r4.P.transform, { input: im, transformMatrix: m4, output: t }, 1)
+			const out = r4.v210(`out${c}`)
+			r4.d.record(r4.P.write, Object.assign({ input: t, output: out, width: r4.W, interlace: 0 }, r4.saver), 1)
+			return out
+		})
+		r4.native.refuse = (name) => name === 'batch'
+		r4.native.runProgramsProgress = () => 2
+		r4.d.touch(outs4[0], 'readonly', 2)
+		expect('a batch refused after two of its three frames: one more launch, for the third', [r4.names(), r4.d.stats.fallbacks, r4.d.stats.batched, (outs4.forEach((o) => r4.d.touch(o, 'readonly', 2)), r4.names().length)],
+			[['chan_compose_v210_1'], 1, 2, 1])
 		setImmediate(() => process.stdout.write(JSON.stringify({ checks, problems }) + '\n'))
 	})
 }

@@ -101,7 +101,7 @@ struct ph_ctx {
   // 33 MB per tick: round 5 measured 40 ms per tick under the fixed 1 GiB of round 4)
   // option "chan_enlarged" (default 1; PH_CHAN_ENLARGED=0 in the environment makes it 0): frames of enlarged clips by read + 2 x 2-block compositor
   int chan_enlarged = !(getenv("PH_CHAN_ENLARGED") && getenv("PH_CHAN_ENLARGED")[0] == '0');
-  std::atomic<int> fail_launches{0};  // option "fail_launches": while non-zero every launch through ph_run_program(s) fails (tests of a binding's error paths)
+  std::atomic<int> fail_launches{0};  // option "fail_launches" (a TEST hook): > 0 every launch through ph_run_program(s) fails; -k: the next k go through, then every one fails
   int host_pool_mb = 4096;
   size_t host_live_bytes = 0, host_peak_bytes = 0;  // mirrors attached to buffers now / at most
   uint64_t host_pins = 0;                           // hipHostMalloc calls so far (ph_ctx_host_pool_stats)
@@ -495,6 +495,22 @@ void *ph_buf_host_ptr(ph_buf *b) {
     }
   }
   return b->hptr;
+}
+
+/* A binding that keeps released buffers of its own (node/index.js parks frames and images whole: handle, device block, pinned mirror)
+ * calls this when one of them gets its next owner: what ph_buf_release + ph_buf_create would have seen to - an asynchronous copy into
+ * or out of the mirror still in flight (release after downloadAsync, before its waitFinish), a ROUTE transfer still reading or writing
+ * the device block on the communication stream, and the previous owner's pending host data (a mirror filled but never handed back). */
+int ph_buf_reuse(ph_buf *b) {
+  if (!b || b->refs.load() <= 0) return fail(PH_E_INVALID, "ph_buf_reuse: NULL or released buffer");
+  if (b->mirror_busy && hipEventSynchronize(b->mirror_busy) != hipSuccess) (void)hipGetLastError();
+  {
+    std::lock_guard<std::mutex> lock(b->ctx->mu);
+    order_queues_after_routes(b->ctx);
+  }
+  b->host_dirty = false;
+  b->lut_dirty = false;
+  return PH_OK;
 }
 
 int ph_buf_host_access(ph_buf *b, int dir, int queue, const void *src, size_t bytes) {
@@ -1320,13 +1336,24 @@ static int fused_call_parse(ph_ctx *ctx, ph_program *prog, const ph_arg *args, i
 #undef TRY
 }
 
-static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue, bool check_only = false) {
+// the "fail_launches" fault injection (tests of a binding's error paths: node/test/soak_run.js, tests/test_boundary_gpu.py): does this launch fail?
+static bool inject_failure(ph_ctx *ctx) {
+  const int v = ctx->fail_launches.load();
+  if (v > 0) return true;
+  if (v < 0 && ctx->fail_launches.fetch_add(1) == -1) ctx->fail_launches.store(1);  // the last one that goes through
+  return false;
+}
+
+// ph_run_program's argument marshalling, one function per kernel family: each checks the job's named arguments against the frame geometry
+// (everything ph_check_program reports) and, unless check_only, makes the typed call.
+#define TRY(x) \
+  if ((rc = (x)) != PH_OK) return rc
+// the wire formats: v210 / pack readers and writers (v210.ts, yuv422p10.ts ... bgra8.ts; Reader / Writer geometry packer.ts:30-83)
+static int dispatch_wire(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue, bool check_only) {
   ph_buf *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr, *o = nullptr;
   double num = 0;
   int rc, w, h;
-  if (!check_only && ctx->fail_launches.load()) return fail(PH_E_HIP, "%s: launch failed: injected (context option fail_launches)", prog->kernel.c_str());
-#define TRY(x) \
-  if ((rc = (x)) != PH_OK) return rc
+  (void)a, (void)b, (void)c, (void)d, (void)o, (void)num, (void)w, (void)h;
   switch (prog->id) {
     case K_PACK_READ:
     case K_PACK_WRITE: {
@@ -1391,6 +1418,39 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       if (!check_only) refresh_buf_lut(ctx, c);
       return check_only ? PH_OK : ph_v210_write(ctx, queue, a->dptr, o->dptr, width, height, interlace, b->dptr, c->dptr);
     }
+    case K_V210_READ_BATCH: {  // l<i>In: v210 frames; l<i>Out: RGBA images; colMatrix / gammaLut / gamutMatrix: the Loader's
+      const uint32_t width = prog->global[0], height = prog->global[1];
+      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
+      const size_t vb = (size_t)ph_v210_pitch_bytes(width) * height, img = (size_t)width * height * 16;
+      const void *ins[ph::kMaxLayers];
+      void *outs[ph::kMaxLayers];
+      for (int i = 0; i < prog->n_layers; ++i) {
+        char nm[16];
+        ph_buf *x = nullptr;
+        snprintf(nm, sizeof nm, "l%dIn", i);
+        TRY(need_buf(args, n, nm, vb, &x));
+        ins[i] = x->dptr;
+        snprintf(nm, sizeof nm, "l%dOut", i);
+        TRY(need_buf(args, n, nm, img, &x));
+        outs[i] = x->dptr;
+      }
+      TRY(need_buf(args, n, "colMatrix", 48, &b));
+      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
+      TRY(need_buf(args, n, "gamutMatrix", 36, &d));
+      if (!check_only) refresh_buf_lut(ctx, c);
+      return check_only ? PH_OK : ph_v210_read_batch(ctx, queue, prog->n_layers, ins, outs, width, height, b->dptr, c->dptr, d->dptr);
+    }
+    default: break;
+  }
+  return fail(PH_E_UNKNOWN_KERNEL, "unhandled kernel id");
+}
+// de-interlacing: yadif, both parities in one launch, and the reader fused with it (yadifCl.ts, yadif.ts:88-145)
+static int dispatch_deint(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue, bool check_only) {
+  ph_buf *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr, *o = nullptr;
+  double num = 0;
+  int rc, w, h;
+  (void)a, (void)b, (void)c, (void)d, (void)o, (void)num, (void)w, (void)h;
+  switch (prog->id) {
     case K_YADIF: {
       double parity, tff, skip;
       TRY(need_buf(args, n, "output", 0, &o));
@@ -1473,6 +1533,17 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       return check_only ? PH_OK : ph_yadif_pair_packed(ctx, queue, prog->n_layers, src, pfmt, width, height, (int)tff, (int)skip, rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32,
                                     b->dptr, c->dptr, d->dptr);
     }
+    default: break;
+  }
+  return fail(PH_E_UNKNOWN_KERNEL, "unhandled kernel id");
+}
+// the compositors: a channel's frame, enlarged layers, the buffer-addressed compositor, the headline kernel, combine_N (combine.ts, mixer.ts:189-228)
+static int dispatch_compose(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue, bool check_only) {
+  ph_buf *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr, *o = nullptr;
+  double num = 0;
+  int rc, w, h;
+  (void)a, (void)b, (void)c, (void)d, (void)o, (void)num, (void)w, (void)h;
+  switch (prog->id) {
     case K_CHAN_COMPOSE: {
       ChanCall call;
       TRY(chan_call_parse(ctx, prog, args, n, check_only, &call));
@@ -1582,28 +1653,35 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
                                           wcm->dptr, wl->dptr);
       return check_only ? PH_OK : ph_compose_write_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
     }
-    case K_V210_READ_BATCH: {  // l<i>In: v210 frames; l<i>Out: RGBA images; colMatrix / gammaLut / gamutMatrix: the Loader's
-      const uint32_t width = prog->global[0], height = prog->global[1];
-      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
-      const size_t vb = (size_t)ph_v210_pitch_bytes(width) * height, img = (size_t)width * height * 16;
-      const void *ins[ph::kMaxLayers];
-      void *outs[ph::kMaxLayers];
+    case K_COMBINE: {
+      const void *layers[ph::kMaxLayers];
+      TRY(need_buf(args, n, "output", 0, &o));
+      TRY(need_image(o, "output", &w, &h));
       for (int i = 0; i < prog->n_layers; ++i) {
         char nm[16];
-        ph_buf *x = nullptr;
         snprintf(nm, sizeof nm, "l%dIn", i);
-        TRY(need_buf(args, n, nm, vb, &x));
-        ins[i] = x->dptr;
-        snprintf(nm, sizeof nm, "l%dOut", i);
-        TRY(need_buf(args, n, nm, img, &x));
-        outs[i] = x->dptr;
+        TRY(need_buf(args, n, nm, (size_t)w * h * 16, &a));
+        layers[i] = a->dptr;
       }
-      TRY(need_buf(args, n, "colMatrix", 48, &b));
-      TRY(need_buf(args, n, "gammaLut", 65536 * 4, &c));
-      TRY(need_buf(args, n, "gamutMatrix", 36, &d));
-      if (!check_only) refresh_buf_lut(ctx, c);
-      return check_only ? PH_OK : ph_v210_read_batch(ctx, queue, prog->n_layers, ins, outs, width, height, b->dptr, c->dptr, d->dptr);
+      return check_only ? PH_OK : ph_combine(ctx, queue, prog->n_layers, layers, w, h, o->dptr);
     }
+    case K_FUSED_V210: {
+      FusedCall f;
+      TRY(fused_call_parse(ctx, prog, args, n, check_only, &f));
+      return check_only ? PH_OK : ph_fused_v210_combine(ctx, queue, f.n, f.layers, f.out, f.width, f.height, f.rd_cm->dptr, f.rd_lut->dptr, f.rd_gm->dptr,
+                                   f.wr_cm->dptr, f.wr_lut->dptr);
+    }
+    default: break;
+  }
+  return fail(PH_E_UNKNOWN_KERNEL, "unhandled kernel id");
+}
+// the f32 image operators: transform, resize, dissolve / mixer / wipe, transition_wipe (transform.ts, resize.ts, transition.ts, mix.ts, wipe.ts)
+static int dispatch_image(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue, bool check_only) {
+  ph_buf *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr, *o = nullptr;
+  double num = 0;
+  int rc, w, h;
+  (void)a, (void)b, (void)c, (void)d, (void)o, (void)num, (void)w, (void)h;
+  switch (prog->id) {
     case K_TRANSFORM: {
       int iw, ih;
       TRY(need_buf(args, n, "input", 0, &a));
@@ -1626,24 +1704,6 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_num(args, n, "offsetY", &oy));
       return check_only ? PH_OK : ph_resize(ctx, queue, a->dptr, iw, ih, (float)scale, (float)ox, (float)oy, b->dptr, o->dptr, w, h);
     }
-    case K_COMBINE: {
-      const void *layers[ph::kMaxLayers];
-      TRY(need_buf(args, n, "output", 0, &o));
-      TRY(need_image(o, "output", &w, &h));
-      for (int i = 0; i < prog->n_layers; ++i) {
-        char nm[16];
-        snprintf(nm, sizeof nm, "l%dIn", i);
-        TRY(need_buf(args, n, nm, (size_t)w * h * 16, &a));
-        layers[i] = a->dptr;
-      }
-      return check_only ? PH_OK : ph_combine(ctx, queue, prog->n_layers, layers, w, h, o->dptr);
-    }
-    case K_FUSED_V210: {
-      FusedCall f;
-      TRY(fused_call_parse(ctx, prog, args, n, check_only, &f));
-      return check_only ? PH_OK : ph_fused_v210_combine(ctx, queue, f.n, f.layers, f.out, f.width, f.height, f.rd_cm->dptr, f.rd_lut->dptr, f.rd_gm->dptr,
-                                   f.wr_cm->dptr, f.wr_lut->dptr);
-    }
     case K_DISSOLVE:
     case K_MIXER:
     case K_WIPE: {
@@ -1664,8 +1724,38 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
       TRY(need_buf(args, n, "maskIn", (size_t)w * h * 16, &c));
       return check_only ? PH_OK : ph_transition_wipe(ctx, queue, a->dptr, b->dptr, c->dptr, w, h, o->dptr);
     }
+    default: break;
   }
+  return fail(PH_E_UNKNOWN_KERNEL, "unhandled kernel id");
+}
 #undef TRY
+static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, int queue, bool check_only = false) {
+  if (!check_only && inject_failure(ctx)) return fail(PH_E_HIP, "%s: launch failed: injected (context option fail_launches)", prog->kernel.c_str());
+  switch (prog->id) {
+    case K_PACK_READ:
+    case K_PACK_WRITE:
+    case K_V210_READ:
+    case K_V210_WRITE:
+    case K_V210_READ_BATCH:
+      return dispatch_wire(ctx, prog, args, n, queue, check_only);
+    case K_YADIF:
+    case K_YADIF_PAIR:
+    case K_V210_YADIF_PAIR:
+      return dispatch_deint(ctx, prog, args, n, queue, check_only);
+    case K_CHAN_COMPOSE:
+    case K_COMPOSE_UP:
+    case K_COMPOSE_V210:
+    case K_COMBINE:
+    case K_FUSED_V210:
+      return dispatch_compose(ctx, prog, args, n, queue, check_only);
+    case K_TRANSFORM:
+    case K_RESIZE:
+    case K_DISSOLVE:
+    case K_MIXER:
+    case K_WIPE:
+    case K_TWIPE:
+      return dispatch_image(ctx, prog, args, n, queue, check_only);
+  }
   return fail(PH_E_UNKNOWN_KERNEL, "unhandled kernel id");
 }
 
@@ -1711,15 +1801,26 @@ int ph_check_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_ar
 }
 
 /* Several recorded jobs handed over in one call (a binding that records jobs and launches them later: node/defer.js).  Exactly the
- * ph_run_program calls in the order given, PROVIDED no job reads what another job of the call writes - with the channel frames among
- * them (chan_compose_v210_<n> programs of one geometry that name the SAME Loader / Saver buffers and make v210 frames) put into
- * launches together (ph_chan_compose_batch). */
+ * ph_run_program calls in the order given - with the channel frames among them (chan_compose_v210_<n> programs of one geometry that name
+ * the SAME Loader / Saver buffers and make v210 frames) put into launches together (ph_chan_compose_batch), likewise consecutive
+ * fused_v210_combine_<n> frames; a job that reads or writes what an earlier job of its group writes (or writes what one reads) is
+ * detected here and starts the next launch, so call order holds (include/phaneron_hip.h).  A call that fails after its checks
+ * (a launch refused) has made the launches of the jobs before the failing group: ph_run_programs_progress says how many. */
+namespace {
+thread_local int g_programs_done = 0;  // jobs of the calling thread's last ph_run_programs call whose launches were made
+}
+int ph_run_programs_progress(int *jobs_done) {
+  if (!jobs_done) return fail(PH_E_INVALID, "ph_run_programs_progress: NULL argument");
+  *jobs_done = g_programs_done;
+  return PH_OK;
+}
 int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_arg *const *args, const int *n_args, int queue) {
   if (!ctx || n_jobs < 1 || !progs || !args || !n_args) return fail(PH_E_INVALID, "ph_run_programs: NULL argument");
   PH_QUEUE("ph_run_programs", queue);
+  g_programs_done = 0;
   int rc = set_device(ctx);
   if (rc) return rc;
-  if (ctx->fail_launches.load()) return fail(PH_E_HIP, "ph_run_programs: launch failed: injected (context option fail_launches)");
+  if (ctx->fail_launches.load() > 0) return fail(PH_E_HIP, "ph_run_programs: launch failed: injected (context option fail_launches)");
   std::vector<ChanCall> calls((size_t)n_jobs);
   std::vector<FusedCall> fused((size_t)n_jobs);
   std::vector<char> kind((size_t)n_jobs, 0);  // 1: a v210 frame from the channel kernel, 2: fused_v210_combine, 0: whatever else, launched as it is
@@ -1739,10 +1840,11 @@ int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_
   for (int j = 0; j < n_jobs;) {
     if (!kind[(size_t)j]) {
       if ((rc = dispatch(ctx, progs[j], args[j], n_args[j], queue))) return rc;
-      ++j;
+      g_programs_done = ++j;
       continue;
     }
     int k = j;
+    if (inject_failure(ctx)) return fail(PH_E_HIP, "ph_run_programs: launch failed: injected (context option fail_launches)");
     if (kind[(size_t)j] == 2) {
       // frames of one size, layer count and recipe: one launch of the headline kernel (ph_fused_v210_combine_batch).  A frame that reads
       // what an earlier frame of the run writes (or writes what one reads or writes) starts the next launch: call order is kept.
@@ -1770,7 +1872,7 @@ int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_
       rc = ph_fused_v210_combine_batch(ctx, queue, (int)outs.size(), f0.n, layers.data(), outs.data(), f0.width, f0.height, f0.rd_cm->dptr, f0.rd_lut->dptr,
                                        f0.rd_gm->dptr, f0.wr_cm->dptr, f0.wr_lut->dptr);
       if (rc) return rc;
-      j = k;
+      g_programs_done = j = k;
       continue;
     }
     const ChanCall &c0 = calls[(size_t)j];
@@ -1803,7 +1905,7 @@ int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_
     rc = ph_chan_compose_batch(ctx, queue, (int)batch.size(), batch.data(), c0.width, c0.height, c0.rd_cm->dptr, c0.rd_lut->dptr, c0.rd_gm->dptr,
                                c0.wr_cm->dptr, c0.wr_lut->dptr);
     if (rc) return rc;
-    j = k;
+    g_programs_done = j = k;
   }
   return PH_OK;
 }

@@ -107,12 +107,12 @@ def test_napi_addon_builds_loads_and_refuses_without_gpu():
           "const want=['abiVersion','setOption','createContext','contextInfo','createBuffer','bufAddRef','bufRelease','bufRefCount',"
           "'hostAccess','waitFinish','createProgram','runProgram','bufferStats','queueWaitQueue','downloadAsync',"
           "'eventRecord','eventWait','eventDone','waitFinishSpin','resolveProgram','gammaLut','colourMatrix',"
-          "'transformMatrix','planeBytes','routeUniqueId','routeInit','routeOp'];"
+          "'transformMatrix','planeBytes','routeUniqueId','routeInit','routeOp','runPrograms','runProgramsProgress','traceBegin','traceEnd'];"
           "for (const k of want) if (typeof a[k] !== 'function') { console.log('missing', k); process.exit(2) }"
           "console.log(a.abiVersion())") % os.path.join(ROOT, "node", "phaneron_napi.node")
     r = subprocess.run([NODE, "-e", js], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.strip() == "7"
+    assert r.stdout.strip() == "8"
     import torch
     if not torch.cuda.is_available():
         js = ("const {clContext}=require('%s'); const c=new clContext({deviceIndex:0});"
@@ -747,3 +747,17 @@ def test_recording_context_soak_fault_and_timings():
     assert res["channels"]["ticks"] == 20000 and res["channels"]["deferred"]["batched"] == 80000 and res["channels"]["deferred"]["launched"] == 20000
     assert "injected" in res["fault"]["deferred"]["rejected"] and res["fault"]["plain"]["rejected"] is None
     assert all(t["write"]["kernelExec"] > 0 for t in res["timings"])
+
+
+@needs_node
+@pytest.mark.gpu
+def test_parked_buffers_are_settled_before_their_next_owner():
+    """node/index.js parks released frames whole (handle, device block, pinned mirror).  The next owner of one whose mirror or block may
+    still be busy - released right after downloadAsync, mapped for writing and never handed back - gets it settled by the library
+    (ph_buf_reuse): it reads back what IT wrote, the previous owner's abandoned host data never reaches the device, and a buffer that
+    was merely created and released still costs no call."""
+    _build_addon()
+    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "park_run.js")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["problems"] == [] and res["checks"] >= 20, res
