@@ -555,6 +555,9 @@ int ph_lut_layout_of(const float *host_lut65536, ph_lut_layout *layout, void *ld
  *          buffer of the same size (the reference creates its destinations per job and frame: io.ts:64-72) - this much,
  *          or as much as was ever attached to live buffers at once if that is more (a pool smaller than the working set
  *          pins a block per buffer again, ~40 ms each); over the budget the oldest blocks are freed first; 0: no pool;
+ *          setting the option trims the pool to the new size and restarts the working-set measurement (after a 2160p
+ *          period a caller sheds the memory by setting the option again; node/index.js parks its frames under a budget
+ *          of its own - parkMb - and trim() hands them back);
  *          "fail_launches" (default 0) - TEST ONLY, a fault injection for the error paths of a binding (node/test/soak_run.js): > 0:
  *          every launch made through ph_run_program / ph_run_programs fails with PH_E_HIP; -k: the next k launches (groups of
  *          ph_run_programs) go through, then every one fails; checks still pass.  Nothing in a deployment sets it;

@@ -1071,6 +1071,7 @@ int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
     {
       std::lock_guard<std::mutex> lock(ctx->mu);
       ctx->host_pool_mb = value;
+      ctx->host_peak_bytes = ctx->host_live_bytes;  // the working set is measured afresh from here (a burst long ago no longer sizes the pool)
       while (ctx->host_pooled_bytes > (size_t)value << 20 && !ctx->host_pool.empty()) {
         auto it = std::prev(ctx->host_pool.end());
         ctx->host_pooled_bytes -= it->first;

@@ -148,6 +148,7 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     current[0] = name2
     record(name2, "channel compositor straight from v210 (ph_chan_compose_v210): [read x5 + transform x4 + transition_wipe + combine_4 + write] "
            "as one kernel, no f32 frame in HBM", "frame", timeit(config2_chan, reps), algo2, 1, {"chan_compose_v210_kernel<0, 0>": 1.0},
+           parity_test="tests/test_chan_gpu.py::test_config2_full_size_with_wipe",
            bytes_as_benched=benched2, bytes_as_benched_note="5 v210 frames in + 1 out + the wipe's mask as the f32 RGBA image the kernel reads "
            "(33 MB); algorithmic_bytes is SURVEY 8d's figure, which counts the mask as a v210-sized input")
     # round 5: the reference runs FOUR channels of <= 1080p in one context through one queue (src/index.ts:45-71,156-160): their frames
@@ -160,7 +161,8 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     record("2 x 4: four channels of config 2's shape in one context, their frames of a tick in one launch (per channel frame)",
            "ph_chan_compose_batch: the four frames share the workgroups of one launch - tables loaded once, the wave steps of all four taken "
            "by the waves as they come free", "frame", timeit(lambda i: batch_jobs[i % R](), reps) / C2, algo2, 1.0 / C2,
-           {"chan_compose_batch_kernel<false>": 1.0 / C2}, bytes_as_benched=benched2, channels_per_launch=C2)
+           {"chan_compose_batch_kernel<false>": 1.0 / C2}, bytes_as_benched=benched2, channels_per_launch=C2,
+           parity_test="tests/test_chan_gpu.py::test_chan_batch_full_size_four_1080p_channels")
     if routes == "all":
         record(name2, "batched reads + compositor with the wipe inside: [read x5], [transform x4 + transition_wipe + combine_4 + write]", "frame",
                timeit(config2_wipe_inside, reps), algo2, 2)
@@ -188,16 +190,18 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     name7 = "720p50: 1 channel, 4 x 1280x720 v210 layers -> 1 v210 frame (lines with a tail quad: the reference's tail arithmetic)"
     current[0] = name7
     record(name7, "fused unpack / CSC / combine_4 / CSC / pack, 1:1 layers (ph_fused_v210_combine, tail instantiation)", "frame",
-           timeit(lambda i: ctx.fused_v210_combine(src7[i % R], out7, w7, h7, *rd7, *wr7), reps), algo7, 1, {"fused_v210_combine_lds_kernel": 1.0})
+           timeit(lambda i: ctx.fused_v210_combine(src7[i % R], out7, w7, h7, *rd7, *wr7), reps), algo7, 1, {"fused_v210_combine_lds_kernel": 1.0},
+           parity_test="tests/test_chains_gpu.py::test_720p_headline_shape_full_size")
     record(name7, "channel compositor straight from v210, a full-frame layer and three quarter-size insets (ph_chan_compose_v210, general instantiation)", "frame",
-           timeit(lambda i: chan7[i % R](), reps), algo7, 1, {"chan_compose_v210_kernel<1, 0>": 1.0})
+           timeit(lambda i: chan7[i % R](), reps), algo7, 1, {"chan_compose_v210_kernel<1, 0>": 1.0}, parity_test="tests/test_chains_gpu.py::test_720p_chain_full_size")
     C7 = 4
     outs7 = [torch.empty_like(out7) for _ in range(C7)]
     batch7 = [ctx.chan_compose_batch([([dict(src=(src7[(i + j) % R][l], w7, h7, mats7[l])) for l in range(4)], outs7[j], 0) for j in range(C7)],
                                      w7, h7, *rd7, *wr7, prepare_only=True) for i in range(R)]
     record("720p50 x 4: four such channels in one context, their frames of a tick in one launch (per channel frame)",
            "ph_chan_compose_batch, a full-frame layer and three quarter-size insets per channel", "frame",
-           timeit(lambda i: batch7[i % R](), reps) / C7, algo7, 1.0 / C7, {"chan_compose_batch_kernel<true>": 1.0 / C7}, channels_per_launch=C7)
+           timeit(lambda i: batch7[i % R](), reps) / C7, algo7, 1.0 / C7, {"chan_compose_batch_kernel<true>": 1.0 / C7}, channels_per_launch=C7,
+           parity_test="tests/test_fullsize_gpu.py::test_four_720p_channels_in_one_launch_full_size")
 
     # ---------------- config 3 -------------------------------------------------------------
     sw, sh, ow, oh = 1920, 1080, 3840, 2160
@@ -281,7 +285,8 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     current[0] = name3
     record(name3, "fused de-interlacing reader (packed RGB fields) + 2x2-block compositor, two launches per frame: [unpack + yadif, both fields, x4 layers] "
            "(ph_v210_yadif_pair_fmt), [transform x4 + combine_4 + write, both fields] (ph_compose_up_write_v210_pair)", "field",
-           timeit(config3_up_pair, reps), algo3, 1.0, {"v210_yadif_pair_kernel": 0.5, "compose_up_write_v210_kernel": 0.5})
+           timeit(config3_up_pair, reps), algo3, 1.0, {"v210_yadif_pair_kernel": 0.5, "compose_up_write_v210_kernel": 0.5},
+           parity_test="tests/test_chains_gpu.py::test_config3_deinterlacing_reader_full_size")
     if routes == "all":
         record(name3, "fused de-interlacing reader (packed RGB fields) + 2x2-block compositor: per frame [unpack + yadif, both fields, x4 layers] "
                "(ph_v210_yadif_pair_fmt), per field [transform x4 + combine_4 + write] (ph_compose_up_write_v210)", "field",
@@ -312,7 +317,8 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
         algo_f = cw * ch * 3 // 2 + capi.v210_pitch_bytes(fw) * fh
         current[0] = what
         record(what, "ph_chan_compose_v210 on the decoder's planes: inside, [yuv420p -> f32 image] (ph_pack_read) + [transform + write] (ph_compose_up_write_v210), two launches", "frame",
-               timeit(lambda i: jobs[i % R](), reps), algo_f, 2, {"fmt_read_lds_kernel": 1.0, "compose_up_write_v210_kernel": 1.0})
+               timeit(lambda i: jobs[i % R](), reps), algo_f, 2, {"fmt_read_lds_kernel": 1.0, "compose_up_write_v210_kernel": 1.0},
+               parity_test="tests/test_fullsize_gpu.py::test_file_playback_as_benched")
     # config 3 in the reference's own formats: 4 x 1080i50 -> yadif -> own size on a 1080p50 channel (src/config.ts:43-78), per output field
     isrc = [v210(fw, fh, 4) for _ in range(R)]
     iwin = [[isrc[k % R][l] for k in range(3)] for l in range(4)]
@@ -334,7 +340,8 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     record("f3: 1 channel, 4 x 1080i50 -> yadif -> own size -> combine_4 -> 1080p50 v210 (per output field)",
            "fused de-interlacing reader (packed RGB fields) + 2x2-block compositor under the default fill, two launches per frame", "field",
            timeit(config3b, reps), 4 * 3 * capi.v210_pitch_bytes(fw) * fh // 2 + capi.v210_pitch_bytes(fw) * fh, 1.0,
-           {"v210_yadif_pair_kernel": 0.5, "compose_up_write_v210_kernel": 0.5})
+           {"v210_yadif_pair_kernel": 0.5, "compose_up_write_v210_kernel": 0.5},
+           parity_test="tests/test_fullsize_gpu.py::test_interlaced_sources_on_a_1080p_channel_as_benched")
     current[0] = name3
     if routes == "all":
         up = img(ow, oh, 4)
