@@ -1064,7 +1064,7 @@ int ph_ctx_set_option(ph_ctx *ctx, const char *name, int value) {
     return ctx->stream_threshold_mb = value, PH_OK;
   }
   if (0 == strcmp(name, "fail_launches")) return ctx->fail_launches.store(value), PH_OK;
-  if (0 == strcmp(name, "chan_enlarged")) return ctx->chan_enlarged = (value != 0), PH_OK;
+  if (0 == strcmp(name, "chan_enlarged")) return ctx->chan_enlarged = (value < 0 || value > 2 ? 1 : value), PH_OK;  // 2: never the one-launch form (A/B, tests)
   if (0 == strcmp(name, "host_pool_mb")) {
     if (value < 0) return fail(PH_E_INVALID, "host_pool_mb: a size in MiB");
     std::vector<ph_ctx::HostBlock> drop;
@@ -2318,6 +2318,51 @@ static bool chan_enlarged_same_shape(int n, const ph_chan_layer *a, const ph_cha
 // and ONE compositor launch (ph_compose_up_write_v210_batch)
 static int chan_compose_enlarged(ph_ctx *ctx, int queue, int jobs, int n, const ph_chan_layer *const *layers, void *const *outs, uint32_t out_w, uint32_t out_h,
                                  uint32_t interlace, const void *rd_cm, const void *rd_lut, const void *rd_gm, const void *wr_cm, const void *wr_lut) {
+  // ONE frame whose layers are all clips in their wire formats: reader and compositor in one launch (ph_kernels_up.hip clip_up_write_v210_kernel) -
+  // no image leaves the chip.  (Several frames of one shape: the batched reads + one compositor launch below.)
+  // Measured (tools/enlarge_bench.py, profiles/r06_clip_up.txt): one decoder's frame 22.5 -> 19.3 us (1080p yuv420p under the default fill), 18.0 -> 17.3
+  // (720p filling 1080p); a v210 clip and frames of several layers are not faster this way (two layers 23.7 -> 24.1 us, four 1080 layers on
+  // 2160p 95 -> 110: the conversions of a tile's rim are done twice) and keep the two launches.
+  if (jobs == 1 && n == 1 && layers[0][0].src.format != PH_SRC_V210 && ctx->chan_enlarged == 1) {
+    bool wire = true, alpha = false;
+    for (int i = 0; i < n && wire; ++i) {
+      const ph_chan_source &S = layers[0][i].src;
+      wire = S.format != PH_SRC_RGBA_F32 && !(((S.format == PH_SRC_YUV420P || S.format == PH_SRC_NV12) && (S.height & 1)));
+      alpha = alpha || S.format == PH_SRC_RGBA8 || S.format == PH_SRC_BGRA8;
+    }
+    const LutRef rref = lds_view(ctx, rd_lut), wref = lds_view(ctx, wr_lut);
+    if (wire && rref.found && wref.found) {
+      ph::ClipUpArgs c{};
+      ph::UpArgs &a = c.up;
+      a.n = n, a.out = outs[0], a.out_w = out_w, a.out_h = out_h;
+      a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0, a.lines = interlace ? out_h / 2 : out_h;
+      a.wr_cm = (const float *)wr_cm, a.wr = wref.view;
+      c.rd = rref.view, c.rd_gm = (const float *)rd_gm;
+      for (int i = 0; i < n; ++i) {
+        const ph_chan_source &S = layers[0][i].src;
+        a.layer[i].w = (uint32_t)S.width, a.layer[i].h = (uint32_t)S.height, a.layer[i].pitch = (uint32_t)S.width * 16u;
+        for (int k = 0; k < 6; ++k) a.layer[i].m[k] = S.matrix9_host[k];
+        const int fmt = S.format == PH_SRC_V210 ? PH_FMT_V210 : PH_FMT_YUV422P10 + (S.format - PH_SRC_YUV422P10);
+        c.src[i] = ph::ClipSrc{S.data, S.data_u, S.data_v, (const float *)(S.col_matrix12 ? S.col_matrix12 : rd_cm), (uint32_t)fmt,
+                               fmt == PH_FMT_V210 ? ph_v210_pitch_bytes((uint32_t)S.width) / 16u : ph::pack_pitch(fmt, (uint32_t)S.width)};
+      }
+      if (a.lines && ph::compose_up_eligible(a)) {
+        const uint32_t grid = ph::clip_up_plan(c, !alpha, (uint32_t)ctx->props.multiProcessorCount);
+        if (grid) {
+          std::lock_guard<std::mutex> scratch(ctx->chan_scratch_mu[queue]);  // until the launch is enqueued
+          {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            int rc = chan_index_reserve(ctx, queue, (size_t)c.wg_bytes * grid + 4096u);
+            if (rc) return rc;
+            c.scratch = (char *)ctx->chan_index[queue];
+          }
+          hipError_t e = ph::launch_clip_up_write_v210(stream_of(ctx, queue), c, !alpha, grid);
+          if (e != hipSuccess) return fail(PH_E_HIP, "ph_chan_compose_v210: launch failed: %s", hipGetErrorString(e));
+          return PH_OK;
+        }
+      }
+    }
+  }
   // the images live in the channel compositor's scratch area of the queue (launches on one queue are in order)
   size_t off[ph::kMaxLayers], per_job = 0;
   bool one_size = true;

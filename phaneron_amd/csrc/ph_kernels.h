@@ -176,6 +176,30 @@ struct UpArgs {
   void *more_out[kMaxUpJobs - 1];
   uint32_t jobs;
 };
+// Clips straight from their wire formats: reader and 2 x 2-block compositor in ONE launch (clip_up_write_v210_kernel).  A workgroup owns a
+// tile of the output; with the reader's table resident it converts the source pixels its tile's taps fall on - once each - into a
+// scratch rectangle of its own (packed f32 RGB, or RGBA when a source carries alpha; it stays in the XCD's L2), swaps the writer's
+// table in and composes from there.
+struct ClipSrc {
+  const void *p0, *p1, *p2;  // the planes (v210 / packed RGB: p0)
+  const float *cm;           // the source's YCbCr -> RGB matrix (device, 12 floats; unused for packed RGB)
+  uint32_t fmt;              // PH_FMT_*
+  uint32_t pitch;            // line pitch in luma samples / pixels; v210: in 16-byte quads
+};
+struct ClipUpArgs {
+  UpArgs up;                 // layer[l].w / h / m: the clip's size and placement (ptr / pitch are the kernel's: the scratch rectangle)
+  ClipSrc src[kMaxLayers];
+  const float *rd_gm;
+  LutView rd;
+  char *scratch;             // grid * wg_bytes
+  uint32_t wg_bytes;
+  uint32_t rect_off[kMaxLayers], rect_cap[kMaxLayers];  // a layer's rectangle inside the workgroup's scratch: offset, bytes reserved
+  uint32_t tcu, trp, gx;     // a tile: wave-step columns x row pairs; tiles per row of tiles
+  uint32_t info_off;         // LDS offset of the per-layer rectangle descriptors (behind the larger table)
+};
+// picks the tiling and fills rect_off / rect_cap / wg_bytes / tcu / trp / gx / info_off; returns the number of workgroups (0: not for this kernel)
+uint32_t clip_up_plan(ClipUpArgs &a, bool rgb12, uint32_t num_cus);
+hipError_t launch_clip_up_write_v210(hipStream_t s, const ClipUpArgs &a, bool rgb12, uint32_t grid);
 bool compose_up_eligible(const UpArgs &a);
 hipError_t launch_compose_up_write_v210(hipStream_t s, const UpArgs &a, bool rgb12, uint32_t num_cus);
 

@@ -245,7 +245,7 @@ struct UpPatch {
 };
 template <bool RGB12>
 __device__ __forceinline__ void up_fetch(const UpLayer &L, const UpGeo &g, UpPatch &p) {
-  const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(L.ptr), 0, (int)(L.pitch * L.h), 0x00020000);
+  const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(L.ptr), 0, (int)(L.pad ? L.pad : L.pitch * L.h), 0x00020000);
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -399,6 +399,349 @@ __global__ __launch_bounds__(kUpBlock) void compose_up_write_v210_kernel(UpArgs 
     }
     up_write<TAILS>(a, st, acc, role, wk, lk);
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Clips straight from their wire formats: [read] x N -> [transform] x N -> combine_N -> v210 write as ONE launch.
+// The two-launch route (reader of the format into an f32 image, then the kernel above) sends every clip's image out of the chip and
+// back - 6 x the frame's compulsory bytes for a 720p clip on a 1080p channel - and pays launch, table load and drain twice for two
+// kernels of ten microseconds each.  Here a workgroup owns a TILE of the output (tcu wave-step columns x trp row pairs).  Phase 1, the
+// reader's table in the LDS: the source pixels the tile's taps fall on are converted once each (v210.ts:58-78 / yuv420p.ts ... the
+// reader's own arithmetic, a wave per source row) into a rectangle of the workgroup's own scratch, which never leaves the XCD's L2.
+// Phase 2, the writer's table swapped in: the kernel above, its nine-texel patches taken from the rectangle.
+// ------------------------------------------------------------------------------------------------------------------------------------
+// PH_CLIP_ABLATE builds (timing experiments, never shipped): bit 0 = stop after phase 1, bit 1 = phase 1 converts nothing, bit 2 = no phase 2 work
+#ifndef PH_CLIP_ABLATE
+#define PH_CLIP_ABLATE 0
+#endif
+enum { CF_V210 = 0, CF_YUV422P10 = 1, CF_YUV422P8 = 2, CF_YUV420P = 3, CF_NV12 = 4, CF_RGBA8 = 5, CF_BGRA8 = 6 };  // = PH_FMT_*
+
+// one source pixel as the reader of its format makes it (ph_kernels_fmt.hip fmt_read_body, ph_kernels_lds.hip v210_read_lds_kernel), in two
+// halves: its samples requested, then converted - a lane requests the samples of all its pixels of a round before it converts the first
+// (a rectangle is a handful of pixels per lane: one at a time, every pixel would wait out its own trip to HBM)
+struct ClipRaw {
+  uint4 w;  // v210: the pixel's word quad; planar: .x .y .z = Y, Cb, Cr; packed RGB: .x = the pixel
+};
+template <int FMT>
+__device__ __forceinline__ ClipRaw clip_fetch(const ClipSrc &S, uint32_t x, uint32_t line) {
+  ClipRaw r;
+  r.w = make_uint4(0u, 0u, 0u, 0u);
+  if (FMT == CF_V210) {
+    r.w = reinterpret_cast<const uint4 *>(S.p0)[(size_t)line * S.pitch + x / 6u];
+  } else if (FMT == CF_RGBA8 || FMT == CF_BGRA8) {
+    r.w.x = reinterpret_cast<const uint32_t *>(S.p0)[(size_t)line * S.pitch + x];
+  } else {
+    const uint32_t cl = (FMT == CF_YUV420P || FMT == CF_NV12) ? line >> 1 : line;
+    if (FMT == CF_YUV422P10) {
+      r.w.x = reinterpret_cast<const uint16_t *>(S.p0)[(size_t)line * S.pitch + x];
+      r.w.y = reinterpret_cast<const uint16_t *>(S.p1)[(size_t)cl * (S.pitch >> 1) + (x >> 1)];
+      r.w.z = reinterpret_cast<const uint16_t *>(S.p2)[(size_t)cl * (S.pitch >> 1) + (x >> 1)];
+    } else if (FMT == CF_NV12) {  // nv12.ts:61-74
+      r.w.x = reinterpret_cast<const uint8_t *>(S.p0)[(size_t)line * S.pitch + x];
+      const uint8_t *c = reinterpret_cast<const uint8_t *>(S.p1) + (size_t)cl * S.pitch + (x & ~1u);
+      r.w.y = c[0], r.w.z = c[1];
+    } else {
+      r.w.x = reinterpret_cast<const uint8_t *>(S.p0)[(size_t)line * S.pitch + x];
+      r.w.y = reinterpret_cast<const uint8_t *>(S.p1)[(size_t)cl * (S.pitch >> 1) + (x >> 1)];
+      r.w.z = reinterpret_cast<const uint8_t *>(S.p2)[(size_t)cl * (S.pitch >> 1) + (x >> 1)];
+    }
+  }
+  return r;
+}
+template <int FMT>
+__device__ __forceinline__ float4 clip_finish(const ClipRaw &raw, uint32_t width, uint32_t x, const ReadK &k, const LutK &lk) {
+  if (FMT == CF_V210) {
+    const uint4 w = raw.w;
+    const uint32_t g = x / 6u, j = x - 6u * g, pr = j >> 1;
+    const uint32_t wy = (j == 0) ? w.x : (j < 3) ? w.y : (j == 3) ? w.z : w.w;  // v210.ts:58-63, as v210_read_lds_kernel
+    const uint32_t sy = (j == 0 || j == 3) ? 10u : (j == 1 || j == 4) ? 0u : 20u;
+    const uint32_t wcb = pr == 0 ? w.x : pr == 1 ? w.y : w.z;
+    const uint32_t wcr = pr == 0 ? w.x : pr == 1 ? w.z : w.w;
+    const uint32_t scr = pr == 0 ? 20u : pr == 1 ? 0u : 10u;
+    const float yf = (float)((wy >> sy) & 0x3ff), cbf = (float)((wcb >> (10u * pr)) & 0x3ff), crf = (float)((wcr >> scr) & 0x3ff);
+    return read_px_lds(yf, cbf, crf, k, lk, x < width - width % 6u ? 1.0f : 0.0f);  // (a line's tail: v210.ts:88-93)
+  }
+  if (FMT == CF_RGBA8 || FMT == CF_BGRA8) {  // rgba8.ts:49-62
+    const uint32_t p = raw.w.x;
+    const float c0 = (float)(p & 0xffu), gf = (float)((p >> 8) & 0xffu), c2 = (float)((p >> 16) & 0xffu), af = (float)(p >> 24);
+    const float rf = FMT == CF_RGBA8 ? c0 : c2, bf = FMT == CF_RGBA8 ? c2 : c0;
+    const float r = lds_lut_at(lk, rf * 65535.0f / 255.0f), g = lds_lut_at(lk, gf * 65535.0f / 255.0f), b = lds_lut_at(lk, bf * 65535.0f / 255.0f);
+    return make_float4(dot3(r, g, b, k.gm[0], k.gm[1], k.gm[2]), dot3(r, g, b, k.gm[3], k.gm[4], k.gm[5]), dot3(r, g, b, k.gm[6], k.gm[7], k.gm[8]),
+                       lds_lut_at(lk, af * 65535.0f / 255.0f));
+  }
+  // (yuv422p10.ts:74-78: dot4 with the offset column, table, gamut - the v210 reader's arithmetic)
+  return read_px_lds((float)raw.w.x, (float)raw.w.y, (float)raw.w.z, k, lk, 1.0f);
+}
+
+// The first tap (column / row) of an output pixel, exactly as up_geo computes it: monotone in the pixel's position (every step is a
+// correctly rounded monotone operation), so a tile's first and last pixels bound the taps of everything between them.
+__device__ __forceinline__ int clip_tap_col(const UpLayer &L, uint32_t x, uint32_t out_w) {
+  const float px = (float)(int)x / (float)(int)out_w - 0.5f;
+  const float sx = dot3(L.m[0], L.m[1], L.m[2], px, 0.0f, 1.0f) + 0.5f;
+  return (int)__builtin_floorf(sx * (float)(int)L.w - 0.5f);
+}
+__device__ __forceinline__ int clip_tap_row(const UpLayer &L, uint32_t line, uint32_t out_h) {
+  const float py = (float)(int)line / (float)(int)out_h - 0.5f;
+  const float sy = dot3(L.m[3], L.m[4], L.m[5], 0.0f, py, 1.0f) + 0.5f;
+  return (int)__builtin_floorf(sy * (float)(int)L.h - 0.5f);
+}
+struct ClipRect {  // uniform: the source rectangle of a tile, inside the image (w == 0: nothing of the image under this tile)
+  uint32_t c0, r0, w, h;
+};
+
+// FIRST: the launch's first rectangle.  Its first round of samples is requested BEFORE the reader's table is loaded (the table load and the
+// samples' trip to HBM overlap), and the table load + barrier happen in here.  Within a rectangle a round's samples are requested before
+// the round before it is converted.
+template <int FMT, bool RGB12, bool FIRST>
+__device__ __forceinline__ void clip_convert(const ClipSrc &S, const UpLayer &L, const ClipRect &R, char *dst, uint32_t ppitch, const float *rd_gm, const LutK &rlk,
+                                             const LutView &rd_view) {
+  // the rectangle's pixels row by row over all the workgroup's lanes, kClipRound of them per lane and round
+  constexpr int kClipRound = FMT == CF_V210 ? 4 : 6;  // (a 720p clip on a 1080p channel: 4.3 K pixels per workgroup - one round)
+  const uint32_t total = R.w * R.h;  // (< 2^24: exact as a float)
+  const float inv_w = 1.0f / (float)(R.w ? R.w : 1u);
+  struct Round {
+    ClipRaw raw[kClipRound];
+    uint32_t col[kClipRound], row[kClipRound];
+  };
+  auto request = [&](uint32_t base, Round &q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < kClipRound; ++i) {
+      const uint32_t idx = base + (uint32_t)i * kUpBlock < total ? base + (uint32_t)i * kUpBlock : total - 1u;  // (lanes past the end redo the last pixel)
+      uint32_t r = (uint32_t)((float)idx * inv_w);  // idx / R.w, off by one at most
+      r -= r * R.w > idx ? 1u : 0u;
+      r += (r + 1u) * R.w <= idx ? 1u : 0u;
+      q.row[i] = r, q.col[i] = idx - r * R.w;
+      q.raw[i] = clip_fetch<FMT>(S, R.c0 + q.col[i], R.r0 + r);
+    }
+  };
+  Round cur;
+  if (total) request(threadIdx.x, cur);  // (uniform)
+  if (FIRST) {
+    lds_lut_load<kUpBlock>(rd_view);
+    __syncthreads();
+  }
+  ReadK k;
+  if (FMT >= CF_RGBA8) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k.gm[i] = rd_gm[i];
+  } else {
+    k = load_read_k(S.cm, rd_gm);
+  }
+  for (uint32_t base = threadIdx.x; base < total; base += kClipRound * kUpBlock) {
+    Round nxt = cur;
+    const uint32_t next_base = base + kClipRound * kUpBlock;
+    if (next_base - threadIdx.x < total) request(next_base < total ? next_base : total - 1u, nxt);  // (uniform test: the whole workgroup takes the round or not)
+#pragma unroll
+    for (int i = 0; i < kClipRound; ++i) {
+      const float4 t = clip_finish<FMT>(cur.raw[i], L.w, R.c0 + cur.col[i], k, rlk);
+      char *at = dst + (size_t)cur.row[i] * ppitch + (size_t)cur.col[i] * (RGB12 ? 12u : 16u);
+      if (RGB12) *reinterpret_cast<ph_u32x3 *>(at) = ph_u32x3{__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z)};
+      else *reinterpret_cast<float4 *>(at) = t;
+    }
+    cur = nxt;
+  }
+}
+
+// a wave step of a tile: as up_step makes it for (col_unit, row pair) of job 0
+__device__ __forceinline__ void clip_step(const UpArgs &a, uint32_t col_unit, uint32_t rp, uint32_t lane, UpStep &st) {
+  st.job = 0;
+  st.x0 = col_unit * kUpCols + 2u * lane;
+  st.live = lane < 63u && st.x0 < a.out_w;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    st.li[dy] = 2u * rp + (uint32_t)dy < a.lines ? 2u * rp + (uint32_t)dy : 2u * rp;
+    st.line[dy] = a.first_line + st.li[dy] * a.line_step;
+    st.py[dy] = (float)(int)st.line[dy] / (float)(int)a.out_h - 0.5f;
+  }
+#pragma unroll
+  for (int dx = 0; dx < 2; ++dx) st.px[dx] = (float)(int)(st.x0 + (uint32_t)dx) / (float)(int)a.out_w - 0.5f;
+}
+
+template <bool RGB12, bool TAILS>
+__global__ __launch_bounds__(kUpBlock) void clip_up_write_v210_kernel(ClipUpArgs c) {
+  const UpArgs &a = c.up;
+  constexpr uint32_t kTexel = RGB12 ? 12u : 16u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // the tile
+  const uint32_t upr = (a.cover_w + kUpCols - 1u) / kUpCols, rps = (a.lines + 1u) / 2u;
+  const uint32_t ty = blockIdx.x / c.gx, tx = blockIdx.x - ty * c.gx;
+  const uint32_t cu0 = tx * c.tcu, rp0 = ty * c.trp;
+  const uint32_t ncu = cu0 + c.tcu <= upr ? c.tcu : upr - cu0, nrp = rp0 + c.trp <= rps ? c.trp : rps - rp0;
+  char *const mine = c.scratch + (size_t)blockIdx.x * c.wg_bytes;
+  // ---- phase 1: the reader's table; every layer's rectangle converted
+  const LutK rlk = make_lut_k(c.rd);
+  uint4 *const info = reinterpret_cast<uint4 *>(g_lds + c.info_off);
+#pragma unroll 1
+  for (int l = 0; l < a.n; ++l) {
+    const UpLayer L = a.layer[l];
+    const ClipSrc S = c.src[l];
+    // the tile's first and last pixels (inside the frame: columns past out_w - the padding of a line with a tail - have no taps that count)
+    const uint32_t x_first = cu0 * kUpCols, x_end = (cu0 + ncu) * kUpCols < a.out_w ? (cu0 + ncu) * kUpCols : a.out_w;
+    const uint32_t li_last = 2u * (rp0 + nrp) < a.lines ? 2u * (rp0 + nrp) - 1u : a.lines - 1u;
+    ClipRect R{0, 0, 0, 0};
+    if (x_first < x_end) {
+      int c_lo = clip_tap_col(L, x_first, a.out_w), c_hi = clip_tap_col(L, x_end - 1u, a.out_w) + 2;  // (a block's patch: three columns from its left pixel's first tap)
+      int r_lo = clip_tap_row(L, a.first_line + 2u * rp0 * a.line_step, a.out_h), r_hi = clip_tap_row(L, a.first_line + li_last * a.line_step, a.out_h) + 2;
+      c_lo = c_lo < 0 ? 0 : c_lo, r_lo = r_lo < 0 ? 0 : r_lo;
+      c_hi = c_hi >= (int)L.w ? (int)L.w - 1 : c_hi, r_hi = r_hi >= (int)L.h ? (int)L.h - 1 : r_hi;
+      if (c_hi >= c_lo && r_hi >= r_lo) R = ClipRect{(uint32_t)c_lo, (uint32_t)r_lo, (uint32_t)(c_hi - c_lo + 1), (uint32_t)(r_hi - r_lo + 1)};
+    }
+    R.c0 = __builtin_amdgcn_readfirstlane(R.c0), R.r0 = __builtin_amdgcn_readfirstlane(R.r0);
+    R.w = __builtin_amdgcn_readfirstlane(R.w), R.h = __builtin_amdgcn_readfirstlane(R.h);
+    const uint32_t ppitch = R.w * kTexel;
+    if (ppitch && R.h * ppitch > c.rect_cap[l]) R.h = c.rect_cap[l] / ppitch;  // (the launcher's bound holds: never taken)
+    char *const dst = mine + c.rect_off[l];
+#if PH_CLIP_ABLATE & 2  // timing experiment only (wrong pixels): nothing converted
+    R.h = 0;
+#endif
+#define PH_CLIP_CASE(F)                                                                                   \
+  case F:                                                                                                  \
+    if (l == 0) clip_convert<F, RGB12, true>(S, L, R, dst, ppitch, c.rd_gm, rlk, c.rd);                    \
+    else clip_convert<F, RGB12, false>(S, L, R, dst, ppitch, c.rd_gm, rlk, c.rd);                          \
+    break;
+    switch (S.fmt) {  // uniform
+      PH_CLIP_CASE(CF_V210)
+      PH_CLIP_CASE(CF_YUV422P10)
+      PH_CLIP_CASE(CF_YUV422P8)
+      PH_CLIP_CASE(CF_YUV420P)
+      PH_CLIP_CASE(CF_NV12)
+      PH_CLIP_CASE(CF_RGBA8)
+      default:
+        if (l == 0) clip_convert<CF_BGRA8, RGB12, true>(S, L, R, dst, ppitch, c.rd_gm, rlk, c.rd);
+        else clip_convert<CF_BGRA8, RGB12, false>(S, L, R, dst, ppitch, c.rd_gm, rlk, c.rd);
+        break;
+    }
+#undef PH_CLIP_CASE
+    // the layer as phase 2 sees it: texel (col, row) of the IMAGE at base + row * ppitch + col * kTexel (only texels of the rectangle are ever
+    // taken: everything else of a patch is outside the image, an offset beyond the buffer's records)
+    if (threadIdx.x == 0) {
+      const uint64_t base = (uint64_t)(uintptr_t)dst - ((uint64_t)R.r0 * ppitch + (uint64_t)R.c0 * kTexel);
+      info[l] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), ppitch ? ppitch : kTexel, 0u);
+    }
+  }
+#if PH_CLIP_ABLATE & 1  // timing experiment only: phase 1 alone
+  return;
+#endif
+  // ---- the swap: every wave's rectangle rows are in L2 (a workgroup's stores are visible to its own later loads), the writer's table comes in
+  __threadfence_block();
+  __syncthreads();
+  const WriteK wk = load_write_k(a.wr_cm);
+  const LutK lk = make_lut_k(a.wr);
+  lds_lut_load<kUpBlock>(a.wr);
+  __syncthreads();
+  // ---- phase 2: the 2 x 2-block compositor on the tile's wave steps
+  const uint32_t role = lane - 3u * (lane / 3u);
+  auto layer_of = [&](int l) __attribute__((always_inline)) {
+    UpLayer L = a.layer[l];
+    const uint4 d = info[l];  // uniform address: one broadcast read
+    const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)d.x) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)d.y) << 32;
+    L.ptr = reinterpret_cast<const void *>((uintptr_t)base);
+    L.pitch = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z);
+    L.pad = kUpOutside - 16u;  // the buffer's records: rows are ppitch apart but columns count from the IMAGE's left edge, so pitch * h is no bound here
+    return L;
+  };
+#if PH_CLIP_ABLATE & 4
+  const uint32_t units = 0;
+#else
+  const uint32_t units = ncu * nrp;
+#endif
+  for (uint32_t u = wave; u < units; u += kUpBlock / 64) {
+    const uint32_t rp_in = ncu == 1u ? u : u / ncu, cu_in = u - rp_in * ncu;
+    UpStep st;
+    clip_step(a, cu0 + cu_in, rp0 + rp_in, lane, st);
+    UpAcc acc[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) acc[dy][dx] = UpAcc{0.0f, 0.0f, 0.0f};
+    UpGeo geo;
+    auto layers = [&](auto inside_tag, auto shared_tag) __attribute__((always_inline)) {
+      constexpr bool INSIDE = decltype(inside_tag)::value, SHARED = decltype(shared_tag)::value;
+      {
+        const UpLayer L = layer_of(0);
+        if (!SHARED) geo = up_geo<RGB12>(L, st);  // (shared: layers of one size and placement have rectangles of one shape, their bases aside)
+        UpPatch p;
+        up_fetch<RGB12>(L, geo, p);
+        up_filter<RGB12, INSIDE, true>(p, geo, acc, lk);
+      }
+#pragma unroll 1
+      for (int l = 1; l < a.n; ++l) {
+        const UpLayer L = layer_of(l);
+        if (!SHARED) geo = up_geo<RGB12>(L, st);
+        UpPatch p;
+        up_fetch<RGB12>(L, geo, p);
+        up_filter<RGB12, INSIDE, false>(p, geo, acc, lk);
+      }
+    };
+    if (a.shared) {  // uniform
+      geo = up_geo<RGB12>(layer_of(0), st);
+      if (RGB12 && geo.all_inside) layers(std::true_type{}, std::true_type{});
+      else layers(std::false_type{}, std::true_type{});
+    } else {
+      layers(std::false_type{}, std::false_type{});
+    }
+    up_write<TAILS>(a, st, acc, role, wk, lk);
+  }
+}
+
+// The tiling: tiles of tcu wave-step columns x trp row pairs, one per workgroup, as even as the frame allows (a workgroup's sixteen waves
+// share its tile's wave steps); then every layer's rectangle bound - the taps of (tcu * 126) columns x (2 * trp) written rows span that
+// many source texels times the magnification, + the patch's third column / row, + one for the rounding of the coordinates.
+uint32_t clip_up_plan(ClipUpArgs &c, bool rgb12, uint32_t num_cus) {
+  UpArgs &a = c.up;
+  if (!a.lines || !a.n || !num_cus) return 0;
+  const bool tails = a.out_w % 48u != 0;
+  a.jobs = 1;
+  a.out_qpitch = v210_pitch_bytes(a.out_w) / 16u;
+  a.cover_w = tails ? a.out_qpitch * 6u : a.out_w;
+  a.shared = 1;
+  for (int l = 1; l < a.n; ++l) {
+    a.shared = a.shared && a.layer[l].w == a.layer[0].w && a.layer[l].h == a.layer[0].h;
+    for (int k = 0; k < 6; ++k) a.shared = a.shared && a.layer[l].m[k] == a.layer[0].m[k];
+  }
+  const uint32_t upr = (a.cover_w + kUpCols - 1u) / kUpCols, rps = (a.lines + 1u) / 2u;
+  uint32_t best = ~0u, tcu = 0, trp = 0;
+  for (uint32_t cx = 1; cx <= 32u && cx <= upr && cx <= num_cus; cx *= 2u) {
+    const uint32_t ry = num_cus / cx < rps ? num_cus / cx : rps;
+    const uint32_t t_cu = (upr + cx - 1u) / cx, t_rp = (rps + ry - 1u) / ry;
+    // wave steps of the fullest workgroup, in rounds of its sixteen waves (what phase 2 takes), + its rectangle's rim (what phase 1 converts twice)
+    const uint32_t rounds = (t_cu * t_rp + kUpBlock / 64 - 1u) / (kUpBlock / 64);
+    const uint32_t cost = rounds * 1024u + t_cu + t_rp;
+    if (cost < best) best = cost, tcu = t_cu, trp = t_rp;
+  }
+  c.tcu = tcu, c.trp = trp, c.gx = (upr + tcu - 1u) / tcu;
+  const uint32_t grid = c.gx * ((rps + trp - 1u) / trp);
+  const uint32_t texel = rgb12 ? 12u : 16u;
+  uint32_t off = 0;
+  for (int l = 0; l < a.n; ++l) {
+    const UpLayer &L = a.layer[l];
+    const double sx = (double)L.m[0] * L.w / a.out_w, sy = (double)L.m[4] * L.h / a.out_h * a.line_step;
+    uint32_t rw = (uint32_t)((tcu * kUpCols - 1u) * sx) + 6u, rh = (uint32_t)((2u * trp - 1u) * sy) + 6u;
+    rw = rw < L.w ? rw : L.w, rh = rh < L.h ? rh : L.h;
+    c.rect_off[l] = off, c.rect_cap[l] = (rw * rh * texel + 255u) & ~255u;
+    off += c.rect_cap[l] + 256u;  // (+ a rim: dead lanes' patches read a few texels past a rectangle's last row)
+  }
+  c.wg_bytes = off;
+  const uint32_t lds = c.rd.bytes > a.wr.bytes ? c.rd.bytes : a.wr.bytes;
+  c.info_off = (lds + 15u) & ~15u;
+  if (c.info_off + 16u * (uint32_t)a.n > (uint32_t)kMaxDynamicLds) return 0;
+  return grid;
+}
+
+hipError_t launch_clip_up_write_v210(hipStream_t s, const ClipUpArgs &c, bool rgb12, uint32_t grid) {
+  if (!grid) return hipErrorInvalidValue;
+  if (trace_launch(rgb12 ? "clip_up_write_v210<rgb>" : "clip_up_write_v210<rgba>")) return hipSuccess;
+  const bool tails = c.up.out_w % 48u != 0;
+  const void *fn = tails ? (rgb12 ? reinterpret_cast<const void *>(clip_up_write_v210_kernel<true, true>) : reinterpret_cast<const void *>(clip_up_write_v210_kernel<false, true>))
+                         : (rgb12 ? reinterpret_cast<const void *>(clip_up_write_v210_kernel<true, false>) : reinterpret_cast<const void *>(clip_up_write_v210_kernel<false, false>));
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
+  if (e != hipSuccess) return e;
+  const uint32_t lds = c.info_off + 16u * (uint32_t)c.up.n;
+  if (tails && rgb12) clip_up_write_v210_kernel<true, true><<<grid, kUpBlock, lds, s>>>(c);
+  else if (tails) clip_up_write_v210_kernel<false, true><<<grid, kUpBlock, lds, s>>>(c);
+  else if (rgb12) clip_up_write_v210_kernel<true, false><<<grid, kUpBlock, lds, s>>>(c);
+  else clip_up_write_v210_kernel<false, false><<<grid, kUpBlock, lds, s>>>(c);
+  return hipGetLastError();
 }
 
 // Does the 2 x 2 block scheme apply?  Unrotated, unmirrored, MAGNIFIED in both directions (then the first taps of the two

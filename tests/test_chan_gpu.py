@@ -646,13 +646,15 @@ def test_chan_batch_random_calls():
 
 
 def both_routes(fn):
-    """run fn() with frames of enlarged clips made by read + 2 x 2-block compositor (the default) and by the channel kernel (option chan_enlarged = 0)"""
+    """run fn() with frames of enlarged clips made by every route there is: the one-launch form where it applies (clips in their wire formats:
+    reader + 2 x 2-block compositor in one kernel; the default), read + 2 x 2-block compositor as two launches (option chan_enlarged = 2), and
+    the channel kernel (chan_enlarged = 0)"""
     import hip_harness as hh
     k = hh.ctx()
     try:
-        for on in (1, 0):
+        for on, name in ((1, "one-launch reader + 2x2-block compositor (where it applies)"), (2, "read + 2x2-block compositor, two launches"), (0, "channel kernel")):
             k.set_option("chan_enlarged", on)
-            fn("read + 2x2-block compositor" if on else "channel kernel")
+            fn(name)
     finally:
         k.set_option("chan_enlarged", 1)
 

@@ -33,11 +33,11 @@ def route_of(layers, ow, oh, interlace=0):
 @pytest.mark.parametrize("cw,ch,name", [(1920, 1080, "f1"), (1280, 720, "f2")])
 def test_file_playback_as_benched(cw, ch, name):
     """f1: a 1080p yuv420p clip under the default fill on a 1080p50 channel; f2: a 720p yuv420p clip filling it - ph_chan_compose_v210 on the
-    decoder's planes with its own 8-bit Loader matrix, by the route the bench times (reader of the format + 2 x 2-block compositor)
-    and by the channel kernel (option chan_enlarged = 0)"""
+    decoder's planes with its own 8-bit Loader matrix, by the route the bench times (reader of the format + 2 x 2-block compositor in ONE launch),
+    by the same two as two launches (option chan_enlarged = 2) and by the channel kernel (chan_enlarged = 0)"""
     clip = frames.pack_random("yuv420p", cw, ch, 1300 + cw)
     layers = [dict(src=Src(clip, cw, ch, m(W, H), fmt="yuv420p"))]
-    assert route_of(layers, W, H) == "pack_read+compose_up_write_v210"
+    assert route_of(layers, W, H) == "clip_up_write_v210<rgb>"
     both_routes(lambda route: check(layers, W, H, "%s: %dx%d yuv420p on %dx%d by the %s" % (name, cw, ch, W, H, route)))
 
 

@@ -98,8 +98,12 @@ ROUTES = [
     ("a yuv422p10 clip under a placed yuv422p10 inset and an image", lambda: chan([clip("yuv422p10", 1920, 1080, 1920, 1080, scale_x=0.8, scale_y=0.8, rotate=0.05), clip("yuv422p10", 960, 540, 1920, 1080, **PIP[1]),
                                                                                     clip("rgba", 1920, 1080, 1920, 1080, rotate=0.01)], 1920, 1080), "chan_compose_v210<3,0>"),
     ("a bgra8 graphic over a v210 clip, both of the channel's size", lambda: chan([clip("v210", 1920, 1080, 1920, 1080), clip("bgra8", 1920, 1080, 1920, 1080)], 1920, 1080), "chan_compose_v210<5,0>"),
-    ("a 1080p yuv420p clip on a 1080p channel (a file's frame under the default fill)", lambda: chan([clip("yuv420p", 1920, 1080, 1920, 1080)], 1920, 1080), "pack_read+compose_up_write_v210"),
-    ("a 720p yuv420p clip filling a 1080p channel", lambda: chan([clip("yuv420p", 1280, 720, 1920, 1080)], 1920, 1080), "pack_read+compose_up_write_v210"),
+    ("a 1080p yuv420p clip on a 1080p channel (a file's frame under the default fill)", lambda: chan([clip("yuv420p", 1920, 1080, 1920, 1080)], 1920, 1080), "clip_up_write_v210<rgb>"),
+    ("a 720p yuv420p clip filling a 1080p channel", lambda: chan([clip("yuv420p", 1280, 720, 1920, 1080)], 1920, 1080), "clip_up_write_v210<rgb>"),
+    ("an enlarged bgra8 graphic (alpha travels with it)", lambda: chan([clip("bgra8", 1280, 720, 1920, 1080)], 1920, 1080), "clip_up_write_v210<rgba>"),
+    ("one 720p v210 clip on a 1080p channel (not faster in one launch: two)", lambda: chan([clip("v210", 1280, 720, 1920, 1080)], 1920, 1080), "v210_read_lds+compose_up_write_v210"),
+    ("a 720p yuv420p clip under a 1080p f32 image: the image is read as it is, so two launches", lambda: chan([clip("yuv420p", 1280, 720, 1920, 1080), clip("rgba", 1920, 1080, 1920, 1080)], 1920, 1080),
+     "pack_read+compose_up_write_v210"),
     ("two 720p v210 clips on a 1080p channel", lambda: chan([clip("v210", 1280, 720, 1920, 1080), clip("v210", 1280, 720, 1920, 1080, scale_x=0.8, scale_y=0.8)], 1920, 1080),
      "v210_read_lds_batch+compose_up_write_v210"),
     ("one live v210 clip under the default fill, alone", lambda: chan([clip("v210", 1920, 1080, 1920, 1080)], 1920, 1080), "chan_compose_v210<0,0>"),

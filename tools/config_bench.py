@@ -316,8 +316,9 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
         torch.cuda.synchronize()
         algo_f = cw * ch * 3 // 2 + capi.v210_pitch_bytes(fw) * fh
         current[0] = what
-        record(what, "ph_chan_compose_v210 on the decoder's planes: inside, [yuv420p -> f32 image] (ph_pack_read) + [transform + write] (ph_compose_up_write_v210), two launches", "frame",
-               timeit(lambda i: jobs[i % R](), reps), algo_f, 2, {"fmt_read_lds_kernel": 1.0, "compose_up_write_v210_kernel": 1.0},
+        record(what, "ph_chan_compose_v210 on the decoder's planes: inside, ONE launch - a workgroup converts the source pixels under its tile of the frame once each (the yuv420p reader) "
+               "into a scratch rectangle that stays in L2, swaps the writer's table in and composes from there (clip_up_write_v210_kernel)", "frame",
+               timeit(lambda i: jobs[i % R](), reps), algo_f, 1, {"clip_up_write_v210_kernel": 1.0},
                parity_test="tests/test_fullsize_gpu.py::test_file_playback_as_benched")
     # config 3 in the reference's own formats: 4 x 1080i50 -> yadif -> own size on a 1080p50 channel (src/config.ts:43-78), per output field
     isrc = [v210(fw, fh, 4) for _ in range(R)]

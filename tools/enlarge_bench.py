@@ -2,7 +2,8 @@
 """A clip smaller than its channel (the reference uploads clips at their own size and lets the Mixer's transform fill the channel:
 src/producer/ffmpegProducer.ts:395-442, mixer.ts:189-228): N v210 layers of sw x sh shown full-frame on an ow x oh channel, three routes:
   chan       ph_chan_compose_v210 on the v210 sources with context option chan_enlarged = 0: the channel kernel, every tap converted
-  routed     the same call as the product makes it (chan_enlarged = 1): read + 2 x 2-block compositor inside the call, scratch images
+  routed     the same call as the product makes it (chan_enlarged = 1): one frame of wire-format clips = reader + 2 x 2-block compositor in ONE launch
+  two_launch the same call with chan_enlarged = 2: read + 2 x 2-block compositor as two launches, scratch images (round 5's route)
   read+chan  ph_v210_read per layer (v210 -> f32 image, once per SOURCE pixel) + ph_chan_compose_v210 on the f32 images
   read+up    ph_v210_read per layer + ph_compose_up_write_v210 (the 2 x 2-block compositor on f32 images)
   python tools/enlarge_bench.py [reps] [layers] [sw] [sh] [ow] [oh]"""
@@ -58,7 +59,7 @@ def main():
         out[0] = outs[0]
     else:
         chan_jobs = [[ctx.chan_compose_v210([dict(src=(s[l], sw, sh, mats[l]) + kind) for l in range(n)], out[0], ow, oh, 0, *rd, *wr, prepare_only=True)] for s in src]
-    routes = {"chan": chan_jobs, "routed": chan_jobs}
+    routes = {"chan": chan_jobs, "routed": chan_jobs, "two_launch": chan_jobs}
     if C == 1 and packing == "v210":
         routes["read+chan"] = [[(lambda s=s, im=im: [ctx.v210_read(s[l], im[l], sw, sh, *rd) for l in range(n)]),
                                 ctx.chan_compose_v210([dict(src=(im[l], sw, sh, mats[l], "rgba")) for l in range(n)], out[1], ow, oh, 0, *rd, *wr, prepare_only=True)]
@@ -71,7 +72,7 @@ def main():
     if only:
         routes = {k: v for k, v in routes.items() if k in ("chan", only)}
     for name, jobs in routes.items():
-        ctx.set_option("chan_enlarged", 0 if name == "chan" else 1)
+        ctx.set_option("chan_enlarged", 0 if name == "chan" else 2 if name == "two_launch" else 1)
         i, t0 = 0, time.perf_counter()
         while i < 8 or time.perf_counter() - t0 < 0.15:
             for j in jobs[i % R]:
@@ -90,7 +91,11 @@ def main():
         res[name] = round(1e3 * e0.elapsed_time(e1) / reps / C, 2)
         if name == "chan":
             kept = out[0].clone()
-    same = {k: bool(torch.equal(kept, out[i])) for k, i in (("routed", 0), ("read+chan", 1), ("read+up", 2)) if k in res}
+        elif name == "routed":
+            same_routed = bool(torch.equal(kept, out[0]))
+    same = {k: bool(torch.equal(kept, out[i])) for k, i in (("two_launch", 0), ("read+chan", 1), ("read+up", 2)) if k in res}
+    if "routed" in res:
+        same["routed"] = same_routed
     print(json.dumps({"bench": "enlarge", "channels_per_call": C, "format": packing, "layers": n, "source": [sw, sh], "channel": [ow, oh], "us_per_frame": res, "same_frame_as_chan": same}), flush=True)
     ctx.close()
 
