@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--no-picture", action="store_true", help="skip the picture-content figure beside the headline (the `content_picture` field)")
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 2 and 3 (the `secondary` field)")
     ap.add_argument("--no-route", action="store_true", help="N > 1: skip BASELINE config 5 (the `route` field)")
     ap.add_argument("--no-traffic", action="store_true",
@@ -211,7 +212,7 @@ def measured_traffic(kernel_substring="fused_v210_combine", timeout_s=150):
     for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         out = tempfile.mkdtemp(prefix="ph_bench_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
-               os.path.abspath(__file__), "--steps", "24", "--warmup", "4", "--cpu-seconds", "0", "--no-secondary", "--no-traffic"]
+               os.path.abspath(__file__), "--steps", "24", "--warmup", "4", "--cpu-seconds", "0", "--no-secondary", "--no-traffic", "--no-picture"]
         env = dict(os.environ, PH_BENCH_FIXED_WARMUP="12", TMPDIR="/tmp")
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PH_BENCH_FORCE_DIST"):
             env.pop(k, None)
@@ -589,6 +590,34 @@ def main():
                         put_valu(detail["SQ_INSTS_VALU_mean"], "measured in this run: rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU (child pass of this script)")
                 else:
                     line["roofline"]["traffic_not_measured"] = detail
+            if not minimal and world == 1 and headline and args.content == "noise" and not args.no_picture:
+                # `value` is measured on independent uniform code values per sample - the worst case for tables in LDS (the 64 lanes of a wave hit
+                # random banks: two thirds of the LDS cycles are bank conflicts).  The same kernel on picture-like frames (gradients + a few codes
+                # of noise: neighbouring pixels look up neighbouring entries), measured here after the timed region, beside it:
+                try:
+                    pring = []
+                    for r in range(2):
+                        pins = [synth_v210(torch, w, h, 0x5EED7000 + 16 * r + l, device, "picture") for l in range(n)]
+                        pring.append(ctx.fused_v210_combine(pins, torch.empty(frame_words, dtype=torch.int32, device=device), w, h, *rd, *wr, prepare_only=True))
+                    torch.cuda.synchronize()
+                    for i in range(300):
+                        pring[i & 1]()
+                    sync()
+                    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    psteps = 1000
+                    p0.record(stream)
+                    for i in range(psteps):
+                        pring[i & 1]()
+                    p1.record(stream)
+                    sync()
+                    pms = p0.elapsed_time(p1) / psteps
+                    line["content_picture"] = {"frames_per_sec_by_kernel_time": round(1e3 / pms, 1), "avg_launch_ms": round(pms, 5),
+                                               "roofline_frac": round(algo_bytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": psteps,
+                                               "note": "the headline kernel on picture-like frames (bench.py --content picture), HIP events on its stream; "
+                                                       "`value` and `roofline.frac` stay the noise figures (worst case for the LDS tables)"}
+                    del pring
+                except Exception as e:
+                    line["content_picture"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if not minimal and world == 1 and not args.no_secondary and C == 1 and (w, h, n) == (WIDTH, HEIGHT, LAYERS):
                 # BASELINE configs 2 and 3 (the compositing configs: real alpha, transforms, de-interlace), fastest route of each,
                 # measured after the timed region; tools/config_bench.py prints every route

@@ -162,7 +162,33 @@ class Deferral {
 		this.pending.add(node)
 		this.stats.recorded++
 		if (program.name === 'write' && program.format !== undefined) this._noteTerminal(node)
-		return ZERO_TIMINGS()
+		// The job's RunTimings: zeros now (nothing has run).  The object is the job's own and is kept with it: on a `profile` context
+		// the launch that finally makes the frame is timed, and its device time is shared out over the jobs it stood in for - the
+		// reference keeps what runProgram returned and prints it after the batch has finished (clJobQueue.ts:121-138, 159-215)
+		node.timings = ZERO_TIMINGS()
+		return node.timings
+	}
+	// profile contexts (node/index.js _timedWrite): between begin and end every job that reaches the device - launched as recorded, or stood
+	// in for by a fused launch - is noted; end(us) shares the measured device time out over them by a rough weight of each operator's
+	// arithmetic, so that the rows of the reference's table are non-zero and sum to the launch's time
+	timedBegin() { this.timed = [] }
+	timedEnd(kernelExec, own) {
+		const jobs = this.timed || []
+		this.timed = null
+		const WEIGHT = { read: 3, write: 3, yadif: 4, transform: 2, resize: 2 } // (everything else - combine_N, transitions, mixer, wipe: 1)
+		const seen = new Set()
+		const list = []
+		for (const n of jobs) if (n.timings && !seen.has(n)) { seen.add(n); list.push(n) }
+		let total = 0
+		for (const n of list) total += WEIGHT[n.program.name] || 1
+		let left = kernelExec
+		list.forEach((n, i) => {
+			const share = i === list.length - 1 ? left : Math.floor(kernelExec * (WEIGHT[n.program.name] || 1) / total)
+			left -= share
+			n.timings.kernelExec = share
+			n.timings.totalTime = share
+		})
+		return own && seen.has(own) ? own.timings : null
 	}
 	_noteTerminal(node) {
 		if (this.terminals.length >= 32) this.terminals = this.terminals.filter((n) => n.state === 'pending')
@@ -402,6 +428,7 @@ class Deferral {
 			this._launch(node.program, node.params, node.queue)
 		} catch (e) { failure = e }
 		this.stats.plain++
+		if (this.timed && !failure) this.timed.push(node)
 		if (failure) for (const o of node.outs) o._failed = failure // whoever asks for them later is told, too
 		this._retire(node, failure ? 'error' : 'done')
 		if (failure) throw failure
@@ -500,6 +527,7 @@ class Deferral {
 			for (const e of g) {
 				this.fieldTwin.set(e.out[0], e.out[1])
 				this.fieldTwin.set(e.out[1], e.out[0])
+				if (this.timed) for (const y of e.nodes) this.timed.push(y)
 				for (const y of e.nodes) this._retire(y, 'done')
 			}
 		}
@@ -756,6 +784,7 @@ class Deferral {
 		return false
 	}
 	_done(plan, twin) {
+		if (this.timed) { for (const u of plan.used) this.timed.push(u); this.timed.push(plan.node) }
 		if (twin && twin.node.state === 'pending') { // the other field's frame came out of the same launch
 			this.stats.fusedNodes += 1 + (plan.n > 1 ? 1 : 0) + plan.n
 			this._retire(twin.node, 'done')

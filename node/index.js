@@ -268,11 +268,20 @@ class clContext {
 		const native = this._native
 		const t0 = process.hrtime.bigint()
 		const from = native.eventRecord(this._ctx, q, true)
-		this._deferral.touch(params.outputY || params.output, 'readonly', q) // runs the frame's chain (a failure rejects runProgram, as on a plain context)
-		const to = native.eventRecord(this._ctx, q, true)
-		await native.eventWait(to)
-		const kernelExec = native.eventElapsed(from, to)
-		return { dataToKernel: zeros.dataToKernel, kernelExec, totalTime: Number((process.hrtime.bigint() - t0) / 1000n) }
+		this._deferral.timedBegin()
+		let kernelExec = 0
+		try {
+			this._deferral.touch(params.outputY || params.output, 'readonly', q) // runs the frame's chain (a failure rejects runProgram, as on a plain context)
+			const to = native.eventRecord(this._ctx, q, true)
+			await native.eventWait(to)
+			kernelExec = native.eventElapsed(from, to)
+		} finally {
+			// the launch's device time over the jobs of the frame: each job's RunTimings object (handed out when it was recorded) gets its share
+			this._deferral.timedEnd(kernelExec, null)
+		}
+		// the write's own row: its share (zeros' object is the write job's), the host time of the whole call as totalTime
+		zeros.totalTime = Math.max(zeros.kernelExec, Number((process.hrtime.bigint() - t0) / 1000n))
+		return zeros
 	}
 
 	async waitFinish(queue) {

@@ -439,6 +439,21 @@ for (const moved of [false, true]) {
 		r4.d.touch(outs4[0], 'readonly', 2)
 		expect('a batch refused after two of its three frames: one more launch, for the third', [r4.names(), r4.d.stats.fallbacks, r4.d.stats.batched, (outs4.forEach((o) => r4.d.touch(o, 'readonly', 2)), r4.names().length)],
 			[['chan_compose_v210_1'], 1, 2, 1])
+		// profile contexts: the device time of the launch that makes a frame is shared out over the frame's jobs, into the RunTimings objects they
+		// were handed when they were recorded (clJobQueue.ts:121-138 keeps them, :159-215 prints them after the batch)
+		const r5 = rig({ early: true })
+		const L5 = r5.loader()
+		const m5 = r5.buffer(48, undefined, 'm')
+		const im5 = r5.image('u'), t5 = r5.image('t'), out5 = r5.v210('out')
+		const rows = [r5.d.record(r5.P.read, Object.assign({ input: r5.v210('s'), output: im5, width: r5.W }, L5), 1),
+			r5.d.record(r5.P.transform, { input: im5, transformMatrix: m5, output: t5 }, 1),
+			r5.d.record(r5.P.write, Object.assign({ input: t5, output: out5, width: r5.W, interlace: 0 }, r5.saver), 1)]
+		expect('recorded jobs report zeros until their frame has run', rows.map((t) => t.kernelExec), [0, 0, 0])
+		r5.d.timedBegin()
+		r5.d.touch(out5, 'readonly', 2)
+		r5.d.timedEnd(100, null)
+		expect('one fused launch of 100 us over read (3 parts), transform (2), write (3): every row non-zero, the rows sum to the launch',
+			[r5.names(), rows.map((t) => t.kernelExec)], [['chan_compose_v210_1'], [37, 25, 38]])
 		setImmediate(() => process.stdout.write(JSON.stringify({ checks, problems }) + '\n'))
 	})
 }

@@ -7,7 +7,7 @@
 //            way: one runPrograms call per tick, every frame through a batch launch, the same counters flat;
 //   fault    launches made to fail (context option fail_launches) while frame K's consumer maps its frame: that hostAccess rejects,
 //            every job callback has fired, the frames after it are the launch-as-posted context's bytes, nothing leaks;
-//   timings  `profile: true`: the terminal `write` of a frame returns the fused launch's device time, the jobs folded into it zeros.
+//   timings  `profile: true`: the fused launch's device time is shared out over the frame's jobs (every row non-zero, the rows sum to the launch).
 // usage: node soak_run.js [frames=100000] (PH_SOAK_ONLY=soak,channels,fault,timings picks phases); prints one JSON object { soak, channels, fault, timings, problems }
 const { Rig } = require('../device.js')
 
@@ -237,9 +237,13 @@ async function timings() {
 		t.push(await rig.run(c.combine(imgs, cm)))
 		const w = await rig.run(c.write(cm, c.ring[f % 3], 0))
 		;[...imgs, cm].forEach((b) => b.release())
-		got.push({ folded: t.map((x) => x.kernelExec), write: w })
-		if (t.some((x) => x.kernelExec !== 0)) problems.push({ timings: f, what: 'a job folded into the frame\'s launch reports a time of its own' })
-		if (!(w.kernelExec > 5 && w.kernelExec < 5000 && w.totalTime >= w.kernelExec)) problems.push({ timings: f, what: `the terminal write's RunTimings: ${JSON.stringify(w)}` })
+		// the frame reached the device as ONE launch when its write was posted: that launch's device time is shared out over the frame's six
+		// jobs (reads 3 parts each, combine 1, write 3), filled into the RunTimings objects the folded jobs were handed when they were recorded
+		const sum = t.reduce((a, x) => a + x.kernelExec, 0) + w.kernelExec
+		got.push({ folded: t.map((x) => x.kernelExec), write: w, sum })
+		if (t.some((x) => !(x.kernelExec > 0))) problems.push({ timings: f, what: `a job folded into the frame's launch has no share of its time: ${JSON.stringify(t)}` })
+		if (!(t[0].kernelExec === t[1].kernelExec && t[0].kernelExec >= 2 * t[4].kernelExec)) problems.push({ timings: f, what: `shares: reads alike, a read about three combines: ${JSON.stringify(t)}` })
+		if (!(sum > 5 && sum < 5000 && w.kernelExec > 0 && w.totalTime >= w.kernelExec)) problems.push({ timings: f, what: `the frame's rows must sum to the launch's device time: ${sum}, write ${JSON.stringify(w)}` })
 	}
 	const st = rig.ctx.deferredStats()
 	if (st.fused !== 4 || st.plain !== 0) problems.push({ timings: 'all', what: `fused ${st.fused}, plain ${st.plain}` })

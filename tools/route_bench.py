@@ -38,7 +38,10 @@ def parse(argv=None):
     ap.add_argument("--check", action="store_true", help="verify (bit for bit) that a routed layer is the source channel's output")
     ap.add_argument("--print-fingerprints", action="store_true", help="print a fingerprint of every channel's final v210 output")
     ap.add_argument("--loopback", action="store_true", help="send same-rank routes through RCCL too (peer = own rank)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.loopback:  # the one-device rehearsal of the hand-off always verifies what arrived (profiles/r05_route_loopback.jsonl said "not run")
+        args.check = True
+    return args
 
 
 def main():
