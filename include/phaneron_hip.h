@@ -38,7 +38,7 @@ extern "C" {
  * 7: additive over 6 - ph_chan_compose_batch (ph_chan_job): several channels' frames in one launch; ph_run_programs; ph_compose_up_write_v210_batch; ph_pack_read_batch;
  *    ph_event_record_timed / ph_event_elapsed_us; ph_ctx_host_pool_stats; "host_pool_mb" defaults to 4096 again and never
  *    keeps less than the working set
- * 8: additive over 7 - ph_trace_begin / ph_trace_end (which kernels made a frame; dry runs); ph_run_programs_progress; ph_buf_reuse */
+ * 8: additive over 7 - ph_trace_begin / ph_trace_end (which kernels made a frame; dry runs); ph_run_programs_progress; ph_buf_reuse; ph_image_unpack_rgb (program "rgb_unpack") */
 #define PH_ABI_VERSION 8
 
 enum {
@@ -315,6 +315,10 @@ int ph_yadif_pair_packed(ph_ctx *ctx, int queue, int n, const ph_deint_source *s
                          int tff, int skip_spatial, int out_format, const void *rd_col_matrix12, const void *rd_gamma_lut,
                          const void *rd_gamut_matrix9);
 
+/* Extension (no reference kernel): a packed f32 RGB image (12 bytes per pixel; PH_IMG_RGB_F32, what ph_v210_yadif_pair_fmt can write) expanded IN
+ * PLACE into the f32 RGBA image (alpha 1) its buffer is declared as - through the queue's scratch area.  Program name "rgb_unpack"
+ * (argument `image`).  For a binding that keeps de-interlaced fields packed while only ph_compose_up_write_v210 reads them. */
+int ph_image_unpack_rgb(ph_ctx *ctx, int queue, void *image, int w, int h);
 /* transform.ts:36-59 (matrix9: device pointer to the 3x3 row-major matrix) */
 int ph_transform(ph_ctx *ctx, int queue, const void *in, int in_w, int in_h, const void *matrix9,
                  void *out, int out_w, int out_h);

@@ -63,6 +63,7 @@ class Deferral {
 		this.launchedOn = new Map() // queue -> number of launches made on it
 		this.orderedAt = new Map() // `${waiter}<${signal}` -> the signal queue's launch count the waiter is ordered behind
 		this.stats = { recorded: 0, launched: 0, fused: 0, fusedNodes: 0, plain: 0, dropped: 0, fallbacks: 0, lastFallback: null }
+		this.packFields = process.env.PHANERON_PACK_FIELDS !== '0' // de-interlaced fields as packed RGB while only the compositor reads them (_deinterlace)
 		this.fieldTwin = new WeakMap() // a de-interlaced field image -> the other field of the same frame (set by the pair launch that made both)
 		// Terminal wire-format `write` jobs that are recorded and not launched yet.  When somebody asks for one of them, the others whose
 		// frames the same kernel can make in the same launch go with it (channels of one format in one context: src/index.ts:45-71).
@@ -92,6 +93,7 @@ class Deferral {
 		buf._producer = null // the pending node that will write it
 		buf._held = 0 // recorded nodes that hold it (ONE native reference stands for all of them: _hold)
 		buf._failed = null // the error of the job that should have produced it (ADVICE r3: every later consumer sees it, not only the first)
+		buf._packed = null // set: the image buffer holds PACKED f32 RGB (12 bytes per pixel) for now; the value is the queue its launch ran on (see _deinterlace)
 	}
 	// two parameter buffers that hold the same bytes (every producer's Loader makes its own LUT and matrices: loadSave.ts:50-99);
 	// the host mirror is what hostAccess wrote, its digest is dropped when the buffer is written again (touch)
@@ -153,6 +155,7 @@ class Deferral {
 		}
 		for (let k = 0; k < outs.length; ++k) {
 			const o = outs[k]
+			if (o._packed != null) { if (whole) o._packed = null; else this._unpack(o) } // (a job that fills part of it needs the real image under its part)
 			o._producer = node
 			o._failed = null
 			this._untwin(o) // (it is no longer the field image a pair launch made)
@@ -254,8 +257,9 @@ class Deferral {
 	// because they had not been made yet) are ordered in front of the access ON THE DEVICE.
 	touch(buf, dir, queue) {
 		Deferral.adopt(buf)
-		if (dir === 'readonly') this.force(buf)
+		if (dir === 'readonly') { this.force(buf); if (buf._packed != null) this._unpack(buf) } // (whoever reads it on the host or sends it away gets the image it is declared as)
 		else {
+			buf._packed = null
 			if (buf._digest) buf._digest = null
 			this._untwin(buf)
 			this.beforeWrite(buf)
@@ -356,6 +360,7 @@ class Deferral {
 				let v = params[k]
 				if (v === undefined || v === null) continue
 				if (k === 'colMatrix' || k === 'gammaLut' || k === 'gamutMatrix' || k === 'outColMatrix' || k === 'outGammaLut') v = first[k]
+				if (v && v._packed != null) this._unpack(v) // (a packed field image as a source of a batched frame: the real image first)
 				nm.push(k)
 				vs.push(Buffer.isBuffer(v) ? v._handle : typeof v === 'boolean' ? (v ? 1 : 0) : v)
 			}
@@ -396,6 +401,11 @@ class Deferral {
 			values.push(Buffer.isBuffer(v) ? v._handle : typeof v === 'boolean' ? (v ? 1 : 0) : v)
 		}
 		if (checkOnly) return this.ctx._native.runProgram(this.ctx._ctx, program._handle, names, values, queue, false, true)
+		// packed field images (see _deinterlace) are images to everybody but the 2 x 2-block compositor that was told so
+		for (let k = 0; k < names.length; ++k) {
+			const v = params[names[k]]
+			if (v && v._packed != null && !(params.packedRgb && /^l\d+In2?$/.test(names[k])) && program.name !== 'rgb_unpack') this._unpack(v)
+		}
 		this.stats.launched++
 		this.launchedOn.set(queue, (this.launchedOn.get(queue) || 0) + 1)
 		return this.ctx._native.runProgram(this.ctx._ctx, program._handle, names, values, queue, false)
@@ -417,6 +427,16 @@ class Deferral {
 			this.stats.lastFallback = `${program.name}: ${e && e.message || e}`
 			return false
 		}
+	}
+	// A de-interlaced field the pair launch wrote as packed f32 RGB into the application's RGBA image buffer (12 of its 16 bytes per
+	// pixel used) becomes the image it is declared as: in place, on the queue that made it (ph_image_unpack_rgb).  Only when somebody
+	// other than the 2 x 2-block compositor wants it - the host, a ROUTE, another kernel, a job run as recorded.
+	_unpack(buf) {
+		const queue = buf._packed
+		if (!buf.imageDims) { buf._packed = null; return }
+		this._launch(this._program('rgb_unpack', buf.imageDims.width, buf.imageDims.height), { image: buf }, queue) // (a failure leaves it marked: nobody takes packed pixels for an image)
+		buf._packed = null
+		this.stats.unpacked = (this.stats.unpacked || 0) + 1
 	}
 	_plain(node) {
 		let failure = null
@@ -458,7 +478,10 @@ class Deferral {
 	// window, for every such layer of the channel, is ONE launch of v210_yadif_pair_<k> on the v210 frames themselves
 	// (unpack + filter, both fields: ph_kernels_deint.hip), bit-identical to read x 3 -> yadif x 2.  Anything that does not
 	// fit (one field only, an image of the window already real, mixed sizes) is left to run as recorded.
-	_deinterlace(layerImages) {
+	// packed: the fields are written as packed f32 RGB (12 bytes per pixel: a v210 source's alpha is 1) into the application's RGBA image
+	// buffers - the caller has seen that the frame's every layer goes to the 2 x 2-block compositor, which reads 25 % less for it and drops
+	// the alpha arithmetic (the library's best route for 1080i sources: DESIGN.md section 5).  Anybody else who asks gets them unpacked.
+	_deinterlace(layerImages, packed) {
 		const found = new Map() // cur image -> { windows of wire-format sources, the two yadif nodes }
 		const PACKING = { v210: 0, yuv422p10: 1, yuv422p8: 2, yuv420p: 3, nv12: 4 } // SDI frames, or the planar frames of interlaced files (PH_FMT_*)
 		// the wire-format frame behind an image of the window: [planes], if it is a pending ToRGBA of `fmt` with the window's Loader recipe
@@ -513,6 +536,7 @@ class Deferral {
 			const e0 = g[0]
 			const params = Object.assign({ tff: e0.tff, skipSpatial: e0.skip }, e0.reader)
 			if (PACKING[e0.fmt]) params.packing = PACKING[e0.fmt]
+			if (packed) params.packedRgb = 1
 			g.forEach((e, i) => {
 				;['Prev', 'Cur', 'Next'].forEach((which, f) => {
 					params[`l${i}${which}`] = e.src[f][0]
@@ -527,6 +551,7 @@ class Deferral {
 			for (const e of g) {
 				this.fieldTwin.set(e.out[0], e.out[1])
 				this.fieldTwin.set(e.out[1], e.out[0])
+				if (packed) e.out[0]._packed = e.out[1]._packed = e0.nodes[0].queue
 				if (this.timed) for (const y of e.nodes) this.timed.push(y)
 				for (const y of e.nodes) this._retire(y, 'done')
 			}
@@ -609,7 +634,22 @@ class Deferral {
 			}
 		}
 		if (layerImages.length > 8) return null
-		this._deinterlace(layerImages)
+		// Will this frame be made by the 2 x 2-block compositor from de-interlaced fields alone?  Every layer [transform of] a pending yadif
+		// output, placed as that compositor takes it (decided from the matrices' host copies, as `enlarged` below): then the fields may
+		// be written packed.
+		const fieldLayer = (img) => {
+			const t = img._producer
+			if (!t || t.state !== 'pending' || t.program.name !== 'transform' || !t.params.input || !t.params.transformMatrix ||
+				t.program.globalWorkItems[0] !== width || t.program.globalWorkItems[1] !== height) return false
+			const f = t.params.input, y = f._producer, d = f.imageDims, mm = t.params.transformMatrix
+			if (!y || y.state !== 'pending' || y.program.name !== 'yadif' || !d || !Buffer.isBuffer(mm) || mm.length < 36 || mm._producer) return false
+			const q = new Float32Array(mm.buffer, mm.byteOffset, 9)
+			if (q[1] !== 0 || q[3] !== 0 || !(q[0] > 0) || !(q[4] > 0)) return false
+			if (!interlace && d.width === width && d.height === height && q[0] === 1 && q[4] === 1 && q[2] === 0 && q[5] === 0) return true
+			return q[0] * d.width <= 0.99 * width && q[4] * d.height * (interlace ? 2 : 1) <= 0.99 * height
+		}
+		const packFields = this.packFields && !outFmt && width % 2 === 0 && layerImages.every(fieldLayer)
+		this._deinterlace(layerImages, packFields)
 
 		// what each layer is made of.  The fused kernel applies ONE gamma table and gamut matrix (`reader`: a call is one colour
 		// space) and one YCbCr matrix to its v210 sources (`packedCm`); a planar source may bring a matrix of its own (the 8-bit
@@ -726,8 +766,16 @@ class Deferral {
 		}
 		if (!outFmt && !anyV210 && width % 2 === 0 && layers.every((l) => l.matrix && !l.transition && enlarged(l))) {
 			const params = Object.assign({ output, interlace }, saver)
-			layers.forEach((l, i) => { params[`l${i}In`] = l.source; params[`l${i}Matrix`] = l.matrix })
-			const twin = this._twinWrite(node, layers) // the frame's other field, recorded too: both in one launch
+			// packed field images: all of them, or none (the compositor takes one image format per launch)
+			const packedLayers = layers.every((l) => l.source._packed != null)
+			if (!packedLayers) for (const l of layers) if (l.source._packed != null) this._unpack(l.source)
+			if (packedLayers) params.packedRgb = 1
+			layers.forEach((l, i) => {
+				params[`l${i}In`] = l.source; params[`l${i}Matrix`] = l.matrix
+				if (packedLayers) { params[`l${i}Width`] = l.source.imageDims.width; params[`l${i}Height`] = l.source.imageDims.height }
+			})
+			let twin = this._twinWrite(node, layers) // the frame's other field, recorded too: both in one launch
+			if (twin && !twin.sources.every((im) => (im._packed != null) === packedLayers)) twin = null
 			if (twin) {
 				const both = Object.assign({ output2: twin.output }, params)
 				twin.sources.forEach((im, i) => { both[`l${i}In2`] = im })

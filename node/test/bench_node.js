@@ -128,7 +128,61 @@ async function channels(frames, w, h) {
 	const ring = []
 	for (let c = 0; c < C; ++c) ring.push([await rig.planes('v210', w, h, 'writeonly'), await rig.planes('v210', w, h, 'writeonly'), await rig.planes('v210', w, h, 'writeonly')])
 	const slotDone = []
-	const one = async (f) => {
+	// PH_NODE_BENCH_INTERLACED=1: the reference's own channel kind - 1080i sources (src/index.ts:45-71), each layer a Yadif window (yadif.ts:88-145,
+	// send_field: two fields per source frame), shown at its own size (the Mixer's default fill), combined and written: a TICK is a source frame =
+	// two output frames per channel.  The layers' v210 sources go round (the same four frames per layer; every tick one new ToRGBA per layer).
+	const interlaced = process.env.PH_NODE_BENCH_INTERLACED === '1'
+	const yadif = interlaced ? await rig.yadif(w, h) : null
+	const window = [] // per channel and layer: the three images of the Yadif window (prev, cur, next)
+	let ring2 = null
+	if (interlaced) {
+		ring2 = []
+		for (let c = 0; c < C; ++c) ring2.push([await rig.planes('v210', w, h, 'writeonly'), await rig.planes('v210', w, h, 'writeonly'), await rig.planes('v210', w, h, 'writeonly')])
+		for (let c = 0; c < C; ++c) {
+			window.push([])
+			for (let l = 0; l < n; ++l) {
+				const three = []
+				for (let i = 0; i < 3; ++i) { const im = await rig.image(w, h); rig.post({ source: `chan${c}`, timestamp: -1 }, read(src[(c + i) % C][l], im)); three.push(im) }
+				window[c].push(three)
+			}
+		}
+		for (let c = 0; c < C; ++c) await rig.board.flush({ source: `chan${c}`, timestamp: -1 })
+	}
+	const oneInterlaced = async (f) => {
+		const slot = f % 3
+		if (slotDone[slot] && !slotDone[slot].done()) await slotDone[slot].wait()
+		const ids = []
+		for (let c = 0; c < C; ++c) {
+			const id = { source: `chan${c}`, timestamp: f }
+			const gone = []
+			for (let l = 0; l < n; ++l) { // the window moves on: one new frame per layer
+				const im = await rig.image(w, h)
+				rig.post(id, read(src[(c + f) % C][l], im))
+				gone.push(window[c][l].shift())
+				window[c][l].push(im)
+			}
+			for (const second of [0, 1]) { // yadif.ts:104 parity = tff ^ !isSecond, tff = 1
+				const placed = []
+				for (let l = 0; l < n; ++l) {
+					const u = window[c][l]
+					const y = await rig.image(w, h)
+					rig.post(id, yadif(u[0], u[1], u[2], y, { parity: second ? 1 : 0, tff: 1, skipSpatial: 0 }))
+					const pl = await rig.image(w, h)
+					rig.post(id, transform(y, pl, mats[0]), () => y.release())
+					placed.push(pl)
+				}
+				const cm = await rig.image(w, h)
+				rig.post(id, combine(placed, cm), () => placed.forEach((b) => b.release()))
+				rig.post(id, write(cm, (second ? ring2 : ring)[c][slot], 0), () => cm.release())
+			}
+			ids.push(id)
+			gone.forEach((b) => b.release())
+		}
+		await Promise.all(ids.map((id) => rig.board.flush(id)))
+		for (let c = 0; c < C; ++c) { rig.ctx.realise(ring[c][slot][0]); rig.ctx.realise(ring2[c][slot][0]) }
+		slotDone[slot] = rig.ctx.recordEvent(rig.ctx.queue.process)
+	}
+	const one = interlaced ? oneInterlaced : async (f) => {
 		const slot = f % 3
 		if (slotDone[slot] && !slotDone[slot].done()) await slotDone[slot].wait()
 		const ids = []
@@ -164,14 +218,19 @@ async function channels(frames, w, h) {
 		slotDone[slot] = rig.ctx.recordEvent(rig.ctx.queue.process)
 	}
 	for (let f = 0; f < 10; ++f) await one(f)
+	// PH_NODE_BENCH_DRY=1: the library chooses its kernels but enqueues nothing (ph_trace_begin(dry)): what is left is the HOST's time per tick
+	const dry = process.env.PH_NODE_BENCH_DRY === '1'
+	if (dry) { await rig.ctx.drain(); rig.ctx._native.traceBegin(true) }
 	const t0 = process.hrtime.bigint()
-	for (let f = 0; f < frames; ++f) await one(10 + f)
+	for (let f = 0; f < frames; ++f) { await one(10 + f); if (dry && f % 50 === 49) { rig.ctx._native.traceEnd(); rig.ctx._native.traceBegin(true) } }
 	await rig.ctx.drain()
 	const sec = Number(process.hrtime.bigint() - t0) / 1e9
-	console.log(JSON.stringify({ bench: 'node', mode: 'channels', shape: file ? `file playback: one ${file[0]}x${file[1]} yuv420p clip under the default fill` : plain ? 'plain reads' : 'config 2', channels: C, early_launch: rig.ctx.earlyLaunch, width: w, height: h, layers: n, frames, channel_frames_per_sec: +(C * frames / sec).toFixed(1),
+	if (dry) rig.ctx._native.traceEnd()
+	console.log(JSON.stringify({ bench: 'node', mode: 'channels', host_only_dry_run: dry || undefined, shape: interlaced ? `${n} x 1080i sources -> yadif (send_field) -> own size -> combine_${n}: two output frames per tick` : file ? `file playback: one ${file[0]}x${file[1]} yuv420p clip under the default fill` : plain ? 'plain reads' : 'config 2', channels: C,
+		us_per_field: interlaced ? +(1e6 * sec / frames / C / 2).toFixed(1) : undefined, pack_fields: interlaced ? process.env.PHANERON_PACK_FIELDS !== '0' : undefined, early_launch: rig.ctx.earlyLaunch, width: w, height: h, layers: n, frames, channel_frames_per_sec: +(C * frames / sec).toFixed(1),
 		us_per_frame: +(1e6 * sec / frames / C).toFixed(1), us_per_tick: +(1e6 * sec / frames).toFixed(1), deferred: rig.ctx.deferredStats(),
 		buffers: rig.ctx.bufferStats() }))
-	;[...src.flat(2), ...ring.flat(2)].forEach((b) => b.release())
+	;[...src.flat(2), ...ring.flat(2), ...(ring2 ? ring2.flat(2) : []), ...window.flat(2)].forEach((b) => b.release())
 	rig.close()
 }
 main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })

@@ -191,6 +191,8 @@ function rig(opt) { // opt.early: frames are launched at the end of the posting 
 	r.d.touch(outs[0], 'readonly', 2)
 	expect('pair launch, then the tap-sharing compositor for BOTH fields of the frame in one launch (the other field\'s chain is recorded too)',
 		r.launches.map((l) => [l[0], /output2/.test(l[2]), /l0In2/.test(l[2])]), [['v210_yadif_pair_1', false, false], ['compose_up_write_v210_1', true, true]])
+	expect('the fields travel packed (12 bytes per pixel) between the two launches, and the compositor is told their size',
+		r.launches.map((l) => [/packedRgb/.test(l[2]), /l0Width,l0Height/.test(l[2])]), [[true, false], [true, true]])
 	r.d.touch(outs[1], 'readonly', 2)
 	expect('the second field has been made already', r.names().length, 2)
 	expect('nothing pending but the recipes of images their owners still hold', Array.from(r.d.pending).map((nd) => nd.program.name).sort(), ['read', 'read', 'read', 'transform', 'transform'])
@@ -229,12 +231,13 @@ for (const moved of [false, true]) {
 		r.d.record(r.P.write, Object.assign({ input: t, output: out, width: r.W, interlace: 0 }, r.saver), 1)
 		outs.push(out)
 	}
-	r.native.refuse = (name) => name !== 'write' && name !== 'transform' && name !== 'v210_yadif_pair_1'
+	r.native.refuse = (name) => name !== 'write' && name !== 'transform' && name !== 'v210_yadif_pair_1' && name !== 'rgb_unpack'
 	r.d.touch(outs[0], 'readonly', 2)
-	expect('refused fused launches: the jobs as recorded', r.names(), ['v210_yadif_pair_1', 'transform', 'write'])
+	// (the pair launch wrote the fields packed - the frame was the 2 x 2-block compositor's to make; when somebody else takes them they are unpacked first)
+	expect('refused fused launches: the field unpacked, then the jobs as recorded', r.names(), ['v210_yadif_pair_1', 'rgb_unpack', 'transform', 'write', 'rgb_unpack']) // (the last one: the other field's frame was tried along with this one)
 	expect('fallbacks counted: the pair form, the single form, the channel kernel - and the other field\'s frame, tried along with the one asked for, likewise', r.d.stats.fallbacks, 6)
 	r.d.touch(outs[1], 'readonly', 2)
-	expect('the other field: as recorded too', r.names().slice(3), ['transform', 'write'])
+	expect('the other field: as recorded too', r.names().slice(5), ['transform', 'write'])
 }
 
 // 6. a packed frame made on the device and read back (write -> read -> write): the fused launch reads `mid` itself, so the job

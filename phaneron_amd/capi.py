@@ -34,7 +34,7 @@ EXPORTS = [
     "ph_program_resolve", "ph_route_unique_id", "ph_route_init", "ph_route_destroy", "ph_route_group_begin",
     "ph_route_group_end", "ph_route_send", "ph_route_recv", "ph_route_after_queue", "ph_queue_after_route",
     "ph_route_wait", "ph_route_stream", "ph_route_comm_count", "ph_chan_compose_v210", "ph_chan_compose_batch", "ph_run_programs", "ph_event_record_timed", "ph_event_elapsed_us", "ph_ctx_host_pool_stats",
-    "ph_v210_yadif_pair_fmt", "ph_compose_up_write_v210", "ph_trace_begin", "ph_trace_end", "ph_run_programs_progress", "ph_buf_reuse",
+    "ph_v210_yadif_pair_fmt", "ph_compose_up_write_v210", "ph_trace_begin", "ph_trace_end", "ph_run_programs_progress", "ph_buf_reuse", "ph_image_unpack_rgb",
 ]
 
 
@@ -213,6 +213,7 @@ def lib():
         "ph_route_comm_count": (ci, [vp, C.POINTER(C.c_int)]),
         "ph_run_programs_progress": (ci, [C.POINTER(ci)]),
         "ph_buf_reuse": (ci, [vp]),
+        "ph_image_unpack_rgb": (ci, [vp, ci, vp, ci, ci]),
         "ph_trace_begin": (ci, [ci]),
         "ph_trace_end": (ci, [C.c_char_p, cs]),
     }

@@ -1717,6 +1717,11 @@ static int dispatch_image(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int
       if (prog->id == K_MIXER) return check_only ? PH_OK : ph_mixer(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
       return check_only ? PH_OK : ph_transition_dissolve(ctx, queue, a->dptr, b->dptr, (float)num, w, h, o->dptr);
     }
+    case K_RGB_UNPACK: {  // image: an f32 RGBA image buffer whose first width * height * 12 bytes hold packed f32 RGB - expanded in place
+      TRY(need_buf(args, n, "image", 0, &o));
+      TRY(need_image(o, "image", &w, &h));
+      return check_only ? PH_OK : ph_image_unpack_rgb(ctx, queue, o->dptr, w, h);
+    }
     case K_TWIPE: {
       TRY(need_buf(args, n, "output", 0, &o));
       TRY(need_image(o, "output", &w, &h));
@@ -1755,6 +1760,7 @@ static int dispatch(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, in
     case K_MIXER:
     case K_WIPE:
     case K_TWIPE:
+    case K_RGB_UNPACK:
       return dispatch_image(ctx, prog, args, n, queue, check_only);
   }
   return fail(PH_E_UNKNOWN_KERNEL, "unhandled kernel id");
@@ -2766,6 +2772,31 @@ int ph_yadif_pair_packed(ph_ctx *ctx, int queue, int n, const ph_deint_source *s
   a.rgb12 = out_format == PH_IMG_RGB_F32 ? 1u : 0u;
   a.cm = (const float *)cm, a.gm = (const float *)gm, a.lut = *v;
   PH_LAUNCH(ph::launch_v210_yadif_pair(stream_of(ctx, queue), a, tff ? 1 : 0, (uint32_t)ctx->props.multiProcessorCount));
+}
+
+/* A packed f32 RGB image (12 bytes per pixel, alpha == 1 implied: what ph_v210_yadif_pair_fmt writes with PH_IMG_RGB_F32) made the f32 RGBA
+ * image of the same pixels, IN PLACE: the packed pixels are copied to the queue's scratch area, then expanded back into the buffer.
+ * For a binding that lets the de-interlacing reader write packed fields into the application's RGBA image buffers while only the 2 x 2-block
+ * compositor reads them, and has to hand over a real image when anybody else asks (node/defer.js). */
+int ph_image_unpack_rgb(ph_ctx *ctx, int queue, void *image, int w, int h) {
+  if (!ctx || !image || w <= 0 || h <= 0) return fail(PH_E_INVALID, "ph_image_unpack_rgb: NULL/zero argument");
+  PH_QUEUE("ph_image_unpack_rgb", queue);
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  const size_t npx = (size_t)w * h;
+  if (ph::trace_launch("rgb_unpack")) return PH_OK;
+  std::lock_guard<std::mutex> scratch(ctx->chan_scratch_mu[queue]);  // until both operations are enqueued (launches on one queue are in order)
+  void *tmp;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    rc = chan_index_reserve(ctx, queue, npx * 12);
+    if (rc) return rc;
+    tmp = ctx->chan_index[queue];
+  }
+  PH_HIP(hipMemcpyAsync(tmp, image, npx * 12, hipMemcpyDeviceToDevice, stream_of(ctx, queue)));
+  hipError_t e = ph::launch_rgb_unpack(stream_of(ctx, queue), tmp, image, npx);
+  if (e != hipSuccess) return fail(PH_E_HIP, "ph_image_unpack_rgb: launch failed: %s", hipGetErrorString(e));
+  return PH_OK;
 }
 
 int ph_transform(ph_ctx *ctx, int queue, const void *in, int iw, int ih, const void *m9, void *out, int ow, int oh) {

@@ -268,5 +268,6 @@ hipError_t launch_combine(hipStream_t s, int n, const CombineArgs &a);
 hipError_t launch_dissolve(hipStream_t s, const void *in0, const void *in1, float mix, int w, int h, void *out);
 hipError_t launch_twipe(hipStream_t s, const void *in0, const void *in1, const void *mask, int w, int h, void *out);
 hipError_t launch_wipe(hipStream_t s, const void *in0, const void *in1, float wipe, int w, int h, void *out);
+hipError_t launch_rgb_unpack(hipStream_t s, const void *packed, void *rgba, size_t npx);
 
 }  // namespace ph

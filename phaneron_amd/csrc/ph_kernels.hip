@@ -575,6 +575,16 @@ hipError_t launch_twipe(hipStream_t s, const void *in0, const void *in1, const v
   return hipGetLastError();
 }
 
+// packed f32 RGB (12 bytes per pixel, alpha == 1 implied: the de-interlacing reader's field images) -> f32 RGBA; src and dst do not overlap
+__global__ __launch_bounds__(kBlock) void rgb_unpack_kernel(const float *__restrict__ src, float4 *__restrict__ dst, size_t npx) {
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < npx; p += (size_t)gridDim.x * kBlock)
+    dst[p] = make_float4(src[3 * p], src[3 * p + 1], src[3 * p + 2], 1.0f);
+}
+hipError_t launch_rgb_unpack(hipStream_t s, const void *packed, void *rgba, size_t npx) {
+  rgb_unpack_kernel<<<stream_grid(npx), kBlock, 0, s>>>((const float *)packed, (float4 *)rgba, npx);
+  return hipGetLastError();
+}
+
 hipError_t launch_wipe(hipStream_t s, const void *in0, const void *in1, float wipe, int w, int h, void *out) {
   wipe_kernel<<<stream_grid((size_t)w * h), kBlock, 0, s>>>((const float4 *)in0, (const float4 *)in1, wipe, w, h,
                                                            (float4 *)out, image_nt((size_t)w * h * 16));

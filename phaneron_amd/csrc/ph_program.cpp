@@ -203,6 +203,7 @@ int resolve_program(const char *src, const char *name, ProgramChoice &c, std::st
   if (0 == strcmp(name, "transition_wipe")) return set(c, K_TWIPE, name, how);
   if (0 == strcmp(name, "mixer")) return set(c, K_MIXER, name, how);
   if (0 == strcmp(name, "wipe")) return set(c, K_WIPE, name, how);
+  if (0 == strcmp(name, "rgb_unpack")) return set(c, K_RGB_UNPACK, name, how);
   err = std::string("unknown kernel '") + name + "'";
   return PH_E_UNKNOWN_KERNEL;
 }

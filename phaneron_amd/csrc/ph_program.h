@@ -23,6 +23,7 @@ enum KernelId {
   K_TWIPE,
   K_MIXER,
   K_WIPE,
+  K_RGB_UNPACK,       // extension: a packed f32 RGB image (12 bytes per pixel) made the f32 RGBA image its buffer is declared as, in place (ph_image_unpack_rgb)
   K_FUSED_V210  // extension: v210 x N -> read, combine_N, write in one launch (ph_fused_v210_combine)
 };
 
