@@ -500,6 +500,40 @@ async function main() {
 		return seen
 	}, { fused: 2, plain: 0, launched: 2, fallbacks: 0 })
 
+	// the same shape, and then the APPLICATION looks at a field itself (a preview, a ROUTE of the layer): the pair launch wrote the fields packed
+	// (12 bytes per pixel, only the compositor was going to read them) - whoever else asks gets the RGBA image the buffer is declared as
+	await scenario('de-interlaced layers, both fields composited, then a field image read by the application', async (s) => {
+		s.frame = 5
+		const u = []
+		const srcs = []
+		for (let i = 0; i < 3; ++i) {
+			const src = await s.source(v210Frame(half, 680 + i), W / 2, H / 2)
+			const im = await s.rig.image(W / 2, H / 2)
+			await s.rig.run(s.readHalf([src], im))
+			srcs.push(src)
+			u.push(im)
+		}
+		const fill = await s.transform.matrix({})
+		const outs = []
+		const fields = []
+		for (const second of [0, 1]) {
+			const y = await s.rig.image(W / 2, H / 2)
+			await s.rig.run(s.yadifHalf(u[0], u[1], u[2], y, { parity: second ? 1 : 0, tff: 1, skipSpatial: 0 }))
+			const im = await s.rig.image(W, H)
+			await s.rig.run(s.transform(y, im, fill))
+			fields.push(y) // (kept: the application will read them)
+			const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+			await s.rig.run(s.write(im, [out], 0))
+			im.release()
+			outs.push(out)
+		}
+		const seen = []
+		for (const out of outs) { seen.push(await s.consume(out)); out.release() }
+		for (const y of fields) { seen.push(await s.consume(y)); y.release() }
+		;[...srcs, ...u].forEach((x) => x.release())
+		return seen
+	}, { fused: 2, plain: 0, launched: 4, fallbacks: 0 }) // the pair launch, both compositors in one launch, two fields unpacked
+
 	// finished images only, one of them rotated: the tap-sharing compositor declines, the channel kernel takes them
 	await scenario('finished images, placed and rotated', async (s) => {
 		s.frame = 6

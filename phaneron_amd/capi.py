@@ -525,6 +525,10 @@ class Context:
             return job
         check(lib().ph_compose_up_write_v210(*args), self.h)
 
+    def image_unpack_rgb(self, image, width, height, queue=QUEUE_PROCESS):
+        """a packed f32 RGB image (12 bytes per pixel) expanded in place into the f32 RGBA image its buffer is sized for (ph_image_unpack_rgb)"""
+        check(lib().ph_image_unpack_rgb(self.h, queue, _ptr(image), width, height), self.h)
+
     def transform(self, src, in_w, in_h, matrix, dst, out_w, out_h, queue=QUEUE_PROCESS):
         check(lib().ph_transform(self.h, queue, _ptr(src), in_w, in_h, _ptr(matrix), _ptr(dst), out_w, out_h), self.h)
 

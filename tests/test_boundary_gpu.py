@@ -491,3 +491,24 @@ def test_host_mirror_pool_covers_the_working_set():
             b.release()
         st2 = ctx.host_pool_stats()
         assert st2["pooled"] <= 64 << 20 and st2["pins"] == 64 + 32, st2
+
+
+def test_packed_fields_unpack_in_place():
+    """ph_image_unpack_rgb (program "rgb_unpack"): the de-interlacing reader's packed-RGB fields written into RGBA-sized buffers and expanded in
+    place are, bit for bit, the RGBA fields the same launch writes directly (alpha 1) - what node/defer.js hands to anybody but the 2 x 2-block
+    compositor; at a size whose image does not fit the scratch area's first allocation, twice in a row (the scratch is reused)"""
+    import torch
+    import frames
+    import hip_harness as hh
+    k = hh.ctx()
+    rd = hh.ColourParams.reader("709", "2020")
+    for w, h in ((192, 54), (1920, 1080), (1920, 1080)):
+        win = [hh.dev(frames.v210_random(w, h, frames.layer_seed(1400 + w, t)).reshape(-1)) for t in range(3)]
+        rgba = [torch.zeros(w * h * 4, dtype=torch.float32, device="cuda") for _ in range(2)]
+        packed = [torch.full((w * h * 4,), 7.0, dtype=torch.float32, device="cuda") for _ in range(2)]
+        k.v210_yadif_pair([(win[0], win[1], win[2], rgba[0], rgba[1])], w, h, 1, False, *rd)
+        k.v210_yadif_pair([(win[0], win[1], win[2], packed[0], packed[1])], w, h, 1, False, *rd, rgb=True)
+        for p in packed:
+            k.image_unpack_rgb(p, w, h)
+        for a, b in zip(rgba, packed):
+            assert np.array_equal(hh.host(a).view(np.uint32), hh.host(b).view(np.uint32)), (w, h)
