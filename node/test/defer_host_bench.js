@@ -26,6 +26,8 @@ function standIn(calls) {
 		createProgram: (_ctx, _src, name) => { count('createProgram'); return { name } },
 		runProgram: (_ctx, _prog, _names, _values, _queue, _timed, checkOnly) => { count(checkOnly ? 'checkProgram' : 'runProgram'); return { dataToKernel: 0, kernelExec: 0, totalTime: 0 } },
 		queueWaitQueue: () => { count('queueWaitQueue') },
+		runPrograms: () => { count('runPrograms') },
+		runProgramsProgress: () => 0,
 		bufferStats: () => ({ liveBuffers: refs.size, liveBytes: 0, pooledBytes: 0 })
 	})
 	return fake

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that regenerates every measured artifact under profiles/ (written to
 # gpurun_out/profile/, copied into profiles/ afterwards).  usage: bash tools/profile_round.sh <tag>
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profile; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -133,6 +133,12 @@ $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
  PHANERON_EARLY_LAUNCH=1 PH_NODE_BENCH_CHANNELS=4 PH_NODE_BENCH_MODES=channels node $ROOT/node/test/bench_node.js 3000 1920 1080;
  for c in 1 4; do for e in 0 1; do PH_NODE_BENCH_PLAIN=1 PHANERON_EARLY_LAUNCH=$e PH_NODE_BENCH_CHANNELS=$c PH_NODE_BENCH_MODES=channels node $ROOT/node/test/bench_node.js 3000 1920 1080; done; done;
  for f in 1920x1080 1280x720; do for c in 1 4; do PH_NODE_BENCH_FILE=$f PH_NODE_BENCH_CHANNELS=$c PH_NODE_BENCH_MODES=channels node $ROOT/node/test/bench_node.js 3000 1920 1080; done; done) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_bench.jsonl
+# round 6: the reference's own channel kind through node (4 x 1080i sources per 1080p channel; fields packed or not; the host's share alone)
+(cd $ROOT && bash tools/r06_node_interlaced.sh) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_interlaced.jsonl
+# round 6: the matrix pipe priced (tools/mfma_probe.hip) and the one-launch clip kernel's phases (timing builds, if the snapshot brought them)
+[ -x $ROOT/tools/mfma_probe ] || hipcc --offload-arch=gfx950 -O3 -o $ROOT/tools/mfma_probe $ROOT/tools/mfma_probe.hip > /dev/null 2>&1
+$ROOT/tools/mfma_probe 2>/dev/null | grep -v '"probe": "step"' > $OUT/${TAG}_mfma_probe.jsonl
+[ -f $ROOT/tools/_variants/libphaneron_hip_clip6.so ] && (cd $ROOT && bash tools/r06_clip_ablate.sh) > $OUT/${TAG}_clip_ablate.txt 2>&1
 node $ROOT/node/test/soak_run.js 100000 2>/dev/null | grep '^{' > $OUT/${TAG}_node_soak.json
 (node $ROOT/node/test/napi_costs.js 1920 1080; node $ROOT/node/test/napi_costs.js 3840 2160; node $ROOT/node/test/defer_host_bench.js 20000; node $ROOT/node/test/defer_host_bench.js 20000 --plain) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_host_costs.jsonl
 # the recording context (node/defer.js) against the launch-as-posted one: scenarios, frames compared byte for byte, launch counters

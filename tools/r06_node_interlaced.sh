@@ -3,5 +3,5 @@ for c in 1 4; do for p in 1 0; do
  PHANERON_PACK_FIELDS=$p PH_NODE_BENCH_INTERLACED=1 PH_NODE_BENCH_CHANNELS=$c PH_NODE_BENCH_MODES=channels node node/test/bench_node.js 1500 1920 1080 2>&1 | tail -1
 done; done
 # the host's share alone (dry run: nothing enqueued)
-for c in 1 4; do PH_NODE_BENCH_DRY=1 PH_NODE_BENCH_INTERLACED=1 PH_NODE_BENCH_CHANNELS=$c PH_NODE_BENCH_MODES=channels node node/test/bench_node.js 1500 1920 1080 2>&1 | tail -1 | cut -c1-330; done
-PH_NODE_BENCH_DRY=1 PH_NODE_BENCH_CHANNELS=4 PH_NODE_BENCH_MODES=channels node node/test/bench_node.js 1500 1920 1080 2>&1 | tail -1 | cut -c1-330
+for c in 1 4; do PH_NODE_BENCH_DRY=1 PH_NODE_BENCH_INTERLACED=1 PH_NODE_BENCH_CHANNELS=$c PH_NODE_BENCH_MODES=channels node node/test/bench_node.js 1500 1920 1080 2>&1 | tail -1; done
+PH_NODE_BENCH_DRY=1 PH_NODE_BENCH_CHANNELS=4 PH_NODE_BENCH_MODES=channels node node/test/bench_node.js 1500 1920 1080 2>&1 | tail -1
