@@ -311,6 +311,7 @@ class Deferral {
 		const plans = []
 		let failure = null
 		try {
+			if (nodes.length > 2) this._deinterlaceAhead(nodes) // (two: the fields of one frame - their windows are one launch anyway)
 			for (const n of nodes) {
 				if (n.state !== 'pending') continue
 				let plan = null
@@ -602,7 +603,9 @@ class Deferral {
 	}
 	// what one fused launch would stand in for: null = the chain does not fold (or there is nothing to gain); else the candidates,
 	// best first, and the nodes they replace.  Making a layer real may launch other recorded jobs (never this write).
-	_plan(node) {
+	// A pending wire-format `write`'s frame, as far as its shape goes: the Writer's geometry against the image's, the output planes, the
+	// images of its layers ([combine_N of] whatever).  null: not a frame a fused launch could make.
+	_writeFrame(node) {
 		// FromRGBA with a Writer whose frame the channel kernel can make: v210 (SDI), yuv422p8 / yuv422p10 (an encoder), rgba8 / bgra8 (the screen)
 		const OUT = { v210: 0, yuv422p10: 1, yuv422p8: 2, yuv420p: 3, nv12: 4, rgba8: 5, bgra8: 6 }
 		if (node.program.name !== 'write' || OUT[node.program.format] === undefined) return null
@@ -635,7 +638,7 @@ class Deferral {
 		}
 		if (layerImages.length > 8) return null
 		// Will this frame be made by the 2 x 2-block compositor from de-interlaced fields alone?  Every layer [transform of] a pending yadif
-		// output, placed as that compositor takes it (decided from the matrices' host copies, as `enlarged` below): then the fields may
+		// output, placed as that compositor takes it (decided from the matrices' host copies, as `enlarged` in _plan): then the fields may
 		// be written packed.
 		const fieldLayer = (img) => {
 			const t = img._producer
@@ -649,6 +652,27 @@ class Deferral {
 			return q[0] * d.width <= 0.99 * width && q[4] * d.height * (interlace ? 2 : 1) <= 0.99 * height
 		}
 		const packFields = this.packFields && !outFmt && width % 2 === 0 && layerImages.every(fieldLayer)
+		return { outFmt, outRgb8, image, top, width, height, interlace, output, m, layerImages, packFields }
+	}
+	// The Yadif windows of ALL the frames about to be planned go to the device in shared launches (up to eight windows each): the reference's
+	// four channels are all 1080i (src/index.ts:45-71) - their windows of a tick in one or two launches of the de-interlacing reader
+	// instead of one per channel.  What each frame's own plan finds afterwards is the finished fields.
+	_deinterlaceAhead(nodes) {
+		const packed = []
+		const plain = []
+		for (const n of nodes) {
+			if (n.state !== 'pending') continue
+			let f = null
+			try { f = this._writeFrame(n) } catch (e) { f = null }
+			if (f) (f.packFields ? packed : plain).push(...f.layerImages)
+		}
+		if (packed.length) this._deinterlace(packed, true)
+		if (plain.length) this._deinterlace(plain, false)
+	}
+	_plan(node) {
+		const frame = this._writeFrame(node)
+		if (!frame) return null
+		const { outFmt, outRgb8, image, top, width, height, interlace, output, m, layerImages, packFields } = frame
 		this._deinterlace(layerImages, packFields)
 
 		// what each layer is made of.  The fused kernel applies ONE gamma table and gamut matrix (`reader`: a call is one colour

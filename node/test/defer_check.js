@@ -457,6 +457,28 @@ for (const moved of [false, true]) {
 		r5.d.timedEnd(100, null)
 		expect('one fused launch of 100 us over read (3 parts), transform (2), write (3): every row non-zero, the rows sum to the launch',
 			[r5.names(), rows.map((t) => t.kernelExec)], [['chan_compose_v210_1'], [37, 25, 38]])
-		setImmediate(() => process.stdout.write(JSON.stringify({ checks, problems }) + '\n'))
+		// two channels of 1080i sources posting their field pairs in one tick: their Yadif windows share ONE launch of the de-interlacing reader
+		// (the reference's four channels are all 1080i: src/index.ts:45-71), then each channel's two frames are one compositor launch
+		const r6 = rig({ early: true })
+		const L6 = r6.loader()
+		const m6 = r6.enlarging()
+		const outs6 = []
+		for (const ch of [0, 1]) {
+			const win = [0, 1, 2].map((i) => { const im = r6.image(`c${ch}w${i}`); r6.d.record(r6.P.read, Object.assign({ input: r6.v210(`c${ch}s${i}`), output: im, width: r6.W }, L6), 1); return im })
+			for (const parity of [0, 1]) {
+				const y = r6.image(`c${ch}y${parity}`)
+				r6.d.record(r6.P.yadif, { prev: win[0], cur: win[1], next: win[2], parity, tff: 1, skipSpatial: 0, output: y }, 1)
+				const t = r6.image(`c${ch}t${parity}`)
+				r6.d.record(r6.P.transform, { input: y, transformMatrix: m6, output: t }, 1)
+				const out = r6.v210(`c${ch}out${parity}`)
+				r6.d.record(r6.P.write, Object.assign({ input: t, output: out, width: r6.W, interlace: 0 }, r6.saver), 1)
+				outs6.push(out)
+			}
+		}
+		setImmediate(() => {
+			expect('two 1080i channels in one tick: one reader launch for both windows, one compositor launch per channel (both fields)',
+				r6.names(), ['v210_yadif_pair_2', 'compose_up_write_v210_1', 'compose_up_write_v210_1'])
+			process.stdout.write(JSON.stringify({ checks, problems }) + '\n')
+		})
 	})
 }

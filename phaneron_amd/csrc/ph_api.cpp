@@ -2233,7 +2233,7 @@ static int chan_index_reserve(ph_ctx *ctx, int queue, size_t need) {
 static int chan_batch_launch(ph_ctx *ctx, int queue, ph::ChanBatchArgs &b, const ph::ChanArgs &g) {
   b.out_w = g.out_w, b.out_h = g.out_h, b.lines = g.lines, b.line_step = g.line_step;
   b.rd_cm = g.rd_cm, b.rd_gm = g.rd_gm, b.wr_cm = g.wr_cm, b.rd = g.rd, b.wr = g.wr;
-  b.tails = g.planar >= 1 ? 1u : 0u, b.out_qpitch = g.out_qpitch, b.out_tail_from = g.out_tail_from;
+  b.tails = g.planar >= 1 ? 1u : 0u, b.planar = g.planar == 2 ? 1u : 0u, b.out_qpitch = g.out_qpitch, b.out_tail_from = g.out_tail_from;
   const size_t each = (ph::chan_index_bytes(g.out_w, g.lines) + 255u) & ~(size_t)255u;
   std::lock_guard<std::mutex> scratch(ctx->chan_scratch_mu[queue]);
   {
@@ -2549,14 +2549,12 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
   // two is a poor one): by the jobs and ops of the call as a whole - a plan, the limits below still hold for every launch
   uint32_t plan_jobs = 0, plan_ops = 0;
   for (int j = 0; j < n_jobs; ++j) {
-    bool wire = false;  // planar / packed-RGB sources: not for the batch kernel
-    uint32_t ops = 0;
+    uint32_t ops = 0;  // (planar / packed-RGB sources share launches too since round 6: the batch kernel's PLANAR instantiation)
     for (int l = 0; l < jobs[j].n; ++l) {
       const ph_chan_layer &L = jobs[j].layers[l];
       ops += L.transition == PH_TRANSITION_WIPE ? 3u : L.transition == PH_TRANSITION_DISSOLVE ? 2u : 1u;
-      wire = wire || L.src.format > PH_SRC_RGBA_F32 || L.incoming.format > PH_SRC_RGBA_F32 || L.mask.format > PH_SRC_RGBA_F32;
     }
-    if (!wire && ops <= (uint32_t)ph::kMaxChanBatchOps && !(ctx->chan_enlarged && chan_layers_enlarged(jobs[j].n, jobs[j].layers, out_w, out_h, jobs[j].interlace)))
+    if (ops <= (uint32_t)ph::kMaxChanBatchOps && !(ctx->chan_enlarged && chan_layers_enlarged(jobs[j].n, jobs[j].layers, out_w, out_h, jobs[j].interlace)))
       ++plan_jobs, plan_ops += ops;
   }
   const uint32_t by_jobs = (plan_jobs + (uint32_t)ph::kMaxChanJobs - 1u) / (uint32_t)ph::kMaxChanJobs;
@@ -2621,7 +2619,32 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
       continue;
     }
     if ((rc = flush_enlarged())) return rc;
-    if (one.planar == 2 || k > ph::kMaxChanBatchOps || fit < 1 || !lines) {  // not for the batch kernel: in its turn, on its own
+    // a planar job's Loader matrices as indices into the launch's small table (those already there are found again)
+    uint8_t cm_of[ph::kMaxChanOps];
+    const float *cm_new[8];
+    int n_cm_new = 0;
+    bool cm_fits = true;
+    auto cm_known = [&](const float *cm) -> int {  // 1 .. 8, or 0
+      for (uint32_t t = 0; t < 8 && b.cm_tab[t]; ++t)
+        if (b.cm_tab[t] == cm) return (int)t + 1;
+      return 0;
+    };
+    uint32_t tab_used = 0;
+    while (tab_used < 8 && b.cm_tab[tab_used]) ++tab_used;
+    for (int i = 0; i < k && one.planar == 2; ++i) {
+      cm_of[i] = 0;
+      const float *cm = one.cm_op[i];
+      if (!cm || cm == (const float *)rd_cm) continue;
+      int at = cm_known(cm);
+      for (int t = 0; t < n_cm_new && !at; ++t)
+        if (cm_new[t] == cm) at = (int)tab_used + t + 1;
+      if (!at) {
+        if (tab_used + (uint32_t)n_cm_new >= 8u) { cm_fits = false; break; }
+        cm_new[n_cm_new] = cm, at = (int)tab_used + (++n_cm_new);
+      }
+      cm_of[i] = (uint8_t)at;
+    }
+    if ((one.planar == 2 && !cm_fits) || k > ph::kMaxChanBatchOps || fit < 1 || !lines) {  // not for the batch kernel: in its turn, on its own
       if ((rc = flush())) return rc;
       if ((rc = ph_chan_compose_v210(ctx, queue, J.n, J.layers, J.out, out_w, out_h, J.interlace, rd_cm, rd_lut, rd_gm, wr_cm, wr_lut))) return rc;
       continue;
@@ -2637,6 +2660,27 @@ int ph_chan_compose_batch(ph_ctx *ctx, int queue, int n_jobs, const ph_chan_job 
     ph::ChanJob &jb = b.job[b.jobs];
     jb.out = J.out, jb.first_op = b.n_ops, jb.n_ops = (uint32_t)k, jb.first_line = J.interlace == 3 ? 1u : 0u;
     for (int i = 0; i < k; ++i) b.op[b.n_ops + i] = one.op[i], b.op_job[b.n_ops + i] = (uint8_t)b.jobs;
+    if (one.planar == 2) {
+      // (a flush above has emptied the launch: the table then starts again - indices made against the old one are made again)
+      if (!b.cm_tab[0] && tab_used) {
+        int renum = 0;
+        for (int i = 0; i < k; ++i)
+          if (cm_of[i]) {
+            const float *cm = one.cm_op[i];
+            int at = 0;
+            for (int t = 0; t < renum && !at; ++t)
+              if (b.cm_tab[t] == cm) at = t + 1;
+            if (!at) b.cm_tab[renum] = cm, at = ++renum;
+            cm_of[i] = (uint8_t)at;
+          }
+      } else {
+        for (int t = 0; t < n_cm_new; ++t) b.cm_tab[tab_used + (uint32_t)t] = cm_new[t];
+      }
+      for (int i = 0; i < k; ++i) {
+        b.plane_u[b.n_ops + i] = one.plane_u[i], b.plane_v[b.n_ops + i] = one.plane_v[i], b.cm_idx[b.n_ops + i] = cm_of[i];
+        b.any_cm |= cm_of[i] ? 1u : 0u;
+      }
+    }
     b.n_ops += (uint32_t)k, ++b.jobs;
   }
   if ((rc = flush_enlarged())) return rc;

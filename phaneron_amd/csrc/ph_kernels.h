@@ -117,7 +117,7 @@ struct ChanArgs {
 // Several channels' frames of ONE geometry and colour recipe in one launch (ph_chan_compose_batch) - what the reference runs: four
 // channels of <= 1080p in one context through one queue (src/index.ts:45-71,156-160, clJobQueue.ts:114-141).  A workgroup takes its
 // share of EVERY job, so the tables are loaded once and the wave steps of all jobs together are dealt to the waves in front of one
-// barrier (ph_kernels_chan.hip).  v210 / f32 image sources, v210 out.
+// barrier (ph_kernels_chan.hip).  Any source kind (round 6: planar / packed-RGB ones in an instantiation of their own), v210 out.
 constexpr int kMaxChanJobs = 8;
 constexpr int kMaxChanBatchOps = 40;  // the ops of all jobs of a launch (the argument block has to stay below 4 KiB)
 struct ChanJob {
@@ -142,6 +142,14 @@ struct ChanBatchArgs {
   uint32_t sched_off;              // LDS byte offset of the jobs' tables behind the gamma table
   uint32_t halo_off, halo_steps;   // as ChanArgs; halo_steps = steps
   uint32_t images_only;            // as ChanArgs: every source of every job is an f32 image - the reader's table is not loaded
+  // round 6: jobs with planar / packed-RGB sources (file playback with insets, graphics over clips) share launches too - the PLANAR
+  // instantiation.  An op's chroma planes, and its Loader matrix as an index into a small table (0: the call's rd_cm; the argument
+  // block has 4 KiB: forty pointers more would not fit)
+  const void *plane_u[kMaxChanBatchOps], *plane_v[kMaxChanBatchOps];
+  const float *cm_tab[8];
+  uint8_t cm_idx[kMaxChanBatchOps];
+  uint32_t planar;                 // 1: some op has a planar / packed-RGB source (launcher: the PLANAR instantiation)
+  uint32_t any_cm;                 // some op brings a Loader matrix of its own: the general dot products throughout (as ChanArgs)
 };
 static_assert(sizeof(ChanBatchArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 // refuses (hipErrorInvalidValue) more than kMaxChanJobs jobs / kMaxChanBatchOps ops: callers split

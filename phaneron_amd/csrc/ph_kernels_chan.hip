@@ -1101,7 +1101,7 @@ __device__ __forceinline__ void chan_halo_pass_batch(const ChanBatchArgs &a, con
   }
 }
 
-template <bool STD, bool TAILS>
+template <bool STD, bool TAILS, bool PLANAR = false>
 __device__ __forceinline__ void chan_phase1_batch(const ChanBatchArgs &a, const ChanShare &sh, const ReadK &rk, const LutK &rlut) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t S = a.steps, total = a.jobs * S;  // S: the most wave steps any workgroup has per job (a step beyond this workgroup's own has no chunk)
@@ -1154,7 +1154,19 @@ __device__ __forceinline__ void chan_phase1_batch(const ChanBatchArgs &a, const 
       ChanHalo halo{false, 0u};
       if ((op.action & kChanActShare) && n < a.halo_steps)  // uniform
         halo = ChanHalo{true, a.halo_off + (((op.action >> kChanActShareShift) & 7u) * a.halo_steps + n) * 36u};
-      chan_sample<STD, TAILS>(op.src, px, py, x, line, rk, rlut, v, halo);
+      // PLANAR: a decoder's planes / a packed-RGB graphic among the sources - the one-job kernel's "everything" sampling (chan_phase1, SRC == 1)
+      if (PLANAR && op.src.kind >= kChanRgba8) {  // uniform
+        chan_sample_rgb8<false>(op.src, px, py, x, line, rk, rlut, v, ChanHalo{false, 0u}, 0u);
+      } else if (PLANAR && op.src.kind >= kChanP10) {
+        if (STD) {
+          chan_sample_planar<true, false>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, rk, rlut, v, ChanHalo{false, 0u});
+        } else {
+          const uint32_t ci = a.cm_idx[k];
+          chan_sample_planar<false, false>(op.src, a.plane_u[k], a.plane_v[k], px, py, x, line, load_read_k(ci ? a.cm_tab[ci - 1u] : a.rd_cm, a.rd_gm), rlut, v, ChanHalo{false, 0u});
+        }
+      } else {
+        chan_sample<STD, TAILS>(op.src, px, py, x, line, rk, rlut, v, halo);
+      }
 #pragma unroll
       for (int p = 0; p < kChanP; ++p) chan_apply(op, v[p], acc[p]);
     }
@@ -1170,7 +1182,7 @@ __device__ __forceinline__ void chan_phase1_batch(const ChanBatchArgs &a, const 
   }
 }
 
-template <bool TAILS>
+template <bool TAILS, bool PLANAR = false>
 __global__ __launch_bounds__(kLdsBlock) void chan_compose_batch_kernel(ChanBatchArgs a) {
   const ReadK rk = load_read_k(a.rd_cm, a.rd_gm);
   const LutK rlut = make_lut_k(a.rd);
@@ -1205,16 +1217,16 @@ __global__ __launch_bounds__(kLdsBlock) void chan_compose_batch_kernel(ChanBatch
   if (touched == 0x9E3779B9u && a.jobs == 0xFFFFFFFFu) reinterpret_cast<uint32_t *>(g_lds + a.sched_off)[3] = touched;  // (never: keeps the loads above)
   __syncthreads();
   PH_CPHASE(1);
-  if (ycbcr_matrix_is_standard(rk)) {
+  if (ycbcr_matrix_is_standard(rk) && !(PLANAR && a.any_cm)) {
     chan_halo_pass_batch<true, TAILS>(a, sh, rk, rlut);
     __syncthreads();
     PH_CPHASE(6);
-    chan_phase1_batch<true, TAILS>(a, sh, rk, rlut);
+    chan_phase1_batch<true, TAILS, PLANAR>(a, sh, rk, rlut);
   } else {
     chan_halo_pass_batch<false, TAILS>(a, sh, rk, rlut);
     __syncthreads();
     PH_CPHASE(6);
-    chan_phase1_batch<false, TAILS>(a, sh, rk, rlut);
+    chan_phase1_batch<false, TAILS, PLANAR>(a, sh, rk, rlut);
   }
   PH_CPHASE(2);
   __syncthreads();
@@ -1325,14 +1337,14 @@ hipError_t launch_chan_compose_batch(hipStream_t s, const ChanBatchArgs &a, uint
   const uint32_t lds_total = b.halo_off + b.n_share * steps * 36u;
   auto go = [&](auto kernel) -> hipError_t {
     char name[48];
-    snprintf(name, sizeof name, "chan_compose_batch<%u>x%u", a.tails ? 1u : 0u, a.jobs);  // (route trace: the instantiation and the jobs sharing it)
+    snprintf(name, sizeof name, "chan_compose_batch<%u>x%u", a.planar ? 2u : a.tails ? 1u : 0u, a.jobs);  // (route trace: the instantiation - 0 whole blocks, 1 line tails, 2 planar sources - and the jobs sharing it)
     if (trace_launch(name)) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
     if (e != hipSuccess) return e;
     kernel<<<grid, kLdsBlock, lds_total, s>>>(b);
     return hipGetLastError();
   };
-  return a.tails ? go(chan_compose_batch_kernel<true>) : go(chan_compose_batch_kernel<false>);
+  return a.planar ? go(chan_compose_batch_kernel<true, true>) : a.tails ? go(chan_compose_batch_kernel<true>) : go(chan_compose_batch_kernel<false>);
 }
 
 size_t chan_index_bytes(uint32_t out_w, uint32_t lines) { return (size_t)out_w * lines * 8u + 64u; }  // + a tail quad's reach past the last line

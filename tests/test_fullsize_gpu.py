@@ -129,3 +129,29 @@ def test_four_720p_channels_in_one_launch_full_size():
     from test_chan_gpu import pip_layers
     w, h = 1280, 720
     check_batch([(pip_layers(w, h, 1370 + c), 0, c) for c in range(4)], w, h, "four 1280x720 channels in one launch")
+
+
+def test_four_channels_of_file_playback_with_an_inset_in_one_launch_full_size():
+    """round 6: jobs with planar sources share the batch kernel's launches (its PLANAR instantiation).  Four channels each playing a 1080p
+    yuv422p10 file with a quarter-size yuv420p inset (its own 8-bit Loader matrix), a fifth with a bgra8 graphic over a v210 clip and a
+    sixth of v210 layers only, in ONE call: every frame against the oracle's chain and against its own single call"""
+    import hip_harness as hh
+    from phaneron_amd import capi
+    jobs = []
+    for c in range(4):
+        full = frames.pack_random("yuv422p10", W, H, 1380 + c)
+        inset = frames.pack_random("yuv420p", 960, 540, 1390 + c)
+        jobs.append(([dict(src=Src(full, W, H, m(W, H), fmt="yuv422p10")), dict(src=Src(inset, 960, 540, m(W, H, **PIP[1 + c % 3]), fmt="yuv420p"))], 0, c))
+    g = frames.pack_random("bgra8", W, H, 1395)
+    jobs.append(([dict(src=Src(frames.v210_random(W, H, frames.layer_seed(1396, 0)), W, H, m(W, H, offset_x=0.3 / W))), dict(src=Src(g, W, H, m(W, H, offset_x=0.3 / W), fmt="bgra8"))], 0, 4))
+    from test_chan_gpu import pip_layers
+    jobs.append((pip_layers(W, H, 1397), 0, 5))
+    # the route first (a dry run): one launch of the planar instantiation for all six
+    import torch
+    from test_chan_gpu import device_layers
+    _, _, rd_d, wr_d = colour("709", "709")
+    outs = [torch.zeros(frames.v210_pitch_bytes(W) * H // 4, dtype=torch.int32, device="cuda") for _ in jobs]
+    with capi.trace(dry_run=True) as t:
+        hh.ctx().chan_compose_batch([(device_layers(l), o, il) for (l, il, _), o in zip(jobs, outs)], W, H, *rd_d, *wr_d)
+    assert t.route == "chan_compose_batch<2>x6", t.route
+    check_batch(jobs, W, H, "four channels of file playback with an inset, a graphic over a clip, a v210 channel: one launch")

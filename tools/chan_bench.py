@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 2 through ph_chan_compose_v210 alone (one launch per frame): the timing loop tools/pmc_kernel.sh profiles.
-  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets|overlay] [sources: v210|yuv422p10|yuv422p8|yuv420p|nv12]
+  python tools/chan_bench.py [reps] [mask: rgba|v210] [variant: wipe|nowipe|layer0|insets|inset|overlay] [sources: v210|yuv422p10|yuv422p8|yuv420p|nv12]
   PH_CHAN_BENCH_JOBS=C: C channels' frames per call of ph_chan_compose_batch (PH_CHAN_BATCH=0: the same call, every job through the
   one-job kernel - the A/B of round 5); PH_CHAN_BENCH_W / _H: another frame size"""
 import json
@@ -67,6 +67,8 @@ def main():
             ls = ls[:1]
         elif variant == "insets":
             ls = ls[1:]
+        elif variant == "inset":  # file playback with one inset: the full-frame clip and a quarter-size one
+            ls = ls[:2]
         elif variant == "overlay":  # a clip under a full-frame graphic with alpha (a bgra8 frame: png / html overlays come as packed RGB)
             ls = [ls[0], dict(src=(overlay, w, h, mats[0], "bgra8"))]
         return ls
