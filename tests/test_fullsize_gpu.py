@@ -155,3 +155,39 @@ def test_four_channels_of_file_playback_with_an_inset_in_one_launch_full_size():
         hh.ctx().chan_compose_batch([(device_layers(l), o, il) for (l, il, _), o in zip(jobs, outs)], W, H, *rd_d, *wr_d)
     assert t.route == "chan_compose_batch<2>x6", t.route
     check_batch(jobs, W, H, "four channels of file playback with an inset, a graphic over a clip, a v210 channel: one launch")
+
+
+def test_one_launch_decoder_frames_random_shapes():
+    """clip_up_write_v210_kernel (a decoder's frame in one launch) on seeded random shapes: clip and channel sizes around the kernel's units (126-column
+    wave steps, row pairs, tiles that end mid-frame, channels narrower than one step, lines with tails), placements that push the clip partly
+    off screen or leave a border, every planar / packed-RGB format, progressive and both fields - each against the oracle's chain, and the route
+    checked to be the one-launch kernel (PH_FUZZ_SEED / PH_FUZZ_CASES: longer campaigns by hand)"""
+    import os
+    r = np.random.default_rng(int(os.environ.get("PH_FUZZ_SEED", "20261002")))
+    fmts = ["yuv420p", "yuv422p10", "yuv422p8", "nv12", "rgba8", "bgra8"]
+    outs = [(126, 8), (128, 10), (252, 6), (384, 54), (640, 36), (1280, 24), (1290, 14), (50, 4), (1920, 40), (2520, 12)]
+    cases, ran = int(os.environ.get("PH_FUZZ_CASES", "40")), 0
+    for case in range(cases):
+        ow, oh = outs[case % len(outs)]
+        fmt = fmts[int(r.integers(0, len(fmts)))]
+        interlace = int(r.choice([0, 0, 1, 3])) if oh % 2 == 0 else 0
+        # a clip no larger than the channel, enlarged by its placement (scale >= 1 / 0.98 per written row) or of the channel's size under the default fill
+        if r.random() < 0.25 and not interlace:
+            sw, sh, kw = ow, oh, dict()
+        else:
+            sw = max(2, int(ow * r.uniform(0.2, 0.9)) // 2 * 2)
+            sh = max(2, int(oh * r.uniform(0.2, 0.9) / (2 if interlace else 1)) // 2 * 2)
+            kw = dict(scale_x=float(r.choice([1.0, 0.8, 0.6])), scale_y=float(r.choice([1.0, 0.8, 0.6])), offset_x=float(r.uniform(-0.3, 0.3)), offset_y=float(r.uniform(-0.3, 0.3)))
+        if fmt in ("yuv420p", "nv12"):
+            sh += sh & 1
+        if ow % 2 or sw % 2:
+            continue
+        clip = frames.pack_random(fmt, sw, sh, 5000 + case)
+        layers = [dict(src=Src(clip, sw, sh, m(ow, oh, **kw), fmt=fmt))]
+        route = route_of(layers, ow, oh, interlace)
+        if not route.startswith("clip_up_write_v210"):
+            continue  # (a shape the compositor does not take: another test's business)
+        check(layers, ow, oh, "one-launch clip case %d: %s %dx%d on %dx%d il %d %r" % (case, fmt, sw, sh, ow, oh, interlace, kw), interlace=interlace,
+              specs=[("709", "709"), ("709", "2020")][case % 2], poison_dst=bool(interlace))
+        ran += 1
+    assert ran >= cases // 2, "only %d of %d random shapes took the one-launch route" % (ran, cases)
