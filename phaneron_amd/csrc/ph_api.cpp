@@ -2329,28 +2329,32 @@ static int chan_compose_enlarged(ph_ctx *ctx, int queue, int jobs, int n, const 
   // Measured (tools/enlarge_bench.py, profiles/r06_clip_up.txt): one decoder's frame 22.5 -> 19.3 us (1080p yuv420p under the default fill), 18.0 -> 17.3
   // (720p filling 1080p); a v210 clip and frames of several layers are not faster this way (two layers 23.7 -> 24.1 us, four 1080 layers on
   // 2160p 95 -> 110: the conversions of a tile's rim are done twice) and keep the two launches.
-  if (jobs == 1 && n == 1 && layers[0][0].src.format != PH_SRC_V210 && ctx->chan_enlarged == 1) {
+  // (several frames of one shape - several channels' file playback - share the launch: a tile belongs to one frame)
+  if (jobs <= ph::kMaxUpJobs && n == 1 && ctx->chan_enlarged == 1) {
     bool wire = true, alpha = false;
-    for (int i = 0; i < n && wire; ++i) {
-      const ph_chan_source &S = layers[0][i].src;
-      wire = S.format != PH_SRC_RGBA_F32 && !(((S.format == PH_SRC_YUV420P || S.format == PH_SRC_NV12) && (S.height & 1)));
+    for (int j = 0; j < jobs && wire; ++j) {
+      const ph_chan_source &S = layers[j][0].src;
+      wire = S.format != PH_SRC_RGBA_F32 && S.format != PH_SRC_V210 && !(((S.format == PH_SRC_YUV420P || S.format == PH_SRC_NV12) && (S.height & 1)));
       alpha = alpha || S.format == PH_SRC_RGBA8 || S.format == PH_SRC_BGRA8;
     }
     const LutRef rref = lds_view(ctx, rd_lut), wref = lds_view(ctx, wr_lut);
     if (wire && rref.found && wref.found) {
       ph::ClipUpArgs c{};
       ph::UpArgs &a = c.up;
-      a.n = n, a.out = outs[0], a.out_w = out_w, a.out_h = out_h;
+      a.n = 1, a.jobs = (uint32_t)jobs, a.out = outs[0], a.out_w = out_w, a.out_h = out_h;
+      for (int j = 1; j < jobs; ++j) a.more_out[j - 1] = outs[j];
       a.line_step = interlace ? 2 : 1, a.first_line = (interlace == 3) ? 1 : 0, a.lines = interlace ? out_h / 2 : out_h;
       a.wr_cm = (const float *)wr_cm, a.wr = wref.view;
       c.rd = rref.view, c.rd_gm = (const float *)rd_gm;
-      for (int i = 0; i < n; ++i) {
-        const ph_chan_source &S = layers[0][i].src;
-        a.layer[i].w = (uint32_t)S.width, a.layer[i].h = (uint32_t)S.height, a.layer[i].pitch = (uint32_t)S.width * 16u;
-        for (int k = 0; k < 6; ++k) a.layer[i].m[k] = S.matrix9_host[k];
-        const int fmt = S.format == PH_SRC_V210 ? PH_FMT_V210 : PH_FMT_YUV422P10 + (S.format - PH_SRC_YUV422P10);
-        c.src[i] = ph::ClipSrc{S.data, S.data_u, S.data_v, (const float *)(S.col_matrix12 ? S.col_matrix12 : rd_cm), (uint32_t)fmt,
-                               fmt == PH_FMT_V210 ? ph_v210_pitch_bytes((uint32_t)S.width) / 16u : ph::pack_pitch(fmt, (uint32_t)S.width)};
+      {
+        const ph_chan_source &S = layers[0][0].src;  // (every job's clip has this size and placement: chan_enlarged_same_shape)
+        a.layer[0].w = (uint32_t)S.width, a.layer[0].h = (uint32_t)S.height, a.layer[0].pitch = (uint32_t)S.width * 16u;
+        for (int k = 0; k < 6; ++k) a.layer[0].m[k] = S.matrix9_host[k];
+      }
+      for (int j = 0; j < jobs; ++j) {
+        const ph_chan_source &S = layers[j][0].src;
+        const int fmt = PH_FMT_YUV422P10 + (S.format - PH_SRC_YUV422P10);
+        c.src[j] = ph::ClipSrc{S.data, S.data_u, S.data_v, (const float *)(S.col_matrix12 ? S.col_matrix12 : rd_cm), (uint32_t)fmt, ph::pack_pitch(fmt, (uint32_t)S.width)};
       }
       if (a.lines && ph::compose_up_eligible(a)) {
         const uint32_t grid = ph::clip_up_plan(c, !alpha, (uint32_t)ctx->props.multiProcessorCount);

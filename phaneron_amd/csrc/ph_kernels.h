@@ -203,6 +203,9 @@ struct ClipUpArgs {
   uint32_t wg_bytes;
   uint32_t rect_off[kMaxLayers], rect_cap[kMaxLayers];  // a layer's rectangle inside the workgroup's scratch: offset, bytes reserved
   uint32_t tcu, trp, gx;     // a tile: wave-step columns x row pairs; tiles per row of tiles
+  // several frames of ONE shape in one launch (up.jobs = 2 .. kMaxUpJobs; single-layer frames only: several channels' file playback):
+  // job j's clip is src[j] (layer[0] has the shape of all), its frame up.out / up.more_out[j - 1]; gy: rows of tiles per job
+  uint32_t gy;
   uint32_t info_off;         // LDS offset of the per-layer rectangle descriptors (behind the larger table)
 };
 // picks the tiling and fills rect_off / rect_cap / wg_bytes / tcu / trp / gx / info_off; returns the number of workgroups (0: not for this kernel)

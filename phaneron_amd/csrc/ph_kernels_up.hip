@@ -543,8 +543,8 @@ __device__ __forceinline__ void clip_convert(const ClipSrc &S, const UpLayer &L,
 }
 
 // a wave step of a tile: as up_step makes it for (col_unit, row pair) of job 0
-__device__ __forceinline__ void clip_step(const UpArgs &a, uint32_t col_unit, uint32_t rp, uint32_t lane, UpStep &st) {
-  st.job = 0;
+__device__ __forceinline__ void clip_step(const UpArgs &a, uint32_t job, uint32_t col_unit, uint32_t rp, uint32_t lane, UpStep &st) {
+  st.job = job;
   st.x0 = col_unit * kUpCols + 2u * lane;
   st.live = lane < 63u && st.x0 < a.out_w;
 #pragma unroll
@@ -564,7 +564,8 @@ __global__ __launch_bounds__(kUpBlock) void clip_up_write_v210_kernel(ClipUpArgs
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // the tile
   const uint32_t upr = (a.cover_w + kUpCols - 1u) / kUpCols, rps = (a.lines + 1u) / 2u;
-  const uint32_t ty = blockIdx.x / c.gx, tx = blockIdx.x - ty * c.gx;
+  const uint32_t tyj = blockIdx.x / c.gx, tx = blockIdx.x - tyj * c.gx;
+  const uint32_t job = a.jobs > 1u ? tyj / c.gy : 0u, ty = tyj - job * c.gy;  // (uniform) several frames of one shape: rows of tiles job after job
   const uint32_t cu0 = tx * c.tcu, rp0 = ty * c.trp;
   const uint32_t ncu = cu0 + c.tcu <= upr ? c.tcu : upr - cu0, nrp = rp0 + c.trp <= rps ? c.trp : rps - rp0;
   char *const mine = c.scratch + (size_t)blockIdx.x * c.wg_bytes;
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(kUpBlock) void clip_up_write_v210_kernel(ClipUpArgs
 #pragma unroll 1
   for (int l = 0; l < a.n; ++l) {
     const UpLayer L = a.layer[l];
-    const ClipSrc S = c.src[l];
+    const ClipSrc S = c.src[a.jobs > 1u ? job : (uint32_t)l];  // (several jobs: single-layer frames, job j's clip in src[j])
     // the tile's first and last pixels (inside the frame: columns past out_w - the padding of a line with a tail - have no taps that count)
     const uint32_t x_first = cu0 * kUpCols, x_end = (cu0 + ncu) * kUpCols < a.out_w ? (cu0 + ncu) * kUpCols : a.out_w;
     const uint32_t li_last = 2u * (rp0 + nrp) < a.lines ? 2u * (rp0 + nrp) - 1u : a.lines - 1u;
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(kUpBlock) void clip_up_write_v210_kernel(ClipUpArgs
   for (uint32_t u = wave; u < units; u += kUpBlock / 64) {
     const uint32_t rp_in = ncu == 1u ? u : u / ncu, cu_in = u - rp_in * ncu;
     UpStep st;
-    clip_step(a, cu0 + cu_in, rp0 + rp_in, lane, st);
+    clip_step(a, job, cu0 + cu_in, rp0 + rp_in, lane, st);
     UpAcc acc[2][2];
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
@@ -690,8 +691,9 @@ __global__ __launch_bounds__(kUpBlock) void clip_up_write_v210_kernel(ClipUpArgs
 uint32_t clip_up_plan(ClipUpArgs &c, bool rgb12, uint32_t num_cus) {
   UpArgs &a = c.up;
   if (!a.lines || !a.n || !num_cus) return 0;
+  if (!a.jobs) a.jobs = 1;
+  if (a.jobs > (uint32_t)kMaxUpJobs || (a.jobs > 1u && a.n != 1)) return 0;
   const bool tails = a.out_w % 48u != 0;
-  a.jobs = 1;
   a.out_qpitch = v210_pitch_bytes(a.out_w) / 16u;
   a.cover_w = tails ? a.out_qpitch * 6u : a.out_w;
   a.shared = 1;
@@ -699,18 +701,18 @@ uint32_t clip_up_plan(ClipUpArgs &c, bool rgb12, uint32_t num_cus) {
     a.shared = a.shared && a.layer[l].w == a.layer[0].w && a.layer[l].h == a.layer[0].h;
     for (int k = 0; k < 6; ++k) a.shared = a.shared && a.layer[l].m[k] == a.layer[0].m[k];
   }
-  const uint32_t upr = (a.cover_w + kUpCols - 1u) / kUpCols, rps = (a.lines + 1u) / 2u;
+  const uint32_t upr = (a.cover_w + kUpCols - 1u) / kUpCols, rps = (a.lines + 1u) / 2u, cus_per_job = num_cus / a.jobs ? num_cus / a.jobs : 1u;
   uint32_t best = ~0u, tcu = 0, trp = 0;
-  for (uint32_t cx = 1; cx <= 32u && cx <= upr && cx <= num_cus; cx *= 2u) {
-    const uint32_t ry = num_cus / cx < rps ? num_cus / cx : rps;
+  for (uint32_t cx = 1; cx <= 32u && cx <= upr && cx <= cus_per_job; cx *= 2u) {
+    const uint32_t ry = cus_per_job / cx < rps ? cus_per_job / cx : rps;  // rows of tiles per job (a tile belongs to one job)
     const uint32_t t_cu = (upr + cx - 1u) / cx, t_rp = (rps + ry - 1u) / ry;
     // wave steps of the fullest workgroup, in rounds of its sixteen waves (what phase 2 takes), + its rectangle's rim (what phase 1 converts twice)
     const uint32_t rounds = (t_cu * t_rp + kUpBlock / 64 - 1u) / (kUpBlock / 64);
     const uint32_t cost = rounds * 1024u + t_cu + t_rp;
     if (cost < best) best = cost, tcu = t_cu, trp = t_rp;
   }
-  c.tcu = tcu, c.trp = trp, c.gx = (upr + tcu - 1u) / tcu;
-  const uint32_t grid = c.gx * ((rps + trp - 1u) / trp);
+  c.tcu = tcu, c.trp = trp, c.gx = (upr + tcu - 1u) / tcu, c.gy = (rps + trp - 1u) / trp;
+  const uint32_t grid = c.gx * c.gy * a.jobs;
   const uint32_t texel = rgb12 ? 12u : 16u;
   uint32_t off = 0;
   for (int l = 0; l < a.n; ++l) {
@@ -730,7 +732,10 @@ uint32_t clip_up_plan(ClipUpArgs &c, bool rgb12, uint32_t num_cus) {
 
 hipError_t launch_clip_up_write_v210(hipStream_t s, const ClipUpArgs &c, bool rgb12, uint32_t grid) {
   if (!grid) return hipErrorInvalidValue;
-  if (trace_launch(rgb12 ? "clip_up_write_v210<rgb>" : "clip_up_write_v210<rgba>")) return hipSuccess;
+  char name[48];
+  if (c.up.jobs > 1u) snprintf(name, sizeof name, "clip_up_write_v210<%s>x%u", rgb12 ? "rgb" : "rgba", c.up.jobs);
+  else snprintf(name, sizeof name, "clip_up_write_v210<%s>", rgb12 ? "rgb" : "rgba");
+  if (trace_launch(name)) return hipSuccess;
   const bool tails = c.up.out_w % 48u != 0;
   const void *fn = tails ? (rgb12 ? reinterpret_cast<const void *>(clip_up_write_v210_kernel<true, true>) : reinterpret_cast<const void *>(clip_up_write_v210_kernel<false, true>))
                          : (rgb12 ? reinterpret_cast<const void *>(clip_up_write_v210_kernel<true, false>) : reinterpret_cast<const void *>(clip_up_write_v210_kernel<false, false>));

@@ -112,7 +112,9 @@ ROUTES = [
     ("four channels of config 2 in one call", lambda: batch([(config2(1920, 1080, wipe=c == 1), 0) for c in range(4)], 1920, 1080), "chan_compose_batch<0>x4"),
     ("four channels each showing a live v210 clip", lambda: batch([([clip("v210", 1920, 1080, 1920, 1080)], 0) for _ in range(4)], 1920, 1080),
      "v210_read_lds_batch+compose_up_write_v210"),
-    ("four channels of 1080p yuv422p10 playback", lambda: batch([([clip("yuv422p10", 1920, 1080, 1920, 1080)], 0) for _ in range(4)], 1920, 1080), "pack_read_batch+compose_up_write_v210"),
+    ("four channels of 1080p yuv422p10 playback", lambda: batch([([clip("yuv422p10", 1920, 1080, 1920, 1080)], 0) for _ in range(4)], 1920, 1080), "clip_up_write_v210<rgb>x4"),
+    ("six channels of 720p yuv420p playback: four frames to a launch, then two", lambda: batch([([clip("yuv420p", 1280, 720, 1920, 1080)], 0) for _ in range(6)], 1920, 1080),
+     "clip_up_write_v210<rgb>x4+clip_up_write_v210<rgb>x2"),
     ("four channels of 1080p yuv422p10 playback with a v210 inset each: the batch kernel's planar instantiation",
      lambda: batch([([clip("yuv422p10", 1920, 1080, 1920, 1080), clip("v210", 960, 540, 1920, 1080, **PIP[2])], 0) for _ in range(4)], 1920, 1080), "chan_compose_batch<2>x4"),
     ("eight channels of config 2 without wipes: one launch", lambda: batch([(config2(1920, 1080, wipe=False), 0) for _ in range(8)], 1920, 1080), "chan_compose_batch<0>x8"),
