@@ -161,7 +161,7 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
     record("2 x 4: four channels of config 2's shape in one context, their frames of a tick in one launch (per channel frame)",
            "ph_chan_compose_batch: the four frames share the workgroups of one launch - tables loaded once, the wave steps of all four taken "
            "by the waves as they come free", "frame", timeit(lambda i: batch_jobs[i % R](), reps) / C2, algo2, 1.0 / C2,
-           {"chan_compose_batch_kernel<false>": 1.0 / C2}, bytes_as_benched=benched2, channels_per_launch=C2,
+           {"chan_compose_batch_kernel<false, false>": 1.0 / C2}, bytes_as_benched=benched2, channels_per_launch=C2,
            parity_test="tests/test_chan_gpu.py::test_chan_batch_full_size_four_1080p_channels")
     if routes == "all":
         record(name2, "batched reads + compositor with the wipe inside: [read x5], [transform x4 + transition_wipe + combine_4 + write]", "frame",
@@ -200,7 +200,7 @@ def measure(ctx, torch, np, capi, routes="all", reps=200):
                                      w7, h7, *rd7, *wr7, prepare_only=True) for i in range(R)]
     record("720p50 x 4: four such channels in one context, their frames of a tick in one launch (per channel frame)",
            "ph_chan_compose_batch, a full-frame layer and three quarter-size insets per channel", "frame",
-           timeit(lambda i: batch7[i % R](), reps) / C7, algo7, 1.0 / C7, {"chan_compose_batch_kernel<true>": 1.0 / C7}, channels_per_launch=C7,
+           timeit(lambda i: batch7[i % R](), reps) / C7, algo7, 1.0 / C7, {"chan_compose_batch_kernel<true, false>": 1.0 / C7}, channels_per_launch=C7,
            parity_test="tests/test_fullsize_gpu.py::test_four_720p_channels_in_one_launch_full_size")
 
     # ---------------- config 3 -------------------------------------------------------------
