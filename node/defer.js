@@ -320,9 +320,20 @@ class Deferral {
 			}
 			// groups of plans one launch can take
 			const groups = []
+			const covered = new Set() // writes that another plan's launch makes along with its own (the other field of a de-interlaced frame)
 			for (const p of plans) {
+				if (covered.has(p.node)) continue
 				if (!p.batchable || !this.ctx._native.runPrograms) { groups.push([p]); continue }
-				let g = groups.find((v) => v[0].batchable && v.length < 8 && v[0].width === p.width && v[0].height === p.height && v[0].node.queue === p.node.queue &&
+				if (p.up) { // frames of the 2 x 2-block compositor: those of one Saver go down together, the library puts like ones into shared launches
+					const twin = p.candidates[0][2]
+					if (twin) covered.add(twin.node)
+					let g = groups.find((v) => v[0].up && v[0].batchable && v.length < 8 && v[0].width === p.width && v[0].height === p.height && v[0].node.queue === p.node.queue &&
+						Deferral.same(v[0].saver.outColMatrix, p.saver.outColMatrix) && Deferral.same(v[0].saver.outGammaLut, p.saver.outGammaLut))
+					if (!g) groups.push((g = []))
+					g.push(p)
+					continue
+				}
+				let g = groups.find((v) => !v[0].up && v[0].batchable && v.length < 8 && v[0].width === p.width && v[0].height === p.height && v[0].node.queue === p.node.queue &&
 					Deferral.sameRecipe(v[0].loader, p.loader) && Deferral.same(v[0].saver.outColMatrix, p.saver.outColMatrix) && Deferral.same(v[0].saver.outGammaLut, p.saver.outGammaLut))
 				if (!g) groups.push((g = []))
 				g.push(p)
@@ -360,8 +371,9 @@ class Deferral {
 			for (const k of Object.keys(params)) {
 				let v = params[k]
 				if (v === undefined || v === null) continue
-				if (k === 'colMatrix' || k === 'gammaLut' || k === 'gamutMatrix' || k === 'outColMatrix' || k === 'outGammaLut') v = first[k]
-				if (v && v._packed != null) this._unpack(v) // (a packed field image as a source of a batched frame: the real image first)
+				if ((k === 'colMatrix' || k === 'gammaLut' || k === 'gamutMatrix' || k === 'outColMatrix' || k === 'outGammaLut') && first[k]) v = first[k]
+				// (a packed field image as a source of a batched frame: the real image first - unless the frame is the compositor's and was told)
+				if (v && v._packed != null && !(params.packedRgb && /^l\d+In2?$/.test(k))) this._unpack(v)
 				nm.push(k)
 				vs.push(Buffer.isBuffer(v) ? v._handle : typeof v === 'boolean' ? (v ? 1 : 0) : v)
 			}
@@ -381,14 +393,14 @@ class Deferral {
 				this.stats.launched++
 				this.stats.batched = (this.stats.batched || 0) + made
 				this.launchedOn.set(queue, (this.launchedOn.get(queue) || 0) + 1)
-				for (const p of plans.slice(0, made)) this._done(p, null)
+				for (const p of plans.slice(0, made)) this._done(p, p.candidates[0][2] || null)
 			}
 			return false
 		}
 		this.stats.launched++
 		this.stats.batched = (this.stats.batched || 0) + plans.length
 		this.launchedOn.set(queue, (this.launchedOn.get(queue) || 0) + 1)
-		for (const p of plans) this._done(p, null)
+		for (const p of plans) this._done(p, p.candidates[0][2] || null) // (a compositor job that made both fields' frames: the twin's write is done too)
 		return true
 	}
 
@@ -842,8 +854,10 @@ class Deferral {
 		// or the channel kernel as the only candidate making a v210 frame (the batch kernel for v210 / image sources)
 		// (frames from planar / packed-RGB clips go along in the same call: the library runs those it cannot put into a shared launch in their turn,
 		// and makes the ones of enlarged clips of one shape together)
-		const batchable = candidates[0][0].startsWith('fused_v210_combine_') || (candidates.length === 1 && candidates[0][0].startsWith('chan_compose_v210_') && !outFmt)
-		return { node, candidates, used, n, width, height, batchable, loader, saver }
+		// ... or frames of the 2 x 2-block compositor (de-interlaced fields at their own size or enlarged: several 1080i channels in a tick)
+		const up = candidates[0][0].startsWith('compose_up_write_v210_')
+		const batchable = up || candidates[0][0].startsWith('fused_v210_combine_') || (candidates.length === 1 && candidates[0][0].startsWith('chan_compose_v210_') && !outFmt)
+		return { node, candidates, used, n, width, height, batchable, up, loader, saver }
 	}
 	// launch the first candidate the library takes; false = none (nothing was launched)
 	_commit(plan) {

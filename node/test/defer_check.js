@@ -475,9 +475,28 @@ for (const moved of [false, true]) {
 				outs6.push(out)
 			}
 		}
+		// the same on an addon with runPrograms: the two channels' compositor jobs (each both fields of its frame) go down in ONE call -
+		// the library makes the four frames in one launch (ph_compose_up_write_v210_batch)
+		const r7 = rig({ early: true, batch: true })
+		const L7 = r7.loader()
+		const m7 = r7.enlarging()
+		for (const ch of [0, 1]) {
+			const win = [0, 1, 2].map((i) => { const im = r7.image(`c${ch}w${i}`); r7.d.record(r7.P.read, Object.assign({ input: r7.v210(`c${ch}s${i}`), output: im, width: r7.W }, L7), 1); return im })
+			for (const parity of [0, 1]) {
+				const y = r7.image(`c${ch}y${parity}`)
+				r7.d.record(r7.P.yadif, { prev: win[0], cur: win[1], next: win[2], parity, tff: 1, skipSpatial: 0, output: y }, 1)
+				const t = r7.image(`c${ch}t${parity}`)
+				r7.d.record(r7.P.transform, { input: y, transformMatrix: m7, output: t }, 1)
+				r7.d.record(r7.P.write, Object.assign({ input: t, output: r7.v210(`c${ch}out${parity}`), width: r7.W, interlace: 0 }, r7.saver), 1)
+			}
+		}
 		setImmediate(() => {
 			expect('two 1080i channels in one tick: one reader launch for both windows, one compositor launch per channel (both fields)',
 				r6.names(), ['v210_yadif_pair_2', 'compose_up_write_v210_1', 'compose_up_write_v210_1'])
+			const b7 = r7.launches.find((l) => l[0].startsWith('batch'))
+			expect('with runPrograms: the channels\' compositor jobs in one call, each with both fields, the packed fields not unpacked on the way',
+				[r7.names(), b7 ? /packedRgb/.test(b7[2]) && /output2/.test(b7[2]) : false, r7.d.stats.unpacked || 0, r7.d.pending.size > 0 ? Array.from(r7.d.pending).filter((n) => n.program.name === 'write').length : 0],
+				[['v210_yadif_pair_2', 'batch:compose_up_write_v210_1+compose_up_write_v210_1'], true, 0, 0])
 			process.stdout.write(JSON.stringify({ checks, problems }) + '\n')
 		})
 	})

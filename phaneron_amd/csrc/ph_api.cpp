@@ -1337,6 +1337,75 @@ static int fused_call_parse(ph_ctx *ctx, ph_program *prog, const ph_arg *args, i
 #undef TRY
 }
 
+// a compose_up_write_v210_<n> job's arguments (ph_run_program and ph_run_programs, which puts like jobs into one launch)
+struct UpCall {
+  int n;
+  bool rgb, pair;
+  ph_image_layer layers[ph::kMaxLayers], layers2[ph::kMaxLayers];
+  ph_buf *o, *o2, *wcm, *wl;
+  uint32_t width, height, interlace;
+};
+static int up_call_parse(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n, bool check_only, UpCall *u) {
+  int rc;
+#define TRY(x) \
+  if ((rc = (x)) != PH_OK) return rc
+  // l<i>In: the layer's image - an RGBA image buffer, or with packedRgb = 1 a buffer of packed f32 RGB (l<i>Width / l<i>Height:
+  // its size); l<i>Matrix: its placement (host mirror, as above); output: v210; outColMatrix / outGammaLut; interlace
+  const uint32_t width = prog->global[0], height = prog->global[1];
+  if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
+  double rgb = 0, interlace = 0;
+  if (find_arg(args, n, "packedRgb")) TRY(need_num(args, n, "packedRgb", &rgb));
+  // output2 + l<i>In2 (optional): a second job of the same shape in the same launch - the other field of a de-interlaced frame
+  // (ph_compose_up_write_v210_pair): same sizes, formats and placements, other data
+  const bool pair = find_arg(args, n, "output2") != nullptr;
+  for (int i = 0; i < prog->n_layers; ++i) {
+    char nm[24];
+    ph_buf *x = nullptr, *m = nullptr, *x2 = nullptr;
+    double lw = 0, lh = 0;
+    snprintf(nm, sizeof nm, "l%dIn", i);
+    TRY(need_buf(args, n, nm, 0, &x));
+    if (pair) {
+      snprintf(nm, sizeof nm, "l%dIn2", i);
+      TRY(need_buf(args, n, nm, x->bytes, &x2));
+      if (rgb == 0) {
+        int w2, h2, w1, h1;
+        TRY(need_image(x2, nm, &w2, &h2));
+        TRY(need_image(x, nm, &w1, &h1));
+        if (w1 != w2 || h1 != h2) return fail(PH_E_INVALID, "kernel argument '%s': the second job's image is %dx%d, the first's %dx%d", nm, w2, h2, w1, h1);
+      }
+      snprintf(nm, sizeof nm, "l%dIn", i);
+    }
+    if (rgb != 0) {
+      snprintf(nm, sizeof nm, "l%dWidth", i);
+      TRY(need_num(args, n, nm, &lw));
+      snprintf(nm, sizeof nm, "l%dHeight", i);
+      TRY(need_num(args, n, nm, &lh));
+      if (lw <= 0 || lh <= 0 || x->bytes < (size_t)lw * (size_t)lh * 12) return fail(PH_E_RANGE, "kernel argument 'l%dIn': smaller than its %gx%g packed-RGB image", i, lw, lh);
+    } else {
+      int iw, ih;
+      TRY(need_image(x, nm, &iw, &ih));
+      lw = iw, lh = ih;
+    }
+    snprintf(nm, sizeof nm, "l%dMatrix", i);
+    TRY(need_buf(args, n, nm, 36, &m));
+    if (!m->hptr) return fail(PH_E_INVALID, "kernel argument '%s': the matrix must have been written through hostAccess (its host copy is what the launch reads)", nm);
+    u->layers[i].data = x->dptr, u->layers[i].format = rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32;
+    u->layers[i].width = (int)lw, u->layers[i].height = (int)lh, u->layers[i].matrix9_host = (const float *)m->hptr;
+    u->layers2[i] = u->layers[i];
+    if (pair) u->layers2[i].data = x2->dptr;
+  }
+  u->o = u->o2 = u->wcm = u->wl = nullptr;
+  TRY(need_buf(args, n, "output", (size_t)ph_v210_pitch_bytes(width) * height, &u->o));
+  if (pair) TRY(need_buf(args, n, "output2", (size_t)ph_v210_pitch_bytes(width) * height, &u->o2));
+  TRY(need_buf(args, n, "outColMatrix", 48, &u->wcm));
+  TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &u->wl));
+  if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
+  if (!check_only) refresh_buf_lut(ctx, u->wl);
+  u->n = prog->n_layers, u->rgb = rgb != 0, u->pair = pair, u->width = width, u->height = height, u->interlace = (uint32_t)interlace;
+#undef TRY
+  return PH_OK;
+}
+
 // the "fail_launches" fault injection (tests of a binding's error paths: node/test/soak_run.js, tests/test_boundary_gpu.py): does this launch fail?
 static bool inject_failure(ph_ctx *ctx) {
   const int v = ctx->fail_launches.load();
@@ -1552,63 +1621,12 @@ static int dispatch_compose(ph_ctx *ctx, ph_program *prog, const ph_arg *args, i
                                   call.rd_cm->dptr, call.rd_lut->dptr, call.rd_gm->dptr, call.wr_cm ? call.wr_cm->dptr : nullptr, call.wr_lut->dptr);
     }
     case K_COMPOSE_UP: {
-      // l<i>In: the layer's image - an RGBA image buffer, or with packedRgb = 1 a buffer of packed f32 RGB (l<i>Width / l<i>Height:
-      // its size); l<i>Matrix: its placement (host mirror, as above); output: v210; outColMatrix / outGammaLut; interlace
-      const uint32_t width = prog->global[0], height = prog->global[1];
-      if (!width || !height) return fail(PH_E_INVALID, "%s: globalWorkItems must be [width, height]", prog->kernel.c_str());
-      double rgb = 0, interlace = 0;
-      if (find_arg(args, n, "packedRgb")) TRY(need_num(args, n, "packedRgb", &rgb));
-      // output2 + l<i>In2 (optional): a second job of the same shape in the same launch - the other field of a de-interlaced frame
-      // (ph_compose_up_write_v210_pair): same sizes, formats and placements, other data
-      const bool pair = find_arg(args, n, "output2") != nullptr;
-      ph_image_layer layers[ph::kMaxLayers], layers2[ph::kMaxLayers];
-      for (int i = 0; i < prog->n_layers; ++i) {
-        char nm[24];
-        ph_buf *x = nullptr, *m = nullptr, *x2 = nullptr;
-        double lw = 0, lh = 0;
-        snprintf(nm, sizeof nm, "l%dIn", i);
-        TRY(need_buf(args, n, nm, 0, &x));
-        if (pair) {
-          snprintf(nm, sizeof nm, "l%dIn2", i);
-          TRY(need_buf(args, n, nm, x->bytes, &x2));
-          if (rgb == 0) {
-            int w2, h2, w1, h1;
-            TRY(need_image(x2, nm, &w2, &h2));
-            TRY(need_image(x, nm, &w1, &h1));
-            if (w1 != w2 || h1 != h2) return fail(PH_E_INVALID, "kernel argument '%s': the second job's image is %dx%d, the first's %dx%d", nm, w2, h2, w1, h1);
-          }
-          snprintf(nm, sizeof nm, "l%dIn", i);
-        }
-        if (rgb != 0) {
-          snprintf(nm, sizeof nm, "l%dWidth", i);
-          TRY(need_num(args, n, nm, &lw));
-          snprintf(nm, sizeof nm, "l%dHeight", i);
-          TRY(need_num(args, n, nm, &lh));
-          if (lw <= 0 || lh <= 0 || x->bytes < (size_t)lw * (size_t)lh * 12) return fail(PH_E_RANGE, "kernel argument 'l%dIn': smaller than its %gx%g packed-RGB image", i, lw, lh);
-        } else {
-          int iw, ih;
-          TRY(need_image(x, nm, &iw, &ih));
-          lw = iw, lh = ih;
-        }
-        snprintf(nm, sizeof nm, "l%dMatrix", i);
-        TRY(need_buf(args, n, nm, 36, &m));
-        if (!m->hptr) return fail(PH_E_INVALID, "kernel argument '%s': the matrix must have been written through hostAccess (its host copy is what the launch reads)", nm);
-        layers[i].data = x->dptr, layers[i].format = rgb != 0 ? PH_IMG_RGB_F32 : PH_IMG_RGBA_F32;
-        layers[i].width = (int)lw, layers[i].height = (int)lh, layers[i].matrix9_host = (const float *)m->hptr;
-        layers2[i] = layers[i];
-        if (pair) layers2[i].data = x2->dptr;
-      }
-      ph_buf *wcm = nullptr, *wl = nullptr, *o2 = nullptr;
-      TRY(need_buf(args, n, "output", (size_t)ph_v210_pitch_bytes(width) * height, &o));
-      if (pair) TRY(need_buf(args, n, "output2", (size_t)ph_v210_pitch_bytes(width) * height, &o2));
-      TRY(need_buf(args, n, "outColMatrix", 48, &wcm));
-      TRY(need_buf(args, n, "outGammaLut", 65536 * 4, &wl));
-      if (find_arg(args, n, "interlace")) TRY(need_num(args, n, "interlace", &interlace));
-      if (!check_only) refresh_buf_lut(ctx, wl);
+      UpCall u;
+      TRY(up_call_parse(ctx, prog, args, n, check_only, &u));
       if (check_only) return PH_OK;
-      if (pair)
-        return ph_compose_up_write_v210_pair(ctx, queue, prog->n_layers, layers, layers2, o->dptr, o2->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
-      return ph_compose_up_write_v210(ctx, queue, prog->n_layers, layers, o->dptr, width, height, (uint32_t)interlace, wcm->dptr, wl->dptr);
+      if (u.pair)
+        return ph_compose_up_write_v210_pair(ctx, queue, u.n, u.layers, u.layers2, u.o->dptr, u.o2->dptr, u.width, u.height, u.interlace, u.wcm->dptr, u.wl->dptr);
+      return ph_compose_up_write_v210(ctx, queue, u.n, u.layers, u.o->dptr, u.width, u.height, u.interlace, u.wcm->dptr, u.wl->dptr);
     }
     case K_COMPOSE_V210: {
       // l<i>In: RGBA image; l<i>Matrix (optional): its 3x3 placement, absent = taken 1:1; l<i>WipeIn + l<i>WipeMask (optional):
@@ -1830,7 +1848,8 @@ int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_
   if (ctx->fail_launches.load() > 0) return fail(PH_E_HIP, "ph_run_programs: launch failed: injected (context option fail_launches)");
   std::vector<ChanCall> calls((size_t)n_jobs);
   std::vector<FusedCall> fused((size_t)n_jobs);
-  std::vector<char> kind((size_t)n_jobs, 0);  // 1: a v210 frame from the channel kernel, 2: fused_v210_combine, 0: whatever else, launched as it is
+  std::vector<UpCall> ups;  // (sized when the first compose_up job shows up: most calls have none)
+  std::vector<char> kind((size_t)n_jobs, 0);  // 1: a v210 frame from the channel kernel, 2: fused_v210_combine, 3: compose_up_write_v210, 0: whatever else, launched as it is
   for (int j = 0; j < n_jobs; ++j) {  // every job is checked before anything is launched: a bad one refuses the call as a whole
     if (!progs[j] || (n_args[j] > 0 && !args[j])) return fail(PH_E_INVALID, "ph_run_programs: job %d: NULL argument", j);
     if ((rc = flush_dirty_args(ctx, args[j], n_args[j], queue))) return rc;
@@ -1840,6 +1859,10 @@ int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_
     } else if (progs[j]->id == K_FUSED_V210) {
       if ((rc = fused_call_parse(ctx, progs[j], args[j], n_args[j], false, &fused[(size_t)j]))) return rc;
       kind[(size_t)j] = 2;
+    } else if (progs[j]->id == K_COMPOSE_UP) {
+      if (ups.empty()) ups.resize((size_t)n_jobs);
+      if ((rc = up_call_parse(ctx, progs[j], args[j], n_args[j], false, &ups[(size_t)j]))) return rc;
+      kind[(size_t)j] = 3;
     } else if ((rc = dispatch(ctx, progs[j], args[j], n_args[j], queue, true))) {
       return rc;
     }
@@ -1878,6 +1901,38 @@ int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_
       }
       rc = ph_fused_v210_combine_batch(ctx, queue, (int)outs.size(), f0.n, layers.data(), outs.data(), f0.width, f0.height, f0.rd_cm->dptr, f0.rd_lut->dptr,
                                        f0.rd_gm->dptr, f0.wr_cm->dptr, f0.wr_lut->dptr);
+      if (rc) return rc;
+      g_programs_done = j = k;
+      continue;
+    }
+    if (kind[(size_t)j] == 3) {
+      // frames of the 2 x 2-block compositor of ONE shape (layer count, image format and sizes, placements, output size, field mode, Saver) -
+      // several channels' frames from de-interlaced fields, each job one frame or a frame's two fields - in one launch of up to
+      // kMaxUpJobs frames (ph_compose_up_write_v210_batch); a job that writes a frame an earlier one of the group writes starts the next
+      const UpCall &u0 = ups[(size_t)j];
+      const ph_image_layer *sets[ph::kMaxUpJobs];
+      void *outs[ph::kMaxUpJobs];
+      int frames = 0;
+      for (; k < n_jobs && kind[(size_t)k] == 3; ++k) {
+        const UpCall &u = ups[(size_t)k];
+        bool same = u.n == u0.n && u.rgb == u0.rgb && u.width == u0.width && u.height == u0.height && u.interlace == u0.interlace && u.wcm == u0.wcm && u.wl == u0.wl;
+        for (int l = 0; l < u.n && same; ++l) {
+          same = u.layers[l].width == u0.layers[l].width && u.layers[l].height == u0.layers[l].height;
+          for (int e = 0; e < 9 && same; ++e) same = u.layers[l].matrix9_host[e] == u0.layers[l].matrix9_host[e];
+        }
+        if (!same || frames + (u.pair ? 2 : 1) > ph::kMaxUpJobs) break;
+        bool clash = u.pair && u.o->dptr == u.o2->dptr;
+        for (int f = 0; f < frames && !clash; ++f) clash = outs[f] == u.o->dptr || (u.pair && outs[f] == u.o2->dptr);
+        if (clash) break;
+        sets[frames] = u.layers, outs[frames++] = u.o->dptr;
+        if (u.pair) sets[frames] = u.layers2, outs[frames++] = u.o2->dptr;
+      }
+      if (k == j) {  // (the first job does not fit a group of its own making - a pair writing one buffer twice: as it is, for its own error)
+        if ((rc = dispatch(ctx, progs[j], args[j], n_args[j], queue))) return rc;
+        g_programs_done = ++j;
+        continue;
+      }
+      rc = ph_compose_up_write_v210_batch(ctx, queue, frames, u0.n, sets, outs, u0.width, u0.height, u0.interlace, u0.wcm->dptr, u0.wl->dptr);
       if (rc) return rc;
       g_programs_done = j = k;
       continue;

@@ -22,9 +22,9 @@ def ctx():
     c.close()
 
 
-def upload(ctx, arr, access="readonly", svm="none", owner="test"):
+def upload(ctx, arr, access="readonly", svm="none", owner="test", dims=None):
     a = np.ascontiguousarray(arr)
-    b = ctx.create_buffer(a.nbytes, access, svm, owner=owner)
+    b = ctx.create_buffer(a.nbytes, access, svm, dims=dims, owner=owner)
     b.host_access("writeonly", capi.QUEUE_LOAD, a)
     return b
 
@@ -512,3 +512,50 @@ def test_packed_fields_unpack_in_place():
             k.image_unpack_rgb(p, w, h)
         for a, b in zip(rgba, packed):
             assert np.array_equal(hh.host(a).view(np.uint32), hh.host(b).view(np.uint32)), (w, h)
+
+
+def test_run_programs_puts_like_compositor_frames_into_one_launch(ctx):
+    """ph_run_programs with compose_up_write_v210_<n> jobs (what node/defer.js makes of channels showing de-interlaced fields): two channels' jobs,
+    each BOTH fields of its frame (output2 / l<i>In2), are one launch of four frames; a third job of another placement starts the next; a job
+    that writes a frame the group already writes starts the next too - every frame equals the same jobs posted one ph_run_program each, and
+    the trace says how the call was launched"""
+    w, h, sw, sh = 384, 54, 192, 30
+    col = Colour(ctx, "709", "709")
+    imgs = [upload(ctx, frames.rgba_random(sw, sh, 1500 + i, -0.05, 1.05).reshape(-1), svm="coarse", dims=(sw, sh)) for i in range(6)]
+    fill, small = np.zeros(12, np.float32), np.zeros(12, np.float32)
+    fill[:9] = capi.transform_matrix(w, h)
+    small[:9] = capi.transform_matrix(w, h, scale_x=0.8, scale_y=0.8)
+    bf, bs = upload(ctx, fill), upload(ctx, small)
+    ctx.wait(capi.QUEUE_LOAD)
+    nbytes = capi.v210_pitch_bytes(w) * h
+    prog = ctx.create_program("phaneron:up", "compose_up_write_v210_1", [w, h])
+    saver = {"outColMatrix": col.wr_cm, "outGammaLut": col.wr_lut, "interlace": 0}
+    sides = []
+    for side in (0, 1):
+        outs = [ctx.create_buffer(nbytes, "writeonly", "coarse") for _ in range(6)]
+        jobs = [(prog, dict(saver, l0In=imgs[0], l0In2=imgs[1], l0Matrix=bf, output=outs[0], output2=outs[1])),   # channel A: both fields
+                (prog, dict(saver, l0In=imgs[2], l0In2=imgs[3], l0Matrix=bf, output=outs[2], output2=outs[3])),   # channel B: both fields -> the same launch
+                (prog, dict(saver, l0In=imgs[4], l0Matrix=bs, output=outs[4])),                                   # another placement: a launch of its own
+                (prog, dict(saver, l0In=imgs[5], l0Matrix=bs, output=outs[5])),                                   # ... shared with this one
+                (prog, dict(saver, l0In=imgs[0], l0Matrix=bs, output=outs[4]))]                                   # writes a frame of the group: the next launch
+        if side == 0:
+            with capi.trace() as t:
+                ctx.run_programs(jobs)
+            assert t.route == "compose_up_write_v210+compose_up_write_v210+compose_up_write_v210", t.route
+        else:
+            for p, params in jobs:
+                ctx.run_program(p, params)
+        ctx.wait()
+        got = []
+        for o in outs:
+            o.host_access("readonly", capi.QUEUE_UNLOAD)
+            got.append(o.host(np.uint32).copy())
+        sides.append(got)
+        for o in outs:
+            o.release()
+    for i, (a, b) in enumerate(zip(*sides)):
+        assert np.array_equal(a, b), "frame %d of the one call differs from the separate calls" % i
+    assert not np.array_equal(sides[0][0], sides[0][2])
+    for x in imgs + [bf, bs]:
+        x.release()
+    col.release()
