@@ -252,7 +252,9 @@ int ph_check_program(ph_ctx *ctx, ph_program *prog, const ph_arg *args, int n_ar
  * programs of one geometry that name the SAME Loader / Saver buffers and make v210 frames - go to the device together
  * (ph_chan_compose_batch: the reference's channels share one context and one queue, src/index.ts:45-71,156-160); likewise consecutive
  * fused_v210_combine_<n> programs of one geometry, layer count and recipe (ph_fused_v210_combine_batch, up to eight per launch; a frame
- * that touches an earlier one's output starts the next launch). */
+ * that touches an earlier one's output starts the next launch), and consecutive compose_up_write_v210_<n> jobs of one shape - layer count,
+ * image format and sizes, placements, frame size, field mode, Saver - each one frame or a frame's two fields (ph_compose_up_write_v210_batch, up to four frames
+ * per launch). */
 int ph_run_programs(ph_ctx *ctx, int n_jobs, ph_program *const *progs, const ph_arg *const *args, const int *n_args, int queue);
 /* How far the calling thread's LAST ph_run_programs call got: the launches of jobs 0 .. *jobs_done - 1 were made (n_jobs after a call
  * that returned PH_OK, 0 after one refused by its checks).  A call that fails at a launch has enqueued the jobs before the failing
