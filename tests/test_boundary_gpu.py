@@ -559,3 +559,48 @@ def test_run_programs_puts_like_compositor_frames_into_one_launch(ctx):
     for x in imgs + [bf, bs]:
         x.release()
     col.release()
+
+
+def test_run_programs_reports_how_far_a_failing_call_got(ctx):
+    """ph_run_programs_progress: a call whose second group is refused at its launch (fault injection: option fail_launches = -1 lets one
+    launch group through, then every one fails) has made the first group's frames - the binding continues behind them instead of rendering
+    them twice; a call refused by its checks has made nothing"""
+    import ctypes
+    w, h = 384, 54
+    col = Colour(ctx, "709", "709")
+    dev = [upload(ctx, frames.v210_random(w, h, frames.layer_seed(160, i)), svm="coarse") for i in range(4)]
+    nbytes = capi.v210_pitch_bytes(w) * h
+    outs = [ctx.create_buffer(nbytes, "writeonly", "coarse") for _ in range(4)]
+    ctx.wait(capi.QUEUE_LOAD)
+    recipe = {"colMatrix": col.rd_cm, "gammaLut": col.rd_lut, "gamutMatrix": col.rd_gm, "outColMatrix": col.wr_cm, "outGammaLut": col.wr_lut}
+    p2 = ctx.create_program("phaneron:fused", "fused_v210_combine_2", [w, h])
+    p1 = ctx.create_program("phaneron:fused", "fused_v210_combine_1", [w, h])
+    # two frames of two layers (one launch), then two of one layer (another launch: another layer count)
+    jobs = [(p2, dict(recipe, output=outs[0], l0In=dev[0], l1In=dev[1])), (p2, dict(recipe, output=outs[1], l0In=dev[2], l1In=dev[3])),
+            (p1, dict(recipe, output=outs[2], l0In=dev[0])), (p1, dict(recipe, output=outs[3], l0In=dev[1]))]
+    done = ctypes.c_int(-1)
+    ctx.set_option("fail_launches", -1)
+    try:
+        with pytest.raises(capi.PhaneronError, match="injected"):
+            ctx.run_programs(jobs)
+        capi.check(capi.lib().ph_run_programs_progress(ctypes.byref(done)))
+        assert done.value == 2
+    finally:
+        ctx.set_option("fail_launches", 0)
+    ctx.run_programs(jobs[done.value:])  # the binding's continuation
+    capi.check(capi.lib().ph_run_programs_progress(ctypes.byref(done)))
+    assert done.value == 2
+    ctx.wait()
+    rd = [orc.v210_read(frames.v210_random(w, h, frames.layer_seed(160, i)), w, h, *col.oracle_rd) for i in range(4)]
+    want = [orc.combine([rd[0], rd[1]]), orc.combine([rd[2], rd[3]]), rd[0], rd[1]]
+    for o, img in zip(outs, want):
+        o.host_access("readonly", capi.QUEUE_UNLOAD)
+        assert np.array_equal(o.host(np.uint32), np.asarray(orc.v210_write(img, w, h, 0, *col.oracle_wr)).reshape(-1).view(np.uint32))
+    bad = dict(recipe, output=outs[0], l0In=dev[0])  # a two-layer program without its second layer: refused by the checks, nothing launched
+    with pytest.raises(capi.PhaneronError):
+        ctx.run_programs([jobs[0], (p2, bad)])
+    capi.check(capi.lib().ph_run_programs_progress(ctypes.byref(done)))
+    assert done.value == 0
+    for x in dev + outs:
+        x.release()
+    col.release()
