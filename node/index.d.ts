@@ -107,6 +107,10 @@ export class clContext {
 	/** deferred contexts: run everything still recorded; returns the recording's counters (null on a plain context) */
 	flushDeferred(): DeferredStats | null
 	deferredStats(): DeferredStats | null
+	/** extension: note the kernels the calls made from here on (this thread) launch; dryRun: choose and check, enqueue nothing */
+	traceBegin(dryRun?: boolean): void
+	/** extension: the kernels launched since traceBegin, '+'-joined, e.g. "v210_yadif_pair+compose_up_write_v210" */
+	traceEnd(): string
 	/** wait until everything launched so far on `queue` has finished (on a deferred context waitFinish(queue.process) returns at once) */
 	drain(queue?: number): Promise<void>
 	/** staging extension: later work on `waiter` starts after everything enqueued so far on `signal` */

@@ -309,6 +309,11 @@ class clContext {
 		return native.waitFinish(this._ctx, queue === undefined ? this.queue.process : queue)
 	}
 	deferredStats() { return this._deferral ? Object.assign({ pending: this._deferral.pending.size }, this._deferral.stats) : null }
+	// extension (ph_trace_begin / ph_trace_end): which kernels the calls made between the two - on this thread - launched, '+'-joined
+	// ("fused_v210_combine_lds", "chan_compose_batch<0>x4", "v210_yadif_pair+compose_up_write_v210" ...); dryRun: everything is chosen and
+	// checked, nothing is enqueued (the frames are not made)
+	traceBegin(dryRun) { this._need().traceBegin(!!dryRun) }
+	traceEnd() { return this._need().traceEnd() }
 
 	// ---- staging extensions (not nodencl; SURVEY 8f-3, node/staging.js) -----------------------------
 	// later work on `waiter` starts only after everything enqueued so far on `signal` has finished

@@ -12,7 +12,6 @@ async function main() {
 	let checks = 0
 	const W = 1920, H = 1080
 	const rig = await Rig.open({ deviceIndex: 0, deferred: true })
-	const native = rig.ctx._native
 	const read = await rig.unpack('v210', W, H, '709', '709')
 	const read420 = await rig.unpack('yuv420p', 1280, 720, '709', '709')
 	const write = await rig.pack('v210', W, H, '709', false)
@@ -30,12 +29,12 @@ async function main() {
 	const keep = []
 	const pin = async (what, want, post) => {
 		await rig.ctx.drain()
-		native.traceBegin(true)
+		rig.ctx.traceBegin(true)
 		let got
 		try {
 			const outs = await post()
 			for (const o of outs) rig.ctx.realise(o)
-		} finally { got = native.traceEnd() }
+		} finally { got = rig.ctx.traceEnd() }
 		++checks
 		routes[what] = got
 		if (got !== want) problems.push({ what, got, want })
@@ -88,13 +87,13 @@ async function main() {
 	// several channels in one tick reach the device in one call (the frames are asked for together at the end of the tick)
 	{
 		await rig.ctx.drain()
-		native.traceBegin(true)
+		rig.ctx.traceBegin(true)
 		let got
 		try {
 			const outs = []
 			for (let c = 0; c < 4; ++c) outs.push(await config2())
 			rig.ctx.realise(outs[0]) // (asking for one takes the others of its shape along: one runPrograms call)
-		} finally { got = native.traceEnd() }
+		} finally { got = rig.ctx.traceEnd() }
 		++checks
 		routes['four channels of config 2\'s shape in one tick'] = got
 		if (got !== 'chan_compose_batch<0>x4') problems.push({ what: 'four channels in one tick', got, want: 'chan_compose_batch<0>x4' })
