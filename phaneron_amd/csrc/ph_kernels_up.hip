@@ -301,7 +301,8 @@ __device__ __forceinline__ void up_filter(const UpPatch &p, const UpGeo &g, UpAc
 // it does not set 0: v210.ts:166-193), then the slots it clears up to the pitch (:131-136).  A lane beyond the line's pixels contributes
 // zero code values, so the same hand-overs and stores make the tail quad's unset words and the cleared slots.
 template <bool TAILS>
-__device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, const UpAcc (&acc)[2][2], uint32_t role, const WriteK &wk, const LutK &lk) {
+__device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, const UpAcc (&acc)[2][2], uint32_t role, const WriteK &wk, const LutK &lk,
+                                         void *frame = nullptr) {  // frame: the step's output frame, where the caller knows it (else by st.job)
   const uint32_t qpl = TAILS ? a.out_qpitch : a.out_w / 6u;
   const uint32_t quad = st.x0 / 6u, full = a.out_w / 6u;
   const bool in_tail = TAILS && quad == full, beyond = TAILS && st.x0 >= a.out_w;  // (a tail's pixels are inside: beyond is false for them)
@@ -340,7 +341,7 @@ __device__ __forceinline__ void up_write(const UpArgs &a, const UpStep &st, cons
       // written whole and once.  (As two dword stores each instruction wrote every other dword and each sector went out twice,
       // half filled: WRITE_SIZE 36.7 MB for a 22.1 MB frame, profiles/r03_pmc_up.txt.)
       typedef uint32_t ph_u2v __attribute__((ext_vector_type(2)));
-      ph_u2v *dst = reinterpret_cast<ph_u2v *>(reinterpret_cast<uint4 *>(st.job ? a.more_out[st.job - 1u] : a.out) + (size_t)st.line[dy] * qpl + st.x0 / 6u) + (role == 2u ? 1 : 0);
+      ph_u2v *dst = reinterpret_cast<ph_u2v *>(reinterpret_cast<uint4 *>(frame ? frame : st.job ? a.more_out[st.job - 1u] : a.out) + (size_t)st.line[dy] * qpl + st.x0 / 6u) + (role == 2u ? 1 : 0);
       __builtin_nontemporal_store(ph_u2v{half.x, half.y}, dst);
     }
   }
@@ -557,7 +558,9 @@ __device__ __forceinline__ void clip_step(const UpArgs &a, uint32_t job, uint32_
   for (int dx = 0; dx < 2; ++dx) st.px[dx] = (float)(int)(st.x0 + (uint32_t)dx) / (float)(int)a.out_w - 0.5f;
 }
 
-template <bool RGB12, bool TAILS>
+// MULTI: several frames of one shape in the launch (an instantiation of its own: a job index alive through both phases costs the
+// one-frame kernel eight spilled registers and 1.3 us, measured)
+template <bool RGB12, bool TAILS, bool MULTI = false>
 __global__ __launch_bounds__(kUpBlock) void clip_up_write_v210_kernel(ClipUpArgs c) {
   const UpArgs &a = c.up;
   constexpr uint32_t kTexel = RGB12 ? 12u : 16u;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(kUpBlock) void clip_up_write_v210_kernel(ClipUpArgs
   // the tile
   const uint32_t upr = (a.cover_w + kUpCols - 1u) / kUpCols, rps = (a.lines + 1u) / 2u;
   const uint32_t tyj = blockIdx.x / c.gx, tx = blockIdx.x - tyj * c.gx;
-  const uint32_t job = a.jobs > 1u ? tyj / c.gy : 0u, ty = tyj - job * c.gy;  // (uniform) several frames of one shape: rows of tiles job after job
+  const uint32_t job = MULTI ? tyj / c.gy : 0u, ty = tyj - job * c.gy;  // (uniform) several frames of one shape: rows of tiles job after job
   const uint32_t cu0 = tx * c.tcu, rp0 = ty * c.trp;
   const uint32_t ncu = cu0 + c.tcu <= upr ? c.tcu : upr - cu0, nrp = rp0 + c.trp <= rps ? c.trp : rps - rp0;
   char *const mine = c.scratch + (size_t)blockIdx.x * c.wg_bytes;
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(kUpBlock) void clip_up_write_v210_kernel(ClipUpArgs
 #pragma unroll 1
   for (int l = 0; l < a.n; ++l) {
     const UpLayer L = a.layer[l];
-    const ClipSrc S = c.src[a.jobs > 1u ? job : (uint32_t)l];  // (several jobs: single-layer frames, job j's clip in src[j])
+    const ClipSrc S = c.src[MULTI ? job : (uint32_t)l];  // (several jobs: single-layer frames, job j's clip in src[j])
     // the tile's first and last pixels (inside the frame: columns past out_w - the padding of a line with a tail - have no taps that count)
     const uint32_t x_first = cu0 * kUpCols, x_end = (cu0 + ncu) * kUpCols < a.out_w ? (cu0 + ncu) * kUpCols : a.out_w;
     const uint32_t li_last = 2u * (rp0 + nrp) < a.lines ? 2u * (rp0 + nrp) - 1u : a.lines - 1u;
@@ -646,10 +649,11 @@ __global__ __launch_bounds__(kUpBlock) void clip_up_write_v210_kernel(ClipUpArgs
 #else
   const uint32_t units = ncu * nrp;
 #endif
+  void *const frame = MULTI && job ? a.more_out[job - 1u] : a.out;  // (uniform: the tile's frame)
   for (uint32_t u = wave; u < units; u += kUpBlock / 64) {
     const uint32_t rp_in = ncu == 1u ? u : u / ncu, cu_in = u - rp_in * ncu;
     UpStep st;
-    clip_step(a, job, cu0 + cu_in, rp0 + rp_in, lane, st);
+    clip_step(a, 0u, cu0 + cu_in, rp0 + rp_in, lane, st);
     UpAcc acc[2][2];
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(kUpBlock) void clip_up_write_v210_kernel(ClipUpArgs
     } else {
       layers(std::false_type{}, std::false_type{});
     }
-    up_write<TAILS>(a, st, acc, role, wk, lk);
+    up_write<TAILS>(a, st, acc, role, wk, lk, frame);
   }
 }
 
@@ -736,17 +740,20 @@ hipError_t launch_clip_up_write_v210(hipStream_t s, const ClipUpArgs &c, bool rg
   if (c.up.jobs > 1u) snprintf(name, sizeof name, "clip_up_write_v210<%s>x%u", rgb12 ? "rgb" : "rgba", c.up.jobs);
   else snprintf(name, sizeof name, "clip_up_write_v210<%s>", rgb12 ? "rgb" : "rgba");
   if (trace_launch(name)) return hipSuccess;
-  const bool tails = c.up.out_w % 48u != 0;
-  const void *fn = tails ? (rgb12 ? reinterpret_cast<const void *>(clip_up_write_v210_kernel<true, true>) : reinterpret_cast<const void *>(clip_up_write_v210_kernel<false, true>))
-                         : (rgb12 ? reinterpret_cast<const void *>(clip_up_write_v210_kernel<true, false>) : reinterpret_cast<const void *>(clip_up_write_v210_kernel<false, false>));
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
-  if (e != hipSuccess) return e;
+  const bool tails = c.up.out_w % 48u != 0, multi = c.up.jobs > 1u;
   const uint32_t lds = c.info_off + 16u * (uint32_t)c.up.n;
-  if (tails && rgb12) clip_up_write_v210_kernel<true, true><<<grid, kUpBlock, lds, s>>>(c);
-  else if (tails) clip_up_write_v210_kernel<false, true><<<grid, kUpBlock, lds, s>>>(c);
-  else if (rgb12) clip_up_write_v210_kernel<true, false><<<grid, kUpBlock, lds, s>>>(c);
-  else clip_up_write_v210_kernel<false, false><<<grid, kUpBlock, lds, s>>>(c);
-  return hipGetLastError();
+  auto go = [&](auto kernel) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds);
+    if (e != hipSuccess) return e;
+    kernel<<<grid, kUpBlock, lds, s>>>(c);
+    return hipGetLastError();
+  };
+  if (multi) {
+    if (tails) return rgb12 ? go(clip_up_write_v210_kernel<true, true, true>) : go(clip_up_write_v210_kernel<false, true, true>);
+    return rgb12 ? go(clip_up_write_v210_kernel<true, false, true>) : go(clip_up_write_v210_kernel<false, false, true>);
+  }
+  if (tails) return rgb12 ? go(clip_up_write_v210_kernel<true, true, false>) : go(clip_up_write_v210_kernel<false, true, false>);
+  return rgb12 ? go(clip_up_write_v210_kernel<true, false, false>) : go(clip_up_write_v210_kernel<false, false, false>);
 }
 
 // Does the 2 x 2 block scheme apply?  Unrotated, unmirrored, MAGNIFIED in both directions (then the first taps of the two
