@@ -19,6 +19,7 @@ def main():
     stream = ctx.torch_stream()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     sw, sh, ow, oh, R = 1920, 1080, 3840, 2160, 6
+    NL = int(os.environ.get("PH_UP_LAYERS", "4"))  # layers of the compositor legs (the reader legs always take four windows)
     rd = [dev(capi.ycbcr2rgb_matrix("709")), dev(capi.gamma2linear_lut("709")), dev(np.concatenate([capi.rgb2rgb_matrix("709", "2020"), np.zeros(3, np.float32)]))]
     wr = [dev(capi.rgb2ycbcr_matrix("2020")), dev(capi.linear2gamma_lut("2020"))]
     torch.cuda.synchronize()
@@ -58,15 +59,15 @@ def main():
         res["deint_rgba_us_per_frame"] = timeit(lambda i: ctx.v210_yadif_pair([win(i, l) + (rgba[i & 1][l][0], rgba[i & 1][l][1]) for l in range(4)], sw, sh, 1, False, *rd))
         res["deint_rgb_us_per_frame"] = timeit(lambda i: ctx.v210_yadif_pair([win(i, l) + (rgb[i & 1][l][0], rgb[i & 1][l][1]) for l in range(4)], sw, sh, 1, False, *rd, rgb=True))
     if which in ("all", "compose"):
-        res["compose_px_rgba_us_per_field"] = timeit(lambda i: ctx.compose_write_v210([(rgba[i & 1][l][(i >> 1) & 1], sw, sh, md) for l in range(4)], out, ow, oh, 0, *wr))
-        jobs_a = [ctx.compose_up_write_v210([(rgba[s][l][p], sw, sh, mh) for l in range(4)], out, ow, oh, 0, *wr, prepare_only=True) for s in range(2) for p in range(2)]
+        res["compose_px_rgba_us_per_field"] = timeit(lambda i: ctx.compose_write_v210([(rgba[i & 1][l][(i >> 1) & 1], sw, sh, md) for l in range(NL)], out, ow, oh, 0, *wr))
+        jobs_a = [ctx.compose_up_write_v210([(rgba[s][l][p], sw, sh, mh) for l in range(NL)], out, ow, oh, 0, *wr, prepare_only=True) for s in range(2) for p in range(2)]
         res["compose_up_rgba_us_per_field"] = timeit(lambda i: jobs_a[i & 3]())
     if which in ("all", "compose", "up", "up_single"):  # up_single: one launch per field only (the counters of tools/pmc_kernel.sh are means per dispatch:
         # a two-field launch among them reads as write amplification - round 3's "36.7 MB for a 22.1 MB frame" was that)
-        jobs_b = [ctx.compose_up_write_v210([(rgb[s][l][p], sw, sh, mh) for l in range(4)], out, ow, oh, 0, *wr, rgb=True, prepare_only=True) for s in range(2) for p in range(2)]
+        jobs_b = [ctx.compose_up_write_v210([(rgb[s][l][p], sw, sh, mh) for l in range(NL)], out, ow, oh, 0, *wr, rgb=True, prepare_only=True) for s in range(2) for p in range(2)]
         res["compose_up_rgb_us_per_field"] = timeit(lambda i: jobs_b[i & 3]())
     if which in ("all", "compose", "up"):
-        pair_jobs = [ctx.compose_up_write_v210_pair([(rgb[s][l][0], sw, sh, mh) for l in range(4)], [(rgb[s][l][1], sw, sh, mh) for l in range(4)], out, out2,
+        pair_jobs = [ctx.compose_up_write_v210_pair([(rgb[s][l][0], sw, sh, mh) for l in range(NL)], [(rgb[s][l][1], sw, sh, mh) for l in range(NL)], out, out2,
                                                     ow, oh, 0, *wr, rgb=True, prepare_only=True) for s in range(2)]
         res["compose_up_rgb_pair_us_per_field"] = round(timeit(lambda i: pair_jobs[i & 1]()) / 2, 2)
     print(json.dumps(res), flush=True)
