@@ -68,13 +68,59 @@ async function main() {
 		rig.ctx.realise(o[0])
 		return f % ring.length === ring.length - 1 ? rig.ctx.drain() : undefined
 	}
-	for (let f = 0; f < 2000; ++f) await one(f)
+	// --interlaced: bench_node.js's PH_NODE_BENCH_INTERLACED tick (one channel): per source frame n new ToRGBA, then twice (send_field)
+	// n x (yadif -> transform) -> combine_n -> write; frames counts TICKS, us_per_frame is per tick (two output frames)
+	let tick = one
+	if (process.argv.includes('--interlaced')) {
+		const yadif = await rig.yadif(w, h)
+		const transform = await rig.transform(w, h)
+		const mat = await transform.matrix({})
+		const ring2 = [await rig.planes('v210', w, h, 'writeonly'), await rig.planes('v210', w, h, 'writeonly'), await rig.planes('v210', w, h, 'writeonly')]
+		const window = []
+		for (let l = 0; l < n; ++l) {
+			const three = []
+			for (let i = 0; i < 3; ++i) { const im = await rig.image(w, h); rig.post({ source: 'chan0', timestamp: -1 }, read(src[l], im)); three.push(im) }
+			window.push(three)
+		}
+		await rig.board.flush({ source: 'chan0', timestamp: -1 })
+		tick = async (f) => {
+			const slot = f % 3
+			const id = { source: 'chan0', timestamp: f }
+			const gone = []
+			for (let l = 0; l < n; ++l) {
+				const im = await rig.image(w, h)
+				rig.post(id, read(src[l], im))
+				gone.push(window[l].shift())
+				window[l].push(im)
+			}
+			for (const second of [0, 1]) {
+				const placed = []
+				for (let l = 0; l < n; ++l) {
+					const u = window[l]
+					const y = await rig.image(w, h)
+					rig.post(id, yadif(u[0], u[1], u[2], y, { parity: second ? 1 : 0, tff: 1, skipSpatial: 0 }))
+					const pl = await rig.image(w, h)
+					rig.post(id, transform(y, pl, mat), () => y.release())
+					placed.push(pl)
+				}
+				const cm = await rig.image(w, h)
+				rig.post(id, combine(placed, cm), () => placed.forEach((b) => b.release()))
+				rig.post(id, write(cm, (second ? ring2 : ring)[slot], 0), () => cm.release())
+			}
+			gone.forEach((b) => b.release())
+			await rig.board.flush(id)
+			rig.ctx.realise(ring[slot][0])
+			rig.ctx.realise(ring2[slot][0])
+			return slot === 2 ? rig.ctx.drain() : undefined
+		}
+	}
+	for (let f = 0; f < 2000; ++f) await tick(f)
 	for (const k of Object.keys(calls)) calls[k] = 0
 	const t0 = process.hrtime.bigint()
-	for (let f = 0; f < frames; ++f) await one(2000 + f)
+	for (let f = 0; f < frames; ++f) await tick(2000 + f)
 	const sec = Number(process.hrtime.bigint() - t0) / 1e9
 	const per = {}
 	for (const k of Object.keys(calls)) per[k] = +(calls[k] / frames).toFixed(2)
-	console.log(JSON.stringify({ bench: 'defer_host', deferred, width: w, height: h, layers: n, frames, us_per_frame: +(1e6 * sec / frames).toFixed(2), addon_calls_per_frame: per, stats: rig.ctx.deferredStats() || undefined }))
+	console.log(JSON.stringify({ bench: 'defer_host', interlaced: process.argv.includes('--interlaced') || undefined, deferred, width: w, height: h, layers: n, frames, us_per_frame: +(1e6 * sec / frames).toFixed(2), addon_calls_per_frame: per, stats: rig.ctx.deferredStats() || undefined }))
 }
 main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })
