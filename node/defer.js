@@ -64,6 +64,12 @@ class Deferral {
 		this.orderedAt = new Map() // `${waiter}<${signal}` -> the signal queue's launch count the waiter is ordered behind
 		this.stats = { recorded: 0, launched: 0, fused: 0, fusedNodes: 0, plain: 0, dropped: 0, fallbacks: 0, lastFallback: null }
 		this.packFields = process.env.PHANERON_PACK_FIELDS !== '0' // de-interlaced fields as packed RGB while only the compositor reads them (_deinterlace)
+		// PHANERON_FIELD_BATCH=1: the Yadif windows of ALL the channels of a tick in shared launches and their compositor frames four to a launch
+		// (round 6's first form).  Measured on four 1080i channels (profiles/r06_node_interlaced.jsonl): the eight-window reader launch gains
+		// 4 % on two of four, the four-frame compositor launch LOSES 33 % on two of two (113 against 2 x 42.5 us: eight 25 MB field images per
+		// channel pair and tick leave the 256 MB MALL before their reader has finished) - so the default is channel by channel, each
+		// channel's reader followed at once by its own two fields' compositor launch
+		this.fieldBatch = process.env.PHANERON_FIELD_BATCH === '1'
 		this.fieldTwin = new WeakMap() // a de-interlaced field image -> the other field of the same frame (set by the pair launch that made both)
 		// Terminal wire-format `write` jobs that are recorded and not launched yet.  When somebody asks for one of them, the others whose
 		// frames the same kernel can make in the same launch go with it (channels of one format in one context: src/index.ts:45-71).
@@ -116,12 +122,17 @@ class Deferral {
 		const ins = []
 		const outs = []
 		const names = Object.keys(params)
+		const kept = {} // the job's own copy of its parameters (the caller may reuse its object)
 		for (let k = 0; k < names.length; ++k) {
 			const v = params[names[k]]
-			if (!Buffer.isBuffer(v)) continue
-			if (!v._handle) throw new Error(`runProgram: parameter '${names[k]}' is a plain Buffer, not an OpenCLBuffer`)
+			kept[names[k]] = v
+			if (typeof v !== 'object' || v === null) continue // (scalars: most of a job's parameters)
+			if (!v._handle) { // a matrix (typed array) - or a plain Buffer, which is refused
+				if (Buffer.isBuffer(v)) throw new Error(`runProgram: parameter '${names[k]}' is a plain Buffer, not an OpenCLBuffer`)
+				continue
+			}
 			if (v._dead) throw new Error('runProgram: a buffer argument has already been released')
-			Deferral.adopt(v)
+			if (v._readers === undefined) Deferral.adopt(v)
 			pushNew(isOutputArg(names[k]) ? outs : ins, v)
 		}
 		// what runProgram would refuse - a missing argument, a buffer too small for the frame - is refused here, with the same
@@ -131,7 +142,7 @@ class Deferral {
 			this._launch(program, params, queue, true)
 			program._checked = this._signature(names, params, queue)
 		}
-		const node = { program, params: Object.assign({}, params), queue, ins, outs, state: 'pending' }
+		const node = { program, params: kept, queue, ins, outs, state: 'pending', timings: null }
 		for (let k = 0; k < ins.length; ++k) { const b = ins[k]; this._hold(b); if (b._readers === NONE) b._readers = [node]; else b._readers.push(node) }
 		for (let k = 0; k < outs.length; ++k) if (!ins.includes(outs[k])) this._hold(outs[k])
 		// a buffer this job overwrites: whoever still wants its present (or pending) contents goes first.  A pending producer is
@@ -140,7 +151,9 @@ class Deferral {
 		// (The job holds its buffers and is registered as their reader BEFORE this - dropping a displaced producer lets go of recipes
 		// nobody reads, and this job's own operands must not be among them - so a failure here, e.g. the stored error of an unrelated
 		// job that one of the displaced ones depended on, has to undo that: ADVICE r4.)
-		const whole = WHOLE_OUTPUT.test(program.name) && !params.interlace
+		// (asked once per program; not enumerable, so that a program object copied under another name asks again)
+		if (program._whole === undefined) Object.defineProperty(program, '_whole', { value: WHOLE_OUTPUT.test(program.name), enumerable: false })
+		const whole = program._whole && !params.interlace
 		try {
 			for (let k = 0; k < outs.length; ++k) {
 				const o = outs[k]
@@ -311,16 +324,24 @@ class Deferral {
 		const plans = []
 		let failure = null
 		try {
-			if (nodes.length > 2) this._deinterlaceAhead(nodes) // (two: the fields of one frame - their windows are one launch anyway)
+			if (nodes.length > 2 && this.fieldBatch) this._deinterlaceAhead(nodes) // (two: the fields of one frame - their windows are one launch anyway)
+			const covered = new Set() // writes that another plan's launch makes along with its own (the other field of a de-interlaced frame)
 			for (const n of nodes) {
-				if (n.state !== 'pending') continue
+				if (n.state !== 'pending' || covered.has(n)) continue
 				let plan = null
 				try { plan = this._plan(n) } catch (e) { if (n === must) failure = e; continue }
-				if (plan) plans.push(plan)
+				if (!plan) continue
+				// a de-interlaced frame's two fields (planning has just launched its windows' reader): their compositor launch follows at
+				// once, while the fields are still in the cache - not after the other channels' readers (fieldBatch: see the constructor)
+				const twin = plan.up && !this.fieldBatch && plan.candidates[0][2]
+				if (twin) { // (the other field's write is done with it - or still pending, and planned next)
+					if (this._fresh(plan) && !this._commit(plan) && plan.node === must) this._plain(plan.node)
+					continue
+				}
+				plans.push(plan)
 			}
 			// groups of plans one launch can take
 			const groups = []
-			const covered = new Set() // writes that another plan's launch makes along with its own (the other field of a de-interlaced frame)
 			for (const p of plans) {
 				if (covered.has(p.node)) continue
 				if (!p.batchable || !this.ctx._native.runPrograms) { groups.push([p]); continue }

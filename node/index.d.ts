@@ -101,6 +101,9 @@ export class clContext {
 	createBuffer(numBytes: number, bufDir: BufDir, bufType: BufSVMType, imageDims?: ImageDims, owner?: string): Promise<OpenCLBuffer>
 	createProgram(kernel: string, options: { name: string; globalWorkItems?: number | Uint32Array | number[]; workItemsPerGroup?: number }): Promise<OpenCLProgram>
 	runProgram(program: OpenCLProgram, params: KernelParams, queue?: number): Promise<RunTimings>
+	/** Recording contexts only: runProgram without the promise (node/jobs.js uses it per job of a batch).  null = not a recording
+	 *  context, or a `profile` one - call runProgram; throws what runProgram would reject with. */
+	recordProgram(program: OpenCLProgram, params: KernelParams, queue?: number): RunTimings | null
 	waitFinish(queue?: number): Promise<void>
 	/** deferred contexts: make these buffers' contents real now, as a consumer on the device would need them */
 	realise(...bufs: OpenCLBuffer[]): void

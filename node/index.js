@@ -79,7 +79,7 @@ function free() {
 		}
 		if (park.parked + this.length <= room) {
 			let list = park.lists.get(this._parkKey)
-			if (!list) park.lists.set(this._parkKey, (list = []))
+			if (!list) { park.lists.set(this._parkKey, (list = [])); park.newest = this._parkKey } // (a new key goes in last)
 			list.push(this)
 			park.parked += this.length
 			park.count++
@@ -106,7 +106,8 @@ function bufferPrototype(native, deferral, park) {
 		downloadAsync: { value: downloadAsync }, _free: { value: free }, _native: { value: native }, _deferral: { value: deferral }, _park: { value: park }
 	})
 }
-const newPark = (on, budgetMb) => ({ on, lists: new Map(), parked: 0, count: 0, live: 0, peak: 0, budget: budgetMb * 1048576 })
+const newPark = (on, budgetMb) => ({ on, lists: new Map(), parked: 0, count: 0, live: 0, peak: 0, budget: budgetMb * 1048576,
+	newest: null /* the key that is last in `lists` */, memo: { bytes: -1, w: 0, h: 0, dir: '', type: '', key: '' } })
 function makeOpenCLBuffer(proto, created, numBytes, imageDims, owner, deferral, parkKey) {
 	const buf = created.buffer
 	Object.setPrototypeOf(buf, proto)
@@ -183,12 +184,21 @@ class clContext {
 		const h = imageDims ? imageDims.height : 0
 		// frames and images (not parameter buffers: a gamma table's registered LDS form goes with its native buffer) may be parked ones
 		const park = this._park
-		const key = park.on && (imageDims || numBytes >= 1048576) ? `${numBytes}|${w}|${h}|${bufDir}|${bufType}` : null
+		// (the key of the call before is kept: a channel asks for the same shape five to ten times a frame)
+		let key = null
+		if (park.on && (imageDims || numBytes >= 1048576)) {
+			const m = park.memo
+			if (m.bytes === numBytes && m.w === w && m.h === h && m.dir === bufDir && m.type === bufType) key = m.key
+			else {
+				key = `${numBytes}|${w}|${h}|${bufDir}|${bufType}`
+				m.bytes = numBytes; m.w = w; m.h = h; m.dir = bufDir; m.type = bufType; m.key = key
+			}
+		}
 		if (key) {
 			park.live += numBytes
 			if (park.live > park.peak) park.peak = park.live
 			const list = park.lists.get(key)
-			if (list && park.lists.size > 1) { park.lists.delete(key); park.lists.set(key, list) } // most recently used last
+			if (list && park.lists.size > 1 && park.newest !== key) { park.lists.delete(key); park.lists.set(key, list); park.newest = key } // most recently used last
 			if (list && list.length) {
 				const buf = list.pop()
 				park.parked -= numBytes
@@ -219,6 +229,7 @@ class clContext {
 		if (!park) return
 		for (const list of park.lists.values()) for (const buf of list) this._native.bufRelease(buf._handle)
 		park.lists.clear()
+		park.newest = null
 		park.parked = 0
 		park.count = 0
 	}
@@ -233,6 +244,15 @@ class clContext {
 		// which wire format a `read` / `write` is for: the recording layer recognises the v210 ends of a channel's chain
 		if (this._deferral && (options.name === 'read' || options.name === 'write')) program.format = native.resolveProgram(String(kernel), options.name).format
 		return program
+	}
+
+	// The recording context's runProgram without the promise: node/jobs.js posts a batch's jobs one after another and an `await` per
+	// job is a microtask turn each (24 a tick on a 1080i channel).  null = not a recording context, or a `profile` one whose terminal
+	// write has to be launched and timed (runProgram does that); throws what runProgram would reject with.
+	recordProgram(program, params, queue) {
+		if (!this._deferral || this.profile) return null
+		this._need()
+		return this._deferral.record(program, params, queue === undefined ? this.queue.process : queue)
 	}
 
 	async runProgram(program, params, queue) {

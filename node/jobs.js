@@ -77,7 +77,11 @@ class JobBoard {
 			const q = this.ctx.queue.process
 			for (const f of batch) {
 				try {
-					for (const j of f.jobs) { await this.ctx.runProgram(j.program, j.params, q); this.stats.kernels++ }
+					for (const j of f.jobs) {
+						// (a recording context takes the job without a promise: clContext.recordProgram)
+						if (!this.ctx.recordProgram || this.ctx.recordProgram(j.program, j.params, q) === null) await this.ctx.runProgram(j.program, j.params, q)
+						this.stats.kernels++
+					}
 				} catch (e) { f.error = e }
 			}
 			let drainError = null

@@ -148,9 +148,10 @@ async function channels(frames, w, h) {
 		}
 		for (let c = 0; c < C; ++c) await rig.board.flush({ source: `chan${c}`, timestamp: -1 })
 	}
+	let waited = 0, waits = 0 // the host held up by the device: the ring's slot (three ticks back) not yet written
 	const oneInterlaced = async (f) => {
 		const slot = f % 3
-		if (slotDone[slot] && !slotDone[slot].done()) await slotDone[slot].wait()
+		if (slotDone[slot] && !slotDone[slot].done()) { const w0 = process.hrtime.bigint(); await slotDone[slot].wait(); waited += Number(process.hrtime.bigint() - w0); waits++ }
 		const ids = []
 		for (let c = 0; c < C; ++c) {
 			const id = { source: `chan${c}`, timestamp: f }
@@ -226,7 +227,10 @@ async function channels(frames, w, h) {
 	await rig.ctx.drain()
 	const sec = Number(process.hrtime.bigint() - t0) / 1e9
 	if (dry) rig.ctx._native.traceEnd()
+	// PH_NODE_BENCH_TRACE=1: the launches one more tick makes, by name (ph_trace_begin: live)
+	if (process.env.PH_NODE_BENCH_TRACE === '1' && !dry) { rig.ctx._native.traceBegin(false); await one(10 + frames); await rig.ctx.drain(); console.log(JSON.stringify({ tick_launches: rig.ctx._native.traceEnd() })) }
 	console.log(JSON.stringify({ bench: 'node', mode: 'channels', host_only_dry_run: dry || undefined, shape: interlaced ? `${n} x 1080i sources -> yadif (send_field) -> own size -> combine_${n}: two output frames per tick` : file ? `file playback: one ${file[0]}x${file[1]} yuv420p clip under the default fill` : plain ? 'plain reads' : 'config 2', channels: C,
+		slot_wait_us_per_tick: interlaced ? +(waited / 1e3 / frames).toFixed(1) : undefined, slot_waits: interlaced ? waits : undefined,
 		us_per_field: interlaced ? +(1e6 * sec / frames / C / 2).toFixed(1) : undefined, pack_fields: interlaced ? process.env.PHANERON_PACK_FIELDS !== '0' : undefined, early_launch: rig.ctx.earlyLaunch, width: w, height: h, layers: n, frames, channel_frames_per_sec: +(C * frames / sec).toFixed(1),
 		us_per_frame: +(1e6 * sec / frames / C).toFixed(1), us_per_tick: +(1e6 * sec / frames).toFixed(1), deferred: rig.ctx.deferredStats(),
 		buffers: rig.ctx.bufferStats() }))

@@ -235,7 +235,8 @@ for (const moved of [false, true]) {
 	r.d.touch(outs[0], 'readonly', 2)
 	// (the pair launch wrote the fields packed - the frame was the 2 x 2-block compositor's to make; when somebody else takes them they are unpacked first)
 	expect('refused fused launches: the field unpacked, then the jobs as recorded', r.names(), ['v210_yadif_pair_1', 'rgb_unpack', 'transform', 'write', 'rgb_unpack']) // (the last one: the other field's frame was tried along with this one)
-	expect('fallbacks counted: the pair form, the single form, the channel kernel - and the other field\'s frame, tried along with the one asked for, likewise', r.d.stats.fallbacks, 6)
+	// (the other field's frame is planned after the first has been made as recorded: no pair form left for it - its single form and the channel kernel)
+	expect('fallbacks counted: the pair form, the single form, the channel kernel - and the other field\'s frame, tried along with the one asked for: two more', r.d.stats.fallbacks, 5)
 	r.d.touch(outs[1], 'readonly', 2)
 	expect('the other field: as recorded too', r.names().slice(5), ['transform', 'write'])
 }
@@ -459,7 +460,9 @@ for (const moved of [false, true]) {
 			[r5.names(), rows.map((t) => t.kernelExec)], [['chan_compose_v210_1'], [37, 25, 38]])
 		// two channels of 1080i sources posting their field pairs in one tick: their Yadif windows share ONE launch of the de-interlacing reader
 		// (the reference's four channels are all 1080i: src/index.ts:45-71), then each channel's two frames are one compositor launch
+		// (PHANERON_FIELD_BATCH=1's form: r6, r7; the default - channel by channel, each reader followed at once by its two fields' compositor launch - r8)
 		const r6 = rig({ early: true })
+		r6.d.fieldBatch = true
 		const L6 = r6.loader()
 		const m6 = r6.enlarging()
 		const outs6 = []
@@ -478,6 +481,7 @@ for (const moved of [false, true]) {
 		// the same on an addon with runPrograms: the two channels' compositor jobs (each both fields of its frame) go down in ONE call -
 		// the library makes the four frames in one launch (ph_compose_up_write_v210_batch)
 		const r7 = rig({ early: true, batch: true })
+		r7.d.fieldBatch = true
 		const L7 = r7.loader()
 		const m7 = r7.enlarging()
 		for (const ch of [0, 1]) {
@@ -490,7 +494,23 @@ for (const moved of [false, true]) {
 				r7.d.record(r7.P.write, Object.assign({ input: t, output: r7.v210(`c${ch}out${parity}`), width: r7.W, interlace: 0 }, r7.saver), 1)
 			}
 		}
+		const r8 = rig({ early: true, batch: true })
+		const L8 = r8.loader()
+		const m8 = r8.enlarging()
+		for (const ch of [0, 1]) {
+			const win = [0, 1, 2].map((i) => { const im = r8.image(`c${ch}w${i}`); r8.d.record(r8.P.read, Object.assign({ input: r8.v210(`c${ch}s${i}`), output: im, width: r8.W }, L8), 1); return im })
+			for (const parity of [0, 1]) {
+				const y = r8.image(`c${ch}y${parity}`)
+				r8.d.record(r8.P.yadif, { prev: win[0], cur: win[1], next: win[2], parity, tff: 1, skipSpatial: 0, output: y }, 1)
+				const t = r8.image(`c${ch}t${parity}`)
+				r8.d.record(r8.P.transform, { input: y, transformMatrix: m8, output: t }, 1)
+				r8.d.record(r8.P.write, Object.assign({ input: t, output: r8.v210(`c${ch}out${parity}`), width: r8.W, interlace: 0 }, r8.saver), 1)
+			}
+		}
 		setImmediate(() => {
+			expect('two 1080i channels in one tick, the default: channel by channel - its windows\' reader, then at once its two fields in one compositor launch',
+				[r8.names(), r8.d.stats.unpacked || 0, Array.from(r8.d.pending).filter((n) => n.program.name === 'write').length],
+				[['v210_yadif_pair_1', 'compose_up_write_v210_1', 'v210_yadif_pair_1', 'compose_up_write_v210_1'], 0, 0])
 			expect('two 1080i channels in one tick: one reader launch for both windows, one compositor launch per channel (both fields)',
 				r6.names(), ['v210_yadif_pair_2', 'compose_up_write_v210_1', 'compose_up_write_v210_1'])
 			const b7 = r7.launches.find((l) => l[0].startsWith('batch'))
