@@ -140,7 +140,7 @@ $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
 $ROOT/tools/mfma_probe 2>/dev/null | grep -v '"probe": "step"' > $OUT/${TAG}_mfma_probe.jsonl
 [ -f $ROOT/tools/_variants/libphaneron_hip_clip6.so ] && (cd $ROOT && bash tools/r06_clip_ablate.sh) > $OUT/${TAG}_clip_ablate.txt 2>&1
 node $ROOT/node/test/soak_run.js 100000 2>/dev/null | grep '^{' > $OUT/${TAG}_node_soak.json
-(node $ROOT/node/test/napi_costs.js 1920 1080; node $ROOT/node/test/napi_costs.js 3840 2160; node $ROOT/node/test/defer_host_bench.js 20000; node $ROOT/node/test/defer_host_bench.js 20000 --plain) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_host_costs.jsonl
+(node $ROOT/node/test/napi_costs.js 1920 1080; node $ROOT/node/test/napi_costs.js 3840 2160; node $ROOT/node/test/defer_host_bench.js 20000; node $ROOT/node/test/defer_host_bench.js 20000 --plain; node $ROOT/node/test/defer_host_bench.js 8000 1920 1080 4 --interlaced) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_host_costs.jsonl
 # the recording context (node/defer.js) against the launch-as-posted one: scenarios, frames compared byte for byte, launch counters
 (node $ROOT/node/test/defer_run.js; node $ROOT/node/test/defer_run.js 1920 64) 2>/dev/null | grep '^{' > $OUT/${TAG}_defer_run.jsonl
 node $ROOT/node/test/defer_fuzz.js 100 400 120 2>/dev/null | grep '^{' > $OUT/${TAG}_defer_fuzz.jsonl
