@@ -138,7 +138,7 @@ $ROOT/tools/microbench 2>/dev/null | grep '^{' > $OUT/${TAG}_microbench.jsonl
 # round 6: the matrix pipe priced (tools/mfma_probe.hip) and the one-launch clip kernel's phases (timing builds, if the snapshot brought them)
 [ -x $ROOT/tools/mfma_probe ] || hipcc --offload-arch=gfx950 -O3 -o $ROOT/tools/mfma_probe $ROOT/tools/mfma_probe.hip > /dev/null 2>&1
 $ROOT/tools/mfma_probe 2>/dev/null | grep -v '"probe": "step"' > $OUT/${TAG}_mfma_probe.jsonl
-[ -f $ROOT/tools/_variants/libphaneron_hip_clip6.so ] && (cd $ROOT && bash tools/r06_clip_ablate.sh) > $OUT/${TAG}_clip_ablate.txt 2>&1
+# (the clip kernel's phase prices, profiles/r06_clip_ablate.txt, come from timing builds: tools/r06_clip_ablate.sh after building the clip1/2/4/6 variants - not part of this run)
 node $ROOT/node/test/soak_run.js 100000 2>/dev/null | grep '^{' > $OUT/${TAG}_node_soak.json
 (node $ROOT/node/test/napi_costs.js 1920 1080; node $ROOT/node/test/napi_costs.js 3840 2160; node $ROOT/node/test/defer_host_bench.js 20000; node $ROOT/node/test/defer_host_bench.js 20000 --plain; node $ROOT/node/test/defer_host_bench.js 8000 1920 1080 4 --interlaced) 2>/dev/null | grep '^{' > $OUT/${TAG}_node_host_costs.jsonl
 # the recording context (node/defer.js) against the launch-as-posted one: scenarios, frames compared byte for byte, launch counters
