@@ -15,8 +15,9 @@ const TICKS = parseInt(process.argv[4] || '12')
 const W = parseInt(process.argv[5] || '384')
 const H = parseInt(process.argv[6] || '54')
 const problems = []
+const routes = process.env.PH_FUZZ_ROUTES === '1' ? new Map() : null // PH_FUZZ_ROUTES=1: count the recording context's launches by kernel
 function rng(seed) { let s = (seed * 2654435761) >>> 0; return () => (s = (Math.imul(s ^ (s >>> 15), 0x2c1b3c6d) + 0x9e3779b9) >>> 0) }
-const SHAPES = ['plain', 'fill', 'fill', 'small', 'small', 'pip', 'graphic']
+const SHAPES = ['plain', 'fill', 'fill', 'small', 'small', 'pip', 'graphic', 'deint', 'deint']
 const CLIPS = ['v210', 'v210', 'yuv420p', 'yuv422p10', 'nv12']
 
 async function play(seed, deferred) {
@@ -27,6 +28,7 @@ async function play(seed, deferred) {
 	const sh = H / 2 + ((H / 2) & 1)
 	const S = { read: {}, transform: await rig.transform(W, H), write: await rig.pack('v210', W, H, '709', false), writeField: await rig.pack('v210', W, H, '709', true), combine: {} }
 	for (const n of [2, 3]) S.combine[n] = await rig.combine(n, W, H)
+	S.yadif = await rig.yadif(W, H)
 	for (const f of ['v210', 'yuv420p', 'yuv422p10', 'nv12', 'bgra8']) {
 		S.read[`${f}|full`] = await rig.unpack(f, W, H, '709', '709')
 		S.read[`${f}|small`] = await rig.unpack(f, sw, sh, '709', '709')
@@ -45,6 +47,7 @@ async function play(seed, deferred) {
 		return planes
 	}
 	const seen = []
+	if (deferred && routes) rig.ctx.traceBegin(false) // (ph_trace_begin: which kernels the recording context's launches were)
 	for (let t = 0; t < TICKS; ++t) {
 		const C = 1 + r() % 6
 		const ids = []
@@ -61,6 +64,43 @@ async function play(seed, deferred) {
 				const pl = await rig.image(W, H)
 				rig.post(id, S.transform(im, pl, matrix), () => im.release())
 				layers.push(pl)
+			}
+			if (shape === 'deint') {
+				// the reference's own channel kind (src/index.ts:45-71): 1 - 3 interlaced v210 sources, each a Yadif window of three frames giving
+				// both fields (send_field: yadif.ts:100-145), every field placed and combined and written - TWO output frames for the tick
+				const n = 1 + r() % 3
+				const fields = [[], []]
+				for (let l = 0; l < n; ++l) {
+					const win = []
+					for (let i = 0; i < 3; ++i) {
+						const planes = await source('v210', 'full')
+						const im = await rig.image(W, H)
+						rig.post(id, S.read['v210|full'](planes, im), () => planes.forEach((p) => p.release()))
+						win.push(im)
+					}
+					const m = l === 0 || r() % 2 ? fillM : pick([smallFill, ...insets])
+					for (const parity of [0, 1]) {
+						const y = await rig.image(W, H)
+						rig.post(id, S.yadif(win[0], win[1], win[2], y, { parity, tff: 1, skipSpatial: r() % 4 === 0 ? 1 : 0 }), parity ? () => win.forEach((b) => b.release()) : undefined)
+						const pl = await rig.image(W, H)
+						rig.post(id, S.transform(y, pl, m), () => y.release())
+						fields[parity].push(pl)
+					}
+				}
+				for (const parity of [0, 1]) {
+					let frame = fields[parity][0]
+					if (n > 1) {
+						frame = await rig.image(W, H)
+						const these = fields[parity]
+						rig.post(id, S.combine[n](these, frame), () => these.forEach((b) => b.release()))
+					}
+					const out = (await rig.planes('v210', W, H, 'writeonly'))[0]
+					const last = frame
+					rig.post(id, S.write(last, [out], 0), () => last.release())
+					outs.push(out)
+				}
+				ids.push(id)
+				continue
 			}
 			if (shape === 'plain') { const n = 1 + r() % 3; for (let l = 0; l < n; ++l) await add('v210', 'full', null) }
 			else if (shape === 'fill') await add(pick(CLIPS), 'full', fillM)
@@ -90,6 +130,7 @@ async function play(seed, deferred) {
 		for (const i of order) { await rig.sync(); await rig.download(outs[i]); seen.push(Buffer.from(outs[i])); outs[i].release() }
 	}
 	await rig.ctx.drain()
+	if (deferred && routes) for (const k of rig.ctx.traceEnd().split('+')) if (k) routes.set(k.replace(/x\d+$/, 'xN'), (routes.get(k.replace(/x\d+$/, 'xN')) || 0) + 1)
 	const st = rig.ctx.flushDeferred ? rig.ctx.deferredStats() : null
 	rig.close()
 	if (rig.ctx.flushDeferred) rig.ctx.flushDeferred()
@@ -111,6 +152,6 @@ async function main() {
 		if (b.st) for (const k of Object.keys(total)) total[k] += b.st[k] || 0
 		if (b.st && b.st.fallbacks) problems.push({ seed, what: `fallback: ${b.st.lastFallback}` })
 	}
-	process.stdout.write(JSON.stringify({ first, seeds, ticks: TICKS, width: W, height: H, problems: problems.slice(0, 8), deferred: total }) + '\n')
+	process.stdout.write(JSON.stringify({ first, seeds, ticks: TICKS, width: W, height: H, problems: problems.slice(0, 8), deferred: total, routes: routes ? Object.fromEntries([...routes].sort((a, b) => b[1] - a[1])) : undefined }) + '\n')
 }
 main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })
