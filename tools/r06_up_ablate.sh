@@ -3,7 +3,8 @@
 # profiles/r06_up_ablate_experiment.patch to phaneron_amd/csrc/ph_kernels_up.hip (its hunks are the successive experiments; each is
 # guarded by a macro), build a variant per macro -
 #   python -c "from phaneron_amd import build; build.build(variant='upab6', extra_flags=['-DPH_UP_ABLATE=6'])"
-# (PH_UP_ABLATE=1..7, PH_UP_PLAIN_STORE, PH_UP_NO_STORE, PH_UP_PRIO=1|2, PH_UP_SLEEP=<n> [PH_UP_SLEEP_PRIO=<p>], PH_UP_PIPE) - and run:
+# (PH_UP_ABLATE=1..7, PH_UP_PLAIN_STORE, PH_UP_NO_STORE, PH_UP_PRIO=1|2, PH_UP_PIPE; the late-start experiment was three lines after the
+# table's barrier - `if ((wave >> 2) & 1) __builtin_amdgcn_s_sleep(N);` - and is not in the patch) - and run:
 #   bash tools/r06_up_ablate.sh "upab1 upab6 pipe" [layers ...]
 # prints tools/up_bench.py's compositor legs for the product library and each named variant, by layer count.
 VARIANTS=${1:-}
