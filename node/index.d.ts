@@ -92,9 +92,11 @@ export class clContext {
 	 * `profile` on a deferred context: a frame's terminal `write` is launched where it is posted and returns the fused launch's device time.
 	 * `earlyLaunch` (default false; PHANERON_EARLY_LAUNCH=1): launch a frame at the end of the tick that posted its terminal `write`.
 	 * `recycleBuffers` (default true; PHANERON_RECYCLE=0): released frames / images are parked for the next createBuffer of their shape,
-	 * up to `parkMb` MiB (default 4096) or the most that was ever in use at once. */
+	 * up to `parkMb` MiB (default 4096) or the most that was ever in use at once.  A parked buffer is taken over as the same JS object;
+	 * `strictHandles` (default false; PHANERON_STRICT_HANDLES=1): a fresh object per takeover, so that a reference kept past release()
+	 * is refused ('... released buffer') instead of aliasing the next owner's buffer - for running an application under test. */
 	constructor(params?: { platformIndex?: number; deviceIndex?: number; overlapping?: boolean; profile?: boolean; spinWaitMicros?: number; deferred?: boolean;
-		earlyLaunch?: boolean; recycleBuffers?: boolean; parkMb?: number })
+		earlyLaunch?: boolean; recycleBuffers?: boolean; parkMb?: number; strictHandles?: boolean })
 	readonly queue: { load: number; process: number; unload: number }
 	initialise(): Promise<void>
 	getPlatformInfo(): PlatformInfo

@@ -125,6 +125,19 @@ function makeOpenCLBuffer(proto, created, numBytes, imageDims, owner, deferral, 
 	return buf
 }
 
+// strictHandles (createBuffer): a parked buffer's block, mirror and native handle under a fresh JS object; the old one keeps `_dead`
+function rewrap(proto, old) {
+	const buf = Buffer.from(old.buffer, old.byteOffset, old.length) // (a view of the same memory: the addon's finalizer hangs on the ArrayBuffer)
+	Object.setPrototypeOf(buf, proto)
+	buf._handle = old._handle
+	buf._parkKey = old._parkKey
+	buf._gen = old._gen
+	buf._unsettled = false
+	buf.numBytes = old.numBytes
+	old._handle = null
+	return buf
+}
+
 class clContext {
 	constructor(params) {
 		params = params || {}
@@ -150,6 +163,10 @@ class clContext {
 		// (default 4096 MiB - or as much as was ever in use at once, if that is more)
 		this.recycleBuffers = params.recycleBuffers === undefined ? process.env.PHANERON_RECYCLE !== '0' : !!params.recycleBuffers
 		this.parkMb = params.parkMb === undefined ? 4096 : params.parkMb
+		// a parked buffer is taken over as the SAME JS object (0.1 us): a reference its previous owner kept past release() then aliases the new
+		// owner's buffer.  strictHandles: true / PHANERON_STRICT_HANDLES=1 hands out a fresh object per takeover (+ ~1 us) and keeps the old one
+		// refused for good - for running an application under test
+		this.strictHandles = params.strictHandles === undefined ? process.env.PHANERON_STRICT_HANDLES === '1' : !!params.strictHandles
 		this._addon = params.addon || null // tests: a stand-in for the N-API addon (node/test/defer_host_bench.js counts the calls the JS layer makes)
 		this.queue = this.overlapping ? { load: 0, process: 1, unload: 2 } : { load: 1, process: 1, unload: 1 }
 		this._ctx = null
@@ -200,7 +217,7 @@ class clContext {
 			const list = park.lists.get(key)
 			if (list && park.lists.size > 1 && park.newest !== key) { park.lists.delete(key); park.lists.set(key, list); park.newest = key } // most recently used last
 			if (list && list.length) {
-				const buf = list.pop()
+				let buf = list.pop()
 				park.parked -= numBytes
 				park.count--
 				// Taken over whole, without a call into the library - unless its mirror or a ROUTE transfer may still be busy with it: a
@@ -208,6 +225,9 @@ class clContext {
 				// owner's fill, RCCL may still be reading the device block on the communication stream, and a mirror the previous owner
 				// filled but never handed back would be uploaded over the next owner's frame.  ph_buf_reuse settles all three (ADVICE r5).
 				if (buf._unsettled) { native.bufReuse(buf._handle); buf._unsettled = false }
+				// strictHandles: the next owner gets a NEW object over the same memory and the parked one stays dead - a reference the previous
+				// owner kept is then refused ('... already released') as nodencl's are, instead of aliasing the new owner's buffer (ADVICE r5)
+				if (this.strictHandles) buf = rewrap(this._bufferProto, buf)
 				buf._gen = (buf._gen || 0) + 1
 				buf._refs = 1
 				buf._dead = false

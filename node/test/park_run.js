@@ -55,6 +55,24 @@ async function main() {
 	f.release()
 	d.release()
 	ctx.trim()
+	// (c) strictHandles: a fresh object per takeover; what the previous owner still holds is refused as a released nodencl buffer is
+	const strict = new clContext({ deviceIndex: 0, strictHandles: true })
+	await strict.initialise()
+	const g = await strict.createBuffer(bytes, 'readwrite', 'coarse', undefined, 'first owner')
+	await g.hostAccess('writeonly', strict.queue.load, fill(0x44))
+	await strict.drain(strict.queue.load)
+	g.release()
+	const h = await strict.createBuffer(bytes, 'readwrite', 'coarse', undefined, 'second owner')
+	let msgs = []
+	try { g.release() } catch (e) { msgs.push(e.message) }
+	try { await g.hostAccess('readonly', strict.queue.unload) } catch (e) { msgs.push(/released/.test(e.message)) }
+	expect('strictHandles: another object over the parked block; the stale one is refused', [h !== g, h.refCount(), msgs], [true, 1, ['release on a released buffer', true]])
+	await h.hostAccess('readonly', strict.queue.unload)
+	let kept = 0
+	for (let i = 0; i < bytes; i += 4099) if (h[i] !== 0x44) ++kept
+	expect('strictHandles: it IS the parked block (the first owner\'s bytes are still on the device)', kept, 0)
+	h.release()
+	strict.trim()
 	console.log(JSON.stringify({ checks, problems, reuses }))
 }
 main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })
