@@ -17,7 +17,9 @@ const H = parseInt(process.argv[6] || '54')
 const problems = []
 const routes = process.env.PH_FUZZ_ROUTES === '1' ? new Map() : null // PH_FUZZ_ROUTES=1: count the recording context's launches by kernel
 function rng(seed) { let s = (seed * 2654435761) >>> 0; return () => (s = (Math.imul(s ^ (s >>> 15), 0x2c1b3c6d) + 0x9e3779b9) >>> 0) }
-const SHAPES = ['plain', 'fill', 'fill', 'small', 'small', 'pip', 'graphic', 'deint', 'deint']
+// PH_FUZZ_NO_DEINT=1: progressive shapes only - every one of those folds into a fused launch (deferred.plain stays 0); a 1080i channel whose
+// two fields disagree on skipSpatial, or whose placement shrinks or turns the picture, runs its Yadif jobs as recorded
+const SHAPES = process.env.PH_FUZZ_NO_DEINT === '1' ? ['plain', 'fill', 'fill', 'small', 'small', 'pip', 'graphic'] : ['plain', 'fill', 'fill', 'small', 'small', 'pip', 'graphic', 'deint', 'deint']
 const CLIPS = ['v210', 'v210', 'yuv420p', 'yuv422p10', 'nv12']
 
 async function play(seed, deferred) {

@@ -720,13 +720,23 @@ def test_random_multi_channel_ticks_equal_the_launch_as_posted_context():
     """node/test/channels_fuzz.js: per tick 1 - 6 channels post a frame each - plain reads, clips under the default fill (v210 and decoders'
     planar frames), clips smaller than the channel, picture-in-picture, graphics with alpha - and the tick goes to the device as one
     runPrograms call: batch kernel, headline batch, read + compositor route (alone and grouped), jobs in their turn, in every order the
-    seeds produce.  Every consumer's frame equals the launch-as-posted context's; nothing refused, nothing left"""
+    seeds produce.  Every consumer's frame equals the launch-as-posted context's; nothing refused, nothing left.  Progressive shapes only:
+    every frame folds (no job runs as recorded).  Then with 1080i channels among them (1 - 3 Yadif windows, both fields' frames: the
+    de-interlacing reader + the 2 x 2-block compositor where the fields agree, the recorded jobs where they do not), in both orders
+    node/defer.js knows for them (channel by channel; PHANERON_FIELD_BATCH=1: the channels' windows and frames in shared launches)"""
     _build_addon()
-    r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "channels_fuzz.js"), "1", "24", "10"], capture_output=True, text=True, timeout=900)
+    fuzz = [NODE, os.path.join(ROOT, "node", "test", "channels_fuzz.js")]
+    r = subprocess.run(fuzz + ["1", "24", "10"], capture_output=True, text=True, timeout=900, env=dict(os.environ, PH_FUZZ_NO_DEINT="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["problems"] == [], res["problems"][:4]
     assert res["deferred"]["fallbacks"] == 0 and res["deferred"]["plain"] == 0 and res["deferred"]["batched"] > res["deferred"]["launched"]
+    for extra in ({"PH_FUZZ_ROUTES": "1"}, {"PH_FUZZ_ROUTES": "1", "PHANERON_FIELD_BATCH": "1"}):
+        r = subprocess.run(fuzz + ["101", "12", "10"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **extra))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        assert res["problems"] == [] and res["deferred"]["fallbacks"] == 0, res
+        assert res["routes"].get("v210_yadif_pair", 0) > 10 and res["routes"].get("compose_up_write_v210", 0) > 10, res["routes"]
 
 
 @needs_node
