@@ -84,6 +84,29 @@ async function main() {
 		}
 		return outs
 	})
+	// config 3's own placements on a 1080p channel: four 1080i sources, the first full-frame, three picture-in-picture at half size (they SHRINK:
+	// not the 2 x 2-block compositor's) - the windows' reader for all four layers, then both fields' frames in ONE launch of the batch kernel, the fields its f32 image sources
+	await pin('four 1080i sources, three of them picture-in-picture, both fields posted', 'v210_yadif_pair+chan_compose_batch<0>x2', async () => {
+		const placedBy = [[], []]
+		for (let l = 0; l < 4; ++l) {
+			const u = []
+			for (let i = 0; i < 3; ++i) { const im = await image(); await rig.run(read(src[(l + i) % 4], im)); u.push(im) }
+			for (const second of [0, 1]) {
+				const y = await image(), pl = await image()
+				await rig.run(yadif(u[0], u[1], u[2], y, { parity: second ? 1 : 0, tff: 1, skipSpatial: 0 }))
+				await rig.run(transform(y, pl, mats[l]))
+				placedBy[second].push(pl)
+			}
+		}
+		const outs = []
+		for (const second of [0, 1]) {
+			const cm = await image(), o = await out()
+			await rig.run(combine(placedBy[second], cm))
+			await rig.run(write(cm, [o], 0))
+			outs.push(o)
+		}
+		return outs
+	})
 	// several channels in one tick reach the device in one call (the frames are asked for together at the end of the tick)
 	{
 		await rig.ctx.drain()

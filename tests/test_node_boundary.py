@@ -778,10 +778,10 @@ def test_parked_buffers_are_settled_before_their_next_owner():
 @pytest.mark.gpu
 def test_recorded_job_streams_reach_the_device_as_the_pinned_kernels():
     """which kernels the recording context's frames become (node/defer.js folds, the library routes): the headline chain, config 2's
-    shape, file playback, a 1080i source's field pair, four channels in a tick - recorded under a dry trace and pinned
+    shape, file playback, a 1080i source's field pair, four 1080i sources with picture-in-picture placements, four channels in a tick - recorded under a dry trace and pinned
     (node/test/routes_run.js; the C-side pins are tests/test_routes_gpu.py)"""
     _build_addon()
     r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "routes_run.js")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
-    assert res["problems"] == [] and res["checks"] == 5, res
+    assert res["problems"] == [] and res["checks"] == 6, res
