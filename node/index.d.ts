@@ -120,7 +120,7 @@ export class clContext {
 	drain(queue?: number): Promise<void>
 	/** staging extension: later work on `waiter` starts after everything enqueued so far on `signal` */
 	queueWaitQueue(waiter: number, signal: number): void
-	/** staging extension */
+	/** staging extension: a point in `queue`; wait() polls on the JS thread for up to `spinWaitMicros` before handing the wait to the libuv pool */
 	recordEvent(queue?: number): QueueEvent
 	/** ROUTE across GPUs: RCCL send / recv on a communication stream of its own, ordered on the device */
 	openRoute(id: Buffer, rank: number, world: number): RouteLink

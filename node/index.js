@@ -365,7 +365,19 @@ class clContext {
 	recordEvent(queue) {
 		const native = this._need()
 		const ev = native.eventRecord(this._ctx, queue === undefined ? this.queue.process : queue)
-		return { wait: () => native.eventWait(ev), done: () => native.eventDone(ev) }
+		// wait(): like waitFinish, first polled on the JS thread for up to spinWaitMicros (a hand-off to the libuv pool and back costs tens of
+		// microseconds, now and then milliseconds - a paced producer waiting for its ring slot sees every one of them)
+		const spin = this.spinWaitMicros
+		return {
+			wait: () => {
+				if (spin > 0) {
+					const until = process.hrtime.bigint() + BigInt(spin) * 1000n
+					do { if (native.eventDone(ev)) return Promise.resolve() } while (process.hrtime.bigint() < until)
+				}
+				return native.eventWait(ev)
+			},
+			done: () => native.eventDone(ev)
+		}
 	}
 
 	// ---- ROUTE across GPUs (not nodencl; routeProducer.ts:63-126 with source and sink on different GPUs) ------
