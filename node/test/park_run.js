@@ -73,6 +73,18 @@ async function main() {
 	expect('strictHandles: it IS the parked block (the first owner\'s bytes are still on the device)', kept, 0)
 	h.release()
 	strict.trim()
+	// (d) an event wait with spinWaitMicros: polled on this thread first, handed to the pool when the poll runs out - either way it ends after the work
+	for (const spinWaitMicros of [0, 20, 5000]) {
+		const c2 = new clContext({ deviceIndex: 0, spinWaitMicros })
+		await c2.initialise()
+		const big = await c2.createBuffer(bytes, 'readwrite', 'coarse', undefined, 'event')
+		await big.hostAccess('writeonly', c2.queue.load, fill(0x5A))
+		const ev = c2.recordEvent(c2.queue.load)
+		await ev.wait()
+		expect(`spinWaitMicros ${spinWaitMicros}: the event is done when wait() resolves`, ev.done(), true)
+		big.release()
+		c2.trim()
+	}
 	console.log(JSON.stringify({ checks, problems, reuses }))
 }
 main().catch((e) => { process.stderr.write(String(e && e.stack || e) + '\n'); process.exit(1) })

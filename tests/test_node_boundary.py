@@ -771,7 +771,7 @@ def test_parked_buffers_are_settled_before_their_next_owner():
     r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "park_run.js")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
-    assert res["problems"] == [] and res["checks"] >= 22, res
+    assert res["problems"] == [] and res["checks"] >= 25, res
 
 
 @needs_node
