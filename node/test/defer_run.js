@@ -54,6 +54,8 @@ async function side(deferred) {
 	s.source = async (bytes, w = W, h = H) => {
 		const p = await rig.planes('v210', w, h)
 		await rig.upload(p[0], bytes)
+		await rig.sync(rig.ctx.queue.load) // (an upload is followed by waitFinish(load) before the frame is used on another queue: ffmpegProducer.ts:514-515 -
+		// hostAccess('writeonly', load, bytes) only ENQUEUES the copy; a full-size frame read at once on the process queue loses that race)
 		return p[0]
 	}
 	// a planar frame on the device: every 10-bit code in 16-bit samples, or every byte
@@ -66,11 +68,13 @@ async function side(deferred) {
 			else for (let i = 0; i < b.length; ++i) b[i] = (r() >>> 8) & 255
 			await rig.upload(p, b)
 		}
+		await rig.sync(rig.ctx.queue.load)
 		return planes
 	}
 	s.image = async (bytes) => {
 		const im = await rig.image(W, H)
 		await rig.upload(im, bytes)
+		await rig.sync(rig.ctx.queue.load)
 		return im
 	}
 	// post a job as a valve does: destination released by the poster once the job's callback has fired
@@ -84,7 +88,10 @@ async function side(deferred) {
 async function scenario(name, fn, expect) {
 	const got = []
 	const stats = []
-	for (const deferred of [false, true]) {
+	// PH_DEFER_SELF=plain|deferred: the same side twice (is a side's own output repeatable?); PH_DEFER_ONLY=<text>: scenarios whose name has it
+	if (process.env.PH_DEFER_ONLY && !name.includes(process.env.PH_DEFER_ONLY)) return
+	const sides = process.env.PH_DEFER_SELF === 'plain' ? [false, false] : process.env.PH_DEFER_SELF === 'deferred' ? [true, true] : [false, true]
+	for (const deferred of sides) {
 		const s = await side(deferred)
 		try {
 			got.push(await fn(s))
@@ -112,7 +119,10 @@ async function scenario(name, fn, expect) {
 		if (Buffer.compare(plain[i], lazy[i]) !== 0) {
 			let at = 0
 			while (at < plain[i].length && plain[i][at] === lazy[i][at]) ++at
-			problems.push({ scenario: name, what: `frame ${i} differs from byte ${at} of ${plain[i].length}` })
+			let last = plain[i].length - 1, n = 0
+			while (last > at && plain[i][last] === lazy[i][last]) --last
+			for (let k = at; k <= last; ++k) if (plain[i][k] !== lazy[i][k]) ++n
+			problems.push({ scenario: name, what: `frame ${i} differs from byte ${at} of ${plain[i].length}`, last, differing: n })
 		}
 	const st = stats[1]
 	if (st && expect) for (const k of Object.keys(expect)) if (st[k] !== expect[k]) problems.push({ scenario: name, what: `deferred counter ${k} = ${st[k]}, expected ${expect[k]}`, stats: st })
@@ -397,6 +407,7 @@ async function main() {
 		await s.rig.run(s.read([bg], ubg))
 		const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
 		await s.rig.upload(out, Buffer.alloc(full, 0x2a))
+		await s.rig.sync(s.rig.ctx.queue.load)
 		for (const field of [1, 3]) {
 			const y = await s.rig.image(W, H)
 			await s.rig.run(s.yadif(u[0], u[1], u[2], y, { parity: field === 1 ? 0 : 1, tff: 1, skipSpatial: 0 }))
@@ -499,6 +510,50 @@ async function main() {
 		;[...srcs, ...u.flat()].forEach((x) => x.release())
 		return seen
 	}, { fused: 2, plain: 0, launched: 2, fallbacks: 0 })
+
+	// the reference's deployment: several channels of 1080i sources posting both fields' frames in one tick (src/index.ts:45-71) - each channel's
+	// windows go to the de-interlacing reader and, at once, its two frames to the compositor (node/defer.js _runMany; PHANERON_FIELD_BATCH=1: the
+	// channels' windows and frames in shared launches) - whichever order, every consumer's frame is the launch-as-posted context's
+	await scenario('three channels of two 1080i sources each, both fields, posted in one tick', async (s) => {
+		s.frame = 6
+		const fill = await s.transform.matrix({})
+		const outs = []
+		const held = []
+		for (let c = 0; c < 3; ++c) {
+			const u = []
+			for (let l = 0; l < 2; ++l) {
+				u.push([])
+				for (let i = 0; i < 3; ++i) {
+					const src = await s.source(v210Frame(full, 900 + 40 * c + 10 * l + i), W, H)
+					const im = await s.rig.image(W, H)
+					await s.rig.run(s.read([src], im))
+					held.push(src, im)
+					u[l].push(im)
+				}
+			}
+			for (const second of [0, 1]) {
+				const placed = []
+				for (let l = 0; l < 2; ++l) {
+					const y = await s.rig.image(W, H)
+					await s.rig.run(s.yadif(u[l][0], u[l][1], u[l][2], y, { parity: second ? 1 : 0, tff: 1, skipSpatial: 0 }))
+					const im = await s.rig.image(W, H)
+					await s.rig.run(s.transform(y, im, fill))
+					y.release()
+					placed.push(im)
+				}
+				const comb = await s.rig.image(W, H)
+				await s.rig.run(s.combine[2](placed, comb))
+				const out = (await s.rig.planes('v210', W, H, 'writeonly'))[0]
+				await s.rig.run(s.write(comb, [out], 0))
+				;[...placed, comb].forEach((x) => x.release())
+				outs.push(out)
+			}
+		}
+		const seen = []
+		for (const i of [3, 0, 5, 1, 2, 4]) { seen.push(await s.consume(outs[i])); outs[i].release() } // (consumers in an order of their own)
+		held.forEach((x) => x.release())
+		return seen
+	}, { plain: 0, fallbacks: 0 })
 
 	// the same shape, and then the APPLICATION looks at a field itself (a preview, a ROUTE of the layer): the pair launch wrote the fields packed
 	// (12 bytes per pixel, only the compositor was going to read them) - whoever else asks gets the RGBA image the buffer is declared as

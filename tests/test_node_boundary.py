@@ -618,7 +618,7 @@ def test_recording_context_gives_the_same_frames_with_one_launch_per_frame():
     recorded, field writes, a de-interlaced layer, intermediates asked for afterwards - give byte for byte the frames of the
     launch-as-posted context, the chains with a fused form as ONE launch per frame, and leave no buffer behind."""
     _build_addon()
-    for size in (("384", "108"), ("1920", "64")):
+    for size in (("384", "108"), ("1920", "64"), ("1920", "1080")):  # (the last: every scenario at the reference's own frame size)
         r = subprocess.run([NODE, os.path.join(ROOT, "node", "test", "defer_run.js"), *size], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         res = json.loads(r.stdout.strip().splitlines()[-1])
