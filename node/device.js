@@ -265,7 +265,9 @@ class Rig {
 	run(job, queue) { return this.ctx.runProgram(job.program, job.params, queue === undefined ? this.ctx.queue.process : queue) }
 	post(id, job, done) { this.board.post(id, job.name, job.program, job.params, done) }
 	sync(queue) { return this.ctx.waitFinish(queue) }
-	async upload(buffer, bytes) { await buffer.hostAccess('writeonly', this.ctx.queue.load, bytes) }
+	// a frame onto the device as a producer loads one: hostAccess('writeonly') ENQUEUES the copy on the load queue, then waitFinish(load) before
+	// the frame is used on another queue (ffmpegProducer.ts:514-515) - without it a job launched at once on the process queue races the copy
+	async upload(buffer, bytes) { await buffer.hostAccess('writeonly', this.ctx.queue.load, bytes); await this.sync(this.ctx.queue.load) }
 	async download(buffer) { await buffer.hostAccess('readonly', this.ctx.queue.unload); return buffer }
 	close() {
 		for (const b of this.constants.values()) b.release()
