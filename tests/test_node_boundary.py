@@ -737,6 +737,11 @@ def test_random_multi_channel_ticks_equal_the_launch_as_posted_context():
         res = json.loads(r.stdout.strip().splitlines()[-1])
         assert res["problems"] == [] and res["deferred"]["fallbacks"] == 0, res
         assert res["routes"].get("v210_yadif_pair", 0) > 10 and res["routes"].get("compose_up_write_v210", 0) > 10, res["routes"]
+    # the reference's own frame size (copies and kernels long enough for an ordering slip between the queues to show)
+    r = subprocess.run(fuzz + ["9000", "3", "5", "1920", "1080"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["problems"] == [] and res["deferred"]["fallbacks"] == 0, res
 
 
 @needs_node

@@ -11,3 +11,4 @@ echo "== PHANERON_FIELD_BATCH=1 node/test/channels_fuzz.js first=40000 seeds=300
 PHANERON_FIELD_BATCH=1 timeout 1200 node node/test/channels_fuzz.js 40000 300 12 2>&1 < /dev/null | tail -1 | cut -c1-900
 echo "== node/test/defer_fuzz.js first=50000 streams=1500 steps=80"
 timeout 1500 node node/test/defer_fuzz.js 50000 1500 80 2>&1 < /dev/null | tail -1 | cut -c1-600
+echo "== node/test/channels_fuzz.js first=9000 seeds=12 ticks=6 at 1920 x 1080"; PH_FUZZ_ROUTES=1 timeout 1500 node node/test/channels_fuzz.js 9000 12 6 1920 1080 2>&1 < /dev/null | tail -1 | cut -c1-1500
