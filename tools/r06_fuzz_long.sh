@@ -12,3 +12,4 @@ PHANERON_FIELD_BATCH=1 timeout 1200 node node/test/channels_fuzz.js 40000 300 12
 echo "== node/test/defer_fuzz.js first=50000 streams=1500 steps=80"
 timeout 1500 node node/test/defer_fuzz.js 50000 1500 80 2>&1 < /dev/null | tail -1 | cut -c1-600
 echo "== node/test/channels_fuzz.js first=9000 seeds=12 ticks=6 at 1920 x 1080"; PH_FUZZ_ROUTES=1 timeout 1500 node node/test/channels_fuzz.js 9000 12 6 1920 1080 2>&1 < /dev/null | tail -1 | cut -c1-1500
+echo "== PHANERON_FUZZ_SIZE=1920x1080 node/test/defer_fuzz.js first=80000 streams=40 steps=60"; PHANERON_FUZZ_SIZE=1920x1080 timeout 1500 node node/test/defer_fuzz.js 80000 40 60 2>&1 < /dev/null | tail -1 | cut -c1-600
